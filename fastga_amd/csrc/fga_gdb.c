@@ -1,0 +1,615 @@
+/* fga_gdb.c -- genome database (GDB) reader and FASTA -> GDB producer.
+ *
+ * Format contract (reference GDB.c):
+ *   skeleton  <root>.gdb   ASCII ONEcode, schema of GDB.c:37-47: 'f' 4 base frequencies, per scaffold
+ *                          'S <name>' followed by 'G <gap>' / 'C <contig length>' lines in order
+ *                          (reader: GDB.c:1313-1355; writer: GDB.c:1589-1614).
+ *   bases     .<root>.bps  every contig starts on a byte boundary, base i sits in bits 2*(i&3) of byte
+ *                          i>>2 (GDB.c:960-976, gene_core.c:372-398), a=0 c=1 g=2 t=3.
+ * The reference's Read_GDB tries <root>.1gdb first and then <root>.gdb (GDB.c:1198-1224); this module
+ * reads the ASCII form (what it also writes).  The binary .1gdb form needs the ONEcode binary codec and
+ * is reported as unsupported with a clear message.
+ */
+#define _GNU_SOURCE
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdarg.h>
+#include <ctype.h>
+#include <time.h>
+#include <unistd.h>
+#include <sys/time.h>
+#include <zlib.h>
+
+#include "fga_host.h"
+
+/* ------------------------------------------------------------------------------------------------ */
+
+static __thread char Error_Msg[1024];
+
+void fga_set_error(const char *fmt, ...)
+{ va_list ap;
+  va_start(ap,fmt);
+  vsnprintf(Error_Msg,sizeof(Error_Msg),fmt,ap);
+  va_end(ap);
+}
+
+const char *fga_last_error(void)
+{ return Error_Msg; }
+
+double fga_wall(void)
+{ struct timeval tv;
+  gettimeofday(&tv,NULL);
+  return tv.tv_sec + 1e-6*tv.tv_usec;
+}
+
+char *fga_path_dir(const char *path)
+{ const char *s = strrchr(path,'/');
+  if (s == NULL)
+    return strdup(".");
+  if (s == path)
+    return strdup("/");
+  return strndup(path,s-path);
+}
+
+char *fga_path_root(const char *path, const char *suffix)
+{ const char *s = strrchr(path,'/');
+  char *r;
+  size_t n, m;
+  s = (s == NULL) ? path : s+1;
+  r = strdup(s);
+  if (suffix != NULL)
+    { n = strlen(r);
+      m = strlen(suffix);
+      if (n >= m && strcmp(r+(n-m),suffix) == 0)
+        r[n-m] = '\0';
+    }
+  return r;
+}
+
+/* strip one of the known skeleton / source extensions from a path */
+static char *strip_gdb_ext(const char *path)
+{ static const char *ext[] = { ".1gdb", ".gdb", ".gix", NULL };
+  char *r = strdup(path);
+  size_t n = strlen(r);
+  int i;
+  for (i = 0; ext[i] != NULL; i++)
+    { size_t m = strlen(ext[i]);
+      if (n > m && strcmp(r+(n-m),ext[i]) == 0)
+        { r[n-m] = '\0';
+          break;
+        }
+    }
+  return r;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ *  Skeleton writer (ASCII ONEcode).  Layout mirrors what the reference's ONEview prints for a .1gdb,
+ *  which its own ASCII reader accepts: header, provenance, reference, embedded schema, counts, data.
+ * ------------------------------------------------------------------------------------------------ */
+
+static const char *GDB_SCHEMA_LINES =
+  "~ D f 4 4 REAL 4 REAL 4 REAL 4 REAL   global: base frequency vector\n"
+  "~ D u 0                               global: upper case when displayed (Deprecated)\n"
+  "~ O S 1 6 STRING                      id for a scaffold\n"
+  "~ D G 1 3 INT                         gap of given length\n"
+  "~ D C 1 3 INT                         contig of given length\n"
+  "~ D M 1 8 INT_LIST                    mask pair list for a contig\n";
+
+static int write_skeleton_file(const fga_gdb *gdb, const char *path, const char *prog,
+                               const char *command)
+{ FILE *f;
+  int   s, c;
+  int64_t ngap, maxs, tots;
+  char  date[64];
+  time_t t = time(NULL);
+
+  f = fopen(path,"w");
+  if (f == NULL)
+    { fga_set_error("cannot open %s for writing",path);
+      return 1;
+    }
+  strftime(date,sizeof(date),"%Y-%m-%d_%H:%M:%S",localtime(&t));
+
+  ngap = 0;
+  maxs = 0;
+  tots = 0;
+  for (s = 0; s < gdb->nscaff; s++)
+    { int64_t spos = 0;
+      int64_t hl = strlen(gdb->headers + gdb->scaffolds[s].hoff);
+      if (hl > maxs) maxs = hl;
+      tots += hl;
+      for (c = gdb->scaffolds[s].fctg; c < gdb->scaffolds[s].ectg; c++)
+        { if (gdb->contigs[c].sbeg > spos)
+            ngap += 1;
+          spos = gdb->contigs[c].sbeg + gdb->contigs[c].clen;
+        }
+      if (gdb->scaffolds[s].slen > spos)
+        ngap += 1;
+    }
+
+  fprintf(f,"1 3 gdb 2 1\n");
+  fprintf(f,"! %d %s 3 0.1 %d %s %d %s\n",(int) strlen(prog),prog,(int) strlen(command),command,
+            (int) strlen(date),date);
+  fprintf(f,".\n");
+  fprintf(f,"< %d %s 1\n",(int) strlen(gdb->srcpath),gdb->srcpath);
+  fprintf(f,".\n");
+  fputs(GDB_SCHEMA_LINES,f);
+  fprintf(f,".\n");
+  fprintf(f,"# f 1\n");
+  fprintf(f,"# S %d\n",gdb->nscaff);
+  fprintf(f,"@ S %lld\n",(long long) maxs);
+  fprintf(f,"+ S %lld\n",(long long) tots);
+  if (ngap > 0)
+    fprintf(f,"# G %lld\n",(long long) ngap);
+  fprintf(f,"# C %d\n",gdb->ncontig);
+  fprintf(f,".\n");
+  fprintf(f,"f %f %f %f %f\n",gdb->freq[0],gdb->freq[1],gdb->freq[2],gdb->freq[3]);
+  for (s = 0; s < gdb->nscaff; s++)
+    { const char *head = gdb->headers + gdb->scaffolds[s].hoff;
+      int64_t spos = 0;
+      fprintf(f,"S %d %s\n",(int) strlen(head),head);
+      for (c = gdb->scaffolds[s].fctg; c < gdb->scaffolds[s].ectg; c++)
+        { if (gdb->contigs[c].sbeg > spos)
+            fprintf(f,"G %lld\n",(long long) (gdb->contigs[c].sbeg - spos));
+          fprintf(f,"C %lld\n",(long long) gdb->contigs[c].clen);
+          spos = gdb->contigs[c].sbeg + gdb->contigs[c].clen;
+        }
+      if (gdb->scaffolds[s].slen > spos)
+        fprintf(f,"G %lld\n",(long long) (gdb->scaffolds[s].slen - spos));
+    }
+  if (fclose(f) != 0)
+    { fga_set_error("IO error writing %s",path);
+      return 1;
+    }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ *  FASTA (optionally gzip'd) -> <root>.gdb + .<root>.bps        (semantics of Create_GDB, GDB.c:800-1090)
+ *    - a scaffold per '>' header, name = header text after leading white space
+ *    - every run of non-acgt symbols of length >= ncut (ncut = 0: every run) splits the scaffold into
+ *      contigs separated by a gap; shorter runs are stored as 'a'
+ *    - base frequencies = counts / total bases, stored as float
+ * ------------------------------------------------------------------------------------------------ */
+
+typedef struct
+  { uint8_t *buf;
+    int64_t  len, cap;
+  } bytevec;
+
+static int bv_push(bytevec *v, uint8_t x)
+{ if (v->len >= v->cap)
+    { v->cap = (int64_t) (1.5*v->cap) + (1<<20);
+      v->buf = realloc(v->buf,v->cap);
+      if (v->buf == NULL)
+        return 1;
+    }
+  v->buf[v->len++] = x;
+  return 0;
+}
+
+int fga_fasta_to_gdb(const char *fasta, const char *target, int ncut)
+{ gzFile   in;
+  fga_gdb  G;
+  bytevec  bps = { NULL, 0, 0 };
+  char    *hdr = NULL;
+  int64_t  hdrcap = 0;
+  int      sctop = 0, cttop = 0;
+  int64_t  count[4] = { 0, 0, 0, 0 };
+  int      number[256];
+  static char *line = NULL;
+  size_t   linecap = 1<<20;
+  int      status = 1;
+  char    *dir = NULL, *root = NULL, *noext = NULL, *bpath = NULL, *gpath = NULL;
+
+  int      m;           /* bit offset inside the byte being filled          */
+  uint8_t  byte;
+  int64_t  clen, spos, nin;
+  int      inscaf;
+
+  memset(&G,0,sizeof(G));
+
+  { int i;
+    for (i = 0; i < 256; i++) number[i] = 4;
+    number['a'] = number['A'] = 0;
+    number['c'] = number['C'] = 1;
+    number['g'] = number['G'] = 2;
+    number['t'] = number['T'] = 3;
+  }
+
+  in = gzopen(fasta,"r");
+  if (in == NULL)
+    { fga_set_error("cannot open FASTA %s",fasta);
+      return 1;
+    }
+  gzbuffer(in,1<<20);
+  line = malloc(linecap);
+  if (line == NULL)
+    goto oom;
+
+  m = 0; byte = 0; clen = 0; spos = 0; nin = 0; inscaf = 0;
+
+#define END_CONTIG()                                                              \
+  { if (clen > 0)                                                                 \
+      { if (m > 0) { if (bv_push(&bps,byte)) goto oom; }                          \
+        byte = 0; m = 0;                                                          \
+        if (G.ncontig >= cttop)                                                   \
+          { cttop = (int) (1.2*G.ncontig) + 1000;                                 \
+            G.contigs = realloc(G.contigs,sizeof(fga_contig)*(cttop+1));          \
+            if (G.contigs == NULL) goto oom;                                      \
+          }                                                                       \
+        G.contigs[G.ncontig].clen = clen;                                         \
+        G.contigs[G.ncontig].sbeg = spos;                                         \
+        G.contigs[G.ncontig].boff = bps.len - ((clen+3)>>2);                      \
+        G.contigs[G.ncontig].scaf = G.nscaff-1;                                   \
+        G.ncontig += 1;                                                           \
+        if (clen > G.maxctg) G.maxctg = clen;                                     \
+        G.seqtot += clen;                                                         \
+        spos += clen;                                                             \
+        clen = 0;                                                                 \
+      }                                                                           \
+  }
+
+#define END_SCAFFOLD()                                                            \
+  { if (inscaf)                                                                   \
+      { END_CONTIG();                                                             \
+        spos += nin; nin = 0;                                                     \
+        G.scaffolds[G.nscaff-1].ectg = G.ncontig;                                 \
+        G.scaffolds[G.nscaff-1].slen = spos;                                      \
+      }                                                                           \
+  }
+
+  while (gzgets(in,line,linecap) != NULL)
+    { size_t len = strlen(line);
+      while (len == linecap-1 && line[len-1] != '\n')      /* very long line: grow and continue */
+        { linecap *= 2;
+          line = realloc(line,linecap);
+          if (line == NULL) goto oom;
+          if (gzgets(in,line+len,linecap-len) == NULL) break;
+          len += strlen(line+len);
+        }
+      while (len > 0 && (line[len-1] == '\n' || line[len-1] == '\r'))
+        line[--len] = '\0';
+
+      if (line[0] == '>')
+        { size_t s;
+          END_SCAFFOLD();
+          for (s = 1; s < len; s++)
+            if (!isspace((unsigned char) line[s]))
+              break;
+          if (G.nscaff >= sctop)
+            { sctop = (int) (1.2*G.nscaff) + 500;
+              G.scaffolds = realloc(G.scaffolds,sizeof(fga_scaffold)*sctop);
+              if (G.scaffolds == NULL) goto oom;
+            }
+          if (G.hdrtot + (int64_t) (len-s) + 1 > hdrcap)
+            { hdrcap = (int64_t) (1.2*(G.hdrtot+(len-s)+1)) + 10000;
+              hdr = realloc(hdr,hdrcap);
+              if (hdr == NULL) goto oom;
+            }
+          G.scaffolds[G.nscaff].fctg = G.ncontig;
+          G.scaffolds[G.nscaff].hoff = G.hdrtot;
+          memcpy(hdr+G.hdrtot,line+s,len-s);
+          G.hdrtot += len-s;
+          hdr[G.hdrtot++] = '\0';
+          G.nscaff += 1;
+          inscaf = 1;
+          spos = 0; clen = 0; nin = 0; m = 0; byte = 0;
+          continue;
+        }
+      if (!inscaf)
+        { fga_set_error("first header of FASTA %s is missing",fasta);
+          goto fail;
+        }
+      { size_t s;
+        for (s = 0; s < len; s++)
+          { int x = number[(unsigned char) line[s]];
+            if (x >= 4)
+              { nin += 1;
+                continue;
+              }
+            if (nin > 0)
+              { if (nin < ncut && clen > 0)      /* short run inside a contig: keep as 'a' */
+                  { int64_t k;
+                    for (k = 0; k < nin; k++)
+                      { if (m == 6) { if (bv_push(&bps,byte)) goto oom; byte = 0; m = 0; }
+                        else m += 2;
+                      }
+                    clen += nin;
+                    count[0] += nin;
+                  }
+                else
+                  { END_CONTIG();
+                    spos += nin;
+                  }
+                nin = 0;
+              }
+            byte |= (uint8_t) (x << m);
+            if (m == 6) { if (bv_push(&bps,byte)) goto oom; byte = 0; m = 0; }
+            else m += 2;
+            count[x] += 1;
+            clen += 1;
+          }
+      }
+    }
+  END_SCAFFOLD();
+  gzclose(in);
+  in = NULL;
+
+  if (G.ncontig == 0)
+    { fga_set_error("FASTA %s holds no sequence",fasta);
+      goto fail;
+    }
+
+  G.headers = hdr;
+  G.freq[0] = (1.*count[0])/G.seqtot;
+  G.freq[1] = (1.*count[1])/G.seqtot;
+  G.freq[2] = (1.*count[2])/G.seqtot;
+  G.freq[3] = (1.*count[3])/G.seqtot;
+
+  { char *rp = realpath(fasta,NULL);
+    G.srcpath = rp ? rp : strdup(fasta);
+  }
+
+  noext = strip_gdb_ext(target);
+  dir   = fga_path_dir(noext);
+  root  = fga_path_root(noext,NULL);
+  if (asprintf(&bpath,"%s/.%s.bps",dir,root) < 0 || asprintf(&gpath,"%s/%s.gdb",dir,root) < 0)
+    goto oom;
+
+  { FILE *b = fopen(bpath,"w");
+    if (b == NULL)
+      { fga_set_error("cannot open %s for writing",bpath);
+        goto fail;
+      }
+    if (bps.len > 0 && fwrite(bps.buf,1,bps.len,b) != (size_t) bps.len)
+      { fga_set_error("IO error writing %s",bpath);
+        fclose(b);
+        goto fail;
+      }
+    fclose(b);
+  }
+
+  { char cmd[2048];
+    snprintf(cmd,sizeof(cmd),"fga_fasta_to_gdb %s %s",fasta,target);
+    if (write_skeleton_file(&G,gpath,"FAtoGDB",cmd))
+      goto fail;
+  }
+  status = 0;
+  goto done;
+
+oom:
+  fga_set_error("out of memory creating GDB for %s",fasta);
+fail:
+  status = 1;
+done:
+  if (in != NULL) gzclose(in);
+  free(line); line = NULL;
+  free(bps.buf);
+  free(hdr);
+  free(G.scaffolds);
+  free(G.contigs);
+  free(G.srcpath);
+  free(noext); free(dir); free(root); free(bpath); free(gpath);
+  return status;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ *  Skeleton reader (ASCII ONEcode) + whole-image load of the .bps   (Read_GDB, GDB.c:1181-1410)
+ * ------------------------------------------------------------------------------------------------ */
+
+int fga_gdb_open(const char *path, fga_gdb **out)
+{ fga_gdb *G;
+  char *noext, *dir, *root, *spath = NULL, *bpath = NULL;
+  FILE *f;
+  char *line = NULL;
+  size_t cap = 0;
+  ssize_t n;
+  int sctop = 0, cttop = 0;
+  int64_t hdrcap = 0, boff, spos;
+  int first = 1;
+
+  *out = NULL;
+  G = calloc(1,sizeof(fga_gdb));
+  if (G == NULL)
+    { fga_set_error("out of memory");
+      return 1;
+    }
+
+  noext = strip_gdb_ext(path);
+  dir   = fga_path_dir(noext);
+  root  = fga_path_root(noext,NULL);
+
+  if (asprintf(&spath,"%s/%s.gdb",dir,root) < 0) spath = NULL;
+  f = (spath != NULL) ? fopen(spath,"r") : NULL;
+  if (f == NULL)
+    { char *one = NULL;
+      if (asprintf(&one,"%s/%s.1gdb",dir,root) >= 0 && access(one,R_OK) == 0)
+        fga_set_error("%s is a binary ONEcode skeleton; this build reads the ASCII form "
+                      "(%s/%s.gdb, e.g. `ONEview %s > %s/%s.gdb`)",one,dir,root,one,dir,root);
+      else
+        fga_set_error("cannot find/open GDB skeleton %s/%s.gdb",dir,root);
+      free(one);
+      goto fail;
+    }
+
+  boff = 0;
+  spos = 0;
+  while ((n = getline(&line,&cap,f)) > 0)
+    { while (n > 0 && (line[n-1] == '\n' || line[n-1] == '\r'))
+        line[--n] = '\0';
+      if (first)
+        { first = 0;
+          if (line[0] != '1' || strstr(line," gdb ") == NULL)
+            { fga_set_error("%s is not an ASCII ONEcode gdb file",spath);
+              goto fail_f;
+            }
+          continue;
+        }
+      switch (line[0])
+      { case '<':
+          if (G->srcpath == NULL)
+            { int len = 0, used = 0;
+              if (sscanf(line+1," %d %n",&len,&used) >= 1 && len >= 0
+                  && (int) strlen(line+1+used) >= len)
+                G->srcpath = strndup(line+1+used,len);
+            }
+          break;
+        case 'f':
+          { double a, c, g, t;
+            if (sscanf(line+1," %lf %lf %lf %lf",&a,&c,&g,&t) != 4)
+              { fga_set_error("%s: malformed f line",spath);
+                goto fail_f;
+              }
+            G->freq[0] = a; G->freq[1] = c; G->freq[2] = g; G->freq[3] = t;
+          }
+          break;
+        case 'S':
+          { int len = 0, used = 0;
+            if (sscanf(line+1," %d %n",&len,&used) < 1 || len < 0
+                || (int) strlen(line+1+used) < len)
+              { fga_set_error("%s: malformed S line",spath);
+                goto fail_f;
+              }
+            if (G->nscaff > 0)
+              { G->scaffolds[G->nscaff-1].ectg = G->ncontig;
+                G->scaffolds[G->nscaff-1].slen = spos;
+              }
+            spos = 0;
+            if (G->nscaff >= sctop)
+              { sctop = (int) (1.2*G->nscaff) + 500;
+                G->scaffolds = realloc(G->scaffolds,sizeof(fga_scaffold)*sctop);
+              }
+            if (G->hdrtot + len + 1 > hdrcap)
+              { hdrcap = (int64_t) (1.2*(G->hdrtot+len+1)) + 10000;
+                G->headers = realloc(G->headers,hdrcap);
+              }
+            if (G->scaffolds == NULL || G->headers == NULL)
+              { fga_set_error("out of memory");
+                goto fail_f;
+              }
+            G->scaffolds[G->nscaff].hoff = G->hdrtot;
+            G->scaffolds[G->nscaff].fctg = G->ncontig;
+            memcpy(G->headers+G->hdrtot,line+1+used,len);
+            G->hdrtot += len;
+            G->headers[G->hdrtot++] = '\0';
+            G->nscaff += 1;
+          }
+          break;
+        case 'G':
+          spos += atoll(line+1);
+          break;
+        case 'C':
+          { int64_t len = atoll(line+1);
+            if (G->nscaff == 0)
+              { fga_set_error("%s: C line before any S line",spath);
+                goto fail_f;
+              }
+            if (G->ncontig >= cttop)
+              { cttop = (int) (1.2*G->ncontig) + 1000;
+                G->contigs = realloc(G->contigs,sizeof(fga_contig)*(cttop+1));
+                if (G->contigs == NULL)
+                  { fga_set_error("out of memory");
+                    goto fail_f;
+                  }
+              }
+            G->contigs[G->ncontig].boff = boff;
+            G->contigs[G->ncontig].sbeg = spos;
+            G->contigs[G->ncontig].clen = len;
+            G->contigs[G->ncontig].scaf = G->nscaff-1;
+            G->ncontig += 1;
+            if (len > G->maxctg) G->maxctg = len;
+            G->seqtot += len;
+            boff += (len+3) >> 2;
+            spos += len;
+          }
+          break;
+        default:     /* header / provenance / schema / count lines, deprecated u and M lines */
+          break;
+      }
+    }
+  fclose(f);
+  f = NULL;
+  if (G->nscaff == 0 || G->ncontig == 0)
+    { fga_set_error("%s holds no scaffolds/contigs",spath);
+      goto fail;
+    }
+  G->scaffolds[G->nscaff-1].ectg = G->ncontig;
+  G->scaffolds[G->nscaff-1].slen = spos;
+  if (G->srcpath == NULL)
+    G->srcpath = strdup("");
+  G->path = strdup(spath);
+
+  if (asprintf(&bpath,"%s/.%s.bps",dir,root) < 0)
+    { fga_set_error("out of memory");
+      goto fail;
+    }
+  { FILE *b = fopen(bpath,"r");
+    if (b == NULL)
+      { fga_set_error("cannot open .bps file %s for GDB %s",bpath,path);
+        goto fail;
+      }
+    G->bpslen = boff;
+    G->bps = malloc(boff+16);
+    if (G->bps == NULL)
+      { fga_set_error("out of memory loading %s",bpath);
+        fclose(b);
+        goto fail;
+      }
+    if (boff > 0 && fread(G->bps,1,boff,b) != (size_t) boff)
+      { fga_set_error("%s is shorter than its skeleton says (%lld bytes)",bpath,(long long) boff);
+        fclose(b);
+        goto fail;
+      }
+    memset(G->bps+boff,0,16);
+    fclose(b);
+  }
+
+  free(line); free(noext); free(dir); free(root); free(spath); free(bpath);
+  *out = G;
+  return 0;
+
+fail_f:
+  if (f != NULL) fclose(f);
+fail:
+  free(line); free(noext); free(dir); free(root); free(spath); free(bpath);
+  free(G->scaffolds); free(G->contigs); free(G->headers); free(G->srcpath); free(G->path);
+  free(G->bps);
+  free(G);
+  return 1;
+}
+
+void fga_gdb_close(fga_gdb *G)
+{ if (G == NULL) return;
+  free(G->scaffolds); free(G->contigs); free(G->headers); free(G->srcpath); free(G->path);
+  free(G->bps);
+  free(G);
+}
+
+int     fga_gdb_ncontig(const fga_gdb *G)            { return G->ncontig; }
+int     fga_gdb_nscaff(const fga_gdb *G)             { return G->nscaff; }
+int64_t fga_gdb_seqtot(const fga_gdb *G)             { return G->seqtot; }
+int64_t fga_gdb_maxctg(const fga_gdb *G)             { return G->maxctg; }
+int64_t fga_gdb_contig_len(const fga_gdb *G, int c)  { return G->contigs[c].clen; }
+void    fga_gdb_freq(const fga_gdb *G, float *f4)    { memcpy(f4,G->freq,4*sizeof(float)); }
+
+/* Unpack contig c into numeric form (0..3), buf must hold clen+2 bytes; buf[0] and buf[clen+1] get the
+ * sentinel 4 the aligner needs either side (GDB.c:1718-1727, gene_core.c:397); returns buf+1. */
+uint8_t *fga_gdb_get_contig(const fga_gdb *G, int c, uint8_t *buf)
+{ const uint8_t *src = G->bps + G->contigs[c].boff;
+  int64_t len = G->contigs[c].clen, i;
+  uint8_t *s = buf+1;
+  buf[0] = 4;
+  for (i = 0; i+4 <= len; i += 4)
+    { uint8_t b = src[i>>2];
+      s[i] = b & 3; s[i+1] = (b>>2) & 3; s[i+2] = (b>>4) & 3; s[i+3] = (b>>6) & 3;
+    }
+  for (; i < len; i++)
+    s[i] = (src[i>>2] >> (2*(i&3))) & 3;
+  s[len] = 4;
+  return s;
+}
+
+int fga_gdb_write_skeleton(const fga_gdb *G, const char *path, const char *prog, const char *command)
+{ return write_skeleton_file(G,path,prog,command); }

@@ -1,0 +1,92 @@
+/* fga_host.h -- internal host-side types shared by the C sources of libfastga_amd.
+ *
+ * On-disk formats follow the reference exactly:
+ *   GDB  : <root>.gdb (ASCII ONEcode) or <root>.1gdb + .<root>.bps       (reference GDB.c:1181-1410)
+ *   GIX  : <root>.gix + .<root>.ktab.<p>                                  (reference GIXmake.c:1490-1580)
+ */
+#ifndef FGA_HOST_H
+#define FGA_HOST_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FGA_KMER      40          /* only k = 40 indices are supported (SURVEY.md hard part 8) */
+#define FGA_NPREFIX   0x1000000   /* 2^24 12-mer prefixes                                       */
+
+typedef struct
+  { int64_t clen;      /* contig length in bases                         */
+    int64_t sbeg;      /* start of contig inside its scaffold            */
+    int64_t boff;      /* byte offset of the contig in the .bps image    */
+    int     scaf;      /* scaffold index                                  */
+  } fga_contig;
+
+typedef struct
+  { int64_t slen;
+    int     fctg, ectg;
+    int64_t hoff;      /* offset of the header string in headers[]       */
+  } fga_scaffold;
+
+struct fga_gdb
+  { int           nscaff;
+    fga_scaffold *scaffolds;
+    int           ncontig;
+    fga_contig   *contigs;
+    int64_t       maxctg;
+    int64_t       seqtot;
+    int64_t       hdrtot;
+    char         *headers;
+    float         freq[4];
+    char         *path;      /* path of the skeleton file as opened      */
+    char         *srcpath;   /* reference line of the skeleton           */
+    uint8_t      *bps;       /* whole 2-bit image (base i of a contig in bits 2*(i&3) of byte i>>2) */
+    int64_t       bpslen;
+  };
+
+struct fga_gix
+  { int       kmer;        /* 40                                                        */
+    int       nparts;      /* number of .ktab parts                                     */
+    int       postbytes;   /* bytes of the in-contig position                           */
+    int       contbytes;   /* bytes of the (length-sorted) contig index + sign bit      */
+    int       ebytes;      /* 9 + postbytes + contbytes                                 */
+    int64_t   maxpre;      /* largest 12-mer panel                                      */
+    int       freq;
+    int       nctg;
+    int      *perm;        /* length-sorted -> original contig index                    */
+    int64_t  *index;       /* [2^24] inclusive cumulative entry count per 24-bit prefix */
+    int64_t   nents;
+    uint8_t  *table;       /* nents * ebytes raw on-disk entries, parts concatenated    */
+    int64_t  *partbeg;     /* [nparts+1] entry offset of each part                      */
+  };
+
+typedef struct fga_gdb fga_gdb;
+typedef struct fga_gix fga_gix;
+
+/* error reporting: thread-local message buffer; functions return 0 on success */
+void        fga_set_error(const char *fmt, ...);
+const char *fga_last_error(void);
+
+/* GDB (fga_gdb.c) */
+int      fga_fasta_to_gdb(const char *fasta, const char *target, int ncut);
+int      fga_gdb_open(const char *path, fga_gdb **out);
+void     fga_gdb_close(fga_gdb *G);
+uint8_t *fga_gdb_get_contig(const fga_gdb *G, int c, uint8_t *buf);
+int      fga_gdb_write_skeleton(const fga_gdb *G, const char *path, const char *prog, const char *command);
+
+/* GIX (fga_gix.c) */
+int      fga_gix_open(const char *path, fga_gix **out);
+void     fga_gix_close(fga_gix *X);
+int      fga_gix_build(const fga_gdb *G, const char *target, int nthreads);
+
+/* small helpers */
+char *fga_path_dir(const char *path);                       /* malloc'd directory part ("." if none) */
+char *fga_path_root(const char *path, const char *suffix);  /* malloc'd basename without suffix      */
+double fga_wall(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,72 @@
+"""ctypes binding of libfastga_amd.so (include/fastga_amd.h)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class FgaError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "libfastga_amd.so")
+
+
+def load_library():
+    """Load the in-tree shared library; raise loudly if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise FgaError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       f"or `make -C fastga_amd/csrc`")
+    L = C.CDLL(path)
+    L.fga_last_error.restype = C.c_char_p
+    _declare(L)
+    _LIB = L
+    return L
+
+
+def check(status, what=""):
+    if status != 0:
+        L = load_library()
+        msg = L.fga_last_error().decode(errors="replace")
+        raise FgaError(f"{what}: {msg}" if what else msg)
+
+
+def _declare(L):
+    vp, i32, i64, cp = C.c_void_p, C.c_int, C.c_int64, C.c_char_p
+    P = C.POINTER
+    sig = {
+        "fga_fasta_to_gdb": (i32, [cp, cp, i32]),
+        "fga_gdb_open": (i32, [cp, P(vp)]),
+        "fga_gdb_close": (None, [vp]),
+        "fga_gdb_ncontig": (i32, [vp]),
+        "fga_gdb_nscaff": (i32, [vp]),
+        "fga_gdb_seqtot": (i64, [vp]),
+        "fga_gdb_maxctg": (i64, [vp]),
+        "fga_gdb_contig_len": (i64, [vp, i32]),
+        "fga_gdb_freq": (None, [vp, P(C.c_float)]),
+        "fga_gdb_get_contig": (vp, [vp, i32, vp]),
+        "fga_gix_build": (i32, [vp, cp, i32]),
+        "fga_gix_open": (i32, [cp, P(vp)]),
+        "fga_gix_close": (None, [vp]),
+        "fga_gix_nents": (i64, [vp]),
+        "fga_gix_ebytes": (i32, [vp]),
+        "fga_gix_postbytes": (i32, [vp]),
+        "fga_gix_contbytes": (i32, [vp]),
+        "fga_gix_nctg": (i32, [vp]),
+        "fga_gix_nparts": (i32, [vp]),
+        "fga_gix_maxpre": (i64, [vp]),
+        "fga_gix_perm": (P(C.c_int), [vp]),
+        "fga_gix_index": (P(C.c_int64), [vp]),
+        "fga_gix_table": (P(C.c_uint8), [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    L._declared = sorted(sig)
