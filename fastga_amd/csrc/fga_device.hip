@@ -1,0 +1,110 @@
+// fga_device.hip -- device context, index upload, seed buffers (C-ABI of include/fastga_amd.h).
+#include "fga_device.hpp"
+
+extern "C" int fga_dev_open(int device, fga_dev **out)
+{ *out = NULL;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    { fga_set_error("no HIP device available (%s): libfastga_amd has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+      return 1;
+    }
+  if (device < 0 || device >= n)
+    { fga_set_error("device %d out of range (have %d)",device,n);
+      return 1;
+    }
+  FGA_HIP(hipSetDevice(device));
+  fga_dev *d = (fga_dev *) calloc(1,sizeof(fga_dev));
+  if (d == NULL)
+    { fga_set_error("out of memory");
+      return 1;
+    }
+  d->device = device;
+  hipDeviceProp_t prop;
+  FGA_HIP(hipGetDeviceProperties(&prop,device));
+  d->ncu = prop.multiProcessorCount;
+  FGA_HIP(hipStreamCreateWithFlags(&d->stream,hipStreamNonBlocking));
+  FGA_HIP(hipEventCreate(&d->ev0));
+  FGA_HIP(hipEventCreate(&d->ev1));
+  *out = d;
+  return 0;
+}
+
+extern "C" void fga_dev_close(fga_dev *d)
+{ if (d == NULL) return;
+  hipSetDevice(d->device);
+  hipStreamSynchronize(d->stream);
+  hipEventDestroy(d->ev0);
+  hipEventDestroy(d->ev1);
+  hipStreamDestroy(d->stream);
+  free(d);
+}
+
+extern "C" int fga_dev_sync(fga_dev *d)
+{ FGA_HIP(hipSetDevice(d->device));
+  FGA_HIP(hipStreamSynchronize(d->stream));
+  return 0;
+}
+
+extern "C" float fga_dev_stage_ms(const fga_dev *d, int stage)
+{ if (stage < 0 || stage >= FGA_NSTAGES) return -1.f;
+  return d->last_ms[stage];
+}
+
+extern "C" int fga_dgix_upload(fga_dev *dev, const fga_gix *X, fga_dgix **out)
+{ *out = NULL;
+  FGA_HIP(hipSetDevice(dev->device));
+  fga_dgix *D = (fga_dgix *) calloc(1,sizeof(fga_dgix));
+  if (D == NULL)
+    { fga_set_error("out of memory");
+      return 1;
+    }
+  D->dev = dev;
+  D->nents = X->nents; D->ebytes = X->ebytes; D->postbytes = X->postbytes; D->contbytes = X->contbytes;
+  D->nctg = X->nctg;
+  size_t tbytes = (size_t) X->nents * X->ebytes;
+  hipError_t e;
+  if ((e = hipMalloc(&D->table,tbytes + 64)) != hipSuccess ||
+      (e = hipMalloc(&D->index,sizeof(int64_t)*FGA_NPREFIX)) != hipSuccess)
+    { fga_set_error("fga_dgix_upload: device allocation of %zu bytes failed: %s",tbytes,hipGetErrorString(e));
+      hipFree(D->table); hipFree(D->index); free(D);
+      return 1;
+    }
+  if ((e = hipMemcpy(D->table,X->table,tbytes + 64,hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemcpy(D->index,X->index,sizeof(int64_t)*FGA_NPREFIX,hipMemcpyHostToDevice)) != hipSuccess)
+    { fga_set_error("fga_dgix_upload: copy failed: %s",hipGetErrorString(e));
+      hipFree(D->table); hipFree(D->index); free(D);
+      return 1;
+    }
+  *out = D;
+  return 0;
+}
+
+extern "C" void fga_dgix_free(fga_dgix *D)
+{ if (D == NULL) return;
+  hipSetDevice(D->dev->device);
+  hipFree(D->table);
+  hipFree(D->index);
+  free(D);
+}
+
+extern "C" int64_t fga_seeds_count(const fga_dseeds *S)    { return S->count; }
+extern "C" int64_t fga_seeds_plen_sum(const fga_dseeds *S) { return S->tseed; }
+
+extern "C" int fga_seeds_download(const fga_dseeds *S, fga_seed *host, int64_t max)
+{ int64_t n = S->count < S->capacity ? S->count : S->capacity;
+  if (n > max) n = max;
+  FGA_HIP(hipSetDevice(S->dev->device));
+  if (n > 0)
+    FGA_HIP(hipMemcpy(host,S->seeds,sizeof(fga_seed)*(size_t) n,hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" void fga_seeds_free(fga_dseeds *S)
+{ if (S == NULL) return;
+  hipSetDevice(S->dev->device);
+  hipFree(S->seeds);
+  hipFree(S->dcount);
+  free(S);
+}

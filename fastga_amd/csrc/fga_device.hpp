@@ -1,0 +1,48 @@
+// fga_device.hpp -- internal device-side types of libfastga_amd (HIP, gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <vector>
+
+#include "fga_host.h"
+#include "fastga_amd.h"
+
+#define FGA_HIP(call)                                                                       \
+  do { hipError_t _e = (call);                                                              \
+       if (_e != hipSuccess)                                                                \
+         { fga_set_error("%s failed at %s:%d: %s",#call,__FILE__,__LINE__,hipGetErrorString(_e)); \
+           return 1;                                                                        \
+         }                                                                                  \
+     } while (0)
+
+struct fga_dev
+  { int          device;
+    hipStream_t  stream;
+    hipEvent_t   ev0, ev1;
+    int          ncu;
+    float        last_ms[8];     // per-stage kernel time of the most recent call (HIP events)
+  };
+
+// device-resident genome index: the on-disk bytes, unchanged
+struct fga_dgix
+  { fga_dev  *dev;
+    uint8_t  *table;      // nents*ebytes raw entries (+ 64 bytes slack)
+    int64_t  *index;      // [2^24] inclusive cumulative counts
+    int64_t   nents;
+    int       ebytes, postbytes, contbytes, nctg;
+  };
+
+// One adaptive seed, 16 bytes (device + host layout of fga_seed in fastga_amd.h)
+//   apos, bpos : in-contig positions as stored in the index payloads
+//   actg       : A contig (length-sorted index) << 8 | plen
+//   bctg       : B contig | (B entry's own sign bit) << 30 | (C-stream flag) << 31
+struct fga_dseeds
+  { fga_dev  *dev;
+    fga_seed *seeds;      // device buffer
+    int64_t   capacity;
+    int64_t   tseed;      // sum of plen over all seeds
+    int64_t   count;      // seeds produced (may exceed capacity -> overflow, buffer holds `capacity`)
+    int64_t  *dcount;     // device counter
+  };

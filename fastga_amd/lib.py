@@ -37,6 +37,14 @@ def check(status, what=""):
         raise FgaError(f"{what}: {msg}" if what else msg)
 
 
+class MergeParams(C.Structure):
+    _fields_ = [("freq", C.c_int), ("soft_mask", C.c_int), ("flip", C.c_int),
+                ("prefix_begin", C.c_int64), ("prefix_end", C.c_int64)]
+
+
+STAGE_MERGE_PARTITION, STAGE_MERGE, STAGE_SORT, STAGE_CHAIN, STAGE_EXTEND = 0, 1, 2, 3, 4
+
+
 def _declare(L):
     vp, i32, i64, cp = C.c_void_p, C.c_int, C.c_int64, C.c_char_p
     P = C.POINTER
@@ -64,6 +72,17 @@ def _declare(L):
         "fga_gix_perm": (P(C.c_int), [vp]),
         "fga_gix_index": (P(C.c_int64), [vp]),
         "fga_gix_table": (P(C.c_uint8), [vp]),
+        "fga_dev_open": (i32, [i32, P(vp)]),
+        "fga_dev_close": (None, [vp]),
+        "fga_dev_sync": (i32, [vp]),
+        "fga_dev_stage_ms": (C.c_float, [vp, i32]),
+        "fga_dgix_upload": (i32, [vp, vp, P(vp)]),
+        "fga_dgix_free": (None, [vp]),
+        "fga_seed_merge": (i32, [vp, vp, vp, P(MergeParams), i64, P(vp)]),
+        "fga_seeds_count": (i64, [vp]),
+        "fga_seeds_plen_sum": (i64, [vp]),
+        "fga_seeds_download": (i32, [vp, vp, i64]),
+        "fga_seeds_free": (None, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -1,0 +1,26 @@
+"""Build synthetic inputs end to end with the product's own producers (FASTA -> GDB -> GIX)."""
+import os
+
+from . import synth
+from .gixio import Gdb, Gix, fasta_to_gdb, build_gix  # noqa: F401
+
+
+def build_genome(workdir, name, contigs, masks=None, threads=8):
+    """write <name>.fa, <name>.gdb, .<name>.bps, <name>.gix, .<name>.ktab.*; returns the root path."""
+    fa = os.path.join(workdir, name + ".fa")
+    root = os.path.join(workdir, name)
+    synth.write_fasta(fa, contigs, prefix=name.lower(), masks=masks)
+    fasta_to_gdb(fa, root)
+    g = Gdb(root + ".gdb")
+    build_gix(g, root, threads)
+    g.close()
+    return root
+
+
+def build_pair(workdir, seed, ncontig, total, divergence, repeat_frac=0.0, inv_frac=0.0, swap_frac=0.0,
+               threads=8, names=("A", "B")):
+    lens = synth.contig_lengths(seed, ncontig, total)
+    A, mA, B, mB = synth.make_pair(seed, lens, divergence, repeat_frac, inv_frac, swap_frac)
+    ra = build_genome(workdir, names[0], A, None, threads)
+    rb = build_genome(workdir, names[1], B, None, threads)
+    return ra, rb

@@ -48,6 +48,51 @@ const int     *fga_gix_perm(const fga_gix *gix);
 const int64_t *fga_gix_index(const fga_gix *gix);
 const uint8_t *fga_gix_table(const fga_gix *gix);
 
+/* ==== device side (MI355X / gfx950) =================================================================== */
+
+typedef struct fga_dev    fga_dev;     /* one GPU: device id, HIP stream, timing events            */
+typedef struct fga_dgix   fga_dgix;    /* device-resident genome index (on-disk bytes, unchanged)  */
+typedef struct fga_dseeds fga_dseeds;  /* device-resident adaptive seeds                            */
+
+/* One adaptive seed.  Carries exactly the fields of the reference's seed temp record
+ * {u8 plen; A post|contig; B post|contig|sign} (FastGA.c:961-966) in a fixed 16-byte layout. */
+typedef struct
+  { uint32_t apos;     /* A in-contig position as stored in the index payload                          */
+    uint32_t bpos;     /* B in-contig position                                                         */
+    uint32_t actg;     /* (A contig, length-sorted index) << 8 | plen                                  */
+    uint32_t bctg;     /* B contig | (B entry's own sign bit) << 30 | (1 << 31 if complement stream)   */
+  } fga_seed;
+
+typedef struct
+  { int     freq;          /* -f : adaptamer frequency cutoff (FastGA.c:4451)                          */
+    int     soft_mask;     /* -M or #mask arguments: mlen = plen (FastGA.c:824-825)                     */
+    int     flip;          /* second pass of -S: table 1 is genome 2 (FastGA.c:2410-2470)               */
+    int64_t prefix_begin;  /* 12-mer prefix range [begin,end) handled by this call (multi-GPU sharding; */
+    int64_t prefix_end;    /*   the reference splits threads the same way, FastGA.c:2291-2321); 0,0=all */
+  } fga_merge_params;
+
+enum { FGA_STAGE_MERGE_PARTITION = 0, FGA_STAGE_MERGE = 1, FGA_STAGE_SORT = 2, FGA_STAGE_CHAIN = 3,
+       FGA_STAGE_EXTEND = 4, FGA_NSTAGES = 8 };
+
+int   fga_dev_open(int device, fga_dev **out);
+void  fga_dev_close(fga_dev *dev);
+int   fga_dev_sync(fga_dev *dev);
+float fga_dev_stage_ms(const fga_dev *dev, int stage);   /* HIP-event time of the stage's last launch */
+
+int   fga_dgix_upload(fga_dev *dev, const fga_gix *gix, fga_dgix **out);
+void  fga_dgix_free(fga_dgix *dgix);
+
+/* Adaptive seed merge: replaces adaptamer_merge -> new_merge_thread (FastGA.c:2281, 610) and, with
+ * t2 == NULL, self_adaptamer_merge -> new_self_merge_thread (FastGA.c:2496, 1616).  Returns 0, or 2 when
+ * more than `capacity` seeds were found (count is still exact; re-run with a larger buffer).
+ * capacity <= 0 picks 2 x (entries of t1 in range) + 1M.                                              */
+int     fga_seed_merge(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
+                       const fga_merge_params *prm, int64_t capacity, fga_dseeds **out);
+int64_t fga_seeds_count(const fga_dseeds *seeds);
+int64_t fga_seeds_plen_sum(const fga_dseeds *seeds);   /* the reference's "ave. len" numerator */
+int     fga_seeds_download(const fga_dseeds *seeds, fga_seed *host, int64_t max);
+void    fga_seeds_free(fga_dseeds *seeds);
+
 #ifdef __cplusplus
 }
 #endif
