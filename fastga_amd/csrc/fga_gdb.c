@@ -129,7 +129,7 @@ static int write_skeleton_file(const fga_gdb *gdb, const char *path, const char 
     }
 
   fprintf(f,"1 3 gdb 2 1\n");
-  fprintf(f,"! %d %s 3 0.1 %d %s %d %s\n",(int) strlen(prog),prog,(int) strlen(command),command,
+  fprintf(f,"! 4 %d %s 3 0.1 %d %s %d %s\n",(int) strlen(prog),prog,(int) strlen(command),command,
             (int) strlen(date),date);
   fprintf(f,".\n");
   fprintf(f,"< %d %s 1\n",(int) strlen(gdb->srcpath),gdb->srcpath);

@@ -14,23 +14,31 @@
 //   A tile therefore holds <= TILE table entries of T1 and T2 together plus <= TILE/2 prefixes -- unless a
 //   single panel is larger than that, in which case the tile is exactly that panel and takes the
 //   global-memory path.
-// LDS-staged tile (the common case), one 256-thread workgroup per tile:
-//   1. the two index slices are loaded as 32-bit offsets relative to the tile start,
+// LDS-staged tile (the common case).  Persistent 256-thread workgroups loop over tiles:
+//   1. both index slices are loaded as 32-bit offsets relative to the tile start,
 //   2. the raw on-disk bytes of both entry ranges stream HBM -> LDS with 16-byte-per-lane coalesced loads
 //      (the tables are consumed in their on-disk 13..16-byte width, nothing is re-packed in HBM),
-//   3. T2 entries are decoded once into 64-bit keys (suffix56 << 8 | mask) in LDS,
-//   4. each lane takes T1 entries: panel lookup (binary search in the index slice), lower bound in the T2
-//      panel, LCP with both neighbours by clz of the key xor, range growth bounded by FREQ,
-//   5. seeds are appended with one global atomic per wavefront (wave-wide exclusive scan of lane counts).
+//   3. the panel of every T1 entry comes from a head-flag scatter + block max-scan (no per-entry search);
+//      T2 entries are decoded once into 64-bit keys (suffix56 << 8 | mask = byte-swapped first 8 bytes),
+//   4. match phase: each lane takes T1 entries (aligned dword LDS reads + v_alignbyte to unpack the odd-width
+//      records), lower bound inside the T2 panel, LCP with both neighbours by clz of the key xor, range
+//      growth bounded by FREQ; results stay in registers,
+//   5. emit phase: one block-wide scan per tile gives every lane its slot in an LDS seed stage, which is
+//      flushed to HBM with ONE global atomic per ~1000 seeds and fully coalesced 16-byte stores (a single
+//      counter word sustains only ~88 atomics/us on MI355X -- per-wave appends would bound the kernel).
 // No MFMA anywhere: integer compare / byte work, HBM-bound by design.
 
 #include "fga_device.hpp"
 
-#define MERGE_THREADS   256
+#define NT              256                  // threads per workgroup
+#define NWAVE           (NT/64)
 #define TILE_COST       1024                 // cost units per tile
+#define EPT             (TILE_COST/NT)       // T1 entries per thread (upper bound)
 #define PCAP            (TILE_COST/2 + 2)    // max prefixes of an LDS tile
-#define KCAP            TILE_COST            // max T2 entries of an LDS tile
-#define RAWCAP          (TILE_COST*16 + 64)  // bytes of raw entries staged per tile (E <= 16)
+#define RAWCAP          (TILE_COST*16 + 96)  // bytes of raw entries staged per tile (E <= 16)
+#define STAGE_CAP       1024                 // seeds staged in LDS between flushes
+
+enum { MODE_PAIR = 0, MODE_FLIP = 1, MODE_SELF = 2 };
 
 struct merge_tile            // 32 bytes
   { int32_t p;               // first prefix of the tile
@@ -90,333 +98,503 @@ __global__ void merge_partition_kernel(merge_args A, merge_tile *tiles)
 // ---------------------------------------------------------------------------------------------------
 // helpers
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lcp_suffix(uint64_t a, uint64_t b)      // a,b = 56-bit suffixes (bases 13..40)
-{ uint64_t x = a ^ b;
-  return x == 0 ? 40 : 12 + ((__clzll((long long) x) - 8) >> 1);
+
+// key = suffix56 << 8 | mask.  LCP in bases (>= 12: same panel) of two keys, ignoring the mask byte.
+__device__ __forceinline__ int lcp_key(uint64_t a, uint64_t b)
+{ uint64_t x = (a ^ b) & ~0xffull;
+  return x == 0 ? 40 : 12 + (__clzll((long long) x) >> 1);
 }
 
-template <typename P>
-__device__ __forceinline__ uint64_t load_be7(P e)                      // bytes 0..6 big-endian -> suffix56
-{ return ((uint64_t) e[0] << 48) | ((uint64_t) e[1] << 40) | ((uint64_t) e[2] << 32)
-       | ((uint64_t) e[3] << 24) | ((uint64_t) e[4] << 16) | ((uint64_t) e[5] << 8) | (uint64_t) e[6];
+__device__ __forceinline__ uint32_t bswap32(uint32_t x)
+{ return __builtin_bswap32(x); }
+
+// 16 bytes starting at byte offset o of an LDS byte array viewed as aligned dwords
+__device__ __forceinline__ void lds_read16(const uint32_t *rawd, uint32_t o, uint32_t &e0, uint32_t &e1,
+                                           uint32_t &e2, uint32_t &e3)
+{ uint32_t w = o >> 2, sh = o & 3;
+  uint32_t d0 = rawd[w], d1 = rawd[w+1], d2 = rawd[w+2], d3 = rawd[w+3], d4 = rawd[w+4];
+  e0 = __builtin_amdgcn_alignbyte(d1,d0,sh);
+  e1 = __builtin_amdgcn_alignbyte(d2,d1,sh);
+  e2 = __builtin_amdgcn_alignbyte(d3,d2,sh);
+  e3 = __builtin_amdgcn_alignbyte(d4,d3,sh);
 }
 
-template <typename P>
-__device__ __forceinline__ uint32_t load_le(P e, int n)
-{ uint32_t v = 0;
-  for (int k = 0; k < n; k++)
-    v |= (uint32_t) e[k] << (8*k);
+__device__ __forceinline__ uint64_t lds_read_key(const uint32_t *rawd, uint32_t o)    // first 8 bytes -> key
+{ uint32_t w = o >> 2, sh = o & 3;
+  uint32_t d0 = rawd[w], d1 = rawd[w+1], d2 = rawd[w+2];
+  uint32_t e0 = __builtin_amdgcn_alignbyte(d1,d0,sh);
+  uint32_t e1 = __builtin_amdgcn_alignbyte(d2,d1,sh);
+  return ((uint64_t) bswap32(e0) << 32) | bswap32(e1);
+}
+
+// payload (bytes 9.. of an entry, little endian) given the entry's dwords e2,e3
+__device__ __forceinline__ void split_payload(uint32_t e2, uint32_t e3, int post, int cont,
+                                              uint32_t &pos, uint32_t &ctg, uint32_t &sign)
+{ uint64_t pv = (((uint64_t) e3 << 32) | e2) >> 8;
+  uint32_t pm = post >= 4 ? 0xffffffffu : ((1u << (8*post)) - 1);
+  pos = (uint32_t) pv & pm;
+  uint32_t c  = (uint32_t) (pv >> (8*post)) & ((1u << (8*cont)) - 1);
+  uint32_t sb = 0x80u << (8*(cont-1));
+  sign = (c & sb) != 0;
+  ctg  = c & (sb-1);
+}
+
+__device__ __forceinline__ int wave_incl_scan_add(int v)
+{ int lane = threadIdx.x & 63;
+  #pragma unroll
+  for (int d = 1; d < 64; d <<= 1)
+    { int y = __shfl_up(v,d,64);
+      if (lane >= d) v += y;
+    }
   return v;
 }
 
-// wave-wide exclusive scan of a small non-negative count; returns the lane's offset, total in `total`
-__device__ __forceinline__ int wave_excl_scan(int v, int &total)
+__device__ __forceinline__ int wave_incl_scan_max(int v)
 { int lane = threadIdx.x & 63;
-  int x = v;
   #pragma unroll
   for (int d = 1; d < 64; d <<= 1)
-    { int y = __shfl_up(x,d,64);
-      if (lane >= d) x += y;
+    { int y = __shfl_up(v,d,64);
+      if (lane >= d) v = v > y ? v : y;
     }
-  total = __shfl(x,63,64);
-  return x - v;
+  return v;
 }
 
-// Everything needed about one T1 entry and its matching T2 run
-struct hit_t
-  { int plen;
-    int cnt;        // seeds this entry emits
-    int64_t low, hgh;
+struct stage_t
+  { fga_seed *buf;               // LDS, STAGE_CAP seeds
+    int      *n;                 // LDS, seeds currently staged
+    int      *wtot;              // LDS, NWAVE per-wave totals
+    unsigned long long *gbase;   // LDS, base returned by the flush atomic
   };
 
-// ---------------------------------------------------------------------------------------------------
-// Accessors: the same matching code runs over an LDS-staged tile or straight from global memory
-// ---------------------------------------------------------------------------------------------------
-struct lds_t2
-  { const uint64_t *key;     // decoded suffix56<<8 | mask
-    const uint8_t  *raw;     // raw entries, entry j at raw + j*E
-    int E, post, cont;
-    __device__ __forceinline__ uint64_t suffix(int64_t j) const { return key[j] >> 8; }
-    __device__ __forceinline__ int      mask(int64_t j)   const { return (int) (key[j] & 0xff); }
-    __device__ __forceinline__ void payload(int64_t j, uint32_t &pos, uint32_t &ctg, uint32_t &sign) const
-    { const uint8_t *e = raw + j*E + 9;
-      pos = load_le(e,post);
-      uint32_t c = load_le(e+post,cont);
-      uint32_t sb = 0x80u << (8*(cont-1));
-      sign = (c & sb) != 0;
-      ctg  = c & (sb-1);
-    }
-  };
-
-struct glb_t2
-  { const uint8_t *tab;      // entry j (absolute index) at tab + j*E
-    int E, post, cont;
-    __device__ __forceinline__ uint64_t suffix(int64_t j) const { return load_be7(tab + j*E); }
-    __device__ __forceinline__ int      mask(int64_t j)   const { return tab[j*E+7]; }
-    __device__ __forceinline__ void payload(int64_t j, uint32_t &pos, uint32_t &ctg, uint32_t &sign) const
-    { const uint8_t *e = tab + j*E + 9;
-      pos = load_le(e,post);
-      uint32_t c = load_le(e+post,cont);
-      uint32_t sb = 0x80u << (8*(cont-1));
-      sign = (c & sb) != 0;
-      ctg  = c & (sb-1);
-    }
-  };
-
-// pair mode: match T1 suffix ks against T2 panel [b0,b1)
-template <typename T2>
-__device__ __forceinline__ void match_pair(const T2 &t2, uint64_t ks, int64_t b0, int64_t b1, int freq, hit_t &h)
-{ int64_t lo = b0, hi = b1;
-  while (lo < hi)
-    { int64_t m = (lo+hi) >> 1;
-      if (t2.suffix(m) < ks) lo = m+1; else hi = m;
-    }
-  int la = (lo > b0) ? lcp_suffix(ks,t2.suffix(lo-1)) : 0;
-  int lc = (lo < b1) ? lcp_suffix(ks,t2.suffix(lo)) : 0;
-  int plen = la > lc ? la : lc;
-  int64_t low = lo, hgh = lo;
-  while (low > b0 && lo-low <= freq && lcp_suffix(ks,t2.suffix(low-1)) >= plen)
-    low -= 1;
-  while (hgh < b1 && hgh-low <= freq && lcp_suffix(ks,t2.suffix(hgh)) >= plen)
-    hgh += 1;
-  h.plen = plen; h.low = low; h.hgh = hgh;
-}
-
-// self mode: entry k of panel [a0,a1); plen = max(lcp with predecessor, lcp with successor)
-template <typename T2>
-__device__ __forceinline__ void match_self(const T2 &t2, int64_t k, int64_t a0, int64_t a1, int freq, hit_t &h)
-{ uint64_t ks = t2.suffix(k);
-  int lk  = (k > a0)   ? lcp_suffix(ks,t2.suffix(k-1)) : 0;
-  int lk1 = (k+1 < a1) ? lcp_suffix(ks,t2.suffix(k+1)) : 11;
-  int plen = lk > lk1 ? lk : lk1;
-  int64_t low = k, hgh = k+1;
-  while (low > a0 && k-low <= freq && lcp_suffix(ks,t2.suffix(low-1)) >= plen)
-    low -= 1;
-  while (hgh < a1 && hgh-low <= freq && lcp_suffix(ks,t2.suffix(hgh)) >= plen)
-    hgh += 1;
-  h.plen = plen; h.low = low; h.hgh = hgh;
-}
-
-// Emit (or count, when out == nullptr-equivalent pass) the seeds of one T1 entry.
-//   s*  : T1 entry fields;  selfk : index of the entry itself inside t2 (self mode) or -1
-template <typename T2, bool COUNT>
-__device__ __forceinline__ int emit_entry(const merge_args &A, const T2 &t2, const hit_t &h,
-                                          int smask, uint32_t spos, uint32_t sctg, uint32_t ssign,
-                                          int64_t selfk, fga_seed *out, int64_t cap, int64_t wpos)
-{ if (h.hgh - h.low >= A.freq)
-    return 0;
-  int mlen = A.soft_mask ? h.plen : 41;
-  if (smask >= mlen)
-    return 0;
-  if (!A.self && !A.flip && ssign)
-    return 0;
-  int n = 0;
-  for (int64_t j = h.low; j < h.hgh; j++)
-    { if (j == selfk || t2.mask(j) >= mlen)
-        continue;
-      uint32_t cpos, cctg, csign;
-      t2.payload(j,cpos,cctg,csign);
-      if (A.flip && csign)
-        continue;
-      if (!COUNT)
-        { fga_seed sd;
-          if (A.flip)            // table 1 is genome 2: A side = c (forward), B side = s
-            { sd.apos = cpos; sd.bpos = spos;
-              sd.actg = (cctg << 8) | (uint32_t) h.plen;
-              sd.bctg = sctg | (ssign << 30) | (ssign << 31);
-            }
-          else if (A.self)       // stream N iff the signs agree; A payload goes out with its sign cleared
-            { sd.apos = spos; sd.bpos = cpos;
-              sd.actg = (sctg << 8) | (uint32_t) h.plen;
-              sd.bctg = cctg | (csign << 30) | ((uint32_t) (ssign != csign) << 31);
-            }
-          else
-            { sd.apos = spos; sd.bpos = cpos;
-              sd.actg = (sctg << 8) | (uint32_t) h.plen;
-              sd.bctg = cctg | (csign << 30) | (csign << 31);
-            }
-          if (wpos+n < cap)
-            out[wpos+n] = sd;
-        }
-      n += 1;
-    }
-  return n;
-}
-
-// Wave-aggregated append: every lane of the wave calls this with its own entry (or cnt = 0).
-template <typename T2>
-__device__ __forceinline__ void wave_append(const merge_args &A, const T2 &t2, const hit_t &h, bool valid,
-                                            int smask, uint32_t spos, uint32_t sctg, uint32_t ssign, int64_t selfk)
-{ int cnt = valid ? emit_entry<T2,true>(A,t2,h,smask,spos,sctg,ssign,selfk,nullptr,0,0) : 0;
-  int total;
-  int off = wave_excl_scan(cnt,total);
-  if (total == 0)
+// flush the LDS stage to HBM: one atomic, coalesced 16-byte stores.  All threads must call it.
+__device__ __forceinline__ void stage_flush(const merge_args &A, const stage_t &S)
+{ int n = *S.n;
+  if (n == 0)
     return;
-  unsigned long long base = 0;
-  int lane = threadIdx.x & 63;
-  int tl = cnt * h.plen, tsum = tl;
+  if (threadIdx.x == 0)
+    *S.gbase = atomicAdd(A.count,(unsigned long long) n);
+  __syncthreads();
+  int64_t base = (int64_t) *S.gbase;
+  for (int x = threadIdx.x; x < n; x += NT)
+    if (base + x < A.cap)
+      A.out[base + x] = S.buf[x];
+  __syncthreads();
+  if (threadIdx.x == 0)
+    *S.n = 0;
+  __syncthreads();
+}
+
+// Block-wide slot assignment for `cnt` seeds per thread.  Returns where this thread writes:
+//   dst = LDS stage (direct == false) or HBM (direct == true), at index `at`.
+__device__ __forceinline__ void block_slots(const merge_args &A, const stage_t &S, int cnt,
+                                            bool &any, bool &direct, int64_t &at)
+{ const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int inc = wave_incl_scan_add(cnt);
+  if (lane == 63)
+    S.wtot[wave] = inc;
+  __syncthreads();
+  int btotal = 0, wbase = 0;
   #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1)
-    tsum += __shfl_xor(tsum,d,64);
-  if (lane == 0)
-    { base = atomicAdd(A.count,(unsigned long long) total);
-      atomicAdd(A.tseed,(unsigned long long) tsum);
+  for (int w = 0; w < NWAVE; w++)
+    { int t = S.wtot[w];
+      if (w < wave) wbase += t;
+      btotal += t;
     }
-  base = __shfl(base,0,64);
-  if (cnt > 0)
-    emit_entry<T2,false>(A,t2,h,smask,spos,sctg,ssign,selfk,A.out,A.cap,(int64_t) base + off);
+  any = btotal > 0;
+  direct = false;
+  at = 0;
+  if (!any)
+    { __syncthreads();
+      return;
+    }
+  if (*S.n + btotal > STAGE_CAP)
+    stage_flush(A,S);
+  if (btotal > STAGE_CAP)
+    { if (threadIdx.x == 0)
+        *S.gbase = atomicAdd(A.count,(unsigned long long) btotal);
+      __syncthreads();
+      direct = true;
+      at = (int64_t) *S.gbase + wbase + (inc - cnt);
+      __syncthreads();
+      return;
+    }
+  at = *S.n + wbase + (inc - cnt);
+  __syncthreads();
+  if (threadIdx.x == 0)
+    *S.n += btotal;
+  // the caller synchronises before the stage is read or flushed again
+}
+
+template <int MODE>
+__device__ __forceinline__ fga_seed make_seed(int plen, uint32_t spos, uint32_t sctg, uint32_t ssign,
+                                              uint32_t cpos, uint32_t cctg, uint32_t csign)
+{ fga_seed sd;
+  if (MODE == MODE_FLIP)          // table 1 is genome 2: A side = c (forward), B side = s
+    { sd.apos = cpos; sd.bpos = spos;
+      sd.actg = (cctg << 8) | (uint32_t) plen;
+      sd.bctg = sctg | (ssign << 30) | (ssign << 31);
+    }
+  else if (MODE == MODE_SELF)     // stream N iff the signs agree; A payload goes out with its sign cleared
+    { sd.apos = spos; sd.bpos = cpos;
+      sd.actg = (sctg << 8) | (uint32_t) plen;
+      sd.bctg = cctg | (csign << 30) | ((uint32_t) (ssign != csign) << 31);
+    }
+  else
+    { sd.apos = spos; sd.bpos = cpos;
+      sd.actg = (sctg << 8) | (uint32_t) plen;
+      sd.bctg = cctg | (csign << 30) | (csign << 31);
+    }
+  return sd;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Oversize tiles: same semantics straight from HBM (byte loads; rare)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t glb_key(const uint8_t *e)
+{ return ((uint64_t) e[0] << 56) | ((uint64_t) e[1] << 48) | ((uint64_t) e[2] << 40) | ((uint64_t) e[3] << 32)
+       | ((uint64_t) e[4] << 24) | ((uint64_t) e[5] << 16) | ((uint64_t) e[6] << 8) | (uint64_t) e[7];
+}
+
+__device__ __forceinline__ void glb_payload(const uint8_t *e, int post, int cont,
+                                            uint32_t &pos, uint32_t &ctg, uint32_t &sign)
+{ uint32_t p = 0, c = 0;
+  for (int k = 0; k < post; k++) p |= (uint32_t) e[9+k] << (8*k);
+  for (int k = 0; k < cont; k++) c |= (uint32_t) e[9+post+k] << (8*k);
+  uint32_t sb = 0x80u << (8*(cont-1));
+  pos = p; sign = (c & sb) != 0; ctg = c & (sb-1);
+}
+
+template <int MODE>
+__device__ void global_tile(const merge_args &A, const stage_t &S, int p0, int p1, int64_t a0, int64_t a1,
+                            unsigned long long &tsum)
+{ const uint8_t *tab2 = (MODE == MODE_SELF) ? A.tab1 : A.tab2;
+  const int64_t *idx2 = (MODE == MODE_SELF) ? A.idx1 : A.idx2;
+  const int E1 = A.E1, E2 = A.E2;
+  const int64_t rounds = (a1 - a0 + NT - 1) / NT;
+  for (int64_t r = 0; r < rounds; r++)
+    { int64_t i = a0 + r*NT + threadIdx.x;
+      int cnt = 0, plen = 0;
+      int64_t low = 0, hgh = 0;
+      uint32_t spos = 0, sctg = 0, ssign = 0;
+      int mlen = 41;
+      if (i < a1)
+        { int lo = p0, hi = p1-1;                   // smallest p with idx1[p] > i
+          while (lo < hi)
+            { int m = lo + ((hi-lo) >> 1);
+              if (A.idx1[m] > i) hi = m; else lo = m+1;
+            }
+          int64_t b0 = idx_at(idx2,lo-1), b1 = idx2[lo];
+          const uint8_t *e = A.tab1 + i*E1;
+          glb_payload(e,A.post1,A.cont1,spos,sctg,ssign);
+          bool go = (b1 > b0) && !(MODE == MODE_PAIR && ssign);
+          if (go)
+            { uint64_t ks = glb_key(e);
+              int64_t lb;
+              if (MODE == MODE_SELF)
+                { int lk  = (i > b0)   ? lcp_key(ks,glb_key(tab2 + (i-1)*E2)) : 0;
+                  int lk1 = (i+1 < b1) ? lcp_key(ks,glb_key(tab2 + (i+1)*E2)) : 11;
+                  plen = lk > lk1 ? lk : lk1;
+                  low = i; hgh = i+1; lb = i;
+                }
+              else
+                { int64_t l = b0, h = b1;
+                  uint64_t kq = ks & ~0xffull;
+                  while (l < h)
+                    { int64_t m = (l+h) >> 1;
+                      if (glb_key(tab2 + m*E2) < kq) l = m+1; else h = m;
+                    }
+                  int la = (l > b0) ? lcp_key(ks,glb_key(tab2 + (l-1)*E2)) : 0;
+                  int lc = (l < b1) ? lcp_key(ks,glb_key(tab2 + l*E2)) : 0;
+                  plen = la > lc ? la : lc;
+                  low = hgh = lb = l;
+                }
+              while (low > b0 && lb-low <= A.freq && lcp_key(ks,glb_key(tab2 + (low-1)*E2)) >= plen)
+                low -= 1;
+              while (hgh < b1 && hgh-low <= A.freq && lcp_key(ks,glb_key(tab2 + hgh*E2)) >= plen)
+                hgh += 1;
+              mlen = A.soft_mask ? plen : 41;
+              if (hgh-low < A.freq && (int) (ks & 0xff) < mlen)
+                for (int64_t j = low; j < hgh; j++)
+                  { const uint8_t *c = tab2 + j*E2;
+                    if ((MODE == MODE_SELF && j == i) || c[7] >= mlen)
+                      continue;
+                    if (MODE == MODE_FLIP)
+                      { uint32_t cp, cc, cs;
+                        glb_payload(c,A.post2,A.cont2,cp,cc,cs);
+                        if (cs) continue;
+                      }
+                    cnt += 1;
+                  }
+            }
+        }
+      bool any, direct;
+      int64_t at;
+      block_slots(A,S,cnt,any,direct,at);
+      if (!any)
+        continue;
+      if (cnt > 0)
+        { tsum += (unsigned long long) cnt * plen;
+          for (int64_t j = low; j < hgh; j++)
+            { const uint8_t *c = tab2 + j*E2;
+              if ((MODE == MODE_SELF && j == i) || c[7] >= mlen)
+                continue;
+              uint32_t cp, cc, cs;
+              glb_payload(c,A.post2,A.cont2,cp,cc,cs);
+              if (MODE == MODE_FLIP && cs)
+                continue;
+              fga_seed sd = make_seed<MODE>(plen,spos,sctg,ssign,cp,cc,cs);
+              if (direct)
+                { if (at < A.cap) A.out[at] = sd; }
+              else
+                S.buf[at] = sd;
+              at += 1;
+            }
+        }
+      __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // the merge kernel
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MERGE_THREADS)
+template <int MODE>
+__global__ __launch_bounds__(NT)
 void seed_merge_kernel(merge_args A)
 { __shared__ uint32_t la[PCAP+1];            // la[q] = #T1 entries of the tile in prefixes <= p0+q
   __shared__ uint32_t lb[PCAP+1];
   __shared__ __attribute__((aligned(16))) uint8_t  raw[RAWCAP];
-  __shared__ __attribute__((aligned(16))) uint64_t keyB[KCAP];
+  __shared__ __attribute__((aligned(16))) uint64_t keyB[TILE_COST];
+  __shared__ __attribute__((aligned(16))) uint16_t own[TILE_COST];
+  __shared__ __attribute__((aligned(16))) fga_seed stagebuf[STAGE_CAP];
+  __shared__ int stage_n;
+  __shared__ int wtot[NWAVE];
+  __shared__ unsigned long long gbase;
 
   const int tid = threadIdx.x;
-  const merge_tile t0 = A.tiles[blockIdx.x];
-  const merge_tile t1 = A.tiles[blockIdx.x+1];
-  const int     p0 = t0.p, p1 = t1.p;
-  const int     np = p1 - p0;
-  if (np <= 0)
-    return;
-  const int64_t a0 = t0.a, a1 = t1.a;
-  const int64_t b0 = A.self ? a0 : t0.b, b1 = A.self ? a1 : t1.b;
-  const int64_t n1 = a1 - a0, n2 = b1 - b0;
-  if (n1 == 0 || n2 == 0)
-    return;
+  stage_t S;
+  S.buf = stagebuf; S.n = &stage_n; S.wtot = wtot; S.gbase = &gbase;
+  if (tid == 0)
+    stage_n = 0;
+  unsigned long long tsum = 0;
+  __syncthreads();
 
   const int E1 = A.E1, E2 = A.E2;
+  const int freq = A.freq;
 
-  // byte extents, aligned down to 16 for the coalesced copy
-  const int64_t s1 = a0*E1, e1 = a1*E1;
-  const int64_t s2 = b0*E2, e2 = b1*E2;
-  const int64_t s1a = s1 & ~(int64_t) 15, s2a = s2 & ~(int64_t) 15;
-  const int64_t len1 = ((e1 - s1a) + 15) & ~(int64_t) 15;
-  const int64_t len2 = A.self ? 0 : (((e2 - s2a) + 15) & ~(int64_t) 15);
+  for (int tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x)
+    { const merge_tile t0 = A.tiles[tile];
+      const merge_tile t1 = A.tiles[tile+1];
+      const int p0 = t0.p, p1 = t1.p;
+      const int np = p1 - p0;
+      if (np <= 0)
+        continue;
+      const int64_t a0 = t0.a, a1 = t1.a;
+      const int64_t b0 = (MODE == MODE_SELF) ? a0 : t0.b, b1 = (MODE == MODE_SELF) ? a1 : t1.b;
+      const int64_t n1l = a1 - a0, n2l = b1 - b0;
+      if (n1l == 0 || n2l == 0)
+        continue;
 
-  const bool fits = (np <= PCAP) && (n2 <= KCAP) && (len1 + len2 <= RAWCAP);
+      // byte extents, aligned down to 16 for the coalesced copy
+      const int64_t s1 = a0*E1, e1 = a1*E1;
+      const int64_t s2 = b0*E2, e2 = b1*E2;
+      const int64_t s1a = s1 & ~(int64_t) 15, s2a = s2 & ~(int64_t) 15;
+      const int64_t len1 = ((e1 - s1a) + 15) & ~(int64_t) 15;
+      const int64_t len2 = (MODE == MODE_SELF) ? 0 : (((e2 - s2a) + 15) & ~(int64_t) 15);
 
-  if (fits)
-    { // 1. index slices
-      for (int q = tid; q < np; q += MERGE_THREADS)
-        { la[q] = (uint32_t) (A.idx1[p0+q] - a0);
-          lb[q] = A.self ? la[q] : (uint32_t) (A.idx2[p0+q] - b0);
+      if (np > PCAP-1 || n1l > TILE_COST || n2l > TILE_COST || len1 + len2 > RAWCAP - 32)
+        { global_tile<MODE>(A,S,p0,p1,a0,a1,tsum);
+          __syncthreads();
+          continue;
         }
-      // 2. raw bytes, 16 B per lane
+      const int n1 = (int) n1l, n2 = (int) n2l;
+
+      // 1. raw bytes HBM -> LDS, 16 B per lane; index slices; clear the owner array
       { const uint4 *g1 = (const uint4 *) (A.tab1 + s1a);
         uint4 *l1 = (uint4 *) raw;
-        int n16 = (int) (len1 >> 4);
-        for (int x = tid; x < n16; x += MERGE_THREADS)
+        const int n16 = (int) (len1 >> 4);
+        for (int x = tid; x < n16; x += NT)
           l1[x] = g1[x];
-        if (!A.self)
+        if (MODE != MODE_SELF)
           { const uint4 *g2 = (const uint4 *) (A.tab2 + s2a);
             uint4 *l2 = (uint4 *) (raw + len1);
-            int m16 = (int) (len2 >> 4);
-            for (int x = tid; x < m16; x += MERGE_THREADS)
+            const int m16 = (int) (len2 >> 4);
+            for (int x = tid; x < m16; x += NT)
               l2[x] = g2[x];
           }
       }
-      __syncthreads();
-
-      const uint8_t *r1 = raw + (s1 - s1a);
-      const uint8_t *r2 = A.self ? r1 : raw + len1 + (s2 - s2a);
-
-      // 3. T2 keys
-      for (int j = tid; j < (int) n2; j += MERGE_THREADS)
-        { const uint8_t *e = r2 + j*E2;
-          keyB[j] = (load_be7(e) << 8) | e[7];
+      for (int q = tid; q < np; q += NT)
+        { la[q] = (uint32_t) (A.idx1[p0+q] - a0);
+          lb[q] = (MODE == MODE_SELF) ? la[q] : (uint32_t) (A.idx2[p0+q] - b0);
         }
+      { uint2 *o2 = (uint2 *) own;
+        for (int x = tid; x < (n1+3)/4; x += NT)
+          o2[x] = make_uint2(0,0);
+      }
       __syncthreads();
 
-      lds_t2 t2;
-      t2.key = keyB; t2.raw = r2; t2.E = E2; t2.post = A.post2; t2.cont = A.cont2;
+      const uint32_t *rawd = (const uint32_t *) raw;
+      const uint32_t o1 = (uint32_t) (s1 - s1a);
+      const uint32_t o2 = (MODE == MODE_SELF) ? o1 : (uint32_t) (len1 + (s2 - s2a));
 
-      // 4./5. one T1 entry per lane per round; whole waves stay in the loop for the wave-wide append
-      const int rounds = ((int) n1 + MERGE_THREADS - 1) / MERGE_THREADS;
-      for (int r = 0; r < rounds; r++)
-        { int  i = r*MERGE_THREADS + tid;
-          bool valid = i < (int) n1;
-          hit_t h; h.plen = 0; h.cnt = 0; h.low = h.hgh = 0;
-          int smask = 0; uint32_t spos = 0, sctg = 0, ssign = 0;
-          int64_t selfk = -1;
-          if (valid)
-            { // panel of entry i: smallest q with la[q] > i
-              int lo = 0, hi = np-1;
+      // 2. head flags of the non-empty T1 panels; T2 keys
+      for (int q = tid; q < np; q += NT)
+        { uint32_t s = q ? la[q-1] : 0;
+          if (la[q] > s)
+            own[s] = (uint16_t) q;
+        }
+      for (int j = tid; j < n2; j += NT)
+        keyB[j] = lds_read_key(rawd,o2 + (uint32_t) j*E2);
+      __syncthreads();
+
+      // 3. owner[i] = max head at or before i (block max-scan, 4 consecutive entries per thread)
+      { uint2 v = ((uint2 *) own)[tid];
+        int x0 = v.x & 0xffff, x1 = v.x >> 16, x2 = v.y & 0xffff, x3 = v.y >> 16;
+        x1 = x1 > x0 ? x1 : x0;
+        x2 = x2 > x1 ? x2 : x1;
+        x3 = x3 > x2 ? x3 : x2;
+        int inc = wave_incl_scan_max(x3);
+        if ((tid & 63) == 63)
+          wtot[tid >> 6] = inc;
+        __syncthreads();
+        int prev = __shfl_up(inc,1,64);
+        if ((tid & 63) == 0) prev = 0;
+        #pragma unroll
+        for (int w = 0; w < NWAVE; w++)
+          if (w < (tid >> 6))
+            { int t = wtot[w];
+              prev = prev > t ? prev : t;
+            }
+        x0 = x0 > prev ? x0 : prev;
+        x1 = x1 > prev ? x1 : prev;
+        x2 = x2 > prev ? x2 : prev;
+        x3 = x3 > prev ? x3 : prev;
+        if (tid*4 < n1)
+          ((uint2 *) own)[tid] = make_uint2((uint32_t) x0 | ((uint32_t) x1 << 16),
+                                            (uint32_t) x2 | ((uint32_t) x3 << 16));
+        __syncthreads();
+      }
+
+      // 4. match phase: T1 entries tid, tid+NT, ...; results packed in registers
+      int      r_low[EPT], r_cnt[EPT], r_plen[EPT];
+      int      total = 0;
+      #pragma unroll
+      for (int r = 0; r < EPT; r++)
+        { const int i = r*NT + tid;
+          r_cnt[r] = 0; r_low[r] = 0; r_plen[r] = 0;
+          if (i >= n1)
+            continue;
+          const uint32_t oe = o1 + (uint32_t) i*E1;
+          // sign test first: complement-strand T1 entries emit nothing in the plain pass (FastGA.c:921-928)
+          if (MODE == MODE_PAIR)
+            { uint32_t sb = oe + E1 - 1;
+              uint32_t wd = rawd[sb >> 2] >> (8*(sb & 3));
+              if (wd & 0x80)
+                continue;
+            }
+          const int q = own[i];
+          const int pb0 = q ? (int) lb[q-1] : 0, pb1 = (int) lb[q];
+          if (pb0 == pb1)
+            continue;
+          const uint64_t ks = (MODE == MODE_SELF) ? keyB[i] : lds_read_key(rawd,oe);
+          int low, hgh, plen, lbnd;
+          if (MODE == MODE_SELF)
+            { int lk  = (i > pb0)   ? lcp_key(ks,keyB[i-1]) : 0;
+              int lk1 = (i+1 < pb1) ? lcp_key(ks,keyB[i+1]) : 11;
+              plen = lk > lk1 ? lk : lk1;
+              low = i; hgh = i+1; lbnd = i;
+            }
+          else
+            { int lo = pb0, hi = pb1;
+              const uint64_t kq = ks & ~0xffull;
               while (lo < hi)
                 { int m = (lo+hi) >> 1;
-                  if (la[m] > (uint32_t) i) hi = m; else lo = m+1;
+                  if (keyB[m] < kq) lo = m+1; else hi = m;
                 }
-              int q = lo;
-              int64_t pb0 = q ? lb[q-1] : 0, pb1 = lb[q];
-              if (pb0 == pb1)
-                valid = false;
-              else
-                { const uint8_t *e = r1 + i*E1;
-                  smask = e[7];
-                  spos  = load_le(e+9,A.post1);
-                  uint32_t c  = load_le(e+9+A.post1,A.cont1);
-                  uint32_t sb = 0x80u << (8*(A.cont1-1));
-                  ssign = (c & sb) != 0;
-                  sctg  = c & (sb-1);
-                  if (A.self)
-                    { selfk = i;
-                      match_self(t2,(int64_t) i,pb0,pb1,A.freq,h);
+              int la_ = (lo > pb0) ? lcp_key(ks,keyB[lo-1]) : 0;
+              int lc_ = (lo < pb1) ? lcp_key(ks,keyB[lo]) : 0;
+              plen = la_ > lc_ ? la_ : lc_;
+              low = hgh = lbnd = lo;
+            }
+          while (low > pb0 && lbnd-low <= freq && lcp_key(ks,keyB[low-1]) >= plen)
+            low -= 1;
+          while (hgh < pb1 && hgh-low <= freq && lcp_key(ks,keyB[hgh]) >= plen)
+            hgh += 1;
+          if (hgh-low >= freq)
+            continue;
+          const int mlen = A.soft_mask ? plen : 41;
+          if ((int) (ks & 0xff) >= mlen)
+            continue;
+          int cnt;
+          if (MODE == MODE_FLIP || A.soft_mask)
+            { cnt = 0;
+              for (int j = low; j < hgh; j++)
+                { if ((int) (keyB[j] & 0xff) >= mlen)
+                    continue;
+                  if (MODE == MODE_FLIP)
+                    { uint32_t sb = o2 + (uint32_t) j*E2 + E2 - 1;
+                      if ((rawd[sb >> 2] >> (8*(sb & 3))) & 0x80)
+                        continue;
                     }
-                  else
-                    match_pair(t2,load_be7(e),pb0,pb1,A.freq,h);
+                  if (MODE == MODE_SELF && j == i)
+                    continue;
+                  cnt += 1;
                 }
             }
-          wave_append(A,t2,h,valid,smask,spos,sctg,ssign,selfk);
+          else
+            cnt = (hgh-low) - (MODE == MODE_SELF ? 1 : 0);
+          r_cnt[r] = cnt; r_low[r] = low | (hgh << 16); r_plen[r] = plen;
+          total += cnt;
+          tsum  += (unsigned long long) cnt * plen;
         }
-    }
-  else
-    { // Oversize tile (one huge panel, possibly with a few neighbours): same logic straight from HBM.
-      glb_t2 t2;
-      t2.tab = A.self ? A.tab1 : A.tab2; t2.E = E2; t2.post = A.post2; t2.cont = A.cont2;
-      const int64_t rounds = (n1 + MERGE_THREADS - 1) / MERGE_THREADS;
-      for (int64_t r = 0; r < rounds; r++)
-        { int64_t i = a0 + r*MERGE_THREADS + tid;      // absolute T1 entry
-          bool valid = i < a1;
-          hit_t h; h.plen = 0; h.cnt = 0; h.low = h.hgh = 0;
-          int smask = 0; uint32_t spos = 0, sctg = 0, ssign = 0;
-          int64_t selfk = -1;
-          if (valid)
-            { int lo = p0, hi = p1-1;                  // smallest p with idx1[p] > i
-              while (lo < hi)
-                { int m = lo + ((hi-lo) >> 1);
-                  if (A.idx1[m] > i) hi = m; else lo = m+1;
-                }
-              int64_t pb0, pb1;
-              if (A.self)
-                { pb0 = idx_at(A.idx1,lo-1); pb1 = A.idx1[lo]; }
-              else
-                { pb0 = idx_at(A.idx2,lo-1); pb1 = A.idx2[lo]; }
-              if (pb0 == pb1)
-                valid = false;
-              else
-                { const uint8_t *e = A.tab1 + i*E1;
-                  smask = e[7];
-                  spos  = load_le(e+9,A.post1);
-                  uint32_t c  = load_le(e+9+A.post1,A.cont1);
-                  uint32_t sb = 0x80u << (8*(A.cont1-1));
-                  ssign = (c & sb) != 0;
-                  sctg  = c & (sb-1);
-                  if (A.self)
-                    { selfk = i;
-                      match_self(t2,i,pb0,pb1,A.freq,h);
+
+      // 5. emit phase
+      bool any, direct;
+      int64_t at;
+      block_slots(A,S,total,any,direct,at);
+      if (any)
+        { if (total > 0)
+            { const int mfull = A.soft_mask;
+              #pragma unroll
+              for (int r = 0; r < EPT; r++)
+                { if (r_cnt[r] == 0)
+                    continue;
+                  const int i = r*NT + tid;
+                  const int low = r_low[r] & 0xffff, hgh = r_low[r] >> 16, plen = r_plen[r];
+                  const int mlen = mfull ? plen : 41;
+                  uint32_t e0, e1_, e2_, e3, spos, sctg, ssign;
+                  lds_read16(rawd,o1 + (uint32_t) i*E1,e0,e1_,e2_,e3);
+                  split_payload(e2_,e3,A.post1,A.cont1,spos,sctg,ssign);
+                  for (int j = low; j < hgh; j++)
+                    { if ((int) (keyB[j] & 0xff) >= mlen)
+                        continue;
+                      if (MODE == MODE_SELF && j == i)
+                        continue;
+                      uint32_t c0, c1, c2, c3, cpos, cctg, csign;
+                      lds_read16(rawd,o2 + (uint32_t) j*E2,c0,c1,c2,c3);
+                      split_payload(c2,c3,A.post2,A.cont2,cpos,cctg,csign);
+                      if (MODE == MODE_FLIP && csign)
+                        continue;
+                      fga_seed sd = make_seed<MODE>(plen,spos,sctg,ssign,cpos,cctg,csign);
+                      if (direct)
+                        { if (at < A.cap) A.out[at] = sd; }
+                      else
+                        stagebuf[at] = sd;
+                      at += 1;
                     }
-                  else
-                    match_pair(t2,load_be7(e),pb0,pb1,A.freq,h);
                 }
             }
-          wave_append(A,t2,h,valid,smask,spos,sctg,ssign,selfk);
         }
+      __syncthreads();     // tile buffers and the stage are reused by the next tile
     }
+
+  __syncthreads();
+  stage_flush(A,S);
+  // sum of plen: one atomic per wave at the very end
+  #pragma unroll
+  for (int d = 32; d >= 1; d >>= 1)
+    tsum += __shfl_xor(tsum,d,64);
+  if ((tid & 63) == 0 && tsum != 0)
+    atomicAdd(A.tseed,tsum);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -435,6 +613,10 @@ extern "C" int fga_seed_merge(fga_dev *dev, const fga_dgix *t1, const fga_dgix *
     { fga_set_error("fga_seed_merge: entries wider than 16 bytes are not supported");
       return 1;
     }
+  if (self && prm->flip)
+    { fga_set_error("fga_seed_merge: flip is meaningless for a self comparison");
+      return 1;
+    }
   FGA_HIP(hipSetDevice(dev->device));
 
   merge_args A;
@@ -447,6 +629,10 @@ extern "C" int fga_seed_merge(fga_dev *dev, const fga_dgix *t1, const fga_dgix *
   if (A.pbeg < 0) A.pbeg = 0;
   if (A.pbeg >= A.pend)
     { fga_set_error("fga_seed_merge: empty prefix range");
+      return 1;
+    }
+  if (A.freq < 1 || A.freq > 255)
+    { fga_set_error("fga_seed_merge: frequency cutoff must be in [1,255]");
       return 1;
     }
 
@@ -492,7 +678,18 @@ extern "C" int fga_seed_merge(fga_dev *dev, const fga_dgix *t1, const fga_dgix *
     hipLaunchKernelGGL(merge_partition_kernel,dim3(nb),dim3(256),0,dev->stream,A,tiles);
   }
   hipEventRecord(dev->ev1,dev->stream);
-  hipLaunchKernelGGL(seed_merge_kernel,dim3(A.ntiles),dim3(MERGE_THREADS),0,dev->stream,A);
+  { int wgs = 3;
+    const char *ev = getenv("FGA_MERGE_WGS");
+    if (ev != NULL && atoi(ev) > 0) wgs = atoi(ev);
+    int grid = dev->ncu * wgs;
+    if (grid > A.ntiles) grid = A.ntiles;
+    if (self)
+      hipLaunchKernelGGL(seed_merge_kernel<MODE_SELF>,dim3(grid),dim3(NT),0,dev->stream,A);
+    else if (prm->flip)
+      hipLaunchKernelGGL(seed_merge_kernel<MODE_FLIP>,dim3(grid),dim3(NT),0,dev->stream,A);
+    else
+      hipLaunchKernelGGL(seed_merge_kernel<MODE_PAIR>,dim3(grid),dim3(NT),0,dev->stream,A);
+  }
   hipEvent_t ev2;
   hipEventCreate(&ev2);
   hipEventRecord(ev2,dev->stream);
