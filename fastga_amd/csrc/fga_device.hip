@@ -31,10 +31,37 @@ extern "C" int fga_dev_open(int device, fga_dev **out)
   return 0;
 }
 
+void *fga_dev_alloc_cached(fga_dev *dev, size_t bytes)
+{ if (dev->cache_ptr != NULL && dev->cache_bytes >= bytes && dev->cache_bytes <= 2*bytes + (64u<<20))
+    { void *p = dev->cache_ptr;
+      dev->cache_ptr = NULL;
+      return p;
+    }
+  if (dev->cache_ptr != NULL)
+    { hipFree(dev->cache_ptr);
+      dev->cache_ptr = NULL;
+    }
+  void *p = NULL;
+  if (hipMalloc(&p,bytes) != hipSuccess)
+    return NULL;
+  return p;
+}
+
+void fga_dev_free_cached(fga_dev *dev, void *ptr, size_t bytes)
+{ if (ptr == NULL) return;
+  if (dev->cache_ptr == NULL)
+    { dev->cache_ptr = ptr;
+      dev->cache_bytes = bytes;
+    }
+  else
+    hipFree(ptr);
+}
+
 extern "C" void fga_dev_close(fga_dev *d)
 { if (d == NULL) return;
   hipSetDevice(d->device);
   hipStreamSynchronize(d->stream);
+  if (d->cache_ptr != NULL) hipFree(d->cache_ptr);
   hipEventDestroy(d->ev0);
   hipEventDestroy(d->ev1);
   hipStreamDestroy(d->stream);
@@ -104,7 +131,7 @@ extern "C" int fga_seeds_download(const fga_dseeds *S, fga_seed *host, int64_t m
 extern "C" void fga_seeds_free(fga_dseeds *S)
 { if (S == NULL) return;
   hipSetDevice(S->dev->device);
-  hipFree(S->seeds);
+  fga_dev_free_cached(S->dev,S->seeds,S->alloc_bytes);
   hipFree(S->dcount);
   free(S);
 }

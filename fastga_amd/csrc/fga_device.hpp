@@ -23,6 +23,9 @@ struct fga_dev
     hipEvent_t   ev0, ev1;
     int          ncu;
     float        last_ms[8];     // per-stage kernel time of the most recent call (HIP events)
+    // one-slot cache of the big seed buffer: hipMalloc/hipFree of GBs per call costs ~100 ms
+    void        *cache_ptr;
+    size_t       cache_bytes;
   };
 
 // device-resident genome index: the on-disk bytes, unchanged
@@ -38,10 +41,14 @@ struct fga_dgix
 //   apos, bpos : in-contig positions as stored in the index payloads
 //   actg       : A contig (length-sorted index) << 8 | plen
 //   bctg       : B contig | (B entry's own sign bit) << 30 | (C-stream flag) << 31
+void *fga_dev_alloc_cached(fga_dev *dev, size_t bytes);     // returns NULL on failure
+void  fga_dev_free_cached(fga_dev *dev, void *ptr, size_t bytes);
+
 struct fga_dseeds
   { fga_dev  *dev;
     fga_seed *seeds;      // device buffer
     int64_t   capacity;
+    size_t    alloc_bytes;
     int64_t   tseed;      // sum of plen over all seeds
     int64_t   count;      // seeds produced (may exceed capacity -> overflow, buffer holds `capacity`)
     int64_t  *dcount;     // device counter

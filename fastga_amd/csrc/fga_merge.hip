@@ -36,7 +36,7 @@
 #define EPT             (TILE_COST/NT)       // T1 entries per thread (upper bound)
 #define PCAP            (TILE_COST/2 + 2)    // max prefixes of an LDS tile
 #define RAWCAP          (TILE_COST*16 + 96)  // bytes of raw entries staged per tile (E <= 16)
-#define STAGE_CAP       1024                 // seeds staged in LDS between flushes
+#define STAGE_CAP       512                  // seeds staged in LDS between flushes
 
 enum { MODE_PAIR = 0, MODE_FLIP = 1, MODE_SELF = 2 };
 
@@ -663,11 +663,12 @@ extern "C" int fga_seed_merge(fga_dev *dev, const fga_dgix *t1, const fga_dgix *
   hipError_t err;
   if ((err = hipMalloc(&tiles,sizeof(merge_tile)*(size_t) (A.ntiles+1))) != hipSuccess ||
       (err = hipMalloc(&counters,2*sizeof(unsigned long long))) != hipSuccess ||
-      (err = hipMalloc(&S->seeds,sizeof(fga_seed)*(size_t) capacity)) != hipSuccess)
+      (S->seeds = (fga_seed *) fga_dev_alloc_cached(dev,sizeof(fga_seed)*(size_t) capacity)) == NULL)
     { fga_set_error("fga_seed_merge: device allocation failed: %s",hipGetErrorString(err));
-      hipFree(tiles); hipFree(counters); hipFree(S->seeds); free(S);
+      hipFree(tiles); hipFree(counters); free(S);
       return 1;
     }
+  S->alloc_bytes = sizeof(fga_seed)*(size_t) capacity;
   S->dcount = (int64_t *) counters;
   A.tiles = tiles; A.out = S->seeds; A.cap = capacity;
   A.count = counters; A.tseed = counters+1;
@@ -678,7 +679,7 @@ extern "C" int fga_seed_merge(fga_dev *dev, const fga_dgix *t1, const fga_dgix *
     hipLaunchKernelGGL(merge_partition_kernel,dim3(nb),dim3(256),0,dev->stream,A,tiles);
   }
   hipEventRecord(dev->ev1,dev->stream);
-  { int wgs = 3;
+  { int wgs = 4;
     const char *ev = getenv("FGA_MERGE_WGS");
     if (ev != NULL && atoi(ev) > 0) wgs = atoi(ev);
     int grid = dev->ncu * wgs;
