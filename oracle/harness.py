@@ -139,3 +139,105 @@ def sorted_records(buf, width):
     a = a.reshape(-1, width)
     order = np.lexsort(a.T[::-1])
     return a[order]
+
+
+# ------------------------------------------------------------------ Local_Alignment: oracle port and real reference
+
+class _OSpec(C.Structure):
+    _fields_ = [("ave_path", C.c_int), ("tspace", C.c_int), ("reach", C.c_int),
+                ("score", C.c_int16 * 32768), ("table", C.c_int16 * 32768)]
+
+
+class _OPath(C.Structure):
+    _fields_ = [("abpos", C.c_int), ("bbpos", C.c_int), ("aepos", C.c_int), ("bepos", C.c_int),
+                ("diffs", C.c_int), ("tlen", C.c_int)]
+
+
+def oracle_spec(ave_corr=0.7, tspace=100, freq=(0.25, 0.25, 0.25, 0.25), reach=0):
+    L = oracle_lib()
+    sp = _OSpec()
+    f = (C.c_float * 4)(*freq)
+    L.oracle_align_spec(C.c_double(ave_corr), C.c_int(tspace), f, C.c_int(reach), C.byref(sp))
+    return sp
+
+
+def pad_seq(s):
+    """numeric sequence with the sentinel 4 either side; returns (buffer, offset-1 view pointer helper)"""
+    buf = np.empty(len(s) + 2, dtype=np.uint8)
+    buf[0] = 4
+    buf[1:-1] = s
+    buf[-1] = 4
+    return buf
+
+
+def oracle_local_alignment(abuf, bbuf, spec, low, hgh, anti, lbord=-1, hbord=-1, acomp=False, selfie=False):
+    """abuf/bbuf: padded buffers from pad_seq.  Returns (abpos,bbpos,aepos,bepos,diffs,trace uint16 array)."""
+    L = oracle_lib()
+    alen, blen = len(abuf) - 2, len(bbuf) - 2
+    out = _OPath()
+    trace = np.zeros(4 * (alen // spec.tspace + 2) + 8, dtype=np.uint16)
+    st = L.oracle_local_alignment(C.c_void_p(abuf.ctypes.data + 1), C.c_int(alen),
+                                  C.c_void_p(bbuf.ctypes.data + 1), C.c_int(blen),
+                                  C.c_int(int(acomp)), C.c_int(int(selfie)), C.byref(spec),
+                                  C.c_int(low), C.c_int(hgh), C.c_int(anti), C.c_int(lbord), C.c_int(hbord),
+                                  C.byref(out), trace.ctypes.data_as(C.c_void_p))
+    if st != 0:
+        raise RuntimeError(f"oracle_local_alignment status {st}")
+    return (out.abpos, out.bbpos, out.aepos, out.bepos, out.diffs, trace[:out.tlen].copy())
+
+
+class _RPath(C.Structure):
+    _fields_ = [("trace", C.c_void_p), ("tlen", C.c_int), ("diffs", C.c_int),
+                ("abpos", C.c_int), ("bbpos", C.c_int), ("aepos", C.c_int), ("bepos", C.c_int)]
+
+
+class _RAlign(C.Structure):
+    _fields_ = [("path", C.POINTER(_RPath)), ("flags", C.c_uint32), ("aseq", C.c_void_p), ("bseq", C.c_void_p),
+                ("alen", C.c_int), ("blen", C.c_int)]
+
+
+_REFALIGN = None
+
+
+def ref_align_lib():
+    global _REFALIGN
+    if _REFALIGN is None:
+        L = C.CDLL(os.path.join(REF, "libalign_ref.so"))
+        L.New_Work_Data.restype = C.c_void_p
+        L.New_Align_Spec.restype = C.c_void_p
+        L.New_Align_Spec.argtypes = [C.c_double, C.c_int, C.POINTER(C.c_float), C.c_int]
+        L.Local_Alignment.argtypes = [C.POINTER(_RAlign), C.c_void_p, C.c_void_p] + [C.c_int] * 5
+        L.Free_Work_Data.argtypes = [C.c_void_p]
+        L.Free_Align_Spec.argtypes = [C.c_void_p]
+        _REFALIGN = L
+    return _REFALIGN
+
+
+class RefAligner:
+    """the real reference's Local_Alignment (align.c:1423) through ctypes."""
+
+    def __init__(self, ave_corr=0.7, tspace=100, freq=(0.25, 0.25, 0.25, 0.25), reach=0):
+        self.L = ref_align_lib()
+        f = (C.c_float * 4)(*freq)
+        self.spec = self.L.New_Align_Spec(ave_corr, tspace, f, reach)
+        self.work = self.L.New_Work_Data()
+
+    def align(self, abuf, bbuf, low, hgh, anti, lbord=-1, hbord=-1, acomp=False, selfie=False):
+        path = _RPath()
+        al = _RAlign()
+        al.path = C.pointer(path)
+        al.flags = 2 if acomp else 0
+        al.aseq = abuf.ctypes.data + 1
+        al.bseq = (abuf.ctypes.data + 1) if selfie else (bbuf.ctypes.data + 1)
+        al.alen = len(abuf) - 2
+        al.blen = len(bbuf) - 2
+        st = self.L.Local_Alignment(C.byref(al), self.work, self.spec, low, hgh, anti, lbord, hbord)
+        if st != 0:
+            raise RuntimeError("reference Local_Alignment failed")
+        n = path.tlen
+        tr = np.ctypeslib.as_array(C.cast(path.trace, C.POINTER(C.c_uint16)), shape=(max(n, 1),))[:n].copy()
+        return (path.abpos, path.bbpos, path.aepos, path.bepos, path.diffs, tr)
+
+    def close(self):
+        self.L.Free_Work_Data(self.work)
+        self.L.Free_Align_Spec(self.spec)

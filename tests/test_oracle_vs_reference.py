@@ -1,0 +1,148 @@
+"""Pins the CPU oracle (oracle/*.c) against the REAL reference built into oracle/_ref.
+
+The reference has no test suite or golden vectors of its own, so parity is pinned by running it:
+ * seed merge  : FastGA's own `_pair.*` seed temp files (kept alive by the unlink shim) vs oracle_seed_merge
+ * alignment   : reference Local_Alignment (libalign_ref.so through ctypes) vs oracle_local_alignment, call by call
+These tests need /root/reference-built binaries and are skipped where oracle/_ref did not travel.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import harness as H
+
+needs_ref = pytest.mark.skipif(not H.have_reference(), reason="oracle/_ref (real reference build) not present")
+
+
+@needs_ref
+def test_our_gix_is_byte_identical_to_reference_gixmake(toy_pair, tmp_path):
+    """fga_gix_build / fga_fasta_to_gdb produce the reference's bytes (.bps, .ktab.*, .gix)."""
+    d, ra, rb = toy_pair
+    import shutil
+    rd = str(tmp_path)
+    shutil.copy(ra + ".fa", os.path.join(rd, "A.fa"))
+    root = H.ref_build_index(os.path.join(rd, "A.fa"), rd, threads=8)
+    assert open(os.path.join(rd, ".A.bps"), "rb").read() == open(os.path.join(d, ".A.bps"), "rb").read()
+    from fastga_amd.gixio import Gix
+    ours, ref = Gix(ra + ".gix"), Gix(root + ".gix")
+    assert ours.nents == ref.nents and ours.ebytes == ref.ebytes
+    assert np.array_equal(ours.index, ref.index)
+    assert np.array_equal(ours.perm, ref.perm)
+    # duplicate k-mers may be ordered differently by the reference's unstable sort (which then also decides
+    # which copy carries the group's lcp byte): compare (k-mer, mask, payload) and (k-mer, lcp) as multisets
+    a = ours.entries()
+    b = ref.entries()
+    for cols in (list(range(8)) + list(range(9, a.shape[1])), list(range(9))):
+        x, y = a[:, cols], b[:, cols]
+        assert np.array_equal(x[np.lexsort(x.T[::-1])], y[np.lexsort(y.T[::-1])])
+    # k-mers are in the same order
+    assert np.array_equal(a[:, :7], b[:, :7])
+
+
+@needs_ref
+@pytest.mark.parametrize("flags,flip", [((), False), (("-S",), True)])
+def test_seed_merge_oracle_matches_reference_seed_files(toy_pair, tmp_path, flags, flip):
+    d, ra, rb = toy_pair
+    from fastga_amd.gixio import Gix
+    r, seeds = H.ref_fastga(ra, rb, str(tmp_path), os.path.join(str(tmp_path), "out"), threads=4,
+                            flags=flags, capture_seeds=True)
+    A, B = Gix(ra + ".gix"), Gix(rb + ".gix")
+    w = 1 + A.pbyte + B.pbyte
+    n, c, nh, ts = H.oracle_seed_merge(A.table, A.index, A.pbyte, B.table, B.index, B.pbyte)
+    if flip:
+        n2, c2, nh2, ts2 = H.oracle_seed_merge(B.table, B.index, B.pbyte, A.table, A.index, A.pbyte, flip=True)
+        n, c, nh = n + n2, c + c2, nh + nh2
+    assert len(seeds[0]) + len(seeds[1]) == nh * w
+    assert np.array_equal(H.sorted_records(seeds[0], w), H.sorted_records(n, w))
+    assert np.array_equal(H.sorted_records(seeds[1], w), H.sorted_records(c, w))
+    tot = [ln for ln in r.stderr.splitlines() if "Total seeds" in ln]
+    assert tot and f"Total seeds = {nh}," in tot[0]
+
+
+@needs_ref
+def test_self_seed_merge_oracle_matches_reference(toy_pair, tmp_path):
+    d, ra, rb = toy_pair
+    from fastga_amd.gixio import Gix
+    r, seeds = H.ref_fastga(ra, None, str(tmp_path), os.path.join(str(tmp_path), "out"), threads=4,
+                            capture_seeds=True)
+    A = Gix(ra + ".gix")
+    w = 1 + 2 * A.pbyte
+    n, c, nh, ts = H.oracle_self_seed_merge(A.table, A.index, A.pbyte)
+    assert np.array_equal(H.sorted_records(seeds[0], w), H.sorted_records(n, w))
+    assert np.array_equal(H.sorted_records(seeds[1], w), H.sorted_records(c, w))
+
+
+def _random_case(rng):
+    from fastga_amd import synth
+    n = int(rng.integers(300, 6000))
+    A = rng.integers(0, 4, n, dtype=np.uint8)
+    div = float(rng.choice([0.0, 0.01, 0.03, 0.08, 0.15, 0.3]))
+    i0 = int(rng.integers(0, n // 3))
+    i1 = int(rng.integers(2 * n // 3, n))
+    acomp = bool(rng.random() < 0.4)
+    Ause = synth.revcomp(A) if acomp else A
+    pre = rng.integers(0, 4, int(rng.integers(0, 300)), dtype=np.uint8)
+    post = rng.integers(0, 4, int(rng.integers(0, 300)), dtype=np.uint8)
+    if rng.random() < 0.3:
+        pre = pre[:0]
+    if rng.random() < 0.3:
+        post = post[:0]
+    B = np.concatenate([pre, synth.mutate(rng, Ause[i0:i1], div), post])
+    a = int(rng.integers(i0, i1))
+    b = min(len(B) - 1, len(pre) + (a - i0))
+    if rng.random() < 0.1:
+        b = int(rng.integers(0, len(B)))          # off-diagonal probe: mostly "nothing found" paths
+    w = int(rng.integers(0, 120))
+    low = (a - b) - int(rng.integers(0, w + 1))
+    lb = hb = -1
+    if rng.random() < 0.2:
+        lb, hb = int(rng.integers(0, 50)), int(rng.integers(0, 50))
+    return Ause, B, acomp, low, low + w, a + b, lb, hb
+
+
+@needs_ref
+def test_local_alignment_oracle_matches_reference_call_by_call():
+    rng = np.random.default_rng(20260926)
+    spec = H.oracle_spec()
+    ref = H.RefAligner()
+    for _ in range(300):
+        A, B, acomp, low, hgh, anti, lb, hb = _random_case(rng)
+        abuf, bbuf = H.pad_seq(A), H.pad_seq(B)
+        r = ref.align(abuf, bbuf, low, hgh, anti, lb, hb, acomp)
+        o = H.oracle_local_alignment(abuf, bbuf, spec, low, hgh, anti, lb, hb, acomp)
+        assert r[:5] == o[:5]
+        assert np.array_equal(r[5], o[5])
+    ref.close()
+
+
+@needs_ref
+def test_local_alignment_oracle_long_and_self_with_borders():
+    from fastga_amd import synth
+    rng = np.random.default_rng(7)
+    freq = (0.3, 0.2, 0.2, 0.3)
+    spec = H.oracle_spec(freq=freq)
+    ref = H.RefAligner(freq=freq)
+    for trial in range(12):
+        n = int(rng.integers(20000, 120000))
+        A = rng.integers(0, 4, n, dtype=np.uint8)
+        if trial % 3 == 2:                      # self comparison with a planted diverged copy, border = diagonal 0
+            cp = synth.mutate(rng, A[1000:6000], 0.05)
+            A[n // 2:n // 2 + len(cp)] = cp
+            abuf = H.pad_seq(A)
+            a, b = n // 2 + 2500, 3500
+            low, hgh, anti = a - b - 20, a - b + 20, a + b
+            r = ref.align(abuf, abuf, low, hgh, anti, low - 1, -1, selfie=True)
+            o = H.oracle_local_alignment(abuf, abuf, spec, low, hgh, anti, low - 1, -1, selfie=True)
+        else:
+            B = synth.mutate(rng, A, float(rng.choice([0.01, 0.05, 0.1, 0.2])))
+            abuf, bbuf = H.pad_seq(A), H.pad_seq(B)
+            a = int(rng.integers(0, n))
+            b = min(len(B) - 1, int(a * len(B) / n))
+            low, hgh, anti = a - b - 30, a - b + 30, a + b
+            r = ref.align(abuf, bbuf, low, hgh, anti)
+            o = H.oracle_local_alignment(abuf, bbuf, spec, low, hgh, anti)
+        assert r[:5] == o[:5]
+        assert np.array_equal(r[5], o[5])
+        assert r[2] - r[0] > 1000
+    ref.close()
