@@ -1,0 +1,361 @@
+/* fga_chain.c -- diagonal-band chain detection over the sorted seed records (host, multi-threaded).
+ *
+ * Replaces the chain scan of align_contigs (reference FastGA.c:3016-3176, 3340-3403) for every
+ * (strand, A contig, B contig) run of the sorted 128-bit keys produced by fga_seed_sort.
+ * Semantics:
+ *   records of one run are grouped by diagonal bucket d = diag>>6.  Each present bucket d forms a *unit*
+ *   together with bucket d+1 when that one is present (aux); a unit whose bucket d was already the d+1 half
+ *   of the previous unit (new = 0) and that has no d+1 partner is skipped.  Inside a unit the two buckets
+ *   are merged by anti-diagonal (ties: bucket d first) and scanned once: a chain continues while
+ *   anti < ahgh + CHAIN_BREAK with ahgh = max(anti + 2*lcp); coverage adds the not-yet-covered part of
+ *   [anti, anti+2*lcp); when a chain ends with cov >= CHAIN_MIN and (mix != 1 || new) it is a *hit*
+ *   (dgmin,dgmax,alow,ahgh), shifted to contig coordinates (FastGA.c:3205-3216).
+ * Units are independent of one another (the `alast` state of the extension loop is per unit), which is what
+ * the GPU extension stage parallelises over; hits of one unit must stay in order.
+ */
+#define _GNU_SOURCE
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <pthread.h>
+
+#include "fga_host.h"
+#include "fastga_amd.h"
+
+#define BUCK_SHIFT  6
+#define BUCK_WIDTH  64
+
+typedef struct { uint64_t lo, hi; } key128;
+
+typedef struct
+  { int wa, wb, wd, wt;
+    int s_anti, s_buck, s_b, s_a, s_strand;     /* bit offsets */
+  } layout;
+
+static inline uint64_t field(const key128 *k, int shift, int width)
+{ uint64_t v;
+  if (shift >= 64)
+    v = k->hi >> (shift-64);
+  else
+    { v = k->lo >> shift;
+      if (shift > 0 && shift+width > 64)
+        v |= k->hi << (64-shift);
+    }
+  if (width < 64)
+    v &= (((uint64_t) 1) << width) - 1;
+  return v;
+}
+
+/* segment id = everything above the bucket field (strand, A contig, B contig) */
+static inline uint64_t segid(const key128 *k, const layout *L)
+{ return field(k,L->s_b,L->wb + L->wa + 1); }
+
+typedef struct
+  { fga_hit  *hits;  int64_t nhit, mhit;
+    fga_unit *units; int64_t nunit, munit;
+  } outvec;
+
+static int push_hit(outvec *o, const fga_hit *h)
+{ if (o->nhit >= o->mhit)
+    { o->mhit = o->mhit*2 + 1024;
+      o->hits = realloc(o->hits,sizeof(fga_hit)*o->mhit);
+      if (o->hits == NULL) return 1;
+    }
+  o->hits[o->nhit++] = *h;
+  return 0;
+}
+
+static int push_unit(outvec *o, const fga_unit *u)
+{ if (o->nunit >= o->munit)
+    { o->munit = o->munit*2 + 256;
+      o->units = realloc(o->units,sizeof(fga_unit)*o->munit);
+      if (o->units == NULL) return 1;
+    }
+  o->units[o->nunit++] = *u;
+  return 0;
+}
+
+typedef struct
+  { const key128 *keys;
+    int64_t       n, c0, c1;
+    layout        L;
+    const fga_chain_params *prm;
+    outvec        out;
+    int           status;
+  } targ;
+
+/* scan one (strand, A contig, B contig) run [beg,end) */
+static int scan_segment(targ *T, int64_t beg, int64_t end)
+{ const key128 *K = T->keys;
+  const layout *L = &T->L;
+  const fga_chain_params *P = T->prm;
+  const int64_t CHAIN_BREAK = P->chain_break, CHAIN_MIN = P->chain_min;
+  const int comp = (int) field(K+beg,L->s_strand,1);
+  const int actg = (int) field(K+beg,L->s_a,L->wa);
+  const int bctg = (int) field(K+beg,L->s_b,L->wb);
+  const int64_t alen = P->alen[actg];
+  const int64_t doffset = alen - (P->amxpos + P->bmxpos);
+  const int64_t aoffset = alen - P->amxpos;
+  int64_t b, m, e, cdiag, ndiag;
+  int     isnew, aux;
+
+#define BUCK(x)  ((int64_t) field(K+(x),L->s_buck,L->wd))
+#define ANTI(x)  ((int64_t) field(K+(x),L->s_anti,L->wt))
+#define DREM(x)  ((int) field(K+(x),6,6))
+#define LCP(x)   ((int) field(K+(x),0,6))
+
+  b = e = beg;
+  cdiag = BUCK(e);
+  while (e < end && BUCK(e) == cdiag)
+    e += 1;
+  isnew = 1;
+
+  while (1)
+    { m = e;
+      aux = 0;
+      ndiag = (e < end) ? BUCK(e) : -1;
+      while (e < end && BUCK(e) == cdiag+1)
+        { e += 1;
+          aux = 1;
+        }
+      ndiag = (e < end) ? BUCK(e) : -1;
+
+      if (isnew || aux)
+        { int64_t s = b, t = m;
+          int64_t ipost = ANTI(s);
+          int64_t apost = aux ? ANTI(t) : INT64_MAX;
+          int64_t ahgh = -CHAIN_BREAK, alow = (apost < ipost) ? apost : ipost, anti;
+          int64_t cov = 0;
+          int     dgmin = 2*BUCK_WIDTH, dgmax = 0, dg, lcp, wch, mix = 0, go = 1;
+          fga_unit U;
+          int64_t  first = T->out.nhit;
+
+          while (go)
+            { if (apost < ipost)
+                { lcp  = LCP(t);
+                  dg   = DREM(t) + BUCK_WIDTH;
+                  anti = apost;
+                  t += 1;
+                  apost = (t >= e) ? INT64_MAX : ANTI(t);
+                  wch = 0x2;
+                }
+              else
+                { anti = ipost;
+                  if (s < m)
+                    { lcp = LCP(s);
+                      dg  = DREM(s);
+                    }
+                  else
+                    lcp = dg = 0;            /* flush step: the values are never used (go becomes 0) */
+                  s += 1;
+                  if (s >= m)
+                    { if (s > m)
+                        go = 0;
+                      else
+                        ipost = INT64_MAX;
+                    }
+                  else
+                    ipost = ANTI(s);
+                  wch = 0x1;
+                }
+              lcp <<= 1;
+
+              if (anti < ahgh + CHAIN_BREAK)
+                { int64_t cps = anti + lcp;
+                  if (cps > ahgh)
+                    { if (anti >= ahgh)
+                        cov += lcp;
+                      else
+                        cov += cps-ahgh;
+                      ahgh = cps;
+                    }
+                  mix |= wch;
+                  if (dg < dgmin)
+                    dgmin = dg;
+                  else if (dg > dgmax)
+                    dgmax = dg;
+                }
+              else
+                { if (cov >= CHAIN_MIN && (mix != 1 || isnew))
+                    { fga_hit H;
+                      int64_t gmin = dgmin + (cdiag << BUCK_SHIFT);
+                      int64_t gmax = dgmax + (cdiag << BUCK_SHIFT);
+                      int64_t lo_ = alow, hi_ = ahgh;
+                      if (comp)
+                        { gmin += doffset; gmax += doffset;
+                          lo_  += aoffset; hi_  += aoffset;
+                        }
+                      else
+                        { gmin -= P->bmxpos; gmax -= P->bmxpos; }
+                      H.dgmin = (int32_t) gmin; H.dgmax = (int32_t) gmax;
+                      H.alow = lo_; H.ahgh = hi_;
+                      H.cov = (int32_t) cov; H.pad = 0;
+                      if (push_hit(&T->out,&H)) return 1;
+                    }
+                  if (go)
+                    { cov  = lcp;
+                      ahgh = anti + lcp;
+                      mix  = wch;
+                      alow = anti;
+                      dgmin = dgmax = dg;
+                    }
+                }
+            }
+          if (T->out.nhit > first)
+            { U.actg = actg; U.bctg = bctg; U.comp = comp; U.nhits = (int32_t) (T->out.nhit - first);
+              U.first_hit = first;
+              U.bucket = cdiag;
+              if (push_unit(&T->out,&U)) return 1;
+            }
+        }
+
+      if (e >= end) break;
+
+      if (aux)
+        { b = m;
+          cdiag += 1;
+          isnew = 0;
+        }
+      else
+        { b = e;
+          cdiag = ndiag;
+          while (e < end && BUCK(e) == cdiag)
+            e += 1;
+          isnew = 1;
+        }
+    }
+  return 0;
+}
+
+static void *chain_thread(void *arg)
+{ targ *T = arg;
+  const key128 *K = T->keys;
+  int64_t i = T->c0;
+  /* first segment start at or after c0 */
+  if (i > 0)
+    { uint64_t prev = segid(K+(i-1),&T->L);
+      while (i < T->n && segid(K+i,&T->L) == prev)
+        i += 1;
+    }
+  while (i < T->c1 && i < T->n)
+    { uint64_t id = segid(K+i,&T->L);
+      int64_t j = i+1;
+      /* gallop to the end of the run */
+      { int64_t step = 1;
+        while (j < T->n && segid(K+j,&T->L) == id)
+          { j += step;
+            step <<= 1;
+          }
+        if (j > T->n) j = T->n;
+        /* now the end is in (j-step/2, j]: binary search */
+        { int64_t lo = (j - (step>>1) > i) ? j - (step>>1) : i+1, hi = j;
+          while (lo < hi)
+            { int64_t md = (lo+hi) >> 1;
+              if (segid(K+md,&T->L) == id) lo = md+1; else hi = md;
+            }
+          j = lo;
+        }
+      }
+      if (scan_segment(T,i,j))
+        { T->status = 1;
+          return NULL;
+        }
+      i = j;
+    }
+  return NULL;
+}
+
+int fga_chain_scan(const void *keys, int64_t n, int wa, int wb, int wd, int wt,
+                   const fga_chain_params *prm, int nthreads, fga_hits **out)
+{ fga_hits *R;
+  targ *T;
+  pthread_t *th;
+  int t;
+  int64_t nh = 0, nu = 0;
+
+  *out = NULL;
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 256) nthreads = 256;
+  if (n < 100000) nthreads = 1;
+  R = calloc(1,sizeof(fga_hits));
+  T = calloc(nthreads,sizeof(targ));
+  th = calloc(nthreads,sizeof(pthread_t));
+  if (R == NULL || T == NULL || th == NULL)
+    { fga_set_error("out of memory");
+      free(R); free(T); free(th);
+      return 1;
+    }
+  for (t = 0; t < nthreads; t++)
+    { T[t].keys = keys; T[t].n = n;
+      T[t].c0 = (n*t)/nthreads; T[t].c1 = (n*(t+1))/nthreads;
+      T[t].L.wa = wa; T[t].L.wb = wb; T[t].L.wd = wd; T[t].L.wt = wt;
+      T[t].L.s_anti = 12; T[t].L.s_buck = 12+wt; T[t].L.s_b = 12+wt+wd; T[t].L.s_a = 12+wt+wd+wb;
+      T[t].L.s_strand = 12+wt+wd+wb+wa;
+      T[t].prm = prm;
+    }
+  for (t = 1; t < nthreads; t++)
+    pthread_create(th+t,NULL,chain_thread,T+t);
+  chain_thread(T);
+  for (t = 1; t < nthreads; t++)
+    pthread_join(th[t],NULL);
+
+  for (t = 0; t < nthreads; t++)
+    { if (T[t].status)
+        { fga_set_error("out of memory in chain scan");
+          for (t = 0; t < nthreads; t++) { free(T[t].out.hits); free(T[t].out.units); }
+          free(R); free(T); free(th);
+          return 1;
+        }
+      nh += T[t].out.nhit;
+      nu += T[t].out.nunit;
+    }
+  R->nhits = nh; R->nunits = nu;
+  R->hits  = malloc(sizeof(fga_hit)*(nh+1));
+  R->units = malloc(sizeof(fga_unit)*(nu+1));
+  nh = nu = 0;
+  for (t = 0; t < nthreads; t++)
+    { int64_t q;
+      memcpy(R->hits+nh,T[t].out.hits,sizeof(fga_hit)*T[t].out.nhit);
+      for (q = 0; q < T[t].out.nunit; q++)
+        { R->units[nu+q] = T[t].out.units[q];
+          R->units[nu+q].first_hit += nh;
+        }
+      nh += T[t].out.nhit;
+      nu += T[t].out.nunit;
+      free(T[t].out.hits); free(T[t].out.units);
+    }
+  free(T); free(th);
+  *out = R;
+  return 0;
+}
+
+int fga_hits_create(const fga_unit *units, int64_t nunits, const fga_hit *hits, int64_t nhits, fga_hits **out)
+{ fga_hits *R = calloc(1,sizeof(fga_hits));
+  *out = NULL;
+  if (R == NULL)
+    { fga_set_error("out of memory");
+      return 1;
+    }
+  R->nhits = nhits; R->nunits = nunits;
+  R->hits  = malloc(sizeof(fga_hit)*(nhits+1));
+  R->units = malloc(sizeof(fga_unit)*(nunits+1));
+  if (R->hits == NULL || R->units == NULL)
+    { free(R->hits); free(R->units); free(R);
+      fga_set_error("out of memory");
+      return 1;
+    }
+  memcpy(R->hits,hits,sizeof(fga_hit)*nhits);
+  memcpy(R->units,units,sizeof(fga_unit)*nunits);
+  *out = R;
+  return 0;
+}
+
+void fga_hits_free(fga_hits *H)
+{ if (H == NULL) return;
+  free(H->hits); free(H->units); free(H);
+}
+
+int64_t         fga_hits_count(const fga_hits *H)   { return H->nhits; }
+int64_t         fga_hits_nunits(const fga_hits *H)  { return H->nunits; }
+const fga_hit  *fga_hits_array(const fga_hits *H)   { return H->hits; }
+const fga_unit *fga_hits_units(const fga_hits *H)   { return H->units; }

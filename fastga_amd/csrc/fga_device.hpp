@@ -5,6 +5,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <vector>
+#include <algorithm>
+#include <utility>
+#include <string.h>
 
 #include "fga_host.h"
 #include "fastga_amd.h"
@@ -52,4 +55,24 @@ struct fga_dseeds
     int64_t   tseed;      // sum of plen over all seeds
     int64_t   count;      // seeds produced (may exceed capacity -> overflow, buffer holds `capacity`)
     int64_t  *dcount;     // device counter
+  };
+
+// sorted 128-bit diagonal records (fga_sort.hip)
+struct fga_dkeys
+  { fga_dev  *dev;
+    uint4    *keys;        // x,y = low 64 bits; z,w = high 64 bits
+    int64_t   count;
+    size_t    alloc_bytes;
+    int       wa, wb, wd, wt;
+    int64_t   amxpos, bmxpos;
+  };
+
+// device-resident genome: the .bps image (padded) and, for genome 1, its per-contig reverse complement
+struct fga_dgenome
+  { fga_dev  *dev;
+    uint8_t  *img, *img_rc;
+    int64_t  *boff, *clen;
+    int      *perm;
+    int       nctg, nperm;
+    int64_t   pad, maxctg;
   };

@@ -1,0 +1,970 @@
+// fga_extend.hip -- O(nd) wave-based local alignment extension on MI355X (gfx950).
+//
+// Replaces Local_Alignment / forward_wave / reverse_wave (reference align.c:1423-1576, 352-874, 878-1418) and
+// the per-hit extension loop of align_contigs (FastGA.c:3227-3341).  One wavefront owns one *unit* (a diagonal
+// bucket pair of one contig pair and strand, fga_chain.c): the hits of a unit must be extended in order because
+// each Local_Alignment start depends on where the previous one ended; different units are independent.
+//
+// Inside a wave step lane = diagonal:
+//   * the three-way furthest-reaching choice reads the previous wave's V from an LDS ring (double buffered),
+//     inherits the winner's 60-column match history T and trace-point list head HA,
+//   * the snake compares 32 bases per step on the 2-bit packed genomes (the .bps image, unchanged, plus a
+//     reverse-complemented image of genome 1 for the complement pass) with xor + ctz/clz,
+//   * M = popcount(T & (2^61-1)) is an invariant of the reference's incremental bookkeeping, so it is not stored,
+//   * the reference's descending-k "new best point" side effects (besta/lasta/trim*) become a wave-wide
+//     exclusive prefix-max: a lane is a record iff its value beats besta and every lane before it in sweep order,
+//   * sequence-end clipping and WAVE_LAG pruning are ballots,
+//   * trace-point pebbles go to a per-wave arena in HBM, slots handed out by a wave-wide scan.
+// The pebble chain is unwound by lane 0 (one pointer chase tip -> root), the trace is written as bytes
+// (Compress_TraceTo8(ovl,0): silent truncation, align.c:3906-3908) and the accept test of FastGA.c:3264-3265 is
+// evaluated in fp64.  No MFMA; latency-bound integer work, reported as such.
+
+#include "fga_device.hpp"
+
+#define RC          512                 // diagonals in the LDS ring
+#define RMASK       (RC-1)
+#define PATH_LEN    60
+#define PATH_TOPB   0x1000000000000000ull
+#define PATH_INT    0x0fffffffffffffffull
+#define WIN61       0x1fffffffffffffffull
+#define TRIM_LEN    15
+#define TRIM_MASK   0x7fff
+#define TRIM_MLAG   250
+#define WAVE_LAG    70
+#define DUB_TRIM    45
+#define BIGI        0x7fffffff
+#define BUCK_ANTI   128
+
+struct ext_seq
+  { const uint32_t *img;      // padded 2-bit image as dwords (16 bases per dword, base i in bits 2*(i&15))
+    int64_t base;             // base index of contig position 0 inside img
+    int     len;
+  };
+
+struct ext_shared             // one per workgroup (= one wavefront)
+  { int      V[2][RC];
+    int      HA[2][RC];
+    uint64_t T[2][RC];
+    int      NA[RC];
+  };
+
+struct ext_state              // wave-uniform alignment state (the reference's Path + trace pointer)
+  { int abpos, bbpos, aepos, bepos, diffs, tlen;
+    int tpos;                 // index of trace[0] inside the per-wave trace scratch
+  };
+
+struct ext_args
+  { // genomes
+    const uint32_t *imgA, *imgAr, *imgB;
+    const int64_t  *boffA, *boffB;       // byte offset of each contig inside the (unpadded) image
+    const int64_t  *clenA, *clenB;
+    const int      *permA, *permB;       // length-sorted -> original contig index
+    int64_t padA, padB;                  // front padding of the images in bytes
+    // work
+    const fga_unit *units; const fga_hit *hits; int nunits;
+    const int      *order;               // units by decreasing estimated work
+    int            *next;                // work-queue head
+    // alignment parameters
+    int   tspace, path_ave, self, aln_min;
+    double aln_rate;
+    const int16_t *table, *score;
+    // scratch (per workgroup)
+    int4     *cells;  int64_t cell_cap;
+    uint16_t *trace;  int64_t trace_cap;     // uint16 per workgroup; trace[0] of a call sits in the middle
+    // output
+    fga_aln  *alns; int64_t aln_cap;
+    uint8_t  *tbytes; int64_t tbytes_cap;
+    unsigned long long *counters;            // [0] alignments, [1] trace bytes, [2] calls, [3] waves, [4] error flag
+  };
+
+// ---------------------------------------------------------------------------------------------------
+// sequence access: 32 bases starting at contig position pos (may lie before 0 / beyond len: padding)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t fetch32(const ext_seq &s, int64_t pos)
+{ int64_t p = s.base + pos;
+  int64_t w = p >> 4;
+  int sh = (int) (p & 15) * 2;
+  uint32_t d0 = s.img[w], d1 = s.img[w+1], d2 = s.img[w+2];
+  uint64_t lo = ((uint64_t) d1 << 32) | d0;
+  uint64_t v = lo >> sh;
+  if (sh)
+    v |= (uint64_t) d2 << (64-sh);
+  return v;
+}
+
+// number of equal bases going forward from (ax,bx), at most lim
+__device__ __forceinline__ int match_fwd(const ext_seq &A, const ext_seq &B, int ax, int bx, int lim)
+{ int L = 0;
+  while (L < lim)
+    { uint64_t x = fetch32(A,(int64_t) ax+L) ^ fetch32(B,(int64_t) bx+L);
+      if (x != 0)
+        { L += (__ffsll((unsigned long long) x) - 1) >> 1;
+          break;
+        }
+      L += 32;
+    }
+  return L < lim ? L : lim;
+}
+
+// number of equal bases going backward: A[ax-1]==B[bx-1], A[ax-2]==B[bx-2], ... at most lim
+__device__ __forceinline__ int match_rev(const ext_seq &A, const ext_seq &B, int ax, int bx, int lim)
+{ int L = 0;
+  while (L < lim)
+    { uint64_t x = fetch32(A,(int64_t) ax-L-32) ^ fetch32(B,(int64_t) bx-L-32);
+      if (x != 0)
+        { L += __clzll((long long) x) >> 1;
+          break;
+        }
+      L += 32;
+    }
+  return L < lim ? L : lim;
+}
+
+__device__ __forceinline__ int base_at(const ext_seq &s, int pos)     // 0..3, or 4 outside [0,len)
+{ if (pos < 0 || pos >= s.len)
+    return 4;
+  int64_t p = s.base + pos;
+  return (s.img[p >> 4] >> ((p & 15)*2)) & 3;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wave-wide helpers (all 64 lanes must call)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wscan_add_excl(int v, int &total)
+{ int lane = threadIdx.x & 63, x = v;
+  #pragma unroll
+  for (int d = 1; d < 64; d <<= 1)
+    { int y = __shfl_up(x,d,64);
+      if (lane >= d) x += y;
+    }
+  total = __shfl(x,63,64);
+  return x - v;
+}
+
+template <int S>
+__device__ __forceinline__ int wscan_best_excl(int v)     // exclusive prefix max (S>0) / min (S<0) in lane order
+{ int lane = threadIdx.x & 63, x = v;
+  #pragma unroll
+  for (int d = 1; d < 64; d <<= 1)
+    { int y = __shfl_up(x,d,64);
+      if (lane >= d) x = (S > 0) ? (x > y ? x : y) : (x < y ? x : y);
+    }
+  int p = __shfl_up(x,1,64);
+  if (lane == 0) p = (S > 0) ? -BIGI : BIGI;
+  return p;
+}
+
+__device__ __forceinline__ int last_lane(uint64_t m)  { return 63 - __clzll((long long) m); }
+__device__ __forceinline__ int first_lane(uint64_t m) { return __ffsll((unsigned long long) m) - 1; }
+
+// ---------------------------------------------------------------------------------------------------
+// one directional wave extension (S = +1 forward_wave, S = -1 reverse_wave)
+// returns 0 ok, 1 pebble arena full, 2 ring too narrow
+// ---------------------------------------------------------------------------------------------------
+template <int S>
+__device__ int ext_wave(const ext_args &G, ext_shared &sh, int4 *cells, uint16_t *trace,
+                        const ext_seq &A, const ext_seq &B, ext_state &P,
+                        int &mind, int maxd, int mida, int minp, int maxp, int aoff,
+                        unsigned long long &nwaves)
+{ const int lane = threadIdx.x & 63;
+  const int ts = G.tspace;
+  const int VNEW = (S > 0) ? -1 : BIGI;
+  int low = mind, hgh = maxd, dif = 0, cur = 0;
+  int more = 1, avail = 0;
+  int aclip = (S > 0) ? BIGI : -BIGI;
+  int bclip = (S > 0) ? -BIGI : BIGI;
+  int besta, bestx, trima, trimx, trimd, trimha, morea, morex, mored, moreha, morem, lasta;
+
+  besta = trima = morea = lasta = mida;
+  bestx = trimx = morex = (mida+hgh)>>1;
+  trimd = mored = 0;
+  trimha = moreha = 0;
+  morem = -1;
+
+  if (hgh-low+8 >= RC)
+    return 2;
+
+  // ---- wave 0 -------------------------------------------------------------------------------
+  { const int span = hgh-low+1;
+    for (int j0 = 0; j0 < span; j0 += 64)
+      { const int j = j0 + lane;
+        const bool act = j < span;
+        const int k = (S > 0) ? hgh-j : low+j;
+        int x = 0, c = 0, cnt = 0, na = 0, mark0 = 0, hitA = 0, hitB = 0;
+        if (act)
+          { x = (mida+k)>>1;
+            if (S > 0)
+              { na = ((x+(ts-aoff))/ts-1)*ts+aoff;
+                mark0 = na;
+                na += ts;
+              }
+            else
+              { na = ((x+(ts-aoff)-1)/ts-1)*ts+aoff;
+                mark0 = x;
+              }
+            int y = x-k, lim, L;
+            if (S > 0)
+              { int ra = A.len-x, rb = B.len-y;
+                lim = ra < rb ? ra : rb;
+                L = match_fwd(A,B,x,y,lim);
+                if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
+                x += L;
+              }
+            else
+              { int ra = x, rb = y;
+                lim = ra < rb ? ra : rb;
+                L = match_rev(A,B,x,y,lim);
+                if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
+                x -= L;
+              }
+            c = (x << 1) - k;
+            if (S > 0) cnt = (x >= na) ? (x-na)/ts+1 : 0;
+            else       cnt = (x <= na) ? (na-x)/ts+1 : 0;
+          }
+        int tot, off = wscan_add_excl(act ? 1+cnt : 0,tot);
+        if ((int64_t) avail + tot > G.cell_cap)
+          return 1;
+        int ha = -1;
+        if (act)
+          { int idx = avail + off;
+            cells[idx] = make_int4(-1,k,0,mark0);
+            ha = idx;
+            for (int q = 0; q < cnt; q++)
+              { idx += 1;
+                cells[idx] = make_int4(ha,k,0,na);
+                ha = idx;
+                na += S*ts;
+              }
+            sh.V[0][k & RMASK] = c;
+            sh.T[0][k & RMASK] = PATH_INT;
+            sh.HA[0][k & RMASK] = ha;
+            sh.NA[k & RMASK] = na;
+          }
+        avail += tot;
+        // strict best in sweep order
+        int pm = wscan_best_excl<S>(act ? c : ((S > 0) ? -BIGI : BIGI));
+        bool rec = act && ((S > 0) ? (c > besta && c > pm) : (c < besta && c < pm));
+        uint64_t rm = __ballot(rec);
+        if (rm)
+          { int l = last_lane(rm);
+            besta = trima = lasta = __shfl(c,l,64);
+            bestx = trimx = __shfl(x,l,64);
+            trimha = __shfl(ha,l,64);
+          }
+        uint64_t am = __ballot(hitA), bm = __ballot(hitB);
+        if (am | bm) more = 0;
+        if (am) aclip = __shfl(k,last_lane(am),64);
+        if (bm && ((S > 0) ? bclip == -BIGI : bclip == BIGI)) bclip = __shfl(k,first_lane(bm),64);
+      }
+  }
+  __syncthreads();
+
+#define CLIP_FROM(kk,withd)                                                           \
+  { uint64_t tt = sh.T[cur][(kk) & RMASK];                                            \
+    int mm = __popcll(tt & WIN61);                                                    \
+    if (morem <= mm)                                                                  \
+      { morem = mm; morea = sh.V[cur][(kk) & RMASK]; morex = (morea+(kk))>>1;         \
+        if (withd) mored = dif;                                                       \
+        moreha = sh.HA[cur][(kk) & RMASK];                                            \
+      }                                                                               \
+  }
+
+#define CLIP_UPDATE(withd)                                                            \
+  if (more == 0)                                                                      \
+    { int cb = (S > 0) ? base_at(B,besta-bestx) : base_at(B,besta-bestx-1);           \
+      int ca = (S > 0) ? base_at(A,bestx) : base_at(A,bestx-1);                       \
+      if (cb != 4 && ca != 4)                                                         \
+        more = 1;                                                                     \
+      if (S > 0)                                                                      \
+        { if (hgh >= aclip) { hgh = aclip-1; CLIP_FROM(aclip,withd) }                 \
+          if (low <= bclip) { low = bclip+1; CLIP_FROM(bclip,withd) }                 \
+          aclip = BIGI; bclip = -BIGI;                                                \
+        }                                                                             \
+      else                                                                            \
+        { if (low <= aclip) { low = aclip+1; CLIP_FROM(aclip,withd) }                 \
+          if (hgh >= bclip) { hgh = bclip-1; CLIP_FROM(bclip,withd) }                 \
+          aclip = -BIGI; bclip = BIGI;                                                \
+        }                                                                             \
+    }
+
+  CLIP_UPDATE(0)
+
+  // ---- successive waves ------------------------------------------------------------------------
+  while (more && ((S > 0) ? lasta >= besta - TRIM_MLAG : lasta <= besta + TRIM_MLAG))
+    { if (hgh-low+8 >= RC)
+        return 2;
+      nwaves += 1;
+      low -= 1;
+      hgh += 1;
+      if (lane == 0)
+        { if (low >= minp)
+            { sh.NA[low & RMASK] = sh.NA[(low+1) & RMASK]; sh.V[cur][low & RMASK] = VNEW; }
+          if (hgh <= maxp)
+            { sh.NA[hgh & RMASK] = sh.NA[(hgh-1) & RMASK]; sh.V[cur][hgh & RMASK] = VNEW; }
+        }
+      if (low < minp) low += 1;
+      if (hgh > maxp) hgh -= 1;
+      dif += 1;
+      if (lane == 0)
+        sh.V[cur][(hgh+1) & RMASK] = sh.V[cur][(low-1) & RMASK] = VNEW;
+      __syncthreads();
+
+      const int span = hgh-low+1;
+      const int nxt = cur^1;
+      uint64_t anyA = 0, anyB = 0;
+      for (int j0 = 0; j0 < span; j0 += 64)
+        { const int j = j0 + lane;
+          const bool act = j < span;
+          const int k = (S > 0) ? hgh-j : low+j;
+          int x = 0, c = 0, ha = -1, hitA = 0, hitB = 0, ncreate = 0, na = 0, cross = 0;
+          uint64_t b = 0;
+          if (act)
+            { int ac = sh.V[cur][k & RMASK];
+              int a1 = sh.V[cur][(k-S) & RMASK];
+              int a2 = sh.V[cur][(k+S) & RMASK];
+              int src;
+              if (S > 0)
+                { if (ac < a1) src = (a1 < a2) ? k+S : k-S;
+                  else         src = (ac < a2) ? k+S : k;
+                }
+              else
+                { if (ac > a1) src = (a1 > a2) ? k+S : k-S;
+                  else         src = (ac > a2) ? k+S : k;
+                }
+              c  = (src == k) ? ac + 2*S : ((src == k-S) ? a1 : a2) + S;
+              b  = sh.T[cur][src & RMASK];
+              ha = sh.HA[cur][src & RMASK];
+              b <<= 1;
+              x = (c+k)>>1;
+              int y = x-k, L;
+              if (S > 0)
+                { int ra = A.len-x, rb = B.len-y;
+                  int lim = ra < rb ? ra : rb;
+                  L = match_fwd(A,B,x,y,lim);
+                  if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
+                  x += L;
+                }
+              else
+                { int ra = x, rb = y;
+                  int lim = ra < rb ? ra : rb;
+                  L = match_rev(A,B,x,y,lim);
+                  if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
+                  x -= L;
+                }
+              if (L > 0)
+                b = (L >= 61) ? ~0ull : ((b << L) | ((1ull << L) - 1));
+              c = (x << 1) - k;
+              na = sh.NA[k & RMASK];
+              if (S > 0) cross = (x >= na) ? (x-na)/ts+1 : 0;
+              else       cross = (x <= na) ? (na-x)/ts+1 : 0;
+              if (cross > 0)
+                { int mk = cells[ha].w;
+                  // crossings strictly beyond the head's mark get a pebble
+                  int skip;
+                  if (S > 0) skip = (mk >= na) ? (mk-na)/ts+1 : 0;
+                  else       skip = (mk <= na) ? (na-mk)/ts+1 : 0;
+                  if (skip > cross) skip = cross;
+                  ncreate = cross - skip;
+                }
+            }
+          int tot = 0, off = 0;
+          uint64_t cm = __ballot(ncreate > 0);
+          if (cm)
+            { off = wscan_add_excl(ncreate,tot);
+              if ((int64_t) avail + tot > G.cell_cap)
+                return 1;
+            }
+          if (act)
+            { if (ncreate > 0)
+                { int idx = avail + off;
+                  int v = na + S*ts*(cross-ncreate);
+                  for (int q = 0; q < ncreate; q++)
+                    { cells[idx] = make_int4(ha,k,dif,v);
+                      ha = idx;
+                      idx += 1;
+                      v += S*ts;
+                    }
+                }
+              if (cross > 0)
+                sh.NA[k & RMASK] = na + S*ts*cross;
+              sh.V[nxt][k & RMASK] = c;
+              sh.T[nxt][k & RMASK] = b;
+              sh.HA[nxt][k & RMASK] = ha;
+            }
+          avail += tot;
+
+          // ordered "new best point" scan (align.c:729-742)
+          int pm = wscan_best_excl<S>(act ? c : ((S > 0) ? -BIGI : BIGI));
+          bool rec = act && ((S > 0) ? (c > besta && c > pm) : (c < besta && c < pm));
+          uint64_t rm = __ballot(rec);
+          if (rm)
+            { int l = last_lane(rm);
+              besta = __shfl(c,l,64);
+              bestx = __shfl(x,l,64);
+              int m = __popcll(b & WIN61);
+              bool good = rec && m >= G.path_ave;
+              uint64_t gm = __ballot(good);
+              if (gm)
+                { lasta = __shfl(c,last_lane(gm),64);
+                  bool trimok = false;
+                  if (good)
+                    { int t1 = G.table[b & TRIM_MASK];
+                      if (t1 >= 0)
+                        trimok = (int) G.table[(b >> TRIM_LEN) & TRIM_MASK] + (int) G.score[b & TRIM_MASK] >= 0;
+                    }
+                  uint64_t tm = __ballot(trimok);
+                  if (tm)
+                    { int l2 = last_lane(tm);
+                      trima = __shfl(c,l2,64);
+                      trimx = __shfl(x,l2,64);
+                      trimd = dif;
+                      trimha = __shfl(ha,l2,64);
+                    }
+                }
+            }
+          uint64_t am = __ballot(hitA), bm = __ballot(hitB);
+          if (am) aclip = __shfl(k,last_lane(am),64);
+          if (bm && !anyB) bclip = __shfl(k,first_lane(bm),64);
+          anyA |= am; anyB |= bm;
+        }
+      if (anyA | anyB) more = 0;
+      cur = nxt;
+      __syncthreads();
+
+      CLIP_UPDATE(1)
+
+      // prune both ends (align.c:782-790)
+      { const int n = besta - S*WAVE_LAG;
+        int nh = low-1, nl = hgh+1;
+        const int sp = hgh-low+1;
+        for (int j0 = 0; j0 < sp; j0 += 64)
+          { int k = low + j0 + lane;
+            bool keep = false;
+            if (k <= hgh)
+              { int v = sh.V[cur][k & RMASK];
+                keep = (S > 0) ? (v >= n) : (v <= n);
+              }
+            uint64_t km = __ballot(keep);
+            if (km)
+              { int f = low + j0 + first_lane(km), l = low + j0 + last_lane(km);
+                if (f < nl) nl = f;
+                if (l > nh) nh = l;
+              }
+          }
+        if (nh < nl)          // nothing survives: the reference leaves hgh < low
+          hgh = low-1;
+        else
+          { hgh = nh; low = nl; }
+      }
+    }
+
+  // ---- unwind the pebble chain (lane 0), tip -> root, then write the trace pairs -------------------
+  { int trimy;
+    if (morem >= 0 && 0 /* reach is always 0 in FastGA (FastGA.c:3757) */)
+      { trimx = morex; trimy = morea - morex; trimd = mored; trimha = moreha; }
+    else
+      trimy = trima - trimx;
+
+    int rootk = 0;
+    if (lane == 0)
+      { // walk tip -> root; pairs come out last-to-first
+        if (S > 0)
+          { // single walk tip -> root; pairs are stored downwards from the top of the scratch so no count
+            // pass is needed (the reverse wave prepends below P.tpos afterwards)
+            int pos = (int) G.trace_cap - 8;
+            const int tend = pos;
+            int4 cur4 = cells[trimha];
+            int lastb, lastd, lastk;
+            if (cur4.x >= 0)
+              { lastb = cur4.w - cur4.y; lastd = cur4.z; lastk = cur4.y; }
+            while (cur4.x >= 0)
+              { int4 prv = cells[cur4.x];
+                int bcur = cur4.w - cur4.y;
+                int bprv = (prv.x >= 0) ? prv.w - prv.y : ((mida - prv.y) >> 1);
+                int dprv = (prv.x >= 0) ? prv.z : 0;
+                pos -= 2;
+                trace[pos]   = (uint16_t) (cur4.z - dprv);
+                trace[pos+1] = (uint16_t) (bcur - bprv);
+                cur4 = prv;
+              }
+            rootk = cur4.y;
+            if (pos == tend)
+              { lastb = (mida - rootk) >> 1; lastd = 0; lastk = rootk; }
+            int atlen = tend - pos;
+            uint16_t *at = trace + pos;
+            if (lastb + lastk != trimx)
+              { at[atlen++] = (uint16_t) (trimd - lastd);
+                at[atlen++] = (uint16_t) (trimy - lastb);
+              }
+            else if (lastb != trimy)
+              { at[atlen-1] = (uint16_t) (at[atlen-1] + (trimy - lastb));
+                at[atlen-2] = (uint16_t) (at[atlen-2] + (trimd - lastd));
+              }
+            P.tlen = atlen;
+            P.tpos = pos;
+          }
+        else
+          { // reverse wave: the list runs tip (towards the alignment start) -> root (at the mid point);
+            // the reference reverses it and walks root -> tip, prepending pairs.
+            // pass 1 reverses the pointers in place exactly like the reference (align.c:1342-1348)
+            int a = -1, h = trimha, bq;
+            while (h >= 0)
+              { bq = cells[h].x;
+                cells[h].x = a;
+                a = h;
+                h = bq;
+              }
+            h = a;
+            uint16_t *at = trace + P.tpos;
+            int atlen = 0;
+            int4 c4 = cells[h];
+            int k = c4.y;
+            int b = c4.w - k, e = 0, d = 0, aa = 0;
+            if ((b+k) % ts != aoff)
+              { h = c4.x;
+                if (h < 0)
+                  { aa = trimy; d = trimd; }
+                else
+                  { c4 = cells[h];
+                    k = c4.y; aa = c4.w - k; d = c4.z;
+                  }
+                if (P.tlen == 0)
+                  { at[--atlen] = (uint16_t) (b-aa);
+                    at[--atlen] = (uint16_t) (d-e);
+                  }
+                else
+                  { at[1] = (uint16_t) (at[1] + (b-aa));
+                    at[0] = (uint16_t) (at[0] + (d-e));
+                  }
+                b = aa;
+                e = d;
+              }
+            if (h >= 0)
+              { for (h = c4.x; h >= 0; h = c4.x)
+                  { c4 = cells[h];
+                    k = c4.y;
+                    aa = c4.w - k;
+                    at[--atlen] = (uint16_t) (b-aa);
+                    d = c4.z;
+                    at[--atlen] = (uint16_t) (d-e);
+                    b = aa;
+                    e = d;
+                  }
+                if (b+k != trimx)
+                  { at[--atlen] = (uint16_t) (b-trimy);
+                    at[--atlen] = (uint16_t) (trimd-e);
+                  }
+                else if (b != trimy)
+                  { at[atlen+1] = (uint16_t) (at[atlen+1] + (b-trimy));
+                    at[atlen]   = (uint16_t) (at[atlen]   + (trimd-e));
+                  }
+              }
+            P.tlen = P.tlen - atlen;
+            P.tpos = P.tpos + atlen;
+          }
+      }
+    // broadcast lane 0's results
+    P.tlen = __shfl(P.tlen,0,64);
+    P.tpos = __shfl(P.tpos,0,64);
+    rootk  = __shfl(rootk,0,64);
+    if (S > 0)
+      { P.aepos = trimx; P.bepos = trimy; P.diffs = trimd;
+        mind = rootk;
+      }
+    else
+      { P.abpos = trimx; P.bbpos = trimy; P.diffs = P.diffs + trimd; }
+  }
+  __syncthreads();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Local_Alignment (align.c:1423-1576), wave-uniform
+// ---------------------------------------------------------------------------------------------------
+__device__ int local_alignment(const ext_args &G, ext_shared &sh, int4 *cells, uint16_t *trace, int64_t tmid,
+                               const ext_seq &A, const ext_seq &B, int acomp,
+                               int low, int hgh, int anti, int lbord, int hbord,
+                               ext_state &P, unsigned long long &nwaves)
+{ int minp, maxp, aoff, st;
+  P.tpos = (int) tmid;
+  P.tlen = 0;
+  while (((anti-hgh)>>1) < 0)
+    hgh -= 1;
+  minp = (lbord < 0) ? -BIGI : low-lbord;
+  maxp = (hbord < 0) ?  BIGI : hgh+hbord;
+  aoff = acomp ? A.len % G.tspace : 0;
+
+  if ((st = ext_wave<+1>(G,sh,cells,trace,A,B,P,low,hgh,anti,minp,maxp,aoff,nwaves)) != 0) return st;
+  int fshort = ((P.aepos + P.bepos) - anti < DUB_TRIM);
+  { int l2 = low;
+    if ((st = ext_wave<-1>(G,sh,cells,trace,A,B,P,l2,low,anti,minp,maxp,aoff,nwaves)) != 0) return st;
+  }
+  int rshort = (anti - (P.abpos + P.bbpos) < DUB_TRIM);
+  if (fshort)
+    { if (rshort)
+        { P.aepos = P.abpos = (P.abpos+P.aepos)>>1;
+          P.bepos = P.bbpos = (P.bbpos+P.bepos)>>1;
+          P.tlen = 0;
+        }
+      else
+        { low  = P.abpos - P.bbpos;
+          anti = P.abpos + P.bbpos;
+          P.tlen = 0;
+          if ((st = ext_wave<+1>(G,sh,cells,trace,A,B,P,low,low,anti,minp,maxp,aoff,nwaves)) != 0) return st;
+        }
+    }
+  else if (rshort)
+    { low  = P.aepos - P.bepos;
+      anti = P.aepos + P.bepos;
+      P.tlen = 0;
+      P.diffs = 0;
+      if ((st = ext_wave<-1>(G,sh,cells,trace,A,B,P,low,low,anti,minp,maxp,aoff,nwaves)) != 0) return st;
+    }
+  if (acomp)
+    { int i = P.abpos; P.abpos = A.len - P.aepos; P.aepos = A.len - i;
+      i = P.bbpos;     P.bbpos = B.len - P.bepos; P.bepos = B.len - i;
+      // the trace pairs are reversed when they are copied out (see emit)
+    }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// kernel: persistent wavefronts pull units from a queue (longest estimated first)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64)
+void extend_kernel(ext_args G)
+{ __shared__ ext_shared sh;
+  const int lane = threadIdx.x;
+  int4     *cells = G.cells + (int64_t) blockIdx.x * G.cell_cap;
+  uint16_t *trace = G.trace + (int64_t) blockIdx.x * G.trace_cap;
+  const int64_t tmid = G.trace_cap/2;
+  unsigned long long ncalls = 0, nwaves = 0;
+
+  while (1)
+    { int ui = 0;
+      if (lane == 0)
+        ui = atomicAdd(G.next,1);
+      ui = __shfl(ui,0,64);
+      if (ui >= G.nunits)
+        break;
+      const int u = G.order[ui];
+      const fga_unit U = G.units[u];
+      const int comp = U.comp;
+      const int ctg1 = G.permA[U.actg], ctg2 = G.permB[U.bctg];
+      ext_seq A, B;
+      A.len = (int) G.clenA[ctg1];
+      B.len = (int) G.clenB[ctg2];
+      B.img = G.imgB; B.base = (G.padB + G.boffB[ctg2]) * 4;
+      if (comp)
+        { A.img = G.imgAr; A.base = (G.padA + G.boffA[ctg1]) * 4; }
+      else
+        { A.img = G.imgA;  A.base = (G.padA + G.boffA[ctg1]) * 4; }
+      const int64_t mlen = (int64_t) A.len + B.len;
+      const int self = G.self && ctg1 == ctg2 && !comp;
+
+      int64_t alast = -1;
+      int seq = 0;
+      ext_state P;
+      P.abpos = P.bbpos = P.aepos = P.bepos = P.diffs = P.tlen = 0; P.tpos = (int) tmid;
+      for (int hi = 0; hi < U.nhits; hi++)
+        { const fga_hit H = G.hits[U.first_hit + hi];
+          int dgmin = H.dgmin, dgmax = H.dgmax;
+          int64_t alow = H.alow, ahgh = H.ahgh, amid, eant;
+          if (ahgh <= alast)
+            continue;
+          if (alow < alast)
+            alow = alast;
+          ahgh -= BUCK_ANTI;
+          do
+            { amid = alow + BUCK_ANTI;
+              if (amid > ahgh)
+                { amid = ahgh;
+                  if (amid + dgmin < 0)
+                    { dgmin = (int) -amid;
+                      if (dgmin > dgmax)
+                        break;
+                    }
+                }
+              int st = 0, called = 1;
+              if (self)
+                { if (dgmin > 0)
+                    st = local_alignment(G,sh,cells,trace,tmid,A,B,comp,dgmin,dgmax,(int) amid,dgmin-1,-1,P,nwaves);
+                  else if (dgmax < 0)
+                    st = local_alignment(G,sh,cells,trace,tmid,A,B,comp,dgmin,dgmax,(int) amid,-1,-(dgmax+1),P,nwaves);
+                  else
+                    { P.abpos = P.aepos = 0; called = 0; }
+                }
+              else
+                st = local_alignment(G,sh,cells,trace,tmid,A,B,comp,dgmin,dgmax,(int) amid,-1,-1,P,nwaves);
+              ncalls += called;
+              if (st != 0)
+                { if (lane == 0)
+                    atomicMax(G.counters+4,(unsigned long long) st);
+                  goto unit_done;
+                }
+              const int rlen = P.aepos - P.abpos;
+              if (rlen >= G.aln_min && G.aln_rate*rlen >= (double) P.diffs)
+                { // emit: Overlap record + trace bytes (reversed pair order for the complement pass)
+                  unsigned long long ai = 0, to = 0;
+                  if (lane == 0)
+                    { ai = atomicAdd(G.counters+0,1ull);
+                      to = atomicAdd(G.counters+1,(unsigned long long) P.tlen);
+                    }
+                  ai = __shfl(ai,0,64);
+                  to = __shfl(to,0,64);
+                  if ((int64_t) ai < G.aln_cap && (int64_t) (to + P.tlen) <= G.tbytes_cap)
+                    { if (lane == 0)
+                        { fga_aln R;
+                          R.tlen = P.tlen; R.diffs = P.diffs;
+                          R.abpos = P.abpos; R.bbpos = P.bbpos; R.aepos = P.aepos; R.bepos = P.bepos;
+                          R.flags = comp ? 1u : 0u;
+                          R.aread = ctg1; R.bread = ctg2;
+                          R.unit = u; R.seq = seq;
+                          R.toff = (int64_t) to;
+                          G.alns[ai] = R;
+                        }
+                      const uint16_t *src = trace + P.tpos;
+                      const int np = P.tlen >> 1;
+                      for (int q = lane; q < np; q += 64)
+                        { int sp = comp ? (np-1-q) : q;
+                          G.tbytes[to + 2*q]   = (uint8_t) src[2*sp];
+                          G.tbytes[to + 2*q+1] = (uint8_t) src[2*sp+1];
+                        }
+                    }
+                  seq += 1;
+                }
+              if (comp)
+                eant = mlen - ((int64_t) P.abpos + P.bbpos);
+              else
+                eant = (int64_t) P.aepos + P.bepos;
+              if (eant <= alow)
+                alow = amid;
+              else
+                alow = eant;
+            }
+          while (alow < ahgh);
+          alast = alow;
+        }
+    unit_done: ;
+    }
+  if (lane == 0)
+    { atomicAdd(G.counters+2,ncalls);
+      atomicAdd(G.counters+3,nwaves);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// reverse-complement image of a packed genome (Complement_Seq of every contig, align.c:4082-4097)
+// ---------------------------------------------------------------------------------------------------
+__global__ void revcomp_kernel(const uint8_t *fwd, uint8_t *rc, const int64_t *boff, const int64_t *clen,
+                               int nctg, int64_t pad)
+{ const int c = blockIdx.y;
+  if (c >= nctg) return;
+  const int64_t len = clen[c], nb = (len+3) >> 2;
+  const uint8_t *src = fwd + pad + boff[c];
+  uint8_t *dst = rc + pad + boff[c];
+  for (int64_t ob = (int64_t) blockIdx.x*blockDim.x + threadIdx.x; ob < nb; ob += (int64_t) gridDim.x*blockDim.x)
+    { uint8_t v = 0;
+      for (int q = 0; q < 4; q++)
+        { int64_t x = ob*4 + q;             // position in the complemented contig
+          if (x < len)
+            { int64_t y = len-1-x;
+              int bse = (src[y >> 2] >> (2*(y & 3))) & 3;
+              v |= (uint8_t) ((3-bse) << (2*q));
+            }
+        }
+      dst[ob] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+#define IMG_PAD 64      // bytes of zero padding before and after a genome image
+
+extern "C" int fga_dgenome_upload(fga_dev *dev, const fga_gdb *G, const int *perm, int nperm, int want_revcomp,
+                                  fga_dgenome **out)
+{ *out = NULL;
+  FGA_HIP(hipSetDevice(dev->device));
+  fga_dgenome *D = (fga_dgenome *) calloc(1,sizeof(fga_dgenome));
+  if (D == NULL)
+    { fga_set_error("out of memory");
+      return 1;
+    }
+  D->dev = dev;
+  D->nctg = G->ncontig;
+  D->nperm = nperm;
+  D->pad = IMG_PAD;
+  D->maxctg = G->maxctg;
+  const size_t bytes = (size_t) G->bpslen + 2*IMG_PAD + 16;
+  std::vector<int64_t> boff(G->ncontig), clen(G->ncontig);
+  for (int c = 0; c < G->ncontig; c++)
+    { boff[c] = G->contigs[c].boff; clen[c] = G->contigs[c].clen; }
+  hipError_t e;
+  if ((e = hipMalloc(&D->img,bytes)) != hipSuccess ||
+      (e = hipMalloc(&D->boff,sizeof(int64_t)*G->ncontig)) != hipSuccess ||
+      (e = hipMalloc(&D->clen,sizeof(int64_t)*G->ncontig)) != hipSuccess ||
+      (e = hipMalloc(&D->perm,sizeof(int)*(nperm > 0 ? nperm : 1))) != hipSuccess ||
+      (want_revcomp && (e = hipMalloc(&D->img_rc,bytes)) != hipSuccess))
+    { fga_set_error("fga_dgenome_upload: device allocation failed: %s",hipGetErrorString(e));
+      hipFree(D->img); hipFree(D->boff); hipFree(D->clen); hipFree(D->perm); hipFree(D->img_rc); free(D);
+      return 1;
+    }
+  hipMemset(D->img,0,bytes);
+  hipMemcpy(D->img + IMG_PAD,G->bps,G->bpslen,hipMemcpyHostToDevice);
+  hipMemcpy(D->boff,boff.data(),sizeof(int64_t)*G->ncontig,hipMemcpyHostToDevice);
+  hipMemcpy(D->clen,clen.data(),sizeof(int64_t)*G->ncontig,hipMemcpyHostToDevice);
+  if (nperm > 0)
+    hipMemcpy(D->perm,perm,sizeof(int)*nperm,hipMemcpyHostToDevice);
+  if (want_revcomp)
+    { hipMemset(D->img_rc,0,bytes);
+      dim3 grid(256,G->ncontig);
+      hipLaunchKernelGGL(revcomp_kernel,grid,dim3(256),0,dev->stream,D->img,D->img_rc,D->boff,D->clen,
+                         G->ncontig,(int64_t) IMG_PAD);
+    }
+  e = hipStreamSynchronize(dev->stream);
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e != hipSuccess)
+    { fga_set_error("fga_dgenome_upload: %s",hipGetErrorString(e));
+      hipFree(D->img); hipFree(D->boff); hipFree(D->clen); hipFree(D->perm); hipFree(D->img_rc); free(D);
+      return 1;
+    }
+  *out = D;
+  return 0;
+}
+
+extern "C" void fga_dgenome_free(fga_dgenome *D)
+{ if (D == NULL) return;
+  hipSetDevice(D->dev->device);
+  hipFree(D->img); hipFree(D->img_rc); hipFree(D->boff); hipFree(D->clen); hipFree(D->perm);
+  free(D);
+}
+
+extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome *GB, const fga_hits *H,
+                          const fga_extend_params *prm, fga_alns **out)
+{ *out = NULL;
+  FGA_HIP(hipSetDevice(dev->device));
+  fga_alns *R = (fga_alns *) calloc(1,sizeof(fga_alns));
+  if (R == NULL)
+    { fga_set_error("out of memory");
+      return 1;
+    }
+  dev->last_ms[FGA_STAGE_EXTEND] = 0.f;
+  if (H->nunits == 0)
+    { *out = R;
+      return 0;
+    }
+  if (GA->img_rc == NULL)
+    { fga_set_error("fga_extend: genome 1 was uploaded without its reverse-complement image");
+      free(R);
+      return 1;
+    }
+
+  // units by decreasing estimated work (sum of hit box lengths): longest first
+  std::vector<int> order(H->nunits);
+  { std::vector<std::pair<int64_t,int>> w(H->nunits);
+    for (int64_t u = 0; u < H->nunits; u++)
+      { int64_t s = 0;
+        for (int q = 0; q < H->units[u].nhits; q++)
+          { const fga_hit &h = H->hits[H->units[u].first_hit + q];
+            s += (h.ahgh - h.alow) + 1000;
+          }
+        w[u] = std::make_pair(-s,(int) u);
+      }
+    std::sort(w.begin(),w.end());
+    for (int64_t u = 0; u < H->nunits; u++) order[u] = w[u].second;
+  }
+
+  int nwg = dev->ncu * 8;
+  { const char *ev = getenv("FGA_EXTEND_WGS");
+    if (ev != NULL && atoi(ev) > 0) nwg = atoi(ev);
+  }
+  if (nwg > H->nunits) nwg = (int) H->nunits;
+  const int64_t maxa = GA->maxctg > GB->maxctg ? GA->maxctg : GB->maxctg;
+  int64_t cell_cap  = prm->cell_cap  > 0 ? prm->cell_cap  : 48*(maxa/prm->tspace + 64) + 4096;
+  int64_t trace_cap = 8*(maxa/prm->tspace + 8) + 64;
+  int64_t aln_cap   = prm->aln_cap   > 0 ? prm->aln_cap   : 4*H->nhits + 1024;
+  int64_t tb_cap    = prm->trace_cap > 0 ? prm->trace_cap : aln_cap * (2*(maxa/prm->tspace) / 8 + 64);
+
+  ext_args A;
+  memset(&A,0,sizeof(A));
+  A.imgA = (const uint32_t *) GA->img; A.imgAr = (const uint32_t *) GA->img_rc; A.imgB = (const uint32_t *) GB->img;
+  A.boffA = GA->boff; A.boffB = GB->boff; A.clenA = GA->clen; A.clenB = GB->clen;
+  A.permA = GA->perm; A.permB = GB->perm; A.padA = GA->pad; A.padB = GB->pad;
+  A.nunits = (int) H->nunits;
+  A.tspace = prm->tspace; A.path_ave = prm->path_ave; A.self = prm->self;
+  A.aln_min = prm->aln_min; A.aln_rate = prm->aln_rate;
+  A.cell_cap = cell_cap; A.trace_cap = trace_cap; A.aln_cap = aln_cap; A.tbytes_cap = tb_cap;
+
+  fga_unit *d_units = NULL; fga_hit *d_hits = NULL; int *d_order = NULL, *d_next = NULL;
+  int16_t *d_tab = NULL;
+  unsigned long long *d_cnt = NULL;
+  hipError_t e;
+  if ((e = hipMalloc(&d_units,sizeof(fga_unit)*H->nunits)) != hipSuccess ||
+      (e = hipMalloc(&d_hits,sizeof(fga_hit)*(H->nhits+1))) != hipSuccess ||
+      (e = hipMalloc(&d_order,sizeof(int)*H->nunits)) != hipSuccess ||
+      (e = hipMalloc(&d_next,sizeof(int))) != hipSuccess ||
+      (e = hipMalloc(&d_tab,sizeof(int16_t)*2*32768)) != hipSuccess ||
+      (e = hipMalloc(&d_cnt,sizeof(unsigned long long)*8)) != hipSuccess ||
+      (e = hipMalloc(&A.cells,sizeof(int4)*(size_t) cell_cap*nwg)) != hipSuccess ||
+      (e = hipMalloc(&A.trace,sizeof(uint16_t)*(size_t) trace_cap*nwg)) != hipSuccess ||
+      (e = hipMalloc(&A.alns,sizeof(fga_aln)*(size_t) aln_cap)) != hipSuccess ||
+      (e = hipMalloc(&A.tbytes,(size_t) tb_cap)) != hipSuccess)
+    { fga_set_error("fga_extend: device allocation failed: %s",hipGetErrorString(e));
+      goto fail;
+    }
+  hipMemcpy(d_units,H->units,sizeof(fga_unit)*H->nunits,hipMemcpyHostToDevice);
+  hipMemcpy(d_hits,H->hits,sizeof(fga_hit)*H->nhits,hipMemcpyHostToDevice);
+  hipMemcpy(d_order,order.data(),sizeof(int)*H->nunits,hipMemcpyHostToDevice);
+  hipMemcpy(d_tab,prm->table,sizeof(int16_t)*32768,hipMemcpyHostToDevice);
+  hipMemcpy(d_tab+32768,prm->score,sizeof(int16_t)*32768,hipMemcpyHostToDevice);
+  hipMemset(d_next,0,sizeof(int));
+  hipMemset(d_cnt,0,sizeof(unsigned long long)*8);
+  A.units = d_units; A.hits = d_hits; A.order = d_order; A.next = d_next;
+  A.table = d_tab; A.score = d_tab+32768; A.counters = d_cnt;
+
+  hipEventRecord(dev->ev0,dev->stream);
+  hipLaunchKernelGGL(extend_kernel,dim3(nwg),dim3(64),0,dev->stream,A);
+  hipEventRecord(dev->ev1,dev->stream);
+  e = hipStreamSynchronize(dev->stream);
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e != hipSuccess)
+    { fga_set_error("fga_extend: kernel failed: %s",hipGetErrorString(e));
+      goto fail;
+    }
+  hipEventElapsedTime(&dev->last_ms[FGA_STAGE_EXTEND],dev->ev0,dev->ev1);
+  { unsigned long long hc[8];
+    hipMemcpy(hc,d_cnt,sizeof(hc),hipMemcpyDeviceToHost);
+    R->naln = (int64_t) hc[0]; R->ntrace = (int64_t) hc[1]; R->ncalls = (int64_t) hc[2]; R->nwaves = (int64_t) hc[3];
+    if (hc[4] != 0)
+      { fga_set_error("fga_extend: %s",hc[4] == 1 ? "trace-point arena exhausted (raise cell_cap)"
+                                                   : "wave wider than the LDS ring (512 diagonals)");
+        goto fail;
+      }
+    if (R->naln > aln_cap || R->ntrace > tb_cap)
+      { fga_set_error("fga_extend: output buffers too small (%lld alignments, %lld trace bytes)",
+                      (long long) R->naln,(long long) R->ntrace);
+        goto fail;
+      }
+    R->alns = (fga_aln *) malloc(sizeof(fga_aln)*(R->naln+1));
+    R->tbytes = (uint8_t *) malloc(R->ntrace+16);
+    if (R->alns == NULL || R->tbytes == NULL)
+      { fga_set_error("out of memory");
+        goto fail;
+      }
+    if (R->naln > 0)
+      hipMemcpy(R->alns,A.alns,sizeof(fga_aln)*R->naln,hipMemcpyDeviceToHost);
+    if (R->ntrace > 0)
+      hipMemcpy(R->tbytes,A.tbytes,R->ntrace,hipMemcpyDeviceToHost);
+  }
+  hipFree(d_units); hipFree(d_hits); hipFree(d_order); hipFree(d_next); hipFree(d_tab); hipFree(d_cnt);
+  hipFree(A.cells); hipFree(A.trace); hipFree(A.alns); hipFree(A.tbytes);
+  *out = R;
+  return 0;
+
+fail:
+  hipFree(d_units); hipFree(d_hits); hipFree(d_order); hipFree(d_next); hipFree(d_tab); hipFree(d_cnt);
+  hipFree(A.cells); hipFree(A.trace); hipFree(A.alns); hipFree(A.tbytes);
+  free(R->alns); free(R->tbytes); free(R);
+  return 1;
+}

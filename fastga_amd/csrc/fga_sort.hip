@@ -1,0 +1,352 @@
+// fga_sort.hip -- seed -> diagonal record transform and device radix sort (gfx950).
+//
+// Replaces reimport_thread (FastGA.c:2641-2747) and rmsd_sort (RSDsort.c:292-377) of the reference.
+//   reference record : {u8 lcp; u8 diag&63; anti[DBYTE]; diag>>6[DBYTE]; jcont[JCONT]}, one panel per A contig,
+//                      sorted ascending reading each record from its LAST byte (RSDsort.c), i.e. by
+//                      (jcont, diag>>6, anti, diag&63, lcp) -- separately for the N and the C stream.
+//   here             : ONE 128-bit key per seed with the same fields packed most-significant first
+//                      [strand | A contig | B contig | diag>>6 | anti | diag&63 | lcp]
+//                      and one global LSD radix sort over the significant bits only.  Ascending key order
+//                      restricted to one (strand, A contig) is exactly the reference's panel order.
+//   N stream: diag = BMXPOS + (i-j), anti = i+j;  C stream: diag = MAXDAG - (i+j), anti = AMXPOS - (i-j)
+//   (FastGA.c:2705-2712).
+//
+// LSD radix sort, 8-bit digits, three kernels per pass (tile histogram, scan, stable scatter).  The scatter ranks
+// keys inside a wavefront with ballot-based digit matching (no per-thread histograms) and keeps per-wave digit
+// counters in LDS; the first pass reads the 16-byte seeds and forms the key on the fly, so the transform
+// costs no extra trip through HBM.  HBM-bound: (2 reads + 1 write) x 16 B x passes.
+
+#include "fga_device.hpp"
+
+#define ST        256            // threads
+#define SITEMS    16             // keys per thread
+#define STILE     (ST*SITEMS)    // keys per tile
+#define SWAVES    (ST/64)
+
+struct key_layout
+  { int wa, wb, wd, wt;          // bit widths of A contig, B contig, diag bucket, anti
+    int64_t amx, bmx;            // AMXPOS, BMXPOS
+  };
+
+struct u128 { uint64_t lo, hi; };
+
+__device__ __forceinline__ u128 make_key(const fga_seed &s, const key_layout &L)
+{ const int64_t i = s.apos, j = s.bpos;
+  const uint32_t comp = s.bctg >> 31;
+  const uint64_t actg = s.actg >> 8, lcp = s.actg & 0xff, bctg = s.bctg & 0x3fffffffu;
+  int64_t diag, anti;
+  if (comp)
+    { diag = (L.amx + L.bmx) - (i + j);
+      anti = L.amx - (i - j);
+    }
+  else
+    { diag = L.bmx + (i - j);
+      anti = i + j;
+    }
+  // pack LSB first: lcp(6) drem(6) anti(wt) bucket(wd) bctg(wb) actg(wa) strand(1)
+  unsigned __int128 k = 0;
+  int sh = 0;
+  k |= (unsigned __int128) (lcp & 63);                     sh += 6;
+  k |= (unsigned __int128) (uint64_t) (diag & 63) << sh;   sh += 6;
+  k |= (unsigned __int128) (uint64_t) anti << sh;          sh += L.wt;
+  k |= (unsigned __int128) (uint64_t) (diag >> 6) << sh;   sh += L.wd;
+  k |= (unsigned __int128) bctg << sh;                     sh += L.wb;
+  k |= (unsigned __int128) actg << sh;                     sh += L.wa;
+  k |= (unsigned __int128) comp << sh;
+  u128 r;
+  r.lo = (uint64_t) k;
+  r.hi = (uint64_t) (k >> 64);
+  return r;
+}
+
+__device__ __forceinline__ uint32_t digit_of(const u128 &k, int shift)
+{ if (shift >= 64)
+    return (uint32_t) (k.hi >> (shift-64)) & 0xff;
+  uint64_t v = k.lo >> shift;
+  if (shift > 56)
+    v |= k.hi << (64-shift);
+  return (uint32_t) v & 0xff;
+}
+
+template <bool FROM_SEEDS>
+__device__ __forceinline__ u128 load_key(const void *in, int64_t i, const key_layout &L)
+{ if (FROM_SEEDS)
+    return make_key(((const fga_seed *) in)[i],L);
+  const uint4 v = ((const uint4 *) in)[i];
+  u128 r;
+  r.lo = ((uint64_t) v.y << 32) | v.x;
+  r.hi = ((uint64_t) v.w << 32) | v.z;
+  return r;
+}
+
+// (1) per-tile digit histogram -> hist[digit*ntiles + tile]
+template <bool FROM_SEEDS>
+__global__ __launch_bounds__(ST)
+void sort_hist_kernel(const void *in, int64_t n, int shift, key_layout L, uint32_t *hist, int ntiles)
+{ __shared__ uint32_t h[256];
+  const int tile = blockIdx.x;
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t) tile * STILE;
+  #pragma unroll 4
+  for (int r = 0; r < SITEMS; r++)
+    { int64_t i = base + r*ST + threadIdx.x;
+      if (i < n)
+        { u128 k = load_key<FROM_SEEDS>(in,i,L);
+          atomicAdd(&h[digit_of(k,shift)],1u);
+        }
+    }
+  __syncthreads();
+  hist[(int64_t) threadIdx.x * ntiles + tile] = h[threadIdx.x];
+}
+
+// (2) exclusive scan of hist (256*ntiles values): chunk-local scan + chunk totals, scan of totals, and the
+//     scatter adds the chunk offset itself.
+#define SCAN_T   1024
+#define SCAN_PER 16
+#define SCAN_CH  (SCAN_T*SCAN_PER)
+
+__global__ __launch_bounds__(SCAN_T)
+void sort_scan_local_kernel(uint32_t *hist, int64_t m, uint32_t *sums)
+{ __shared__ uint32_t wsum[SCAN_T/64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t base = (int64_t) blockIdx.x * SCAN_CH + (int64_t) tid * SCAN_PER;
+  uint32_t v[SCAN_PER], s = 0;
+  #pragma unroll
+  for (int q = 0; q < SCAN_PER; q++)
+    { int64_t i = base + q;
+      v[q] = (i < m) ? hist[i] : 0;
+      s += v[q];
+    }
+  uint32_t inc = s;
+  #pragma unroll
+  for (int d = 1; d < 64; d <<= 1)
+    { uint32_t y = __shfl_up(inc,d,64);
+      if (lane >= d) inc += y;
+    }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t off = 0, tot = 0;
+  #pragma unroll
+  for (int w = 0; w < SCAN_T/64; w++)
+    { uint32_t t = wsum[w];
+      if (w < wave) off += t;
+      tot += t;
+    }
+  uint32_t run = off + inc - s;
+  #pragma unroll
+  for (int q = 0; q < SCAN_PER; q++)
+    { int64_t i = base + q;
+      if (i < m) hist[i] = run;
+      run += v[q];
+    }
+  if (tid == 0)
+    sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(SCAN_T)
+void sort_scan_sums_kernel(uint32_t *sums, int nch)        // exclusive scan, single workgroup
+{ __shared__ uint32_t wsum[SCAN_T/64];
+  __shared__ uint32_t carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nch; base += SCAN_T)
+    { int i = base + tid;
+      uint32_t v = (i < nch) ? sums[i] : 0, inc = v;
+      #pragma unroll
+      for (int d = 1; d < 64; d <<= 1)
+        { uint32_t y = __shfl_up(inc,d,64);
+          if (lane >= d) inc += y;
+        }
+      if (lane == 63) wsum[wave] = inc;
+      __syncthreads();
+      uint32_t off = carry;
+      for (int w = 0; w < wave; w++)
+        off += wsum[w];
+      if (i < nch) sums[i] = off + inc - v;
+      __syncthreads();
+      if (tid == SCAN_T-1)
+        carry = off + inc;
+      __syncthreads();
+    }
+}
+
+// (3) stable scatter
+template <bool FROM_SEEDS>
+__global__ __launch_bounds__(ST)
+void sort_scatter_kernel(const void *in, uint4 *out, int64_t n, int shift, key_layout L,
+                         const uint32_t *hist, const uint32_t *sums, int ntiles)
+{ __shared__ uint32_t wcnt[SWAVES][256];      // per-wave digit counts, then per-wave digit bases
+  const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int x = tid; x < SWAVES*256; x += ST)
+    (&wcnt[0][0])[x] = 0;
+  __syncthreads();
+
+  // item order inside the tile: wave-major, then round, then lane  (coalesced 64-key loads per round)
+  const int64_t wbase = (int64_t) tile * STILE + (int64_t) wave * (64*SITEMS);
+  u128     key[SITEMS];
+  uint16_t rank[SITEMS];
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64-lane));
+  #pragma unroll
+  for (int r = 0; r < SITEMS; r++)
+    { int64_t i = wbase + r*64 + lane;
+      bool ok = i < n;
+      uint32_t d = 256;
+      if (ok)
+        { key[r] = load_key<FROM_SEEDS>(in,i,L);
+          d = digit_of(key[r],shift);
+        }
+      // lanes with the same digit (invalid lanes form their own group and are ignored)
+      uint64_t peers = __ballot(ok);
+      #pragma unroll
+      for (int b = 0; b < 8; b++)
+        { uint64_t m = __ballot((d >> b) & 1);
+          peers &= ((d >> b) & 1) ? m : ~m;
+        }
+      uint32_t before = __popcll(peers & lt);
+      uint32_t basec = 0;
+      if (ok)
+        basec = wcnt[wave][d];
+      rank[r] = (uint16_t) (basec + before);
+      // the last peer publishes the new count (one writer per digit)
+      if (ok && (peers >> lane) >> 1 == 0)
+        wcnt[wave][d] = basec + before + 1;
+    }
+  __syncthreads();
+  // per-wave exclusive bases per digit: thread d handles digit d
+  { const int64_t hi = (int64_t) tid * ntiles + tile;
+    uint32_t run = hist[hi] + sums[hi / SCAN_CH];
+    #pragma unroll
+    for (int w = 0; w < SWAVES; w++)
+      { uint32_t c = wcnt[w][tid];
+        wcnt[w][tid] = run;
+        run += c;
+      }
+  }
+  __syncthreads();
+  #pragma unroll
+  for (int r = 0; r < SITEMS; r++)
+    { int64_t i = wbase + r*64 + lane;
+      if (i < n)
+        { uint32_t d = digit_of(key[r],shift);
+          int64_t pos = (int64_t) wcnt[wave][d] + rank[r];
+          uint4 v;
+          v.x = (uint32_t) key[r].lo; v.y = (uint32_t) (key[r].lo >> 32);
+          v.z = (uint32_t) key[r].hi; v.w = (uint32_t) (key[r].hi >> 32);
+          out[pos] = v;
+        }
+    }
+}
+
+static int bits_for(int64_t maxval)      // bits needed to hold values 0..maxval
+{ int b = 1;
+  while ((maxval >> b) != 0) b++;
+  return b;
+}
+
+extern "C" int fga_seed_sort(fga_dev *dev, const fga_dseeds *S, const fga_sort_params *prm, fga_dkeys **out)
+{ *out = NULL;
+  if (dev == NULL || S == NULL || prm == NULL)
+    { fga_set_error("fga_seed_sort: null argument");
+      return 1;
+    }
+  FGA_HIP(hipSetDevice(dev->device));
+  const int64_t n = S->count < S->capacity ? S->count : S->capacity;
+  key_layout L;
+  L.amx = prm->amxpos; L.bmx = prm->bmxpos;
+  L.wa = bits_for(prm->nctg_a > 0 ? prm->nctg_a-1 : 0);
+  L.wb = bits_for(prm->nctg_b > 0 ? prm->nctg_b-1 : 0);
+  L.wt = bits_for(prm->amxpos + prm->bmxpos);
+  L.wd = bits_for((prm->amxpos + prm->bmxpos) >> 6);
+  const int tbits = 12 + L.wt + L.wd + L.wb + L.wa + 1;
+  if (tbits > 128)
+    { fga_set_error("fga_seed_sort: key of %d bits does not fit 128",tbits);
+      return 1;
+    }
+  fga_dkeys *K = (fga_dkeys *) calloc(1,sizeof(fga_dkeys));
+  if (K == NULL)
+    { fga_set_error("out of memory");
+      return 1;
+    }
+  K->dev = dev; K->count = n;
+  K->wa = L.wa; K->wb = L.wb; K->wd = L.wd; K->wt = L.wt;
+  K->amxpos = prm->amxpos; K->bmxpos = prm->bmxpos;
+  const int npass = (tbits + 7) / 8;
+  const int ntiles = (int) ((n + STILE - 1) / STILE);
+  dev->last_ms[FGA_STAGE_SORT] = 0.f;
+  if (n == 0)
+    { *out = K;
+      return 0;
+    }
+  uint4 *buf[2] = { NULL, NULL };
+  uint32_t *hist = NULL, *sums = NULL;
+  const int64_t hm = (int64_t) 256*ntiles;
+  const int nch = (int) ((hm + SCAN_CH - 1) / SCAN_CH);
+  hipError_t e;
+  K->alloc_bytes = sizeof(uint4)*(size_t) n;
+  if ((e = hipMalloc(&buf[0],K->alloc_bytes)) != hipSuccess ||
+      (e = hipMalloc(&buf[1],K->alloc_bytes)) != hipSuccess ||
+      (e = hipMalloc(&hist,sizeof(uint32_t)*256*(size_t) ntiles)) != hipSuccess ||
+      (e = hipMalloc(&sums,sizeof(uint32_t)*(size_t) (nch+1))) != hipSuccess)
+    { fga_set_error("fga_seed_sort: device allocation failed: %s",hipGetErrorString(e));
+      hipFree(buf[0]); hipFree(buf[1]); hipFree(hist); hipFree(sums); free(K);
+      return 1;
+    }
+  hipEventRecord(dev->ev0,dev->stream);
+  const void *src = S->seeds;
+  int cur = 0;
+  for (int p = 0; p < npass; p++)
+    { const int shift = 8*p;
+      uint4 *dst = buf[cur];
+      if (p == 0)
+        { hipLaunchKernelGGL(sort_hist_kernel<true>,dim3(ntiles),dim3(ST),0,dev->stream,src,n,shift,L,hist,ntiles);
+          hipLaunchKernelGGL(sort_scan_local_kernel,dim3(nch),dim3(SCAN_T),0,dev->stream,hist,hm,sums);
+          hipLaunchKernelGGL(sort_scan_sums_kernel,dim3(1),dim3(SCAN_T),0,dev->stream,sums,nch);
+          hipLaunchKernelGGL(sort_scatter_kernel<true>,dim3(ntiles),dim3(ST),0,dev->stream,src,dst,n,shift,L,hist,sums,ntiles);
+        }
+      else
+        { hipLaunchKernelGGL(sort_hist_kernel<false>,dim3(ntiles),dim3(ST),0,dev->stream,src,n,shift,L,hist,ntiles);
+          hipLaunchKernelGGL(sort_scan_local_kernel,dim3(nch),dim3(SCAN_T),0,dev->stream,hist,hm,sums);
+          hipLaunchKernelGGL(sort_scan_sums_kernel,dim3(1),dim3(SCAN_T),0,dev->stream,sums,nch);
+          hipLaunchKernelGGL(sort_scatter_kernel<false>,dim3(ntiles),dim3(ST),0,dev->stream,src,dst,n,shift,L,hist,sums,ntiles);
+        }
+      src = dst;
+      cur ^= 1;
+    }
+  hipEventRecord(dev->ev1,dev->stream);
+  e = hipStreamSynchronize(dev->stream);
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e != hipSuccess)
+    { fga_set_error("fga_seed_sort: kernel failed: %s",hipGetErrorString(e));
+      hipFree(buf[0]); hipFree(buf[1]); hipFree(hist); hipFree(sums); free(K);
+      return 1;
+    }
+  hipEventElapsedTime(&dev->last_ms[FGA_STAGE_SORT],dev->ev0,dev->ev1);
+  K->keys = (uint4 *) src;
+  hipFree(src == buf[0] ? buf[1] : buf[0]);
+  hipFree(hist);
+  hipFree(sums);
+  *out = K;
+  return 0;
+}
+
+extern "C" int64_t fga_keys_count(const fga_dkeys *K) { return K->count; }
+
+extern "C" int fga_keys_download(const fga_dkeys *K, void *host, int64_t max)
+{ int64_t n = K->count < max ? K->count : max;
+  FGA_HIP(hipSetDevice(K->dev->device));
+  if (n > 0)
+    FGA_HIP(hipMemcpy(host,K->keys,sizeof(uint4)*(size_t) n,hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" void fga_keys_layout(const fga_dkeys *K, int *wa, int *wb, int *wd, int *wt)
+{ *wa = K->wa; *wb = K->wb; *wd = K->wd; *wt = K->wt; }
+
+extern "C" void fga_keys_free(fga_dkeys *K)
+{ if (K == NULL) return;
+  hipSetDevice(K->dev->device);
+  hipFree(K->keys);
+  free(K);
+}

@@ -3,7 +3,9 @@ import ctypes as C
 
 import numpy as np
 
-from .lib import load_library, check, MergeParams, FgaError, STAGE_MERGE, STAGE_MERGE_PARTITION  # noqa: F401
+from .lib import (load_library, check, MergeParams, SortParams, ChainParams, Hits, ExtendParams, Alns,  # noqa: F401
+                  FgaError, STAGE_MERGE,
+                  STAGE_MERGE_PARTITION, STAGE_SORT, STAGE_CHAIN, STAGE_EXTEND)
 
 SEED_DTYPE = np.dtype([("apos", "<u4"), ("bpos", "<u4"), ("actg", "<u4"), ("bctg", "<u4")])
 
@@ -107,3 +109,152 @@ def seeds_to_reference_bytes(seeds, ipost, icont, jpost, jcont):
         col += 1
     comp = (seeds["bctg"] >> 31).astype(bool)
     return out[~comp].tobytes(), out[comp].tobytes()
+
+
+KEY_DTYPE = np.dtype([("lo", "<u8"), ("hi", "<u8")])
+
+
+class Keys:
+    """device-resident sorted diagonal records (128-bit keys)."""
+
+    def __init__(self, dev, h):
+        self.dev = dev
+        self.h = h
+        self.count = dev.L.fga_keys_count(h)
+        w = [C.c_int() for _ in range(4)]
+        dev.L.fga_keys_layout(h, *[C.byref(x) for x in w])
+        self.wa, self.wb, self.wd, self.wt = [x.value for x in w]
+
+    def download(self):
+        out = np.empty(self.count, dtype=KEY_DTYPE)
+        check(self.dev.L.fga_keys_download(self.h, out.ctypes.data_as(C.c_void_p), self.count), "download keys")
+        return out
+
+    def fields(self, keys=None):
+        """dict of the packed fields as int64 arrays (host side decode, for tests)."""
+        k = self.download() if keys is None else keys
+        lo = k["lo"].astype(object)
+        hi = k["hi"].astype(object)
+        big = [(int(h) << 64) | int(l) for l, h in zip(lo, hi)]
+        out = {}
+        sh = 0
+        for name, w in (("lcp", 6), ("drem", 6), ("anti", self.wt), ("bucket", self.wd),
+                        ("bctg", self.wb), ("actg", self.wa), ("strand", 1)):
+            m = (1 << w) - 1
+            out[name] = np.array([(v >> sh) & m for v in big], dtype=np.int64)
+            sh += w
+        return out
+
+    def free(self):
+        if self.h:
+            self.dev.L.fga_keys_free(self.h)
+            self.h = C.c_void_p()
+
+
+def seed_sort(dev, seeds, amxpos, bmxpos, nctg_a, nctg_b):
+    prm = SortParams(amxpos, bmxpos, nctg_a, nctg_b)
+    h = C.c_void_p()
+    check(dev.L.fga_seed_sort(dev.h, seeds.h, C.byref(prm), C.byref(h)), "seed sort")
+    return Keys(dev, h)
+
+
+HIT_DTYPE = np.dtype([("dgmin", "<i4"), ("dgmax", "<i4"), ("alow", "<i8"), ("ahgh", "<i8"),
+                      ("cov", "<i4"), ("pad", "<i4")])
+UNIT_DTYPE = np.dtype([("actg", "<i4"), ("bctg", "<i4"), ("comp", "<i4"), ("nhits", "<i4"),
+                       ("first_hit", "<i8"), ("bucket", "<i8")])
+ALN_DTYPE = np.dtype([("tlen", "<i4"), ("diffs", "<i4"), ("abpos", "<i4"), ("bbpos", "<i4"),
+                      ("aepos", "<i4"), ("bepos", "<i4"), ("flags", "<u4"), ("aread", "<i4"),
+                      ("bread", "<i4"), ("unit", "<i4"), ("seq", "<i4"), ("pad", "<i4"), ("toff", "<i8")])
+
+
+class HitList:
+    """host-side hits + units (fga_hits)."""
+
+    def __init__(self, L, ptr):
+        self.L = L
+        self.ptr = ptr
+        self.nhits = L.fga_hits_count(ptr)
+        self.nunits = L.fga_hits_nunits(ptr)
+
+    @property
+    def hits(self):
+        if self.nhits == 0:
+            return np.zeros(0, dtype=HIT_DTYPE)
+        buf = (C.c_char * (self.nhits * HIT_DTYPE.itemsize)).from_address(self.L.fga_hits_array(self.ptr))
+        return np.frombuffer(buf, dtype=HIT_DTYPE).copy()
+
+    @property
+    def units(self):
+        if self.nunits == 0:
+            return np.zeros(0, dtype=UNIT_DTYPE)
+        buf = (C.c_char * (self.nunits * UNIT_DTYPE.itemsize)).from_address(self.L.fga_hits_units(self.ptr))
+        return np.frombuffer(buf, dtype=UNIT_DTYPE).copy()
+
+    def free(self):
+        if self.ptr:
+            self.L.fga_hits_free(self.ptr)
+            self.ptr = None
+
+
+def chain_scan(keys_host, layout, chain_break, chain_min, amxpos, bmxpos, alen_sorted, nthreads=8):
+    """keys_host: structured (lo,hi) array; layout = (wa,wb,wd,wt); alen_sorted: A contig lengths by sorted index."""
+    L = load_library()
+    al = np.ascontiguousarray(alen_sorted, dtype=np.int64)
+    prm = ChainParams(chain_break, chain_min, amxpos, bmxpos, al.ctypes.data)
+    out = C.POINTER(Hits)()
+    k = np.ascontiguousarray(keys_host)
+    check(L.fga_chain_scan(k.ctypes.data_as(C.c_void_p), len(k), *layout, C.byref(prm), nthreads, C.byref(out)),
+          "chain scan")
+    return HitList(L, out)
+
+
+def hits_from_arrays(units, hits):
+    L = load_library()
+    u = np.ascontiguousarray(units, dtype=UNIT_DTYPE)
+    h = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+    out = C.POINTER(Hits)()
+    check(L.fga_hits_create(u.ctypes.data_as(C.c_void_p), len(u), h.ctypes.data_as(C.c_void_p), len(h),
+                            C.byref(out)), "hits create")
+    return HitList(L, out)
+
+
+def align_spec(ave_corr, tspace, freq):
+    L = load_library()
+    table = np.zeros(32768, dtype=np.int16)
+    score = np.zeros(32768, dtype=np.int16)
+    pa = C.c_int()
+    f = (C.c_float * 4)(*freq)
+    check(L.fga_align_spec(ave_corr, tspace, f, C.byref(pa), table.ctypes.data_as(C.c_void_p),
+                           score.ctypes.data_as(C.c_void_p)), "align spec")
+    return pa.value, table, score
+
+
+class DeviceGenome:
+    def __init__(self, dev, gdb, perm, want_revcomp):
+        self.dev = dev
+        self.h = C.c_void_p()
+        p = np.ascontiguousarray(perm, dtype=np.int32)
+        check(dev.L.fga_dgenome_upload(dev.h, gdb.h, p.ctypes.data_as(C.c_void_p), len(p), int(want_revcomp),
+                                       C.byref(self.h)), "upload genome")
+
+    def free(self):
+        if self.h:
+            self.dev.L.fga_dgenome_free(self.h)
+            self.h = C.c_void_p()
+
+
+def extend(dev, ga, gb, hitlist, path_ave, table, score, tspace=100, self_cmp=False, aln_min=50,
+           aln_rate=0.35, cell_cap=0):
+    prm = ExtendParams(tspace, path_ave, table.ctypes.data, score.ctypes.data, int(self_cmp), aln_min,
+                       aln_rate, cell_cap, 0, 0)
+    out = C.POINTER(Alns)()
+    check(dev.L.fga_extend(dev.h, ga.h, gb.h, hitlist.ptr, C.byref(prm), C.byref(out)), "extend")
+    a = out.contents
+    n, nt = a.naln, a.ntrace
+    alns = np.frombuffer((C.c_char * (n * ALN_DTYPE.itemsize)).from_address(a.alns), dtype=ALN_DTYPE).copy() \
+        if n > 0 else np.zeros(0, dtype=ALN_DTYPE)
+    tb = np.frombuffer((C.c_char * nt).from_address(a.tbytes), dtype=np.uint8).copy() if nt > 0 \
+        else np.zeros(0, dtype=np.uint8)
+    stats = {"calls": a.ncalls, "waves": a.nwaves}
+    dev.L.fga_alns_free(out)
+    return alns, tb, stats

@@ -42,6 +42,30 @@ class MergeParams(C.Structure):
                 ("prefix_begin", C.c_int64), ("prefix_end", C.c_int64)]
 
 
+class ChainParams(C.Structure):
+    _fields_ = [("chain_break", C.c_int64), ("chain_min", C.c_int64), ("amxpos", C.c_int64),
+                ("bmxpos", C.c_int64), ("alen", C.c_void_p)]
+
+
+class Hits(C.Structure):
+    _fields_ = [("nhits", C.c_int64), ("nunits", C.c_int64), ("hits", C.c_void_p), ("units", C.c_void_p)]
+
+
+class ExtendParams(C.Structure):
+    _fields_ = [("tspace", C.c_int), ("path_ave", C.c_int), ("table", C.c_void_p), ("score", C.c_void_p),
+                ("self", C.c_int), ("aln_min", C.c_int), ("aln_rate", C.c_double),
+                ("cell_cap", C.c_int64), ("aln_cap", C.c_int64), ("trace_cap", C.c_int64)]
+
+
+class Alns(C.Structure):
+    _fields_ = [("naln", C.c_int64), ("ntrace", C.c_int64), ("ncalls", C.c_int64), ("nwaves", C.c_int64),
+                ("alns", C.c_void_p), ("tbytes", C.c_void_p)]
+
+
+class SortParams(C.Structure):
+    _fields_ = [("amxpos", C.c_int64), ("bmxpos", C.c_int64), ("nctg_a", C.c_int), ("nctg_b", C.c_int)]
+
+
 STAGE_MERGE_PARTITION, STAGE_MERGE, STAGE_SORT, STAGE_CHAIN, STAGE_EXTEND = 0, 1, 2, 3, 4
 
 
@@ -83,6 +107,23 @@ def _declare(L):
         "fga_seeds_plen_sum": (i64, [vp]),
         "fga_seeds_download": (i32, [vp, vp, i64]),
         "fga_seeds_free": (None, [vp]),
+        "fga_seed_sort": (i32, [vp, vp, P(SortParams), P(vp)]),
+        "fga_keys_count": (i64, [vp]),
+        "fga_keys_layout": (None, [vp, P(i32), P(i32), P(i32), P(i32)]),
+        "fga_keys_download": (i32, [vp, vp, i64]),
+        "fga_keys_free": (None, [vp]),
+        "fga_chain_scan": (i32, [vp, i64, i32, i32, i32, i32, P(ChainParams), i32, P(P(Hits))]),
+        "fga_hits_create": (i32, [vp, i64, vp, i64, P(P(Hits))]),
+        "fga_hits_free": (None, [P(Hits)]),
+        "fga_hits_count": (i64, [P(Hits)]),
+        "fga_hits_nunits": (i64, [P(Hits)]),
+        "fga_hits_array": (vp, [P(Hits)]),
+        "fga_hits_units": (vp, [P(Hits)]),
+        "fga_align_spec": (i32, [C.c_double, i32, P(C.c_float), P(i32), vp, vp]),
+        "fga_dgenome_upload": (i32, [vp, vp, vp, i32, i32, P(vp)]),
+        "fga_dgenome_free": (None, [vp]),
+        "fga_extend": (i32, [vp, vp, vp, P(Hits), P(ExtendParams), P(P(Alns))]),
+        "fga_alns_free": (None, [P(Alns)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

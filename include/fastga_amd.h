@@ -93,6 +93,97 @@ int64_t fga_seeds_plen_sum(const fga_dseeds *seeds);   /* the reference's "ave. 
 int     fga_seeds_download(const fga_dseeds *seeds, fga_seed *host, int64_t max);
 void    fga_seeds_free(fga_dseeds *seeds);
 
+/* Seed -> diagonal record transform + sort: replaces reimport_thread (FastGA.c:2641-2747) and rmsd_sort
+ * (RSDsort.c:292).  Result: 128-bit keys, ascending, fields packed most-significant first
+ * [strand | A contig | B contig | diag>>6 | anti | diag&63 | lcp] with the bit widths of fga_keys_layout. */
+typedef struct fga_dkeys fga_dkeys;
+typedef struct
+  { int64_t amxpos, bmxpos;    /* longest contig of genome 1 / genome 2 (FastGA.c:5020-5041)  */
+    int     nctg_a, nctg_b;    /* contig counts (bounds of the contig fields)                 */
+  } fga_sort_params;
+
+int     fga_seed_sort(fga_dev *dev, const fga_dseeds *seeds, const fga_sort_params *prm, fga_dkeys **out);
+int64_t fga_keys_count(const fga_dkeys *keys);
+void    fga_keys_layout(const fga_dkeys *keys, int *wa, int *wb, int *wd, int *wt);
+int     fga_keys_download(const fga_dkeys *keys, void *host /* 16 B per key: lo64, hi64 */, int64_t max);
+void    fga_keys_free(fga_dkeys *keys);
+
+/* ---- chain detection: replaces the chain scan of align_contigs (FastGA.c:3016-3176, 3340-3403) ------------ */
+typedef struct
+  { int32_t dgmin, dgmax;      /* diagonal range of the chain ("tube"), contig coordinates (FastGA.c:3205-3216) */
+    int64_t alow, ahgh;        /* anti-diagonal range                                                           */
+    int32_t cov, pad;
+  } fga_hit;                   /* 32 bytes */
+
+typedef struct
+  { int32_t actg, bctg;        /* length-sorted contig indices                    */
+    int32_t comp;              /* 1: complement stream                            */
+    int32_t nhits;
+    int64_t first_hit;         /* index of the unit's first hit                   */
+    int64_t bucket;            /* diag>>6 of the unit's first bucket              */
+  } fga_unit;                  /* 32 bytes; a unit = bucket pair (d,d+1) of one contig pair and strand */
+
+typedef struct
+  { int64_t chain_break;       /* -s, doubled (FastGA.c:4547)                     */
+    int64_t chain_min;         /* -c, doubled (FastGA.c:4495)                     */
+    int64_t amxpos, bmxpos;
+    const int64_t *alen;       /* A contig lengths by length-sorted index         */
+  } fga_chain_params;
+
+typedef struct
+  { int64_t   nhits, nunits;
+    fga_hit  *hits;
+    fga_unit *units;
+  } fga_hits;
+
+int  fga_chain_scan(const void *keys /* n x {lo64,hi64} */, int64_t n, int wa, int wb, int wd, int wt,
+                    const fga_chain_params *prm, int nthreads, fga_hits **out);
+int  fga_hits_create(const fga_unit *units, int64_t nunits, const fga_hit *hits, int64_t nhits, fga_hits **out);
+void fga_hits_free(fga_hits *hits);
+int64_t         fga_hits_count(const fga_hits *hits);
+int64_t         fga_hits_nunits(const fga_hits *hits);
+const fga_hit  *fga_hits_array(const fga_hits *hits);
+const fga_unit *fga_hits_units(const fga_hits *hits);
+
+/* ---- wave extension: replaces the per-hit loop of align_contigs (FastGA.c:3227-3341) around Local_Alignment
+ *      (align.h:235-236), New_Align_Spec (align.h:196) and the accept test + Compress_TraceTo8 (FastGA.c:3264-3281) */
+typedef struct fga_dgenome fga_dgenome;    /* device-resident 2-bit genome (+ reverse-complement image) */
+
+typedef struct
+  { int32_t  tlen, diffs, abpos, bbpos, aepos, bepos;   /* Path (align.h:89-95), trace as tlen bytes  */
+    uint32_t flags;                                      /* COMP_FLAG (0x1) for the complement stream  */
+    int32_t  aread, bread;                               /* original contig indices                    */
+    int32_t  unit, seq;                                  /* provenance: unit index, order inside it    */
+    int32_t  pad;
+    int64_t  toff;                                       /* offset of the trace bytes                  */
+  } fga_aln;                                             /* 56 bytes */
+
+typedef struct
+  { int     tspace;            /* 100 (FastGA.c:46)                                              */
+    int     path_ave;          /* Align_Spec.ave_path (align.c:251)                              */
+    const int16_t *table;      /* 32768 entries each (align.c:207-218)                           */
+    const int16_t *score;
+    int     self;              /* comparing a genome against itself                              */
+    int     aln_min;           /* ALIGN_MIN - 50 (FastGA.c:3013)                                 */
+    double  aln_rate;          /* ALIGN_RATE + .05 (FastGA.c:3014)                               */
+    int64_t cell_cap;          /* trace-point cells per wavefront (0: derived from contig size)  */
+    int64_t aln_cap, trace_cap;/* output capacities (0: derived from the hit count)              */
+  } fga_extend_params;
+
+typedef struct
+  { int64_t  naln, ntrace, ncalls, nwaves;
+    fga_aln *alns;             /* host copies */
+    uint8_t *tbytes;
+  } fga_alns;
+
+int  fga_align_spec(double ave_corr, int tspace, const float *freq4, int *path_ave, int16_t *table, int16_t *score);
+int  fga_dgenome_upload(fga_dev *dev, const fga_gdb *gdb, const int *perm, int nperm, int want_revcomp,
+                        fga_dgenome **out);
+void fga_dgenome_free(fga_dgenome *g);
+int  fga_extend(fga_dev *dev, const fga_dgenome *ga, const fga_dgenome *gb, const fga_hits *hits,
+                const fga_extend_params *prm, fga_alns **out);
+void fga_alns_free(fga_alns *alns);
+
 #ifdef __cplusplus
 }
 #endif
