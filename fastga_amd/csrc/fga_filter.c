@@ -1,0 +1,297 @@
+/* fga_filter.c -- redundancy removal and final ordering of the accepted alignments (host).
+ *
+ * Replaces the tail of align_contigs (reference FastGA.c:3405-3694: ALIGN_SORT, the two elimination
+ * passes, entwine FastGA.c:2818-2941) and the ordering of la_sort / la_merge (FastGA.c:3800-3835, 3906-3918).
+ *
+ * Per (A contig, B contig, strand), over the alignments in discovery order (unit by unit, in hit order):
+ *   1. stable sort by abpos;
+ *   2. pass 1 (j descending, k > j while a-intervals overlap): identical start => drop the one whose a-interval
+ *      ends first (identical boxes: the reference compares `diffs < aepos`, kept literally); identical end =>
+ *      drop the one that starts later;
+ *   3. pass 2: for surviving overlapping pairs whose b-intervals intersect, walk both traces trace point by trace
+ *      point ("entwine"); if they pass through a common trace point, FUSE: o keeps its trace up to that point and
+ *      takes w's from there (diffs = sum of the per-segment diffs); otherwise, if the paths never cross, drop the
+ *      one whose box lies inside the other's box grown by BOX_FUZZ = 10.
+ * Output order: (aread, abpos, bread, comp, order of survival) -- the reference's per-thread SORT_MAP order;
+ * its cross-thread merge only compares (aread, abpos, thread slot), which coincides unless two records of
+ * different threads tie on (aread, abpos) (SURVEY.md hard part 7).
+ */
+#define _GNU_SOURCE
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "fga_host.h"
+#include "fastga_amd.h"
+
+#define TSPACE      100
+#define BOX_FUZZ    10
+#define ELIMINATED  0x4
+
+typedef struct
+  { int tlen, diffs, abpos, bbpos, aepos, bepos;
+    unsigned flags;
+    int aread, bread;
+    uint8_t *trace;         /* points into the input byte pool or to owned memory */
+    int owns;
+    int64_t ord;            /* discovery order */
+  } rec;
+
+static int entwine(const rec *jp, const uint8_t *jtrace, const rec *kp, const uint8_t *ktrace, int *where)
+{ int ac, b2, y2, yp, ae;
+  int i, j, k;
+  int min;
+
+  *where = -1;
+  y2 = jp->bbpos;
+  b2 = kp->bbpos;
+  j  = jp->abpos/TSPACE;
+  k  = kp->abpos/TSPACE;
+  ac = k*TSPACE;
+  j = 1 + 2*(k-j);
+  k = 1;
+  for (i = 1; i < j; i += 2)
+    y2 += jtrace[i];
+  if (j == 1)
+    yp = y2 + (jtrace[j] * (kp->abpos - jp->abpos)) / (ac+TSPACE - jp->abpos);
+  else
+    yp = y2 + (jtrace[j] * (kp->abpos - ac)) / TSPACE;
+
+  min = b2-yp;
+  ae = jp->aepos;
+  if (ae > kp->aepos)
+    ae = kp->aepos;
+
+  for (ac += TSPACE; ac < ae; ac += TSPACE)
+    { y2 += jtrace[j];
+      b2 += ktrace[k];
+      j += 2;
+      k += 2;
+      i = b2-y2;
+      if (min < 0 && min < i)
+        min = (i >= 0) ? 0 : i;
+      else if (min > 0 && min > i)
+        min = (i <= 0) ? 0 : i;
+      if (i == 0)
+        *where = ac;
+    }
+
+  ac -= TSPACE;
+  if (ae == jp->aepos)
+    { y2 = jp->bepos;
+      if (kp->aepos >= ac)
+        b2 += (ktrace[k] * (ae - ac)) / TSPACE;
+      else
+        b2 += (ktrace[k] * (ae - ac)) / (kp->aepos - ac);
+    }
+  else
+    { b2 = kp->bepos;
+      if (jp->aepos >= ac)
+        y2 += (jtrace[j] * (ae - ac)) / TSPACE;
+      else
+        y2 += (jtrace[j] * (ae - ac)) / (jp->aepos - ac);
+    }
+  i = b2-y2;
+  if (min < 0 && min < i)
+    min = (i >= 0) ? 0 : i;
+  else if (min > 0 && min > i)
+    min = (i <= 0) ? 0 : i;
+  return min;
+}
+
+static int by_abpos(const void *l, const void *r)
+{ const rec *a = *(rec * const *) l, *b = *(rec * const *) r;
+  if (a->abpos != b->abpos) return a->abpos - b->abpos;
+  return (a->ord < b->ord) ? -1 : (a->ord > b->ord);
+}
+
+static int by_final(const void *l, const void *r)
+{ const rec *a = *(rec * const *) l, *b = *(rec * const *) r;
+  if (a->aread != b->aread) return a->aread - b->aread;
+  if (a->abpos != b->abpos) return a->abpos - b->abpos;
+  if (a->bread != b->bread) return a->bread - b->bread;
+  if ((a->flags & 1) != (b->flags & 1)) return (int) (a->flags & 1) - (int) (b->flags & 1);
+  return (a->ord < b->ord) ? -1 : (a->ord > b->ord);
+}
+
+static int by_discovery(const void *l, const void *r)
+{ const fga_aln *a = l, *b = r;
+  if (a->unit != b->unit) return a->unit < b->unit ? -1 : 1;
+  return a->seq - b->seq;
+}
+
+/* filter one contig pair / strand: perm[0..n) sorted by abpos */
+static int filter_segment(rec **perm, int n)
+{ int j, k, where, dist;
+
+  for (j = n-1; j >= 0; j--)
+    { rec *o = perm[j];
+      for (k = j+1; k < n; k++)
+        { rec *w = perm[k];
+          if (o->aepos <= w->abpos)
+            break;
+          if (w->flags & ELIMINATED)
+            continue;
+          if (o->abpos == w->abpos && o->bbpos == w->bbpos)
+            { if (o->aepos == w->aepos && o->bepos == w->bepos)
+                { if (o->diffs < w->aepos)
+                    { w->flags |= ELIMINATED; continue; }
+                  else
+                    { o->flags |= ELIMINATED; break; }
+                }
+              else
+                { if (o->aepos > w->aepos)
+                    { w->flags |= ELIMINATED; continue; }
+                  else
+                    { o->flags |= ELIMINATED; break; }
+                }
+            }
+          else if (o->aepos == w->aepos && o->bepos == w->bepos)
+            { if (o->abpos < w->abpos)
+                { w->flags |= ELIMINATED; continue; }
+              else
+                { o->flags |= ELIMINATED; break; }
+            }
+        }
+    }
+
+  for (j = n-1; j >= 0; j--)
+    { rec *o = perm[j];
+      if (o->flags & ELIMINATED)
+        continue;
+      for (k = j+1; k < n; k++)
+        { rec *w = perm[k];
+          if (o->aepos <= w->abpos)
+            break;
+          if (w->flags & ELIMINATED)
+            continue;
+          if (o->bepos <= w->bbpos || o->bbpos >= w->bepos)
+            continue;
+          dist = entwine(o,o->trace,w,w->trace,&where);
+          if (where != -1)
+            { int ocut = 2 * (((where-o->abpos)-1)/TSPACE+1);
+              int wcut = 2 * (((where-w->abpos)-1)/TSPACE+1);
+              int ntlen = ocut + (w->tlen-wcut);
+              uint8_t *nt = malloc(ntlen > 0 ? ntlen : 1);
+              int d = 0, h = 0, g;
+              if (nt == NULL)
+                return 1;
+              for (g = 0; g < ocut; g += 2)
+                { d += (nt[h] = o->trace[g]);
+                  nt[h+1] = o->trace[g+1];
+                  h += 2;
+                }
+              for (g = wcut; g < w->tlen; g += 2)
+                { d += (nt[h] = w->trace[g]);
+                  nt[h+1] = w->trace[g+1];
+                  h += 2;
+                }
+              if (o->owns) free(o->trace);
+              if (w->owns) { free(w->trace); w->owns = 0; w->trace = NULL; }
+              o->tlen  = ntlen;
+              o->diffs = d;
+              o->aepos = w->aepos;
+              o->bepos = w->bepos;
+              w->flags |= ELIMINATED;
+              o->owns  = 1;
+              o->trace = nt;
+              continue;
+            }
+          if (dist != 0)
+            { if ((o->aepos - o->abpos) + BOX_FUZZ >= w->aepos - w->abpos)
+                { if (w->aepos <= o->aepos+BOX_FUZZ && w->bbpos >= o->bbpos-BOX_FUZZ &&
+                      w->bepos <= o->bepos+BOX_FUZZ)
+                    { w->flags |= ELIMINATED;
+                      continue;
+                    }
+                }
+              else
+                { if (o->aepos <= w->aepos+BOX_FUZZ && o->bbpos >= w->bbpos-BOX_FUZZ &&
+                      o->bepos <= w->bepos+BOX_FUZZ && o->abpos >= w->abpos-BOX_FUZZ)
+                    { o->flags |= ELIMINATED;
+                      continue;
+                    }
+                }
+            }
+        }
+    }
+  return 0;
+}
+
+/* in: alignments as produced by fga_extend (any order); out: filtered + finally ordered copy */
+int fga_filter_alignments(const fga_alns *in, fga_alns **out)
+{ fga_alns *R;
+  fga_aln  *sorted = NULL;
+  rec      *recs = NULL, **perm = NULL, **live = NULL;
+  int64_t   n = in->naln, i, j, nlive = 0, tbytes = 0, off;
+
+  *out = NULL;
+  R = calloc(1,sizeof(fga_alns));
+  if (R == NULL) goto oom;
+  R->ncalls = in->ncalls; R->nwaves = in->nwaves;
+  if (n == 0)
+    { R->alns = malloc(sizeof(fga_aln)); R->tbytes = malloc(16);
+      *out = R;
+      return 0;
+    }
+  sorted = malloc(sizeof(fga_aln)*n);
+  recs   = malloc(sizeof(rec)*n);
+  perm   = malloc(sizeof(rec *)*n);
+  live   = malloc(sizeof(rec *)*n);
+  if (sorted == NULL || recs == NULL || perm == NULL || live == NULL) goto oom;
+  memcpy(sorted,in->alns,sizeof(fga_aln)*n);
+  qsort(sorted,n,sizeof(fga_aln),by_discovery);
+  for (i = 0; i < n; i++)
+    { rec *r = recs+i;
+      const fga_aln *a = sorted+i;
+      r->tlen = a->tlen; r->diffs = a->diffs; r->abpos = a->abpos; r->bbpos = a->bbpos;
+      r->aepos = a->aepos; r->bepos = a->bepos; r->flags = a->flags; r->aread = a->aread; r->bread = a->bread;
+      r->trace = in->tbytes + a->toff; r->owns = 0; r->ord = i;
+      perm[i] = r;
+    }
+  /* segments = runs of equal (aread, bread, comp) in discovery order (units are key-ordered) */
+  for (i = 0; i < n; i = j)
+    { for (j = i+1; j < n; j++)
+        if (recs[j].aread != recs[i].aread || recs[j].bread != recs[i].bread ||
+            (recs[j].flags & 1) != (recs[i].flags & 1))
+          break;
+      qsort(perm+i,j-i,sizeof(rec *),by_abpos);
+      if (filter_segment(perm+i,(int) (j-i))) goto oom;
+      { int64_t q;
+        for (q = i; q < j; q++)
+          if (!(perm[q]->flags & ELIMINATED))
+            { perm[q]->ord = nlive;           /* order of survival = the reference's file order */
+              live[nlive++] = perm[q];
+              tbytes += perm[q]->tlen;
+            }
+      }
+    }
+  qsort(live,nlive,sizeof(rec *),by_final);
+
+  R->naln = nlive; R->ntrace = tbytes;
+  R->alns = malloc(sizeof(fga_aln)*(nlive+1));
+  R->tbytes = malloc(tbytes+16);
+  if (R->alns == NULL || R->tbytes == NULL) goto oom;
+  off = 0;
+  for (i = 0; i < nlive; i++)
+    { rec *r = live[i];
+      fga_aln *a = R->alns+i;
+      memset(a,0,sizeof(*a));
+      a->tlen = r->tlen; a->diffs = r->diffs; a->abpos = r->abpos; a->bbpos = r->bbpos;
+      a->aepos = r->aepos; a->bepos = r->bepos; a->flags = r->flags & 0x3; a->aread = r->aread; a->bread = r->bread;
+      a->unit = -1; a->seq = (int32_t) i; a->toff = off;
+      memcpy(R->tbytes+off,r->trace,r->tlen);
+      off += r->tlen;
+    }
+  for (i = 0; i < n; i++)
+    if (recs[i].owns) free(recs[i].trace);
+  free(sorted); free(recs); free(perm); free(live);
+  *out = R;
+  return 0;
+
+oom:
+  fga_set_error("out of memory in alignment filter");
+  free(sorted); free(recs); free(perm); free(live);
+  if (R != NULL) { free(R->alns); free(R->tbytes); free(R); }
+  return 1;
+}

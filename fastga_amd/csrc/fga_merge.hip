@@ -600,9 +600,9 @@ void seed_merge_kernel(merge_args A)
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
-extern "C" int fga_seed_merge(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
-                              const fga_merge_params *prm, int64_t capacity, fga_dseeds **out)
-{ *out = NULL;
+static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
+                      const fga_merge_params *prm, int64_t capacity, fga_dseeds **out, fga_dseeds *append)
+{ if (out != NULL) *out = NULL;
   if (dev == NULL || t1 == NULL || prm == NULL)
     { fga_set_error("fga_seed_merge: null argument");
       return 1;
@@ -648,32 +648,47 @@ extern "C" int fga_seed_merge(fga_dev *dev, const fga_dgix *t1, const fga_dgix *
   int64_t total = (c1e + c2e + 2*(int64_t) A.pend) - A.base;
   A.ntiles = (int) (total / TILE_COST) + 1;
 
-  fga_dseeds *S = (fga_dseeds *) calloc(1,sizeof(fga_dseeds));
+  fga_dseeds *S = append;
   if (S == NULL)
-    { fga_set_error("out of memory");
-      return 1;
+    { S = (fga_dseeds *) calloc(1,sizeof(fga_dseeds));
+      if (S == NULL)
+        { fga_set_error("out of memory");
+          return 1;
+        }
+      S->dev = dev;
+      if (capacity <= 0)
+        capacity = 2*(c1e - c1b) + (1<<20);
+      S->capacity = capacity;
     }
-  S->dev = dev;
-  if (capacity <= 0)
-    capacity = 2*(c1e - c1b) + (1<<20);
-  S->capacity = capacity;
+  else
+    capacity = S->capacity;
 
   merge_tile *tiles = NULL;
   unsigned long long *counters = NULL;
   hipError_t err;
-  if ((err = hipMalloc(&tiles,sizeof(merge_tile)*(size_t) (A.ntiles+1))) != hipSuccess ||
-      (err = hipMalloc(&counters,2*sizeof(unsigned long long))) != hipSuccess ||
-      (S->seeds = (fga_seed *) fga_dev_alloc_cached(dev,sizeof(fga_seed)*(size_t) capacity)) == NULL)
-    { fga_set_error("fga_seed_merge: device allocation failed: %s",hipGetErrorString(err));
-      hipFree(tiles); hipFree(counters); free(S);
-      return 1;
+  if (append != NULL)
+    { counters = (unsigned long long *) S->dcount;
+      if ((err = hipMalloc(&tiles,sizeof(merge_tile)*(size_t) (A.ntiles+1))) != hipSuccess)
+        { fga_set_error("fga_seed_merge: device allocation failed: %s",hipGetErrorString(err));
+          return 1;
+        }
     }
-  S->alloc_bytes = sizeof(fga_seed)*(size_t) capacity;
-  S->dcount = (int64_t *) counters;
+  else
+    { if ((err = hipMalloc(&tiles,sizeof(merge_tile)*(size_t) (A.ntiles+1))) != hipSuccess ||
+          (err = hipMalloc(&counters,2*sizeof(unsigned long long))) != hipSuccess ||
+          (S->seeds = (fga_seed *) fga_dev_alloc_cached(dev,sizeof(fga_seed)*(size_t) capacity)) == NULL)
+        { fga_set_error("fga_seed_merge: device allocation failed: %s",hipGetErrorString(err));
+          hipFree(tiles); hipFree(counters); free(S);
+          return 1;
+        }
+      S->alloc_bytes = sizeof(fga_seed)*(size_t) capacity;
+      S->dcount = (int64_t *) counters;
+    }
   A.tiles = tiles; A.out = S->seeds; A.cap = capacity;
   A.count = counters; A.tseed = counters+1;
 
-  hipMemsetAsync(counters,0,2*sizeof(unsigned long long),dev->stream);
+  if (append == NULL)
+    hipMemsetAsync(counters,0,2*sizeof(unsigned long long),dev->stream);
   hipEventRecord(dev->ev0,dev->stream);
   { int nb = (A.ntiles + 1 + 255) / 256;
     hipLaunchKernelGGL(merge_partition_kernel,dim3(nb),dim3(256),0,dev->stream,A,tiles);
@@ -701,7 +716,9 @@ extern "C" int fga_seed_merge(fga_dev *dev, const fga_dgix *t1, const fga_dgix *
   if (err != hipSuccess)
     { fga_set_error("fga_seed_merge: kernel failed: %s",hipGetErrorString(err));
       hipEventDestroy(ev2);
-      hipFree(tiles); hipFree(counters); hipFree(S->seeds); free(S);
+      hipFree(tiles);
+      if (append == NULL)
+        { hipFree(counters); hipFree(S->seeds); free(S); }
       return 1;
     }
   hipEventElapsedTime(&dev->last_ms[FGA_STAGE_MERGE_PARTITION],dev->ev0,dev->ev1);
@@ -710,11 +727,24 @@ extern "C" int fga_seed_merge(fga_dev *dev, const fga_dgix *t1, const fga_dgix *
   hipFree(tiles);
   S->count  = (int64_t) hc[0];
   S->tseed  = (int64_t) hc[1];
-  *out = S;
+  if (out != NULL) *out = S;
   if (S->count > S->capacity)
     { fga_set_error("fga_seed_merge: %lld seeds exceed the buffer capacity %lld (re-run with a larger capacity)",
                     (long long) S->count,(long long) S->capacity);
       return 2;
     }
   return 0;
+}
+
+extern "C" int fga_seed_merge(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
+                              const fga_merge_params *prm, int64_t capacity, fga_dseeds **out)
+{ return merge_impl(dev,t1,t2,prm,capacity,out,NULL); }
+
+extern "C" int fga_seed_merge_append(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
+                                     const fga_merge_params *prm, fga_dseeds *seeds)
+{ if (seeds == NULL)
+    { fga_set_error("fga_seed_merge_append: null seed buffer");
+      return 1;
+    }
+  return merge_impl(dev,t1,t2,prm,0,NULL,seeds);
 }

@@ -1,0 +1,177 @@
+/* fga_pipeline.c -- the FastGA hot path end to end on one GPU: the span of the reference's "Total Resources"
+ * line (FastGA.c:4828-4829, 5263-5264): prebuilt GDB + GIX in, .1aln out.
+ *
+ *   phase 1  adaptive seed merge          adaptamer_merge / self_adaptamer_merge (FastGA.c:2281, 2496)   GPU
+ *   phase 2  seed -> diagonal record sort reimport_thread + rmsd_sort (FastGA.c:2641, RSDsort.c:292)     GPU
+ *            chain detection              align_contigs scan (FastGA.c:3016-3176)                        host threads
+ *            wave extension               Local_Alignment loop (FastGA.c:3227-3341, align.c:1423)        GPU
+ *            redundancy filter            FastGA.c:3405-3694                                             host
+ *   phase 3  order + emit                 la_sort / la_merge (FastGA.c:3800-4133)                        host
+ */
+#define _GNU_SOURCE
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include "fga_host.h"
+#include "fastga_amd.h"
+
+int fga_run(const char *root1, const char *root2, const fga_run_params *P, fga_run_stats *S)
+{ fga_gdb *g1 = NULL, *g2 = NULL;
+  fga_gix *x1 = NULL, *x2 = NULL;
+  fga_dev *dev = NULL;
+  fga_dgix *d1 = NULL, *d2 = NULL;
+  fga_dgenome *dg1 = NULL, *dg2 = NULL;
+  fga_dseeds *seeds = NULL;
+  fga_dkeys *keys = NULL;
+  fga_hits *hits = NULL;
+  fga_alns *raw = NULL, *fin = NULL;
+  void *hkeys = NULL;
+  int64_t *alen = NULL;
+  int16_t *table = NULL;
+  const int self = (root2 == NULL);
+  int status = 1, i;
+  double t0, t1;
+  fga_run_stats st;
+
+  memset(&st,0,sizeof(st));
+  t0 = fga_wall();
+  if (fga_gdb_open(root1,&g1) || fga_gix_open(root1,&x1)) goto done;
+  if (!self)
+    { if (fga_gdb_open(root2,&g2) || fga_gix_open(root2,&x2)) goto done; }
+  if (x1->nctg < g1->ncontig || (!self && x2->nctg < g2->ncontig))
+    { fga_set_error("genome index and genome database disagree on the number of contigs");
+      goto done;
+    }
+  st.load_s = fga_wall() - t0;
+
+  if (fga_dev_open(P->device,&dev)) goto done;
+  t0 = fga_wall();
+  if (fga_dgix_upload(dev,x1,&d1)) goto done;
+  if (!self && fga_dgix_upload(dev,x2,&d2)) goto done;
+  if (fga_dgenome_upload(dev,g1,x1->perm,x1->nctg,1,&dg1)) goto done;
+  if (self)
+    dg2 = dg1;
+  else if (fga_dgenome_upload(dev,g2,x2->perm,x2->nctg,0,&dg2)) goto done;
+  st.upload_s = fga_wall() - t0;
+
+  /* ---- phase 1 ---- */
+  t0 = fga_wall();
+  { fga_merge_params mp;
+    int rc;
+    memset(&mp,0,sizeof(mp));
+    mp.freq = P->freq; mp.soft_mask = P->soft_mask; mp.flip = 0;
+    rc = fga_seed_merge(dev,d1,self ? NULL : d2,&mp,0,&seeds);
+    if (rc == 2)
+      { int64_t need = fga_seeds_count(seeds) + 1024;
+        fga_seeds_free(seeds); seeds = NULL;
+        rc = fga_seed_merge(dev,d1,self ? NULL : d2,&mp,need,&seeds);
+      }
+    if (rc) goto done;
+    if (P->symmetric && !self)
+      { mp.flip = 1;
+        rc = fga_seed_merge_append(dev,d2,d1,&mp,seeds);
+        if (rc) goto done;
+      }
+    st.nseeds = fga_seeds_count(seeds);
+    st.seed_len_sum = fga_seeds_plen_sum(seeds);
+    if (self) { st.nseeds /= 2; st.seed_len_sum /= 2; }
+  }
+  st.merge_s = fga_wall() - t0;
+  st.merge_kernel_ms = fga_dev_stage_ms(dev,FGA_STAGE_MERGE);
+
+  /* ---- phase 2 ---- */
+  t0 = fga_wall();
+  { fga_sort_params sp;
+    sp.amxpos = g1->maxctg; sp.bmxpos = self ? g1->maxctg : g2->maxctg;
+    sp.nctg_a = x1->nctg;   sp.nctg_b = self ? x1->nctg : x2->nctg;
+    if (fga_seed_sort(dev,seeds,&sp,&keys)) goto done;
+    fga_seeds_free(seeds); seeds = NULL;
+    st.sort_kernel_ms = fga_dev_stage_ms(dev,FGA_STAGE_SORT);
+  }
+  t1 = fga_wall();
+  st.sort_s = t1 - t0;
+
+  { int64_t n = fga_keys_count(keys);
+    int wa, wb, wd, wt;
+    fga_chain_params cp;
+    fga_keys_layout(keys,&wa,&wb,&wd,&wt);
+    hkeys = malloc(16*(size_t) (n+1));
+    alen  = malloc(sizeof(int64_t)*x1->nctg);
+    if (hkeys == NULL || alen == NULL)
+      { fga_set_error("out of memory");
+        goto done;
+      }
+    if (fga_keys_download(keys,hkeys,n)) goto done;
+    fga_keys_free(keys); keys = NULL;
+    for (i = 0; i < x1->nctg; i++)
+      alen[i] = (x1->perm[i] < g1->ncontig) ? g1->contigs[x1->perm[i]].clen : FGA_KMER;
+    cp.chain_break = P->chain_break; cp.chain_min = P->chain_min;
+    cp.amxpos = g1->maxctg; cp.bmxpos = self ? g1->maxctg : g2->maxctg;
+    cp.alen = alen;
+    st.download_s = fga_wall() - t1;
+    t1 = fga_wall();
+    if (fga_chain_scan(hkeys,n,wa,wb,wd,wt,&cp,P->nthreads,&hits)) goto done;
+    free(hkeys); hkeys = NULL;
+    st.nhits = hits->nhits;
+    st.nunits = hits->nunits;
+    st.chain_s = fga_wall() - t1;
+  }
+
+  t1 = fga_wall();
+  { fga_extend_params ep;
+    int path_ave;
+    memset(&ep,0,sizeof(ep));
+    table = malloc(sizeof(int16_t)*2*32768);
+    if (table == NULL)
+      { fga_set_error("out of memory");
+        goto done;
+      }
+    fga_align_spec(1.-P->align_rate,100,g1->freq,&path_ave,table,table+32768);
+    ep.tspace = 100; ep.path_ave = path_ave; ep.table = table; ep.score = table+32768;
+    ep.self = self; ep.aln_min = P->align_min - 50; ep.aln_rate = P->align_rate + .05;
+    if (fga_extend(dev,dg1,dg2,hits,&ep,&raw)) goto done;
+    st.nalns = raw->naln; st.ncalls = raw->ncalls; st.nwaves = raw->nwaves;
+    st.extend_kernel_ms = fga_dev_stage_ms(dev,FGA_STAGE_EXTEND);
+  }
+  st.extend_s = fga_wall() - t1;
+
+  t1 = fga_wall();
+  if (fga_filter_alignments(raw,&fin)) goto done;
+  st.nlive = fin->naln;
+  for (i = 0; i < fin->naln; i++)
+    st.cover += fin->alns[i].aepos - fin->alns[i].abpos;
+  st.filter_s = fga_wall() - t1;
+
+  /* ---- phase 3 ---- */
+  t1 = fga_wall();
+  if (P->out_path != NULL)
+    { char *n1 = NULL, *n2 = NULL;
+      const char *cmd = P->command_line ? P->command_line : "FastGA";
+      int rc;
+      if (asprintf(&n1,"%s",g1->path) < 0) n1 = NULL;
+      if (!self && asprintf(&n2,"%s",g2->path) < 0) n2 = NULL;
+      rc = fga_write_1aln(P->out_path,g1,self ? NULL : g2,fin,100,n1 ? n1 : root1,n2,cmd);
+      free(n1); free(n2);
+      if (rc) goto done;
+    }
+  st.write_s = fga_wall() - t1;
+  st.phase23_s = fga_wall() - t0 - 0;
+  status = 0;
+
+done:
+  if (S != NULL) *S = st;
+  free(hkeys); free(alen); free(table);
+  fga_alns_free(raw); fga_alns_free(fin);
+  fga_hits_free(hits);
+  fga_keys_free(keys);
+  fga_seeds_free(seeds);
+  if (dg2 != dg1) fga_dgenome_free(dg2);
+  fga_dgenome_free(dg1);
+  fga_dgix_free(d2); fga_dgix_free(d1);
+  fga_dev_close(dev);
+  fga_gix_close(x2); fga_gix_close(x1);
+  fga_gdb_close(g2); fga_gdb_close(g1);
+  return status;
+}

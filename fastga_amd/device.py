@@ -258,3 +258,15 @@ def extend(dev, ga, gb, hitlist, path_ave, table, score, tspace=100, self_cmp=Fa
     stats = {"calls": a.ncalls, "waves": a.nwaves}
     dev.L.fga_alns_free(out)
     return alns, tb, stats
+
+
+def run(root1, root2=None, out_path=None, device=0, freq=10, soft_mask=False, symmetric=False, chain_break=1000,
+        chain_min=85, align_min=100, identity=0.7, nthreads=8, command_line="FastGA"):
+    """The whole hot path (fga_run): prebuilt GDB/GIX roots in, .1aln out.  Returns the stats as a dict."""
+    from .lib import RunParams, RunStats
+    L = load_library()
+    prm = RunParams(device, freq, int(soft_mask), int(symmetric), 2 * chain_break, 2 * chain_min, align_min,
+                    1.0 - identity, nthreads, out_path.encode() if out_path else None, command_line.encode())
+    st = RunStats()
+    check(L.fga_run(root1.encode(), root2.encode() if root2 else None, C.byref(prm), C.byref(st)), "fga_run")
+    return {n: getattr(st, n) for n, _ in RunStats._fields_}

@@ -62,6 +62,21 @@ class Alns(C.Structure):
                 ("alns", C.c_void_p), ("tbytes", C.c_void_p)]
 
 
+class RunParams(C.Structure):
+    _fields_ = [("device", C.c_int), ("freq", C.c_int), ("soft_mask", C.c_int), ("symmetric", C.c_int),
+                ("chain_break", C.c_int), ("chain_min", C.c_int), ("align_min", C.c_int),
+                ("align_rate", C.c_double), ("nthreads", C.c_int), ("out_path", C.c_char_p),
+                ("command_line", C.c_char_p)]
+
+
+class RunStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("nseeds", "seed_len_sum", "nhits", "nunits", "nalns", "nlive", "cover",
+                                         "ncalls", "nwaves")] + \
+               [(n, C.c_double) for n in ("load_s", "upload_s", "merge_s", "sort_s", "download_s", "chain_s",
+                                          "extend_s", "filter_s", "write_s", "phase23_s")] + \
+               [(n, C.c_float) for n in ("merge_kernel_ms", "sort_kernel_ms", "extend_kernel_ms")]
+
+
 class SortParams(C.Structure):
     _fields_ = [("amxpos", C.c_int64), ("bmxpos", C.c_int64), ("nctg_a", C.c_int), ("nctg_b", C.c_int)]
 
@@ -124,6 +139,10 @@ def _declare(L):
         "fga_dgenome_free": (None, [vp]),
         "fga_extend": (i32, [vp, vp, vp, P(Hits), P(ExtendParams), P(P(Alns))]),
         "fga_alns_free": (None, [P(Alns)]),
+        "fga_seed_merge_append": (i32, [vp, vp, vp, P(MergeParams), vp]),
+        "fga_filter_alignments": (i32, [P(Alns), P(P(Alns))]),
+        "fga_write_1aln": (i32, [cp, vp, vp, P(Alns), i32, cp, cp, cp]),
+        "fga_run": (i32, [cp, cp, P(RunParams), P(RunStats)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

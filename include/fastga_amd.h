@@ -184,6 +184,38 @@ int  fga_extend(fga_dev *dev, const fga_dgenome *ga, const fga_dgenome *gb, cons
                 const fga_extend_params *prm, fga_alns **out);
 void fga_alns_free(fga_alns *alns);
 
+/* second pass of -S appended to an existing seed buffer (FastGA.c:2410-2470); buffer must have room */
+int  fga_seed_merge_append(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2, const fga_merge_params *prm,
+                           fga_dseeds *seeds);
+
+/* ---- redundancy filter + final order (FastGA.c:3405-3694, 3800-3835) and .1aln emission (alncode.c:239-305) ---- */
+int  fga_filter_alignments(const fga_alns *in, fga_alns **out);
+int  fga_write_1aln(const char *path, const fga_gdb *g1, const fga_gdb *g2 /* NULL: self */, const fga_alns *alns,
+                    int tspace, const char *db1_name, const char *db2_name, const char *command_line);
+
+/* ---- the whole hot path: what `FastGA -1:<out> <root1> [<root2>]` does between "GIX present" and ".1aln closed" */
+typedef struct
+  { int     device;
+    int     freq;            /* -f (10)                    */
+    int     soft_mask;       /* -M or #mask                */
+    int     symmetric;       /* -S                         */
+    int     chain_break;     /* 2 * -s (2000)              */
+    int     chain_min;       /* 2 * -c (170)               */
+    int     align_min;       /* -l (100)                   */
+    double  align_rate;      /* 1 - (-i) (0.3)             */
+    int     nthreads;        /* host threads (-T)          */
+    const char *out_path;    /* <name>.1aln (NULL: no file) */
+    const char *command_line;
+  } fga_run_params;
+
+typedef struct
+  { int64_t nseeds, seed_len_sum, nhits, nunits, nalns, nlive, cover, ncalls, nwaves;
+    double  load_s, upload_s, merge_s, sort_s, download_s, chain_s, extend_s, filter_s, write_s, phase23_s;
+    float   merge_kernel_ms, sort_kernel_ms, extend_kernel_ms;
+  } fga_run_stats;
+
+int  fga_run(const char *root1, const char *root2 /* NULL: self */, const fga_run_params *prm, fga_run_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif
