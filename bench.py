@@ -35,38 +35,49 @@ def parse():
     ap.add_argument("--div", type=float, default=0.02)
     ap.add_argument("--contigs", type=int, default=40)
     ap.add_argument("--workdir", default=None)
-    ap.add_argument("--cpu-mbp", type=float, default=8.0, help="size of the bounded CPU-baseline sample, Mbp")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--verify", action="store_true", help="also compare our .1aln with the reference's (ONEview)")
     return ap.parse_args()
 
 
-def cpu_baseline(args, workdir):
-    """Reference FastGA (oracle/_ref) on a bounded sample pair built by our own producers; falls back to the
-    oracle's seed-merge port if the reference binaries did not travel."""
-    from fastga_amd import workload
+def cpu_baseline(args, ra, rb, workdir, verify_against=None):
+    """The REAL reference FastGA (oracle/_ref, built from /root/reference by oracle/Makefile) on this box's host
+    cores, on the bench's own pair (prebuilt GDB/GIX from our producers); falls back to a smaller pair if the bench
+    pair is large, and to the oracle's seed-merge port if the reference binaries did not travel."""
     from oracle import harness as H
     ncores = os.cpu_count() or 1
     threads = max(1, min(32, ncores))
-    d = os.path.join(workdir, "cpu")
-    os.makedirs(d, exist_ok=True)
-    mbp = args.cpu_mbp
-    ra, rb = workload.build_pair(d, seed=4242, ncontig=max(threads, 32), total=int(mbp * 1e6),
-                                 divergence=args.div, repeat_frac=0.05, inv_frac=0.02, swap_frac=0.02,
-                                 threads=threads)
+    mbp = args.mbp
     if H.have_reference():
+        d = os.path.join(workdir, "cpu")
+        os.makedirs(d, exist_ok=True)
+        if mbp > 150:                       # keep the baseline leg to tens of seconds
+            from fastga_amd import workload
+            mbp = 100.0
+            ra, rb = workload.build_pair(d, seed=4242, ncontig=max(threads, 40), total=int(mbp * 1e6),
+                                         divergence=args.div, repeat_frac=0.05, inv_frac=0.02, swap_frac=0.02,
+                                         threads=threads)
         t = time.time()
-        H.ref_fastga(ra, rb, d, os.path.join(d, "ref"), threads=threads)
+        r, _ = H.ref_fastga(ra, rb, d, os.path.join(d, "ref"), threads=threads)
         dt = time.time() - t
-        return {"value": mbp * 1e-3 / dt, "unit": "Gbp-pair/s", "cores": threads, "kind": "reference",
-                "sample": f"oracle/_ref/FastGA -T{threads} on a synthetic {mbp:g} Mbp x {mbp:g} Mbp pair "
-                          f"(same generator, {dt:.1f} s wall, prebuilt GDB/GIX)"}
+        phases = [ln.strip() for ln in r.stderr.replace("\r", "\n").splitlines() if "Resources" in ln]
+        out = {"value": mbp * 1e-3 / dt, "unit": "Gbp-pair/s", "cores": threads, "kind": "reference",
+               "sample": f"oracle/_ref/FastGA -T{threads} -1:ref on the bench pair ({mbp:g} Mbp x {mbp:g} Mbp, "
+                         f"prebuilt GDB/GIX, tmp on local disk): {dt:.2f} s wall; " + " | ".join(phases)}
+        if verify_against is not None and mbp == args.mbp:
+            a = H.oneview(verify_against)
+            b = H.oneview(os.path.join(d, "ref.1aln"))
+            out["identical_1aln"] = (a == b)
+            out["records"] = sum(1 for ln in b if ln.startswith("A "))
+        return out
     from fastga_amd.gixio import Gix
     A, B = Gix(ra + ".gix"), Gix(rb + ".gix")
+    npre = 1 << 20                          # 1/16 of the prefix space
     t = time.time()
-    H.oracle_seed_merge(A.table, A.index, A.pbyte, B.table, B.index, B.pbyte)
+    H.oracle_seed_merge(A.table, A.index, A.pbyte, B.table, B.index, B.pbyte, pfirst=0, plast=npre)
     dt = time.time() - t
-    return {"value": mbp * 1e-3 / dt, "unit": "Gbp-pair/s", "cores": 1, "kind": "port",
-            "sample": f"oracle seed-merge restatement only, {mbp:g} Mbp pair, {dt:.1f} s"}
+    return {"value": mbp * 1e-3 / 16 / dt, "unit": "Gbp-pair/s", "cores": 1, "kind": "port",
+            "sample": f"oracle seed-merge restatement only, 1/16 of the k-mer prefix space, {dt:.1f} s"}
 
 
 def main():
@@ -82,7 +93,6 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from fastga_amd import workload, device as D
-    from fastga_amd.gixio import Gix
 
     workdir = args.workdir or tempfile.mkdtemp(prefix=f"fga_bench_r{rank}_")
     os.makedirs(workdir, exist_ok=True)
@@ -92,21 +102,17 @@ def main():
     ra, rb = workload.build_pair(workdir, seed=1 + rank, ncontig=args.contigs, total=total,
                                  divergence=args.div, repeat_frac=0.05, inv_frac=0.02, swap_frac=0.02,
                                  threads=threads)
-    A, B = Gix(ra + ".gix"), Gix(rb + ".gix")
     prep_s = time.time() - t0
 
-    dev = D.Device(local)
-    dA, dB = dev.upload(A), dev.upload(B)
+    # inputs resident in HBM before the timed region: both GIX tables + both 2-bit genomes
+    ses = D.Session(ra, rb, device=local)
+    out1aln = os.path.join(workdir, f"bench_r{rank}.1aln")
 
     def step():
-        s = D.seed_merge(dev, dA, dB)
-        n = s.count
-        ms = dev.stage_ms(D.STAGE_MERGE)
-        s.free()
-        return n, ms
+        return ses.run(out_path=out1aln, nthreads=threads, command_line="bench.py FastGA hot path")
 
     def barrier():
-        dev.sync()
+        ses.sync()
         if dist is not None:
             import torch
             dist.barrier()
@@ -116,36 +122,50 @@ def main():
         step()
     barrier()
     t = time.time()
-    kms, nseeds = [], 0
+    stats = []
     for _ in range(args.steps):
-        nseeds, ms = step()
-        kms.append(ms)
+        stats.append(step())
     barrier()
     elapsed = time.time() - t
 
+    nrec = stats[-1]["nlive"]
     if dist is not None:
         import torch
         tt = torch.tensor([elapsed], device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        # the only cross-rank traffic of the path: gather the per-rank record counts (RCCL over xGMI)
+        cnt = torch.tensor([nrec], device="cuda", dtype=torch.int64)
+        allc = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(allc, cnt)
+        nrec = int(sum(int(c.item()) for c in allc))
 
     if rank == 0:
         ms_per_step = 1000.0 * elapsed / args.steps
-        pair_gbp = 0.5 * (A_seqtot(ra) + A_seqtot(rb)) * 1e-9
+        pair_gbp = 0.5 * (ses.bases[0] + ses.bases[1]) * 1e-9
         value = world * pair_gbp / (ms_per_step / 1000.0)
-        seed_bytes = 1 + A.pbyte + B.pbyte
-        alg_bytes = A.nents * A.ebytes + B.nents * B.ebytes + nseeds * seed_bytes
-        kavg = sum(kms) / len(kms)
+        last = stats[-1]
+        nseeds = last["nseeds"]
+        alg_bytes = ses.table_bytes + nseeds * ses.seed_bytes
+        kavg = sum(s["merge_kernel_ms"] for s in stats) / len(stats)
         achieved = alg_bytes / (kavg * 1e-3) / 1e9
+        stage_ms = {k: round(1000 * sum(s[k] for s in stats) / len(stats), 2)
+                    for k in ("merge_s", "sort_s", "download_s", "chain_s", "extend_s", "filter_s", "write_s")}
         out = {
             "metric": "Gbp-pair aligned/sec", "value": value, "unit": "Gbp-pair/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int64",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32/u64",
             "data": "synthetic",
             "config": {"workload": f"synthetic {args.mbp:g} Mbp vs {args.mbp:g} Mbp, {args.div*100:g}% divergence, "
-                                   f"{args.contigs} contigs, 5% repeats, 2% inversions/swaps (BASELINE configs[1])",
-                       "stages": "seed-merge (GPU); sort/chain/extend not yet in the timed step",
-                       "seeds": int(nseeds), "entries": [int(A.nents), int(B.nents)],
+                                   f"{args.contigs} contigs, 5% repeats, 2% inversions/swaps (BASELINE configs[1]); "
+                                   f"one pair per GPU",
+                       "step": "seed merge -> sort -> chain scan -> wave extension -> redundancy filter -> .1aln "
+                               "written; GIX tables + genomes resident in HBM",
+                       "seeds": int(nseeds), "hits": int(last["nhits"]), "alignments": int(last["nalns"]),
+                       "records": int(nrec), "la_calls": int(last["ncalls"]), "waves": int(last["nwaves"]),
+                       "stage_ms": stage_ms,
+                       "kernel_ms": {"merge": round(kavg, 3), "sort": round(last["sort_kernel_ms"], 3),
+                                     "extend": round(last["extend_kernel_ms"], 3)},
                        "prep_s": round(prep_s, 1)},
             "roofline": {"kernel": "seed_merge_kernel", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -153,13 +173,14 @@ def main():
         }
         if not args.no_cpu:
             try:
-                out["cpu_baseline"] = cpu_baseline(args, workdir)
+                out["cpu_baseline"] = cpu_baseline(args, ra, rb, workdir,
+                                                   verify_against=out1aln if args.verify else None)
             except Exception as e:      # the baseline leg must never take the bench line down
-                out["cpu_baseline"] = {"value": None, "unit": "Gbp-pair/s", "cores": 0, "kind": "port",
+                out["cpu_baseline"] = {"value": None, "unit": "Gbp-pair/s", "cores": 0, "kind": "reference",
                                        "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
 
-    dA.free(); dB.free(); dev.close()
+    ses.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -31,37 +31,60 @@ extern "C" int fga_dev_open(int device, fga_dev **out)
   return 0;
 }
 
-void *fga_dev_alloc_cached(fga_dev *dev, size_t bytes)
-{ if (dev->cache_ptr != NULL && dev->cache_bytes >= bytes && dev->cache_bytes <= 2*bytes + (64u<<20))
-    { void *p = dev->cache_ptr;
-      dev->cache_ptr = NULL;
+void *fga_dev_acquire(fga_dev *dev, int slot, size_t bytes)
+{ if (bytes == 0) bytes = 16;
+  if (slot < 0 || slot >= SLOT_COUNT || dev->slot_busy[slot])
+    { void *p = NULL;                       // slot taken (or none asked): a private allocation
+      if (hipMalloc(&p,bytes) != hipSuccess)
+        return NULL;
       return p;
     }
-  if (dev->cache_ptr != NULL)
-    { hipFree(dev->cache_ptr);
-      dev->cache_ptr = NULL;
+  if (dev->slot_ptr[slot] == NULL || dev->slot_bytes[slot] < bytes)
+    { if (dev->slot_ptr[slot] != NULL)
+        hipFree(dev->slot_ptr[slot]);
+      dev->slot_ptr[slot] = NULL;
+      size_t want = bytes + bytes/8;
+      if (hipMalloc(&dev->slot_ptr[slot],want) != hipSuccess)
+        { want = bytes;
+          if (hipMalloc(&dev->slot_ptr[slot],want) != hipSuccess)
+            { dev->slot_ptr[slot] = NULL; dev->slot_bytes[slot] = 0;
+              return NULL;
+            }
+        }
+      dev->slot_bytes[slot] = want;
     }
-  void *p = NULL;
-  if (hipMalloc(&p,bytes) != hipSuccess)
-    return NULL;
-  return p;
+  dev->slot_busy[slot] = 1;
+  return dev->slot_ptr[slot];
 }
 
-void fga_dev_free_cached(fga_dev *dev, void *ptr, size_t bytes)
+void fga_dev_release(fga_dev *dev, int slot, void *ptr)
 { if (ptr == NULL) return;
-  if (dev->cache_ptr == NULL)
-    { dev->cache_ptr = ptr;
-      dev->cache_bytes = bytes;
-    }
+  if (slot >= 0 && slot < SLOT_COUNT && dev->slot_ptr[slot] == ptr)
+    dev->slot_busy[slot] = 0;
   else
     hipFree(ptr);
+}
+
+void *fga_dev_pinned(fga_dev *dev, size_t bytes)
+{ if (dev->pinned == NULL || dev->pinned_bytes < bytes)
+    { if (dev->pinned != NULL) hipHostFree(dev->pinned);
+      dev->pinned = NULL;
+      if (hipHostMalloc(&dev->pinned,bytes + bytes/8,hipHostMallocDefault) != hipSuccess)
+        { dev->pinned = NULL; dev->pinned_bytes = 0;
+          return NULL;
+        }
+      dev->pinned_bytes = bytes + bytes/8;
+    }
+  return dev->pinned;
 }
 
 extern "C" void fga_dev_close(fga_dev *d)
 { if (d == NULL) return;
   hipSetDevice(d->device);
   hipStreamSynchronize(d->stream);
-  if (d->cache_ptr != NULL) hipFree(d->cache_ptr);
+  for (int q = 0; q < SLOT_COUNT; q++)
+    if (d->slot_ptr[q] != NULL) hipFree(d->slot_ptr[q]);
+  if (d->pinned != NULL) hipHostFree(d->pinned);
   hipEventDestroy(d->ev0);
   hipEventDestroy(d->ev1);
   hipStreamDestroy(d->stream);
@@ -131,7 +154,7 @@ extern "C" int fga_seeds_download(const fga_dseeds *S, fga_seed *host, int64_t m
 extern "C" void fga_seeds_free(fga_dseeds *S)
 { if (S == NULL) return;
   hipSetDevice(S->dev->device);
-  fga_dev_free_cached(S->dev,S->seeds,S->alloc_bytes);
+  fga_dev_release(S->dev,S->slot,S->seeds);
   hipFree(S->dcount);
   free(S);
 }

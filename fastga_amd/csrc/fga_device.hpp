@@ -26,9 +26,13 @@ struct fga_dev
     hipEvent_t   ev0, ev1;
     int          ncu;
     float        last_ms[8];     // per-stage kernel time of the most recent call (HIP events)
-    // one-slot cache of the big seed buffer: hipMalloc/hipFree of GBs per call costs ~100 ms
-    void        *cache_ptr;
-    size_t       cache_bytes;
+    // grow-only workspace slots: hipMalloc/hipFree of GB-sized buffers costs ~100 ms each, so the big
+    // buffers of the pipeline stay with the device context between calls
+    void        *slot_ptr[16];
+    size_t       slot_bytes[16];
+    int          slot_busy[16];
+    void        *pinned;          // pinned host staging buffer (key download)
+    size_t       pinned_bytes;
   };
 
 // device-resident genome index: the on-disk bytes, unchanged
@@ -44,14 +48,17 @@ struct fga_dgix
 //   apos, bpos : in-contig positions as stored in the index payloads
 //   actg       : A contig (length-sorted index) << 8 | plen
 //   bctg       : B contig | (B entry's own sign bit) << 30 | (C-stream flag) << 31
-void *fga_dev_alloc_cached(fga_dev *dev, size_t bytes);     // returns NULL on failure
-void  fga_dev_free_cached(fga_dev *dev, void *ptr, size_t bytes);
+enum { SLOT_SEEDS = 0, SLOT_SORT0, SLOT_SORT1, SLOT_HIST, SLOT_TILES, SLOT_CELLS, SLOT_TRACE, SLOT_ALNS,
+       SLOT_TBYTES, SLOT_MISC, SLOT_COUNT };
+void *fga_dev_acquire(fga_dev *dev, int slot, size_t bytes);   // NULL on failure; pair with fga_dev_release
+void  fga_dev_release(fga_dev *dev, int slot, void *ptr);
+void *fga_dev_pinned(fga_dev *dev, size_t bytes);              // host pinned staging, grow-only
 
 struct fga_dseeds
   { fga_dev  *dev;
     fga_seed *seeds;      // device buffer
     int64_t   capacity;
-    size_t    alloc_bytes;
+    int       slot;       // workspace slot the seed buffer came from (-1: own allocation)
     int64_t   tseed;      // sum of plen over all seeds
     int64_t   count;      // seeds produced (may exceed capacity -> overflow, buffer holds `capacity`)
     int64_t  *dcount;     // device counter
@@ -63,6 +70,7 @@ struct fga_dkeys
     uint4    *keys;        // x,y = low 64 bits; z,w = high 64 bits
     int64_t   count;
     size_t    alloc_bytes;
+    int       slot;
     int       wa, wb, wd, wt;
     int64_t   amxpos, bmxpos;
   };

@@ -875,13 +875,13 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
     for (int64_t u = 0; u < H->nunits; u++) order[u] = w[u].second;
   }
 
-  int nwg = dev->ncu * 8;
+  int nwg = dev->ncu * 4;
   { const char *ev = getenv("FGA_EXTEND_WGS");
     if (ev != NULL && atoi(ev) > 0) nwg = atoi(ev);
   }
   if (nwg > H->nunits) nwg = (int) H->nunits;
   const int64_t maxa = GA->maxctg > GB->maxctg ? GA->maxctg : GB->maxctg;
-  int64_t cell_cap  = prm->cell_cap  > 0 ? prm->cell_cap  : 48*(maxa/prm->tspace + 64) + 4096;
+  int64_t cell_cap  = prm->cell_cap  > 0 ? prm->cell_cap  : 24*(maxa/prm->tspace + 64) + 4096;
   int64_t trace_cap = 8*(maxa/prm->tspace + 8) + 64;
   int64_t aln_cap   = prm->aln_cap   > 0 ? prm->aln_cap   : 4*H->nhits + 1024;
   int64_t tb_cap    = prm->trace_cap > 0 ? prm->trace_cap : aln_cap * (2*(maxa/prm->tspace) / 8 + 64);
@@ -905,12 +905,17 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
       (e = hipMalloc(&d_order,sizeof(int)*H->nunits)) != hipSuccess ||
       (e = hipMalloc(&d_next,sizeof(int))) != hipSuccess ||
       (e = hipMalloc(&d_tab,sizeof(int16_t)*2*32768)) != hipSuccess ||
-      (e = hipMalloc(&d_cnt,sizeof(unsigned long long)*8)) != hipSuccess ||
-      (e = hipMalloc(&A.cells,sizeof(int4)*(size_t) cell_cap*nwg)) != hipSuccess ||
-      (e = hipMalloc(&A.trace,sizeof(uint16_t)*(size_t) trace_cap*nwg)) != hipSuccess ||
-      (e = hipMalloc(&A.alns,sizeof(fga_aln)*(size_t) aln_cap)) != hipSuccess ||
-      (e = hipMalloc(&A.tbytes,(size_t) tb_cap)) != hipSuccess)
+      (e = hipMalloc(&d_cnt,sizeof(unsigned long long)*8)) != hipSuccess)
     { fga_set_error("fga_extend: device allocation failed: %s",hipGetErrorString(e));
+      goto fail;
+    }
+  A.cells  = (int4 *)     fga_dev_acquire(dev,SLOT_CELLS,sizeof(int4)*(size_t) cell_cap*nwg);
+  A.trace  = (uint16_t *) fga_dev_acquire(dev,SLOT_TRACE,sizeof(uint16_t)*(size_t) trace_cap*nwg);
+  A.alns   = (fga_aln *)  fga_dev_acquire(dev,SLOT_ALNS,sizeof(fga_aln)*(size_t) aln_cap);
+  A.tbytes = (uint8_t *)  fga_dev_acquire(dev,SLOT_TBYTES,(size_t) tb_cap);
+  if (A.cells == NULL || A.trace == NULL || A.alns == NULL || A.tbytes == NULL)
+    { fga_set_error("fga_extend: device allocation failed (%lld MB of trace-point cells)",
+                    (long long) (sizeof(int4)*(size_t) cell_cap*nwg >> 20));
       goto fail;
     }
   hipMemcpy(d_units,H->units,sizeof(fga_unit)*H->nunits,hipMemcpyHostToDevice);
@@ -958,13 +963,15 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
       hipMemcpy(R->tbytes,A.tbytes,R->ntrace,hipMemcpyDeviceToHost);
   }
   hipFree(d_units); hipFree(d_hits); hipFree(d_order); hipFree(d_next); hipFree(d_tab); hipFree(d_cnt);
-  hipFree(A.cells); hipFree(A.trace); hipFree(A.alns); hipFree(A.tbytes);
+  fga_dev_release(dev,SLOT_CELLS,A.cells); fga_dev_release(dev,SLOT_TRACE,A.trace);
+  fga_dev_release(dev,SLOT_ALNS,A.alns); fga_dev_release(dev,SLOT_TBYTES,A.tbytes);
   *out = R;
   return 0;
 
 fail:
   hipFree(d_units); hipFree(d_hits); hipFree(d_order); hipFree(d_next); hipFree(d_tab); hipFree(d_cnt);
-  hipFree(A.cells); hipFree(A.trace); hipFree(A.alns); hipFree(A.tbytes);
+  fga_dev_release(dev,SLOT_CELLS,A.cells); fga_dev_release(dev,SLOT_TRACE,A.trace);
+  fga_dev_release(dev,SLOT_ALNS,A.alns); fga_dev_release(dev,SLOT_TBYTES,A.tbytes);
   free(R->alns); free(R->tbytes); free(R);
   return 1;
 }

@@ -676,12 +676,12 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
   else
     { if ((err = hipMalloc(&tiles,sizeof(merge_tile)*(size_t) (A.ntiles+1))) != hipSuccess ||
           (err = hipMalloc(&counters,2*sizeof(unsigned long long))) != hipSuccess ||
-          (S->seeds = (fga_seed *) fga_dev_alloc_cached(dev,sizeof(fga_seed)*(size_t) capacity)) == NULL)
+          (S->seeds = (fga_seed *) fga_dev_acquire(dev,SLOT_SEEDS,sizeof(fga_seed)*(size_t) capacity)) == NULL)
         { fga_set_error("fga_seed_merge: device allocation failed: %s",hipGetErrorString(err));
           hipFree(tiles); hipFree(counters); free(S);
           return 1;
         }
-      S->alloc_bytes = sizeof(fga_seed)*(size_t) capacity;
+      S->slot = SLOT_SEEDS;
       S->dcount = (int64_t *) counters;
     }
   A.tiles = tiles; A.out = S->seeds; A.cap = capacity;
@@ -718,7 +718,7 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
       hipEventDestroy(ev2);
       hipFree(tiles);
       if (append == NULL)
-        { hipFree(counters); hipFree(S->seeds); free(S); }
+        { hipFree(counters); fga_dev_release(dev,SLOT_SEEDS,S->seeds); free(S); }
       return 1;
     }
   hipEventElapsedTime(&dev->last_ms[FGA_STAGE_MERGE_PARTITION],dev->ev0,dev->ev1);

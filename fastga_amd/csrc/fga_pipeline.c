@@ -17,12 +17,78 @@
 #include "fga_host.h"
 #include "fastga_amd.h"
 
-int fga_run(const char *root1, const char *root2, const fga_run_params *P, fga_run_stats *S)
-{ fga_gdb *g1 = NULL, *g2 = NULL;
-  fga_gix *x1 = NULL, *x2 = NULL;
-  fga_dev *dev = NULL;
-  fga_dgix *d1 = NULL, *d2 = NULL;
-  fga_dgenome *dg1 = NULL, *dg2 = NULL;
+struct fga_session
+  { fga_gdb *g1, *g2;
+    fga_gix *x1, *x2;
+    fga_dev *dev;
+    fga_dgix *d1, *d2;
+    fga_dgenome *dg1, *dg2;
+    int self;
+    double load_s, upload_s;
+  };
+
+void fga_session_close(fga_session *Z)
+{ if (Z == NULL) return;
+  if (Z->dg2 != Z->dg1) fga_dgenome_free(Z->dg2);
+  fga_dgenome_free(Z->dg1);
+  fga_dgix_free(Z->d2); fga_dgix_free(Z->d1);
+  fga_dev_close(Z->dev);
+  fga_gix_close(Z->x2); fga_gix_close(Z->x1);
+  fga_gdb_close(Z->g2); fga_gdb_close(Z->g1);
+  free(Z);
+}
+
+/* load GDB + GIX of both genomes and make them resident in HBM */
+int fga_session_open(const char *root1, const char *root2, int device, fga_session **out)
+{ fga_session *Z = calloc(1,sizeof(fga_session));
+  double t0;
+  *out = NULL;
+  if (Z == NULL)
+    { fga_set_error("out of memory");
+      return 1;
+    }
+  Z->self = (root2 == NULL);
+  t0 = fga_wall();
+  if (fga_gdb_open(root1,&Z->g1) || fga_gix_open(root1,&Z->x1)) goto fail;
+  if (!Z->self)
+    { if (fga_gdb_open(root2,&Z->g2) || fga_gix_open(root2,&Z->x2)) goto fail; }
+  if (Z->x1->nctg < Z->g1->ncontig || (!Z->self && Z->x2->nctg < Z->g2->ncontig))
+    { fga_set_error("genome index and genome database disagree on the number of contigs");
+      goto fail;
+    }
+  Z->load_s = fga_wall() - t0;
+  if (fga_dev_open(device,&Z->dev)) goto fail;
+  t0 = fga_wall();
+  if (fga_dgix_upload(Z->dev,Z->x1,&Z->d1)) goto fail;
+  if (!Z->self && fga_dgix_upload(Z->dev,Z->x2,&Z->d2)) goto fail;
+  if (fga_dgenome_upload(Z->dev,Z->g1,Z->x1->perm,Z->x1->nctg,1,&Z->dg1)) goto fail;
+  if (Z->self)
+    Z->dg2 = Z->dg1;
+  else if (fga_dgenome_upload(Z->dev,Z->g2,Z->x2->perm,Z->x2->nctg,0,&Z->dg2)) goto fail;
+  Z->upload_s = fga_wall() - t0;
+  *out = Z;
+  return 0;
+fail:
+  fga_session_close(Z);
+  return 1;
+}
+
+fga_dev *fga_session_device(fga_session *Z) { return Z->dev; }
+int64_t  fga_session_table_bytes(const fga_session *Z)
+{ return Z->x1->nents*Z->x1->ebytes + (Z->self ? 0 : Z->x2->nents*Z->x2->ebytes); }
+int      fga_session_seed_bytes(const fga_session *Z)
+{ return 1 + Z->x1->postbytes + Z->x1->contbytes + (Z->self ? Z->x1->postbytes + Z->x1->contbytes
+                                                            : Z->x2->postbytes + Z->x2->contbytes); }
+int64_t  fga_session_bases(const fga_session *Z, int which)
+{ return which == 0 ? Z->g1->seqtot : (Z->self ? Z->g1->seqtot : Z->g2->seqtot); }
+
+/* one pass of the hot path over the resident inputs: phases 1-3 */
+int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
+{ fga_gdb *g1 = Z->g1, *g2 = Z->g2;
+  fga_gix *x1 = Z->x1, *x2 = Z->x2;
+  fga_dev *dev = Z->dev;
+  fga_dgix *d1 = Z->d1, *d2 = Z->d2;
+  fga_dgenome *dg1 = Z->dg1, *dg2 = Z->dg2;
   fga_dseeds *seeds = NULL;
   fga_dkeys *keys = NULL;
   fga_hits *hits = NULL;
@@ -30,39 +96,22 @@ int fga_run(const char *root1, const char *root2, const fga_run_params *P, fga_r
   void *hkeys = NULL;
   int64_t *alen = NULL;
   int16_t *table = NULL;
-  const int self = (root2 == NULL);
+  const int self = Z->self;
   int status = 1, i;
-  double t0, t1;
+  double t0, t1, tstart;
   fga_run_stats st;
 
   memset(&st,0,sizeof(st));
-  t0 = fga_wall();
-  if (fga_gdb_open(root1,&g1) || fga_gix_open(root1,&x1)) goto done;
-  if (!self)
-    { if (fga_gdb_open(root2,&g2) || fga_gix_open(root2,&x2)) goto done; }
-  if (x1->nctg < g1->ncontig || (!self && x2->nctg < g2->ncontig))
-    { fga_set_error("genome index and genome database disagree on the number of contigs");
-      goto done;
-    }
-  st.load_s = fga_wall() - t0;
-
-  if (fga_dev_open(P->device,&dev)) goto done;
-  t0 = fga_wall();
-  if (fga_dgix_upload(dev,x1,&d1)) goto done;
-  if (!self && fga_dgix_upload(dev,x2,&d2)) goto done;
-  if (fga_dgenome_upload(dev,g1,x1->perm,x1->nctg,1,&dg1)) goto done;
-  if (self)
-    dg2 = dg1;
-  else if (fga_dgenome_upload(dev,g2,x2->perm,x2->nctg,0,&dg2)) goto done;
-  st.upload_s = fga_wall() - t0;
-
+  st.load_s = Z->load_s; st.upload_s = Z->upload_s;
+  tstart = fga_wall();
   /* ---- phase 1 ---- */
   t0 = fga_wall();
   { fga_merge_params mp;
     int rc;
     memset(&mp,0,sizeof(mp));
     mp.freq = P->freq; mp.soft_mask = P->soft_mask; mp.flip = 0;
-    rc = fga_seed_merge(dev,d1,self ? NULL : d2,&mp,0,&seeds);
+    rc = fga_seed_merge(dev,d1,self ? NULL : d2,&mp,
+                        (P->symmetric && !self) ? 2*(x1->nents + x2->nents) + (1<<20) : 0,&seeds);
     if (rc == 2)
       { int64_t need = fga_seeds_count(seeds) + 1024;
         fga_seeds_free(seeds); seeds = NULL;
@@ -97,13 +146,14 @@ int fga_run(const char *root1, const char *root2, const fga_run_params *P, fga_r
     int wa, wb, wd, wt;
     fga_chain_params cp;
     fga_keys_layout(keys,&wa,&wb,&wd,&wt);
-    hkeys = malloc(16*(size_t) (n+1));
+    const void *pk;
     alen  = malloc(sizeof(int64_t)*x1->nctg);
-    if (hkeys == NULL || alen == NULL)
+    if (alen == NULL)
       { fga_set_error("out of memory");
         goto done;
       }
-    if (fga_keys_download(keys,hkeys,n)) goto done;
+    pk = fga_keys_download_pinned(keys);
+    if (pk == NULL) goto done;
     fga_keys_free(keys); keys = NULL;
     for (i = 0; i < x1->nctg; i++)
       alen[i] = (x1->perm[i] < g1->ncontig) ? g1->contigs[x1->perm[i]].clen : FGA_KMER;
@@ -112,8 +162,7 @@ int fga_run(const char *root1, const char *root2, const fga_run_params *P, fga_r
     cp.alen = alen;
     st.download_s = fga_wall() - t1;
     t1 = fga_wall();
-    if (fga_chain_scan(hkeys,n,wa,wb,wd,wt,&cp,P->nthreads,&hits)) goto done;
-    free(hkeys); hkeys = NULL;
+    if (fga_chain_scan(pk,n,wa,wb,wd,wt,&cp,P->nthreads,&hits)) goto done;
     st.nhits = hits->nhits;
     st.nunits = hits->nunits;
     st.chain_s = fga_wall() - t1;
@@ -152,12 +201,12 @@ int fga_run(const char *root1, const char *root2, const fga_run_params *P, fga_r
       int rc;
       if (asprintf(&n1,"%s",g1->path) < 0) n1 = NULL;
       if (!self && asprintf(&n2,"%s",g2->path) < 0) n2 = NULL;
-      rc = fga_write_1aln(P->out_path,g1,self ? NULL : g2,fin,100,n1 ? n1 : root1,n2,cmd);
+      rc = fga_write_1aln(P->out_path,g1,self ? NULL : g2,fin,100,n1 ? n1 : "genome1",n2,cmd);
       free(n1); free(n2);
       if (rc) goto done;
     }
   st.write_s = fga_wall() - t1;
-  st.phase23_s = fga_wall() - t0 - 0;
+  st.phase23_s = fga_wall() - tstart;
   status = 0;
 
 done:
@@ -167,11 +216,15 @@ done:
   fga_hits_free(hits);
   fga_keys_free(keys);
   fga_seeds_free(seeds);
-  if (dg2 != dg1) fga_dgenome_free(dg2);
-  fga_dgenome_free(dg1);
-  fga_dgix_free(d2); fga_dgix_free(d1);
-  fga_dev_close(dev);
-  fga_gix_close(x2); fga_gix_close(x1);
-  fga_gdb_close(g2); fga_gdb_close(g1);
   return status;
+}
+
+int fga_run(const char *root1, const char *root2, const fga_run_params *P, fga_run_stats *S)
+{ fga_session *Z;
+  int rc;
+  if (fga_session_open(root1,root2,P->device,&Z))
+    return 1;
+  rc = fga_session_run(Z,P,S);
+  fga_session_close(Z);
+  return rc;
 }

@@ -285,14 +285,17 @@ extern "C" int fga_seed_sort(fga_dev *dev, const fga_dseeds *S, const fga_sort_p
   const int nch = (int) ((hm + SCAN_CH - 1) / SCAN_CH);
   hipError_t e;
   K->alloc_bytes = sizeof(uint4)*(size_t) n;
-  if ((e = hipMalloc(&buf[0],K->alloc_bytes)) != hipSuccess ||
-      (e = hipMalloc(&buf[1],K->alloc_bytes)) != hipSuccess ||
-      (e = hipMalloc(&hist,sizeof(uint32_t)*256*(size_t) ntiles)) != hipSuccess ||
-      (e = hipMalloc(&sums,sizeof(uint32_t)*(size_t) (nch+1))) != hipSuccess)
-    { fga_set_error("fga_seed_sort: device allocation failed: %s",hipGetErrorString(e));
-      hipFree(buf[0]); hipFree(buf[1]); hipFree(hist); hipFree(sums); free(K);
+  e = hipSuccess;
+  buf[0] = (uint4 *) fga_dev_acquire(dev,SLOT_SORT0,K->alloc_bytes);
+  buf[1] = (uint4 *) fga_dev_acquire(dev,SLOT_SORT1,K->alloc_bytes);
+  hist   = (uint32_t *) fga_dev_acquire(dev,SLOT_HIST,sizeof(uint32_t)*(256*(size_t) ntiles + nch + 1));
+  if (buf[0] == NULL || buf[1] == NULL || hist == NULL)
+    { fga_set_error("fga_seed_sort: device allocation failed");
+      fga_dev_release(dev,SLOT_SORT0,buf[0]); fga_dev_release(dev,SLOT_SORT1,buf[1]);
+      fga_dev_release(dev,SLOT_HIST,hist); free(K);
       return 1;
     }
+  sums = hist + 256*(size_t) ntiles;
   hipEventRecord(dev->ev0,dev->stream);
   const void *src = S->seeds;
   int cur = 0;
@@ -319,14 +322,15 @@ extern "C" int fga_seed_sort(fga_dev *dev, const fga_dseeds *S, const fga_sort_p
   if (e == hipSuccess) e = hipGetLastError();
   if (e != hipSuccess)
     { fga_set_error("fga_seed_sort: kernel failed: %s",hipGetErrorString(e));
-      hipFree(buf[0]); hipFree(buf[1]); hipFree(hist); hipFree(sums); free(K);
+      fga_dev_release(dev,SLOT_SORT0,buf[0]); fga_dev_release(dev,SLOT_SORT1,buf[1]);
+      fga_dev_release(dev,SLOT_HIST,hist); free(K);
       return 1;
     }
   hipEventElapsedTime(&dev->last_ms[FGA_STAGE_SORT],dev->ev0,dev->ev1);
   K->keys = (uint4 *) src;
-  hipFree(src == buf[0] ? buf[1] : buf[0]);
-  hipFree(hist);
-  hipFree(sums);
+  K->slot = (src == buf[0]) ? SLOT_SORT0 : SLOT_SORT1;
+  if (src == buf[0]) fga_dev_release(dev,SLOT_SORT1,buf[1]); else fga_dev_release(dev,SLOT_SORT0,buf[0]);
+  fga_dev_release(dev,SLOT_HIST,hist);
   *out = K;
   return 0;
 }
@@ -347,6 +351,23 @@ extern "C" void fga_keys_layout(const fga_dkeys *K, int *wa, int *wb, int *wd, i
 extern "C" void fga_keys_free(fga_dkeys *K)
 { if (K == NULL) return;
   hipSetDevice(K->dev->device);
-  hipFree(K->keys);
+  fga_dev_release(K->dev,K->slot,K->keys);
   free(K);
+}
+
+// zero-copy variant for the pipeline: keys land in the device context's pinned staging buffer
+extern "C" const void *fga_keys_download_pinned(const fga_dkeys *K)
+{ if (hipSetDevice(K->dev->device) != hipSuccess) return NULL;
+  void *h = fga_dev_pinned(K->dev,sizeof(uint4)*(size_t) (K->count+1));
+  if (h == NULL)
+    { fga_set_error("fga_keys_download_pinned: cannot allocate %lld bytes of pinned memory",
+                    (long long) (sizeof(uint4)*(K->count+1)));
+      return NULL;
+    }
+  if (K->count > 0 &&
+      hipMemcpy(h,K->keys,sizeof(uint4)*(size_t) K->count,hipMemcpyDeviceToHost) != hipSuccess)
+    { fga_set_error("fga_keys_download_pinned: copy failed");
+      return NULL;
+    }
+  return h;
 }

@@ -270,3 +270,33 @@ def run(root1, root2=None, out_path=None, device=0, freq=10, soft_mask=False, sy
     st = RunStats()
     check(L.fga_run(root1.encode(), root2.encode() if root2 else None, C.byref(prm), C.byref(st)), "fga_run")
     return {n: getattr(st, n) for n, _ in RunStats._fields_}
+
+
+class Session:
+    """inputs resident in HBM; run() is one pass of the hot path (fga_session_*)."""
+
+    def __init__(self, root1, root2=None, device=0):
+        self.L = load_library()
+        self.h = C.c_void_p()
+        check(self.L.fga_session_open(root1.encode(), root2.encode() if root2 else None, device, C.byref(self.h)),
+              "open session")
+        self.table_bytes = self.L.fga_session_table_bytes(self.h)
+        self.seed_bytes = self.L.fga_session_seed_bytes(self.h)
+        self.bases = (self.L.fga_session_bases(self.h, 0), self.L.fga_session_bases(self.h, 1))
+
+    def run(self, out_path=None, freq=10, soft_mask=False, symmetric=False, chain_break=1000, chain_min=85,
+            align_min=100, identity=0.7, nthreads=8, command_line="FastGA"):
+        from .lib import RunParams, RunStats
+        prm = RunParams(0, freq, int(soft_mask), int(symmetric), 2 * chain_break, 2 * chain_min, align_min,
+                        1.0 - identity, nthreads, out_path.encode() if out_path else None, command_line.encode())
+        st = RunStats()
+        check(self.L.fga_session_run(self.h, C.byref(prm), C.byref(st)), "session run")
+        return {n: getattr(st, n) for n, _ in RunStats._fields_}
+
+    def sync(self):
+        check(self.L.fga_dev_sync(self.L.fga_session_device(self.h)), "sync")
+
+    def close(self):
+        if self.h:
+            self.L.fga_session_close(self.h)
+            self.h = C.c_void_p()

@@ -126,6 +126,7 @@ def _declare(L):
         "fga_keys_count": (i64, [vp]),
         "fga_keys_layout": (None, [vp, P(i32), P(i32), P(i32), P(i32)]),
         "fga_keys_download": (i32, [vp, vp, i64]),
+        "fga_keys_download_pinned": (vp, [vp]),
         "fga_keys_free": (None, [vp]),
         "fga_chain_scan": (i32, [vp, i64, i32, i32, i32, i32, P(ChainParams), i32, P(P(Hits))]),
         "fga_hits_create": (i32, [vp, i64, vp, i64, P(P(Hits))]),
@@ -143,6 +144,13 @@ def _declare(L):
         "fga_filter_alignments": (i32, [P(Alns), P(P(Alns))]),
         "fga_write_1aln": (i32, [cp, vp, vp, P(Alns), i32, cp, cp, cp]),
         "fga_run": (i32, [cp, cp, P(RunParams), P(RunStats)]),
+        "fga_session_open": (i32, [cp, cp, i32, P(vp)]),
+        "fga_session_run": (i32, [vp, P(RunParams), P(RunStats)]),
+        "fga_session_close": (None, [vp]),
+        "fga_session_device": (vp, [vp]),
+        "fga_session_table_bytes": (i64, [vp]),
+        "fga_session_seed_bytes": (i32, [vp]),
+        "fga_session_bases": (i64, [vp, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

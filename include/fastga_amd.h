@@ -106,6 +106,7 @@ int     fga_seed_sort(fga_dev *dev, const fga_dseeds *seeds, const fga_sort_para
 int64_t fga_keys_count(const fga_dkeys *keys);
 void    fga_keys_layout(const fga_dkeys *keys, int *wa, int *wb, int *wd, int *wt);
 int     fga_keys_download(const fga_dkeys *keys, void *host /* 16 B per key: lo64, hi64 */, int64_t max);
+const void *fga_keys_download_pinned(const fga_dkeys *keys);  /* into the device context's pinned staging buffer */
 void    fga_keys_free(fga_dkeys *keys);
 
 /* ---- chain detection: replaces the chain scan of align_contigs (FastGA.c:3016-3176, 3340-3403) ------------ */
@@ -215,6 +216,16 @@ typedef struct
   } fga_run_stats;
 
 int  fga_run(const char *root1, const char *root2 /* NULL: self */, const fga_run_params *prm, fga_run_stats *stats);
+
+/* the same with the inputs kept resident in HBM between passes (what bench.py times) */
+typedef struct fga_session fga_session;
+int      fga_session_open(const char *root1, const char *root2, int device, fga_session **out);
+int      fga_session_run(fga_session *s, const fga_run_params *prm, fga_run_stats *stats);
+void     fga_session_close(fga_session *s);
+fga_dev *fga_session_device(fga_session *s);
+int64_t  fga_session_table_bytes(const fga_session *s);   /* N1*E1 + N2*E2                          */
+int      fga_session_seed_bytes(const fga_session *s);    /* 1 + IBYTE + JBYTE of the reference seed */
+int64_t  fga_session_bases(const fga_session *s, int which);
 
 #ifdef __cplusplus
 }
