@@ -174,22 +174,63 @@ int fga_write_1aln(const char *path, const fga_gdb *g1, const fga_gdb *g2, const
   if (g2 != NULL)
     write_skeleton(f,g2);
 
-  for (i = 0; i < A->naln; i++)
-    { const fga_aln *a = A->alns+i;
-      const uint8_t *tr = A->tbytes + a->toff;
-      int x;
-      fprintf(f,"A %d %d %d %d %d %d\n",a->aread,a->abpos,a->aepos,a->bread,a->bbpos,a->bepos);
-      if (a->flags & 1)
-        fprintf(f,"R\n");
-      fprintf(f,"D %d\n",a->diffs);
-      fprintf(f,"T %d",a->tlen/2);
-      for (x = 1; x < a->tlen; x += 2)
-        fprintf(f," %d",tr[x]);
-      fprintf(f,"\nX %d",a->tlen/2);
-      for (x = 0; x < a->tlen; x += 2)
-        fprintf(f," %d",tr[x]);
-      fprintf(f,"\n");
+  { /* the record body dominates the file: format it by hand into a large buffer */
+    size_t cap = (size_t) 1 << 22, len = 0;
+    char *buf = malloc(cap + 65536);
+    if (buf == NULL)
+      { fga_set_error("out of memory");
+        fclose(f);
+        free(obuf);
+        return 1;
+      }
+#define PUT_INT(v)                                                     \
+    { unsigned _u; int _n = 0; char _t[12]; int _v = (v);              \
+      if (_v < 0) { buf[len++] = '-'; _u = (unsigned) (-(long long) _v); } else _u = (unsigned) _v; \
+      do { _t[_n++] = (char) ('0' + _u % 10); _u /= 10; } while (_u);  \
+      while (_n) buf[len++] = _t[--_n];                                \
     }
+    for (i = 0; i < A->naln; i++)
+      { const fga_aln *a = A->alns+i;
+        const uint8_t *tr = A->tbytes + a->toff;
+        int x, q;
+        int fld[6];
+        fld[0] = a->aread; fld[1] = a->abpos; fld[2] = a->aepos; fld[3] = a->bread; fld[4] = a->bbpos; fld[5] = a->bepos;
+        buf[len++] = 'A';
+        for (q = 0; q < 6; q++)
+          { buf[len++] = ' ';
+            PUT_INT(fld[q])
+          }
+        buf[len++] = '\n';
+        if (a->flags & 1)
+          { buf[len++] = 'R'; buf[len++] = '\n'; }
+        buf[len++] = 'D'; buf[len++] = ' ';
+        PUT_INT(a->diffs)
+        buf[len++] = '\n';
+        for (q = 1; q >= 0; q--)
+          { buf[len++] = q ? 'T' : 'X'; buf[len++] = ' ';
+            PUT_INT(a->tlen/2)
+            for (x = q; x < a->tlen; x += 2)
+              { unsigned v = tr[x];
+                buf[len++] = ' ';
+                if (v >= 100) { buf[len++] = (char) ('0' + v/100); v %= 100; buf[len++] = (char) ('0' + v/10); buf[len++] = (char) ('0' + v%10); }
+                else if (v >= 10) { buf[len++] = (char) ('0' + v/10); buf[len++] = (char) ('0' + v%10); }
+                else buf[len++] = (char) ('0' + v);
+                if (len >= cap)
+                  { fwrite(buf,1,len,f);
+                    len = 0;
+                  }
+              }
+            buf[len++] = '\n';
+          }
+        if (len >= cap)
+          { fwrite(buf,1,len,f);
+            len = 0;
+          }
+      }
+    if (len > 0)
+      fwrite(buf,1,len,f);
+    free(buf);
+  }
   if (fclose(f) != 0)
     { fga_set_error("IO error writing %s",path);
       free(obuf);

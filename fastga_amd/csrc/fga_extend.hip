@@ -35,18 +35,35 @@
 #define BIGI        0x7fffffff
 #define BUCK_ANTI   128
 
+#define WDW         512                 // dwords per LDS sequence window (8192 bases)
+#define WINB        (WDW*16)
+
+#define LDS_PTR __attribute__((address_space(3)))
+
 struct ext_seq
   { const uint32_t *img;      // padded 2-bit image as dwords (16 bases per dword, base i in bits 2*(i&15))
     int64_t base;             // base index of contig position 0 inside img
     int     len;
+    LDS_PTR uint32_t *win;    // LDS window: a dword-aligned copy of img[p0/16 .. p0/16 + WDW)
+    int64_t  p0;              // image base index of the window start (multiple of 16); -1: empty
   };
 
-struct ext_shared             // one per workgroup (= one wavefront)
+// One workgroup = one wavefront.  LDS operations of one wavefront complete in order, so lanes see each other's
+// writes without s_barrier; WAVE_SYNC() is only a compiler-level wavefront-scope fence (no re-ordering, no stale
+// register copies of LDS).  A __syncthreads() here would also wait for the outstanding pebble stores to HBM.
+#define WAVE_SYNC()  do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL,"wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+struct ext_shared
   { int      V[2][RC];
     int      HA[2][RC];
+    int      HM[2][RC];     // mark of the pebble HA points at (saves a dependent HBM read per crossing)
     uint64_t T[2][RC];
     int      NA[RC];
+    uint32_t winA[WDW+4];     // sliding windows of the two packed sequences around the wave front
+    uint32_t winB[WDW+4];
   };
+
+struct ext_prof
+  { unsigned long long t_steps, t_unwind, t_total, nsteps, ph[6]; };
 
 struct ext_state              // wave-uniform alignment state (the reference's Path + trace pointer)
   { int abpos, bbpos, aepos, bepos, diffs, tlen;
@@ -65,7 +82,7 @@ struct ext_args
     const int      *order;               // units by decreasing estimated work
     int            *next;                // work-queue head
     // alignment parameters
-    int   tspace, path_ave, self, aln_min;
+    int   tspace, path_ave, self, aln_min, mscore;
     double aln_rate;
     const int16_t *table, *score;
     // scratch (per workgroup)
@@ -82,9 +99,17 @@ struct ext_args
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t fetch32(const ext_seq &s, int64_t pos)
 { int64_t p = s.base + pos;
-  int64_t w = p >> 4;
   int sh = (int) (p & 15) * 2;
-  uint32_t d0 = s.img[w], d1 = s.img[w+1], d2 = s.img[w+2];
+  uint32_t d0, d1, d2;
+  int64_t q = p - s.p0;
+  if (s.p0 >= 0 && q >= 0 && q + 48 <= WINB)          // inside the LDS window
+    { int w = (int) (q >> 4);
+      d0 = s.win[w]; d1 = s.win[w+1]; d2 = s.win[w+2];
+    }
+  else
+    { int64_t w = p >> 4;
+      d0 = s.img[w]; d1 = s.img[w+1]; d2 = s.img[w+2];
+    }
   uint64_t lo = ((uint64_t) d1 << 32) | d0;
   uint64_t v = lo >> sh;
   if (sh)
@@ -130,44 +155,107 @@ __device__ __forceinline__ int base_at(const ext_seq &s, int pos)     // 0..3, o
 // ---------------------------------------------------------------------------------------------------
 // wave-wide helpers (all 64 lanes must call)
 // ---------------------------------------------------------------------------------------------------
+// Wave64 scans on the DPP cross-lane network (row_shr 1/2/4/8 inside rows of 16, then row_bcast:15 / row_bcast:31
+// across rows) instead of ds_bpermute round trips through the LDS crossbar: 6 VALU-rate ops per scan.
+#define DPP_STEP(OPX,CTRL,RMASK_)                                                   \
+  { int _t = __builtin_amdgcn_update_dpp(ID,x,CTRL,RMASK_,0xf,false); x = OPX; }
+
+__device__ __forceinline__ int rdlane(int v, int l)      // l is wave-uniform
+{ return __builtin_amdgcn_readlane(v,l); }
+
 __device__ __forceinline__ int wscan_add_excl(int v, int &total)
-{ int lane = threadIdx.x & 63, x = v;
-  #pragma unroll
-  for (int d = 1; d < 64; d <<= 1)
-    { int y = __shfl_up(x,d,64);
-      if (lane >= d) x += y;
-    }
-  total = __shfl(x,63,64);
+{ const int ID = 0;
+  int x = v;
+  DPP_STEP(x+_t,0x111,0xf) DPP_STEP(x+_t,0x112,0xf) DPP_STEP(x+_t,0x114,0xf) DPP_STEP(x+_t,0x118,0xf)
+  DPP_STEP(x+_t,0x142,0xa) DPP_STEP(x+_t,0x143,0xc)
+  total = rdlane(x,63);
   return x - v;
 }
 
 template <int S>
 __device__ __forceinline__ int wscan_best_excl(int v)     // exclusive prefix max (S>0) / min (S<0) in lane order
-{ int lane = threadIdx.x & 63, x = v;
-  #pragma unroll
-  for (int d = 1; d < 64; d <<= 1)
-    { int y = __shfl_up(x,d,64);
-      if (lane >= d) x = (S > 0) ? (x > y ? x : y) : (x < y ? x : y);
+{ const int ID = (S > 0) ? -BIGI : BIGI;
+  int x = v;
+  if (S > 0)
+    { DPP_STEP(x > _t ? x : _t,0x111,0xf) DPP_STEP(x > _t ? x : _t,0x112,0xf) DPP_STEP(x > _t ? x : _t,0x114,0xf)
+      DPP_STEP(x > _t ? x : _t,0x118,0xf) DPP_STEP(x > _t ? x : _t,0x142,0xa) DPP_STEP(x > _t ? x : _t,0x143,0xc)
     }
-  int p = __shfl_up(x,1,64);
-  if (lane == 0) p = (S > 0) ? -BIGI : BIGI;
-  return p;
+  else
+    { DPP_STEP(x < _t ? x : _t,0x111,0xf) DPP_STEP(x < _t ? x : _t,0x112,0xf) DPP_STEP(x < _t ? x : _t,0x114,0xf)
+      DPP_STEP(x < _t ? x : _t,0x118,0xf) DPP_STEP(x < _t ? x : _t,0x142,0xa) DPP_STEP(x < _t ? x : _t,0x143,0xc)
+    }
+  return __builtin_amdgcn_update_dpp(ID,x,0x138,0xf,0xf,false);     // wave_shr:1 -> exclusive
 }
 
 __device__ __forceinline__ int last_lane(uint64_t m)  { return 63 - __clzll((long long) m); }
 __device__ __forceinline__ int first_lane(uint64_t m) { return __ffsll((unsigned long long) m) - 1; }
+
+// TABLE / SCORE of the reference's Align_Spec (align.c:207-218) evaluated on the fly: for a 15-bit match
+// pattern p (most significant bit = oldest column) with match = +ms and mismatch = -(1000-ms),
+//   score(p) = sum over the 15 columns,   table(p) = score(p) - max over proper prefixes (incl. empty) of the prefix sum
+// both truncated to int16 exactly like the stored tables.  ~60 integer ops instead of two dependent HBM/L2 reads.
+__device__ __forceinline__ int trim_score(uint32_t p, int ms)
+{ int ones = __popc(p);
+  return (int) (int16_t) (ms*ones - (1000-ms)*(15-ones));
+}
+
+__device__ __forceinline__ int trim_table(uint32_t p, int ms)
+{ int score = 0, mx = 0;
+  const int ds = 1000-ms;
+  #pragma unroll
+  for (int i = 14; i >= 0; i--)
+    { mx = score > mx ? score : mx;
+      score += ((p >> i) & 1) ? ms : -ds;
+    }
+  return (int) (int16_t) (score - mx);
+}
+
+
+// (re)load the LDS window of a sequence so that contig position `pos` sits `before` bases after its start;
+// wave-uniform, all lanes participate; the caller synchronises before the next fetch
+__device__ __forceinline__ void win_load(ext_seq &s, int pos, int before)
+{ int64_t p0 = (s.base + pos - before) & ~(int64_t) 15;
+  if (p0 < 0) p0 = 0;
+  const uint32_t *g = s.img + (p0 >> 4);
+  for (int i = threadIdx.x & 63; i < WDW; i += 64)
+    s.win[i] = g[i];
+  s.p0 = p0;
+}
+
+// keep [pos-lo, pos+hi] inside the window; S > 0 keeps most of the window ahead of pos, S < 0 behind it
+template <int S>
+__device__ __forceinline__ bool win_track(ext_seq &s, int pos)
+{ int64_t p = s.base + pos;
+  if (S > 0)
+    { if (s.p0 >= 0 && p - 384 >= s.p0 && p + 1536 <= s.p0 + WINB)
+        return false;
+      win_load(s,pos,512);
+    }
+  else
+    { if (s.p0 >= 0 && p + 384 <= s.p0 + WINB && p - 1536 >= s.p0)
+        return false;
+      win_load(s,pos,WINB-512);
+    }
+  return true;
+}
 
 // ---------------------------------------------------------------------------------------------------
 // one directional wave extension (S = +1 forward_wave, S = -1 reverse_wave)
 // returns 0 ok, 1 pebble arena full, 2 ring too narrow
 // ---------------------------------------------------------------------------------------------------
 template <int S>
-__device__ int ext_wave(const ext_args &G, ext_shared &sh, int4 *cells, uint16_t *trace,
-                        const ext_seq &A, const ext_seq &B, ext_state &P,
+__device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext_shared *shp, int4 *cells, uint16_t *trace,
+                        ext_seq &Ain, ext_seq &Bin, ext_state &P,
                         int &mind, int maxd, int mida, int minp, int maxp, int aoff,
-                        unsigned long long &nwaves)
+                        unsigned long long &nwaves_out, ext_prof &PF)
 { const int lane = threadIdx.x & 63;
-  const int ts = G.tspace;
+  const unsigned long long tstart = clock64();
+  // everything the wave loop touches lives in registers: by-reference arguments of a non-inlined device function
+  // sit in scratch (HBM-backed) memory, and a scratch access per step costs more than the step itself
+  ext_seq A = Ain, B = Bin;
+  unsigned long long nwaves = 0;
+  const int ts = G.tspace, path_ave = G.path_ave, mscore = G.mscore;
+  const int64_t cell_cap = G.cell_cap;
   const int VNEW = (S > 0) ? -1 : BIGI;
   int low = mind, hgh = maxd, dif = 0, cur = 0;
   int more = 1, avail = 0;
@@ -183,6 +271,10 @@ __device__ int ext_wave(const ext_args &G, ext_shared &sh, int4 *cells, uint16_t
 
   if (hgh-low+8 >= RC)
     return 2;
+
+  win_track<S>(A,bestx);
+  win_track<S>(B,mida-bestx);
+  WAVE_SYNC();
 
   // ---- wave 0 -------------------------------------------------------------------------------
   { const int span = hgh-low+1;
@@ -222,7 +314,7 @@ __device__ int ext_wave(const ext_args &G, ext_shared &sh, int4 *cells, uint16_t
             else       cnt = (x <= na) ? (na-x)/ts+1 : 0;
           }
         int tot, off = wscan_add_excl(act ? 1+cnt : 0,tot);
-        if ((int64_t) avail + tot > G.cell_cap)
+        if ((int64_t) avail + tot > cell_cap)
           return 1;
         int ha = -1;
         if (act)
@@ -235,10 +327,11 @@ __device__ int ext_wave(const ext_args &G, ext_shared &sh, int4 *cells, uint16_t
                 ha = idx;
                 na += S*ts;
               }
-            sh.V[0][k & RMASK] = c;
-            sh.T[0][k & RMASK] = PATH_INT;
-            sh.HA[0][k & RMASK] = ha;
-            sh.NA[k & RMASK] = na;
+            shp->V[0][k & RMASK] = c;
+            shp->T[0][k & RMASK] = PATH_INT;
+            shp->HA[0][k & RMASK] = ha;
+            shp->HM[0][k & RMASK] = (cnt > 0) ? na - S*ts : mark0;
+            shp->NA[k & RMASK] = na;
           }
         avail += tot;
         // strict best in sweep order
@@ -247,25 +340,25 @@ __device__ int ext_wave(const ext_args &G, ext_shared &sh, int4 *cells, uint16_t
         uint64_t rm = __ballot(rec);
         if (rm)
           { int l = last_lane(rm);
-            besta = trima = lasta = __shfl(c,l,64);
-            bestx = trimx = __shfl(x,l,64);
-            trimha = __shfl(ha,l,64);
+            besta = trima = lasta = rdlane(c,l);
+            bestx = trimx = rdlane(x,l);
+            trimha = rdlane(ha,l);
           }
         uint64_t am = __ballot(hitA), bm = __ballot(hitB);
         if (am | bm) more = 0;
-        if (am) aclip = __shfl(k,last_lane(am),64);
-        if (bm && ((S > 0) ? bclip == -BIGI : bclip == BIGI)) bclip = __shfl(k,first_lane(bm),64);
+        if (am) aclip = rdlane(k,last_lane(am));
+        if (bm && ((S > 0) ? bclip == -BIGI : bclip == BIGI)) bclip = rdlane(k,first_lane(bm));
       }
   }
-  __syncthreads();
+  WAVE_SYNC();
 
 #define CLIP_FROM(kk,withd)                                                           \
-  { uint64_t tt = sh.T[cur][(kk) & RMASK];                                            \
+  { uint64_t tt = shp->T[cur][(kk) & RMASK];                                            \
     int mm = __popcll(tt & WIN61);                                                    \
     if (morem <= mm)                                                                  \
-      { morem = mm; morea = sh.V[cur][(kk) & RMASK]; morex = (morea+(kk))>>1;         \
+      { morem = mm; morea = shp->V[cur][(kk) & RMASK]; morex = (morea+(kk))>>1;         \
         if (withd) mored = dif;                                                       \
-        moreha = sh.HA[cur][(kk) & RMASK];                                            \
+        moreha = shp->HA[cur][(kk) & RMASK];                                            \
       }                                                                               \
   }
 
@@ -298,17 +391,19 @@ __device__ int ext_wave(const ext_args &G, ext_shared &sh, int4 *cells, uint16_t
       hgh += 1;
       if (lane == 0)
         { if (low >= minp)
-            { sh.NA[low & RMASK] = sh.NA[(low+1) & RMASK]; sh.V[cur][low & RMASK] = VNEW; }
+            { shp->NA[low & RMASK] = shp->NA[(low+1) & RMASK]; shp->V[cur][low & RMASK] = VNEW; }
           if (hgh <= maxp)
-            { sh.NA[hgh & RMASK] = sh.NA[(hgh-1) & RMASK]; sh.V[cur][hgh & RMASK] = VNEW; }
+            { shp->NA[hgh & RMASK] = shp->NA[(hgh-1) & RMASK]; shp->V[cur][hgh & RMASK] = VNEW; }
         }
       if (low < minp) low += 1;
       if (hgh > maxp) hgh -= 1;
       dif += 1;
       if (lane == 0)
-        sh.V[cur][(hgh+1) & RMASK] = sh.V[cur][(low-1) & RMASK] = VNEW;
-      __syncthreads();
-
+        shp->V[cur][(hgh+1) & RMASK] = shp->V[cur][(low-1) & RMASK] = VNEW;
+      win_track<S>(A,bestx);
+      win_track<S>(B,besta-bestx);
+      WAVE_SYNC();
+    
       const int span = hgh-low+1;
       const int nxt = cur^1;
       uint64_t anyA = 0, anyB = 0;
@@ -316,12 +411,12 @@ __device__ int ext_wave(const ext_args &G, ext_shared &sh, int4 *cells, uint16_t
         { const int j = j0 + lane;
           const bool act = j < span;
           const int k = (S > 0) ? hgh-j : low+j;
-          int x = 0, c = 0, ha = -1, hitA = 0, hitB = 0, ncreate = 0, na = 0, cross = 0;
+          int x = 0, c = 0, ha = -1, hm = 0, hitA = 0, hitB = 0, ncreate = 0, na = 0, cross = 0;
           uint64_t b = 0;
           if (act)
-            { int ac = sh.V[cur][k & RMASK];
-              int a1 = sh.V[cur][(k-S) & RMASK];
-              int a2 = sh.V[cur][(k+S) & RMASK];
+            { int ac = shp->V[cur][k & RMASK];
+              int a1 = shp->V[cur][(k-S) & RMASK];
+              int a2 = shp->V[cur][(k+S) & RMASK];
               int src;
               if (S > 0)
                 { if (ac < a1) src = (a1 < a2) ? k+S : k-S;
@@ -332,8 +427,9 @@ __device__ int ext_wave(const ext_args &G, ext_shared &sh, int4 *cells, uint16_t
                   else         src = (ac > a2) ? k+S : k;
                 }
               c  = (src == k) ? ac + 2*S : ((src == k-S) ? a1 : a2) + S;
-              b  = sh.T[cur][src & RMASK];
-              ha = sh.HA[cur][src & RMASK];
+              b  = shp->T[cur][src & RMASK];
+              ha = shp->HA[cur][src & RMASK];
+              hm = shp->HM[cur][src & RMASK];
               b <<= 1;
               x = (c+k)>>1;
               int y = x-k, L;
@@ -354,11 +450,11 @@ __device__ int ext_wave(const ext_args &G, ext_shared &sh, int4 *cells, uint16_t
               if (L > 0)
                 b = (L >= 61) ? ~0ull : ((b << L) | ((1ull << L) - 1));
               c = (x << 1) - k;
-              na = sh.NA[k & RMASK];
+              na = shp->NA[k & RMASK];
               if (S > 0) cross = (x >= na) ? (x-na)/ts+1 : 0;
               else       cross = (x <= na) ? (na-x)/ts+1 : 0;
               if (cross > 0)
-                { int mk = cells[ha].w;
+                { int mk = hm;
                   // crossings strictly beyond the head's mark get a pebble
                   int skip;
                   if (S > 0) skip = (mk >= na) ? (mk-na)/ts+1 : 0;
@@ -371,7 +467,7 @@ __device__ int ext_wave(const ext_args &G, ext_shared &sh, int4 *cells, uint16_t
           uint64_t cm = __ballot(ncreate > 0);
           if (cm)
             { off = wscan_add_excl(ncreate,tot);
-              if ((int64_t) avail + tot > G.cell_cap)
+              if ((int64_t) avail + tot > cell_cap)
                 return 1;
             }
           if (act)
@@ -381,15 +477,17 @@ __device__ int ext_wave(const ext_args &G, ext_shared &sh, int4 *cells, uint16_t
                   for (int q = 0; q < ncreate; q++)
                     { cells[idx] = make_int4(ha,k,dif,v);
                       ha = idx;
+                      hm = v;
                       idx += 1;
                       v += S*ts;
                     }
                 }
               if (cross > 0)
-                sh.NA[k & RMASK] = na + S*ts*cross;
-              sh.V[nxt][k & RMASK] = c;
-              sh.T[nxt][k & RMASK] = b;
-              sh.HA[nxt][k & RMASK] = ha;
+                shp->NA[k & RMASK] = na + S*ts*cross;
+              shp->V[nxt][k & RMASK] = c;
+              shp->T[nxt][k & RMASK] = b;
+              shp->HA[nxt][k & RMASK] = ha;
+              shp->HM[nxt][k & RMASK] = hm;
             }
           avail += tot;
 
@@ -399,38 +497,38 @@ __device__ int ext_wave(const ext_args &G, ext_shared &sh, int4 *cells, uint16_t
           uint64_t rm = __ballot(rec);
           if (rm)
             { int l = last_lane(rm);
-              besta = __shfl(c,l,64);
-              bestx = __shfl(x,l,64);
+              besta = rdlane(c,l);
+              bestx = rdlane(x,l);
               int m = __popcll(b & WIN61);
-              bool good = rec && m >= G.path_ave;
+              bool good = rec && m >= path_ave;
               uint64_t gm = __ballot(good);
               if (gm)
-                { lasta = __shfl(c,last_lane(gm),64);
+                { lasta = rdlane(c,last_lane(gm));
                   bool trimok = false;
                   if (good)
-                    { int t1 = G.table[b & TRIM_MASK];
-                      if (t1 >= 0)
-                        trimok = (int) G.table[(b >> TRIM_LEN) & TRIM_MASK] + (int) G.score[b & TRIM_MASK] >= 0;
+                    { const uint32_t plo = (uint32_t) b & TRIM_MASK, phi = (uint32_t) (b >> TRIM_LEN) & TRIM_MASK;
+                      if (trim_table(plo,mscore) >= 0)
+                        trimok = trim_table(phi,mscore) + trim_score(plo,mscore) >= 0;
                     }
                   uint64_t tm = __ballot(trimok);
                   if (tm)
                     { int l2 = last_lane(tm);
-                      trima = __shfl(c,l2,64);
-                      trimx = __shfl(x,l2,64);
+                      trima = rdlane(c,l2);
+                      trimx = rdlane(x,l2);
                       trimd = dif;
-                      trimha = __shfl(ha,l2,64);
+                      trimha = rdlane(ha,l2);
                     }
                 }
             }
           uint64_t am = __ballot(hitA), bm = __ballot(hitB);
-          if (am) aclip = __shfl(k,last_lane(am),64);
-          if (bm && !anyB) bclip = __shfl(k,first_lane(bm),64);
+          if (am) aclip = rdlane(k,last_lane(am));
+          if (bm && !anyB) bclip = rdlane(k,first_lane(bm));
           anyA |= am; anyB |= bm;
         }
       if (anyA | anyB) more = 0;
       cur = nxt;
-      __syncthreads();
-
+      WAVE_SYNC();
+    
       CLIP_UPDATE(1)
 
       // prune both ends (align.c:782-790)
@@ -441,7 +539,7 @@ __device__ int ext_wave(const ext_args &G, ext_shared &sh, int4 *cells, uint16_t
           { int k = low + j0 + lane;
             bool keep = false;
             if (k <= hgh)
-              { int v = sh.V[cur][k & RMASK];
+              { int v = shp->V[cur][k & RMASK];
                 keep = (S > 0) ? (v >= n) : (v <= n);
               }
             uint64_t km = __ballot(keep);
@@ -466,6 +564,11 @@ __device__ int ext_wave(const ext_args &G, ext_shared &sh, int4 *cells, uint16_t
       trimy = trima - trimx;
 
     int rootk = 0;
+    const unsigned long long tun = clock64();
+    PF.t_steps += tun - tstart;
+    nwaves_out += nwaves;
+    Ain.p0 = A.p0; Bin.p0 = B.p0;
+    __syncthreads();          // once per call: all pebble stores of the wave are complete before the pointer chase
     if (lane == 0)
       { // walk tip -> root; pairs come out last-to-first
         if (S > 0)
@@ -564,27 +667,27 @@ __device__ int ext_wave(const ext_args &G, ext_shared &sh, int4 *cells, uint16_t
           }
       }
     // broadcast lane 0's results
-    P.tlen = __shfl(P.tlen,0,64);
-    P.tpos = __shfl(P.tpos,0,64);
-    rootk  = __shfl(rootk,0,64);
+    P.tlen = rdlane(P.tlen,0);
+    P.tpos = rdlane(P.tpos,0);
+    rootk  = rdlane(rootk,0);
     if (S > 0)
       { P.aepos = trimx; P.bepos = trimy; P.diffs = trimd;
         mind = rootk;
       }
     else
       { P.abpos = trimx; P.bbpos = trimy; P.diffs = P.diffs + trimd; }
+    PF.t_unwind += clock64() - tun;
   }
-  __syncthreads();
   return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------
 // Local_Alignment (align.c:1423-1576), wave-uniform
 // ---------------------------------------------------------------------------------------------------
-__device__ int local_alignment(const ext_args &G, ext_shared &sh, int4 *cells, uint16_t *trace, int64_t tmid,
-                               const ext_seq &A, const ext_seq &B, int acomp,
+__device__ int local_alignment(const ext_args &G, LDS_PTR ext_shared *sh, int4 *cells, uint16_t *trace, int64_t tmid,
+                               ext_seq &A, ext_seq &B, int acomp,
                                int low, int hgh, int anti, int lbord, int hbord,
-                               ext_state &P, unsigned long long &nwaves)
+                               ext_state &P, unsigned long long &nwaves, ext_prof &PF)
 { int minp, maxp, aoff, st;
   P.tpos = (int) tmid;
   P.tlen = 0;
@@ -594,10 +697,10 @@ __device__ int local_alignment(const ext_args &G, ext_shared &sh, int4 *cells, u
   maxp = (hbord < 0) ?  BIGI : hgh+hbord;
   aoff = acomp ? A.len % G.tspace : 0;
 
-  if ((st = ext_wave<+1>(G,sh,cells,trace,A,B,P,low,hgh,anti,minp,maxp,aoff,nwaves)) != 0) return st;
+  if ((st = ext_wave<+1>(G,sh,cells,trace,A,B,P,low,hgh,anti,minp,maxp,aoff,nwaves,PF)) != 0) return st;
   int fshort = ((P.aepos + P.bepos) - anti < DUB_TRIM);
   { int l2 = low;
-    if ((st = ext_wave<-1>(G,sh,cells,trace,A,B,P,l2,low,anti,minp,maxp,aoff,nwaves)) != 0) return st;
+    if ((st = ext_wave<-1>(G,sh,cells,trace,A,B,P,l2,low,anti,minp,maxp,aoff,nwaves,PF)) != 0) return st;
   }
   int rshort = (anti - (P.abpos + P.bbpos) < DUB_TRIM);
   if (fshort)
@@ -610,7 +713,7 @@ __device__ int local_alignment(const ext_args &G, ext_shared &sh, int4 *cells, u
         { low  = P.abpos - P.bbpos;
           anti = P.abpos + P.bbpos;
           P.tlen = 0;
-          if ((st = ext_wave<+1>(G,sh,cells,trace,A,B,P,low,low,anti,minp,maxp,aoff,nwaves)) != 0) return st;
+          if ((st = ext_wave<+1>(G,sh,cells,trace,A,B,P,low,low,anti,minp,maxp,aoff,nwaves,PF)) != 0) return st;
         }
     }
   else if (rshort)
@@ -618,7 +721,7 @@ __device__ int local_alignment(const ext_args &G, ext_shared &sh, int4 *cells, u
       anti = P.aepos + P.bepos;
       P.tlen = 0;
       P.diffs = 0;
-      if ((st = ext_wave<-1>(G,sh,cells,trace,A,B,P,low,low,anti,minp,maxp,aoff,nwaves)) != 0) return st;
+      if ((st = ext_wave<-1>(G,sh,cells,trace,A,B,P,low,low,anti,minp,maxp,aoff,nwaves,PF)) != 0) return st;
     }
   if (acomp)
     { int i = P.abpos; P.abpos = A.len - P.aepos; P.aepos = A.len - i;
@@ -633,12 +736,16 @@ __device__ int local_alignment(const ext_args &G, ext_shared &sh, int4 *cells, u
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64)
 void extend_kernel(ext_args G)
-{ __shared__ ext_shared sh;
+{ __shared__ ext_shared sh_storage;
+  LDS_PTR ext_shared *sh = (LDS_PTR ext_shared *) &sh_storage;
   const int lane = threadIdx.x;
   int4     *cells = G.cells + (int64_t) blockIdx.x * G.cell_cap;
   uint16_t *trace = G.trace + (int64_t) blockIdx.x * G.trace_cap;
   const int64_t tmid = G.trace_cap/2;
   unsigned long long ncalls = 0, nwaves = 0;
+  ext_prof PF; PF.t_steps = PF.t_unwind = PF.t_total = PF.nsteps = 0;
+  for (int q = 0; q < 6; q++) PF.ph[q] = 0;
+  const unsigned long long tk0 = clock64();
 
   while (1)
     { int ui = 0;
@@ -654,6 +761,8 @@ void extend_kernel(ext_args G)
       ext_seq A, B;
       A.len = (int) G.clenA[ctg1];
       B.len = (int) G.clenB[ctg2];
+      A.win = (LDS_PTR uint32_t *) sh->winA; A.p0 = -1;
+      B.win = (LDS_PTR uint32_t *) sh->winB; B.p0 = -1;
       B.img = G.imgB; B.base = (G.padB + G.boffB[ctg2]) * 4;
       if (comp)
         { A.img = G.imgAr; A.base = (G.padA + G.boffA[ctg1]) * 4; }
@@ -688,14 +797,14 @@ void extend_kernel(ext_args G)
               int st = 0, called = 1;
               if (self)
                 { if (dgmin > 0)
-                    st = local_alignment(G,sh,cells,trace,tmid,A,B,comp,dgmin,dgmax,(int) amid,dgmin-1,-1,P,nwaves);
+                    st = local_alignment(G,sh,cells,trace,tmid,A,B,comp,dgmin,dgmax,(int) amid,dgmin-1,-1,P,nwaves,PF);
                   else if (dgmax < 0)
-                    st = local_alignment(G,sh,cells,trace,tmid,A,B,comp,dgmin,dgmax,(int) amid,-1,-(dgmax+1),P,nwaves);
+                    st = local_alignment(G,sh,cells,trace,tmid,A,B,comp,dgmin,dgmax,(int) amid,-1,-(dgmax+1),P,nwaves,PF);
                   else
                     { P.abpos = P.aepos = 0; called = 0; }
                 }
               else
-                st = local_alignment(G,sh,cells,trace,tmid,A,B,comp,dgmin,dgmax,(int) amid,-1,-1,P,nwaves);
+                st = local_alignment(G,sh,cells,trace,tmid,A,B,comp,dgmin,dgmax,(int) amid,-1,-1,P,nwaves,PF);
               ncalls += called;
               if (st != 0)
                 { if (lane == 0)
@@ -750,6 +859,12 @@ void extend_kernel(ext_args G)
   if (lane == 0)
     { atomicAdd(G.counters+2,ncalls);
       atomicAdd(G.counters+3,nwaves);
+      atomicMax(G.counters+5,PF.t_steps);
+      atomicMax(G.counters+6,PF.t_unwind);
+      atomicMax(G.counters+7,clock64()-tk0);
+      atomicAdd(G.counters+8,PF.t_steps);
+      atomicAdd(G.counters+9,PF.t_unwind);
+      atomicMax(G.counters+10,nwaves);
     }
 }
 
@@ -780,7 +895,7 @@ __global__ void revcomp_kernel(const uint8_t *fwd, uint8_t *rc, const int64_t *b
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
-#define IMG_PAD 64      // bytes of zero padding before and after a genome image
+#define IMG_PAD 4096    // bytes of zero padding before and after a genome image (>= one LDS window)
 
 extern "C" int fga_dgenome_upload(fga_dev *dev, const fga_gdb *G, const int *perm, int nperm, int want_revcomp,
                                   fga_dgenome **out)
@@ -894,6 +1009,7 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
   A.nunits = (int) H->nunits;
   A.tspace = prm->tspace; A.path_ave = prm->path_ave; A.self = prm->self;
   A.aln_min = prm->aln_min; A.aln_rate = prm->aln_rate;
+  A.mscore = prm->score[0x7fff] / 15;      // SCORE[all matches] = 15 * mscore
   A.cell_cap = cell_cap; A.trace_cap = trace_cap; A.aln_cap = aln_cap; A.tbytes_cap = tb_cap;
 
   fga_unit *d_units = NULL; fga_hit *d_hits = NULL; int *d_order = NULL, *d_next = NULL;
@@ -905,7 +1021,7 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
       (e = hipMalloc(&d_order,sizeof(int)*H->nunits)) != hipSuccess ||
       (e = hipMalloc(&d_next,sizeof(int))) != hipSuccess ||
       (e = hipMalloc(&d_tab,sizeof(int16_t)*2*32768)) != hipSuccess ||
-      (e = hipMalloc(&d_cnt,sizeof(unsigned long long)*8)) != hipSuccess)
+      (e = hipMalloc(&d_cnt,sizeof(unsigned long long)*32)) != hipSuccess)
     { fga_set_error("fga_extend: device allocation failed: %s",hipGetErrorString(e));
       goto fail;
     }
@@ -924,7 +1040,7 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
   hipMemcpy(d_tab,prm->table,sizeof(int16_t)*32768,hipMemcpyHostToDevice);
   hipMemcpy(d_tab+32768,prm->score,sizeof(int16_t)*32768,hipMemcpyHostToDevice);
   hipMemset(d_next,0,sizeof(int));
-  hipMemset(d_cnt,0,sizeof(unsigned long long)*8);
+  hipMemset(d_cnt,0,sizeof(unsigned long long)*32);
   A.units = d_units; A.hits = d_hits; A.order = d_order; A.next = d_next;
   A.table = d_tab; A.score = d_tab+32768; A.counters = d_cnt;
 
@@ -938,8 +1054,14 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
       goto fail;
     }
   hipEventElapsedTime(&dev->last_ms[FGA_STAGE_EXTEND],dev->ev0,dev->ev1);
-  { unsigned long long hc[8];
+  { unsigned long long hc[32];
     hipMemcpy(hc,d_cnt,sizeof(hc),hipMemcpyDeviceToHost);
+    if (getenv("FGA_EXTEND_PROFILE") != NULL)
+      fprintf(stderr,"extend profile: max per wavefront: steps %.2f Mcyc, unwind %.2f Mcyc, total %.2f Mcyc, waves %llu; "
+                     "sum: steps %.1f Mcyc unwind %.1f Mcyc; kernel %.2f ms, %d workgroups, %lld units\n",
+              hc[5]*1e-6,hc[6]*1e-6,hc[7]*1e-6,hc[10],hc[8]*1e-6,hc[9]*1e-6,dev->last_ms[FGA_STAGE_EXTEND],nwg,
+              (long long) H->nunits);
+
     R->naln = (int64_t) hc[0]; R->ntrace = (int64_t) hc[1]; R->ncalls = (int64_t) hc[2]; R->nwaves = (int64_t) hc[3];
     if (hc[4] != 0)
       { fga_set_error("fga_extend: %s",hc[4] == 1 ? "trace-point arena exhausted (raise cell_cap)"
