@@ -171,6 +171,11 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "algorithmic_bytes": int(alg_bytes), "kernel_ms": kavg},
         }
+        if abs(args.mbp - 100.0) < 1e-9 and abs(args.div - 0.02) < 1e-9:    # the profiled configuration
+            tr, src = pmc_traffic()
+            if tr is not None:
+                out["roofline"]["traffic"] = tr
+                out["roofline"]["traffic_source"] = src
         if not args.no_cpu:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, ra, rb, workdir,
@@ -184,6 +189,27 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic():
+    """HBM bytes per seed_merge_kernel launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/r*_pmc_summary.csv): FETCH_SIZE is in KiB and reads exactly half of a wide coalesced stream on
+    gfx950 (MI355X_MICROARCH.md, HBM section) -> x2; WRITE_SIZE in KiB."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv")))
+    if not files:
+        return None, None
+    fetch = write = None
+    for r in csv.DictReader(open(files[-1])):
+        if "seed_merge_kernel" in r["kernel"]:
+            if r["counter"] == "FETCH_SIZE":
+                fetch = float(r["avg_per_launch"])
+            elif r["counter"] == "WRITE_SIZE":
+                write = float(r["avg_per_launch"])
+    if fetch is None or write is None:
+        return None, None
+    return int((2.0 * fetch + write) * 1024), os.path.relpath(files[-1], ROOT)
 
 
 def A_seqtot(root):

@@ -63,3 +63,20 @@ def test_pair_merge_freq_and_mask(loaded):
 def test_self_merge(loaded):
     dev, A, B, dA, dB = loaded
     _compare(dev, A, None, dA, None)
+
+
+def test_prefix_range_shards_union_is_full(loaded):
+    """multi-GPU phase-1 sharding: per-range launches produce disjoint seed sets whose union is the full set."""
+    from fastga_amd import device as D
+    from fastga_amd.parallel import prefix_shards
+    dev, A, B, dA, dB = loaded
+    full = D.seed_merge(dev, dA, dB)
+    allseeds = np.sort(full.download().view(np.dtype((np.void, 16))))
+    full.free()
+    parts = []
+    for b, e in prefix_shards(A.index, B.index, 3):
+        s = D.seed_merge(dev, dA, dB, prefix_begin=b, prefix_end=e)
+        parts.append(s.download())
+        s.free()
+    got = np.sort(np.concatenate(parts).view(np.dtype((np.void, 16))))
+    assert np.array_equal(got, allseeds)
