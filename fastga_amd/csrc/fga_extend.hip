@@ -62,6 +62,8 @@ struct ext_shared
     uint32_t winB[WDW+4];
   };
 
+__device__ int g_dbg = 0;
+
 struct ext_prof
   { unsigned long long t_steps, t_unwind, t_total, nsteps, ph[6]; };
 
@@ -82,7 +84,7 @@ struct ext_args
     const int      *order;               // units by decreasing estimated work
     int            *next;                // work-queue head
     // alignment parameters
-    int   tspace, path_ave, self, aln_min, mscore;
+    int   tspace, path_ave, self, aln_min, mscore, force_lds, dbg_unit;
     double aln_rate;
     const int16_t *table, *score;
     // scratch (per workgroup)
@@ -240,334 +242,21 @@ __device__ __forceinline__ bool win_track(ext_seq &s, int pos)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// one directional wave extension (S = +1 forward_wave, S = -1 reverse_wave)
-// returns 0 ok, 1 pebble arena full, 2 ring too narrow
+// unwind the pebble chain of one wave extension into trace pairs (align.c:805-870 / 1325-1415); lane 0 chases
+// the pointers, the others wait.  Shared by the register and the LDS-ring wave routines.
 // ---------------------------------------------------------------------------------------------------
 template <int S>
-__device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext_shared *shp, int4 *cells, uint16_t *trace,
-                        ext_seq &Ain, ext_seq &Bin, ext_state &P,
-                        int &mind, int maxd, int mida, int minp, int maxp, int aoff,
-                        unsigned long long &nwaves_out, ext_prof &PF)
+__device__ __attribute__((noinline)) void ext_unwind(const ext_args &G, int4 *cells, uint16_t *trace, ext_state &P,
+                                                     ext_prof &PF, int mida, int aoff, int trima, int trimx, int trimd,
+                                                     int trimha, int &mind)
 { const int lane = threadIdx.x & 63;
-  const unsigned long long tstart = clock64();
-  // everything the wave loop touches lives in registers: by-reference arguments of a non-inlined device function
-  // sit in scratch (HBM-backed) memory, and a scratch access per step costs more than the step itself
-  ext_seq A = Ain, B = Bin;
-  unsigned long long nwaves = 0;
-  const int ts = G.tspace, path_ave = G.path_ave, mscore = G.mscore;
-  const int64_t cell_cap = G.cell_cap;
-  const int VNEW = (S > 0) ? -1 : BIGI;
-  int low = mind, hgh = maxd, dif = 0, cur = 0;
-  int more = 1, avail = 0;
-  int aclip = (S > 0) ? BIGI : -BIGI;
-  int bclip = (S > 0) ? -BIGI : BIGI;
-  int besta, bestx, trima, trimx, trimd, trimha, morea, morex, mored, moreha, morem, lasta;
-
-  besta = trima = morea = lasta = mida;
-  bestx = trimx = morex = (mida+hgh)>>1;
-  trimd = mored = 0;
-  trimha = moreha = 0;
-  morem = -1;
-
-  if (hgh-low+8 >= RC)
-    return 2;
-
-  win_track<S>(A,bestx);
-  win_track<S>(B,mida-bestx);
-  WAVE_SYNC();
-
-  // ---- wave 0 -------------------------------------------------------------------------------
-  { const int span = hgh-low+1;
-    for (int j0 = 0; j0 < span; j0 += 64)
-      { const int j = j0 + lane;
-        const bool act = j < span;
-        const int k = (S > 0) ? hgh-j : low+j;
-        int x = 0, c = 0, cnt = 0, na = 0, mark0 = 0, hitA = 0, hitB = 0;
-        if (act)
-          { x = (mida+k)>>1;
-            if (S > 0)
-              { na = ((x+(ts-aoff))/ts-1)*ts+aoff;
-                mark0 = na;
-                na += ts;
-              }
-            else
-              { na = ((x+(ts-aoff)-1)/ts-1)*ts+aoff;
-                mark0 = x;
-              }
-            int y = x-k, lim, L;
-            if (S > 0)
-              { int ra = A.len-x, rb = B.len-y;
-                lim = ra < rb ? ra : rb;
-                L = match_fwd(A,B,x,y,lim);
-                if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
-                x += L;
-              }
-            else
-              { int ra = x, rb = y;
-                lim = ra < rb ? ra : rb;
-                L = match_rev(A,B,x,y,lim);
-                if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
-                x -= L;
-              }
-            c = (x << 1) - k;
-            if (S > 0) cnt = (x >= na) ? (x-na)/ts+1 : 0;
-            else       cnt = (x <= na) ? (na-x)/ts+1 : 0;
-          }
-        int tot, off = wscan_add_excl(act ? 1+cnt : 0,tot);
-        if ((int64_t) avail + tot > cell_cap)
-          return 1;
-        int ha = -1;
-        if (act)
-          { int idx = avail + off;
-            cells[idx] = make_int4(-1,k,0,mark0);
-            ha = idx;
-            for (int q = 0; q < cnt; q++)
-              { idx += 1;
-                cells[idx] = make_int4(ha,k,0,na);
-                ha = idx;
-                na += S*ts;
-              }
-            shp->V[0][k & RMASK] = c;
-            shp->T[0][k & RMASK] = PATH_INT;
-            shp->HA[0][k & RMASK] = ha;
-            shp->HM[0][k & RMASK] = (cnt > 0) ? na - S*ts : mark0;
-            shp->NA[k & RMASK] = na;
-          }
-        avail += tot;
-        // strict best in sweep order
-        int pm = wscan_best_excl<S>(act ? c : ((S > 0) ? -BIGI : BIGI));
-        bool rec = act && ((S > 0) ? (c > besta && c > pm) : (c < besta && c < pm));
-        uint64_t rm = __ballot(rec);
-        if (rm)
-          { int l = last_lane(rm);
-            besta = trima = lasta = rdlane(c,l);
-            bestx = trimx = rdlane(x,l);
-            trimha = rdlane(ha,l);
-          }
-        uint64_t am = __ballot(hitA), bm = __ballot(hitB);
-        if (am | bm) more = 0;
-        if (am) aclip = rdlane(k,last_lane(am));
-        if (bm && ((S > 0) ? bclip == -BIGI : bclip == BIGI)) bclip = rdlane(k,first_lane(bm));
-      }
-  }
-  WAVE_SYNC();
-
-#define CLIP_FROM(kk,withd)                                                           \
-  { uint64_t tt = shp->T[cur][(kk) & RMASK];                                            \
-    int mm = __popcll(tt & WIN61);                                                    \
-    if (morem <= mm)                                                                  \
-      { morem = mm; morea = shp->V[cur][(kk) & RMASK]; morex = (morea+(kk))>>1;         \
-        if (withd) mored = dif;                                                       \
-        moreha = shp->HA[cur][(kk) & RMASK];                                            \
-      }                                                                               \
-  }
-
-#define CLIP_UPDATE(withd)                                                            \
-  if (more == 0)                                                                      \
-    { int cb = (S > 0) ? base_at(B,besta-bestx) : base_at(B,besta-bestx-1);           \
-      int ca = (S > 0) ? base_at(A,bestx) : base_at(A,bestx-1);                       \
-      if (cb != 4 && ca != 4)                                                         \
-        more = 1;                                                                     \
-      if (S > 0)                                                                      \
-        { if (hgh >= aclip) { hgh = aclip-1; CLIP_FROM(aclip,withd) }                 \
-          if (low <= bclip) { low = bclip+1; CLIP_FROM(bclip,withd) }                 \
-          aclip = BIGI; bclip = -BIGI;                                                \
-        }                                                                             \
-      else                                                                            \
-        { if (low <= aclip) { low = aclip+1; CLIP_FROM(aclip,withd) }                 \
-          if (hgh >= bclip) { hgh = bclip-1; CLIP_FROM(bclip,withd) }                 \
-          aclip = -BIGI; bclip = BIGI;                                                \
-        }                                                                             \
-    }
-
-  CLIP_UPDATE(0)
-
-  // ---- successive waves ------------------------------------------------------------------------
-  while (more && ((S > 0) ? lasta >= besta - TRIM_MLAG : lasta <= besta + TRIM_MLAG))
-    { if (hgh-low+8 >= RC)
-        return 2;
-      nwaves += 1;
-      low -= 1;
-      hgh += 1;
-      if (lane == 0)
-        { if (low >= minp)
-            { shp->NA[low & RMASK] = shp->NA[(low+1) & RMASK]; shp->V[cur][low & RMASK] = VNEW; }
-          if (hgh <= maxp)
-            { shp->NA[hgh & RMASK] = shp->NA[(hgh-1) & RMASK]; shp->V[cur][hgh & RMASK] = VNEW; }
-        }
-      if (low < minp) low += 1;
-      if (hgh > maxp) hgh -= 1;
-      dif += 1;
-      if (lane == 0)
-        shp->V[cur][(hgh+1) & RMASK] = shp->V[cur][(low-1) & RMASK] = VNEW;
-      win_track<S>(A,bestx);
-      win_track<S>(B,besta-bestx);
-      WAVE_SYNC();
-    
-      const int span = hgh-low+1;
-      const int nxt = cur^1;
-      uint64_t anyA = 0, anyB = 0;
-      for (int j0 = 0; j0 < span; j0 += 64)
-        { const int j = j0 + lane;
-          const bool act = j < span;
-          const int k = (S > 0) ? hgh-j : low+j;
-          int x = 0, c = 0, ha = -1, hm = 0, hitA = 0, hitB = 0, ncreate = 0, na = 0, cross = 0;
-          uint64_t b = 0;
-          if (act)
-            { int ac = shp->V[cur][k & RMASK];
-              int a1 = shp->V[cur][(k-S) & RMASK];
-              int a2 = shp->V[cur][(k+S) & RMASK];
-              int src;
-              if (S > 0)
-                { if (ac < a1) src = (a1 < a2) ? k+S : k-S;
-                  else         src = (ac < a2) ? k+S : k;
-                }
-              else
-                { if (ac > a1) src = (a1 > a2) ? k+S : k-S;
-                  else         src = (ac > a2) ? k+S : k;
-                }
-              c  = (src == k) ? ac + 2*S : ((src == k-S) ? a1 : a2) + S;
-              b  = shp->T[cur][src & RMASK];
-              ha = shp->HA[cur][src & RMASK];
-              hm = shp->HM[cur][src & RMASK];
-              b <<= 1;
-              x = (c+k)>>1;
-              int y = x-k, L;
-              if (S > 0)
-                { int ra = A.len-x, rb = B.len-y;
-                  int lim = ra < rb ? ra : rb;
-                  L = match_fwd(A,B,x,y,lim);
-                  if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
-                  x += L;
-                }
-              else
-                { int ra = x, rb = y;
-                  int lim = ra < rb ? ra : rb;
-                  L = match_rev(A,B,x,y,lim);
-                  if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
-                  x -= L;
-                }
-              if (L > 0)
-                b = (L >= 61) ? ~0ull : ((b << L) | ((1ull << L) - 1));
-              c = (x << 1) - k;
-              na = shp->NA[k & RMASK];
-              if (S > 0) cross = (x >= na) ? (x-na)/ts+1 : 0;
-              else       cross = (x <= na) ? (na-x)/ts+1 : 0;
-              if (cross > 0)
-                { int mk = hm;
-                  // crossings strictly beyond the head's mark get a pebble
-                  int skip;
-                  if (S > 0) skip = (mk >= na) ? (mk-na)/ts+1 : 0;
-                  else       skip = (mk <= na) ? (na-mk)/ts+1 : 0;
-                  if (skip > cross) skip = cross;
-                  ncreate = cross - skip;
-                }
-            }
-          int tot = 0, off = 0;
-          uint64_t cm = __ballot(ncreate > 0);
-          if (cm)
-            { off = wscan_add_excl(ncreate,tot);
-              if ((int64_t) avail + tot > cell_cap)
-                return 1;
-            }
-          if (act)
-            { if (ncreate > 0)
-                { int idx = avail + off;
-                  int v = na + S*ts*(cross-ncreate);
-                  for (int q = 0; q < ncreate; q++)
-                    { cells[idx] = make_int4(ha,k,dif,v);
-                      ha = idx;
-                      hm = v;
-                      idx += 1;
-                      v += S*ts;
-                    }
-                }
-              if (cross > 0)
-                shp->NA[k & RMASK] = na + S*ts*cross;
-              shp->V[nxt][k & RMASK] = c;
-              shp->T[nxt][k & RMASK] = b;
-              shp->HA[nxt][k & RMASK] = ha;
-              shp->HM[nxt][k & RMASK] = hm;
-            }
-          avail += tot;
-
-          // ordered "new best point" scan (align.c:729-742)
-          int pm = wscan_best_excl<S>(act ? c : ((S > 0) ? -BIGI : BIGI));
-          bool rec = act && ((S > 0) ? (c > besta && c > pm) : (c < besta && c < pm));
-          uint64_t rm = __ballot(rec);
-          if (rm)
-            { int l = last_lane(rm);
-              besta = rdlane(c,l);
-              bestx = rdlane(x,l);
-              int m = __popcll(b & WIN61);
-              bool good = rec && m >= path_ave;
-              uint64_t gm = __ballot(good);
-              if (gm)
-                { lasta = rdlane(c,last_lane(gm));
-                  bool trimok = false;
-                  if (good)
-                    { const uint32_t plo = (uint32_t) b & TRIM_MASK, phi = (uint32_t) (b >> TRIM_LEN) & TRIM_MASK;
-                      if (trim_table(plo,mscore) >= 0)
-                        trimok = trim_table(phi,mscore) + trim_score(plo,mscore) >= 0;
-                    }
-                  uint64_t tm = __ballot(trimok);
-                  if (tm)
-                    { int l2 = last_lane(tm);
-                      trima = rdlane(c,l2);
-                      trimx = rdlane(x,l2);
-                      trimd = dif;
-                      trimha = rdlane(ha,l2);
-                    }
-                }
-            }
-          uint64_t am = __ballot(hitA), bm = __ballot(hitB);
-          if (am) aclip = rdlane(k,last_lane(am));
-          if (bm && !anyB) bclip = rdlane(k,first_lane(bm));
-          anyA |= am; anyB |= bm;
-        }
-      if (anyA | anyB) more = 0;
-      cur = nxt;
-      WAVE_SYNC();
-    
-      CLIP_UPDATE(1)
-
-      // prune both ends (align.c:782-790)
-      { const int n = besta - S*WAVE_LAG;
-        int nh = low-1, nl = hgh+1;
-        const int sp = hgh-low+1;
-        for (int j0 = 0; j0 < sp; j0 += 64)
-          { int k = low + j0 + lane;
-            bool keep = false;
-            if (k <= hgh)
-              { int v = shp->V[cur][k & RMASK];
-                keep = (S > 0) ? (v >= n) : (v <= n);
-              }
-            uint64_t km = __ballot(keep);
-            if (km)
-              { int f = low + j0 + first_lane(km), l = low + j0 + last_lane(km);
-                if (f < nl) nl = f;
-                if (l > nh) nh = l;
-              }
-          }
-        if (nh < nl)          // nothing survives: the reference leaves hgh < low
-          hgh = low-1;
-        else
-          { hgh = nh; low = nl; }
-      }
-    }
-
+  const int ts = G.tspace;
   // ---- unwind the pebble chain (lane 0), tip -> root, then write the trace pairs -------------------
-  { int trimy;
-    if (morem >= 0 && 0 /* reach is always 0 in FastGA (FastGA.c:3757) */)
-      { trimx = morex; trimy = morea - morex; trimd = mored; trimha = moreha; }
-    else
-      trimy = trima - trimx;
+  { // the reference picks the "more" tip only when spec->reach is set; FastGA always passes reach = 0 (FastGA.c:3757)
+    const int trimy = trima - trimx;
 
     int rootk = 0;
     const unsigned long long tun = clock64();
-    PF.t_steps += tun - tstart;
-    nwaves_out += nwaves;
-    Ain.p0 = A.p0; Bin.p0 = B.p0;
     __syncthreads();          // once per call: all pebble stores of the wave are complete before the pointer chase
     if (lane == 0)
       { // walk tip -> root; pairs come out last-to-first
@@ -678,16 +367,671 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
       { P.abpos = trimx; P.bbpos = trimy; P.diffs = P.diffs + trimd; }
     PF.t_unwind += clock64() - tun;
   }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// one directional wave extension (S = +1 forward_wave, S = -1 reverse_wave)
+// returns 0 ok, 1 pebble arena full, 2 ring too narrow
+// ---------------------------------------------------------------------------------------------------
+template <int S>
+__device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext_shared *shp, int4 *cells, uint16_t *trace,
+                        ext_seq &Ain, ext_seq &Bin, ext_state &P,
+                        int &mind, int maxd, int mida, int minp, int maxp, int aoff,
+                        unsigned long long &nwaves_out, ext_prof &PF)
+{ const int lane = threadIdx.x & 63;
+  const unsigned long long tstart = clock64();
+  // everything the wave loop touches lives in registers: by-reference arguments of a non-inlined device function
+  // sit in scratch (HBM-backed) memory, and a scratch access per step costs more than the step itself
+  ext_seq A = Ain, B = Bin;
+  unsigned long long nwaves = 0;
+  const int ts = G.tspace, path_ave = G.path_ave, mscore = G.mscore;
+  const int64_t cell_cap = G.cell_cap;
+  const int VNEW = (S > 0) ? -1 : BIGI;
+  int low = mind, hgh = maxd, dif = 0, cur = 0;
+  int more = 1, avail = 0;
+  int aclip = (S > 0) ? BIGI : -BIGI;
+  int bclip = (S > 0) ? -BIGI : BIGI;
+  int besta, bestx, trima, trimx, trimd, trimha, morea, morex, mored, moreha, morem, lasta;
+
+  besta = trima = morea = lasta = mida;
+  bestx = trimx = morex = (mida+hgh)>>1;
+  trimd = mored = 0;
+  trimha = moreha = 0;
+  morem = -1;
+
+  if (hgh-low+8 >= RC)
+    { Ain.p0 = A.p0; Bin.p0 = B.p0; return 2; }
+
+  win_track<S>(A,bestx);
+  win_track<S>(B,mida-bestx);
+  WAVE_SYNC();
+
+  // ---- wave 0 -------------------------------------------------------------------------------
+  { const int span = hgh-low+1;
+    for (int j0 = 0; j0 < span; j0 += 64)
+      { const int j = j0 + lane;
+        const bool act = j < span;
+        const int k = (S > 0) ? hgh-j : low+j;
+        int x = 0, c = 0, cnt = 0, na = 0, mark0 = 0, hitA = 0, hitB = 0;
+        if (act)
+          { x = (mida+k)>>1;
+            if (S > 0)
+              { na = ((x+(ts-aoff))/ts-1)*ts+aoff;
+                mark0 = na;
+                na += ts;
+              }
+            else
+              { na = ((x+(ts-aoff)-1)/ts-1)*ts+aoff;
+                mark0 = x;
+              }
+            int y = x-k, lim, L;
+            if (S > 0)
+              { int ra = A.len-x, rb = B.len-y;
+                lim = ra < rb ? ra : rb;
+                L = match_fwd(A,B,x,y,lim);
+                if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
+                x += L;
+              }
+            else
+              { int ra = x, rb = y;
+                lim = ra < rb ? ra : rb;
+                L = match_rev(A,B,x,y,lim);
+                if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
+                x -= L;
+              }
+            c = (x << 1) - k;
+            if (S > 0) cnt = (x >= na) ? (x-na)/ts+1 : 0;
+            else       cnt = (x <= na) ? (na-x)/ts+1 : 0;
+          }
+        int tot, off = wscan_add_excl(act ? 1+cnt : 0,tot);
+        if ((int64_t) avail + tot > cell_cap)
+          { Ain.p0 = A.p0; Bin.p0 = B.p0; return 1; }
+        int ha = -1;
+        if (act)
+          { int idx = avail + off;
+            cells[idx] = make_int4(-1,k,0,mark0);
+            ha = idx;
+            for (int q = 0; q < cnt; q++)
+              { idx += 1;
+                cells[idx] = make_int4(ha,k,0,na);
+                ha = idx;
+                na += S*ts;
+              }
+            shp->V[0][k & RMASK] = c;
+            shp->T[0][k & RMASK] = PATH_INT;
+            shp->HA[0][k & RMASK] = ha;
+            shp->HM[0][k & RMASK] = (cnt > 0) ? na - S*ts : mark0;
+            shp->NA[k & RMASK] = na;
+          }
+        avail += tot;
+        // strict best in sweep order
+        int pm = wscan_best_excl<S>(act ? c : ((S > 0) ? -BIGI : BIGI));
+        bool rec = act && ((S > 0) ? (c > besta && c > pm) : (c < besta && c < pm));
+        uint64_t rm = __ballot(rec);
+        if (rm)
+          { int l = last_lane(rm);
+            besta = trima = lasta = rdlane(c,l);
+            bestx = trimx = rdlane(x,l);
+            trimha = rdlane(ha,l);
+          }
+        uint64_t am = __ballot(hitA), bm = __ballot(hitB);
+        if (am | bm) more = 0;
+        if (am) aclip = rdlane(k,last_lane(am));
+        if (bm && ((S > 0) ? bclip == -BIGI : bclip == BIGI)) bclip = rdlane(k,first_lane(bm));
+      }
+  }
+  WAVE_SYNC();
+
+#define CLIP_FROM(kk,withd)                                                           \
+  { uint64_t tt = shp->T[cur][(kk) & RMASK];                                            \
+    int mm = __popcll(tt & WIN61);                                                    \
+    if (morem <= mm)                                                                  \
+      { morem = mm; morea = shp->V[cur][(kk) & RMASK]; morex = (morea+(kk))>>1;         \
+        if (withd) mored = dif;                                                       \
+        moreha = shp->HA[cur][(kk) & RMASK];                                            \
+      }                                                                               \
+  }
+
+#define CLIP_UPDATE(withd)                                                            \
+  if (more == 0)                                                                      \
+    { int cb = (S > 0) ? base_at(B,besta-bestx) : base_at(B,besta-bestx-1);           \
+      int ca = (S > 0) ? base_at(A,bestx) : base_at(A,bestx-1);                       \
+      if (cb != 4 && ca != 4)                                                         \
+        more = 1;                                                                     \
+      if (S > 0)                                                                      \
+        { if (hgh >= aclip) { hgh = aclip-1; CLIP_FROM(aclip,withd) }                 \
+          if (low <= bclip) { low = bclip+1; CLIP_FROM(bclip,withd) }                 \
+          aclip = BIGI; bclip = -BIGI;                                                \
+        }                                                                             \
+      else                                                                            \
+        { if (low <= aclip) { low = aclip+1; CLIP_FROM(aclip,withd) }                 \
+          if (hgh >= bclip) { hgh = bclip-1; CLIP_FROM(bclip,withd) }                 \
+          aclip = -BIGI; bclip = BIGI;                                                \
+        }                                                                             \
+    }
+
+  CLIP_UPDATE(0)
+
+  // ---- successive waves ------------------------------------------------------------------------
+  while (more && ((S > 0) ? lasta >= besta - TRIM_MLAG : lasta <= besta + TRIM_MLAG))
+    { if (hgh-low+8 >= RC)
+        { Ain.p0 = A.p0; Bin.p0 = B.p0; return 2; }
+      nwaves += 1;
+      low -= 1;
+      hgh += 1;
+      if (lane == 0)
+        { if (low >= minp)
+            { shp->NA[low & RMASK] = shp->NA[(low+1) & RMASK]; shp->V[cur][low & RMASK] = VNEW; }
+          if (hgh <= maxp)
+            { shp->NA[hgh & RMASK] = shp->NA[(hgh-1) & RMASK]; shp->V[cur][hgh & RMASK] = VNEW; }
+        }
+      if (low < minp) low += 1;
+      if (hgh > maxp) hgh -= 1;
+      dif += 1;
+      if (lane == 0)
+        shp->V[cur][(hgh+1) & RMASK] = shp->V[cur][(low-1) & RMASK] = VNEW;
+      win_track<S>(A,bestx);
+      win_track<S>(B,besta-bestx);
+      WAVE_SYNC();
+    
+      const int span = hgh-low+1;
+      const int nxt = cur^1;
+      uint64_t anyA = 0, anyB = 0;
+      for (int j0 = 0; j0 < span; j0 += 64)
+        { const int j = j0 + lane;
+          const bool act = j < span;
+          const int k = (S > 0) ? hgh-j : low+j;
+          int x = 0, c = 0, ha = -1, hm = 0, hitA = 0, hitB = 0, ncreate = 0, na = 0, cross = 0;
+          uint64_t b = 0;
+          if (act)
+            { int ac = shp->V[cur][k & RMASK];
+              int a1 = shp->V[cur][(k-S) & RMASK];
+              int a2 = shp->V[cur][(k+S) & RMASK];
+              int src;
+              if (S > 0)
+                { if (ac < a1) src = (a1 < a2) ? k+S : k-S;
+                  else         src = (ac < a2) ? k+S : k;
+                }
+              else
+                { if (ac > a1) src = (a1 > a2) ? k+S : k-S;
+                  else         src = (ac > a2) ? k+S : k;
+                }
+              c  = (src == k) ? ac + 2*S : ((src == k-S) ? a1 : a2) + S;
+              b  = shp->T[cur][src & RMASK];
+              ha = shp->HA[cur][src & RMASK];
+              hm = shp->HM[cur][src & RMASK];
+              b <<= 1;
+              x = (c+k)>>1;
+              int y = x-k, L;
+              if (S > 0)
+                { int ra = A.len-x, rb = B.len-y;
+                  int lim = ra < rb ? ra : rb;
+                  L = match_fwd(A,B,x,y,lim);
+                  if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
+                  x += L;
+                }
+              else
+                { int ra = x, rb = y;
+                  int lim = ra < rb ? ra : rb;
+                  L = match_rev(A,B,x,y,lim);
+                  if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
+                  x -= L;
+                }
+              if (L > 0)
+                b = (L >= 61) ? ~0ull : ((b << L) | ((1ull << L) - 1));
+              c = (x << 1) - k;
+              na = shp->NA[k & RMASK];
+              if (S > 0) cross = (x >= na) ? (x-na)/ts+1 : 0;
+              else       cross = (x <= na) ? (na-x)/ts+1 : 0;
+              if (cross > 0)
+                { int mk = hm;
+                  // crossings strictly beyond the head's mark get a pebble
+                  int skip;
+                  if (S > 0) skip = (mk >= na) ? (mk-na)/ts+1 : 0;
+                  else       skip = (mk <= na) ? (na-mk)/ts+1 : 0;
+                  if (skip > cross) skip = cross;
+                  ncreate = cross - skip;
+                }
+            }
+          int tot = 0, off = 0;
+          uint64_t cm = __ballot(ncreate > 0);
+          if (cm)
+            { off = wscan_add_excl(ncreate,tot);
+              if ((int64_t) avail + tot > cell_cap)
+                { Ain.p0 = A.p0; Bin.p0 = B.p0; return 1; }
+            }
+          if (act)
+            { if (ncreate > 0)
+                { int idx = avail + off;
+                  int v = na + S*ts*(cross-ncreate);
+                  for (int q = 0; q < ncreate; q++)
+                    { cells[idx] = make_int4(ha,k,dif,v);
+                      ha = idx;
+                      hm = v;
+                      idx += 1;
+                      v += S*ts;
+                    }
+                }
+              if (cross > 0)
+                shp->NA[k & RMASK] = na + S*ts*cross;
+              shp->V[nxt][k & RMASK] = c;
+              shp->T[nxt][k & RMASK] = b;
+              shp->HA[nxt][k & RMASK] = ha;
+              shp->HM[nxt][k & RMASK] = hm;
+            }
+          avail += tot;
+
+          // ordered "new best point" scan (align.c:729-742)
+          int pm = wscan_best_excl<S>(act ? c : ((S > 0) ? -BIGI : BIGI));
+          bool rec = act && ((S > 0) ? (c > besta && c > pm) : (c < besta && c < pm));
+          uint64_t rm = __ballot(rec);
+          if (rm)
+            { int l = last_lane(rm);
+              besta = rdlane(c,l);
+              bestx = rdlane(x,l);
+              int m = __popcll(b & WIN61);
+              bool good = rec && m >= path_ave;
+              uint64_t gm = __ballot(good);
+              if (gm)
+                { lasta = rdlane(c,last_lane(gm));
+                  bool trimok = false;
+                  if (good)
+                    { const uint32_t plo = (uint32_t) b & TRIM_MASK, phi = (uint32_t) (b >> TRIM_LEN) & TRIM_MASK;
+                      if (trim_table(plo,mscore) >= 0)
+                        trimok = trim_table(phi,mscore) + trim_score(plo,mscore) >= 0;
+                    }
+                  uint64_t tm = __ballot(trimok);
+                  if (tm)
+                    { int l2 = last_lane(tm);
+                      trima = rdlane(c,l2);
+                      trimx = rdlane(x,l2);
+                      trimd = dif;
+                      trimha = rdlane(ha,l2);
+                    }
+                }
+            }
+          uint64_t am = __ballot(hitA), bm = __ballot(hitB);
+          if (am) aclip = rdlane(k,last_lane(am));
+          if (bm && !anyB) bclip = rdlane(k,first_lane(bm));
+          anyA |= am; anyB |= bm;
+        }
+      if (anyA | anyB) more = 0;
+      cur = nxt;
+      WAVE_SYNC();
+    
+      CLIP_UPDATE(1)
+
+      // prune both ends (align.c:782-790)
+      { const int n = besta - S*WAVE_LAG;
+        int nh = low-1, nl = hgh+1;
+        const int sp = hgh-low+1;
+        for (int j0 = 0; j0 < sp; j0 += 64)
+          { int k = low + j0 + lane;
+            bool keep = false;
+            if (k <= hgh)
+              { int v = shp->V[cur][k & RMASK];
+                keep = (S > 0) ? (v >= n) : (v <= n);
+              }
+            uint64_t km = __ballot(keep);
+            if (km)
+              { int f = low + j0 + first_lane(km), l = low + j0 + last_lane(km);
+                if (f < nl) nl = f;
+                if (l > nh) nh = l;
+              }
+          }
+        if (nh < nl)          // nothing survives: the reference leaves hgh < low
+          hgh = low-1;
+        else
+          { hgh = nh; low = nl; }
+      }
+    }
+
+  PF.t_steps += clock64() - tstart;
+  nwaves_out += nwaves;
+  Ain.p0 = A.p0; Bin.p0 = B.p0;
+  (void) morea; (void) morex; (void) mored; (void) moreha;
+  ext_unwind<S>(G,cells,trace,P,PF,mida,aoff,trima,trimx,trimd,trimha,mind);
+  return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Register-resident wave extension: the common case (wave narrower than 60 diagonals).
+//   lane l holds diagonal k = kref - S*l, so lane order IS the reference's sweep order for both directions,
+//   the second-priority neighbour V[k-S] sits in lane l+1 and the third-priority V[k+S] in lane l-1.
+//   V, T, HA, HM, NA live in VGPRs; neighbour values travel over DPP wave_shl:1 / wave_shr:1; no LDS state at
+//   all (only the two sequence windows).  When the wave drifts to the edge of the 64 lanes all registers are
+//   rotated (ds_bpermute, rare); if it grows wider than 60 diagonals the routine returns 3 and the caller redoes
+//   the whole Local_Alignment with the LDS-ring routine (results are deterministic, so this is exact).
+// ---------------------------------------------------------------------------------------------------
+#define FROM_NEXT(v,oldv) __builtin_amdgcn_update_dpp(oldv,v,0x130,0xf,0xf,false)    /* lane l gets lane l+1 */
+#define FROM_PREV(v,oldv) __builtin_amdgcn_update_dpp(oldv,v,0x138,0xf,0xf,false)    /* lane l gets lane l-1 */
+#define REG_MAXW 60
+
+template <int S>
+__device__ __attribute__((noinline)) int ext_wave_reg(const ext_args &G, int4 *cells, uint16_t *trace,
+                        ext_seq &Ain, ext_seq &Bin, ext_state &P,
+                        int &mind, int maxd, int mida, int minp, int maxp, int aoff,
+                        unsigned long long &nwaves_out, ext_prof &PF)
+{ const int lane = threadIdx.x & 63;
+  const unsigned long long tstart = clock64();
+  ext_seq A = Ain, B = Bin;
+  unsigned long long nwaves = 0;
+  const int ts = G.tspace, path_ave = G.path_ave, mscore = G.mscore;
+  const int64_t cell_cap = G.cell_cap;
+  const int VNEW = (S > 0) ? -1 : BIGI;
+  int low = mind, hgh = maxd, dif = 0;
+  int more = 1, avail = 0;
+  int aclip = (S > 0) ? BIGI : -BIGI;
+  int bclip = (S > 0) ? -BIGI : BIGI;
+  int besta, bestx, trima, trimx, trimd, trimha, morem, lasta;
+
+  besta = trima = lasta = mida;
+  bestx = trimx = (mida+hgh)>>1;
+  trimd = 0;
+  trimha = 0;
+  morem = -1;
+
+  if (hgh-low+1 > REG_MAXW)
+    { Ain.p0 = A.p0; Bin.p0 = B.p0; return 3; }
+
+  // lane <-> diagonal map, window centred
+  int kref;
+  { const int l0 = (64 - (hgh-low+1)) >> 1;
+    kref = (S > 0) ? hgh + l0 : low - l0;
+  }
+#define KOF(l)    ((S > 0) ? kref - (l) : kref + (l))
+#define LOF(kk)   ((S > 0) ? kref - (kk) : (kk) - kref)
+
+  win_track<S>(A,bestx);
+  win_track<S>(B,mida-bestx);
+  WAVE_SYNC();
+
+  int      V = VNEW, HA = -1, HM = 0, NA = 0;
+  uint64_t T = PATH_INT;
+
+  // ---- wave 0 ----------------------------------------------------------------------------------
+  { const int k = KOF(lane);
+    const bool act = k >= low && k <= hgh;
+    int x = 0, c = 0, cnt = 0, na = 0, mark0 = 0, hitA = 0, hitB = 0;
+    if (act)
+      { x = (mida+k)>>1;
+        if (S > 0)
+          { na = ((x+(ts-aoff))/ts-1)*ts+aoff;
+            mark0 = na;
+            na += ts;
+          }
+        else
+          { na = ((x+(ts-aoff)-1)/ts-1)*ts+aoff;
+            mark0 = x;
+          }
+        int y = x-k, L;
+        if (S > 0)
+          { int ra = A.len-x, rb = B.len-y;
+            int lim = ra < rb ? ra : rb;
+            L = match_fwd(A,B,x,y,lim);
+            if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
+            x += L;
+          }
+        else
+          { int ra = x, rb = y;
+            int lim = ra < rb ? ra : rb;
+            L = match_rev(A,B,x,y,lim);
+            if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
+            x -= L;
+          }
+        c = (x << 1) - k;
+        if (S > 0) cnt = (x >= na) ? (x-na)/ts+1 : 0;
+        else       cnt = (x <= na) ? (na-x)/ts+1 : 0;
+      }
+    int tot, off = wscan_add_excl(act ? 1+cnt : 0,tot);
+    if ((int64_t) avail + tot > cell_cap)
+      { Ain.p0 = A.p0; Bin.p0 = B.p0; return 1; }
+    int ha = -1, hm = 0;
+    if (act)
+      { int idx = avail + off;
+        cells[idx] = make_int4(-1,k,0,mark0);
+        ha = idx; hm = mark0;
+        for (int q = 0; q < cnt; q++)
+          { idx += 1;
+            cells[idx] = make_int4(ha,k,0,na);
+            ha = idx; hm = na;
+            na += S*ts;
+          }
+        V = c; T = PATH_INT; HA = ha; HM = hm; NA = na;
+      }
+    avail += tot;
+    int pm = wscan_best_excl<S>(act ? c : ((S > 0) ? -BIGI : BIGI));
+    bool rec = act && ((S > 0) ? (c > besta && c > pm) : (c < besta && c < pm));
+    uint64_t rm = __ballot(rec);
+    if (rm)
+      { int l = last_lane(rm);
+        besta = trima = lasta = rdlane(c,l);
+        bestx = trimx = rdlane(x,l);
+        trimha = rdlane(ha,l);
+      }
+    uint64_t am = __ballot(hitA), bm = __ballot(hitB);
+    if (am | bm) more = 0;
+    if (am) aclip = KOF(last_lane(am));
+    if (bm) bclip = KOF(first_lane(bm));
+  }
+
+#define RCLIP_FROM(kk)                                                               \
+  { const int _l = LOF(kk);                                                          \
+    uint32_t tlo = (uint32_t) rdlane((int) (uint32_t) T,_l);                         \
+    uint32_t thi = (uint32_t) rdlane((int) (uint32_t) (T >> 32),_l);                 \
+    int mm = __popcll((((uint64_t) thi << 32) | tlo) & WIN61);                       \
+    if (morem <= mm)                                                                 \
+      morem = mm;                                                                    \
+  }
+
+#define RCLIP_UPDATE()                                                               \
+  if (more == 0)                                                                     \
+    { int cb = (S > 0) ? base_at(B,besta-bestx) : base_at(B,besta-bestx-1);          \
+      int ca = (S > 0) ? base_at(A,bestx) : base_at(A,bestx-1);                      \
+      if (cb != 4 && ca != 4)                                                        \
+        more = 1;                                                                    \
+      if (S > 0)                                                                     \
+        { if (hgh >= aclip) { hgh = aclip-1; RCLIP_FROM(aclip) }                     \
+          if (low <= bclip) { low = bclip+1; RCLIP_FROM(bclip) }                     \
+          aclip = BIGI; bclip = -BIGI;                                               \
+        }                                                                            \
+      else                                                                           \
+        { if (low <= aclip) { low = aclip+1; RCLIP_FROM(aclip) }                     \
+          if (hgh >= bclip) { hgh = bclip-1; RCLIP_FROM(bclip) }                     \
+          aclip = -BIGI; bclip = BIGI;                                               \
+        }                                                                            \
+    }
+
+  RCLIP_UPDATE()
+
+  // ---- successive waves ------------------------------------------------------------------------
+  while (more && ((S > 0) ? lasta >= besta - TRIM_MLAG : lasta <= besta + TRIM_MLAG))
+    { nwaves += 1;
+      low -= 1;
+      hgh += 1;
+      const bool newlow = low >= minp, newhgh = hgh <= maxp;
+      if (!newlow) low += 1;
+      if (!newhgh) hgh -= 1;
+      if (hgh-low+1 > REG_MAXW)
+        { Ain.p0 = A.p0; Bin.p0 = B.p0; return 3; }
+      dif += 1;
+
+      // keep the active lanes inside [1,62]: rotate every register when the wave has drifted
+      { const int la = LOF((S > 0) ? hgh : low), lb = LOF((S > 0) ? low : hgh);     // first / last active lane
+        if (la < 1 || lb > 62)
+          { const int want = (64 - (lb-la+1)) >> 1;
+            const int delta = want - la;                    // new lane = old lane + delta
+            const int srcl = lane - delta;
+            V  = __shfl(V,srcl,64);
+            HA = __shfl(HA,srcl,64);
+            HM = __shfl(HM,srcl,64);
+            NA = __shfl(NA,srcl,64);
+            uint32_t tlo = (uint32_t) __shfl((int) (uint32_t) T,srcl,64);
+            uint32_t thi = (uint32_t) __shfl((int) (uint32_t) (T >> 32),srcl,64);
+            T = ((uint64_t) thi << 32) | tlo;
+            kref = (S > 0) ? kref + delta : kref - delta;
+          }
+      }
+
+      const int k = KOF(lane);
+      const bool act = k >= low && k <= hgh;
+      // new diagonals take the trace-point schedule of their inner neighbour; everything outside is VNEW
+      { int na_next = FROM_NEXT(NA,0), na_prev = FROM_PREV(NA,0);
+        if (newlow && k == low) NA = (S > 0) ? na_prev : na_next;      // NA[low] = NA[low+1]
+        if (newhgh && k == hgh) NA = (S > 0) ? na_next : na_prev;      // NA[hgh] = NA[hgh-1]
+        if (!act || (newlow && k == low) || (newhgh && k == hgh))
+          V = VNEW;
+      }
+
+      win_track<S>(A,bestx);
+      win_track<S>(B,besta-bestx);
+      WAVE_SYNC();
+
+      int x = 0, c = 0, ha = -1, hm = 0, hitA = 0, hitB = 0, ncreate = 0, na = NA, cross = 0;
+      uint64_t b = 0;
+      { const int ac = V;
+        const int a1 = FROM_NEXT(V,VNEW);              // V[k-S]
+        const int a2 = FROM_PREV(V,VNEW);              // V[k+S]
+        int pick;                                      // 0 self, 1 next lane (k-S), 2 previous lane (k+S)
+        if (S > 0)
+          { if (ac < a1) pick = (a1 < a2) ? 2 : 1;
+            else         pick = (ac < a2) ? 2 : 0;
+          }
+        else
+          { if (ac > a1) pick = (a1 > a2) ? 2 : 1;
+            else         pick = (ac > a2) ? 2 : 0;
+          }
+        const uint32_t tlo = (uint32_t) T, thi = (uint32_t) (T >> 32);
+        const uint32_t nlo = (uint32_t) FROM_NEXT((int) tlo,0), nhi = (uint32_t) FROM_NEXT((int) thi,0);
+        const uint32_t plo = (uint32_t) FROM_PREV((int) tlo,0), phi = (uint32_t) FROM_PREV((int) thi,0);
+        const int nha = FROM_NEXT(HA,-1), pha = FROM_PREV(HA,-1);
+        const int nhm = FROM_NEXT(HM,0),  phm = FROM_PREV(HM,0);
+        if (act)
+          { if (pick == 0)      { c = ac + 2*S; b = T; ha = HA; hm = HM; }
+            else if (pick == 1) { c = a1 + S; b = ((uint64_t) nhi << 32) | nlo; ha = nha; hm = nhm; }
+            else                { c = a2 + S; b = ((uint64_t) phi << 32) | plo; ha = pha; hm = phm; }
+            b <<= 1;
+            x = (c+k)>>1;
+            int y = x-k, L;
+            if (S > 0)
+              { int ra = A.len-x, rb = B.len-y;
+                int lim = ra < rb ? ra : rb;
+                L = match_fwd(A,B,x,y,lim);
+                if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
+                x += L;
+              }
+            else
+              { int ra = x, rb = y;
+                int lim = ra < rb ? ra : rb;
+                L = match_rev(A,B,x,y,lim);
+                if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
+                x -= L;
+              }
+            if (L > 0)
+              b = (L >= 61) ? ~0ull : ((b << L) | ((1ull << L) - 1));
+            c = (x << 1) - k;
+            if (S > 0) cross = (x >= na) ? (x-na)/ts+1 : 0;
+            else       cross = (x <= na) ? (na-x)/ts+1 : 0;
+            if (cross > 0)
+              { int skip;
+                if (S > 0) skip = (hm >= na) ? (hm-na)/ts+1 : 0;
+                else       skip = (hm <= na) ? (na-hm)/ts+1 : 0;
+                if (skip > cross) skip = cross;
+                ncreate = cross - skip;
+              }
+          }
+      }
+      int tot = 0, off = 0;
+      uint64_t cm = __ballot(ncreate > 0);
+      if (cm)
+        { off = wscan_add_excl(ncreate,tot);
+          if ((int64_t) avail + tot > cell_cap)
+            { Ain.p0 = A.p0; Bin.p0 = B.p0; return 1; }
+        }
+      if (act)
+        { if (ncreate > 0)
+            { int idx = avail + off;
+              int v = na + S*ts*(cross-ncreate);
+              for (int q = 0; q < ncreate; q++)
+                { cells[idx] = make_int4(ha,k,dif,v);
+                  ha = idx;
+                  hm = v;
+                  idx += 1;
+                  v += S*ts;
+                }
+            }
+          if (cross > 0)
+            NA = na + S*ts*cross;
+          V = c; T = b; HA = ha; HM = hm;
+        }
+      avail += tot;
+
+      // ordered "new best point" scan (align.c:729-742)
+      int pm = wscan_best_excl<S>(act ? c : ((S > 0) ? -BIGI : BIGI));
+      bool rec = act && ((S > 0) ? (c > besta && c > pm) : (c < besta && c < pm));
+      uint64_t rm = __ballot(rec);
+      if (rm)
+        { int l = last_lane(rm);
+          besta = rdlane(c,l);
+          bestx = rdlane(x,l);
+          int m = __popcll(b & WIN61);
+          bool good = rec && m >= path_ave;
+          uint64_t gm = __ballot(good);
+          if (gm)
+            { lasta = rdlane(c,last_lane(gm));
+              bool trimok = false;
+              if (good)
+                { const uint32_t qlo = (uint32_t) b & TRIM_MASK, qhi = (uint32_t) (b >> TRIM_LEN) & TRIM_MASK;
+                  if (trim_table(qlo,mscore) >= 0)
+                    trimok = trim_table(qhi,mscore) + trim_score(qlo,mscore) >= 0;
+                }
+              uint64_t tm = __ballot(trimok);
+              if (tm)
+                { int l2 = last_lane(tm);
+                  trima = rdlane(c,l2);
+                  trimx = rdlane(x,l2);
+                  trimd = dif;
+                  trimha = rdlane(ha,l2);
+                }
+            }
+        }
+      uint64_t am = __ballot(hitA), bm = __ballot(hitB);
+      if (am) aclip = KOF(last_lane(am));
+      if (bm) bclip = KOF(first_lane(bm));
+      if (am | bm) more = 0;
+
+      RCLIP_UPDATE()
+
+      // prune both ends (align.c:782-790)
+      { const int n = besta - S*WAVE_LAG;
+        const bool inr = k >= low && k <= hgh;
+        uint64_t km = __ballot(inr && ((S > 0) ? (V >= n) : (V <= n)));
+        if (km == 0)
+          hgh = low-1;
+        else
+          { const int f = first_lane(km), l = last_lane(km);
+            if (S > 0) { hgh = kref - f; low = kref - l; }
+            else       { low = kref + f; hgh = kref + l; }
+          }
+      }
+    }
+
+  PF.t_steps += clock64() - tstart;
+  nwaves_out += nwaves;
+  Ain.p0 = A.p0; Bin.p0 = B.p0;
+  ext_unwind<S>(G,cells,trace,P,PF,mida,aoff,trima,trimx,trimd,trimha,mind);
   return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------
 // Local_Alignment (align.c:1423-1576), wave-uniform
 // ---------------------------------------------------------------------------------------------------
-__device__ int local_alignment(const ext_args &G, LDS_PTR ext_shared *sh, int4 *cells, uint16_t *trace, int64_t tmid,
-                               ext_seq &A, ext_seq &B, int acomp,
-                               int low, int hgh, int anti, int lbord, int hbord,
-                               ext_state &P, unsigned long long &nwaves, ext_prof &PF)
+template <bool REG>
+__device__ int local_alignment_impl(const ext_args &G, LDS_PTR ext_shared *sh, int4 *cells, uint16_t *trace, int64_t tmid,
+                                    ext_seq &A, ext_seq &B, int acomp,
+                                    int low, int hgh, int anti, int lbord, int hbord,
+                                    ext_state &P, unsigned long long &nwaves, ext_prof &PF)
 { int minp, maxp, aoff, st;
   P.tpos = (int) tmid;
   P.tlen = 0;
@@ -697,10 +1041,14 @@ __device__ int local_alignment(const ext_args &G, LDS_PTR ext_shared *sh, int4 *
   maxp = (hbord < 0) ?  BIGI : hgh+hbord;
   aoff = acomp ? A.len % G.tspace : 0;
 
-  if ((st = ext_wave<+1>(G,sh,cells,trace,A,B,P,low,hgh,anti,minp,maxp,aoff,nwaves,PF)) != 0) return st;
+#define WAVE_CALL(SS,lo_,hi_,an_)                                                                          \
+  (REG ? ext_wave_reg<SS>(G,cells,trace,A,B,P,lo_,hi_,an_,minp,maxp,aoff,nwaves,PF)                         \
+       : ext_wave<SS>(G,sh,cells,trace,A,B,P,lo_,hi_,an_,minp,maxp,aoff,nwaves,PF))
+
+  if ((st = WAVE_CALL(+1,low,hgh,anti)) != 0) return st;
   int fshort = ((P.aepos + P.bepos) - anti < DUB_TRIM);
   { int l2 = low;
-    if ((st = ext_wave<-1>(G,sh,cells,trace,A,B,P,l2,low,anti,minp,maxp,aoff,nwaves,PF)) != 0) return st;
+    if ((st = WAVE_CALL(-1,l2,low,anti)) != 0) return st;
   }
   int rshort = (anti - (P.abpos + P.bbpos) < DUB_TRIM);
   if (fshort)
@@ -713,7 +1061,7 @@ __device__ int local_alignment(const ext_args &G, LDS_PTR ext_shared *sh, int4 *
         { low  = P.abpos - P.bbpos;
           anti = P.abpos + P.bbpos;
           P.tlen = 0;
-          if ((st = ext_wave<+1>(G,sh,cells,trace,A,B,P,low,low,anti,minp,maxp,aoff,nwaves,PF)) != 0) return st;
+          if ((st = WAVE_CALL(+1,low,low,anti)) != 0) return st;
         }
     }
   else if (rshort)
@@ -721,7 +1069,7 @@ __device__ int local_alignment(const ext_args &G, LDS_PTR ext_shared *sh, int4 *
       anti = P.aepos + P.bepos;
       P.tlen = 0;
       P.diffs = 0;
-      if ((st = ext_wave<-1>(G,sh,cells,trace,A,B,P,low,low,anti,minp,maxp,aoff,nwaves,PF)) != 0) return st;
+      if ((st = WAVE_CALL(-1,low,low,anti)) != 0) return st;
     }
   if (acomp)
     { int i = P.abpos; P.abpos = A.len - P.aepos; P.aepos = A.len - i;
@@ -729,6 +1077,18 @@ __device__ int local_alignment(const ext_args &G, LDS_PTR ext_shared *sh, int4 *
       // the trace pairs are reversed when they are copied out (see emit)
     }
   return 0;
+}
+
+__device__ int local_alignment(const ext_args &G, LDS_PTR ext_shared *sh, int4 *cells, uint16_t *trace, int64_t tmid,
+                               ext_seq &A, ext_seq &B, int acomp,
+                               int low, int hgh, int anti, int lbord, int hbord,
+                               ext_state &P, unsigned long long &nwaves, ext_prof &PF)
+{ int st = G.force_lds ? 3 : local_alignment_impl<true>(G,sh,cells,trace,tmid,A,B,acomp,low,hgh,anti,lbord,hbord,P,nwaves,PF);
+  if (st == 3)      // a wave grew wider than the register routine holds: redo the call on the LDS ring
+    { PF.nsteps += 1;
+      st = local_alignment_impl<false>(G,sh,cells,trace,tmid,A,B,acomp,low,hgh,anti,lbord,hbord,P,nwaves,PF);
+    }
+  return st;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -865,6 +1225,7 @@ void extend_kernel(ext_args G)
       atomicAdd(G.counters+8,PF.t_steps);
       atomicAdd(G.counters+9,PF.t_unwind);
       atomicMax(G.counters+10,nwaves);
+      atomicAdd(G.counters+11,PF.nsteps);
     }
 }
 
@@ -1010,6 +1371,8 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
   A.tspace = prm->tspace; A.path_ave = prm->path_ave; A.self = prm->self;
   A.aln_min = prm->aln_min; A.aln_rate = prm->aln_rate;
   A.mscore = prm->score[0x7fff] / 15;      // SCORE[all matches] = 15 * mscore
+  A.force_lds = getenv("FGA_EXTEND_FORCE_LDS") != NULL;
+  A.dbg_unit = getenv("FGA_EXTEND_DEBUG_UNIT") ? atoi(getenv("FGA_EXTEND_DEBUG_UNIT")) : -1;
   A.cell_cap = cell_cap; A.trace_cap = trace_cap; A.aln_cap = aln_cap; A.tbytes_cap = tb_cap;
 
   fga_unit *d_units = NULL; fga_hit *d_hits = NULL; int *d_order = NULL, *d_next = NULL;
@@ -1058,9 +1421,9 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
     hipMemcpy(hc,d_cnt,sizeof(hc),hipMemcpyDeviceToHost);
     if (getenv("FGA_EXTEND_PROFILE") != NULL)
       fprintf(stderr,"extend profile: max per wavefront: steps %.2f Mcyc, unwind %.2f Mcyc, total %.2f Mcyc, waves %llu; "
-                     "sum: steps %.1f Mcyc unwind %.1f Mcyc; kernel %.2f ms, %d workgroups, %lld units\n",
+                     "sum: steps %.1f Mcyc unwind %.1f Mcyc; kernel %.2f ms, %d workgroups, %lld units, %llu LDS-ring fallbacks\n",
               hc[5]*1e-6,hc[6]*1e-6,hc[7]*1e-6,hc[10],hc[8]*1e-6,hc[9]*1e-6,dev->last_ms[FGA_STAGE_EXTEND],nwg,
-              (long long) H->nunits);
+              (long long) H->nunits,hc[11]);
 
     R->naln = (int64_t) hc[0]; R->ntrace = (int64_t) hc[1]; R->ncalls = (int64_t) hc[2]; R->nwaves = (int64_t) hc[3];
     if (hc[4] != 0)
