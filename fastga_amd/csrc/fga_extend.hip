@@ -60,9 +60,10 @@ struct ext_shared
     int      NA[RC];
     uint32_t winA[WDW+4];     // sliding windows of the two packed sequences around the wave front
     uint32_t winB[WDW+4];
+    int      tsum[32];        // 5-column groups of the trim tables: sum, max prefix incl. / excl. the full group
+    int      tmaxi[32];
+    int      tmaxe[32];
   };
-
-__device__ int g_dbg = 0;
 
 struct ext_prof
   { unsigned long long t_steps, t_unwind, t_total, nsteps, ph[6]; };
@@ -119,16 +120,46 @@ __device__ __forceinline__ uint64_t fetch32(const ext_seq &s, int64_t pos)
   return v;
 }
 
-// number of equal bases going forward from (ax,bx), at most lim
+// 64 bases starting at contig position pos as two 64-bit words (lo = first 32 bases)
+__device__ __forceinline__ void fetch64(const ext_seq &s, int64_t pos, uint64_t &lo, uint64_t &hi)
+{ int64_t p = s.base + pos;
+  int sh = (int) (p & 15) * 2;
+  uint32_t d0, d1, d2, d3, d4;
+  int64_t q = p - s.p0;
+  if (s.p0 >= 0 && q >= 0 && q + 80 <= WINB)
+    { int w = (int) (q >> 4);
+      d0 = s.win[w]; d1 = s.win[w+1]; d2 = s.win[w+2]; d3 = s.win[w+3]; d4 = s.win[w+4];
+    }
+  else
+    { int64_t w = p >> 4;
+      d0 = s.img[w]; d1 = s.img[w+1]; d2 = s.img[w+2]; d3 = s.img[w+3]; d4 = s.img[w+4];
+    }
+  uint64_t a = ((uint64_t) d1 << 32) | d0, b = ((uint64_t) d3 << 32) | d2;
+  if (sh)
+    { lo = (a >> sh) | (b << (64-sh));
+      hi = (b >> sh) | ((uint64_t) d4 << (64-sh));
+    }
+  else
+    { lo = a; hi = b; }
+}
+
+// number of equal bases going forward from (ax,bx), at most lim; 64 bases per step
 __device__ __forceinline__ int match_fwd(const ext_seq &A, const ext_seq &B, int ax, int bx, int lim)
 { int L = 0;
   while (L < lim)
-    { uint64_t x = fetch32(A,(int64_t) ax+L) ^ fetch32(B,(int64_t) bx+L);
+    { uint64_t alo, ahi, blo, bhi;
+      fetch64(A,(int64_t) ax+L,alo,ahi);
+      fetch64(B,(int64_t) bx+L,blo,bhi);
+      uint64_t x = alo ^ blo, y = ahi ^ bhi;
       if (x != 0)
         { L += (__ffsll((unsigned long long) x) - 1) >> 1;
           break;
         }
-      L += 32;
+      if (y != 0)
+        { L += 32 + ((__ffsll((unsigned long long) y) - 1) >> 1);
+          break;
+        }
+      L += 64;
     }
   return L < lim ? L : lim;
 }
@@ -137,12 +168,19 @@ __device__ __forceinline__ int match_fwd(const ext_seq &A, const ext_seq &B, int
 __device__ __forceinline__ int match_rev(const ext_seq &A, const ext_seq &B, int ax, int bx, int lim)
 { int L = 0;
   while (L < lim)
-    { uint64_t x = fetch32(A,(int64_t) ax-L-32) ^ fetch32(B,(int64_t) bx-L-32);
-      if (x != 0)
-        { L += __clzll((long long) x) >> 1;
+    { uint64_t alo, ahi, blo, bhi;
+      fetch64(A,(int64_t) ax-L-64,alo,ahi);
+      fetch64(B,(int64_t) bx-L-64,blo,bhi);
+      uint64_t x = alo ^ blo, y = ahi ^ bhi;      // y holds the 32 bases nearest to (ax,bx)
+      if (y != 0)
+        { L += __clzll((long long) y) >> 1;
           break;
         }
-      L += 32;
+      if (x != 0)
+        { L += 32 + (__clzll((long long) x) >> 1);
+          break;
+        }
+      L += 64;
     }
   return L < lim ? L : lim;
 }
@@ -192,26 +230,39 @@ __device__ __forceinline__ int wscan_best_excl(int v)     // exclusive prefix ma
 __device__ __forceinline__ int last_lane(uint64_t m)  { return 63 - __clzll((long long) m); }
 __device__ __forceinline__ int first_lane(uint64_t m) { return __ffsll((unsigned long long) m) - 1; }
 
-// TABLE / SCORE of the reference's Align_Spec (align.c:207-218) evaluated on the fly: for a 15-bit match
-// pattern p (most significant bit = oldest column) with match = +ms and mismatch = -(1000-ms),
-//   score(p) = sum over the 15 columns,   table(p) = score(p) - max over proper prefixes (incl. empty) of the prefix sum
-// both truncated to int16 exactly like the stored tables.  ~60 integer ops instead of two dependent HBM/L2 reads.
+// TABLE / SCORE of the reference's Align_Spec (align.c:207-218) without the two 64 KB tables: for a 15-bit match
+// pattern p (most significant bit = oldest column), match = +ms, mismatch = -(1000-ms),
+//   score(p) = sum over the 15 columns,   table(p) = score(p) - max over proper prefixes (incl. empty) of the prefix sum,
+// both truncated to int16 like the stored tables.  The pattern is cut into three 5-column groups whose
+// (sum, max prefix) come from a 32-entry LDS table filled at kernel start: 3 independent LDS reads + ~10 integer ops.
 __device__ __forceinline__ int trim_score(uint32_t p, int ms)
 { int ones = __popc(p);
   return (int) (int16_t) (ms*ones - (1000-ms)*(15-ones));
 }
 
-__device__ __forceinline__ int trim_table(uint32_t p, int ms)
-{ int score = 0, mx = 0;
-  const int ds = 1000-ms;
-  #pragma unroll
-  for (int i = 14; i >= 0; i--)
-    { mx = score > mx ? score : mx;
-      score += ((p >> i) & 1) ? ms : -ds;
+__device__ __forceinline__ void trim_fill(LDS_PTR ext_shared *sh, int ms)
+{ const int lane = threadIdx.x & 63;
+  if (lane < 32)
+    { int score = 0, mi = 0, me = 0;
+      const int ds = 1000-ms;
+      #pragma unroll
+      for (int i = 4; i >= 0; i--)
+        { score += ((lane >> i) & 1) ? ms : -ds;
+          if (i > 0) { me = score > me ? score : me; }
+          mi = score > mi ? score : mi;
+        }
+      sh->tsum[lane] = score; sh->tmaxi[lane] = mi; sh->tmaxe[lane] = me;
     }
-  return (int) (int16_t) (score - mx);
 }
 
+__device__ __forceinline__ int trim_table(LDS_PTR ext_shared *sh, uint32_t p)
+{ const uint32_t g1 = (p >> 10) & 31, g2 = (p >> 5) & 31, g3 = p & 31;
+  const int s1 = sh->tsum[g1], s2 = sh->tsum[g2], s3 = sh->tsum[g3];
+  const int m1 = sh->tmaxi[g1], m2 = s1 + sh->tmaxi[g2], m3 = s1 + s2 + sh->tmaxe[g3];
+  int mx = m1 > m2 ? m1 : m2;
+  mx = mx > m3 ? mx : m3;
+  return (int) (int16_t) (s1 + s2 + s3 - mx);
+}
 
 // (re)load the LDS window of a sequence so that contig position `pos` sits `before` bases after its start;
 // wave-uniform, all lanes participate; the caller synchronises before the next fetch
@@ -229,12 +280,12 @@ template <int S>
 __device__ __forceinline__ bool win_track(ext_seq &s, int pos)
 { int64_t p = s.base + pos;
   if (S > 0)
-    { if (s.p0 >= 0 && p - 384 >= s.p0 && p + 1536 <= s.p0 + WINB)
+    { if (s.p0 >= 0 && p - 448 >= s.p0 && p + 1536 <= s.p0 + WINB)
         return false;
       win_load(s,pos,512);
     }
   else
-    { if (s.p0 >= 0 && p + 384 <= s.p0 + WINB && p - 1536 >= s.p0)
+    { if (s.p0 >= 0 && p + 448 <= s.p0 + WINB && p - 1536 >= s.p0)
         return false;
       win_load(s,pos,WINB-512);
     }
@@ -370,9 +421,27 @@ __device__ __attribute__((noinline)) void ext_unwind(const ext_args &G, int4 *ce
 }
 
 // ---------------------------------------------------------------------------------------------------
-// one directional wave extension (S = +1 forward_wave, S = -1 reverse_wave)
-// returns 0 ok, 1 pebble arena full, 2 ring too narrow
+// One directional wave extension (S = +1 forward_wave align.c:352-874, S = -1 reverse_wave align.c:878-1418).
+// returns 0 ok, 1 pebble arena full, 2 wave wider than the LDS ring.
+//
+// Two representations of the per-diagonal state (V, T, HA, HM, NA), switched on the fly by the wave width:
+//   REGISTER mode (width <= 60, the common case): lane l holds diagonal k = kref - S*l, so lane order IS the
+//     reference's sweep order for both directions; V[k-S] sits in lane l+1 and V[k+S] in lane l-1 and travel over
+//     DPP wave_shl:1 / wave_shr:1 -- no LDS traffic except the two sequence windows.  When the wave drifts to
+//     the edge of the 64 lanes every register is rotated (ds_bpermute, rare).
+//   RING mode (wider waves): the state lives in a double-buffered LDS ring indexed by k & 511 and the wave is
+//     swept in chunks of 64 diagonals.
+//   A wave that grows beyond 60 diagonals spills its registers to the ring and continues there; when it has
+//     shrunk to <= 40 it is reloaded into registers.
 // ---------------------------------------------------------------------------------------------------
+#define FROM_NEXT(v,oldv) __builtin_amdgcn_update_dpp(oldv,v,0x130,0xf,0xf,false)    /* lane l gets lane l+1 */
+#define FROM_PREV(v,oldv) __builtin_amdgcn_update_dpp(oldv,v,0x138,0xf,0xf,false)    /* lane l gets lane l-1 */
+#define REG_MAXW 60
+#define REG_BACK 40
+#define KOF(l)    ((S > 0) ? kref - (l) : kref + (l))
+#define LOF(kk)   ((S > 0) ? kref - (kk) : (kk) - kref)
+#define BAIL(code) { Ain.p0 = A.p0; Bin.p0 = B.p0; return code; }
+
 template <int S>
 __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext_shared *shp, int4 *cells, uint16_t *trace,
                         ext_seq &Ain, ext_seq &Bin, ext_state &P,
@@ -383,7 +452,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
   // everything the wave loop touches lives in registers: by-reference arguments of a non-inlined device function
   // sit in scratch (HBM-backed) memory, and a scratch access per step costs more than the step itself
   ext_seq A = Ain, B = Bin;
-  unsigned long long nwaves = 0;
+  unsigned long long nwaves = 0, nspill = 0;
   const int ts = G.tspace, path_ave = G.path_ave, mscore = G.mscore;
   const int64_t cell_cap = G.cell_cap;
   const int VNEW = (S > 0) ? -1 : BIGI;
@@ -391,27 +460,35 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
   int more = 1, avail = 0;
   int aclip = (S > 0) ? BIGI : -BIGI;
   int bclip = (S > 0) ? -BIGI : BIGI;
-  int besta, bestx, trima, trimx, trimd, trimha, morea, morex, mored, moreha, morem, lasta;
+  int besta, bestx, trima, trimx, trimd, trimha, lasta;
 
-  besta = trima = morea = lasta = mida;
-  bestx = trimx = morex = (mida+hgh)>>1;
-  trimd = mored = 0;
-  trimha = moreha = 0;
-  morem = -1;
+  besta = trima = lasta = mida;
+  bestx = trimx = (mida+hgh)>>1;
+  trimd = 0;
+  trimha = 0;
 
   if (hgh-low+8 >= RC)
-    { Ain.p0 = A.p0; Bin.p0 = B.p0; return 2; }
+    BAIL(2)
+
+  bool regmode = !G.force_lds && (hgh-low+1 <= REG_MAXW);
+  int  kref = 0;
+  int      V = VNEW, HA = -1, HM = 0, NA = 0;      // register-mode state of this lane's diagonal
+  uint64_t T = PATH_INT;
+  if (regmode)
+    { const int l0 = (64 - (hgh-low+1)) >> 1;
+      kref = (S > 0) ? hgh + l0 : low - l0;
+    }
 
   win_track<S>(A,bestx);
   win_track<S>(B,mida-bestx);
   WAVE_SYNC();
 
-  // ---- wave 0 -------------------------------------------------------------------------------
+  // ---- wave 0 (align.c:425-512 / 949-1035) ---------------------------------------------------------
   { const int span = hgh-low+1;
     for (int j0 = 0; j0 < span; j0 += 64)
-      { const int j = j0 + lane;
-        const bool act = j < span;
-        const int k = (S > 0) ? hgh-j : low+j;
+      { int k; bool act;
+        if (regmode) { k = KOF(lane); act = k >= low && k <= hgh; }
+        else         { const int j = j0 + lane; act = j < span; k = (S > 0) ? hgh-j : low+j; }
         int x = 0, c = 0, cnt = 0, na = 0, mark0 = 0, hitA = 0, hitB = 0;
         if (act)
           { x = (mida+k)>>1;
@@ -424,17 +501,17 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
               { na = ((x+(ts-aoff)-1)/ts-1)*ts+aoff;
                 mark0 = x;
               }
-            int y = x-k, lim, L;
+            int y = x-k, L;
             if (S > 0)
               { int ra = A.len-x, rb = B.len-y;
-                lim = ra < rb ? ra : rb;
+                int lim = ra < rb ? ra : rb;
                 L = match_fwd(A,B,x,y,lim);
                 if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
                 x += L;
               }
             else
               { int ra = x, rb = y;
-                lim = ra < rb ? ra : rb;
+                int lim = ra < rb ? ra : rb;
                 L = match_rev(A,B,x,y,lim);
                 if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
                 x -= L;
@@ -445,26 +522,29 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
           }
         int tot, off = wscan_add_excl(act ? 1+cnt : 0,tot);
         if ((int64_t) avail + tot > cell_cap)
-          { Ain.p0 = A.p0; Bin.p0 = B.p0; return 1; }
-        int ha = -1;
+          BAIL(1)
+        int ha = -1, hm = 0;
         if (act)
           { int idx = avail + off;
             cells[idx] = make_int4(-1,k,0,mark0);
-            ha = idx;
+            ha = idx; hm = mark0;
             for (int q = 0; q < cnt; q++)
               { idx += 1;
                 cells[idx] = make_int4(ha,k,0,na);
-                ha = idx;
+                ha = idx; hm = na;
                 na += S*ts;
               }
-            shp->V[0][k & RMASK] = c;
-            shp->T[0][k & RMASK] = PATH_INT;
-            shp->HA[0][k & RMASK] = ha;
-            shp->HM[0][k & RMASK] = (cnt > 0) ? na - S*ts : mark0;
-            shp->NA[k & RMASK] = na;
+            if (regmode)
+              { V = c; T = PATH_INT; HA = ha; HM = hm; NA = na; }
+            else
+              { shp->V[0][k & RMASK] = c;
+                shp->T[0][k & RMASK] = PATH_INT;
+                shp->HA[0][k & RMASK] = ha;
+                shp->HM[0][k & RMASK] = hm;
+                shp->NA[k & RMASK] = na;
+              }
           }
         avail += tot;
-        // strict best in sweep order
         int pm = wscan_best_excl<S>(act ? c : ((S > 0) ? -BIGI : BIGI));
         bool rec = act && ((S > 0) ? (c > besta && c > pm) : (c < besta && c < pm));
         uint64_t rm = __ballot(rec);
@@ -482,123 +562,163 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
   }
   WAVE_SYNC();
 
-#define CLIP_FROM(kk,withd)                                                           \
-  { uint64_t tt = shp->T[cur][(kk) & RMASK];                                            \
-    int mm = __popcll(tt & WIN61);                                                    \
-    if (morem <= mm)                                                                  \
-      { morem = mm; morea = shp->V[cur][(kk) & RMASK]; morex = (morea+(kk))>>1;         \
-        if (withd) mored = dif;                                                       \
-        moreha = shp->HA[cur][(kk) & RMASK];                                            \
-      }                                                                               \
-  }
-
-#define CLIP_UPDATE(withd)                                                            \
+  // sequence ends reached: drop the clipped diagonals, go on unless the best point itself sits on an end
+  // (align.c:755-780; the "more" tip is only used with reach = 1, which FastGA never sets, FastGA.c:3757)
+#define CLIP_UPDATE()                                                                 \
   if (more == 0)                                                                      \
     { int cb = (S > 0) ? base_at(B,besta-bestx) : base_at(B,besta-bestx-1);           \
       int ca = (S > 0) ? base_at(A,bestx) : base_at(A,bestx-1);                       \
       if (cb != 4 && ca != 4)                                                         \
         more = 1;                                                                     \
       if (S > 0)                                                                      \
-        { if (hgh >= aclip) { hgh = aclip-1; CLIP_FROM(aclip,withd) }                 \
-          if (low <= bclip) { low = bclip+1; CLIP_FROM(bclip,withd) }                 \
+        { if (hgh >= aclip) hgh = aclip-1;                                            \
+          if (low <= bclip) low = bclip+1;                                            \
           aclip = BIGI; bclip = -BIGI;                                                \
         }                                                                             \
       else                                                                            \
-        { if (low <= aclip) { low = aclip+1; CLIP_FROM(aclip,withd) }                 \
-          if (hgh >= bclip) { hgh = bclip-1; CLIP_FROM(bclip,withd) }                 \
+        { if (low <= aclip) low = aclip+1;                                            \
+          if (hgh >= bclip) hgh = bclip-1;                                            \
           aclip = -BIGI; bclip = BIGI;                                                \
         }                                                                             \
     }
 
-  CLIP_UPDATE(0)
+  CLIP_UPDATE()
 
-  // ---- successive waves ------------------------------------------------------------------------
+  // ---- successive waves (align.c:546-803 / 1067-1323) ----------------------------------------------
   while (more && ((S > 0) ? lasta >= besta - TRIM_MLAG : lasta <= besta + TRIM_MLAG))
-    { if (hgh-low+8 >= RC)
-        { Ain.p0 = A.p0; Bin.p0 = B.p0; return 2; }
-      nwaves += 1;
+    { nwaves += 1;
+      const int olow = low, ohgh = hgh;            // the diagonals that hold valid state
       low -= 1;
       hgh += 1;
-      if (lane == 0)
-        { if (low >= minp)
-            { shp->NA[low & RMASK] = shp->NA[(low+1) & RMASK]; shp->V[cur][low & RMASK] = VNEW; }
-          if (hgh <= maxp)
-            { shp->NA[hgh & RMASK] = shp->NA[(hgh-1) & RMASK]; shp->V[cur][hgh & RMASK] = VNEW; }
-        }
-      if (low < minp) low += 1;
-      if (hgh > maxp) hgh -= 1;
+      const bool newlow = low >= minp, newhgh = hgh <= maxp;
+      if (!newlow) low += 1;
+      if (!newhgh) hgh -= 1;
+      if (hgh-low+8 >= RC)
+        BAIL(2)
       dif += 1;
-      if (lane == 0)
-        shp->V[cur][(hgh+1) & RMASK] = shp->V[cur][(low-1) & RMASK] = VNEW;
+      const int width = hgh-low+1;
+
+      // ---- representation switch ----
+      if (regmode && width > REG_MAXW)
+        { const int k = KOF(lane);
+          if (k >= olow && k <= ohgh)
+            { shp->V[cur][k & RMASK] = V;
+              shp->T[cur][k & RMASK] = T;
+              shp->HA[cur][k & RMASK] = HA;
+              shp->HM[cur][k & RMASK] = HM;
+              shp->NA[k & RMASK] = NA;
+            }
+          regmode = false;
+          nspill += 1;
+          WAVE_SYNC();
+        }
+      else if (!regmode && width <= REG_BACK && !G.force_lds)
+        { const int l0 = (64 - width) >> 1;
+          kref = (S > 0) ? hgh + l0 : low - l0;
+          const int k = KOF(lane);
+          V = VNEW; HA = -1; HM = 0; NA = 0; T = PATH_INT;
+          if (k >= olow && k <= ohgh)
+            { V  = shp->V[cur][k & RMASK];
+              T  = shp->T[cur][k & RMASK];
+              HA = shp->HA[cur][k & RMASK];
+              HM = shp->HM[cur][k & RMASK];
+              NA = shp->NA[k & RMASK];
+            }
+          regmode = true;
+        }
+
       win_track<S>(A,bestx);
       win_track<S>(B,besta-bestx);
-      WAVE_SYNC();
-    
-      const int span = hgh-low+1;
-      const int nxt = cur^1;
+
       uint64_t anyA = 0, anyB = 0;
-      for (int j0 = 0; j0 < span; j0 += 64)
-        { const int j = j0 + lane;
-          const bool act = j < span;
-          const int k = (S > 0) ? hgh-j : low+j;
-          int x = 0, c = 0, ha = -1, hm = 0, hitA = 0, hitB = 0, ncreate = 0, na = 0, cross = 0;
+
+      if (regmode)
+        { // keep the active lanes inside [1,62]: rotate every register when the wave has drifted
+          { const int la = LOF((S > 0) ? hgh : low), lb = LOF((S > 0) ? low : hgh);     // first / last active lane
+            if (la < 1 || lb > 62)
+              { const int want = (64 - (lb-la+1)) >> 1;
+                const int delta = want - la;                    // new lane = old lane + delta
+                const int srcl = lane - delta;
+                V  = __shfl(V,srcl,64);
+                HA = __shfl(HA,srcl,64);
+                HM = __shfl(HM,srcl,64);
+                NA = __shfl(NA,srcl,64);
+                uint32_t tlo = (uint32_t) __shfl((int) (uint32_t) T,srcl,64);
+                uint32_t thi = (uint32_t) __shfl((int) (uint32_t) (T >> 32),srcl,64);
+                T = ((uint64_t) thi << 32) | tlo;
+                kref = (S > 0) ? kref + delta : kref - delta;
+              }
+          }
+          WAVE_SYNC();
+          const int k = KOF(lane);
+          const bool act = k >= low && k <= hgh;
+          // new diagonals take the trace-point schedule of their inner neighbour; everything outside is VNEW
+          { int na_next = FROM_NEXT(NA,0), na_prev = FROM_PREV(NA,0);
+            if (newlow && k == low) NA = (S > 0) ? na_prev : na_next;      // NA[low] = NA[low+1]
+            if (newhgh && k == hgh) NA = (S > 0) ? na_next : na_prev;      // NA[hgh] = NA[hgh-1]
+            if (!act || (newlow && k == low) || (newhgh && k == hgh))
+              V = VNEW;
+          }
+          int x = 0, c = 0, ha = -1, hm = 0, hitA = 0, hitB = 0, ncreate = 0, na = NA, cross = 0;
           uint64_t b = 0;
-          if (act)
-            { int ac = shp->V[cur][k & RMASK];
-              int a1 = shp->V[cur][(k-S) & RMASK];
-              int a2 = shp->V[cur][(k+S) & RMASK];
-              int src;
-              if (S > 0)
-                { if (ac < a1) src = (a1 < a2) ? k+S : k-S;
-                  else         src = (ac < a2) ? k+S : k;
-                }
-              else
-                { if (ac > a1) src = (a1 > a2) ? k+S : k-S;
-                  else         src = (ac > a2) ? k+S : k;
-                }
-              c  = (src == k) ? ac + 2*S : ((src == k-S) ? a1 : a2) + S;
-              b  = shp->T[cur][src & RMASK];
-              ha = shp->HA[cur][src & RMASK];
-              hm = shp->HM[cur][src & RMASK];
-              b <<= 1;
-              x = (c+k)>>1;
-              int y = x-k, L;
-              if (S > 0)
-                { int ra = A.len-x, rb = B.len-y;
-                  int lim = ra < rb ? ra : rb;
-                  L = match_fwd(A,B,x,y,lim);
-                  if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
-                  x += L;
-                }
-              else
-                { int ra = x, rb = y;
-                  int lim = ra < rb ? ra : rb;
-                  L = match_rev(A,B,x,y,lim);
-                  if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
-                  x -= L;
-                }
-              if (L > 0)
-                b = (L >= 61) ? ~0ull : ((b << L) | ((1ull << L) - 1));
-              c = (x << 1) - k;
-              na = shp->NA[k & RMASK];
-              if (S > 0) cross = (x >= na) ? (x-na)/ts+1 : 0;
-              else       cross = (x <= na) ? (na-x)/ts+1 : 0;
-              if (cross > 0)
-                { int mk = hm;
-                  // crossings strictly beyond the head's mark get a pebble
-                  int skip;
-                  if (S > 0) skip = (mk >= na) ? (mk-na)/ts+1 : 0;
-                  else       skip = (mk <= na) ? (na-mk)/ts+1 : 0;
-                  if (skip > cross) skip = cross;
-                  ncreate = cross - skip;
-                }
-            }
+          { const int ac = V;
+            const int a1 = FROM_NEXT(V,VNEW);              // V[k-S]
+            const int a2 = FROM_PREV(V,VNEW);              // V[k+S]
+            int pick;                                      // 0 self, 1 next lane (k-S), 2 previous lane (k+S)
+            if (S > 0)
+              { if (ac < a1) pick = (a1 < a2) ? 2 : 1;
+                else         pick = (ac < a2) ? 2 : 0;
+              }
+            else
+              { if (ac > a1) pick = (a1 > a2) ? 2 : 1;
+                else         pick = (ac > a2) ? 2 : 0;
+              }
+            const uint32_t tlo = (uint32_t) T, thi = (uint32_t) (T >> 32);
+            const uint32_t nlo = (uint32_t) FROM_NEXT((int) tlo,0), nhi = (uint32_t) FROM_NEXT((int) thi,0);
+            const uint32_t plo = (uint32_t) FROM_PREV((int) tlo,0), phi = (uint32_t) FROM_PREV((int) thi,0);
+            const int nha = FROM_NEXT(HA,-1), pha = FROM_PREV(HA,-1);
+            const int nhm = FROM_NEXT(HM,0),  phm = FROM_PREV(HM,0);
+            if (act)
+              { if (pick == 0)      { c = ac + 2*S; b = T; ha = HA; hm = HM; }
+                else if (pick == 1) { c = a1 + S; b = ((uint64_t) nhi << 32) | nlo; ha = nha; hm = nhm; }
+                else                { c = a2 + S; b = ((uint64_t) phi << 32) | plo; ha = pha; hm = phm; }
+                b <<= 1;
+                x = (c+k)>>1;
+                int y = x-k, L;
+                if (S > 0)
+                  { int ra = A.len-x, rb = B.len-y;
+                    int lim = ra < rb ? ra : rb;
+                    L = match_fwd(A,B,x,y,lim);
+                    if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
+                    x += L;
+                  }
+                else
+                  { int ra = x, rb = y;
+                    int lim = ra < rb ? ra : rb;
+                    L = match_rev(A,B,x,y,lim);
+                    if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
+                    x -= L;
+                  }
+                if (L > 0)
+                  b = (L >= 61) ? ~0ull : ((b << L) | ((1ull << L) - 1));
+                c = (x << 1) - k;
+                if (S > 0) cross = (x >= na) ? (x-na)/ts+1 : 0;
+                else       cross = (x <= na) ? (na-x)/ts+1 : 0;
+                if (cross > 0)
+                  { int skip;
+                    if (S > 0) skip = (hm >= na) ? (hm-na)/ts+1 : 0;
+                    else       skip = (hm <= na) ? (na-hm)/ts+1 : 0;
+                    if (skip > cross) skip = cross;
+                    ncreate = cross - skip;
+                  }
+              }
+          }
           int tot = 0, off = 0;
           uint64_t cm = __ballot(ncreate > 0);
           if (cm)
             { off = wscan_add_excl(ncreate,tot);
               if ((int64_t) avail + tot > cell_cap)
-                { Ain.p0 = A.p0; Bin.p0 = B.p0; return 1; }
+                BAIL(1)
             }
           if (act)
             { if (ncreate > 0)
@@ -613,11 +733,8 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                     }
                 }
               if (cross > 0)
-                shp->NA[k & RMASK] = na + S*ts*cross;
-              shp->V[nxt][k & RMASK] = c;
-              shp->T[nxt][k & RMASK] = b;
-              shp->HA[nxt][k & RMASK] = ha;
-              shp->HM[nxt][k & RMASK] = hm;
+                NA = na + S*ts*cross;
+              V = c; T = b; HA = ha; HM = hm;
             }
           avail += tot;
 
@@ -636,9 +753,9 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                 { lasta = rdlane(c,last_lane(gm));
                   bool trimok = false;
                   if (good)
-                    { const uint32_t plo = (uint32_t) b & TRIM_MASK, phi = (uint32_t) (b >> TRIM_LEN) & TRIM_MASK;
-                      if (trim_table(plo,mscore) >= 0)
-                        trimok = trim_table(phi,mscore) + trim_score(plo,mscore) >= 0;
+                    { const uint32_t qlo = (uint32_t) b & TRIM_MASK, qhi = (uint32_t) (b >> TRIM_LEN) & TRIM_MASK;
+                      if (trim_table(shp,qlo) >= 0)
+                        trimok = trim_table(shp,qhi) + trim_score(qlo,mscore) >= 0;
                     }
                   uint64_t tm = __ballot(trimok);
                   if (tm)
@@ -651,373 +768,188 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                 }
             }
           uint64_t am = __ballot(hitA), bm = __ballot(hitB);
-          if (am) aclip = rdlane(k,last_lane(am));
-          if (bm && !anyB) bclip = rdlane(k,first_lane(bm));
-          anyA |= am; anyB |= bm;
-        }
-      if (anyA | anyB) more = 0;
-      cur = nxt;
-      WAVE_SYNC();
-    
-      CLIP_UPDATE(1)
+          if (am) aclip = KOF(last_lane(am));
+          if (bm) bclip = KOF(first_lane(bm));
+          anyA = am; anyB = bm;
+          if (anyA | anyB) more = 0;
 
-      // prune both ends (align.c:782-790)
-      { const int n = besta - S*WAVE_LAG;
-        int nh = low-1, nl = hgh+1;
-        const int sp = hgh-low+1;
-        for (int j0 = 0; j0 < sp; j0 += 64)
-          { int k = low + j0 + lane;
-            bool keep = false;
-            if (k <= hgh)
-              { int v = shp->V[cur][k & RMASK];
-                keep = (S > 0) ? (v >= n) : (v <= n);
-              }
-            uint64_t km = __ballot(keep);
-            if (km)
-              { int f = low + j0 + first_lane(km), l = low + j0 + last_lane(km);
-                if (f < nl) nl = f;
-                if (l > nh) nh = l;
-              }
-          }
-        if (nh < nl)          // nothing survives: the reference leaves hgh < low
-          hgh = low-1;
-        else
-          { hgh = nh; low = nl; }
-      }
-    }
+          CLIP_UPDATE()
 
-  PF.t_steps += clock64() - tstart;
-  nwaves_out += nwaves;
-  Ain.p0 = A.p0; Bin.p0 = B.p0;
-  (void) morea; (void) morex; (void) mored; (void) moreha;
-  ext_unwind<S>(G,cells,trace,P,PF,mida,aoff,trima,trimx,trimd,trimha,mind);
-  return 0;
-}
-
-
-// ---------------------------------------------------------------------------------------------------
-// Register-resident wave extension: the common case (wave narrower than 60 diagonals).
-//   lane l holds diagonal k = kref - S*l, so lane order IS the reference's sweep order for both directions,
-//   the second-priority neighbour V[k-S] sits in lane l+1 and the third-priority V[k+S] in lane l-1.
-//   V, T, HA, HM, NA live in VGPRs; neighbour values travel over DPP wave_shl:1 / wave_shr:1; no LDS state at
-//   all (only the two sequence windows).  When the wave drifts to the edge of the 64 lanes all registers are
-//   rotated (ds_bpermute, rare); if it grows wider than 60 diagonals the routine returns 3 and the caller redoes
-//   the whole Local_Alignment with the LDS-ring routine (results are deterministic, so this is exact).
-// ---------------------------------------------------------------------------------------------------
-#define FROM_NEXT(v,oldv) __builtin_amdgcn_update_dpp(oldv,v,0x130,0xf,0xf,false)    /* lane l gets lane l+1 */
-#define FROM_PREV(v,oldv) __builtin_amdgcn_update_dpp(oldv,v,0x138,0xf,0xf,false)    /* lane l gets lane l-1 */
-#define REG_MAXW 60
-
-template <int S>
-__device__ __attribute__((noinline)) int ext_wave_reg(const ext_args &G, int4 *cells, uint16_t *trace,
-                        ext_seq &Ain, ext_seq &Bin, ext_state &P,
-                        int &mind, int maxd, int mida, int minp, int maxp, int aoff,
-                        unsigned long long &nwaves_out, ext_prof &PF)
-{ const int lane = threadIdx.x & 63;
-  const unsigned long long tstart = clock64();
-  ext_seq A = Ain, B = Bin;
-  unsigned long long nwaves = 0;
-  const int ts = G.tspace, path_ave = G.path_ave, mscore = G.mscore;
-  const int64_t cell_cap = G.cell_cap;
-  const int VNEW = (S > 0) ? -1 : BIGI;
-  int low = mind, hgh = maxd, dif = 0;
-  int more = 1, avail = 0;
-  int aclip = (S > 0) ? BIGI : -BIGI;
-  int bclip = (S > 0) ? -BIGI : BIGI;
-  int besta, bestx, trima, trimx, trimd, trimha, morem, lasta;
-
-  besta = trima = lasta = mida;
-  bestx = trimx = (mida+hgh)>>1;
-  trimd = 0;
-  trimha = 0;
-  morem = -1;
-
-  if (hgh-low+1 > REG_MAXW)
-    { Ain.p0 = A.p0; Bin.p0 = B.p0; return 3; }
-
-  // lane <-> diagonal map, window centred
-  int kref;
-  { const int l0 = (64 - (hgh-low+1)) >> 1;
-    kref = (S > 0) ? hgh + l0 : low - l0;
-  }
-#define KOF(l)    ((S > 0) ? kref - (l) : kref + (l))
-#define LOF(kk)   ((S > 0) ? kref - (kk) : (kk) - kref)
-
-  win_track<S>(A,bestx);
-  win_track<S>(B,mida-bestx);
-  WAVE_SYNC();
-
-  int      V = VNEW, HA = -1, HM = 0, NA = 0;
-  uint64_t T = PATH_INT;
-
-  // ---- wave 0 ----------------------------------------------------------------------------------
-  { const int k = KOF(lane);
-    const bool act = k >= low && k <= hgh;
-    int x = 0, c = 0, cnt = 0, na = 0, mark0 = 0, hitA = 0, hitB = 0;
-    if (act)
-      { x = (mida+k)>>1;
-        if (S > 0)
-          { na = ((x+(ts-aoff))/ts-1)*ts+aoff;
-            mark0 = na;
-            na += ts;
-          }
-        else
-          { na = ((x+(ts-aoff)-1)/ts-1)*ts+aoff;
-            mark0 = x;
-          }
-        int y = x-k, L;
-        if (S > 0)
-          { int ra = A.len-x, rb = B.len-y;
-            int lim = ra < rb ? ra : rb;
-            L = match_fwd(A,B,x,y,lim);
-            if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
-            x += L;
-          }
-        else
-          { int ra = x, rb = y;
-            int lim = ra < rb ? ra : rb;
-            L = match_rev(A,B,x,y,lim);
-            if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
-            x -= L;
-          }
-        c = (x << 1) - k;
-        if (S > 0) cnt = (x >= na) ? (x-na)/ts+1 : 0;
-        else       cnt = (x <= na) ? (na-x)/ts+1 : 0;
-      }
-    int tot, off = wscan_add_excl(act ? 1+cnt : 0,tot);
-    if ((int64_t) avail + tot > cell_cap)
-      { Ain.p0 = A.p0; Bin.p0 = B.p0; return 1; }
-    int ha = -1, hm = 0;
-    if (act)
-      { int idx = avail + off;
-        cells[idx] = make_int4(-1,k,0,mark0);
-        ha = idx; hm = mark0;
-        for (int q = 0; q < cnt; q++)
-          { idx += 1;
-            cells[idx] = make_int4(ha,k,0,na);
-            ha = idx; hm = na;
-            na += S*ts;
-          }
-        V = c; T = PATH_INT; HA = ha; HM = hm; NA = na;
-      }
-    avail += tot;
-    int pm = wscan_best_excl<S>(act ? c : ((S > 0) ? -BIGI : BIGI));
-    bool rec = act && ((S > 0) ? (c > besta && c > pm) : (c < besta && c < pm));
-    uint64_t rm = __ballot(rec);
-    if (rm)
-      { int l = last_lane(rm);
-        besta = trima = lasta = rdlane(c,l);
-        bestx = trimx = rdlane(x,l);
-        trimha = rdlane(ha,l);
-      }
-    uint64_t am = __ballot(hitA), bm = __ballot(hitB);
-    if (am | bm) more = 0;
-    if (am) aclip = KOF(last_lane(am));
-    if (bm) bclip = KOF(first_lane(bm));
-  }
-
-#define RCLIP_FROM(kk)                                                               \
-  { const int _l = LOF(kk);                                                          \
-    uint32_t tlo = (uint32_t) rdlane((int) (uint32_t) T,_l);                         \
-    uint32_t thi = (uint32_t) rdlane((int) (uint32_t) (T >> 32),_l);                 \
-    int mm = __popcll((((uint64_t) thi << 32) | tlo) & WIN61);                       \
-    if (morem <= mm)                                                                 \
-      morem = mm;                                                                    \
-  }
-
-#define RCLIP_UPDATE()                                                               \
-  if (more == 0)                                                                     \
-    { int cb = (S > 0) ? base_at(B,besta-bestx) : base_at(B,besta-bestx-1);          \
-      int ca = (S > 0) ? base_at(A,bestx) : base_at(A,bestx-1);                      \
-      if (cb != 4 && ca != 4)                                                        \
-        more = 1;                                                                    \
-      if (S > 0)                                                                     \
-        { if (hgh >= aclip) { hgh = aclip-1; RCLIP_FROM(aclip) }                     \
-          if (low <= bclip) { low = bclip+1; RCLIP_FROM(bclip) }                     \
-          aclip = BIGI; bclip = -BIGI;                                               \
-        }                                                                            \
-      else                                                                           \
-        { if (low <= aclip) { low = aclip+1; RCLIP_FROM(aclip) }                     \
-          if (hgh >= bclip) { hgh = bclip-1; RCLIP_FROM(bclip) }                     \
-          aclip = -BIGI; bclip = BIGI;                                               \
-        }                                                                            \
-    }
-
-  RCLIP_UPDATE()
-
-  // ---- successive waves ------------------------------------------------------------------------
-  while (more && ((S > 0) ? lasta >= besta - TRIM_MLAG : lasta <= besta + TRIM_MLAG))
-    { nwaves += 1;
-      low -= 1;
-      hgh += 1;
-      const bool newlow = low >= minp, newhgh = hgh <= maxp;
-      if (!newlow) low += 1;
-      if (!newhgh) hgh -= 1;
-      if (hgh-low+1 > REG_MAXW)
-        { Ain.p0 = A.p0; Bin.p0 = B.p0; return 3; }
-      dif += 1;
-
-      // keep the active lanes inside [1,62]: rotate every register when the wave has drifted
-      { const int la = LOF((S > 0) ? hgh : low), lb = LOF((S > 0) ? low : hgh);     // first / last active lane
-        if (la < 1 || lb > 62)
-          { const int want = (64 - (lb-la+1)) >> 1;
-            const int delta = want - la;                    // new lane = old lane + delta
-            const int srcl = lane - delta;
-            V  = __shfl(V,srcl,64);
-            HA = __shfl(HA,srcl,64);
-            HM = __shfl(HM,srcl,64);
-            NA = __shfl(NA,srcl,64);
-            uint32_t tlo = (uint32_t) __shfl((int) (uint32_t) T,srcl,64);
-            uint32_t thi = (uint32_t) __shfl((int) (uint32_t) (T >> 32),srcl,64);
-            T = ((uint64_t) thi << 32) | tlo;
-            kref = (S > 0) ? kref + delta : kref - delta;
-          }
-      }
-
-      const int k = KOF(lane);
-      const bool act = k >= low && k <= hgh;
-      // new diagonals take the trace-point schedule of their inner neighbour; everything outside is VNEW
-      { int na_next = FROM_NEXT(NA,0), na_prev = FROM_PREV(NA,0);
-        if (newlow && k == low) NA = (S > 0) ? na_prev : na_next;      // NA[low] = NA[low+1]
-        if (newhgh && k == hgh) NA = (S > 0) ? na_next : na_prev;      // NA[hgh] = NA[hgh-1]
-        if (!act || (newlow && k == low) || (newhgh && k == hgh))
-          V = VNEW;
-      }
-
-      win_track<S>(A,bestx);
-      win_track<S>(B,besta-bestx);
-      WAVE_SYNC();
-
-      int x = 0, c = 0, ha = -1, hm = 0, hitA = 0, hitB = 0, ncreate = 0, na = NA, cross = 0;
-      uint64_t b = 0;
-      { const int ac = V;
-        const int a1 = FROM_NEXT(V,VNEW);              // V[k-S]
-        const int a2 = FROM_PREV(V,VNEW);              // V[k+S]
-        int pick;                                      // 0 self, 1 next lane (k-S), 2 previous lane (k+S)
-        if (S > 0)
-          { if (ac < a1) pick = (a1 < a2) ? 2 : 1;
-            else         pick = (ac < a2) ? 2 : 0;
-          }
-        else
-          { if (ac > a1) pick = (a1 > a2) ? 2 : 1;
-            else         pick = (ac > a2) ? 2 : 0;
-          }
-        const uint32_t tlo = (uint32_t) T, thi = (uint32_t) (T >> 32);
-        const uint32_t nlo = (uint32_t) FROM_NEXT((int) tlo,0), nhi = (uint32_t) FROM_NEXT((int) thi,0);
-        const uint32_t plo = (uint32_t) FROM_PREV((int) tlo,0), phi = (uint32_t) FROM_PREV((int) thi,0);
-        const int nha = FROM_NEXT(HA,-1), pha = FROM_PREV(HA,-1);
-        const int nhm = FROM_NEXT(HM,0),  phm = FROM_PREV(HM,0);
-        if (act)
-          { if (pick == 0)      { c = ac + 2*S; b = T; ha = HA; hm = HM; }
-            else if (pick == 1) { c = a1 + S; b = ((uint64_t) nhi << 32) | nlo; ha = nha; hm = nhm; }
-            else                { c = a2 + S; b = ((uint64_t) phi << 32) | plo; ha = pha; hm = phm; }
-            b <<= 1;
-            x = (c+k)>>1;
-            int y = x-k, L;
-            if (S > 0)
-              { int ra = A.len-x, rb = B.len-y;
-                int lim = ra < rb ? ra : rb;
-                L = match_fwd(A,B,x,y,lim);
-                if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
-                x += L;
-              }
+          // prune both ends (align.c:782-790)
+          { const int n = besta - S*WAVE_LAG;
+            const bool inr = k >= low && k <= hgh;
+            uint64_t km = __ballot(inr && ((S > 0) ? (V >= n) : (V <= n)));
+            if (km == 0)
+              hgh = low-1;
             else
-              { int ra = x, rb = y;
-                int lim = ra < rb ? ra : rb;
-                L = match_rev(A,B,x,y,lim);
-                if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
-                x -= L;
-              }
-            if (L > 0)
-              b = (L >= 61) ? ~0ull : ((b << L) | ((1ull << L) - 1));
-            c = (x << 1) - k;
-            if (S > 0) cross = (x >= na) ? (x-na)/ts+1 : 0;
-            else       cross = (x <= na) ? (na-x)/ts+1 : 0;
-            if (cross > 0)
-              { int skip;
-                if (S > 0) skip = (hm >= na) ? (hm-na)/ts+1 : 0;
-                else       skip = (hm <= na) ? (na-hm)/ts+1 : 0;
-                if (skip > cross) skip = cross;
-                ncreate = cross - skip;
+              { const int f = first_lane(km), l = last_lane(km);
+                if (S > 0) { hgh = kref - f; low = kref - l; }
+                else       { low = kref + f; hgh = kref + l; }
               }
           }
-      }
-      int tot = 0, off = 0;
-      uint64_t cm = __ballot(ncreate > 0);
-      if (cm)
-        { off = wscan_add_excl(ncreate,tot);
-          if ((int64_t) avail + tot > cell_cap)
-            { Ain.p0 = A.p0; Bin.p0 = B.p0; return 1; }
         }
-      if (act)
-        { if (ncreate > 0)
-            { int idx = avail + off;
-              int v = na + S*ts*(cross-ncreate);
-              for (int q = 0; q < ncreate; q++)
-                { cells[idx] = make_int4(ha,k,dif,v);
-                  ha = idx;
-                  hm = v;
-                  idx += 1;
-                  v += S*ts;
-                }
+      else
+        { // ---------------- RING mode ----------------
+          if (lane == 0)
+            { if (newlow)
+                { shp->NA[low & RMASK] = shp->NA[(low+1) & RMASK]; shp->V[cur][low & RMASK] = VNEW; }
+              if (newhgh)
+                { shp->NA[hgh & RMASK] = shp->NA[(hgh-1) & RMASK]; shp->V[cur][hgh & RMASK] = VNEW; }
+              shp->V[cur][(hgh+1) & RMASK] = shp->V[cur][(low-1) & RMASK] = VNEW;
             }
-          if (cross > 0)
-            NA = na + S*ts*cross;
-          V = c; T = b; HA = ha; HM = hm;
-        }
-      avail += tot;
+          WAVE_SYNC();
 
-      // ordered "new best point" scan (align.c:729-742)
-      int pm = wscan_best_excl<S>(act ? c : ((S > 0) ? -BIGI : BIGI));
-      bool rec = act && ((S > 0) ? (c > besta && c > pm) : (c < besta && c < pm));
-      uint64_t rm = __ballot(rec);
-      if (rm)
-        { int l = last_lane(rm);
-          besta = rdlane(c,l);
-          bestx = rdlane(x,l);
-          int m = __popcll(b & WIN61);
-          bool good = rec && m >= path_ave;
-          uint64_t gm = __ballot(good);
-          if (gm)
-            { lasta = rdlane(c,last_lane(gm));
-              bool trimok = false;
-              if (good)
-                { const uint32_t qlo = (uint32_t) b & TRIM_MASK, qhi = (uint32_t) (b >> TRIM_LEN) & TRIM_MASK;
-                  if (trim_table(qlo,mscore) >= 0)
-                    trimok = trim_table(qhi,mscore) + trim_score(qlo,mscore) >= 0;
+          const int span = hgh-low+1;
+          const int nxt = cur^1;
+          for (int j0 = 0; j0 < span; j0 += 64)
+            { const int j = j0 + lane;
+              const bool act = j < span;
+              const int k = (S > 0) ? hgh-j : low+j;
+              int x = 0, c = 0, ha = -1, hm = 0, hitA = 0, hitB = 0, ncreate = 0, na = 0, cross = 0;
+              uint64_t b = 0;
+              if (act)
+                { int ac = shp->V[cur][k & RMASK];
+                  int a1 = shp->V[cur][(k-S) & RMASK];
+                  int a2 = shp->V[cur][(k+S) & RMASK];
+                  int src;
+                  if (S > 0)
+                    { if (ac < a1) src = (a1 < a2) ? k+S : k-S;
+                      else         src = (ac < a2) ? k+S : k;
+                    }
+                  else
+                    { if (ac > a1) src = (a1 > a2) ? k+S : k-S;
+                      else         src = (ac > a2) ? k+S : k;
+                    }
+                  c  = (src == k) ? ac + 2*S : ((src == k-S) ? a1 : a2) + S;
+                  b  = shp->T[cur][src & RMASK];
+                  ha = shp->HA[cur][src & RMASK];
+                  hm = shp->HM[cur][src & RMASK];
+                  b <<= 1;
+                  x = (c+k)>>1;
+                  int y = x-k, L;
+                  if (S > 0)
+                    { int ra = A.len-x, rb = B.len-y;
+                      int lim = ra < rb ? ra : rb;
+                      L = match_fwd(A,B,x,y,lim);
+                      if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
+                      x += L;
+                    }
+                  else
+                    { int ra = x, rb = y;
+                      int lim = ra < rb ? ra : rb;
+                      L = match_rev(A,B,x,y,lim);
+                      if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
+                      x -= L;
+                    }
+                  if (L > 0)
+                    b = (L >= 61) ? ~0ull : ((b << L) | ((1ull << L) - 1));
+                  c = (x << 1) - k;
+                  na = shp->NA[k & RMASK];
+                  if (S > 0) cross = (x >= na) ? (x-na)/ts+1 : 0;
+                  else       cross = (x <= na) ? (na-x)/ts+1 : 0;
+                  if (cross > 0)
+                    { int skip;
+                      if (S > 0) skip = (hm >= na) ? (hm-na)/ts+1 : 0;
+                      else       skip = (hm <= na) ? (na-hm)/ts+1 : 0;
+                      if (skip > cross) skip = cross;
+                      ncreate = cross - skip;
+                    }
                 }
-              uint64_t tm = __ballot(trimok);
-              if (tm)
-                { int l2 = last_lane(tm);
-                  trima = rdlane(c,l2);
-                  trimx = rdlane(x,l2);
-                  trimd = dif;
-                  trimha = rdlane(ha,l2);
+              int tot = 0, off = 0;
+              uint64_t cm = __ballot(ncreate > 0);
+              if (cm)
+                { off = wscan_add_excl(ncreate,tot);
+                  if ((int64_t) avail + tot > cell_cap)
+                    BAIL(1)
                 }
+              if (act)
+                { if (ncreate > 0)
+                    { int idx = avail + off;
+                      int v = na + S*ts*(cross-ncreate);
+                      for (int q = 0; q < ncreate; q++)
+                        { cells[idx] = make_int4(ha,k,dif,v);
+                          ha = idx;
+                          hm = v;
+                          idx += 1;
+                          v += S*ts;
+                        }
+                    }
+                  if (cross > 0)
+                    shp->NA[k & RMASK] = na + S*ts*cross;
+                  shp->V[nxt][k & RMASK] = c;
+                  shp->T[nxt][k & RMASK] = b;
+                  shp->HA[nxt][k & RMASK] = ha;
+                  shp->HM[nxt][k & RMASK] = hm;
+                }
+              avail += tot;
+
+              int pm = wscan_best_excl<S>(act ? c : ((S > 0) ? -BIGI : BIGI));
+              bool rec = act && ((S > 0) ? (c > besta && c > pm) : (c < besta && c < pm));
+              uint64_t rm = __ballot(rec);
+              if (rm)
+                { int l = last_lane(rm);
+                  besta = rdlane(c,l);
+                  bestx = rdlane(x,l);
+                  int m = __popcll(b & WIN61);
+                  bool good = rec && m >= path_ave;
+                  uint64_t gm = __ballot(good);
+                  if (gm)
+                    { lasta = rdlane(c,last_lane(gm));
+                      bool trimok = false;
+                      if (good)
+                        { const uint32_t qlo = (uint32_t) b & TRIM_MASK, qhi = (uint32_t) (b >> TRIM_LEN) & TRIM_MASK;
+                          if (trim_table(shp,qlo) >= 0)
+                            trimok = trim_table(shp,qhi) + trim_score(qlo,mscore) >= 0;
+                        }
+                      uint64_t tm = __ballot(trimok);
+                      if (tm)
+                        { int l2 = last_lane(tm);
+                          trima = rdlane(c,l2);
+                          trimx = rdlane(x,l2);
+                          trimd = dif;
+                          trimha = rdlane(ha,l2);
+                        }
+                    }
+                }
+              uint64_t am = __ballot(hitA), bm = __ballot(hitB);
+              if (am) aclip = rdlane(k,last_lane(am));
+              if (bm && !anyB) bclip = rdlane(k,first_lane(bm));
+              anyA |= am; anyB |= bm;
             }
-        }
-      uint64_t am = __ballot(hitA), bm = __ballot(hitB);
-      if (am) aclip = KOF(last_lane(am));
-      if (bm) bclip = KOF(first_lane(bm));
-      if (am | bm) more = 0;
+          if (anyA | anyB) more = 0;
+          cur = nxt;
+          WAVE_SYNC();
 
-      RCLIP_UPDATE()
+          CLIP_UPDATE()
 
-      // prune both ends (align.c:782-790)
-      { const int n = besta - S*WAVE_LAG;
-        const bool inr = k >= low && k <= hgh;
-        uint64_t km = __ballot(inr && ((S > 0) ? (V >= n) : (V <= n)));
-        if (km == 0)
-          hgh = low-1;
-        else
-          { const int f = first_lane(km), l = last_lane(km);
-            if (S > 0) { hgh = kref - f; low = kref - l; }
-            else       { low = kref + f; hgh = kref + l; }
+          // prune both ends (align.c:782-790)
+          { const int n = besta - S*WAVE_LAG;
+            int nh = low-1, nl = hgh+1;
+            const int sp = hgh-low+1;
+            for (int j0 = 0; j0 < sp; j0 += 64)
+              { int k = low + j0 + lane;
+                bool keep = false;
+                if (k <= hgh)
+                  { int v = shp->V[cur][k & RMASK];
+                    keep = (S > 0) ? (v >= n) : (v <= n);
+                  }
+                uint64_t km = __ballot(keep);
+                if (km)
+                  { int f = low + j0 + first_lane(km), l = low + j0 + last_lane(km);
+                    if (f < nl) nl = f;
+                    if (l > nh) nh = l;
+                  }
+              }
+            if (nh < nl)          // nothing survives: the reference leaves hgh < low
+              hgh = low-1;
+            else
+              { hgh = nh; low = nl; }
           }
-      }
+        }
     }
 
   PF.t_steps += clock64() - tstart;
+  PF.nsteps += nspill;
   nwaves_out += nwaves;
   Ain.p0 = A.p0; Bin.p0 = B.p0;
   ext_unwind<S>(G,cells,trace,P,PF,mida,aoff,trima,trimx,trimd,trimha,mind);
@@ -1027,11 +959,10 @@ __device__ __attribute__((noinline)) int ext_wave_reg(const ext_args &G, int4 *c
 // ---------------------------------------------------------------------------------------------------
 // Local_Alignment (align.c:1423-1576), wave-uniform
 // ---------------------------------------------------------------------------------------------------
-template <bool REG>
-__device__ int local_alignment_impl(const ext_args &G, LDS_PTR ext_shared *sh, int4 *cells, uint16_t *trace, int64_t tmid,
-                                    ext_seq &A, ext_seq &B, int acomp,
-                                    int low, int hgh, int anti, int lbord, int hbord,
-                                    ext_state &P, unsigned long long &nwaves, ext_prof &PF)
+__device__ int local_alignment(const ext_args &G, LDS_PTR ext_shared *sh, int4 *cells, uint16_t *trace, int64_t tmid,
+                               ext_seq &A, ext_seq &B, int acomp,
+                               int low, int hgh, int anti, int lbord, int hbord,
+                               ext_state &P, unsigned long long &nwaves, ext_prof &PF)
 { int minp, maxp, aoff, st;
   P.tpos = (int) tmid;
   P.tlen = 0;
@@ -1041,14 +972,10 @@ __device__ int local_alignment_impl(const ext_args &G, LDS_PTR ext_shared *sh, i
   maxp = (hbord < 0) ?  BIGI : hgh+hbord;
   aoff = acomp ? A.len % G.tspace : 0;
 
-#define WAVE_CALL(SS,lo_,hi_,an_)                                                                          \
-  (REG ? ext_wave_reg<SS>(G,cells,trace,A,B,P,lo_,hi_,an_,minp,maxp,aoff,nwaves,PF)                         \
-       : ext_wave<SS>(G,sh,cells,trace,A,B,P,lo_,hi_,an_,minp,maxp,aoff,nwaves,PF))
-
-  if ((st = WAVE_CALL(+1,low,hgh,anti)) != 0) return st;
+  if ((st = ext_wave<+1>(G,sh,cells,trace,A,B,P,low,hgh,anti,minp,maxp,aoff,nwaves,PF)) != 0) return st;
   int fshort = ((P.aepos + P.bepos) - anti < DUB_TRIM);
   { int l2 = low;
-    if ((st = WAVE_CALL(-1,l2,low,anti)) != 0) return st;
+    if ((st = ext_wave<-1>(G,sh,cells,trace,A,B,P,l2,low,anti,minp,maxp,aoff,nwaves,PF)) != 0) return st;
   }
   int rshort = (anti - (P.abpos + P.bbpos) < DUB_TRIM);
   if (fshort)
@@ -1061,7 +988,7 @@ __device__ int local_alignment_impl(const ext_args &G, LDS_PTR ext_shared *sh, i
         { low  = P.abpos - P.bbpos;
           anti = P.abpos + P.bbpos;
           P.tlen = 0;
-          if ((st = WAVE_CALL(+1,low,low,anti)) != 0) return st;
+          if ((st = ext_wave<+1>(G,sh,cells,trace,A,B,P,low,low,anti,minp,maxp,aoff,nwaves,PF)) != 0) return st;
         }
     }
   else if (rshort)
@@ -1069,7 +996,7 @@ __device__ int local_alignment_impl(const ext_args &G, LDS_PTR ext_shared *sh, i
       anti = P.aepos + P.bepos;
       P.tlen = 0;
       P.diffs = 0;
-      if ((st = WAVE_CALL(-1,low,low,anti)) != 0) return st;
+      if ((st = ext_wave<-1>(G,sh,cells,trace,A,B,P,low,low,anti,minp,maxp,aoff,nwaves,PF)) != 0) return st;
     }
   if (acomp)
     { int i = P.abpos; P.abpos = A.len - P.aepos; P.aepos = A.len - i;
@@ -1079,18 +1006,6 @@ __device__ int local_alignment_impl(const ext_args &G, LDS_PTR ext_shared *sh, i
   return 0;
 }
 
-__device__ int local_alignment(const ext_args &G, LDS_PTR ext_shared *sh, int4 *cells, uint16_t *trace, int64_t tmid,
-                               ext_seq &A, ext_seq &B, int acomp,
-                               int low, int hgh, int anti, int lbord, int hbord,
-                               ext_state &P, unsigned long long &nwaves, ext_prof &PF)
-{ int st = G.force_lds ? 3 : local_alignment_impl<true>(G,sh,cells,trace,tmid,A,B,acomp,low,hgh,anti,lbord,hbord,P,nwaves,PF);
-  if (st == 3)      // a wave grew wider than the register routine holds: redo the call on the LDS ring
-    { PF.nsteps += 1;
-      st = local_alignment_impl<false>(G,sh,cells,trace,tmid,A,B,acomp,low,hgh,anti,lbord,hbord,P,nwaves,PF);
-    }
-  return st;
-}
-
 // ---------------------------------------------------------------------------------------------------
 // kernel: persistent wavefronts pull units from a queue (longest estimated first)
 // ---------------------------------------------------------------------------------------------------
@@ -1098,6 +1013,8 @@ __global__ __launch_bounds__(64)
 void extend_kernel(ext_args G)
 { __shared__ ext_shared sh_storage;
   LDS_PTR ext_shared *sh = (LDS_PTR ext_shared *) &sh_storage;
+  trim_fill(sh,G.mscore);
+  __syncthreads();
   const int lane = threadIdx.x;
   int4     *cells = G.cells + (int64_t) blockIdx.x * G.cell_cap;
   uint16_t *trace = G.trace + (int64_t) blockIdx.x * G.trace_cap;
@@ -1421,7 +1338,7 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
     hipMemcpy(hc,d_cnt,sizeof(hc),hipMemcpyDeviceToHost);
     if (getenv("FGA_EXTEND_PROFILE") != NULL)
       fprintf(stderr,"extend profile: max per wavefront: steps %.2f Mcyc, unwind %.2f Mcyc, total %.2f Mcyc, waves %llu; "
-                     "sum: steps %.1f Mcyc unwind %.1f Mcyc; kernel %.2f ms, %d workgroups, %lld units, %llu LDS-ring fallbacks\n",
+                     "sum: steps %.1f Mcyc unwind %.1f Mcyc; kernel %.2f ms, %d workgroups, %lld units, %llu register->ring spills\n",
               hc[5]*1e-6,hc[6]*1e-6,hc[7]*1e-6,hc[10],hc[8]*1e-6,hc[9]*1e-6,dev->last_ms[FGA_STAGE_EXTEND],nwg,
               (long long) H->nunits,hc[11]);
 
