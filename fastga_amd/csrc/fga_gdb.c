@@ -207,6 +207,9 @@ int fga_fasta_to_gdb(const char *fasta, const char *target, int ncut)
   uint8_t  byte;
   int64_t  clen, spos, nin;
   int      inscaf;
+  /* soft mask = lower-case runs (Create_GDB keeps them as an implicit .1ano, GDB.c:988-1010) */
+  int64_t  mrun = -1, nmask = 0, mcap = 0;
+  int64_t *mctg = NULL, *mbeg = NULL, *mend = NULL;
 
   memset(&G,0,sizeof(G));
 
@@ -230,9 +233,21 @@ int fga_fasta_to_gdb(const char *fasta, const char *target, int ncut)
 
   m = 0; byte = 0; clen = 0; spos = 0; nin = 0; inscaf = 0;
 
+#define PUSH_MASK(b_,e_)                                                          \
+  { if (nmask >= mcap)                                                            \
+      { mcap = mcap*2 + 1024;                                                     \
+        mctg = realloc(mctg,sizeof(int64_t)*mcap);                                \
+        mbeg = realloc(mbeg,sizeof(int64_t)*mcap);                                \
+        mend = realloc(mend,sizeof(int64_t)*mcap);                                \
+        if (mctg == NULL || mbeg == NULL || mend == NULL) goto oom;               \
+      }                                                                           \
+    mctg[nmask] = G.ncontig; mbeg[nmask] = (b_); mend[nmask] = (e_); nmask += 1;  \
+  }
+
 #define END_CONTIG()                                                              \
   { if (clen > 0)                                                                 \
-      { if (m > 0) { if (bv_push(&bps,byte)) goto oom; }                          \
+      { if (mrun >= 0) { PUSH_MASK(mrun,clen) mrun = -1; }                        \
+        if (m > 0) { if (bv_push(&bps,byte)) goto oom; }                          \
         byte = 0; m = 0;                                                          \
         if (G.ncontig >= cttop)                                                   \
           { cttop = (int) (1.2*G.ncontig) + 1000;                                 \
@@ -325,6 +340,12 @@ int fga_fasta_to_gdb(const char *fasta, const char *target, int ncut)
                   }
                 nin = 0;
               }
+            if (line[s] >= 96)                      /* lower case: inside a soft-mask run */
+              { if (mrun < 0) mrun = clen; }
+            else if (mrun >= 0)
+              { PUSH_MASK(mrun,clen)
+                mrun = -1;
+              }
             byte |= (uint8_t) (x << m);
             if (m == 6) { if (bv_push(&bps,byte)) goto oom; byte = 0; m = 0; }
             else m += 2;
@@ -371,6 +392,28 @@ int fga_fasta_to_gdb(const char *fasta, const char *target, int ncut)
     fclose(b);
   }
 
+  { char *mpath = NULL;             /* soft-mask side file (only when the FASTA mixes cases) */
+    if (asprintf(&mpath,"%s/.%s.msk",dir,root) < 0) goto oom;
+    if (nmask > 0 && nmask < G.seqtot)
+      { FILE *mf = fopen(mpath,"w");
+        int64_t hdr[2];
+        if (mf == NULL)
+          { fga_set_error("cannot open %s for writing",mpath);
+            free(mpath);
+            goto fail;
+          }
+        hdr[0] = G.ncontig; hdr[1] = nmask;
+        fwrite(hdr,sizeof(int64_t),2,mf);
+        fwrite(mctg,sizeof(int64_t),nmask,mf);
+        fwrite(mbeg,sizeof(int64_t),nmask,mf);
+        fwrite(mend,sizeof(int64_t),nmask,mf);
+        fclose(mf);
+      }
+    else
+      unlink(mpath);
+    free(mpath);
+  }
+
   { char cmd[2048];
     snprintf(cmd,sizeof(cmd),"fga_fasta_to_gdb %s %s",fasta,target);
     if (write_skeleton_file(&G,gpath,"FAtoGDB",cmd))
@@ -386,6 +429,7 @@ fail:
 done:
   if (in != NULL) gzclose(in);
   free(line); line = NULL;
+  free(mctg); free(mbeg); free(mend);
   free(bps.buf);
   free(hdr);
   free(G.scaffolds);
@@ -566,6 +610,34 @@ int fga_gdb_open(const char *path, fga_gdb **out)
     fclose(b);
   }
 
+  { char *mpath = NULL;
+    FILE *mf;
+    if (asprintf(&mpath,"%s/.%s.msk",dir,root) >= 0 && (mf = fopen(mpath,"r")) != NULL)
+      { int64_t hdr[2], *ctg = NULL, i;
+        if (fread(hdr,sizeof(int64_t),2,mf) == 2 && hdr[0] == G->ncontig && hdr[1] > 0)
+          { G->nmask = hdr[1];
+            ctg = malloc(sizeof(int64_t)*G->nmask);
+            G->mbeg = malloc(sizeof(int64_t)*G->nmask);
+            G->mend = malloc(sizeof(int64_t)*G->nmask);
+            G->moff = calloc(G->ncontig+1,sizeof(int64_t));
+            if (ctg != NULL && G->mbeg != NULL && G->mend != NULL && G->moff != NULL &&
+                fread(ctg,sizeof(int64_t),G->nmask,mf) == (size_t) G->nmask &&
+                fread(G->mbeg,sizeof(int64_t),G->nmask,mf) == (size_t) G->nmask &&
+                fread(G->mend,sizeof(int64_t),G->nmask,mf) == (size_t) G->nmask)
+              { for (i = 0; i < G->nmask; i++)
+                  G->moff[ctg[i]+1] += 1;
+                for (i = 0; i < G->ncontig; i++)
+                  G->moff[i+1] += G->moff[i];
+              }
+            else
+              G->nmask = 0;
+            free(ctg);
+          }
+        fclose(mf);
+      }
+    free(mpath);
+  }
+
   free(line); free(noext); free(dir); free(root); free(spath); free(bpath);
   *out = G;
   return 0;
@@ -584,6 +656,7 @@ void fga_gdb_close(fga_gdb *G)
 { if (G == NULL) return;
   free(G->scaffolds); free(G->contigs); free(G->headers); free(G->srcpath); free(G->path);
   free(G->bps);
+  free(G->moff); free(G->mbeg); free(G->mend);
   free(G);
 }
 
@@ -592,6 +665,7 @@ int     fga_gdb_nscaff(const fga_gdb *G)             { return G->nscaff; }
 int64_t fga_gdb_seqtot(const fga_gdb *G)             { return G->seqtot; }
 int64_t fga_gdb_maxctg(const fga_gdb *G)             { return G->maxctg; }
 int64_t fga_gdb_contig_len(const fga_gdb *G, int c)  { return G->contigs[c].clen; }
+int64_t fga_gdb_nmask(const fga_gdb *G)              { return G->nmask; }
 void    fga_gdb_freq(const fga_gdb *G, float *f4)    { memcpy(f4,G->freq,4*sizeof(float)); }
 
 /* Unpack contig c into numeric form (0..3), buf must hold clen+2 bytes; buf[0] and buf[clen+1] get the

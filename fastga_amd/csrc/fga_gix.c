@@ -217,6 +217,7 @@ typedef struct
     uint32_t      *count;      /* [2^24] per-prefix counts (pass 0, atomic)              */
     int64_t       *cursor;     /* [2^24] per-prefix write cursors (pass 1, atomic)       */
     krec          *recs;
+    int            use_mask;   /* fill the soft-mask byte from gdb->mbeg/mend             */
     int           *next;       /* shared work counter over contigs                       */
     int64_t        nfwd, ncmp;
   } scan_arg;
@@ -256,6 +257,11 @@ static void scan_contig(scan_arg *A, int c)
   }
   ctg  = (uint64_t) A->invp[c];
   sign = ((uint64_t) 0x80) << (8*(A->contbytes-1));
+  /* soft mask byte of the k-mers whose syncmer starts at j: bases from j to the end of the mask interval that
+     holds j, capped at 40; 0 outside intervals (setup_thread_with_masks, GIXmake.c:1100-1108)              */
+  int64_t mi = 0, mtop = 0;
+  if (A->use_mask && G->nmask > 0)
+    { mi = G->moff[c]; mtop = G->moff[c+1]; }
 
   { uint8_t *s = seq+1;
     for (j = 0; j+12 <= len; j++)
@@ -265,6 +271,15 @@ static void scan_contig(scan_arg *A, int c)
           if (v8[j+q] < m) m = v8[j+q];
         if (v8[j] != m && v8[j+4] != m)
           continue;
+        uint8_t pbg = 0;
+        if (mi < mtop)
+          { while (mi < mtop && j >= G->mend[mi])
+              mi += 1;
+            if (mi < mtop && j >= G->mbeg[mi])
+              { int64_t d = G->mend[mi] - j;
+                pbg = (uint8_t) (d > FGA_KMER ? FGA_KMER : d);
+              }
+          }
 
         if (j <= len-FGA_KMER)                       /* forward k-mer [j,j+40) */
           { uint32_t pre = 0;
@@ -281,7 +296,7 @@ static void scan_contig(scan_arg *A, int c)
                   suf = (suf<<2) | s[j+k];
                 w = __atomic_fetch_add(A->cursor+pre,1,__ATOMIC_RELAXED);
                 r = A->recs + w;
-                r->suf = suf; r->pre = pre; r->mask = 0;
+                r->suf = suf; r->pre = pre; r->mask = pbg;
                 r->pay = (uint64_t) j | (ctg << (8*A->postbytes));
               }
             A->nfwd += 1;
@@ -301,7 +316,7 @@ static void scan_contig(scan_arg *A, int c)
                   suf = (suf<<2) | (3 - s[j+11-k]);
                 w = __atomic_fetch_add(A->cursor+pre,1,__ATOMIC_RELAXED);
                 r = A->recs + w;
-                r->suf = suf; r->pre = pre; r->mask = 0;
+                r->suf = suf; r->pre = pre; r->mask = pbg;
                 r->pay = (uint64_t) (j+12) | ((ctg|sign) << (8*A->postbytes));
               }
             A->ncmp += 1;
@@ -392,7 +407,13 @@ static int write_full(int fd, const void *buf, int64_t n)
 /* Build <root>.gix + .<root>.ktab.* for `gdb`.  `nthreads` plays the role of GIXmake's -T: it sets the
  * worker count, the number of table parts (GIXmake.c:1907-1917) and the padding of the contig count to
  * >= nthreads with fake 40-base contigs (short_GDB_fix, GIXmake.c:1605-1624).                          */
+int fga_gix_build_masked(const fga_gdb *G, const char *target, int nthreads, int use_mask);
+
 int fga_gix_build(const fga_gdb *G, const char *target, int nthreads)
+{ return fga_gix_build_masked(G,target,nthreads,0); }
+
+/* use_mask: fill the per-entry soft-mask byte from the GDB's lower-case intervals (GIXmake's `#` argument) */
+int fga_gix_build_masked(const fga_gdb *G, const char *target, int nthreads, int use_mask)
 { int      nreal = G->ncontig, nctg;
   int64_t *clen = NULL;
   int     *perm = NULL, *invp = NULL;
@@ -480,6 +501,7 @@ int fga_gix_build(const fga_gdb *G, const char *target, int nthreads)
           { args[i].gdb = G; args[i].invp = invp;
             args[i].postbytes = postbytes; args[i].contbytes = contbytes;
             args[i].pass = pass; args[i].count = count; args[i].cursor = cursor; args[i].recs = recs;
+            args[i].use_mask = use_mask;
             args[i].next = &next; args[i].nfwd = args[i].ncmp = 0;
           }
         for (i = 1; i < nthreads; i++)

@@ -44,6 +44,11 @@ struct fga_gdb
     char         *srcpath;   /* reference line of the skeleton           */
     uint8_t      *bps;       /* whole 2-bit image (base i of a contig in bits 2*(i&3) of byte i>>2) */
     int64_t       bpslen;
+    /* soft mask (lower-case runs of the FASTA), contig coordinates, from .<root>.msk when present:
+       intervals [mbeg[i],mend[i]) for i in [moff[c],moff[c+1])                                        */
+    int64_t       nmask;
+    int64_t      *moff;      /* [ncontig+1] */
+    int64_t      *mbeg, *mend;
   };
 
 struct fga_gix

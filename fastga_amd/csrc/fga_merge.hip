@@ -32,11 +32,17 @@
 
 #define NT              256                  // threads per workgroup
 #define NWAVE           (NT/64)
+#ifndef TILE_COST
 #define TILE_COST       1024                 // cost units per tile
+#endif
 #define EPT             (TILE_COST/NT)       // T1 entries per thread (upper bound)
 #define PCAP            (TILE_COST/2 + 2)    // max prefixes of an LDS tile
 #define RAWCAP          (TILE_COST*16 + 96)  // bytes of raw entries staged per tile (E <= 16)
+#ifndef STAGE_CAP
 #define STAGE_CAP       512                  // seeds staged in LDS between flushes
+#endif
+
+static_assert(TILE_COST <= 4*NT,"the owner max-scan handles 4 entries per thread");
 
 enum { MODE_PAIR = 0, MODE_FLIP = 1, MODE_SELF = 2 };
 

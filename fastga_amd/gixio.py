@@ -78,5 +78,5 @@ def fasta_to_gdb(fasta, target, ncut=0):
     check(L.fga_fasta_to_gdb(fasta.encode(), target.encode(), ncut), f"FASTA->GDB {fasta}")
 
 
-def build_gix(gdb, target, nthreads=8):
-    check(gdb.L.fga_gix_build(gdb.h, target.encode(), nthreads), f"GIX build {target}")
+def build_gix(gdb, target, nthreads=8, use_mask=False):
+    check(gdb.L.fga_gix_build_masked(gdb.h, target.encode(), nthreads, int(use_mask)), f"GIX build {target}")

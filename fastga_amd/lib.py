@@ -99,6 +99,8 @@ def _declare(L):
         "fga_gdb_freq": (None, [vp, P(C.c_float)]),
         "fga_gdb_get_contig": (vp, [vp, i32, vp]),
         "fga_gix_build": (i32, [vp, cp, i32]),
+        "fga_gix_build_masked": (i32, [vp, cp, i32, i32]),
+        "fga_gdb_nmask": (i64, [vp]),
         "fga_gix_open": (i32, [cp, P(vp)]),
         "fga_gix_close": (None, [vp]),
         "fga_gix_nents": (i64, [vp]),

@@ -5,14 +5,14 @@ from . import synth
 from .gixio import Gdb, Gix, fasta_to_gdb, build_gix  # noqa: F401
 
 
-def build_genome(workdir, name, contigs, masks=None, threads=8):
+def build_genome(workdir, name, contigs, masks=None, threads=8, use_mask=False):
     """write <name>.fa, <name>.gdb, .<name>.bps, <name>.gix, .<name>.ktab.*; returns the root path."""
     fa = os.path.join(workdir, name + ".fa")
     root = os.path.join(workdir, name)
     synth.write_fasta(fa, contigs, prefix=name.lower(), masks=masks)
     fasta_to_gdb(fa, root)
     g = Gdb(root + ".gdb")
-    build_gix(g, root, threads)
+    build_gix(g, root, threads, use_mask=use_mask)
     g.close()
     return root
 

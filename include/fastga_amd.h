@@ -35,6 +35,8 @@ uint8_t *fga_gdb_get_contig(const fga_gdb *gdb, int contig, uint8_t *buf /* clen
 /* ---- GIX: replaces GIXmake (GIXmake.c:1635-2058) and Open_Kmer_Stream + Open_Post_List header parse
  *      (libfastk.c:785-907, FastGA.c:283-333) ------------------------------------------------------------- */
 int            fga_gix_build(const fga_gdb *gdb, const char *target, int nthreads);
+int            fga_gix_build_masked(const fga_gdb *gdb, const char *target, int nthreads, int use_mask); /* GIXmake ... # */
+int64_t        fga_gdb_nmask(const fga_gdb *gdb);   /* soft-mask (lower-case) intervals carried by the GDB */
 int            fga_gix_open(const char *path, fga_gix **out);
 void           fga_gix_close(fga_gix *gix);
 int64_t        fga_gix_nents(const fga_gix *gix);

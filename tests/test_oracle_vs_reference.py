@@ -146,3 +146,32 @@ def test_local_alignment_oracle_long_and_self_with_borders():
         assert np.array_equal(r[5], o[5])
         assert r[2] - r[0] > 1000
     ref.close()
+
+
+@needs_ref
+def test_soft_mask_bytes_match_single_thread_reference(tmp_path, built_library):
+    """Lower-case FASTA runs -> per-entry mask byte (GIXmake `#`, GIXmake.c:1100-1108).  The reference's masked
+    build races between its threads (a thread parks a sentinel in the *next* contig's first mask interval while
+    another thread may be scanning that contig, GIXmake.c:1085-1088), so the pin is `GIXmake -T1`."""
+    import shutil
+    from fastga_amd import synth
+    from fastga_amd.gixio import Gdb, Gix, fasta_to_gdb, build_gix
+    d = str(tmp_path)
+    lens = synth.contig_lengths(3, 10, 400_000)
+    A, mA, _, _ = synth.make_pair(3, lens, 0.0, repeat_frac=0.15, self_only=True)
+    fa = os.path.join(d, "A.fa")
+    synth.write_fasta(fa, A, prefix="a", masks=mA)
+    od = os.path.join(d, "ours")
+    os.makedirs(od)
+    fasta_to_gdb(fa, os.path.join(od, "A"))
+    g = Gdb(os.path.join(od, "A.gdb"))
+    assert g.L.fga_gdb_nmask(g.h) > 0
+    build_gix(g, os.path.join(od, "A"), 8, use_mask=True)
+    H.run([H.ref_bin("FAtoGDB"), fa], cwd=d)
+    H.run([H.ref_bin("GIXmake"), "-T1", f"-P{d}", os.path.join(d, "A"), "#"], cwd=d)
+    ga_, gb_ = Gix(os.path.join(od, "A.gix")), Gix(os.path.join(d, "A.gix"))    # keep alive: entries() are views
+    a, b = ga_.entries(), gb_.entries()
+    assert a.shape == b.shape and (a[:, 7] != 0).sum() > 1000
+    for cols in (list(range(8)) + list(range(9, a.shape[1])), list(range(7)) + [8]):
+        x, y = a[:, cols], b[:, cols]
+        assert np.array_equal(x[np.lexsort(x.T[::-1])], y[np.lexsort(y.T[::-1])])
