@@ -84,44 +84,56 @@ typedef struct
     int           status;
   } targ;
 
-/* scan one (strand, A contig, B contig) run [beg,end) */
-static int scan_segment(targ *T, int64_t beg, int64_t end)
+/* Scan the units whose first bucket starts inside [c0,c1).  Units are independent: a unit is the bucket run d
+ * starting at a "bucket head" plus the directly following run when it is bucket d+1 of the same segment (aux);
+ * `isnew` only needs to know whether the run just before the head is bucket d-1 of the same segment.  So any
+ * thread can start at any bucket head, which gives far more parallel slack than whole (strand,A,B) segments. */
+static int scan_range(targ *T, int64_t c0, int64_t c1)
 { const key128 *K = T->keys;
   const layout *L = &T->L;
   const fga_chain_params *P = T->prm;
+  const int64_t n = T->n;
   const int64_t CHAIN_BREAK = P->chain_break, CHAIN_MIN = P->chain_min;
-  const int comp = (int) field(K+beg,L->s_strand,1);
-  const int actg = (int) field(K+beg,L->s_a,L->wa);
-  const int bctg = (int) field(K+beg,L->s_b,L->wb);
-  const int64_t alen = P->alen[actg];
-  const int64_t doffset = alen - (P->amxpos + P->bmxpos);
-  const int64_t aoffset = alen - P->amxpos;
-  int64_t b, m, e, cdiag, ndiag;
-  int     isnew, aux;
+  int64_t b, m, e;
 
 #define BUCK(x)  ((int64_t) field(K+(x),L->s_buck,L->wd))
 #define ANTI(x)  ((int64_t) field(K+(x),L->s_anti,L->wt))
 #define DREM(x)  ((int) field(K+(x),6,6))
 #define LCP(x)   ((int) field(K+(x),0,6))
+#define SAMEBK(x,sid,bk) (segid(K+(x),L) == (sid) && BUCK(x) == (bk))
 
-  b = e = beg;
-  cdiag = BUCK(e);
-  while (e < end && BUCK(e) == cdiag)
-    e += 1;
-  isnew = 1;
+  /* first bucket head at or after c0 */
+  b = c0;
+  if (b > 0)
+    { uint64_t sid = segid(K+(b-1),L);
+      int64_t  bk  = BUCK(b-1);
+      while (b < n && SAMEBK(b,sid,bk))
+        b += 1;
+    }
 
-  while (1)
-    { m = e;
-      aux = 0;
-      ndiag = (e < end) ? BUCK(e) : -1;
-      while (e < end && BUCK(e) == cdiag+1)
-        { e += 1;
-          aux = 1;
-        }
-      ndiag = (e < end) ? BUCK(e) : -1;
+  while (b < c1 && b < n)
+    { const uint64_t sid = segid(K+b,L);
+      const int64_t cdiag = BUCK(b);
+      int isnew, aux;
+      /* run d = [b,m) */
+      m = b+1;
+      while (m < n && SAMEBK(m,sid,cdiag))
+        m += 1;
+      /* run d+1 = [m,e) if present */
+      e = m;
+      while (e < n && SAMEBK(e,sid,cdiag+1))
+        e += 1;
+      aux = (e > m);
+      isnew = !(b > 0 && SAMEBK(b-1,sid,cdiag-1));
 
       if (isnew || aux)
-        { int64_t s = b, t = m;
+        { const int comp = (int) field(K+b,L->s_strand,1);
+          const int actg = (int) field(K+b,L->s_a,L->wa);
+          const int bctg = (int) field(K+b,L->s_b,L->wb);
+          const int64_t alen = P->alen[actg];
+          const int64_t doffset = alen - (P->amxpos + P->bmxpos);
+          const int64_t aoffset = alen - P->amxpos;
+          int64_t s = b, t = m;
           int64_t ipost = ANTI(s);
           int64_t apost = aux ? ANTI(t) : INT64_MAX;
           int64_t ahgh = -CHAIN_BREAK, alow = (apost < ipost) ? apost : ipost, anti;
@@ -208,60 +220,15 @@ static int scan_segment(targ *T, int64_t beg, int64_t end)
               if (push_unit(&T->out,&U)) return 1;
             }
         }
-
-      if (e >= end) break;
-
-      if (aux)
-        { b = m;
-          cdiag += 1;
-          isnew = 0;
-        }
-      else
-        { b = e;
-          cdiag = ndiag;
-          while (e < end && BUCK(e) == cdiag)
-            e += 1;
-          isnew = 1;
-        }
+      b = m;      /* the next unit starts at the following bucket head */
     }
   return 0;
 }
 
 static void *chain_thread(void *arg)
 { targ *T = arg;
-  const key128 *K = T->keys;
-  int64_t i = T->c0;
-  /* first segment start at or after c0 */
-  if (i > 0)
-    { uint64_t prev = segid(K+(i-1),&T->L);
-      while (i < T->n && segid(K+i,&T->L) == prev)
-        i += 1;
-    }
-  while (i < T->c1 && i < T->n)
-    { uint64_t id = segid(K+i,&T->L);
-      int64_t j = i+1;
-      /* gallop to the end of the run */
-      { int64_t step = 1;
-        while (j < T->n && segid(K+j,&T->L) == id)
-          { j += step;
-            step <<= 1;
-          }
-        if (j > T->n) j = T->n;
-        /* now the end is in (j-step/2, j]: binary search */
-        { int64_t lo = (j - (step>>1) > i) ? j - (step>>1) : i+1, hi = j;
-          while (lo < hi)
-            { int64_t md = (lo+hi) >> 1;
-              if (segid(K+md,&T->L) == id) lo = md+1; else hi = md;
-            }
-          j = lo;
-        }
-      }
-      if (scan_segment(T,i,j))
-        { T->status = 1;
-          return NULL;
-        }
-      i = j;
-    }
+  if (scan_range(T,T->c0,T->c1))
+    T->status = 1;
   return NULL;
 }
 
@@ -277,6 +244,7 @@ int fga_chain_scan(const void *keys, int64_t n, int wa, int wb, int wd, int wt,
   if (nthreads < 1) nthreads = 1;
   if (nthreads > 256) nthreads = 256;
   if (n < 100000) nthreads = 1;
+  else if (n / nthreads < 20000) nthreads = (int) (n/20000) + 1;
   R = calloc(1,sizeof(fga_hits));
   T = calloc(nthreads,sizeof(targ));
   th = calloc(nthreads,sizeof(pthread_t));

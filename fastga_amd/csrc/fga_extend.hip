@@ -1276,6 +1276,12 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
   const int64_t maxa = GA->maxctg > GB->maxctg ? GA->maxctg : GB->maxctg;
   int64_t cell_cap  = prm->cell_cap  > 0 ? prm->cell_cap  : 24*(maxa/prm->tspace + 64) + 4096;
   int64_t trace_cap = 8*(maxa/prm->tspace + 8) + 64;
+  { // bound the per-wavefront scratch to ~24 GB in total: long contigs get fewer concurrent wavefronts
+    int64_t per = (int64_t) sizeof(int4)*cell_cap + (int64_t) sizeof(uint16_t)*trace_cap;
+    int64_t maxwg = ((int64_t) 24 << 30) / per;
+    if (maxwg < 64) maxwg = 64;
+    if (nwg > maxwg) nwg = (int) maxwg;
+  }
   int64_t aln_cap   = prm->aln_cap   > 0 ? prm->aln_cap   : 4*H->nhits + 1024;
   int64_t tb_cap    = prm->trace_cap > 0 ? prm->trace_cap : aln_cap * (2*(maxa/prm->tspace) / 8 + 64);
 

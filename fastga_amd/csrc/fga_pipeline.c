@@ -162,7 +162,11 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
     cp.alen = alen;
     st.download_s = fga_wall() - t1;
     t1 = fga_wall();
-    if (fga_chain_scan(pk,n,wa,wb,wd,wt,&cp,P->nthreads,&hits)) goto done;
+    { long nc = sysconf(_SC_NPROCESSORS_ONLN);       /* the scan is memory-bound and embarrassingly parallel */
+      int nt = P->nthreads > 0 ? P->nthreads : 1;
+      if (nc > nt) nt = (int) (nc > 128 ? 128 : nc);
+      if (fga_chain_scan(pk,n,wa,wb,wd,wt,&cp,nt,&hits)) goto done;
+    }
     st.nhits = hits->nhits;
     st.nunits = hits->nunits;
     st.chain_s = fga_wall() - t1;

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""tools/scale_check.py -- robustness at scale: build a synthetic genome (pair or self, repeat-heavy, soft-masked) with
+our own producers and run the whole hot path once; prints stage times and counts."""
+import argparse, os, sys, tempfile, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from fastga_amd import workload, synth, device as D
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--mbp", type=float, default=300.0)
+ap.add_argument("--contigs", type=int, default=40)
+ap.add_argument("--div", type=float, default=0.02)
+ap.add_argument("--repeats", type=float, default=0.30)
+ap.add_argument("--self", dest="self_", action="store_true")
+ap.add_argument("--mask", action="store_true")
+ap.add_argument("--threads", type=int, default=32)
+a = ap.parse_args()
+d = tempfile.mkdtemp(prefix="fga_scale_")
+t = time.time()
+lens = synth.contig_lengths(2, a.contigs, int(a.mbp * 1e6))
+A, mA, B, mB = synth.make_pair(2, lens, a.div, repeat_frac=a.repeats, inv_frac=0.02, swap_frac=0.02, self_only=a.self_)
+print(f"synth {time.time()-t:.1f}s", flush=True); t = time.time()
+ra = workload.build_genome(d, "A", A, masks=mA if a.mask else None, threads=a.threads, use_mask=a.mask)
+rb = None if a.self_ else workload.build_genome(d, "B", B, threads=a.threads)
+print(f"GDB+GIX build {time.time()-t:.1f}s", flush=True); t = time.time()
+ses = D.Session(ra, rb)
+print(f"load+upload {time.time()-t:.1f}s  table bytes {ses.table_bytes/1e9:.2f} GB", flush=True)
+for rep in range(2):
+    t = time.time()
+    st = ses.run(out_path=os.path.join(d, "out.1aln"), nthreads=a.threads, soft_mask=a.mask)
+    dt = time.time() - t
+    print(f"run {rep}: {dt*1000:.0f} ms  seeds {st['nseeds']} hits {st['nhits']} units {st['nunits']} alns {st['nalns']} "
+          f"live {st['nlive']} calls {st['ncalls']} waves {st['nwaves']}", flush=True)
+    print("   stages ms:", {k: round(1000*st[k], 1) for k in ("merge_s","sort_s","download_s","chain_s","extend_s","filter_s","write_s")},
+          "kernels ms:", {k: round(st[k], 2) for k in ("merge_kernel_ms","sort_kernel_ms","extend_kernel_ms")}, flush=True)
+    alg = ses.table_bytes + st["nseeds"] * (2 if a.self_ else 1) * ses.seed_bytes
+    print(f"   merge kernel {alg/st['merge_kernel_ms']/1e6:.0f} GB/s algorithmic", flush=True)
+ses.close()
