@@ -34,6 +34,7 @@
 #define DUB_TRIM    45
 #define BIGI        0x7fffffff
 #define BUCK_ANTI   128
+#define TS          100                 // trace-point spacing: FastGA only ever uses TSPACE = 100 (FastGA.c:46)
 
 #define WDW         512                 // dwords per LDS sequence window (8192 bases)
 #define WINB        (WDW*16)
@@ -46,6 +47,8 @@ struct ext_seq
     int     len;
     LDS_PTR uint32_t *win;    // LDS window: a dword-aligned copy of img[p0/16 .. p0/16 + WDW)
     int64_t  p0;              // image base index of the window start (multiple of 16); -1: empty
+    int      w0;              // contig position of the window start (p0 - base), valid when p0 >= 0
+    int      bsh;             // base & 15
   };
 
 // One workgroup = one wavefront.  LDS operations of one wavefront complete in order, so lanes see each other's
@@ -120,21 +123,21 @@ __device__ __forceinline__ uint64_t fetch32(const ext_seq &s, int64_t pos)
   return v;
 }
 
-// 64 bases starting at contig position pos as two 64-bit words (lo = first 32 bases)
-__device__ __forceinline__ void fetch64(const ext_seq &s, int64_t pos, uint64_t &lo, uint64_t &hi)
-{ int64_t p = s.base + pos;
-  int sh = (int) (p & 15) * 2;
+// 64 bases starting at contig position pos as two 64-bit words (lo = first 32 bases); all window arithmetic
+// is 32-bit and relative to the window start
+__device__ __forceinline__ void fetch64(const ext_seq &s, int pos, uint64_t &lo, uint64_t &hi)
+{ const int sh = ((s.bsh + pos) & 15) * 2;
   uint32_t d0, d1, d2, d3, d4;
-  int64_t q = p - s.p0;
+  const int q = pos - s.w0;
   if (s.p0 >= 0 && q >= 0 && q + 80 <= WINB)
-    { int w = (int) (q >> 4);
+    { const int w = q >> 4;
       d0 = s.win[w]; d1 = s.win[w+1]; d2 = s.win[w+2]; d3 = s.win[w+3]; d4 = s.win[w+4];
     }
   else
-    { int64_t w = p >> 4;
+    { const int64_t w = (s.base + pos) >> 4;
       d0 = s.img[w]; d1 = s.img[w+1]; d2 = s.img[w+2]; d3 = s.img[w+3]; d4 = s.img[w+4];
     }
-  uint64_t a = ((uint64_t) d1 << 32) | d0, b = ((uint64_t) d3 << 32) | d2;
+  const uint64_t a = ((uint64_t) d1 << 32) | d0, b = ((uint64_t) d3 << 32) | d2;
   if (sh)
     { lo = (a >> sh) | (b << (64-sh));
       hi = (b >> sh) | ((uint64_t) d4 << (64-sh));
@@ -148,8 +151,8 @@ __device__ __forceinline__ int match_fwd(const ext_seq &A, const ext_seq &B, int
 { int L = 0;
   while (L < lim)
     { uint64_t alo, ahi, blo, bhi;
-      fetch64(A,(int64_t) ax+L,alo,ahi);
-      fetch64(B,(int64_t) bx+L,blo,bhi);
+      fetch64(A,ax+L,alo,ahi);
+      fetch64(B,bx+L,blo,bhi);
       uint64_t x = alo ^ blo, y = ahi ^ bhi;
       if (x != 0)
         { L += (__ffsll((unsigned long long) x) - 1) >> 1;
@@ -169,8 +172,8 @@ __device__ __forceinline__ int match_rev(const ext_seq &A, const ext_seq &B, int
 { int L = 0;
   while (L < lim)
     { uint64_t alo, ahi, blo, bhi;
-      fetch64(A,(int64_t) ax-L-64,alo,ahi);
-      fetch64(B,(int64_t) bx-L-64,blo,bhi);
+      fetch64(A,ax-L-64,alo,ahi);
+      fetch64(B,bx-L-64,blo,bhi);
       uint64_t x = alo ^ blo, y = ahi ^ bhi;      // y holds the 32 bases nearest to (ax,bx)
       if (y != 0)
         { L += __clzll((long long) y) >> 1;
@@ -273,19 +276,20 @@ __device__ __forceinline__ void win_load(ext_seq &s, int pos, int before)
   for (int i = threadIdx.x & 63; i < WDW; i += 64)
     s.win[i] = g[i];
   s.p0 = p0;
+  s.w0 = (int) (p0 - s.base);
 }
 
 // keep [pos-lo, pos+hi] inside the window; S > 0 keeps most of the window ahead of pos, S < 0 behind it
 template <int S>
 __device__ __forceinline__ bool win_track(ext_seq &s, int pos)
-{ int64_t p = s.base + pos;
+{ const int q = pos - s.w0;
   if (S > 0)
-    { if (s.p0 >= 0 && p - 448 >= s.p0 && p + 1536 <= s.p0 + WINB)
+    { if (s.p0 >= 0 && q >= 448 && q + 1536 <= WINB)
         return false;
       win_load(s,pos,512);
     }
   else
-    { if (s.p0 >= 0 && p + 448 <= s.p0 + WINB && p - 1536 >= s.p0)
+    { if (s.p0 >= 0 && q + 448 <= WINB && q >= 1536)
         return false;
       win_load(s,pos,WINB-512);
     }
@@ -301,7 +305,7 @@ __device__ __attribute__((noinline)) void ext_unwind(const ext_args &G, int4 *ce
                                                      ext_prof &PF, int mida, int aoff, int trima, int trimx, int trimd,
                                                      int trimha, int &mind)
 { const int lane = threadIdx.x & 63;
-  const int ts = G.tspace;
+  const int ts = TS;
   // ---- unwind the pebble chain (lane 0), tip -> root, then write the trace pairs -------------------
   { // the reference picks the "more" tip only when spec->reach is set; FastGA always passes reach = 0 (FastGA.c:3757)
     const int trimy = trima - trimx;
@@ -440,7 +444,7 @@ __device__ __attribute__((noinline)) void ext_unwind(const ext_args &G, int4 *ce
 #define REG_BACK 40
 #define KOF(l)    ((S > 0) ? kref - (l) : kref + (l))
 #define LOF(kk)   ((S > 0) ? kref - (kk) : (kk) - kref)
-#define BAIL(code) { Ain.p0 = A.p0; Bin.p0 = B.p0; return code; }
+#define BAIL(code) { Ain.p0 = A.p0; Ain.w0 = A.w0; Bin.p0 = B.p0; Bin.w0 = B.w0; return code; }
 
 template <int S>
 __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext_shared *shp, int4 *cells, uint16_t *trace,
@@ -453,7 +457,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
   // sit in scratch (HBM-backed) memory, and a scratch access per step costs more than the step itself
   ext_seq A = Ain, B = Bin;
   unsigned long long nwaves = 0, nspill = 0;
-  const int ts = G.tspace, path_ave = G.path_ave, mscore = G.mscore;
+  const int ts = TS, path_ave = G.path_ave, mscore = G.mscore;
   const int64_t cell_cap = G.cell_cap;
   const int VNEW = (S > 0) ? -1 : BIGI;
   int low = mind, hgh = maxd, dif = 0, cur = 0;
@@ -627,8 +631,10 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
           regmode = true;
         }
 
-      win_track<S>(A,bestx);
-      win_track<S>(B,besta-bestx);
+      if ((dif & 3) == 0)       // fetches outside the window fall back to HBM, so tracking may lag a few steps
+        { win_track<S>(A,bestx);
+          win_track<S>(B,besta-bestx);
+        }
 
       uint64_t anyA = 0, anyB = 0;
 
@@ -951,7 +957,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
   PF.t_steps += clock64() - tstart;
   PF.nsteps += nspill;
   nwaves_out += nwaves;
-  Ain.p0 = A.p0; Bin.p0 = B.p0;
+  Ain.p0 = A.p0; Ain.w0 = A.w0; Bin.p0 = B.p0; Bin.w0 = B.w0;
   ext_unwind<S>(G,cells,trace,P,PF,mida,aoff,trima,trimx,trimd,trimha,mind);
   return 0;
 }
@@ -970,7 +976,7 @@ __device__ int local_alignment(const ext_args &G, LDS_PTR ext_shared *sh, int4 *
     hgh -= 1;
   minp = (lbord < 0) ? -BIGI : low-lbord;
   maxp = (hbord < 0) ?  BIGI : hgh+hbord;
-  aoff = acomp ? A.len % G.tspace : 0;
+  aoff = acomp ? A.len % TS : 0;
 
   if ((st = ext_wave<+1>(G,sh,cells,trace,A,B,P,low,hgh,anti,minp,maxp,aoff,nwaves,PF)) != 0) return st;
   int fshort = ((P.aepos + P.bepos) - anti < DUB_TRIM);
@@ -1038,13 +1044,14 @@ void extend_kernel(ext_args G)
       ext_seq A, B;
       A.len = (int) G.clenA[ctg1];
       B.len = (int) G.clenB[ctg2];
-      A.win = (LDS_PTR uint32_t *) sh->winA; A.p0 = -1;
-      B.win = (LDS_PTR uint32_t *) sh->winB; B.p0 = -1;
-      B.img = G.imgB; B.base = (G.padB + G.boffB[ctg2]) * 4;
+      A.win = (LDS_PTR uint32_t *) sh->winA; A.p0 = -1; A.w0 = 0;
+      B.win = (LDS_PTR uint32_t *) sh->winB; B.p0 = -1; B.w0 = 0;
+      B.img = G.imgB; B.base = (G.padB + G.boffB[ctg2]) * 4; B.bsh = (int) (B.base & 15);
       if (comp)
         { A.img = G.imgAr; A.base = (G.padA + G.boffA[ctg1]) * 4; }
       else
         { A.img = G.imgA;  A.base = (G.padA + G.boffA[ctg1]) * 4; }
+      A.bsh = (int) (A.base & 15);
       const int64_t mlen = (int64_t) A.len + B.len;
       const int self = G.self && ctg1 == ctg2 && !comp;
 
