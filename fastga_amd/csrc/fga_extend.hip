@@ -68,6 +68,8 @@ struct ext_shared
     int      tmaxe[32];
   };
 
+__shared__ ext_shared ext_lds;     // the one LDS block of a (single-wavefront) workgroup
+
 struct ext_prof
   { unsigned long long t_steps, t_unwind, t_total, nsteps, ph[6]; };
 
@@ -188,12 +190,8 @@ __device__ __forceinline__ int match_rev(const ext_seq &A, const ext_seq &B, int
   return L < lim ? L : lim;
 }
 
-__device__ __forceinline__ int base_at(const ext_seq &s, int pos)     // 0..3, or 4 outside [0,len)
-{ if (pos < 0 || pos >= s.len)
-    return 4;
-  int64_t p = s.base + pos;
-  return (s.img[p >> 4] >> ((p & 15)*2)) & 3;
-}
+struct wseq;
+__device__ __forceinline__ int base_at(const wseq &s, int pos);
 
 // ---------------------------------------------------------------------------------------------------
 // wave-wide helpers (all 64 lanes must call)
@@ -294,6 +292,122 @@ __device__ __forceinline__ bool win_track(ext_seq &s, int pos)
       win_load(s,pos,WINB-512);
     }
   return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wave-uniform values.  Arguments of a non-inlined device function arrive in VGPRs and everything derived from
+// them is treated as divergent (exec-mask branches, VALU bookkeeping); readfirstlane moves them to SGPRs so the
+// wave bookkeeping (low/hgh/besta/..., window tests, branches) runs on the scalar unit.
+// ---------------------------------------------------------------------------------------------------
+#define GLB_PTR __attribute__((address_space(1)))
+typedef int v4i __attribute__((ext_vector_type(4)));      // a pebble cell as a plain 16-byte vector (int4 layout)
+#define UNI(v) __builtin_amdgcn_readfirstlane((int) (v))
+__device__ __forceinline__ int64_t uni64(int64_t v)
+{ const uint32_t lo = (uint32_t) UNI((uint32_t) v), hi = (uint32_t) UNI((uint32_t) ((uint64_t) v >> 32));
+  return (int64_t) (((uint64_t) hi << 32) | lo);
+}
+
+struct wseq                   // ext_seq with every field wave-uniform and explicit address spaces
+  { const GLB_PTR uint32_t *img;
+    LDS_PTR uint32_t *win;
+    int64_t base;
+    int     len, w0, bsh;     // window start as a contig position; base & 15
+  };
+
+__device__ __forceinline__ void wseq_from(wseq &W, const ext_seq &s, LDS_PTR uint32_t *win)
+{ W.img  = (const GLB_PTR uint32_t *) uni64((int64_t) s.img);
+  W.win  = win;
+  W.base = uni64(s.base);
+  W.len  = UNI(s.len);
+  W.bsh  = (int) (W.base & 15);
+  W.w0   = UNI(s.w0);
+}
+
+__device__ __forceinline__ void wseq_load(wseq &s, int pos, int before)     // see win_load
+{ int64_t p0 = (s.base + pos - before) & ~(int64_t) 15;
+  if (p0 < 0) p0 = 0;
+  const GLB_PTR uint32_t *g = s.img + (p0 >> 4);
+  for (int i = threadIdx.x & 63; i < WDW; i += 64)
+    s.win[i] = g[i];
+  s.w0 = (int) (p0 - s.base);
+}
+
+__device__ __forceinline__ int base_at(const wseq &s, int pos)     // 0..3, or 4 outside [0,len)
+{ if (pos < 0 || pos >= s.len)
+    return 4;
+  int64_t p = s.base + pos;
+  return (s.img[p >> 4] >> ((p & 15)*2)) & 3;
+}
+
+template <int S>
+__device__ __forceinline__ void wseq_track(wseq &s, int pos)
+{ const int q = pos - s.w0;
+  if (S > 0)
+    { if (q < 448 || q + 1536 > WINB)
+        wseq_load(s,pos,512);
+    }
+  else
+    { if (q + 448 > WINB || q < 1536)
+        wseq_load(s,pos,WINB-512);
+    }
+}
+
+// length of the snake from (ax,bx): equal bases going forward (S > 0: A[ax+i] == B[bx+i]) or backward (S < 0:
+// A[ax-1-i] == B[bx-1-i]), at most lim.  64 bases per round: ten LDS dwords issued together when both stretches
+// lie inside the windows (else straight from the HBM images), aligned with one v_alignbit per dword.
+template <int S>
+__device__ __forceinline__ int snake(const wseq &A, const wseq &B, int ax, int bx, int lim)
+{ int L = 0;
+  while (L < lim)
+    { const int pa = (S > 0) ? ax+L : ax-L-64, pb = (S > 0) ? bx+L : bx-L-64;
+      const int qa = pa - A.w0, qb = pb - B.w0;
+      uint32_t a0, a1, a2, a3, a4, b0, b1, b2, b3, b4;
+      if ((uint32_t) qa <= (uint32_t) (WINB-80) && (uint32_t) qb <= (uint32_t) (WINB-80))
+        { LDS_PTR const uint32_t *wa = A.win + (qa >> 4), *wb = B.win + (qb >> 4);
+          a0 = wa[0]; a1 = wa[1]; a2 = wa[2]; a3 = wa[3]; a4 = wa[4];
+          b0 = wb[0]; b1 = wb[1]; b2 = wb[2]; b3 = wb[3]; b4 = wb[4];
+        }
+      else
+        { const GLB_PTR uint32_t *ga = A.img + ((A.base + pa) >> 4), *gb = B.img + ((B.base + pb) >> 4);
+          a0 = ga[0]; a1 = ga[1]; a2 = ga[2]; a3 = ga[3]; a4 = ga[4];
+          b0 = gb[0]; b1 = gb[1]; b2 = gb[2]; b3 = gb[3]; b4 = gb[4];
+        }
+      const uint32_t sa = (uint32_t) ((A.bsh + pa) & 15) * 2, sb = (uint32_t) ((B.bsh + pb) & 15) * 2;
+      const uint32_t x0 = __builtin_amdgcn_alignbit(a1,a0,sa) ^ __builtin_amdgcn_alignbit(b1,b0,sb);
+      const uint32_t x1 = __builtin_amdgcn_alignbit(a2,a1,sa) ^ __builtin_amdgcn_alignbit(b2,b1,sb);
+      const uint32_t x2 = __builtin_amdgcn_alignbit(a3,a2,sa) ^ __builtin_amdgcn_alignbit(b3,b2,sb);
+      const uint32_t x3 = __builtin_amdgcn_alignbit(a4,a3,sa) ^ __builtin_amdgcn_alignbit(b4,b3,sb);
+      const uint64_t X = ((uint64_t) x1 << 32) | x0, Y = ((uint64_t) x3 << 32) | x2;
+      int n;
+      if (S > 0)
+        n = X ? ((__ffsll((unsigned long long) X) - 1) >> 1) : (Y ? 32 + ((__ffsll((unsigned long long) Y) - 1) >> 1) : 64);
+      else          // Y holds the 32 bases nearest to (ax,bx)
+        n = Y ? (__clzll((long long) Y) >> 1) : (X ? 32 + (__clzll((long long) X) >> 1) : 64);
+      L += n;
+      if (n < 64)
+        break;
+    }
+  return L < lim ? L : lim;
+}
+
+// exclusive prefix max in lane order of non-negative values (0 for lane 0): zero is the identity, so every step
+// is one fused v_max_i32_dpp
+__device__ __forceinline__ int wscan_max_excl_nn(int v)
+{ int x = v, t;
+  t = __builtin_amdgcn_update_dpp(0,x,0x111,0xf,0xf,true); x = x > t ? x : t;
+  t = __builtin_amdgcn_update_dpp(0,x,0x112,0xf,0xf,true); x = x > t ? x : t;
+  t = __builtin_amdgcn_update_dpp(0,x,0x114,0xf,0xf,true); x = x > t ? x : t;
+  t = __builtin_amdgcn_update_dpp(0,x,0x118,0xf,0xf,true); x = x > t ? x : t;
+  t = __builtin_amdgcn_update_dpp(0,x,0x142,0xa,0xf,false); x = x > t ? x : t;
+  t = __builtin_amdgcn_update_dpp(0,x,0x143,0xc,0xf,false); x = x > t ? x : t;
+  return __builtin_amdgcn_update_dpp(0,x,0x138,0xf,0xf,false);
+}
+
+// both trim-table tests of a "good" point (align.c:737-741) with their six LDS reads in one round trip
+__device__ __forceinline__ bool trim_ok(LDS_PTR ext_shared *sh, uint64_t b, int ms)
+{ const uint32_t qlo = (uint32_t) b & TRIM_MASK, qhi = (uint32_t) (b >> TRIM_LEN) & TRIM_MASK;
+  const int tlo = trim_table(sh,qlo), thi = trim_table(sh,qhi);
+  return tlo >= 0 && thi + trim_score(qlo,ms) >= 0;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -444,23 +558,30 @@ __device__ __attribute__((noinline)) void ext_unwind(const ext_args &G, int4 *ce
 #define REG_BACK 40
 #define KOF(l)    ((S > 0) ? kref - (l) : kref + (l))
 #define LOF(kk)   ((S > 0) ? kref - (kk) : (kk) - kref)
-#define BAIL(code) { Ain.p0 = A.p0; Ain.w0 = A.w0; Bin.p0 = B.p0; Bin.w0 = B.w0; return code; }
+#define WIN_BACK() { Ain.p0 = A.base + A.w0; Ain.w0 = A.w0; Bin.p0 = B.base + B.w0; Bin.w0 = B.w0; }
+#define BAIL(code) { WIN_BACK() return code; }
 
 template <int S>
-__device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext_shared *shp, int4 *cells, uint16_t *trace,
+__device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext_shared *shp_in, int4 *cells_in, uint16_t *trace,
                         ext_seq &Ain, ext_seq &Bin, ext_state &P,
-                        int &mind, int maxd, int mida, int minp, int maxp, int aoff,
+                        int &mind, int maxd_in, int mida_in, int minp_in, int maxp_in, int aoff_in,
                         unsigned long long &nwaves_out, ext_prof &PF)
 { const int lane = threadIdx.x & 63;
   const unsigned long long tstart = clock64();
-  // everything the wave loop touches lives in registers: by-reference arguments of a non-inlined device function
-  // sit in scratch (HBM-backed) memory, and a scratch access per step costs more than the step itself
-  ext_seq A = Ain, B = Bin;
+  // everything the wave loop touches lives in registers (by-reference arguments of a non-inlined device function
+  // sit in scratch memory), and everything wave-uniform is moved to SGPRs first
+  LDS_PTR ext_shared *shp = (LDS_PTR ext_shared *) &ext_lds;
+  wseq A, B;
+  wseq_from(A,Ain,(LDS_PTR uint32_t *) shp->winA);
+  wseq_from(B,Bin,(LDS_PTR uint32_t *) shp->winB);
+  GLB_PTR v4i *cells = (GLB_PTR v4i *) uni64((int64_t) cells_in);
+  const int maxd = UNI(maxd_in), mida = UNI(mida_in), minp = UNI(minp_in), maxp = UNI(maxp_in), aoff = UNI(aoff_in);
   unsigned long long nwaves = 0, nspill = 0;
-  const int ts = TS, path_ave = G.path_ave, mscore = G.mscore;
-  const int64_t cell_cap = G.cell_cap;
+  const int ts = TS, path_ave = UNI(G.path_ave), mscore = UNI(G.mscore);
+  const int64_t cell_cap = uni64(G.cell_cap);
+  const bool force_lds = UNI(G.force_lds) != 0;
   const int VNEW = (S > 0) ? -1 : BIGI;
-  int low = mind, hgh = maxd, dif = 0, cur = 0;
+  int low = UNI(mind), hgh = maxd, dif = 0, cur = 0;
   int more = 1, avail = 0;
   int aclip = (S > 0) ? BIGI : -BIGI;
   int bclip = (S > 0) ? -BIGI : BIGI;
@@ -474,7 +595,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
   if (hgh-low+8 >= RC)
     BAIL(2)
 
-  bool regmode = !G.force_lds && (hgh-low+1 <= REG_MAXW);
+  bool regmode = !force_lds && (hgh-low+1 <= REG_MAXW);
   int  kref = 0;
   int      V = VNEW, HA = -1, HM = 0, NA = 0;      // register-mode state of this lane's diagonal
   uint64_t T = PATH_INT;
@@ -483,8 +604,8 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
       kref = (S > 0) ? hgh + l0 : low - l0;
     }
 
-  win_track<S>(A,bestx);
-  win_track<S>(B,mida-bestx);
+  if (UNI(Ain.p0 < 0)) wseq_load(A,bestx,(S > 0) ? 512 : WINB-512); else wseq_track<S>(A,bestx);
+  if (UNI(Bin.p0 < 0)) wseq_load(B,mida-bestx,(S > 0) ? 512 : WINB-512); else wseq_track<S>(B,mida-bestx);
   WAVE_SYNC();
 
   // ---- wave 0 (align.c:425-512 / 949-1035) ---------------------------------------------------------
@@ -509,14 +630,14 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
             if (S > 0)
               { int ra = A.len-x, rb = B.len-y;
                 int lim = ra < rb ? ra : rb;
-                L = match_fwd(A,B,x,y,lim);
+                L = snake<+1>(A,B,x,y,lim);
                 if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
                 x += L;
               }
             else
               { int ra = x, rb = y;
                 int lim = ra < rb ? ra : rb;
-                L = match_rev(A,B,x,y,lim);
+                L = snake<-1>(A,B,x,y,lim);
                 if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
                 x -= L;
               }
@@ -530,11 +651,11 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
         int ha = -1, hm = 0;
         if (act)
           { int idx = avail + off;
-            cells[idx] = make_int4(-1,k,0,mark0);
+            cells[idx] = (v4i) { -1,k,0,mark0 };
             ha = idx; hm = mark0;
             for (int q = 0; q < cnt; q++)
               { idx += 1;
-                cells[idx] = make_int4(ha,k,0,na);
+                cells[idx] = (v4i) { ha,k,0,na };
                 ha = idx; hm = na;
                 na += S*ts;
               }
@@ -549,8 +670,9 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
               }
           }
         avail += tot;
-        int pm = wscan_best_excl<S>(act ? c : ((S > 0) ? -BIGI : BIGI));
-        bool rec = act && ((S > 0) ? (c > besta && c > pm) : (c < besta && c < pm));
+        const int cn = act ? ((S > 0) ? c : BIGI - c) : 0;          // non-negative, larger = better
+          const int pm = wscan_max_excl_nn(cn);
+        bool rec = act && ((S > 0) ? c > besta : c < besta) && cn > pm;
         uint64_t rm = __ballot(rec);
         if (rm)
           { int l = last_lane(rm);
@@ -616,7 +738,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
           nspill += 1;
           WAVE_SYNC();
         }
-      else if (!regmode && width <= REG_BACK && !G.force_lds)
+      else if (!regmode && width <= REG_BACK && !force_lds)
         { const int l0 = (64 - width) >> 1;
           kref = (S > 0) ? hgh + l0 : low - l0;
           const int k = KOF(lane);
@@ -632,8 +754,8 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
         }
 
       if ((dif & 3) == 0)       // fetches outside the window fall back to HBM, so tracking may lag a few steps
-        { win_track<S>(A,bestx);
-          win_track<S>(B,besta-bestx);
+        { wseq_track<S>(A,bestx);
+          wseq_track<S>(B,besta-bestx);
         }
 
       uint64_t anyA = 0, anyB = 0;
@@ -694,14 +816,14 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                 if (S > 0)
                   { int ra = A.len-x, rb = B.len-y;
                     int lim = ra < rb ? ra : rb;
-                    L = match_fwd(A,B,x,y,lim);
+                    L = snake<+1>(A,B,x,y,lim);
                     if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
                     x += L;
                   }
                 else
                   { int ra = x, rb = y;
                     int lim = ra < rb ? ra : rb;
-                    L = match_rev(A,B,x,y,lim);
+                    L = snake<-1>(A,B,x,y,lim);
                     if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
                     x -= L;
                   }
@@ -731,7 +853,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                 { int idx = avail + off;
                   int v = na + S*ts*(cross-ncreate);
                   for (int q = 0; q < ncreate; q++)
-                    { cells[idx] = make_int4(ha,k,dif,v);
+                    { cells[idx] = (v4i) { ha,k,dif,v };
                       ha = idx;
                       hm = v;
                       idx += 1;
@@ -745,8 +867,9 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
           avail += tot;
 
           // ordered "new best point" scan (align.c:729-742)
-          int pm = wscan_best_excl<S>(act ? c : ((S > 0) ? -BIGI : BIGI));
-          bool rec = act && ((S > 0) ? (c > besta && c > pm) : (c < besta && c < pm));
+          const int cn = act ? ((S > 0) ? c : BIGI - c) : 0;          // non-negative, larger = better
+          const int pm = wscan_max_excl_nn(cn);
+          bool rec = act && ((S > 0) ? c > besta : c < besta) && cn > pm;
           uint64_t rm = __ballot(rec);
           if (rm)
             { int l = last_lane(rm);
@@ -759,9 +882,8 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                 { lasta = rdlane(c,last_lane(gm));
                   bool trimok = false;
                   if (good)
-                    { const uint32_t qlo = (uint32_t) b & TRIM_MASK, qhi = (uint32_t) (b >> TRIM_LEN) & TRIM_MASK;
-                      if (trim_table(shp,qlo) >= 0)
-                        trimok = trim_table(shp,qhi) + trim_score(qlo,mscore) >= 0;
+                    {
+                      trimok = trim_ok(shp,b,mscore);
                     }
                   uint64_t tm = __ballot(trimok);
                   if (tm)
@@ -836,14 +958,14 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                   if (S > 0)
                     { int ra = A.len-x, rb = B.len-y;
                       int lim = ra < rb ? ra : rb;
-                      L = match_fwd(A,B,x,y,lim);
+                      L = snake<+1>(A,B,x,y,lim);
                       if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
                       x += L;
                     }
                   else
                     { int ra = x, rb = y;
                       int lim = ra < rb ? ra : rb;
-                      L = match_rev(A,B,x,y,lim);
+                      L = snake<-1>(A,B,x,y,lim);
                       if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
                       x -= L;
                     }
@@ -873,7 +995,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                     { int idx = avail + off;
                       int v = na + S*ts*(cross-ncreate);
                       for (int q = 0; q < ncreate; q++)
-                        { cells[idx] = make_int4(ha,k,dif,v);
+                        { cells[idx] = (v4i) { ha,k,dif,v };
                           ha = idx;
                           hm = v;
                           idx += 1;
@@ -889,8 +1011,9 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                 }
               avail += tot;
 
-              int pm = wscan_best_excl<S>(act ? c : ((S > 0) ? -BIGI : BIGI));
-              bool rec = act && ((S > 0) ? (c > besta && c > pm) : (c < besta && c < pm));
+              const int cn = act ? ((S > 0) ? c : BIGI - c) : 0;          // non-negative, larger = better
+          const int pm = wscan_max_excl_nn(cn);
+              bool rec = act && ((S > 0) ? c > besta : c < besta) && cn > pm;
               uint64_t rm = __ballot(rec);
               if (rm)
                 { int l = last_lane(rm);
@@ -903,9 +1026,8 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                     { lasta = rdlane(c,last_lane(gm));
                       bool trimok = false;
                       if (good)
-                        { const uint32_t qlo = (uint32_t) b & TRIM_MASK, qhi = (uint32_t) (b >> TRIM_LEN) & TRIM_MASK;
-                          if (trim_table(shp,qlo) >= 0)
-                            trimok = trim_table(shp,qhi) + trim_score(qlo,mscore) >= 0;
+                        {
+                          trimok = trim_ok(shp,b,mscore);
                         }
                       uint64_t tm = __ballot(trimok);
                       if (tm)
@@ -957,8 +1079,8 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
   PF.t_steps += clock64() - tstart;
   PF.nsteps += nspill;
   nwaves_out += nwaves;
-  Ain.p0 = A.p0; Ain.w0 = A.w0; Bin.p0 = B.p0; Bin.w0 = B.w0;
-  ext_unwind<S>(G,cells,trace,P,PF,mida,aoff,trima,trimx,trimd,trimha,mind);
+  WIN_BACK()
+  ext_unwind<S>(G,cells_in,trace,P,PF,mida,aoff,trima,trimx,trimd,trimha,mind);
   return 0;
 }
 
@@ -1017,8 +1139,7 @@ __device__ int local_alignment(const ext_args &G, LDS_PTR ext_shared *sh, int4 *
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64)
 void extend_kernel(ext_args G)
-{ __shared__ ext_shared sh_storage;
-  LDS_PTR ext_shared *sh = (LDS_PTR ext_shared *) &sh_storage;
+{ LDS_PTR ext_shared *sh = (LDS_PTR ext_shared *) &ext_lds;
   trim_fill(sh,G.mscore);
   __syncthreads();
   const int lane = threadIdx.x;
