@@ -300,6 +300,7 @@ __device__ __forceinline__ bool win_track(ext_seq &s, int pos)
 // wave bookkeeping (low/hgh/besta/..., window tests, branches) runs on the scalar unit.
 // ---------------------------------------------------------------------------------------------------
 #define GLB_PTR __attribute__((address_space(1)))
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 typedef int v4i __attribute__((ext_vector_type(4)));      // a pebble cell as a plain 16-byte vector (int4 layout)
 #define UNI(v) __builtin_amdgcn_readfirstlane((int) (v))
 __device__ __forceinline__ int64_t uni64(int64_t v)
@@ -352,41 +353,70 @@ __device__ __forceinline__ void wseq_track(wseq &s, int pos)
     }
 }
 
+// One round of a snake: the number of equal bases (0..64) from (pa,pb) in direction S, where pa/pb is the lowest
+// position of the 64-base stretch.  Ten LDS dwords issued together, aligned with one v_alignbit per dword.
+template <int S>
+__device__ __forceinline__ int snake_cmp(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t sa,
+                                         uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t b4, uint32_t sb)
+{ const uint32_t x0 = __builtin_amdgcn_alignbit(a1,a0,sa) ^ __builtin_amdgcn_alignbit(b1,b0,sb);
+  const uint32_t x1 = __builtin_amdgcn_alignbit(a2,a1,sa) ^ __builtin_amdgcn_alignbit(b2,b1,sb);
+  const uint32_t x2 = __builtin_amdgcn_alignbit(a3,a2,sa) ^ __builtin_amdgcn_alignbit(b3,b2,sb);
+  const uint32_t x3 = __builtin_amdgcn_alignbit(a4,a3,sa) ^ __builtin_amdgcn_alignbit(b4,b3,sb);
+  // position of the first difference as a bit index into x3:x2:x1:x0 (forward) / from the top (backward), 128 if none;
+  // v_ffbl / v_ffbh return -1 for a zero word, which the unsigned min chain turns into "look further"
+  uint32_t f;
+  if (S > 0)
+    { uint32_t f0 = x0 ? (uint32_t) __builtin_ctz(x0) : 128u, f1 = x1 ? 32u + (uint32_t) __builtin_ctz(x1) : 128u;
+      uint32_t f2 = x2 ? 64u + (uint32_t) __builtin_ctz(x2) : 128u, f3 = x3 ? 96u + (uint32_t) __builtin_ctz(x3) : 128u;
+      f0 = f0 < f1 ? f0 : f1; f2 = f2 < f3 ? f2 : f3;
+      f = f0 < f2 ? f0 : f2;
+    }
+  else          // x3 holds the 16 bases nearest to (ax,bx)
+    { uint32_t f3 = x3 ? (uint32_t) __builtin_clz(x3) : 128u, f2 = x2 ? 32u + (uint32_t) __builtin_clz(x2) : 128u;
+      uint32_t f1 = x1 ? 64u + (uint32_t) __builtin_clz(x1) : 128u, f0 = x0 ? 96u + (uint32_t) __builtin_clz(x0) : 128u;
+      f3 = f3 < f2 ? f3 : f2; f1 = f1 < f0 ? f1 : f0;
+      f = f3 < f1 ? f3 : f1;
+    }
+  return (int) (f >> 1);
+}
+
+template <int S>
+__device__ __attribute__((noinline)) int snake_hbm(const GLB_PTR uint32_t *ga, const GLB_PTR uint32_t *gb, uint32_t sa, uint32_t sb)
+{ // rare: a stretch outside the LDS windows, straight from the HBM images.  Kept out of line so that the compiler's
+  // waitcnt bookkeeping of the common path never sees an outstanding global load (it would make every wave step
+  // wait for the acknowledgement of the previous pebble stores).
+  const uint32_t a0 = ga[0], a1 = ga[1], a2 = ga[2], a3 = ga[3], a4 = ga[4];
+  const uint32_t b0 = gb[0], b1 = gb[1], b2 = gb[2], b3 = gb[3], b4 = gb[4];
+  return snake_cmp<S>(a0,a1,a2,a3,a4,sa,b0,b1,b2,b3,b4,sb);
+}
+
+template <int S>
+__device__ __forceinline__ int snake_round(const wseq &A, const wseq &B, int pa, int pb)
+{ const int qa = pa - A.w0, qb = pb - B.w0;
+  const uint32_t sa = (uint32_t) ((A.bsh + pa) & 15) * 2, sb = (uint32_t) ((B.bsh + pb) & 15) * 2;
+  const bool inw = (uint32_t) qa <= (uint32_t) (WINB-80) && (uint32_t) qb <= (uint32_t) (WINB-80);
+  int n;
+  if (__builtin_expect(__ballot(!inw) == 0,1))
+    { LDS_PTR const uint32_t *wa = A.win + (qa >> 4), *wb = B.win + (qb >> 4);
+      n = snake_cmp<S>(wa[0],wa[1],wa[2],wa[3],wa[4],sa,wb[0],wb[1],wb[2],wb[3],wb[4],sb);
+    }
+  else
+    n = snake_hbm<S>(A.img + ((A.base + pa) >> 4),B.img + ((B.base + pb) >> 4),sa,sb);
+  return n;
+}
+
 // length of the snake from (ax,bx): equal bases going forward (S > 0: A[ax+i] == B[bx+i]) or backward (S < 0:
-// A[ax-1-i] == B[bx-1-i]), at most lim.  64 bases per round: ten LDS dwords issued together when both stretches
-// lie inside the windows (else straight from the HBM images), aligned with one v_alignbit per dword.
+// A[ax-1-i] == B[bx-1-i]), at most lim.  The first 64-base round is straight-line code (reading past lim only
+// touches padding or the neighbouring contig, and the result is clamped); longer snakes loop.
 template <int S>
 __device__ __forceinline__ int snake(const wseq &A, const wseq &B, int ax, int bx, int lim)
-{ int L = 0;
-  while (L < lim)
-    { const int pa = (S > 0) ? ax+L : ax-L-64, pb = (S > 0) ? bx+L : bx-L-64;
-      const int qa = pa - A.w0, qb = pb - B.w0;
-      uint32_t a0, a1, a2, a3, a4, b0, b1, b2, b3, b4;
-      if ((uint32_t) qa <= (uint32_t) (WINB-80) && (uint32_t) qb <= (uint32_t) (WINB-80))
-        { LDS_PTR const uint32_t *wa = A.win + (qa >> 4), *wb = B.win + (qb >> 4);
-          a0 = wa[0]; a1 = wa[1]; a2 = wa[2]; a3 = wa[3]; a4 = wa[4];
-          b0 = wb[0]; b1 = wb[1]; b2 = wb[2]; b3 = wb[3]; b4 = wb[4];
-        }
-      else
-        { const GLB_PTR uint32_t *ga = A.img + ((A.base + pa) >> 4), *gb = B.img + ((B.base + pb) >> 4);
-          a0 = ga[0]; a1 = ga[1]; a2 = ga[2]; a3 = ga[3]; a4 = ga[4];
-          b0 = gb[0]; b1 = gb[1]; b2 = gb[2]; b3 = gb[3]; b4 = gb[4];
-        }
-      const uint32_t sa = (uint32_t) ((A.bsh + pa) & 15) * 2, sb = (uint32_t) ((B.bsh + pb) & 15) * 2;
-      const uint32_t x0 = __builtin_amdgcn_alignbit(a1,a0,sa) ^ __builtin_amdgcn_alignbit(b1,b0,sb);
-      const uint32_t x1 = __builtin_amdgcn_alignbit(a2,a1,sa) ^ __builtin_amdgcn_alignbit(b2,b1,sb);
-      const uint32_t x2 = __builtin_amdgcn_alignbit(a3,a2,sa) ^ __builtin_amdgcn_alignbit(b3,b2,sb);
-      const uint32_t x3 = __builtin_amdgcn_alignbit(a4,a3,sa) ^ __builtin_amdgcn_alignbit(b4,b3,sb);
-      const uint64_t X = ((uint64_t) x1 << 32) | x0, Y = ((uint64_t) x3 << 32) | x2;
-      int n;
-      if (S > 0)
-        n = X ? ((__ffsll((unsigned long long) X) - 1) >> 1) : (Y ? 32 + ((__ffsll((unsigned long long) Y) - 1) >> 1) : 64);
-      else          // Y holds the 32 bases nearest to (ax,bx)
-        n = Y ? (__clzll((long long) Y) >> 1) : (X ? 32 + (__clzll((long long) X) >> 1) : 64);
-      L += n;
-      if (n < 64)
-        break;
-    }
+{ int n = snake_round<S>(A,B,(S > 0) ? ax : ax-64,(S > 0) ? bx : bx-64);
+  int L = n;
+  if (__builtin_expect(__ballot(n == 64 && lim > 64) != 0,0))
+    while (n == 64 && L < lim)
+      { n = snake_round<S>(A,B,(S > 0) ? ax+L : ax-L-64,(S > 0) ? bx+L : bx-L-64);
+        L += n;
+      }
   return L < lim ? L : lim;
 }
 
@@ -792,25 +822,22 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
           { const int ac = V;
             const int a1 = FROM_NEXT(V,VNEW);              // V[k-S]
             const int a2 = FROM_PREV(V,VNEW);              // V[k+S]
-            int pick;                                      // 0 self, 1 next lane (k-S), 2 previous lane (k+S)
-            if (S > 0)
-              { if (ac < a1) pick = (a1 < a2) ? 2 : 1;
-                else         pick = (ac < a2) ? 2 : 0;
-              }
-            else
-              { if (ac > a1) pick = (a1 > a2) ? 2 : 1;
-                else         pick = (ac > a2) ? 2 : 0;
-              }
+            // furthest of self / next lane (k-S) / previous lane (k+S), ties to self, then k-S (align.c:583-608):
+            // selects only, no divergent branches
+            const bool p1 = (S > 0) ? ac < a1 : ac > a1;
+            const int  m1 = p1 ? a1 : ac;
+            const bool p2 = (S > 0) ? m1 < a2 : m1 > a2;
             const uint32_t tlo = (uint32_t) T, thi = (uint32_t) (T >> 32);
             const uint32_t nlo = (uint32_t) FROM_NEXT((int) tlo,0), nhi = (uint32_t) FROM_NEXT((int) thi,0);
             const uint32_t plo = (uint32_t) FROM_PREV((int) tlo,0), phi = (uint32_t) FROM_PREV((int) thi,0);
             const int nha = FROM_NEXT(HA,-1), pha = FROM_PREV(HA,-1);
             const int nhm = FROM_NEXT(HM,0),  phm = FROM_PREV(HM,0);
             if (act)
-              { if (pick == 0)      { c = ac + 2*S; b = T; ha = HA; hm = HM; }
-                else if (pick == 1) { c = a1 + S; b = ((uint64_t) nhi << 32) | nlo; ha = nha; hm = nhm; }
-                else                { c = a2 + S; b = ((uint64_t) phi << 32) | plo; ha = pha; hm = phm; }
-                b <<= 1;
+              { c  = p2 ? a2 + S : (p1 ? a1 + S : ac + 2*S);
+                ha = p2 ? pha : (p1 ? nha : HA);
+                hm = p2 ? phm : (p1 ? nhm : HM);
+                const uint32_t blo = p2 ? plo : (p1 ? nlo : tlo), bhi = p2 ? phi : (p1 ? nhi : thi);
+                b = (((uint64_t) bhi << 32) | blo) << 1;
                 x = (c+k)>>1;
                 int y = x-k, L;
                 if (S > 0)
@@ -827,18 +854,14 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                     if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
                     x -= L;
                   }
-                if (L > 0)
-                  b = (L >= 61) ? ~0ull : ((b << L) | ((1ull << L) - 1));
+                b = (L >= 61) ? ~0ull : ((b << L) | ((1ull << L) - 1));
                 c = (x << 1) - k;
-                if (S > 0) cross = (x >= na) ? (x-na)/ts+1 : 0;
-                else       cross = (x <= na) ? (na-x)/ts+1 : 0;
-                if (cross > 0)
-                  { int skip;
-                    if (S > 0) skip = (hm >= na) ? (hm-na)/ts+1 : 0;
-                    else       skip = (hm <= na) ? (na-hm)/ts+1 : 0;
-                    if (skip > cross) skip = cross;
-                    ncreate = cross - skip;
-                  }
+                { const int dx = (S > 0) ? x-na : na-x, dh = (S > 0) ? hm-na : na-hm;
+                  cross = (dx >= 0) ? dx/ts+1 : 0;
+                  int skip = (dh >= 0) ? dh/ts+1 : 0;
+                  if (skip > cross) skip = cross;
+                  ncreate = cross - skip;
+                }
               }
           }
           int tot = 0, off = 0;
@@ -973,15 +996,12 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                     b = (L >= 61) ? ~0ull : ((b << L) | ((1ull << L) - 1));
                   c = (x << 1) - k;
                   na = shp->NA[k & RMASK];
-                  if (S > 0) cross = (x >= na) ? (x-na)/ts+1 : 0;
-                  else       cross = (x <= na) ? (na-x)/ts+1 : 0;
-                  if (cross > 0)
-                    { int skip;
-                      if (S > 0) skip = (hm >= na) ? (hm-na)/ts+1 : 0;
-                      else       skip = (hm <= na) ? (na-hm)/ts+1 : 0;
-                      if (skip > cross) skip = cross;
-                      ncreate = cross - skip;
-                    }
+                  { const int dx = (S > 0) ? x-na : na-x, dh = (S > 0) ? hm-na : na-hm;
+                    cross = (dx >= 0) ? dx/ts+1 : 0;
+                    int skip = (dh >= 0) ? dh/ts+1 : 0;
+                    if (skip > cross) skip = cross;
+                    ncreate = cross - skip;
+                  }
                 }
               int tot = 0, off = 0;
               uint64_t cm = __ballot(ncreate > 0);
