@@ -444,128 +444,174 @@ __device__ __forceinline__ bool trim_ok(LDS_PTR ext_shared *sh, uint64_t b, int 
 // unwind the pebble chain of one wave extension into trace pairs (align.c:805-870 / 1325-1415); lane 0 chases
 // the pointers, the others wait.  Shared by the register and the LDS-ring wave routines.
 // ---------------------------------------------------------------------------------------------------
+// The chase is a chain of dependent reads (an L2 round trip each); but a pebble's predecessor was created only a few
+// wave steps earlier, i.e. a few cells lower in the arena.  So the wavefront loads a coalesced window of 64
+// consecutive cells (lane l holds cells[base+l]) and follows the chain inside it with v_readlane -- about twenty
+// links per memory round trip instead of one.
+struct cell_window
+  { const GLB_PTR v4i *cells;
+    int base;                 // window = cells[base .. base+64)
+    v4i w;
+  };
+
+template <int DIR>             // DIR < 0: the walk goes to lower indices, DIR > 0: to higher ones
+__device__ __forceinline__ v4i cw_get(cell_window &W, int idx)      // idx is wave-uniform
+{ if (idx < W.base || idx >= W.base + 64)
+    { W.base = (DIR < 0) ? (idx > 63 ? idx-63 : 0) : idx;
+      W.w = W.cells[W.base + (int) (threadIdx.x & 63)];
+    }
+  const int l = idx - W.base;
+  v4i r;
+  r.x = rdlane(W.w.x,l); r.y = rdlane(W.w.y,l); r.z = rdlane(W.w.z,l); r.w = rdlane(W.w.w,l);
+  return r;
+}
+
 template <int S>
-__device__ __attribute__((noinline)) void ext_unwind(const ext_args &G, int4 *cells, uint16_t *trace, ext_state &P,
-                                                     ext_prof &PF, int mida, int aoff, int trima, int trimx, int trimd,
-                                                     int trimha, int &mind)
+__device__ __attribute__((noinline)) void ext_unwind(const ext_args &G, int4 *cells_in, uint16_t *trace_in, ext_state &P,
+                                                     ext_prof &PF, int mida_in, int aoff_in, int trima_in, int trimx_in,
+                                                     int trimd_in, int trimha_in, int &mind)
 { const int lane = threadIdx.x & 63;
   const int ts = TS;
-  // ---- unwind the pebble chain (lane 0), tip -> root, then write the trace pairs -------------------
-  { // the reference picks the "more" tip only when spec->reach is set; FastGA always passes reach = 0 (FastGA.c:3757)
-    const int trimy = trima - trimx;
+  const int mida = UNI(mida_in), aoff = UNI(aoff_in), trima = UNI(trima_in), trimx = UNI(trimx_in);
+  const int trimd = UNI(trimd_in), trimha = UNI(trimha_in);
+  GLB_PTR v4i *cells = (GLB_PTR v4i *) uni64((int64_t) cells_in);
+  GLB_PTR uint16_t *trace = (GLB_PTR uint16_t *) uni64((int64_t) trace_in);
+  const bool l0 = (lane == 0);
+  // the reference picks the "more" tip only when spec->reach is set; FastGA always passes reach = 0 (FastGA.c:3757)
+  const int trimy = trima - trimx;
+  int tlen = UNI(P.tlen), tpos = UNI(P.tpos);
+  int rootk = 0;
+  const unsigned long long tun = clock64();
+  __syncthreads();          // once per call: all pebble stores of the wave are complete before the pointer chase
+  cell_window W;
+  W.cells = cells; W.base = -1000; W.w = (v4i) { 0,0,0,0 };
 
-    int rootk = 0;
-    const unsigned long long tun = clock64();
-    __syncthreads();          // once per call: all pebble stores of the wave are complete before the pointer chase
-    if (lane == 0)
-      { // walk tip -> root; pairs come out last-to-first
-        if (S > 0)
-          { // single walk tip -> root; pairs are stored downwards from the top of the scratch so no count
-            // pass is needed (the reverse wave prepends below P.tpos afterwards)
-            int pos = (int) G.trace_cap - 8;
-            const int tend = pos;
-            int4 cur4 = cells[trimha];
-            int lastb, lastd, lastk;
-            if (cur4.x >= 0)
-              { lastb = cur4.w - cur4.y; lastd = cur4.z; lastk = cur4.y; }
-            while (cur4.x >= 0)
-              { int4 prv = cells[cur4.x];
-                int bcur = cur4.w - cur4.y;
-                int bprv = (prv.x >= 0) ? prv.w - prv.y : ((mida - prv.y) >> 1);
-                int dprv = (prv.x >= 0) ? prv.z : 0;
-                pos -= 2;
-                trace[pos]   = (uint16_t) (cur4.z - dprv);
-                trace[pos+1] = (uint16_t) (bcur - bprv);
-                cur4 = prv;
-              }
-            rootk = cur4.y;
-            if (pos == tend)
-              { lastb = (mida - rootk) >> 1; lastd = 0; lastk = rootk; }
-            int atlen = tend - pos;
-            uint16_t *at = trace + pos;
-            if (lastb + lastk != trimx)
-              { at[atlen++] = (uint16_t) (trimd - lastd);
-                at[atlen++] = (uint16_t) (trimy - lastb);
-              }
-            else if (lastb != trimy)
-              { at[atlen-1] = (uint16_t) (at[atlen-1] + (trimy - lastb));
-                at[atlen-2] = (uint16_t) (at[atlen-2] + (trimd - lastd));
-              }
-            P.tlen = atlen;
-            P.tpos = pos;
-          }
-        else
-          { // reverse wave: the list runs tip (towards the alignment start) -> root (at the mid point);
-            // the reference reverses it and walks root -> tip, prepending pairs.
-            // pass 1 reverses the pointers in place exactly like the reference (align.c:1342-1348)
-            int a = -1, h = trimha, bq;
-            while (h >= 0)
-              { bq = cells[h].x;
-                cells[h].x = a;
-                a = h;
-                h = bq;
-              }
-            h = a;
-            uint16_t *at = trace + P.tpos;
-            int atlen = 0;
-            int4 c4 = cells[h];
-            int k = c4.y;
-            int b = c4.w - k, e = 0, d = 0, aa = 0;
-            if ((b+k) % ts != aoff)
-              { h = c4.x;
-                if (h < 0)
-                  { aa = trimy; d = trimd; }
-                else
-                  { c4 = cells[h];
-                    k = c4.y; aa = c4.w - k; d = c4.z;
-                  }
-                if (P.tlen == 0)
-                  { at[--atlen] = (uint16_t) (b-aa);
-                    at[--atlen] = (uint16_t) (d-e);
-                  }
-                else
-                  { at[1] = (uint16_t) (at[1] + (b-aa));
-                    at[0] = (uint16_t) (at[0] + (d-e));
-                  }
-                b = aa;
-                e = d;
-              }
-            if (h >= 0)
-              { for (h = c4.x; h >= 0; h = c4.x)
-                  { c4 = cells[h];
-                    k = c4.y;
-                    aa = c4.w - k;
-                    at[--atlen] = (uint16_t) (b-aa);
-                    d = c4.z;
-                    at[--atlen] = (uint16_t) (d-e);
-                    b = aa;
-                    e = d;
-                  }
-                if (b+k != trimx)
-                  { at[--atlen] = (uint16_t) (b-trimy);
-                    at[--atlen] = (uint16_t) (trimd-e);
-                  }
-                else if (b != trimy)
-                  { at[atlen+1] = (uint16_t) (at[atlen+1] + (b-trimy));
-                    at[atlen]   = (uint16_t) (at[atlen]   + (trimd-e));
-                  }
-              }
-            P.tlen = P.tlen - atlen;
-            P.tpos = P.tpos + atlen;
-          }
-      }
-    // broadcast lane 0's results
-    P.tlen = rdlane(P.tlen,0);
-    P.tpos = rdlane(P.tpos,0);
-    rootk  = rdlane(rootk,0);
-    if (S > 0)
-      { P.aepos = trimx; P.bepos = trimy; P.diffs = trimd;
-        mind = rootk;
-      }
-    else
-      { P.abpos = trimx; P.bbpos = trimy; P.diffs = P.diffs + trimd; }
-    PF.t_unwind += clock64() - tun;
-  }
+  if (S > 0)
+    { // single walk tip -> root; the pairs come out last-to-first and are stored downwards from the top of the
+      // scratch, so no count pass is needed (the reverse wave prepends below tpos afterwards)
+      int pos = (int) UNI((int) G.trace_cap) - 8;
+      const int tend = pos;
+      v4i cur4 = cw_get<-1>(W,trimha);
+      int lastb = 0, lastd = 0, lastk = 0;
+      if (cur4.x >= 0)
+        { lastb = cur4.w - cur4.y; lastd = cur4.z; lastk = cur4.y; }
+      while (cur4.x >= 0)
+        { const v4i prv = cw_get<-1>(W,cur4.x);
+          const int bcur = cur4.w - cur4.y;
+          const int bprv = (prv.x >= 0) ? prv.w - prv.y : ((mida - prv.y) >> 1);
+          const int dprv = (prv.x >= 0) ? prv.z : 0;
+          pos -= 2;
+          if (l0)
+            { trace[pos]   = (uint16_t) (cur4.z - dprv);
+              trace[pos+1] = (uint16_t) (bcur - bprv);
+            }
+          cur4 = prv;
+        }
+      rootk = cur4.y;
+      if (pos == tend)
+        { lastb = (mida - rootk) >> 1; lastd = 0; lastk = rootk; }
+      int atlen = tend - pos;
+      GLB_PTR uint16_t *at = trace + pos;
+      if (lastb + lastk != trimx)
+        { if (l0)
+            { at[atlen]   = (uint16_t) (trimd - lastd);
+              at[atlen+1] = (uint16_t) (trimy - lastb);
+            }
+          atlen += 2;
+        }
+      else if (lastb != trimy)
+        { if (l0)
+            { at[atlen-1] = (uint16_t) (at[atlen-1] + (trimy - lastb));
+              at[atlen-2] = (uint16_t) (at[atlen-2] + (trimd - lastd));
+            }
+        }
+      tlen = atlen;
+      tpos = pos;
+    }
+  else
+    { // reverse wave: the list runs tip (towards the alignment start) -> root (at the mid point); the reference
+      // reverses it and walks root -> tip, prepending pairs.  Pass 1 reverses the pointers in place exactly like the
+      // reference (align.c:1342-1348); pass 2 walks the reversed list through windows that extend upwards.
+      int a = -1, h = trimha;
+      while (h >= 0)
+        { const int bq = cw_get<-1>(W,h).x;
+          if (l0)
+            ((GLB_PTR int *) (cells + h))[0] = a;
+          a = h;
+          h = bq;
+        }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST,"workgroup");       // the reversed pointers are visible to pass 2
+      __builtin_amdgcn_s_waitcnt(0);
+      W.base = -1000;
+      h = a;
+      GLB_PTR uint16_t *at = trace + tpos;
+      int atlen = 0;
+      v4i c4 = cw_get<+1>(W,h);
+      int k = c4.y;
+      int b = c4.w - k, e = 0, d = 0, aa = 0;
+      if ((b+k) % ts != aoff)
+        { h = c4.x;
+          if (h < 0)
+            { aa = trimy; d = trimd; }
+          else
+            { c4 = cw_get<+1>(W,h);
+              k = c4.y; aa = c4.w - k; d = c4.z;
+            }
+          if (tlen == 0)
+            { atlen -= 2;
+              if (l0)
+                { at[atlen+1] = (uint16_t) (b-aa);
+                  at[atlen]   = (uint16_t) (d-e);
+                }
+            }
+          else if (l0)
+            { at[1] = (uint16_t) (at[1] + (b-aa));
+              at[0] = (uint16_t) (at[0] + (d-e));
+            }
+          b = aa;
+          e = d;
+        }
+      if (h >= 0)
+        { for (h = c4.x; h >= 0; h = c4.x)
+            { c4 = cw_get<+1>(W,h);
+              k = c4.y;
+              aa = c4.w - k;
+              d = c4.z;
+              atlen -= 2;
+              if (l0)
+                { at[atlen+1] = (uint16_t) (b-aa);
+                  at[atlen]   = (uint16_t) (d-e);
+                }
+              b = aa;
+              e = d;
+            }
+          if (b+k != trimx)
+            { atlen -= 2;
+              if (l0)
+                { at[atlen+1] = (uint16_t) (b-trimy);
+                  at[atlen]   = (uint16_t) (trimd-e);
+                }
+            }
+          else if (b != trimy)
+            { if (l0)
+                { at[atlen+1] = (uint16_t) (at[atlen+1] + (b-trimy));
+                  at[atlen]   = (uint16_t) (at[atlen]   + (trimd-e));
+                }
+            }
+        }
+      tlen = tlen - atlen;
+      tpos = tpos + atlen;
+    }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST,"workgroup");           // lane 0's trace pairs before any lane reads them
+  P.tlen = tlen;
+  P.tpos = tpos;
+  if (S > 0)
+    { P.aepos = trimx; P.bepos = trimy; P.diffs = trimd;
+      mind = rootk;
+    }
+  else
+    { P.abpos = trimx; P.bbpos = trimy; P.diffs = P.diffs + trimd; }
+  PF.t_unwind += clock64() - tun;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1459,7 +1505,7 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
     { fga_set_error("fga_extend: device allocation failed: %s",hipGetErrorString(e));
       goto fail;
     }
-  A.cells  = (int4 *)     fga_dev_acquire(dev,SLOT_CELLS,sizeof(int4)*(size_t) cell_cap*nwg);
+  A.cells  = (int4 *)     fga_dev_acquire(dev,SLOT_CELLS,sizeof(int4)*((size_t) cell_cap*nwg + 64));     // + one unwind window
   A.trace  = (uint16_t *) fga_dev_acquire(dev,SLOT_TRACE,sizeof(uint16_t)*(size_t) trace_cap*nwg);
   A.alns   = (fga_aln *)  fga_dev_acquire(dev,SLOT_ALNS,sizeof(fga_aln)*(size_t) aln_cap);
   A.tbytes = (uint8_t *)  fga_dev_acquire(dev,SLOT_TBYTES,(size_t) tb_cap);
