@@ -146,27 +146,20 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
     int wa, wb, wd, wt;
     fga_chain_params cp;
     fga_keys_layout(keys,&wa,&wb,&wd,&wt);
-    const void *pk;
+    (void) n;
     alen  = malloc(sizeof(int64_t)*x1->nctg);
     if (alen == NULL)
       { fga_set_error("out of memory");
         goto done;
       }
-    pk = fga_keys_download_pinned(keys);
-    if (pk == NULL) goto done;
-    fga_keys_free(keys); keys = NULL;
     for (i = 0; i < x1->nctg; i++)
       alen[i] = (x1->perm[i] < g1->ncontig) ? g1->contigs[x1->perm[i]].clen : FGA_KMER;
     cp.chain_break = P->chain_break; cp.chain_min = P->chain_min;
     cp.amxpos = g1->maxctg; cp.bmxpos = self ? g1->maxctg : g2->maxctg;
-    cp.alen = alen;
-    st.download_s = fga_wall() - t1;
-    t1 = fga_wall();
-    { long nc = sysconf(_SC_NPROCESSORS_ONLN);       /* the scan is memory-bound and embarrassingly parallel */
-      int nt = P->nthreads > 0 ? P->nthreads : 1;
-      if (nc > nt) nt = (int) (nc > 128 ? 128 : nc);
-      if (fga_chain_scan(pk,n,wa,wb,wd,wt,&cp,nt,&hits)) goto done;
-    }
+    cp.alen = alen; cp.nalen = x1->nctg;
+    st.download_s = 0.;                              /* the sorted records never leave HBM any more */
+    if (fga_chain_scan_device(dev,keys,&cp,&hits)) goto done;
+    fga_keys_free(keys); keys = NULL;
     st.nhits = hits->nhits;
     st.nunits = hits->nunits;
     st.chain_s = fga_wall() - t1;

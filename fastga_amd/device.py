@@ -200,12 +200,21 @@ def chain_scan(keys_host, layout, chain_break, chain_min, amxpos, bmxpos, alen_s
     """keys_host: structured (lo,hi) array; layout = (wa,wb,wd,wt); alen_sorted: A contig lengths by sorted index."""
     L = load_library()
     al = np.ascontiguousarray(alen_sorted, dtype=np.int64)
-    prm = ChainParams(chain_break, chain_min, amxpos, bmxpos, al.ctypes.data)
+    prm = ChainParams(chain_break, chain_min, amxpos, bmxpos, al.ctypes.data, len(al))
     out = C.POINTER(Hits)()
     k = np.ascontiguousarray(keys_host)
     check(L.fga_chain_scan(k.ctypes.data_as(C.c_void_p), len(k), *layout, C.byref(prm), nthreads, C.byref(out)),
           "chain scan")
     return HitList(L, out)
+
+
+def chain_scan_device(dev, keys, chain_break, chain_min, amxpos, bmxpos, alen_sorted):
+    """The chain scan on the device-resident sorted keys (`keys`: a Keys object of seed_sort)."""
+    al = np.ascontiguousarray(alen_sorted, dtype=np.int64)
+    prm = ChainParams(chain_break, chain_min, amxpos, bmxpos, al.ctypes.data, len(al))
+    out = C.POINTER(Hits)()
+    check(dev.L.fga_chain_scan_device(dev.h, keys.h, C.byref(prm), C.byref(out)), "device chain scan")
+    return HitList(dev.L, out)
 
 
 def hits_from_arrays(units, hits):

@@ -44,7 +44,7 @@ class MergeParams(C.Structure):
 
 class ChainParams(C.Structure):
     _fields_ = [("chain_break", C.c_int64), ("chain_min", C.c_int64), ("amxpos", C.c_int64),
-                ("bmxpos", C.c_int64), ("alen", C.c_void_p)]
+                ("bmxpos", C.c_int64), ("alen", C.c_void_p), ("nalen", C.c_int64)]
 
 
 class Hits(C.Structure):
@@ -131,6 +131,7 @@ def _declare(L):
         "fga_keys_download_pinned": (vp, [vp]),
         "fga_keys_free": (None, [vp]),
         "fga_chain_scan": (i32, [vp, i64, i32, i32, i32, i32, P(ChainParams), i32, P(P(Hits))]),
+        "fga_chain_scan_device": (i32, [vp, vp, P(ChainParams), P(P(Hits))]),
         "fga_hits_create": (i32, [vp, i64, vp, i64, P(P(Hits))]),
         "fga_hits_free": (None, [P(Hits)]),
         "fga_hits_count": (i64, [P(Hits)]),

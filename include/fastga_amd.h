@@ -131,6 +131,7 @@ typedef struct
     int64_t chain_min;         /* -c, doubled (FastGA.c:4495)                     */
     int64_t amxpos, bmxpos;
     const int64_t *alen;       /* A contig lengths by length-sorted index         */
+    int64_t nalen;             /* entries in alen (the device scan copies them)   */
   } fga_chain_params;
 
 typedef struct
@@ -141,6 +142,9 @@ typedef struct
 
 int  fga_chain_scan(const void *keys /* n x {lo64,hi64} */, int64_t n, int wa, int wb, int wd, int wt,
                     const fga_chain_params *prm, int nthreads, fga_hits **out);
+/* the same scan on the device-resident keys: the 16 B/record stream stays in HBM, only the hits come back.
+ * Units are returned in the order of fga_chain_scan (by first record), hits contiguous per unit. */
+int  fga_chain_scan_device(fga_dev *dev, const fga_dkeys *keys, const fga_chain_params *prm, fga_hits **out);
 int  fga_hits_create(const fga_unit *units, int64_t nunits, const fga_hit *hits, int64_t nhits, fga_hits **out);
 void fga_hits_free(fga_hits *hits);
 int64_t         fga_hits_count(const fga_hits *hits);

@@ -1,0 +1,60 @@
+"""GPU parity: the device chain scan (thread-per-bucket + wave-parallel kernels) against the host restatement of
+the reference's scan (align_contigs, FastGA.c:3016-3176) on the same sorted records -- bit-exact hits and units.
+The small/long unit threshold is varied so that every unit also goes through the wave-parallel kernel."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _scan_both(ra, rb, limits, chain_min=170, chain_break=2000):
+    from fastga_amd.gixio import Gix, Gdb
+    from fastga_amd import device as D
+    A, B = Gix(ra + ".gix"), Gix(rb + ".gix")
+    ga, gb = Gdb(ra + ".gdb"), Gdb(rb + ".gdb")
+    amx, bmx = int(ga.maxctg), int(gb.maxctg)
+    dev = D.Device(0)
+    dA, dB = dev.upload(A), dev.upload(B)
+    seeds = D.seed_merge(dev, dA, dB)
+    keys = D.seed_sort(dev, seeds, amx, bmx, A.nctg, B.nctg)
+    seeds.free()
+    alen_sorted = ga.clen[A.perm]
+    ref = D.chain_scan(keys.download(), (keys.wa, keys.wb, keys.wd, keys.wt), chain_break, chain_min, amx, bmx,
+                       alen_sorted, nthreads=4)
+    ru, rh = ref.units, ref.hits
+    out = []
+    for lim in limits:
+        if lim is None:
+            os.environ.pop("FGA_CHAIN_SMALL_LIMIT", None)
+        else:
+            os.environ["FGA_CHAIN_SMALL_LIMIT"] = str(lim)
+        try:
+            got = D.chain_scan_device(dev, keys, chain_break, chain_min, amx, bmx, alen_sorted)
+        finally:
+            os.environ.pop("FGA_CHAIN_SMALL_LIMIT", None)
+        out.append((lim, got.units, got.hits))
+        got.free()
+    ref.free(); keys.free(); dA.free(); dB.free(); dev.close()
+    return ru, rh, out
+
+
+@pytest.mark.parametrize("chain_min", [170, 100])
+def test_device_chain_scan_matches_host(toy_pair, chain_min):
+    d, ra, rb = toy_pair
+    ru, rh, out = _scan_both(ra, rb, [None, 3, 0], chain_min=chain_min)
+    assert len(rh) > 20
+    for lim, u, h in out:
+        assert len(u) == len(ru) and len(h) == len(rh), (lim, len(u), len(ru), len(h), len(rh))
+        assert np.array_equal(u, ru), lim
+        assert np.array_equal(h, rh), lim
+
+
+def test_device_chain_scan_self(toy_pair):
+    """self comparison: every contig pairs with itself, which gives the longest buckets"""
+    d, ra, rb = toy_pair
+    ru, rh, out = _scan_both(ra, ra, [None, 0])
+    assert len(rh) > 0
+    for lim, u, h in out:
+        assert np.array_equal(u, ru) and np.array_equal(h, rh), lim
