@@ -303,6 +303,7 @@ __device__ __forceinline__ bool win_track(ext_seq &s, int pos)
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 typedef int v4i __attribute__((ext_vector_type(4)));      // a pebble cell as a plain 16-byte vector (int4 layout)
 #define UNI(v) __builtin_amdgcn_readfirstlane((int) (v))
+#define BALLOT(p) __builtin_amdgcn_ballot_w64(p)
 __device__ __forceinline__ int64_t uni64(int64_t v)
 { const uint32_t lo = (uint32_t) UNI((uint32_t) v), hi = (uint32_t) UNI((uint32_t) ((uint64_t) v >> 32));
   return (int64_t) (((uint64_t) hi << 32) | lo);
@@ -396,7 +397,7 @@ __device__ __forceinline__ int snake_round(const wseq &A, const wseq &B, int pa,
   const uint32_t sa = (uint32_t) ((A.bsh + pa) & 15) * 2, sb = (uint32_t) ((B.bsh + pb) & 15) * 2;
   const bool inw = (uint32_t) qa <= (uint32_t) (WINB-80) && (uint32_t) qb <= (uint32_t) (WINB-80);
   int n;
-  if (__builtin_expect(__ballot(!inw) == 0,1))
+  if (__builtin_expect(BALLOT(!inw) == 0,1))
     { LDS_PTR const uint32_t *wa = A.win + (qa >> 4), *wb = B.win + (qb >> 4);
       n = snake_cmp<S>(wa[0],wa[1],wa[2],wa[3],wa[4],sa,wb[0],wb[1],wb[2],wb[3],wb[4],sb);
     }
@@ -412,7 +413,7 @@ template <int S>
 __device__ __forceinline__ int snake(const wseq &A, const wseq &B, int ax, int bx, int lim)
 { int n = snake_round<S>(A,B,(S > 0) ? ax : ax-64,(S > 0) ? bx : bx-64);
   int L = n;
-  if (__builtin_expect(__ballot(n == 64 && lim > 64) != 0,0))
+  if (__builtin_expect(BALLOT(n == 64 && lim > 64) != 0,0))
     while (n == 64 && L < lim)
       { n = snake_round<S>(A,B,(S > 0) ? ax+L : ax-L-64,(S > 0) ? bx+L : bx-L-64);
         L += n;
@@ -437,7 +438,7 @@ __device__ __forceinline__ int wscan_max_excl_nn(int v)
 __device__ __forceinline__ bool trim_ok(LDS_PTR ext_shared *sh, uint64_t b, int ms)
 { const uint32_t qlo = (uint32_t) b & TRIM_MASK, qhi = (uint32_t) (b >> TRIM_LEN) & TRIM_MASK;
   const int tlo = trim_table(sh,qlo), thi = trim_table(sh,qhi);
-  return tlo >= 0 && thi + trim_score(qlo,ms) >= 0;
+  return (tlo >= 0) & (thi + trim_score(qlo,ms) >= 0);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -628,8 +629,10 @@ __device__ __attribute__((noinline)) void ext_unwind(const ext_args &G, int4 *ce
 //   A wave that grows beyond 60 diagonals spills its registers to the ring and continues there; when it has
 //     shrunk to <= 40 it is reloaded into registers.
 // ---------------------------------------------------------------------------------------------------
-#define FROM_NEXT(v,oldv) __builtin_amdgcn_update_dpp(oldv,v,0x130,0xf,0xf,false)    /* lane l gets lane l+1 */
-#define FROM_PREV(v,oldv) __builtin_amdgcn_update_dpp(oldv,v,0x138,0xf,0xf,false)    /* lane l gets lane l-1 */
+// lane l gets lane l+1 / l-1.  The active lanes are kept inside [1,62] and lanes 0 and 63 hold VNEW, so what the
+// two end lanes receive is never used: no `old` operand to initialise.
+#define FROM_NEXT(v,oldv) __builtin_amdgcn_mov_dpp(v,0x130,0xf,0xf,true)
+#define FROM_PREV(v,oldv) __builtin_amdgcn_mov_dpp(v,0x138,0xf,0xf,true)
 #define REG_MAXW 60
 #define REG_BACK 40
 #define KOF(l)    ((S > 0) ? kref - (l) : kref + (l))
@@ -654,7 +657,8 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
   const int maxd = UNI(maxd_in), mida = UNI(mida_in), minp = UNI(minp_in), maxp = UNI(maxp_in), aoff = UNI(aoff_in);
   unsigned long long nwaves = 0, nspill = 0;
   const int ts = TS, path_ave = UNI(G.path_ave), mscore = UNI(G.mscore);
-  const int64_t cell_cap = uni64(G.cell_cap);
+  const int64_t cell_cap64 = uni64(G.cell_cap);
+  const int cell_cap = (int) (cell_cap64 < (1ll << 30) ? cell_cap64 : (1ll << 30));     // 32-bit arena arithmetic
   const bool force_lds = UNI(G.force_lds) != 0;
   const int VNEW = (S > 0) ? -1 : BIGI;
   int low = UNI(mind), hgh = maxd, dif = 0, cur = 0;
@@ -722,7 +726,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
             else       cnt = (x <= na) ? (na-x)/ts+1 : 0;
           }
         int tot, off = wscan_add_excl(act ? 1+cnt : 0,tot);
-        if ((int64_t) avail + tot > cell_cap)
+        if (avail + tot > cell_cap)
           BAIL(1)
         int ha = -1, hm = 0;
         if (act)
@@ -749,14 +753,14 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
         const int cn = act ? ((S > 0) ? c : BIGI - c) : 0;          // non-negative, larger = better
           const int pm = wscan_max_excl_nn(cn);
         bool rec = act && ((S > 0) ? c > besta : c < besta) && cn > pm;
-        uint64_t rm = __ballot(rec);
+        uint64_t rm = BALLOT(rec);
         if (rm)
           { int l = last_lane(rm);
             besta = trima = lasta = rdlane(c,l);
             bestx = trimx = rdlane(x,l);
             trimha = rdlane(ha,l);
           }
-        uint64_t am = __ballot(hitA), bm = __ballot(hitB);
+        uint64_t am = BALLOT(hitA), bm = BALLOT(hitB);
         if (am | bm) more = 0;
         if (am) aclip = rdlane(k,last_lane(am));
         if (bm && ((S > 0) ? bclip == -BIGI : bclip == BIGI)) bclip = rdlane(k,first_lane(bm));
@@ -911,10 +915,15 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
               }
           }
           int tot = 0, off = 0;
-          uint64_t cm = __ballot(ncreate > 0);
+          uint64_t cm = BALLOT(ncreate > 0);
           if (cm)
-            { off = wscan_add_excl(ncreate,tot);
-              if ((int64_t) avail + tot > cell_cap)
+            { if (BALLOT(ncreate > 1) == 0)        // the usual case, one pebble per crossing lane: slots by mbcnt
+                { off = (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (cm >> 32),__builtin_amdgcn_mbcnt_lo((uint32_t) cm,0u));
+                  tot = __popcll(cm);
+                }
+              else
+                off = wscan_add_excl(ncreate,tot);
+              if (avail + tot > cell_cap)
                 BAIL(1)
             }
           if (act)
@@ -939,14 +948,14 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
           const int cn = act ? ((S > 0) ? c : BIGI - c) : 0;          // non-negative, larger = better
           const int pm = wscan_max_excl_nn(cn);
           bool rec = act && ((S > 0) ? c > besta : c < besta) && cn > pm;
-          uint64_t rm = __ballot(rec);
+          uint64_t rm = BALLOT(rec);
           if (rm)
             { int l = last_lane(rm);
               besta = rdlane(c,l);
               bestx = rdlane(x,l);
               int m = __popcll(b & WIN61);
               bool good = rec && m >= path_ave;
-              uint64_t gm = __ballot(good);
+              uint64_t gm = BALLOT(good);
               if (gm)
                 { lasta = rdlane(c,last_lane(gm));
                   bool trimok = false;
@@ -954,7 +963,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                     {
                       trimok = trim_ok(shp,b,mscore);
                     }
-                  uint64_t tm = __ballot(trimok);
+                  uint64_t tm = BALLOT(trimok);
                   if (tm)
                     { int l2 = last_lane(tm);
                       trima = rdlane(c,l2);
@@ -964,7 +973,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                     }
                 }
             }
-          uint64_t am = __ballot(hitA), bm = __ballot(hitB);
+          uint64_t am = BALLOT(hitA), bm = BALLOT(hitB);
           if (am) aclip = KOF(last_lane(am));
           if (bm) bclip = KOF(first_lane(bm));
           anyA = am; anyB = bm;
@@ -975,7 +984,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
           // prune both ends (align.c:782-790)
           { const int n = besta - S*WAVE_LAG;
             const bool inr = k >= low && k <= hgh;
-            uint64_t km = __ballot(inr && ((S > 0) ? (V >= n) : (V <= n)));
+            uint64_t km = BALLOT(inr && ((S > 0) ? (V >= n) : (V <= n)));
             if (km == 0)
               hgh = low-1;
             else
@@ -1050,10 +1059,10 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                   }
                 }
               int tot = 0, off = 0;
-              uint64_t cm = __ballot(ncreate > 0);
+              uint64_t cm = BALLOT(ncreate > 0);
               if (cm)
                 { off = wscan_add_excl(ncreate,tot);
-                  if ((int64_t) avail + tot > cell_cap)
+                  if (avail + tot > cell_cap)
                     BAIL(1)
                 }
               if (act)
@@ -1080,14 +1089,14 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
               const int cn = act ? ((S > 0) ? c : BIGI - c) : 0;          // non-negative, larger = better
           const int pm = wscan_max_excl_nn(cn);
               bool rec = act && ((S > 0) ? c > besta : c < besta) && cn > pm;
-              uint64_t rm = __ballot(rec);
+              uint64_t rm = BALLOT(rec);
               if (rm)
                 { int l = last_lane(rm);
                   besta = rdlane(c,l);
                   bestx = rdlane(x,l);
                   int m = __popcll(b & WIN61);
                   bool good = rec && m >= path_ave;
-                  uint64_t gm = __ballot(good);
+                  uint64_t gm = BALLOT(good);
                   if (gm)
                     { lasta = rdlane(c,last_lane(gm));
                       bool trimok = false;
@@ -1095,7 +1104,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                         {
                           trimok = trim_ok(shp,b,mscore);
                         }
-                      uint64_t tm = __ballot(trimok);
+                      uint64_t tm = BALLOT(trimok);
                       if (tm)
                         { int l2 = last_lane(tm);
                           trima = rdlane(c,l2);
@@ -1105,7 +1114,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                         }
                     }
                 }
-              uint64_t am = __ballot(hitA), bm = __ballot(hitB);
+              uint64_t am = BALLOT(hitA), bm = BALLOT(hitB);
               if (am) aclip = rdlane(k,last_lane(am));
               if (bm && !anyB) bclip = rdlane(k,first_lane(bm));
               anyA |= am; anyB |= bm;
@@ -1127,7 +1136,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                   { int v = shp->V[cur][k & RMASK];
                     keep = (S > 0) ? (v >= n) : (v <= n);
                   }
-                uint64_t km = __ballot(keep);
+                uint64_t km = BALLOT(keep);
                 if (km)
                   { int f = low + j0 + first_lane(km), l = low + j0 + last_lane(km);
                     if (f < nl) nl = f;
