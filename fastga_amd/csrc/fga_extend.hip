@@ -914,10 +914,14 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                 }
               }
           }
+          // the trim-table lookups of this lane's history (needed below only when the lane sets a new good best
+          // point) are issued now, so that their LDS round trip overlaps the pebble stores and the record scan
+          const bool tok = act ? trim_ok(shp,b,mscore) : false;
           int tot = 0, off = 0;
           uint64_t cm = BALLOT(ncreate > 0);
           if (cm)
-            { if (BALLOT(ncreate > 1) == 0)        // the usual case, one pebble per crossing lane: slots by mbcnt
+            { const bool single = (BALLOT(ncreate > 1) == 0);
+              if (single)                            // the usual case, one pebble per crossing lane: slots by mbcnt
                 { off = (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (cm >> 32),__builtin_amdgcn_mbcnt_lo((uint32_t) cm,0u));
                   tot = __popcll(cm);
                 }
@@ -925,9 +929,15 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                 off = wscan_add_excl(ncreate,tot);
               if (avail + tot > cell_cap)
                 BAIL(1)
-            }
-          if (act)
-            { if (ncreate > 0)
+              if (single)
+                { if (ncreate > 0)
+                    { const int idx = avail + off;
+                      hm = na + S*ts*(cross-1);
+                      cells[idx] = (v4i) { ha,k,dif,hm };
+                      ha = idx;
+                    }
+                }
+              else if (ncreate > 0)
                 { int idx = avail + off;
                   int v = na + S*ts*(cross-ncreate);
                   for (int q = 0; q < ncreate; q++)
@@ -938,8 +948,9 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                       v += S*ts;
                     }
                 }
-              if (cross > 0)
-                NA = na + S*ts*cross;
+            }
+          if (act)
+            { NA = na + S*ts*cross;
               V = c; T = b; HA = ha; HM = hm;
             }
           avail += tot;
@@ -958,11 +969,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
               uint64_t gm = BALLOT(good);
               if (gm)
                 { lasta = rdlane(c,last_lane(gm));
-                  bool trimok = false;
-                  if (good)
-                    {
-                      trimok = trim_ok(shp,b,mscore);
-                    }
+                  const bool trimok = good && tok;
                   uint64_t tm = BALLOT(trimok);
                   if (tm)
                     { int l2 = last_lane(tm);
@@ -1099,11 +1106,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                   uint64_t gm = BALLOT(good);
                   if (gm)
                     { lasta = rdlane(c,last_lane(gm));
-                      bool trimok = false;
-                      if (good)
-                        {
-                          trimok = trim_ok(shp,b,mscore);
-                        }
+                      const bool trimok = good && trim_ok(shp,b,mscore);
                       uint64_t tm = BALLOT(trimok);
                       if (tm)
                         { int l2 = last_lane(tm);
