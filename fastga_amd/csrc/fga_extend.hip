@@ -467,6 +467,35 @@ __device__ __forceinline__ v4i cw_get(cell_window &W, int idx)      // idx is wa
   return r;
 }
 
+// Trace pairs (and reversed pebble pointers) are not stored one by one -- a global store per link makes every link
+// wait for the previous store's acknowledgement as soon as the next window is read -- but collected in
+// one VGPR, lane j = j-th value of the batch, and written 64 at a time.
+struct lane_batch
+  { uint32_t val;       // lane j: j-th value pushed since the last flush
+    uint32_t key;       // lane j: its destination (scattered batches only)
+    int      n;         // wave-uniform fill
+  };
+__device__ __forceinline__ void lb_push(lane_batch &B, uint32_t v, uint32_t k)     // v, k wave-uniform
+{ const bool mine = (int) (threadIdx.x & 63) == B.n;
+  B.val = mine ? v : B.val;
+  B.key = mine ? k : B.key;
+  B.n += 1;
+}
+// contiguous, descending: the j-th value goes to dword (top - j) of d32
+__device__ __forceinline__ void lb_flush_desc(lane_batch &B, GLB_PTR uint32_t *d32, int64_t top)
+{ const int lane = threadIdx.x & 63;
+  if (lane < B.n)
+    d32[top - lane] = B.val;
+  B.n = 0;
+}
+// scattered: the j-th value goes to the first dword of cell key_j
+__device__ __forceinline__ void lb_flush_cells(lane_batch &B, GLB_PTR v4i *cells)
+{ const int lane = threadIdx.x & 63;
+  if (lane < B.n)
+    ((GLB_PTR int *) (cells + B.key))[0] = (int) B.val;
+  B.n = 0;
+}
+
 template <int S>
 __device__ __attribute__((noinline)) void ext_unwind(const ext_args &G, int4 *cells_in, uint16_t *trace_in, ext_state &P,
                                                      ext_prof &PF, int mida_in, int aoff_in, int trima_in, int trimx_in,
@@ -492,6 +521,9 @@ __device__ __attribute__((noinline)) void ext_unwind(const ext_args &G, int4 *ce
       // scratch, so no count pass is needed (the reverse wave prepends below tpos afterwards)
       int pos = (int) UNI((int) G.trace_cap) - 8;
       const int tend = pos;
+      GLB_PTR uint32_t *tr32 = (GLB_PTR uint32_t *) trace;      // trace is dword aligned and every pos is even
+      lane_batch LB; LB.val = 0; LB.key = 0; LB.n = 0;
+      int ptop = 0;                                             // dword index of the batch's first pair
       v4i cur4 = cw_get<-1>(W,trimha);
       int lastb = 0, lastd = 0, lastk = 0;
       if (cur4.x >= 0)
@@ -502,12 +534,15 @@ __device__ __attribute__((noinline)) void ext_unwind(const ext_args &G, int4 *ce
           const int bprv = (prv.x >= 0) ? prv.w - prv.y : ((mida - prv.y) >> 1);
           const int dprv = (prv.x >= 0) ? prv.z : 0;
           pos -= 2;
-          if (l0)
-            { trace[pos]   = (uint16_t) (cur4.z - dprv);
-              trace[pos+1] = (uint16_t) (bcur - bprv);
-            }
+          if (LB.n == 0)
+            ptop = pos >> 1;
+          lb_push(LB,((uint32_t) (cur4.z - dprv) & 0xffffu) | ((uint32_t) (bcur - bprv) << 16),0u);
+          if (LB.n == 64)
+            lb_flush_desc(LB,tr32,ptop);
           cur4 = prv;
         }
+      lb_flush_desc(LB,tr32,ptop);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST,"workgroup");
       rootk = cur4.y;
       if (pos == tend)
         { lastb = (mida - rootk) >> 1; lastd = 0; lastk = rootk; }
@@ -534,13 +569,16 @@ __device__ __attribute__((noinline)) void ext_unwind(const ext_args &G, int4 *ce
       // reverses it and walks root -> tip, prepending pairs.  Pass 1 reverses the pointers in place exactly like the
       // reference (align.c:1342-1348); pass 2 walks the reversed list through windows that extend upwards.
       int a = -1, h = trimha;
+      lane_batch LB; LB.val = 0; LB.key = 0; LB.n = 0;
       while (h >= 0)
         { const int bq = cw_get<-1>(W,h).x;
-          if (l0)
-            ((GLB_PTR int *) (cells + h))[0] = a;
+          lb_push(LB,(uint32_t) a,(uint32_t) h);
+          if (LB.n == 64)
+            lb_flush_cells(LB,cells);
           a = h;
           h = bq;
         }
+      lb_flush_cells(LB,cells);
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST,"workgroup");       // the reversed pointers are visible to pass 2
       __builtin_amdgcn_s_waitcnt(0);
       W.base = -1000;
@@ -573,19 +611,24 @@ __device__ __attribute__((noinline)) void ext_unwind(const ext_args &G, int4 *ce
           e = d;
         }
       if (h >= 0)
-        { for (h = c4.x; h >= 0; h = c4.x)
+        { GLB_PTR uint32_t *at32 = (GLB_PTR uint32_t *) at;    // tpos is even
+          int ptop = 0;
+          for (h = c4.x; h >= 0; h = c4.x)
             { c4 = cw_get<+1>(W,h);
               k = c4.y;
               aa = c4.w - k;
               d = c4.z;
               atlen -= 2;
-              if (l0)
-                { at[atlen+1] = (uint16_t) (b-aa);
-                  at[atlen]   = (uint16_t) (d-e);
-                }
+              if (LB.n == 0)
+                ptop = atlen >> 1;
+              lb_push(LB,((uint32_t) (d-e) & 0xffffu) | ((uint32_t) (b-aa) << 16),0u);
+              if (LB.n == 64)
+                lb_flush_desc(LB,at32,ptop);
               b = aa;
               e = d;
             }
+          lb_flush_desc(LB,at32,ptop);
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST,"workgroup");
           if (b+k != trimx)
             { atlen -= 2;
               if (l0)
