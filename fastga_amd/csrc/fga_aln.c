@@ -17,6 +17,7 @@
 #include <string.h>
 #include <time.h>
 #include <unistd.h>
+#include <pthread.h>
 
 #include "fga_host.h"
 #include "fastga_amd.h"
@@ -91,6 +92,69 @@ static void write_skeleton(FILE *f, const fga_gdb *G)
       if (G->scaffolds[s].slen > spos)
         fprintf(f,"G %lld\n",(long long) (G->scaffolds[s].slen - spos));
     }
+}
+
+typedef struct
+  { const fga_alns *A;
+    int64_t i0, i1;
+    char   *buf;
+    size_t  len;
+    int     fail;
+  } fmt_job;
+
+#define PUT_INT(v)                                                     \
+    { unsigned _u; int _n = 0; char _t[12]; int _v = (v);              \
+      if (_v < 0) { buf[len++] = '-'; _u = (unsigned) (-(long long) _v); } else _u = (unsigned) _v; \
+      do { _t[_n++] = (char) ('0' + _u % 10); _u /= 10; } while (_u);  \
+      while (_n) buf[len++] = _t[--_n];                                \
+    }
+
+/* A / R / D / T / X lines of records [i0,i1) */
+static void *fmt_thread(void *arg)
+{ fmt_job *J = arg;
+  const fga_alns *A = J->A;
+  int64_t i;
+  size_t cap = 64, len = 0;
+  char *buf;
+  for (i = J->i0; i < J->i1; i++)
+    cap += 160 + 4*(size_t) A->alns[i].tlen;        /* <= 4 chars per trace byte incl. the separator */
+  buf = malloc(cap);
+  if (buf == NULL)
+    { J->fail = 1;
+      return NULL;
+    }
+  for (i = J->i0; i < J->i1; i++)
+    { const fga_aln *a = A->alns+i;
+      const uint8_t *tr = A->tbytes + a->toff;
+      int x, q;
+      int fld[6];
+      fld[0] = a->aread; fld[1] = a->abpos; fld[2] = a->aepos; fld[3] = a->bread; fld[4] = a->bbpos; fld[5] = a->bepos;
+      buf[len++] = 'A';
+      for (q = 0; q < 6; q++)
+        { buf[len++] = ' ';
+          PUT_INT(fld[q])
+        }
+      buf[len++] = '\n';
+      if (a->flags & 1)
+        { buf[len++] = 'R'; buf[len++] = '\n'; }
+      buf[len++] = 'D'; buf[len++] = ' ';
+      PUT_INT(a->diffs)
+      buf[len++] = '\n';
+      for (q = 1; q >= 0; q--)
+        { buf[len++] = q ? 'T' : 'X'; buf[len++] = ' ';
+          PUT_INT(a->tlen/2)
+          for (x = q; x < a->tlen; x += 2)
+            { unsigned v = tr[x];
+              buf[len++] = ' ';
+              if (v >= 100) { buf[len++] = (char) ('0' + v/100); v %= 100; buf[len++] = (char) ('0' + v/10); buf[len++] = (char) ('0' + v%10); }
+              else if (v >= 10) { buf[len++] = (char) ('0' + v/10); buf[len++] = (char) ('0' + v%10); }
+              else buf[len++] = (char) ('0' + v);
+            }
+          buf[len++] = '\n';
+        }
+    }
+  J->buf = buf; J->len = len;
+  return NULL;
 }
 
 int fga_write_1aln(const char *path, const fga_gdb *g1, const fga_gdb *g2, const fga_alns *A, int tspace,
@@ -174,62 +238,42 @@ int fga_write_1aln(const char *path, const fga_gdb *g1, const fga_gdb *g2, const
   if (g2 != NULL)
     write_skeleton(f,g2);
 
-  { /* the record body dominates the file: format it by hand into a large buffer */
-    size_t cap = (size_t) 1 << 22, len = 0;
-    char *buf = malloc(cap + 65536);
-    if (buf == NULL)
-      { fga_set_error("out of memory");
-        fclose(f);
-        free(obuf);
-        return 1;
+  { /* the record body dominates the file: records are formatted by hand, in parallel (contiguous record ranges
+       into per-thread buffers sized from the trace lengths), and written in order */
+    int nth = 8, t;
+    fmt_job  job[8];
+    pthread_t th[8];
+    long nc = sysconf(_SC_NPROCESSORS_ONLN);
+    if (nc > 0 && nc < nth) nth = (int) nc;
+    if (totT < 200000) nth = 1;
+    for (t = 0; t < nth; t++)
+      { job[t].A = A;
+        job[t].i0 = (A->naln*t)/nth; job[t].i1 = (A->naln*(t+1))/nth;
+        job[t].buf = NULL; job[t].len = 0; job[t].fail = 0;
       }
-#define PUT_INT(v)                                                     \
-    { unsigned _u; int _n = 0; char _t[12]; int _v = (v);              \
-      if (_v < 0) { buf[len++] = '-'; _u = (unsigned) (-(long long) _v); } else _u = (unsigned) _v; \
-      do { _t[_n++] = (char) ('0' + _u % 10); _u /= 10; } while (_u);  \
-      while (_n) buf[len++] = _t[--_n];                                \
-    }
-    for (i = 0; i < A->naln; i++)
-      { const fga_aln *a = A->alns+i;
-        const uint8_t *tr = A->tbytes + a->toff;
-        int x, q;
-        int fld[6];
-        fld[0] = a->aread; fld[1] = a->abpos; fld[2] = a->aepos; fld[3] = a->bread; fld[4] = a->bbpos; fld[5] = a->bepos;
-        buf[len++] = 'A';
-        for (q = 0; q < 6; q++)
-          { buf[len++] = ' ';
-            PUT_INT(fld[q])
-          }
-        buf[len++] = '\n';
-        if (a->flags & 1)
-          { buf[len++] = 'R'; buf[len++] = '\n'; }
-        buf[len++] = 'D'; buf[len++] = ' ';
-        PUT_INT(a->diffs)
-        buf[len++] = '\n';
-        for (q = 1; q >= 0; q--)
-          { buf[len++] = q ? 'T' : 'X'; buf[len++] = ' ';
-            PUT_INT(a->tlen/2)
-            for (x = q; x < a->tlen; x += 2)
-              { unsigned v = tr[x];
-                buf[len++] = ' ';
-                if (v >= 100) { buf[len++] = (char) ('0' + v/100); v %= 100; buf[len++] = (char) ('0' + v/10); buf[len++] = (char) ('0' + v%10); }
-                else if (v >= 10) { buf[len++] = (char) ('0' + v/10); buf[len++] = (char) ('0' + v%10); }
-                else buf[len++] = (char) ('0' + v);
-                if (len >= cap)
-                  { fwrite(buf,1,len,f);
-                    len = 0;
-                  }
-              }
-            buf[len++] = '\n';
-          }
-        if (len >= cap)
-          { fwrite(buf,1,len,f);
-            len = 0;
+    for (t = 1; t < nth; t++)
+      if (pthread_create(th+t,NULL,fmt_thread,job+t) != 0)
+        { fmt_thread(job+t); th[t] = 0; }
+    fmt_thread(job);
+    for (t = 1; t < nth; t++)
+      if (th[t] != 0)
+        pthread_join(th[t],NULL);
+    for (t = 0; t < nth; t++)
+      { if (job[t].fail)
+          { int q;
+            for (q = 0; q < nth; q++) free(job[q].buf);
+            fga_set_error("out of memory");
+            fclose(f);
+            free(obuf);
+            return 1;
           }
       }
-    if (len > 0)
-      fwrite(buf,1,len,f);
-    free(buf);
+    fflush(f);
+    for (t = 0; t < nth; t++)
+      { if (job[t].len > 0)
+          fwrite(job[t].buf,1,job[t].len,f);
+        free(job[t].buf);
+      }
   }
   if (fclose(f) != 0)
     { fga_set_error("IO error writing %s",path);
