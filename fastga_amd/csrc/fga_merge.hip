@@ -44,6 +44,17 @@
 
 static_assert(TILE_COST <= 4*NT,"the owner max-scan handles 4 entries per thread");
 
+#ifdef MERGE_PROF      // per-phase cycle accounting of workgroup thread 0 (tools/merge_bench.py prints it)
+__device__ unsigned long long merge_prof[8];
+#define PROF_DECL  unsigned long long _pt = clock64(), _pa[8] = {0,0,0,0,0,0,0,0};
+#define PROF(k)    { unsigned long long _n = clock64(); _pa[k] += _n - _pt; _pt = _n; }
+#define PROF_END   if (threadIdx.x == 0) for (int _k = 0; _k < 8; _k++) atomicAdd(merge_prof+_k,_pa[_k]);
+#else
+#define PROF_DECL
+#define PROF(k)
+#define PROF_END
+#endif
+
 enum { MODE_PAIR = 0, MODE_FLIP = 1, MODE_SELF = 2 };
 
 struct merge_tile            // 32 bytes
@@ -383,6 +394,7 @@ void seed_merge_kernel(merge_args A)
     stage_n = 0;
   unsigned long long tsum = 0;
   __syncthreads();
+  PROF_DECL
 
   const int E1 = A.E1, E2 = A.E2;
   const int freq = A.freq;
@@ -437,6 +449,7 @@ void seed_merge_kernel(merge_args A)
           o2[x] = make_uint2(0,0);
       }
       __syncthreads();
+      PROF(0)
 
       const uint32_t *rawd = (const uint32_t *) raw;
       const uint32_t o1 = (uint32_t) (s1 - s1a);
@@ -451,6 +464,7 @@ void seed_merge_kernel(merge_args A)
       for (int j = tid; j < n2; j += NT)
         keyB[j] = lds_read_key(rawd,o2 + (uint32_t) j*E2);
       __syncthreads();
+      PROF(1)
 
       // 3. owner[i] = max head at or before i (block max-scan, 4 consecutive entries per thread)
       { uint2 v = ((uint2 *) own)[tid];
@@ -480,6 +494,7 @@ void seed_merge_kernel(merge_args A)
         __syncthreads();
       }
 
+      PROF(2)
       // 4. match phase: T1 entries tid, tid+NT, ...; results packed in registers
       int      r_low[EPT], r_cnt[EPT], r_plen[EPT];
       int      total = 0;
@@ -553,10 +568,12 @@ void seed_merge_kernel(merge_args A)
           tsum  += (unsigned long long) cnt * plen;
         }
 
+      PROF(3)
       // 5. emit phase
       bool any, direct;
       int64_t at;
       block_slots(A,S,total,any,direct,at);
+      PROF(4)
       if (any)
         { if (total > 0)
             { const int mfull = A.soft_mask;
@@ -591,7 +608,9 @@ void seed_merge_kernel(merge_args A)
             }
         }
       __syncthreads();     // tile buffers and the stage are reused by the next tile
+      PROF(5)
     }
+  PROF_END
 
   __syncthreads();
   stage_flush(A,S);
@@ -727,6 +746,15 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
         { hipFree(counters); fga_dev_release(dev,SLOT_SEEDS,S->seeds); free(S); }
       return 1;
     }
+#ifdef MERGE_PROF
+  { unsigned long long hp[8], z[8] = {0,0,0,0,0,0,0,0};
+    hipMemcpyFromSymbol(hp,HIP_SYMBOL(merge_prof),sizeof(hp));
+    hipMemcpyToSymbol(HIP_SYMBOL(merge_prof),z,sizeof(z));
+    double tot = 0; for (int k = 0; k < 6; k++) tot += (double) hp[k];
+    fprintf(stderr,"merge phases (%% of WG cycles): load %.1f  heads+keys %.1f  owner-scan %.1f  match %.1f  slots %.1f  emit %.1f\n",
+            100*hp[0]/tot,100*hp[1]/tot,100*hp[2]/tot,100*hp[3]/tot,100*hp[4]/tot,100*hp[5]/tot);
+  }
+#endif
   hipEventElapsedTime(&dev->last_ms[FGA_STAGE_MERGE_PARTITION],dev->ev0,dev->ev1);
   hipEventElapsedTime(&dev->last_ms[FGA_STAGE_MERGE],dev->ev1,ev2);
   hipEventDestroy(ev2);
