@@ -100,7 +100,7 @@ static int write_skeleton_file(const fga_gdb *gdb, const char *path, const char 
                                const char *command)
 { FILE *f;
   int   s, c;
-  int64_t ngap, maxs, tots;
+  int64_t ngap, maxs, tots, maxc, maxg;
   char  date[64];
   time_t t = time(NULL);
 
@@ -114,18 +114,23 @@ static int write_skeleton_file(const fga_gdb *gdb, const char *path, const char 
   ngap = 0;
   maxs = 0;
   tots = 0;
+  maxc = maxg = 0;
   for (s = 0; s < gdb->nscaff; s++)
-    { int64_t spos = 0;
+    { int64_t spos = 0, sg = 0;
       int64_t hl = strlen(gdb->headers + gdb->scaffolds[s].hoff);
       if (hl > maxs) maxs = hl;
       tots += hl;
       for (c = gdb->scaffolds[s].fctg; c < gdb->scaffolds[s].ectg; c++)
         { if (gdb->contigs[c].sbeg > spos)
-            ngap += 1;
+            sg += 1;
           spos = gdb->contigs[c].sbeg + gdb->contigs[c].clen;
         }
       if (gdb->scaffolds[s].slen > spos)
-        ngap += 1;
+        sg += 1;
+      ngap += sg;
+      if (sg > maxg) maxg = sg;
+      if (gdb->scaffolds[s].ectg - gdb->scaffolds[s].fctg > maxc)
+        maxc = gdb->scaffolds[s].ectg - gdb->scaffolds[s].fctg;
     }
 
   fprintf(f,"1 3 gdb 2 1\n");
@@ -140,8 +145,11 @@ static int write_skeleton_file(const fga_gdb *gdb, const char *path, const char 
   fprintf(f,"# S %d\n",gdb->nscaff);
   fprintf(f,"@ S %lld\n",(long long) maxs);
   fprintf(f,"+ S %lld\n",(long long) tots);
+  fprintf(f,"%% S # C %lld\n",(long long) maxc);          /* per-scaffold maxima, as ONElib accumulates them */
   if (ngap > 0)
-    fprintf(f,"# G %lld\n",(long long) ngap);
+    { fprintf(f,"%% S # G %lld\n",(long long) maxg);
+      fprintf(f,"# G %lld\n",(long long) ngap);
+    }
   fprintf(f,"# C %d\n",gdb->ncontig);
   fprintf(f,".\n");
   fprintf(f,"f %f %f %f %f\n",gdb->freq[0],gdb->freq[1],gdb->freq[2],gdb->freq[3]);
@@ -244,8 +252,8 @@ int fga_fasta_to_gdb(const char *fasta, const char *target, int ncut)
     mctg[nmask] = G.ncontig; mbeg[nmask] = (b_); mend[nmask] = (e_); nmask += 1;  \
   }
 
-#define END_CONTIG()                                                              \
-  { if (clen > 0)                                                                 \
+#define END_CONTIG(force)                                                         \
+  { if (clen > 0 || (force))                                                      \
       { if (mrun >= 0) { PUSH_MASK(mrun,clen) mrun = -1; }                        \
         if (m > 0) { if (bv_push(&bps,byte)) goto oom; }                          \
         byte = 0; m = 0;                                                          \
@@ -268,8 +276,12 @@ int fga_fasta_to_gdb(const char *fasta, const char *target, int ncut)
 
 #define END_SCAFFOLD()                                                            \
   { if (inscaf)                                                                   \
-      { END_CONTIG();                                                             \
-        spos += nin; nin = 0;                                                     \
+      { END_CONTIG(0);                                                            \
+        nin = 0;                        /* N's that end a scaffold are not recorded (GDB.c:856-859, 947-950) */ \
+        if (spos == 0)                                                            \
+          { fga_set_error("missing sequence entry for scaffold %d of %s",G.nscaff,fasta); \
+            goto fail;                                                            \
+          }                                                                       \
         G.scaffolds[G.nscaff-1].ectg = G.ncontig;                                 \
         G.scaffolds[G.nscaff-1].slen = spos;                                      \
       }                                                                           \
@@ -325,7 +337,7 @@ int fga_fasta_to_gdb(const char *fasta, const char *target, int ncut)
                 continue;
               }
             if (nin > 0)
-              { if (nin < ncut && clen > 0)      /* short run inside a contig: keep as 'a' */
+              { if (nin < ncut)                  /* short run: kept as a's (GDB.c:880-896) */
                   { int64_t k;
                     for (k = 0; k < nin; k++)
                       { if (m == 6) { if (bv_push(&bps,byte)) goto oom; byte = 0; m = 0; }
@@ -334,8 +346,8 @@ int fga_fasta_to_gdb(const char *fasta, const char *target, int ncut)
                     clen += nin;
                     count[0] += nin;
                   }
-                else
-                  { END_CONTIG();
+                else                             /* a run at the scaffold start leaves a zero-length contig */
+                  { END_CONTIG(1);
                     spos += nin;
                   }
                 nin = 0;

@@ -220,6 +220,9 @@ typedef struct
     int            use_mask;   /* fill the soft-mask byte from gdb->mbeg/mend             */
     int           *next;       /* shared work counter over contigs                       */
     int64_t        nfwd, ncmp;
+    int64_t       *sbuck;      /* [1024] shared: 5-base bucket counts of EVERY syncmer, both strands, whether or not
+                                  its 40-mer fits the contig -- the reference sizes its table parts from this
+                                  sample (sample_thread, GIXmake.c:163-327), not from the final table           */
   } scan_arg;
 
 static inline uint8_t comp4(uint8_t x)     /* reverse complement of a packed 4-mer */
@@ -271,6 +274,16 @@ static void scan_contig(scan_arg *A, int c)
           if (v8[j+q] < m) m = v8[j+q];
         if (v8[j] != m && v8[j+4] != m)
           continue;
+        if (A->pass == 0)
+          { uint32_t f5 = 0, c5 = 0;
+            int k;
+            for (k = 0; k < 5; k++)
+              { f5 = (f5<<2) | s[j+k];
+                c5 = (c5<<2) | (uint32_t) (3 - s[j+11-k]);
+              }
+            __atomic_fetch_add(A->sbuck+f5,1,__ATOMIC_RELAXED);
+            __atomic_fetch_add(A->sbuck+c5,1,__ATOMIC_RELAXED);
+          }
         uint8_t pbg = 0;
         if (mi < mtop)
           { while (mi < mtop && j >= G->mend[mi])
@@ -418,6 +431,7 @@ int fga_gix_build_masked(const fga_gdb *G, const char *target, int nthreads, int
   int64_t *clen = NULL;
   int     *perm = NULL, *invp = NULL;
   int      postbytes, contbytes, ebytes, nparts;
+  int64_t  sbuck[1024];
   uint32_t *count = NULL;
   int64_t  *index = NULL, *cursor = NULL;
   krec     *recs = NULL;
@@ -492,6 +506,7 @@ int fga_gix_build_masked(const fga_gdb *G, const char *target, int nthreads, int
   if (count == NULL || index == NULL || cursor == NULL || th == NULL) goto oom;
 
   /* pass 0: count entries per 12-mer prefix; pass 1: scatter */
+  memset(sbuck,0,sizeof(sbuck));
   { scan_arg *args = calloc(nthreads,sizeof(scan_arg));
     int pass, next;
     if (args == NULL) goto oom;
@@ -503,6 +518,7 @@ int fga_gix_build_masked(const fga_gdb *G, const char *target, int nthreads, int
             args[i].pass = pass; args[i].count = count; args[i].cursor = cursor; args[i].recs = recs;
             args[i].use_mask = use_mask;
             args[i].next = &next; args[i].nfwd = args[i].ncmp = 0;
+            args[i].sbuck = sbuck;
           }
         for (i = 1; i < nthreads; i++)
           pthread_create(th+i,NULL,scan_thread,args+i);
@@ -556,8 +572,9 @@ int fga_gix_build_masked(const fga_gdb *G, const char *target, int nthreads, int
     int     n, b, part;
     int64_t t;
 
-    for (b = 0; b < 1024; b++)
-      buck[b] = index[((b+1)<<14)-1];
+    buck[0] = sbuck[0];                                /* cumulative sample histogram */
+    for (b = 1; b < 1024; b++)
+      buck[b] = buck[b-1] + sbuck[b];
     ksplit[0] = 0;
     n = 1;
     t = buck[1023]/nparts;

@@ -8,7 +8,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _compare(ra, rb, workdir, strict_order=True, **kw):
+def _compare(ra, rb, workdir, strict_order=True, allow_empty=False, **kw):
     from fastga_amd import device as D
     from oracle import harness as H
     if not H.have_reference():
@@ -27,7 +27,7 @@ def _compare(ra, rb, workdir, strict_order=True, **kw):
     H.ref_fastga(ra, rb, workdir, os.path.join(workdir, "ref"), threads=8, flags=flags)
     a = H.oneview(ours)
     b = H.oneview(os.path.join(workdir, "ref.1aln"))
-    assert st["nlive"] > 0
+    assert allow_empty or st["nlive"] > 0
     assert len(a) == len(b), (len(a), len(b), st)
     if strict_order:
         for x, y in zip(a, b):
@@ -47,7 +47,7 @@ def _compare(ra, rb, workdir, strict_order=True, **kw):
 
 
 def _split_records(lines):
-    first = next(i for i, ln in enumerate(lines) if ln.startswith("A "))
+    first = next((i for i, ln in enumerate(lines) if ln.startswith("A ")), len(lines))
     recs, cur = [], []
     for ln in lines[first:]:
         if ln.startswith("A ") and cur:
