@@ -1,15 +1,27 @@
-/* fga_aln.c -- .1aln writer (ASCII ONEcode).
+/* fga_aln.c -- .1aln writers (binary and ASCII ONEcode).
  *
  * Replaces open_Aln_Write / Write_Aln_Overlap / Write_Aln_Trace (reference alncode.c:239-305) and Write_Skeleton
  * (GDB.c:2065-2092) as used by la_merge (FastGA.c:4049-4113).  The reference writes the *binary* ONEcode form
- * through its vendored ONElib; this writer emits the equivalent *ASCII* ONEcode file (same schema alncode.c:19-52,
- * same line content and order), which the reference's own readers (ONEview, ALNshow, ONEaln) accept and which
- * `ONEview` prints identically apart from the '!' provenance and '<' path lines.  An ASCII
- * file must embed its schema ('~' lines) and its count lines ('#', '@', '+', '%') ahead of the data, so the
- * statistics are accumulated first and the body is written second.
+ * through its vendored ONElib; fga_write_1aln_binary emits that container natively (same schema alncode.c:19-52,
+ * same line content and order), so the reference's seeking readers (ALNtoPAF, ALNshow, ...: oneGoto needs the object
+ * index of the binary footer) take the file as they take their own.  fga_write_1aln writes the equivalent ASCII
+ * ONEcode file, which `ONEview` prints identically apart from the '!' provenance and '<' path lines.
  *   body:  t <tspace> / g + skeleton of genome 1 / g + skeleton of genome 2 (not for self) /
  *          per alignment: A aread abpos aepos bread bbpos bepos / R (complement) / D diffs /
  *                         T n b-deltas (odd trace bytes) / X n diffs (even trace bytes)
+ * An ASCII file must embed its schema ('~' lines) and its count lines ('#', '@', '+', '%') ahead of the data, so the
+ * statistics are accumulated first and the body is written second; a binary file carries them in its footer.
+ *
+ * Binary ONEcode as written here (the container format of ONElib.c, restated):
+ *   ASCII header: "1 3 aln 2 1", '!' provenance, '<' references, the '~' schema lines, "$ 0" (little endian)
+ *   data lines:   1 type byte 0x80 | k << 1  (k = letter index: 'A'..'Z' 0..25, 'a'..'z' 26..51; bit 0 = list codec
+ *                 in use, never set here), then the fields: INT and list lengths as variable-length "ltf" integers
+ *                 (0..63 in one byte 0x40|v, up to 8191 in two bytes 0x20|hi,lo, else a byte count n-1 and the n low
+ *                 bytes), STRING bytes raw, INT_LIST as ltf(first), one byte w, then the successive differences in w
+ *                 bytes each (w = the smallest signed width that holds every difference)
+ *   '\n' end of data; footer: per line type in schema order its ASCII count lines ('#' count, '@' max list, '+' list
+ *                 total, '%' per-object maxima) and, for object types (g, S, A), a binary '&' line holding the byte
+ *                 offset of the data start and of every object; "^\n"; the footer's own offset as 8 raw bytes.
  */
 #define _GNU_SOURCE
 #include <stdio.h>
@@ -282,4 +294,313 @@ int fga_write_1aln(const char *path, const fga_gdb *g1, const fga_gdb *g2, const
     }
   free(obuf);
   return 0;
+}
+
+
+/* ------------------------------------------------------------------------------------------------------------
+ * binary ONEcode
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct { uint8_t *p; size_t len, cap; int fail; } bbuf;
+
+static void bb_need(bbuf *B, size_t n)
+{ if (B->len + n > B->cap)
+    { size_t nc = B->cap*2 + n + 4096;
+      uint8_t *q = realloc(B->p,nc);
+      if (q == NULL) { B->fail = 1; return; }
+      B->p = q; B->cap = nc;
+    }
+}
+
+static inline int ltf_put(uint8_t *u, int64_t val)        /* ONElib's integer packing (intPut), <= 9 bytes */
+{ if (val >= 0)
+    { if (val < 0x40)   { u[0] = (uint8_t) (val | 0x40); return 1; }
+      if (val < 0x2000) { u[0] = (uint8_t) ((val >> 8) | 0x20); u[1] = (uint8_t) (val & 0xff); return 2; }
+      { int n = 2; uint64_t v = (uint64_t) val;
+        while (n < 8 && (v >> (8*n)) != 0) n += 1;
+        u[0] = (uint8_t) (n-1);
+        memcpy(u+1,&v,8);
+        return n+1;
+      }
+    }
+  if (val >= -0x40) { u[0] = (uint8_t) (val | 0x40); return 1; }
+  { int n = 2; uint64_t v = (uint64_t) val;
+    while (n < 8 && (~v >> (8*n)) != 0) n += 1;
+    u[0] = (uint8_t) (0x80 | (n-1));
+    memcpy(u+1,&v,8);
+    return n+1;
+  }
+}
+
+#define TYPE_BYTE(t) ((uint8_t) (0x80 | ((((t) >= 'a') ? 26 + ((t)-'a') : ((t)-'A')) << 1)))
+#define INDEX_BYTE   ((uint8_t) (0x80 | (53 << 1)))                  /* '&' */
+
+static void bb_type(bbuf *B, char t)
+{ bb_need(B,1); if (B->fail) return;
+  B->p[B->len++] = TYPE_BYTE(t);
+}
+static void bb_int(bbuf *B, int64_t v)
+{ bb_need(B,16); if (B->fail) return;
+  B->len += ltf_put(B->p+B->len,v);
+}
+static void bb_bytes(bbuf *B, const void *src, size_t n)
+{ bb_need(B,n); if (B->fail) return;
+  memcpy(B->p+B->len,src,n); B->len += n;
+}
+
+/* INT_LIST of n values v[0], v[stride], ...: length, first value, difference width, differences */
+static void bb_bytelist(bbuf *B, const uint8_t *v, int n, int stride)
+{ int i, w = 1;
+  bb_int(B,n);
+  if (n <= 0) return;
+  bb_int(B,v[0]);
+  if (n == 1) return;
+  for (i = 1; i < n; i++)
+    { int d = (int) v[i*stride] - (int) v[(i-1)*stride];
+      if (d >= 128 || d < -128) { w = 2; break; }
+    }
+  bb_need(B,1 + (size_t) (n-1)*w); if (B->fail) return;
+  B->p[B->len++] = (uint8_t) w;
+  for (i = 1; i < n; i++)
+    { int d = (int) v[i*stride] - (int) v[(i-1)*stride];
+      B->p[B->len++] = (uint8_t) (d & 0xff);
+      if (w == 2) B->p[B->len++] = (uint8_t) ((d >> 8) & 0xff);
+    }
+}
+
+/* the '&' index line of object type t: offsets[0..n] (n+1 >= 2 values) */
+static void bb_index(bbuf *B, char t, const int64_t *off, int64_t n)
+{ int64_t i; uint64_t mask = 0; int w;
+  bb_need(B,2); if (B->fail) return;
+  B->p[B->len++] = INDEX_BYTE;
+  B->p[B->len++] = (uint8_t) t;
+  bb_int(B,n+1);
+  bb_int(B,off[0]);
+  for (i = 1; i <= n; i++)
+    { int64_t d = off[i]-off[i-1];
+      mask |= (uint64_t) (d >= 0 ? d : -(d+1));
+    }
+  mask >>= 7;
+  for (w = 1; w < 8 && mask != 0; w++)
+    mask >>= 8;
+  bb_need(B,1 + (size_t) n*w); if (B->fail) return;
+  B->p[B->len++] = (uint8_t) w;
+  for (i = 1; i <= n; i++)
+    { int64_t d = off[i]-off[i-1];
+      memcpy(B->p+B->len,&d,w);            /* little endian: the w low bytes */
+      B->len += w;
+    }
+}
+
+static void bin_skeleton(bbuf *B, const fga_gdb *G, int64_t base, int64_t *goff, int64_t *ng, int64_t *soff, int64_t *ns)
+{ int s, c;
+  goff[++(*ng)] = base + (int64_t) B->len;
+  bb_type(B,'g');
+  for (s = 0; s < G->nscaff; s++)
+    { const char *head = G->headers + G->scaffolds[s].hoff;
+      int64_t spos = 0;
+      size_t hl = strlen(head);
+      soff[++(*ns)] = base + (int64_t) B->len;
+      bb_type(B,'S'); bb_int(B,(int64_t) hl); bb_bytes(B,head,hl);
+      for (c = G->scaffolds[s].fctg; c < G->scaffolds[s].ectg; c++)
+        { if (G->contigs[c].sbeg > spos)
+            { bb_type(B,'G'); bb_int(B,G->contigs[c].sbeg - spos); }
+          bb_type(B,'C'); bb_int(B,G->contigs[c].clen);
+          spos = G->contigs[c].sbeg + G->contigs[c].clen;
+        }
+      if (G->scaffolds[s].slen > spos)
+        { bb_type(B,'G'); bb_int(B,G->scaffolds[s].slen - spos); }
+    }
+}
+
+typedef struct
+  { const fga_alns *A;
+    int64_t i0, i1;
+    bbuf    B;
+    int64_t *rel;            /* start of record i relative to the job's buffer */
+  } bin_job;
+
+static void *bin_thread(void *arg)
+{ bin_job *J = arg;
+  const fga_alns *A = J->A;
+  int64_t i;
+  for (i = J->i0; i < J->i1 && !J->B.fail; i++)
+    { const fga_aln *a = A->alns+i;
+      const uint8_t *tr = A->tbytes + a->toff;
+      J->rel[i-J->i0] = (int64_t) J->B.len;
+      bb_type(&J->B,'A');
+      bb_int(&J->B,a->aread); bb_int(&J->B,a->abpos); bb_int(&J->B,a->aepos);
+      bb_int(&J->B,a->bread); bb_int(&J->B,a->bbpos); bb_int(&J->B,a->bepos);
+      if (a->flags & 1)
+        bb_type(&J->B,'R');
+      bb_type(&J->B,'D'); bb_int(&J->B,a->diffs);
+      bb_type(&J->B,'T'); bb_bytelist(&J->B,tr+1,a->tlen/2,2);
+      bb_type(&J->B,'X'); bb_bytelist(&J->B,tr,a->tlen/2,2);
+    }
+  return NULL;
+}
+
+int fga_write_1aln_binary(const char *path, const fga_gdb *g1, const fga_gdb *g2, const fga_alns *A, int tspace,
+                          const char *db1_name, const char *db2_name, const char *command_line)
+{ FILE *f;
+  skel_stats st;
+  int64_t i, nR = 0, maxT = 0, totT = 0;
+  int64_t *goff = NULL, *soff = NULL, *aoff = NULL, ng = 0, ns = 0;
+  int64_t base, nscaf;
+  char date[64], *cwd;
+  time_t t = time(NULL);
+  bbuf H, B, F;
+  int nth = 8, q, rc = 1;
+  bin_job job[8];
+  pthread_t th[8];
+
+  memset(&H,0,sizeof(H)); memset(&B,0,sizeof(B)); memset(&F,0,sizeof(F));
+  memset(job,0,sizeof(job));
+  memset(&st,0,sizeof(st));
+  skeleton_stats(g1,&st);
+  if (g2 != NULL)
+    skeleton_stats(g2,&st);
+  for (i = 0; i < A->naln; i++)
+    { int64_t tl = A->alns[i].tlen/2;
+      if (A->alns[i].flags & 1) nR += 1;
+      if (tl > maxT) maxT = tl;
+      totT += tl;
+    }
+  nscaf = g1->nscaff + (g2 != NULL ? g2->nscaff : 0);
+  goff = malloc(sizeof(int64_t)*4);
+  soff = malloc(sizeof(int64_t)*(nscaf+2));
+  aoff = malloc(sizeof(int64_t)*(A->naln+2));
+  if (goff == NULL || soff == NULL || aoff == NULL) goto oom;
+
+  /* ---- ASCII header ---- */
+  strftime(date,sizeof(date),"%Y-%m-%d_%H:%M:%S",localtime(&t));
+  cwd = getcwd(NULL,0);
+  { char *hdr = NULL;
+    int   n;
+    n = asprintf(&hdr,"1 3 aln 2 1\n! 4 6 FastGA 3 0.1 %d %s %d %s\n.\n< %d %s 1\n",
+                 (int) strlen(command_line),command_line,(int) strlen(date),date,(int) strlen(db1_name),db1_name);
+    if (n < 0) { free(cwd); goto oom; }
+    bb_bytes(&H,hdr,(size_t) n); free(hdr);
+    if (g2 != NULL && db2_name != NULL)
+      { n = asprintf(&hdr,"< %d %s 2\n",(int) strlen(db2_name),db2_name);
+        if (n < 0) { free(cwd); goto oom; }
+        bb_bytes(&H,hdr,(size_t) n); free(hdr);
+      }
+    if (cwd != NULL)
+      { n = asprintf(&hdr,"< %d %s 3\n",(int) strlen(cwd),cwd);
+        if (n < 0) { free(cwd); goto oom; }
+        bb_bytes(&H,hdr,(size_t) n); free(hdr);
+      }
+    free(cwd);
+    bb_bytes(&H,".\n",2);
+    bb_bytes(&H,ALN_SCHEMA_LINES,strlen(ALN_SCHEMA_LINES));
+    bb_bytes(&H,"$ 0\n",4);
+  }
+  if (H.fail) goto oom;
+  base = (int64_t) H.len;                       /* the data starts here: index[0] of every object type */
+  goff[0] = soff[0] = aoff[0] = base;
+
+  /* ---- data: t, skeletons, then the records (formatted in parallel) ---- */
+  bb_type(&B,'t'); bb_int(&B,tspace);
+  bin_skeleton(&B,g1,base,goff,&ng,soff,&ns);
+  if (g2 != NULL)
+    bin_skeleton(&B,g2,base,goff,&ng,soff,&ns);
+  if (B.fail) goto oom;
+
+  { long nc = sysconf(_SC_NPROCESSORS_ONLN);
+    if (nc > 0 && nc < nth) nth = (int) nc;
+    if (totT < 200000) nth = 1;
+  }
+  for (q = 0; q < nth; q++)
+    { job[q].A = A;
+      job[q].i0 = (A->naln*q)/nth; job[q].i1 = (A->naln*(q+1))/nth;
+      job[q].rel = malloc(sizeof(int64_t)*(job[q].i1-job[q].i0+1));
+      if (job[q].rel == NULL) goto oom;
+    }
+  for (q = 1; q < nth; q++)
+    if (pthread_create(th+q,NULL,bin_thread,job+q) != 0)
+      { bin_thread(job+q); th[q] = 0; }
+  bin_thread(job);
+  for (q = 1; q < nth; q++)
+    if (th[q] != 0)
+      pthread_join(th[q],NULL);
+  { int64_t pos = base + (int64_t) B.len;
+    for (q = 0; q < nth; q++)
+      { if (job[q].B.fail) goto oom;
+        for (i = job[q].i0; i < job[q].i1; i++)
+          aoff[i+1] = pos + job[q].rel[i-job[q].i0];
+        pos += (int64_t) job[q].B.len;
+      }
+  }
+
+  /* ---- footer: counts in schema order (t g S G C a A p L R D T X ...), '&' index lines of g, S, A ---- */
+#define FPRINT(...) { char *_s = NULL; int _n = asprintf(&_s,__VA_ARGS__); if (_n < 0) goto oom; bb_bytes(&F,_s,(size_t) _n); free(_s); }
+  FPRINT("# t 1\n")
+  FPRINT("# g %lld\n",(long long) ng)
+  FPRINT("%% g # C %lld\n",(long long) st.gC)
+  if (st.gG > 0) FPRINT("%% g # G %lld\n",(long long) st.gG)
+  FPRINT("%% g # S %lld\n",(long long) st.gS)
+  FPRINT("%% g + S %lld\n",(long long) st.gSt)
+  bb_index(&F,'g',goff,ng);
+  FPRINT("# S %lld\n",(long long) st.nS)
+  FPRINT("@ S %lld\n",(long long) st.maxS)
+  FPRINT("+ S %lld\n",(long long) st.totS)
+  FPRINT("%% S # C %lld\n",(long long) st.sC)
+  if (st.sG > 0) FPRINT("%% S # G %lld\n",(long long) st.sG)
+  bb_index(&F,'S',soff,ns);
+  if (st.nG > 0) FPRINT("# G %lld\n",(long long) st.nG)
+  FPRINT("# C %lld\n",(long long) st.nC)
+  if (A->naln > 0)
+    { FPRINT("# A %lld\n",(long long) A->naln)
+      FPRINT("%% A # D 1\n")
+      if (nR > 0) FPRINT("%% A # R 1\n")
+      FPRINT("%% A # T 1\n")
+      if (maxT > 0) FPRINT("%% A + T %lld\n",(long long) maxT)
+      FPRINT("%% A # X 1\n")
+      if (maxT > 0) FPRINT("%% A + X %lld\n",(long long) maxT)
+      bb_index(&F,'A',aoff,A->naln);
+      if (nR > 0) FPRINT("# R %lld\n",(long long) nR)
+      FPRINT("# D %lld\n",(long long) A->naln)
+      FPRINT("# T %lld\n",(long long) A->naln)
+      if (maxT > 0) FPRINT("@ T %lld\n",(long long) maxT)
+      if (totT > 0) FPRINT("+ T %lld\n",(long long) totT)
+      FPRINT("# X %lld\n",(long long) A->naln)
+      if (maxT > 0) FPRINT("@ X %lld\n",(long long) maxT)
+      if (totT > 0) FPRINT("+ X %lld\n",(long long) totT)
+    }
+  FPRINT("^\n")
+#undef FPRINT
+  if (F.fail) goto oom;
+
+  f = fopen(path,"w");
+  if (f == NULL)
+    { fga_set_error("cannot open %s for writing",path);
+      goto done;
+    }
+  { int64_t foot = base + (int64_t) B.len + 1;       /* + the end-of-data '\n' */
+    int ok = 1;
+    ok &= fwrite(H.p,1,H.len,f) == H.len;
+    ok &= fwrite(B.p,1,B.len,f) == B.len;
+    for (q = 0; q < nth; q++)
+      { if (job[q].B.len > 0)
+          ok &= fwrite(job[q].B.p,1,job[q].B.len,f) == job[q].B.len;
+        foot += (int64_t) job[q].B.len;
+      }
+    ok &= fputc('\n',f) != EOF;
+    ok &= fwrite(F.p,1,F.len,f) == F.len;
+    ok &= fwrite(&foot,sizeof(int64_t),1,f) == 1;
+    if (fclose(f) != 0 || !ok)
+      { fga_set_error("IO error writing %s",path);
+        goto done;
+      }
+  }
+  rc = 0;
+  goto done;
+
+oom:
+  fga_set_error("out of memory");
+done:
+  for (q = 0; q < 8; q++) { free(job[q].B.p); free(job[q].rel); }
+  free(H.p); free(B.p); free(F.p);
+  free(goff); free(soff); free(aoff);
+  return rc;
 }

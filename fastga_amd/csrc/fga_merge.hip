@@ -30,7 +30,9 @@
 
 #include "fga_device.hpp"
 
+#ifndef NT
 #define NT              256                  // threads per workgroup
+#endif
 #define NWAVE           (NT/64)
 #ifndef TILE_COST
 #define TILE_COST       1024                 // cost units per tile
@@ -374,8 +376,14 @@ __device__ void global_tile(const merge_args &A, const stage_t &S, int p0, int p
 // ---------------------------------------------------------------------------------------------------
 // the merge kernel
 // ---------------------------------------------------------------------------------------------------
+#ifdef MERGE_WAVES_PER_EU          // occupancy experiments: cap the VGPR budget so that this many waves fit a SIMD
+#define MERGE_OCC __attribute__((amdgpu_waves_per_eu(MERGE_WAVES_PER_EU,MERGE_WAVES_PER_EU)))
+#else
+#define MERGE_OCC
+#endif
+
 template <int MODE>
-__global__ __launch_bounds__(NT)
+__global__ __launch_bounds__(NT) MERGE_OCC
 void seed_merge_kernel(merge_args A)
 { __shared__ uint32_t la[PCAP+1];            // la[q] = #T1 entries of the tile in prefixes <= p0+q
   __shared__ uint32_t lb[PCAP+1];

@@ -146,6 +146,7 @@ def _declare(L):
         "fga_seed_merge_append": (i32, [vp, vp, vp, P(MergeParams), vp]),
         "fga_filter_alignments": (i32, [P(Alns), P(P(Alns))]),
         "fga_write_1aln": (i32, [cp, vp, vp, P(Alns), i32, cp, cp, cp]),
+        "fga_write_1aln_binary": (i32, [cp, vp, vp, P(Alns), i32, cp, cp, cp]),
         "fga_run": (i32, [cp, cp, P(RunParams), P(RunStats)]),
         "fga_session_open": (i32, [cp, cp, i32, P(vp)]),
         "fga_session_run": (i32, [vp, P(RunParams), P(RunStats)]),

@@ -199,6 +199,10 @@ int  fga_seed_merge_append(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
 int  fga_filter_alignments(const fga_alns *in, fga_alns **out);
 int  fga_write_1aln(const char *path, const fga_gdb *g1, const fga_gdb *g2 /* NULL: self */, const fga_alns *alns,
                     int tspace, const char *db1_name, const char *db2_name, const char *command_line);
+/* the same content in the binary ONEcode container the reference writes (object index in the footer, so the
+ * reference's seeking readers -- ALNtoPAF, ALNshow -- accept it); fga_write_1aln is the ASCII form */
+int  fga_write_1aln_binary(const char *path, const fga_gdb *g1, const fga_gdb *g2 /* NULL: self */, const fga_alns *alns,
+                           int tspace, const char *db1_name, const char *db2_name, const char *command_line);
 
 /* ---- the whole hot path: what `FastGA -1:<out> <root1> [<root2>]` does between "GIX present" and ".1aln closed" */
 typedef struct

@@ -1,0 +1,82 @@
+"""The .1aln writers (host C, no GPU needed): a reference-produced .1aln is parsed from its ONEview text, written
+again by fga_write_1aln_binary / fga_write_1aln, and the reference's own tools must see the same file:
+ONEview text identical (minus provenance/path lines), and ALNtoPAF -- which seeks through the binary object index
+(oneGoto) -- prints the same PAF, plain and with -x (re-alignment between trace points through the GDB)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import harness as H
+
+needs_ref = pytest.mark.skipif(not H.have_reference(), reason="oracle/_ref (real reference build) not present")
+
+
+def _parse_records(lines):
+    """A/R/D/T/X lines of ONEview text -> (ALN_DTYPE array, trace bytes) in the interleaved trace layout of fga_aln"""
+    from fastga_amd.device import ALN_DTYPE
+    recs, tb = [], []
+    cur = None
+    off = 0
+    for ln in lines:
+        t = ln[0]
+        f = ln.split()
+        if t == "A":
+            cur = dict(aread=int(f[1]), abpos=int(f[2]), aepos=int(f[3]), bread=int(f[4]), bbpos=int(f[5]),
+                       bepos=int(f[6]), flags=0, diffs=0, T=[], X=[])
+            recs.append(cur)
+        elif t == "R":
+            cur["flags"] = 1
+        elif t == "D":
+            cur["diffs"] = int(f[1])
+        elif t == "T":
+            cur["T"] = [int(x) for x in f[2:]]
+        elif t == "X":
+            cur["X"] = [int(x) for x in f[2:]]
+    arr = np.zeros(len(recs), dtype=ALN_DTYPE)
+    for i, r in enumerate(recs):
+        n = len(r["T"])
+        assert n == len(r["X"])
+        inter = np.empty(2 * n, dtype=np.uint8)
+        inter[0::2] = r["X"]
+        inter[1::2] = r["T"]
+        tb.append(inter)
+        arr[i] = (2 * n, r["diffs"], r["abpos"], r["bbpos"], r["aepos"], r["bepos"], r["flags"], r["aread"],
+                  r["bread"], -1, i, 0, off)
+        off += 2 * n
+    return arr, (np.concatenate(tb) if tb else np.zeros(0, np.uint8))
+
+
+@needs_ref
+@pytest.mark.parametrize("self_cmp", [False, True])
+def test_writers_round_trip_through_reference_tools(toy_pair, tmp_path, built_library, self_cmp):
+    from fastga_amd.lib import load_library, Alns
+    from fastga_amd.gixio import Gdb
+    d, ra, rb = toy_pair
+    w = str(tmp_path)
+    H.ref_fastga(ra, None if self_cmp else rb, w, os.path.join(w, "ref"), threads=4)
+    ref = os.path.join(w, "ref.1aln")
+    txt = H.oneview(ref)
+    alns, tb = _parse_records(txt)
+    assert len(alns) > 10
+    L = load_library()
+    g1 = Gdb(ra + ".gdb")
+    g2 = None if self_cmp else Gdb(rb + ".gdb")
+    A = Alns(len(alns), len(tb), 0, 0, alns.ctypes.data, tb.ctypes.data)
+    keep = lambda lines: [ln for ln in lines if ln[0] not in "!<"]          # noqa: E731
+    for name, fn in (("bin", L.fga_write_1aln_binary), ("txt", L.fga_write_1aln)):
+        out = os.path.join(w, name + ".1aln")
+        rc = fn(out.encode(), g1.h, g2.h if g2 is not None else None, C.byref(A), 100, (ra + ".gdb").encode(),
+                None if self_cmp else (rb + ".gdb").encode(), b"FastGA test")
+        assert rc == 0
+        assert keep(H.oneview(out)) == keep(txt), name
+    head = open(os.path.join(w, "bin.1aln"), "rb").read(4096)
+    assert b"\n$ 0\n" in head                                                # really the binary container
+    for flags in ((), ("-x",)):
+        a = H.run([H.ref_bin("ALNtoPAF"), "-T3", *flags, os.path.join(w, "bin.1aln")], cwd=w).stdout
+        b = H.run([H.ref_bin("ALNtoPAF"), "-T3", *flags, ref], cwd=w).stdout
+        assert len(a.splitlines()) == len(alns) and a == b, flags
+    g1.close()
+    if g2 is not None:
+        g2.close()

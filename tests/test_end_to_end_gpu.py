@@ -120,3 +120,21 @@ def test_soft_masked_pair_matches_reference(tmp_path, built_library):
     assert st["nseeds"] < plain["nseeds"]                 # the mask really removed seeds
     H.ref_fastga(ra, rb, d, os.path.join(d, "ref"), threads=8, flags=["-M"])
     assert H.oneview(ours) == H.oneview(os.path.join(d, "ref.1aln"))
+
+
+def test_reference_tools_accept_our_1aln(toy_pair, tmp_path):
+    """Drop-in at the tool level: the reference's own ALNtoPAF (plain and -x, which re-aligns between trace points
+    and so needs the bases through the GDB named in the file) prints the same PAF for our .1aln as for its own."""
+    from fastga_amd import device as D
+    from oracle import harness as H
+    if not H.have_reference():
+        pytest.skip("oracle/_ref did not travel")
+    d, ra, rb = toy_pair
+    w = str(tmp_path)
+    ours = os.path.join(w, "ours.1aln")
+    D.run(ra, rb, ours, nthreads=8)
+    H.ref_fastga(ra, rb, w, os.path.join(w, "ref"), threads=8)
+    for flags in ((), ("-x",)):
+        a = H.run([H.ref_bin("ALNtoPAF"), "-T4", *flags, ours], cwd=w).stdout.splitlines()
+        b = H.run([H.ref_bin("ALNtoPAF"), "-T4", *flags, os.path.join(w, "ref.1aln")], cwd=w).stdout.splitlines()
+        assert len(a) > 10 and a == b, flags
