@@ -452,8 +452,249 @@ done:
 }
 
 /* ------------------------------------------------------------------------------------------------
- *  Skeleton reader (ASCII ONEcode) + whole-image load of the .bps   (Read_GDB, GDB.c:1181-1410)
+ *  Skeleton reader (ASCII or binary ONEcode) + whole-image load of the .bps   (Read_GDB, GDB.c:1181-1410)
  * ------------------------------------------------------------------------------------------------ */
+
+typedef struct
+  { fga_gdb *G;
+    int      sctop, cttop;
+    int64_t  hdrcap, boff, spos;
+  } skel_ctx;
+
+/* one skeleton line: 'f' (r4), 'S' (str,len), 'G' / 'C' (ival), '<' (str,len); everything else is ignored
+ * (provenance, schema, counts, deprecated u and M lines) */
+static int skel_line(skel_ctx *X, char type, const char *str, int64_t len, int64_t ival, const double *r4)
+{ fga_gdb *G = X->G;
+  switch (type)
+  { case '<':
+      if (G->srcpath == NULL)
+        G->srcpath = strndup(str,(size_t) len);
+      break;
+    case 'f':
+      G->freq[0] = (float) r4[0]; G->freq[1] = (float) r4[1]; G->freq[2] = (float) r4[2]; G->freq[3] = (float) r4[3];
+      break;
+    case 'S':
+      if (G->nscaff > 0)
+        { G->scaffolds[G->nscaff-1].ectg = G->ncontig;
+          G->scaffolds[G->nscaff-1].slen = X->spos;
+        }
+      X->spos = 0;
+      if (G->nscaff >= X->sctop)
+        { X->sctop = (int) (1.2*G->nscaff) + 500;
+          G->scaffolds = realloc(G->scaffolds,sizeof(fga_scaffold)*X->sctop);
+        }
+      if (G->hdrtot + len + 1 > X->hdrcap)
+        { X->hdrcap = (int64_t) (1.2*(G->hdrtot+len+1)) + 10000;
+          G->headers = realloc(G->headers,X->hdrcap);
+        }
+      if (G->scaffolds == NULL || G->headers == NULL)
+        { fga_set_error("out of memory");
+          return 1;
+        }
+      G->scaffolds[G->nscaff].hoff = G->hdrtot;
+      G->scaffolds[G->nscaff].fctg = G->ncontig;
+      memcpy(G->headers+G->hdrtot,str,(size_t) len);
+      G->hdrtot += len;
+      G->headers[G->hdrtot++] = '\0';
+      G->nscaff += 1;
+      break;
+    case 'G':
+      X->spos += ival;
+      break;
+    case 'C':
+      if (G->nscaff == 0)
+        { fga_set_error("GDB skeleton: C line before any S line");
+          return 1;
+        }
+      if (G->ncontig >= X->cttop)
+        { X->cttop = (int) (1.2*G->ncontig) + 1000;
+          G->contigs = realloc(G->contigs,sizeof(fga_contig)*(X->cttop+1));
+          if (G->contigs == NULL)
+            { fga_set_error("out of memory");
+              return 1;
+            }
+        }
+      G->contigs[G->ncontig].boff = X->boff;
+      G->contigs[G->ncontig].sbeg = X->spos;
+      G->contigs[G->ncontig].clen = ival;
+      G->contigs[G->ncontig].scaf = G->nscaff-1;
+      G->ncontig += 1;
+      if (ival > G->maxctg) G->maxctg = ival;
+      G->seqtot += ival;
+      X->boff += (ival+3) >> 2;
+      X->spos += ival;
+      break;
+    default:
+      break;
+  }
+  return 0;
+}
+
+/* "<len> <text>" of an ASCII ONEcode string field */
+static int ascii_string(const char *p, const char **str, int64_t *len)
+{ int l = 0, used = 0;
+  if (sscanf(p," %d %n",&l,&used) < 1 || l < 0 || (int) strlen(p+used) < l)
+    return 1;
+  *str = p+used; *len = l;
+  return 0;
+}
+
+/* ---- binary ONEcode (the container ONElib writes; see fga_aln.c for the layout) ---- */
+enum { F_INT = 1, F_REAL, F_CHAR, F_STRING, F_INT_LIST, F_REAL_LIST, F_STRING_LIST, F_DNA };
+
+static int ltf_get(const uint8_t *u, const uint8_t *end, int64_t *val)   /* bytes used, 0 on overrun */
+{ int n;
+  uint64_t v = 0;
+  if (u >= end) return 0;
+  switch (u[0] >> 5)
+  { case 2: case 3: *val = u[0] & 0x3f; return 1;
+    case 6: case 7: *val = (int64_t) (int8_t) u[0]; return 1;
+    case 1: if (u+1 >= end) return 0;
+            *val = ((int64_t) (u[0] & 0x1f) << 8) | u[1]; return 2;
+    case 0: case 4:
+      n = (u[0] & 7) + 1;                         /* payload bytes */
+      if (n < 2 || u+n >= end) return 0;
+      memcpy(&v,u+1,(size_t) n);
+      if ((u[0] >> 5) == 4 && n < 8)              /* negative: sign extend */
+        v |= ~(uint64_t) 0 << (8*n);
+      *val = (int64_t) v;
+      return n+1;
+    default: return 0;
+  }
+}
+
+static int read_binary_skeleton(skel_ctx *X, const uint8_t *buf, size_t size, const char *spath)
+{ /* field lists per line type from the '~' schema lines of the header */
+  uint8_t nfld[128], fld[128][8];
+  const uint8_t *p = buf, *end = buf + size;
+  int seen_dollar = 0;
+  memset(nfld,0xff,sizeof(nfld));
+
+  while (p < end && !seen_dollar)                 /* ASCII header */
+    { const uint8_t *e = memchr(p,'\n',(size_t) (end-p));
+      size_t n = e ? (size_t) (e-p) : (size_t) (end-p);
+      char *ln = strndup((const char *) p,n);
+      if (ln == NULL) { fga_set_error("out of memory"); return 1; }
+      if (ln[0] == '~' && (ln[2] == 'O' || ln[2] == 'D') && n > 6)
+        { int t = (unsigned char) ln[4], k = 0, nf = 0, used = 0;
+          const char *q = ln+5;
+          if (sscanf(q," %d%n",&nf,&used) == 1 && nf <= 8 && t < 128)
+            { q += used;
+              for (k = 0; k < nf; k++)
+                { int l = 0; char name[32];
+                  if (sscanf(q," %d %31s%n",&l,name,&used) < 2) break;
+                  q += used;
+                  fld[t][k] = !strcmp(name,"INT") ? F_INT : !strcmp(name,"REAL") ? F_REAL : !strcmp(name,"CHAR") ? F_CHAR :
+                              !strcmp(name,"STRING") ? F_STRING : !strcmp(name,"INT_LIST") ? F_INT_LIST :
+                              !strcmp(name,"REAL_LIST") ? F_REAL_LIST : !strcmp(name,"DNA") ? F_DNA : F_STRING_LIST;
+                }
+              if (k == nf) nfld[t] = (uint8_t) nf;
+            }
+        }
+      else if (ln[0] == '<')
+        { const char *str; int64_t len;
+          if (ascii_string(ln+1,&str,&len) == 0 && skel_line(X,'<',str,len,0,NULL)) { free(ln); return 1; }
+        }
+      else if (ln[0] == '$')
+        { if (atoi(ln+1) != 0)
+            { fga_set_error("%s is a big-endian ONEcode file",spath);
+              free(ln);
+              return 1;
+            }
+          seen_dollar = 1;
+        }
+      free(ln);
+      p += n + (e ? 1 : 0);
+    }
+  if (!seen_dollar)
+    { fga_set_error("%s: binary ONEcode header has no $ line",spath);
+      return 1;
+    }
+
+  while (p < end && *p != '\n')                   /* data lines until the end-of-data marker */
+    { uint8_t x = *p++;
+      int k = (x & 0x7f) >> 1, t, i;
+      const char *str = NULL;
+      int64_t slen = 0, ival = 0;
+      double r4[4] = {0,0,0,0};
+      int nr = 0, first_int = 1;
+      if (!(x & 0x80) || k >= 52)
+        { fga_set_error("%s: unexpected byte 0x%02x in the binary data section",spath,x);
+          return 1;
+        }
+      t = k < 26 ? 'A'+k : 'a'+(k-26);
+      if (nfld[t] == 0xff)
+        { fga_set_error("%s: line type %c is not in the file's schema",spath,t);
+          return 1;
+        }
+      for (i = 0; i < nfld[t]; i++)
+        { int64_t v;
+          int u;
+          switch (fld[t][i])
+          { case F_INT:
+              if ((u = ltf_get(p,end,&v)) == 0) goto trunc;
+              p += u;
+              if (first_int) { ival = v; first_int = 0; }
+              break;
+            case F_REAL:
+              if (p+8 > end) goto trunc;
+              if (nr < 4) memcpy(r4+nr,p,8);
+              nr += 1; p += 8;
+              break;
+            case F_CHAR:
+              if (p+1 > end) goto trunc;
+              p += 1;
+              break;
+            default:                              /* a list: its length first */
+              if ((u = ltf_get(p,end,&v)) == 0 || v < 0) goto trunc;
+              p += u;
+              if ((x & 1) && v > 0)
+                { fga_set_error("%s holds codec-compressed %c lines; convert it with `ONEview %s > <root>.gdb`",
+                                spath,t,spath);
+                  return 1;
+                }
+              if (fld[t][i] == F_STRING)
+                { if (p+v > end) goto trunc;
+                  str = (const char *) p; slen = v; p += v;
+                }
+              else if (fld[t][i] == F_INT_LIST)
+                { int64_t f0;
+                  if (v > 0)
+                    { if ((u = ltf_get(p,end,&f0)) == 0) goto trunc;
+                      p += u;
+                      if (v > 1)
+                        { int w;
+                          if (p >= end) goto trunc;
+                          w = *p++;
+                          if (w < 1 || w > 8 || p + (v-1)*w > end) goto trunc;
+                          p += (v-1)*w;
+                        }
+                    }
+                }
+              else if (fld[t][i] == F_REAL_LIST)
+                { if (p + 8*v > end) goto trunc;
+                  p += 8*v;
+                }
+              else if (fld[t][i] == F_DNA)
+                { if (p + ((v+3)>>2) > end) goto trunc;
+                  p += (v+3)>>2;
+                }
+              else
+                { fga_set_error("%s: string-list lines are not supported",spath);
+                  return 1;
+                }
+              break;
+          }
+        }
+      if (skel_line(X,(char) t,str,slen,ival,r4))
+        return 1;
+    }
+  return 0;
+
+trunc:
+  fga_set_error("%s: truncated or malformed binary ONEcode line",spath);
+  return 1;
+}
 
 int fga_gdb_open(const char *path, fga_gdb **out)
 { fga_gdb *G;
@@ -462,9 +703,9 @@ int fga_gdb_open(const char *path, fga_gdb **out)
   char *line = NULL;
   size_t cap = 0;
   ssize_t n;
-  int sctop = 0, cttop = 0;
-  int64_t hdrcap = 0, boff, spos;
+  skel_ctx X;
   int first = 1;
+  int64_t boff;
 
   *out = NULL;
   G = calloc(1,sizeof(fga_gdb));
@@ -472,127 +713,112 @@ int fga_gdb_open(const char *path, fga_gdb **out)
     { fga_set_error("out of memory");
       return 1;
     }
+  memset(&X,0,sizeof(X));
+  X.G = G;
 
   noext = strip_gdb_ext(path);
   dir   = fga_path_dir(noext);
   root  = fga_path_root(noext,NULL);
 
-  if (asprintf(&spath,"%s/%s.gdb",dir,root) < 0) spath = NULL;
+  /* <root>.1gdb (binary or ASCII ONEcode, what the reference writes) first, then <root>.gdb */
+  if (asprintf(&spath,"%s/%s.1gdb",dir,root) < 0) spath = NULL;
   f = (spath != NULL) ? fopen(spath,"r") : NULL;
   if (f == NULL)
-    { char *one = NULL;
-      if (asprintf(&one,"%s/%s.1gdb",dir,root) >= 0 && access(one,R_OK) == 0)
-        fga_set_error("%s is a binary ONEcode skeleton; this build reads the ASCII form "
-                      "(%s/%s.gdb, e.g. `ONEview %s > %s/%s.gdb`)",one,dir,root,one,dir,root);
-      else
-        fga_set_error("cannot find/open GDB skeleton %s/%s.gdb",dir,root);
-      free(one);
+    { free(spath);
+      if (asprintf(&spath,"%s/%s.gdb",dir,root) < 0) spath = NULL;
+      f = (spath != NULL) ? fopen(spath,"r") : NULL;
+    }
+  if (f == NULL)
+    { fga_set_error("cannot find/open GDB skeleton %s/%s.1gdb or .gdb",dir,root);
       goto fail;
     }
 
-  boff = 0;
-  spos = 0;
+  { /* binary container?  The header of a binary file ends with a "$ <endian>" line */
+    uint8_t *buf = NULL;
+    size_t   size = 0, got;
+    int      binary = 0;
+    if (fseek(f,0,SEEK_END) == 0)
+      { long sz = ftell(f);
+        rewind(f);
+        if (sz > 0 && (buf = malloc((size_t) sz + 1)) != NULL)
+          { got = fread(buf,1,(size_t) sz,f);
+            size = got;
+            buf[size] = '\0';
+            { const uint8_t *q = buf;
+              while (q < buf+size)                  /* scan the ASCII header lines only */
+                { const uint8_t *e = memchr(q,'\n',(size_t) (buf+size-q));
+                  if (q[0] == '$') { binary = 1; break; }
+                  if (e == NULL || (q[0] & 0x80) || (q[0] >= 'A' && q[0] <= 'z' && q[0] != '~'))
+                    break;
+                  q = e+1;
+                }
+            }
+          }
+        rewind(f);
+      }
+    if (binary)
+      { int rc;
+        if (size < 8 || memcmp(buf,"1 ",2) != 0 || strstr((char *) buf," gdb ") == NULL)
+          { fga_set_error("%s is not a ONEcode gdb file",spath);
+            free(buf);
+            goto fail_f;
+          }
+        rc = read_binary_skeleton(&X,buf,size,spath);
+        free(buf);
+        if (rc) goto fail_f;
+        goto parsed;
+      }
+    free(buf);
+  }
+
   while ((n = getline(&line,&cap,f)) > 0)
     { while (n > 0 && (line[n-1] == '\n' || line[n-1] == '\r'))
         line[--n] = '\0';
       if (first)
         { first = 0;
           if (line[0] != '1' || strstr(line," gdb ") == NULL)
-            { fga_set_error("%s is not an ASCII ONEcode gdb file",spath);
+            { fga_set_error("%s is not a ONEcode gdb file",spath);
               goto fail_f;
             }
           continue;
         }
       switch (line[0])
-      { case '<':
-          if (G->srcpath == NULL)
-            { int len = 0, used = 0;
-              if (sscanf(line+1," %d %n",&len,&used) >= 1 && len >= 0
-                  && (int) strlen(line+1+used) >= len)
-                G->srcpath = strndup(line+1+used,len);
-            }
+      { case '<': case 'S':
+          { const char *str; int64_t len;
+            if (ascii_string(line+1,&str,&len))
+              { if (line[0] == '<') break;
+                fga_set_error("%s: malformed S line",spath);
+                goto fail_f;
+              }
+            if (skel_line(&X,line[0],str,len,0,NULL)) goto fail_f;
+          }
           break;
         case 'f':
-          { double a, c, g, t;
-            if (sscanf(line+1," %lf %lf %lf %lf",&a,&c,&g,&t) != 4)
+          { double r4[4];
+            if (sscanf(line+1," %lf %lf %lf %lf",r4,r4+1,r4+2,r4+3) != 4)
               { fga_set_error("%s: malformed f line",spath);
                 goto fail_f;
               }
-            G->freq[0] = a; G->freq[1] = c; G->freq[2] = g; G->freq[3] = t;
+            if (skel_line(&X,'f',NULL,0,0,r4)) goto fail_f;
           }
           break;
-        case 'S':
-          { int len = 0, used = 0;
-            if (sscanf(line+1," %d %n",&len,&used) < 1 || len < 0
-                || (int) strlen(line+1+used) < len)
-              { fga_set_error("%s: malformed S line",spath);
-                goto fail_f;
-              }
-            if (G->nscaff > 0)
-              { G->scaffolds[G->nscaff-1].ectg = G->ncontig;
-                G->scaffolds[G->nscaff-1].slen = spos;
-              }
-            spos = 0;
-            if (G->nscaff >= sctop)
-              { sctop = (int) (1.2*G->nscaff) + 500;
-                G->scaffolds = realloc(G->scaffolds,sizeof(fga_scaffold)*sctop);
-              }
-            if (G->hdrtot + len + 1 > hdrcap)
-              { hdrcap = (int64_t) (1.2*(G->hdrtot+len+1)) + 10000;
-                G->headers = realloc(G->headers,hdrcap);
-              }
-            if (G->scaffolds == NULL || G->headers == NULL)
-              { fga_set_error("out of memory");
-                goto fail_f;
-              }
-            G->scaffolds[G->nscaff].hoff = G->hdrtot;
-            G->scaffolds[G->nscaff].fctg = G->ncontig;
-            memcpy(G->headers+G->hdrtot,line+1+used,len);
-            G->hdrtot += len;
-            G->headers[G->hdrtot++] = '\0';
-            G->nscaff += 1;
-          }
-          break;
-        case 'G':
-          spos += atoll(line+1);
-          break;
-        case 'C':
-          { int64_t len = atoll(line+1);
-            if (G->nscaff == 0)
-              { fga_set_error("%s: C line before any S line",spath);
-                goto fail_f;
-              }
-            if (G->ncontig >= cttop)
-              { cttop = (int) (1.2*G->ncontig) + 1000;
-                G->contigs = realloc(G->contigs,sizeof(fga_contig)*(cttop+1));
-                if (G->contigs == NULL)
-                  { fga_set_error("out of memory");
-                    goto fail_f;
-                  }
-              }
-            G->contigs[G->ncontig].boff = boff;
-            G->contigs[G->ncontig].sbeg = spos;
-            G->contigs[G->ncontig].clen = len;
-            G->contigs[G->ncontig].scaf = G->nscaff-1;
-            G->ncontig += 1;
-            if (len > G->maxctg) G->maxctg = len;
-            G->seqtot += len;
-            boff += (len+3) >> 2;
-            spos += len;
-          }
+        case 'G': case 'C':
+          if (skel_line(&X,line[0],NULL,0,atoll(line+1),NULL)) goto fail_f;
           break;
         default:     /* header / provenance / schema / count lines, deprecated u and M lines */
           break;
       }
     }
+parsed:
   fclose(f);
   f = NULL;
+  boff = X.boff;
   if (G->nscaff == 0 || G->ncontig == 0)
     { fga_set_error("%s holds no scaffolds/contigs",spath);
       goto fail;
     }
   G->scaffolds[G->nscaff-1].ectg = G->ncontig;
-  G->scaffolds[G->nscaff-1].slen = spos;
+  G->scaffolds[G->nscaff-1].slen = X.spos;
   if (G->srcpath == NULL)
     G->srcpath = strdup("");
   G->path = strdup(spath);

@@ -41,3 +41,34 @@ def test_edge_fasta_gdb_and_gix_match_reference(tmp_path, built_library):
         x, y = a[:, cols], b[:, cols]
         assert np.array_equal(x[np.lexsort(x.T[::-1])], y[np.lexsort(y.T[::-1])])
     g.close()
+
+
+@needs_ref
+def test_reference_binary_1gdb_is_read_directly(tmp_path, built_library):
+    """fga_gdb_open on the reference's own binary ONEcode skeleton (<root>.1gdb + .<root>.bps) gives the same genome as
+    our ASCII <root>.gdb of the same FASTA"""
+    from fastga_amd.gixio import Gdb, fasta_to_gdb
+    d = str(tmp_path)
+    od, rd = os.path.join(d, "ours"), os.path.join(d, "ref")
+    os.makedirs(od); os.makedirs(rd)
+    sc = make_edge_scaffolds(3)
+    for w in (od, rd):
+        write_edge_fasta(os.path.join(w, "E.fa"), sc, seed=1)
+    fasta_to_gdb(os.path.join(od, "E.fa"), os.path.join(od, "E"))
+    H.run([H.ref_bin("FAtoGDB"), os.path.join(rd, "E.fa"), os.path.join(rd, "E.1gdb")], cwd=rd)
+    assert b"\n$ 0\n" in open(os.path.join(rd, "E.1gdb"), "rb").read(4096)          # binary container
+    a, b = Gdb(os.path.join(od, "E")), Gdb(os.path.join(rd, "E"))
+    assert a.ncontig == b.ncontig and a.seqtot == b.seqtot and a.maxctg == b.maxctg
+    assert np.array_equal(a.clen, b.clen)
+    for c in range(a.ncontig):
+        assert np.array_equal(a.contig(c), b.contig(c))
+    # the skeleton written back from the binary read equals the reference's own ONEview of it
+    import ctypes as C
+    out = os.path.join(d, "back.1aln")
+    from fastga_amd.lib import Alns
+    A = Alns(0, 0, 0, 0, None, None)
+    assert a.L.fga_write_1aln_binary(out.encode(), b.h, None, C.byref(A), 100, b"E", None, b"t") == 0
+    skel = [ln for ln in H.oneview(out) if ln[0] in "gSGC"]
+    ref = [ln for ln in H.oneview(os.path.join(rd, "E.1gdb")) if ln[0] in "SGC"]
+    assert [ln for ln in skel if ln[0] != "g"] == ref
+    a.close(); b.close()

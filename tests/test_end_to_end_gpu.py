@@ -138,3 +138,21 @@ def test_reference_tools_accept_our_1aln(toy_pair, tmp_path):
         a = H.run([H.ref_bin("ALNtoPAF"), "-T4", *flags, ours], cwd=w).stdout.splitlines()
         b = H.run([H.ref_bin("ALNtoPAF"), "-T4", *flags, os.path.join(w, "ref.1aln")], cwd=w).stdout.splitlines()
         assert len(a) > 10 and a == b, flags
+
+
+def test_runs_on_the_reference_s_own_index_files(toy_pair, tmp_path):
+    """The drop-in scenario: FAtoGDB + GIXmake of the reference build the inputs (binary <root>.1gdb, .bps, .gix,
+    .ktab.*); our pipeline reads them as they are and writes the same .1aln as the reference FastGA on the same files."""
+    import shutil
+    from oracle import harness as H
+    if not H.have_reference():
+        pytest.skip("oracle/_ref did not travel")
+    d, ra, rb = toy_pair
+    w = str(tmp_path)
+    roots = []
+    for r in (ra, rb):
+        fa = os.path.join(w, os.path.basename(r) + ".fa")
+        shutil.copy(r + ".fa", fa)
+        roots.append(H.ref_build_index(fa, w, threads=8))
+    assert os.path.exists(roots[0] + ".1gdb") and not os.path.exists(roots[0] + ".gdb")
+    _compare(roots[0], roots[1], w)

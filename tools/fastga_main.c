@@ -46,14 +46,10 @@ static int prepare(const char *src, char **root, int nthreads, int verbose)
 { int isfa;
   char *r = root_of(src,&isfa);
   *root = r;
-  if (!exists("%s.gdb",r))
+  if (!exists("%s.1gdb",r) && !exists("%s.gdb",r))          /* both ONEcode forms of the skeleton are read */
     { static const char *fext[] = { ".fa", ".fna", ".fasta", ".fa.gz", ".fna.gz", ".fasta.gz", NULL };
       char *fa = NULL;
       int i;
-      if (exists("%s.1gdb",r))
-        { fprintf(stderr,"FastGA: %s.1gdb is a binary ONEcode skeleton; this build reads %s.gdb (ASCII)\n",r,r);
-          return 1;
-        }
       if (isfa)
         fa = strdup(src);
       else
