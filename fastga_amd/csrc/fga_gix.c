@@ -193,6 +193,7 @@ int            fga_gix_postbytes(const fga_gix *X) { return X->postbytes; }
 int            fga_gix_contbytes(const fga_gix *X) { return X->contbytes; }
 int            fga_gix_nctg(const fga_gix *X)      { return X->nctg; }
 int            fga_gix_nparts(const fga_gix *X)    { return X->nparts; }
+int64_t        fga_gix_part_begin(const fga_gix *X, int p) { return (p < 0 || p > X->nparts) ? -1 : X->partbeg[p]; }
 int64_t        fga_gix_maxpre(const fga_gix *X)    { return X->maxpre; }
 const int     *fga_gix_perm(const fga_gix *X)      { return X->perm; }
 const int64_t *fga_gix_index(const fga_gix *X)     { return X->index; }

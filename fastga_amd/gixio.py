@@ -52,6 +52,7 @@ class Gix:
         self.pbyte = self.postbytes + self.contbytes
         self.nctg = L.fga_gix_nctg(h)
         self.nparts = L.fga_gix_nparts(h)
+        self.partbeg = np.array([L.fga_gix_part_begin(h, p) for p in range(self.nparts + 1)], dtype=np.int64)
         self.maxpre = L.fga_gix_maxpre(h)
         self.perm = np.ctypeslib.as_array(L.fga_gix_perm(h), shape=(self.nctg,)).copy()
         self.index = np.ctypeslib.as_array(L.fga_gix_index(h), shape=(NPREFIX,))

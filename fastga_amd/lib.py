@@ -109,6 +109,7 @@ def _declare(L):
         "fga_gix_contbytes": (i32, [vp]),
         "fga_gix_nctg": (i32, [vp]),
         "fga_gix_nparts": (i32, [vp]),
+        "fga_gix_part_begin": (i64, [vp, i32]),
         "fga_gix_maxpre": (i64, [vp]),
         "fga_gix_perm": (P(C.c_int), [vp]),
         "fga_gix_index": (P(C.c_int64), [vp]),

@@ -45,6 +45,7 @@ int            fga_gix_postbytes(const fga_gix *gix);
 int            fga_gix_contbytes(const fga_gix *gix);
 int            fga_gix_nctg(const fga_gix *gix);
 int            fga_gix_nparts(const fga_gix *gix);
+int64_t        fga_gix_part_begin(const fga_gix *gix, int part);   /* first entry of table part (0..nparts) */
 int64_t        fga_gix_maxpre(const fga_gix *gix);
 const int     *fga_gix_perm(const fga_gix *gix);
 const int64_t *fga_gix_index(const fga_gix *gix);
