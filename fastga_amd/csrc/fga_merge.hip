@@ -158,6 +158,12 @@ __device__ __forceinline__ void split_payload(uint32_t e2, uint32_t e3, int post
   ctg  = c & (sb-1);
 }
 
+// pull the 64-byte line at p towards L2 (the tile load proper follows an iteration later).  The byte is a real load
+// whose value is folded into a dummy accumulator only AFTER the next tile's own loads have been issued, so the
+// wait for it coincides with the wait the tile load needs anyway.
+__device__ __forceinline__ uint32_t l2_touch(const uint8_t *p)
+{ return *(const volatile uint8_t *) p; }
+
 __device__ __forceinline__ int wave_incl_scan_add(int v)
 { int lane = threadIdx.x & 63;
   #pragma unroll
@@ -407,9 +413,39 @@ void seed_merge_kernel(merge_args A)
   const int E1 = A.E1, E2 = A.E2;
   const int freq = A.freq;
 
+  // the descriptors of the NEXT tile are fetched one iteration ahead and its table bytes / index slices are pulled
+  // into L2 with throw-away loads, so that the tile load at the top of an iteration is one L2 round trip instead
+  // of two dependent HBM round trips
+  uint32_t pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0, pfacc = 0;
+  merge_tile nt0 = A.tiles[blockIdx.x < A.ntiles ? blockIdx.x : 0];
+  merge_tile nt1 = A.tiles[blockIdx.x < A.ntiles ? blockIdx.x+1 : 0];
   for (int tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x)
-    { const merge_tile t0 = A.tiles[tile];
-      const merge_tile t1 = A.tiles[tile+1];
+    { const merge_tile t0 = nt0;
+      const merge_tile t1 = nt1;
+      const uint32_t ppf = pf0 + pf1 + pf2 + pf3;        // touched for THIS tile an iteration ago
+      { const int nx = tile + gridDim.x;
+        if (nx < A.ntiles)
+          { nt0 = A.tiles[nx]; nt1 = A.tiles[nx+1];
+            const int64_t q1 = nt0.a*E1, r1 = nt1.a*E1;
+            const int64_t q2 = ((MODE == MODE_SELF) ? nt0.a : nt0.b)*E2, r2 = ((MODE == MODE_SELF) ? nt1.a : nt1.b)*E2;
+            const int np2 = nt1.p - nt0.p;
+            // one byte per 64-byte line and lane; the value is never used
+            int64_t off = (q1 & ~(int64_t) 63) + 64*(int64_t) tid;
+            pf0 = pf1 = pf2 = pf3 = 0;
+            if (off < r1 && r1 - q1 <= RAWCAP)
+              pf0 = l2_touch(A.tab1 + off);
+            if (MODE != MODE_SELF)
+              { off = (q2 & ~(int64_t) 63) + 64*(int64_t) tid;
+                if (off < r2 && r2 - q2 <= RAWCAP)
+                  pf1 = l2_touch(A.tab2 + off);
+              }
+            if (tid*8 < np2 && np2 <= PCAP)
+              { pf2 = l2_touch((const uint8_t *) (A.idx1 + nt0.p + tid*8));
+                if (MODE != MODE_SELF)
+                  pf3 = l2_touch((const uint8_t *) (A.idx2 + nt0.p + tid*8));
+              }
+          }
+      }
       const int p0 = t0.p, p1 = t1.p;
       const int np = p1 - p0;
       if (np <= 0)
@@ -452,6 +488,7 @@ void seed_merge_kernel(merge_args A)
         { la[q] = (uint32_t) (A.idx1[p0+q] - a0);
           lb[q] = (MODE == MODE_SELF) ? la[q] : (uint32_t) (A.idx2[p0+q] - b0);
         }
+      pfacc += ppf;
       { uint2 *o2 = (uint2 *) own;
         for (int x = tid; x < (n1+3)/4; x += NT)
           o2[x] = make_uint2(0,0);
@@ -475,6 +512,8 @@ void seed_merge_kernel(merge_args A)
       PROF(1)
 
       // 3. owner[i] = max head at or before i (block max-scan, 4 consecutive entries per thread)
+      int nlive;
+      uint32_t *clist = (uint32_t *) (keyB + n2);
       { uint2 v = ((uint2 *) own)[tid];
         int x0 = v.x & 0xffff, x1 = v.x >> 16, x2 = v.y & 0xffff, x3 = v.y >> 16;
         x1 = x1 > x0 ? x1 : x0;
@@ -496,34 +535,63 @@ void seed_merge_kernel(merge_args A)
         x1 = x1 > prev ? x1 : prev;
         x2 = x2 > prev ? x2 : prev;
         x3 = x3 > prev ? x3 : prev;
-        if (tid*4 < n1)
-          ((uint2 *) own)[tid] = make_uint2((uint32_t) x0 | ((uint32_t) x1 << 16),
-                                            (uint32_t) x2 | ((uint32_t) x3 << 16));
+        // 3b. compaction: only the T1 entries that can emit -- forward strand in the plain pass (FastGA.c:921-928)
+        //     and a non-empty T2 panel -- go on to the match phase, packed (i | q << 16) behind the T2 keys
+        //     (8 n2 + 4 n1 <= 8 TILE_COST bytes), so that its rounds run with full wavefronts instead of half-empty ones
+        int live = 0;
+        uint32_t pk[4];
+        { const int xs[4] = { x0, x1, x2, x3 };
+          #pragma unroll
+          for (int e = 0; e < 4; e++)
+            { const int i = tid*4 + e, q = xs[e];
+              bool ok = i < n1;
+              if (ok)
+                { const int pb0 = q ? (int) lb[q-1] : 0, pb1 = (int) lb[q];
+                  ok = pb1 > pb0;
+                  if (ok && MODE == MODE_PAIR)
+                    { const uint32_t sb = o1 + (uint32_t) i*E1 + E1 - 1;
+                      ok = !((rawd[sb >> 2] >> (8*(sb & 3))) & 0x80);
+                    }
+                }
+              pk[e] = ok ? ((uint32_t) i | ((uint32_t) q << 16)) : 0xffffffffu;
+              live += ok;
+            }
+        }
+        const int linc = wave_incl_scan_add(live);
+        __syncthreads();                                  // everybody has read wtot[] (the max scan) by now
+        if ((tid & 63) == 63)
+          wtot[tid >> 6] = linc;
+        __syncthreads();
+        int lbase = linc - live;
+        nlive = 0;
+        #pragma unroll
+        for (int w = 0; w < NWAVE; w++)
+          { const int t = wtot[w];
+            if (w < (tid >> 6)) lbase += t;
+            nlive += t;
+          }
+        #pragma unroll
+        for (int e = 0; e < 4; e++)
+          if (pk[e] != 0xffffffffu)
+            clist[lbase++] = pk[e];
         __syncthreads();
       }
 
       PROF(2)
       // 4. match phase: T1 entries tid, tid+NT, ...; results packed in registers
-      int      r_low[EPT], r_cnt[EPT], r_plen[EPT];
+      int      r_low[EPT], r_cnt[EPT], r_plen[EPT], r_i[EPT];
       int      total = 0;
       #pragma unroll
       for (int r = 0; r < EPT; r++)
-        { const int i = r*NT + tid;
-          r_cnt[r] = 0; r_low[r] = 0; r_plen[r] = 0;
-          if (i >= n1)
+        { const int c = r*NT + tid;
+          r_cnt[r] = 0; r_low[r] = 0; r_plen[r] = 0; r_i[r] = 0;
+          if (c >= nlive)
             continue;
+          const uint32_t ce = clist[c];
+          const int i = (int) (ce & 0xffff), q = (int) (ce >> 16);
+          r_i[r] = i;
           const uint32_t oe = o1 + (uint32_t) i*E1;
-          // sign test first: complement-strand T1 entries emit nothing in the plain pass (FastGA.c:921-928)
-          if (MODE == MODE_PAIR)
-            { uint32_t sb = oe + E1 - 1;
-              uint32_t wd = rawd[sb >> 2] >> (8*(sb & 3));
-              if (wd & 0x80)
-                continue;
-            }
-          const int q = own[i];
           const int pb0 = q ? (int) lb[q-1] : 0, pb1 = (int) lb[q];
-          if (pb0 == pb1)
-            continue;
           const uint64_t ks = (MODE == MODE_SELF) ? keyB[i] : lds_read_key(rawd,oe);
           int low, hgh, plen, lbnd;
           if (MODE == MODE_SELF)
@@ -589,7 +657,7 @@ void seed_merge_kernel(merge_args A)
               for (int r = 0; r < EPT; r++)
                 { if (r_cnt[r] == 0)
                     continue;
-                  const int i = r*NT + tid;
+                  const int i = r_i[r];
                   const int low = r_low[r] & 0xffff, hgh = r_low[r] >> 16, plen = r_plen[r];
                   const int mlen = mfull ? plen : 41;
                   uint32_t e0, e1_, e2_, e3, spos, sctg, ssign;
@@ -622,6 +690,7 @@ void seed_merge_kernel(merge_args A)
 
   __syncthreads();
   stage_flush(A,S);
+  asm volatile("" :: "v"(pfacc));          // keeps the L2 touches alive
   // sum of plen: one atomic per wave at the very end
   #pragma unroll
   for (int d = 32; d >= 1; d >>= 1)
