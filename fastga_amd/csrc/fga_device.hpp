@@ -58,6 +58,7 @@ struct fga_dseeds
   { fga_dev  *dev;
     fga_seed *seeds;      // device buffer
     int64_t   capacity;
+    int64_t   phys_capacity;   // slots actually allocated: capacity + room for the wave kernel's unused chunk tails
     int       slot;       // workspace slot the seed buffer came from (-1: own allocation)
     int64_t   tseed;      // sum of plen over all seeds
     int64_t   count;      // seeds produced (may exceed capacity -> overflow, buffer holds `capacity`)

@@ -76,6 +76,9 @@ struct merge_args
     int   pbeg, pend;                 // prefix range handled by this call
     int64_t base;                     // cost(pbeg-1)
     int   ntiles;
+    int   tile_cost;                  // cost units per tile of this launch's partition
+    int   pairs;                      // tiles[] holds (begin,end) descriptor pairs of queued tiles; count in *npairs
+    const unsigned long long *npairs; int pair_cap;
     const merge_tile *tiles;
     fga_seed *out; int64_t cap;
     unsigned long long *count;        // seeds produced
@@ -98,7 +101,7 @@ __global__ void merge_partition_kernel(merge_args A, merge_tile *tiles)
   else if (w == A.ntiles)
     p = A.pend;
   else
-    { int64_t target = A.base + (int64_t) w * TILE_COST;
+    { int64_t target = A.base + (int64_t) w * A.tile_cost;
       int lo = A.pbeg, hi = A.pend;
       while (lo < hi)
         { int mid = lo + ((hi-lo) >> 1);
@@ -417,14 +420,20 @@ void seed_merge_kernel(merge_args A)
   // into L2 with throw-away loads, so that the tile load at the top of an iteration is one L2 round trip instead
   // of two dependent HBM round trips
   uint32_t pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0, pfacc = 0;
-  merge_tile nt0 = A.tiles[blockIdx.x < A.ntiles ? blockIdx.x : 0];
-  merge_tile nt1 = A.tiles[blockIdx.x < A.ntiles ? blockIdx.x+1 : 0];
-  for (int tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x)
+  const int step = A.pairs ? 2 : 1;
+  int ntl = A.ntiles;
+  if (A.pairs)
+    { const unsigned long long np_ = *A.npairs;
+      ntl = 2 * (int) (np_ < (unsigned long long) A.pair_cap ? np_ : (unsigned long long) A.pair_cap);
+    }
+  merge_tile nt0 = A.tiles[(int) blockIdx.x*step < ntl ? blockIdx.x*step : 0];
+  merge_tile nt1 = A.tiles[(int) blockIdx.x*step < ntl ? blockIdx.x*step+1 : 0];
+  for (int tile = blockIdx.x*step; tile < ntl; tile += gridDim.x*step)
     { const merge_tile t0 = nt0;
       const merge_tile t1 = nt1;
       const uint32_t ppf = pf0 + pf1 + pf2 + pf3;        // touched for THIS tile an iteration ago
-      { const int nx = tile + gridDim.x;
-        if (nx < A.ntiles)
+      { const int nx = tile + gridDim.x*step;
+        if (nx < ntl)
           { nt0 = A.tiles[nx]; nt1 = A.tiles[nx+1];
             const int64_t q1 = nt0.a*E1, r1 = nt1.a*E1;
             const int64_t q2 = ((MODE == MODE_SELF) ? nt0.a : nt0.b)*E2, r2 = ((MODE == MODE_SELF) ? nt1.a : nt1.b)*E2;
@@ -463,7 +472,7 @@ void seed_merge_kernel(merge_args A)
       const int64_t len1 = ((e1 - s1a) + 15) & ~(int64_t) 15;
       const int64_t len2 = (MODE == MODE_SELF) ? 0 : (((e2 - s2a) + 15) & ~(int64_t) 15);
 
-      if (np > PCAP-1 || n1l > TILE_COST || n2l > TILE_COST || len1 + len2 > RAWCAP - 32)
+      if (np > PCAP-1 || n1l + n2l > TILE_COST || len1 + len2 > RAWCAP - 32)
         { global_tile<MODE>(A,S,p0,p1,a0,a1,tsum);
           __syncthreads();
           continue;
@@ -700,6 +709,358 @@ void seed_merge_kernel(merge_args A)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// the wave-per-tile merge kernel
+// ---------------------------------------------------------------------------------------------------
+// Same tile algorithm, but one wavefront owns one (4x smaller) tile and never meets another wavefront: no workgroup
+// barrier, no block scan, no shared stage.  Steps are separated by wavefront-scope fences only; scans are DPP / mbcnt.
+// Output: a wavefront reserves CHUNK_SEEDS slots of the seed buffer with ONE global atomic and fills them over
+// many tiles with direct 16-byte stores; a tile that does not fit the rest of the chunk spills into the next one, so
+// the only unused slots are the tail of each wavefront's last chunk.  Those "holes" are recorded and closed afterwards
+// by moving the seeds at the end of the buffer into them (seed order is irrelevant: the sort follows).
+// Tiles that do not fit the per-wave LDS budget (a single k-mer panel of more than WTILE_COST entries) are queued and
+// go through the workgroup kernel above.
+#ifndef WTILE_COST
+#define WTILE_COST      256
+#endif
+static_assert(WTILE_COST == 256,"the per-lane owner scan and the owner clear assume 4 entries per lane");
+#define WEPT            (WTILE_COST/64)
+#define WPCAP           (WTILE_COST/2 + 2)
+#define WRAWCAP         (WTILE_COST*16 + 96)
+#ifndef CHUNK_SEEDS
+#define CHUNK_SEEDS     1024
+#endif
+
+#define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL,"wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+struct wave_out
+  { unsigned long long *holes;      // [2*hole_cap] begin,end of unused slot ranges
+    unsigned long long *ctr;        // [0] holes, [1] queued oversize tiles
+    int                *bigq;
+    int                 hole_cap, big_cap;
+  };
+
+__device__ __forceinline__ int wave_excl_scan_add_dpp(int v, int &total)
+{ int x = v, t;
+  t = __builtin_amdgcn_update_dpp(0,x,0x111,0xf,0xf,true); x += t;
+  t = __builtin_amdgcn_update_dpp(0,x,0x112,0xf,0xf,true); x += t;
+  t = __builtin_amdgcn_update_dpp(0,x,0x114,0xf,0xf,true); x += t;
+  t = __builtin_amdgcn_update_dpp(0,x,0x118,0xf,0xf,true); x += t;
+  t = __builtin_amdgcn_update_dpp(0,x,0x142,0xa,0xf,false); x += t;
+  t = __builtin_amdgcn_update_dpp(0,x,0x143,0xc,0xf,false); x += t;
+  total = __builtin_amdgcn_readlane(x,63);
+  return x - v;
+}
+
+__device__ __forceinline__ int wave_incl_scan_max_dpp(int v)      // v >= 0
+{ int x = v, t;
+  t = __builtin_amdgcn_update_dpp(0,x,0x111,0xf,0xf,true); x = x > t ? x : t;
+  t = __builtin_amdgcn_update_dpp(0,x,0x112,0xf,0xf,true); x = x > t ? x : t;
+  t = __builtin_amdgcn_update_dpp(0,x,0x114,0xf,0xf,true); x = x > t ? x : t;
+  t = __builtin_amdgcn_update_dpp(0,x,0x118,0xf,0xf,true); x = x > t ? x : t;
+  t = __builtin_amdgcn_update_dpp(0,x,0x142,0xa,0xf,false); x = x > t ? x : t;
+  t = __builtin_amdgcn_update_dpp(0,x,0x143,0xc,0xf,false); x = x > t ? x : t;
+  return x;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64)
+void seed_merge_wave_kernel(merge_args A, wave_out W)
+{ __shared__ uint16_t la[WPCAP+1];
+  __shared__ uint16_t lb[WPCAP+1];
+  __shared__ __attribute__((aligned(16))) uint8_t  raw[WRAWCAP];
+  __shared__ __attribute__((aligned(16))) uint64_t keyB[WTILE_COST];
+  __shared__ __attribute__((aligned(16))) uint16_t own[WTILE_COST];
+
+  const int lane = threadIdx.x;
+  const int E1 = A.E1, E2 = A.E2;
+  const int freq = A.freq;
+  unsigned long long tsum = 0;
+  int64_t chunk_pos = 0, chunk_end = 0;         // this wavefront's current output chunk (wave-uniform)
+
+  uint32_t pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0, pfacc = 0;
+  merge_tile nt0 = A.tiles[blockIdx.x < (unsigned) A.ntiles ? blockIdx.x : 0];
+  merge_tile nt1 = A.tiles[blockIdx.x < (unsigned) A.ntiles ? blockIdx.x+1 : 0];
+  for (int tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x)
+    { const merge_tile t0 = nt0;
+      const merge_tile t1 = nt1;
+      const uint32_t ppf = pf0 + pf1 + pf2 + pf3;
+      { const int nx = tile + gridDim.x;
+        if (nx < A.ntiles)
+          { nt0 = A.tiles[nx]; nt1 = A.tiles[nx+1];
+            const int64_t q1 = nt0.a*E1, r1 = nt1.a*E1;
+            const int64_t q2 = ((MODE == MODE_SELF) ? nt0.a : nt0.b)*E2, r2 = ((MODE == MODE_SELF) ? nt1.a : nt1.b)*E2;
+            const int np2 = nt1.p - nt0.p;
+            int64_t off = (q1 & ~(int64_t) 63) + 64*(int64_t) lane;
+            pf0 = pf1 = pf2 = pf3 = 0;
+            if (off < r1 && r1 - q1 <= WRAWCAP)
+              pf0 = l2_touch(A.tab1 + off);
+            if (MODE != MODE_SELF)
+              { off = (q2 & ~(int64_t) 63) + 64*(int64_t) lane;
+                if (off < r2 && r2 - q2 <= WRAWCAP)
+                  pf1 = l2_touch(A.tab2 + off);
+              }
+            if (lane*8 < np2 && np2 <= WPCAP)
+              { pf2 = l2_touch((const uint8_t *) (A.idx1 + nt0.p + lane*8));
+                if (MODE != MODE_SELF)
+                  pf3 = l2_touch((const uint8_t *) (A.idx2 + nt0.p + lane*8));
+              }
+          }
+      }
+      const int p0 = t0.p, p1 = t1.p;
+      const int np = p1 - p0;
+      if (np <= 0)
+        continue;
+      const int64_t a0 = t0.a, a1 = t1.a;
+      const int64_t b0 = (MODE == MODE_SELF) ? a0 : t0.b, b1 = (MODE == MODE_SELF) ? a1 : t1.b;
+      const int64_t n1l = a1 - a0, n2l = b1 - b0;
+      if (n1l == 0 || n2l == 0)
+        continue;
+      const int64_t s1 = a0*E1, e1 = a1*E1;
+      const int64_t s2 = b0*E2, e2 = b1*E2;
+      const int64_t s1a = s1 & ~(int64_t) 15, s2a = s2 & ~(int64_t) 15;
+      const int64_t len1 = ((e1 - s1a) + 15) & ~(int64_t) 15;
+      const int64_t len2 = (MODE == MODE_SELF) ? 0 : (((e2 - s2a) + 15) & ~(int64_t) 15);
+      if (np > WPCAP-1 || n1l + n2l > WTILE_COST || len1 + len2 > WRAWCAP - 32)
+        { if (lane == 0)                            // oversize: the workgroup kernel takes it afterwards
+            { const unsigned long long q = atomicAdd(W.ctr+1,1ull);
+              if ((int64_t) q < W.big_cap)
+                W.bigq[q] = tile;
+            }
+          continue;
+        }
+      const int n1 = (int) n1l, n2 = (int) n2l;
+
+      // 1. raw bytes HBM -> LDS, index slices, owner array cleared
+      { const uint4 *g1 = (const uint4 *) (A.tab1 + s1a);
+        uint4 *l1 = (uint4 *) raw;
+        const int n16 = (int) (len1 >> 4);
+        for (int x = lane; x < n16; x += 64)
+          l1[x] = g1[x];
+        if (MODE != MODE_SELF)
+          { const uint4 *g2 = (const uint4 *) (A.tab2 + s2a);
+            uint4 *l2 = (uint4 *) (raw + len1);
+            const int m16 = (int) (len2 >> 4);
+            for (int x = lane; x < m16; x += 64)
+              l2[x] = g2[x];
+          }
+      }
+      for (int q = lane; q < np; q += 64)
+        { la[q] = (uint16_t) (A.idx1[p0+q] - a0);
+          lb[q] = (MODE == MODE_SELF) ? la[q] : (uint16_t) (A.idx2[p0+q] - b0);
+        }
+      pfacc += ppf;
+      ((uint2 *) own)[lane] = make_uint2(0,0);       // WTILE_COST = 4 entries per lane
+      WSYNC();
+
+      const uint32_t *rawd = (const uint32_t *) raw;
+      const uint32_t o1 = (uint32_t) (s1 - s1a);
+      const uint32_t o2 = (MODE == MODE_SELF) ? o1 : (uint32_t) (len1 + (s2 - s2a));
+
+      // 2. head flags of the non-empty T1 panels; T2 keys
+      for (int q = lane; q < np; q += 64)
+        { const uint32_t s = q ? la[q-1] : 0;
+          if (la[q] > s)
+            own[s] = (uint16_t) q;
+        }
+      for (int j = lane; j < n2; j += 64)
+        keyB[j] = lds_read_key(rawd,o2 + (uint32_t) j*E2);
+      WSYNC();
+
+      // 3. owner of every T1 entry (wave max-scan, 4 consecutive entries per lane) and compaction of the entries that
+      //    can emit, packed (i | q << 16) behind the T2 keys
+      int nlive;
+      uint32_t *clist = (uint32_t *) (keyB + n2);
+      { const uint2 v = ((const uint2 *) own)[lane];
+        int x0 = v.x & 0xffff, x1 = v.x >> 16, x2 = v.y & 0xffff, x3 = v.y >> 16;
+        x1 = x1 > x0 ? x1 : x0;
+        x2 = x2 > x1 ? x2 : x1;
+        x3 = x3 > x2 ? x3 : x2;
+        const int inc = wave_incl_scan_max_dpp(x3);
+        const int prev = __builtin_amdgcn_update_dpp(0,inc,0x138,0xf,0xf,false);      // lane-1's inclusive value, 0 for lane 0
+        x0 = x0 > prev ? x0 : prev;
+        x1 = x1 > prev ? x1 : prev;
+        x2 = x2 > prev ? x2 : prev;
+        x3 = x3 > prev ? x3 : prev;
+        int live = 0;
+        uint32_t pk[4];
+        const int xs[4] = { x0, x1, x2, x3 };
+        #pragma unroll
+        for (int e = 0; e < 4; e++)
+          { const int i = lane*4 + e, q = xs[e];
+            bool ok = i < n1;
+            if (ok)
+              { const int pb0 = q ? (int) lb[q-1] : 0, pb1 = (int) lb[q];
+                ok = pb1 > pb0;
+                if (ok && MODE == MODE_PAIR)
+                  { const uint32_t sb = o1 + (uint32_t) i*E1 + E1 - 1;
+                    ok = !((rawd[sb >> 2] >> (8*(sb & 3))) & 0x80);
+                  }
+              }
+            pk[e] = ok ? ((uint32_t) i | ((uint32_t) q << 16)) : 0xffffffffu;
+            live += ok;
+          }
+        int lbase = wave_excl_scan_add_dpp(live,nlive);
+        #pragma unroll
+        for (int e = 0; e < 4; e++)
+          if (pk[e] != 0xffffffffu)
+            clist[lbase++] = pk[e];
+      }
+      WSYNC();
+
+      // 4. match phase
+      int r_low[WEPT], r_cnt[WEPT], r_plen[WEPT], r_i[WEPT];
+      int total = 0;
+      #pragma unroll
+      for (int r = 0; r < WEPT; r++)
+        { const int c = r*64 + lane;
+          r_cnt[r] = 0; r_low[r] = 0; r_plen[r] = 0; r_i[r] = 0;
+          if (c >= nlive)
+            continue;
+          const uint32_t ce = clist[c];
+          const int i = (int) (ce & 0xffff), q = (int) (ce >> 16);
+          r_i[r] = i;
+          const uint32_t oe = o1 + (uint32_t) i*E1;
+          const int pb0 = q ? (int) lb[q-1] : 0, pb1 = (int) lb[q];
+          const uint64_t ks = (MODE == MODE_SELF) ? keyB[i] : lds_read_key(rawd,oe);
+          int low, hgh, plen, lbnd;
+          if (MODE == MODE_SELF)
+            { int lk  = (i > pb0)   ? lcp_key(ks,keyB[i-1]) : 0;
+              int lk1 = (i+1 < pb1) ? lcp_key(ks,keyB[i+1]) : 11;
+              plen = lk > lk1 ? lk : lk1;
+              low = i; hgh = i+1; lbnd = i;
+            }
+          else
+            { int lo = pb0, hi = pb1;
+              const uint64_t kq = ks & ~0xffull;
+              while (lo < hi)
+                { int m = (lo+hi) >> 1;
+                  if (keyB[m] < kq) lo = m+1; else hi = m;
+                }
+              int la_ = (lo > pb0) ? lcp_key(ks,keyB[lo-1]) : 0;
+              int lc_ = (lo < pb1) ? lcp_key(ks,keyB[lo]) : 0;
+              plen = la_ > lc_ ? la_ : lc_;
+              low = hgh = lbnd = lo;
+            }
+          while (low > pb0 && lbnd-low <= freq && lcp_key(ks,keyB[low-1]) >= plen)
+            low -= 1;
+          while (hgh < pb1 && hgh-low <= freq && lcp_key(ks,keyB[hgh]) >= plen)
+            hgh += 1;
+          if (hgh-low >= freq)
+            continue;
+          const int mlen = A.soft_mask ? plen : 41;
+          if ((int) (ks & 0xff) >= mlen)
+            continue;
+          int cnt;
+          if (MODE == MODE_FLIP || A.soft_mask)
+            { cnt = 0;
+              for (int j = low; j < hgh; j++)
+                { if ((int) (keyB[j] & 0xff) >= mlen)
+                    continue;
+                  if (MODE == MODE_FLIP)
+                    { uint32_t sb = o2 + (uint32_t) j*E2 + E2 - 1;
+                      if ((rawd[sb >> 2] >> (8*(sb & 3))) & 0x80)
+                        continue;
+                    }
+                  if (MODE == MODE_SELF && j == i)
+                    continue;
+                  cnt += 1;
+                }
+            }
+          else
+            cnt = (hgh-low) - (MODE == MODE_SELF ? 1 : 0);
+          r_cnt[r] = cnt; r_low[r] = low | (hgh << 16); r_plen[r] = plen;
+          total += cnt;
+          tsum  += (unsigned long long) cnt * plen;
+        }
+
+      // 5. slots: the lane's seeds take slots [off, off+total) of the wavefront's T, mapped onto the rest of the
+      //    current chunk and, beyond it, a freshly reserved one
+      int T;
+      int off = wave_excl_scan_add_dpp(total,T);
+      if (T > 0)
+        { const int64_t rem = chunk_end - chunk_pos;
+          int64_t nbase = 0, nsize = 0;
+          if ((int64_t) T > rem)
+            { nsize = ((int64_t) T - rem) > CHUNK_SEEDS ? ((int64_t) T - rem) : CHUNK_SEEDS;
+              unsigned long long b = 0;
+              if (lane == 0)
+                b = atomicAdd(A.count,(unsigned long long) nsize);
+              const uint32_t blo = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) b);
+              const uint32_t bhi = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (b >> 32));
+              nbase = (int64_t) (((uint64_t) bhi << 32) | blo);
+            }
+          if (total > 0)
+            { const int mfull = A.soft_mask;
+              #pragma unroll
+              for (int r = 0; r < WEPT; r++)
+                { if (r_cnt[r] == 0)
+                    continue;
+                  const int i = r_i[r];
+                  const int low = r_low[r] & 0xffff, hgh = r_low[r] >> 16, plen = r_plen[r];
+                  const int mlen = mfull ? plen : 41;
+                  uint32_t e0, e1_, e2_, e3, spos, sctg, ssign;
+                  lds_read16(rawd,o1 + (uint32_t) i*E1,e0,e1_,e2_,e3);
+                  split_payload(e2_,e3,A.post1,A.cont1,spos,sctg,ssign);
+                  for (int j = low; j < hgh; j++)
+                    { if ((int) (keyB[j] & 0xff) >= mlen)
+                        continue;
+                      if (MODE == MODE_SELF && j == i)
+                        continue;
+                      uint32_t c0, c1, c2, c3, cpos, cctg, csign;
+                      lds_read16(rawd,o2 + (uint32_t) j*E2,c0,c1,c2,c3);
+                      split_payload(c2,c3,A.post2,A.cont2,cpos,cctg,csign);
+                      if (MODE == MODE_FLIP && csign)
+                        continue;
+                      const int64_t at = ((int64_t) off < rem) ? chunk_pos + off : nbase + ((int64_t) off - rem);
+                      if (at < A.cap)
+                        A.out[at] = make_seed<MODE>(plen,spos,sctg,ssign,cpos,cctg,csign);
+                      off += 1;
+                    }
+                }
+            }
+          if ((int64_t) T > rem)
+            { chunk_pos = nbase + ((int64_t) T - rem); chunk_end = nbase + nsize; }
+          else
+            chunk_pos += T;
+        }
+      WSYNC();      // the tile buffers are reused by the next tile
+    }
+
+  if (lane == 0 && chunk_end > chunk_pos)          // the unused tail of the last chunk
+    { const unsigned long long h = atomicAdd(W.ctr+0,1ull);
+      if ((int64_t) h < W.hole_cap)
+        { W.holes[2*h] = (unsigned long long) chunk_pos; W.holes[2*h+1] = (unsigned long long) chunk_end; }
+    }
+  asm volatile("" :: "v"(pfacc));
+  #pragma unroll
+  for (int d = 32; d >= 1; d >>= 1)
+    tsum += __shfl_xor(tsum,d,64);
+  if (lane == 0 && tsum != 0)
+    atomicAdd(A.tseed,tsum);
+}
+
+// tile descriptor pairs of the queued oversize tiles, for the workgroup kernel in pair mode
+__global__ void gather_big_tiles_kernel(const merge_tile *tiles, const int *bigq, const unsigned long long *nbig,
+                                        int big_cap, merge_tile *pairs)
+{ const int k = blockIdx.x*blockDim.x + threadIdx.x;
+  const int n = (int) (*nbig < (unsigned long long) big_cap ? *nbig : (unsigned long long) big_cap);
+  if (k >= n)
+    return;
+  pairs[2*k]   = tiles[bigq[k]];
+  pairs[2*k+1] = tiles[bigq[k]+1];
+}
+
+// close the holes: copy `len` seeds from src to dst for every planned move (one workgroup per move)
+struct seed_move { int64_t src, dst, len; };
+__global__ void hole_fill_kernel(fga_seed *seeds, const seed_move *moves, int nmoves)
+{ if ((int) blockIdx.x >= nmoves)
+    return;
+  const seed_move m = moves[blockIdx.x];
+  for (int64_t x = threadIdx.x; x < m.len; x += blockDim.x)
+    seeds[m.dst + x] = seeds[m.src + x];
+}
+
+// ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
 static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
@@ -748,7 +1109,11 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
     }
   A.base = c1b + c2b + 2*(int64_t) A.pbeg;
   int64_t total = (c1e + c2e + 2*(int64_t) A.pend) - A.base;
-  A.ntiles = (int) (total / TILE_COST) + 1;
+  // FGA_MERGE_V1=1 selects the workgroup-per-tile kernel for everything (the wave kernel's fallback path otherwise)
+  int use_wave = 1;
+  { const char *e = getenv("FGA_MERGE_V1");
+    if (e != NULL && atoi(e) != 0) use_wave = 0;
+  }
 
   fga_dseeds *S = append;
   if (S == NULL)
@@ -761,83 +1126,221 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
       if (capacity <= 0)
         capacity = 2*(c1e - c1b) + (1<<20);
       S->capacity = capacity;
+      // every wavefront of the wave kernel may leave up to a chunk unused until the holes are closed, in this
+      // call and in a later append (-S)
+      S->phys_capacity = capacity + 2*(int64_t) dev->ncu * 32 * CHUNK_SEEDS;
     }
   else
     capacity = S->capacity;
+  const int64_t phys = S->phys_capacity;
 
-  merge_tile *tiles = NULL;
   unsigned long long *counters = NULL;
   hipError_t err;
   if (append != NULL)
-    { counters = (unsigned long long *) S->dcount;
-      if ((err = hipMalloc(&tiles,sizeof(merge_tile)*(size_t) (A.ntiles+1))) != hipSuccess)
-        { fga_set_error("fga_seed_merge: device allocation failed: %s",hipGetErrorString(err));
-          return 1;
-        }
-    }
+    counters = (unsigned long long *) S->dcount;
   else
-    { if ((err = hipMalloc(&tiles,sizeof(merge_tile)*(size_t) (A.ntiles+1))) != hipSuccess ||
-          (err = hipMalloc(&counters,2*sizeof(unsigned long long))) != hipSuccess ||
-          (S->seeds = (fga_seed *) fga_dev_acquire(dev,SLOT_SEEDS,sizeof(fga_seed)*(size_t) capacity)) == NULL)
+    { if ((err = hipMalloc(&counters,2*sizeof(unsigned long long))) != hipSuccess ||
+          (S->seeds = (fga_seed *) fga_dev_acquire(dev,SLOT_SEEDS,sizeof(fga_seed)*(size_t) S->phys_capacity)) == NULL)
         { fga_set_error("fga_seed_merge: device allocation failed: %s",hipGetErrorString(err));
-          hipFree(tiles); hipFree(counters); free(S);
+          hipFree(counters); free(S);
           return 1;
         }
       S->slot = SLOT_SEEDS;
       S->dcount = (int64_t *) counters;
+      hipMemsetAsync(counters,0,2*sizeof(unsigned long long),dev->stream);
     }
-  A.tiles = tiles; A.out = S->seeds; A.cap = capacity;
+  A.out = S->seeds; A.cap = phys;
   A.count = counters; A.tseed = counters+1;
+  A.pairs = 0; A.npairs = NULL; A.pair_cap = 0;
 
-  if (append == NULL)
-    hipMemsetAsync(counters,0,2*sizeof(unsigned long long),dev->stream);
-  hipEventRecord(dev->ev0,dev->stream);
-  { int nb = (A.ntiles + 1 + 255) / 256;
-    hipLaunchKernelGGL(merge_partition_kernel,dim3(nb),dim3(256),0,dev->stream,A,tiles);
-  }
-  hipEventRecord(dev->ev1,dev->stream);
-  { int wgs = 4;
-    const char *ev = getenv("FGA_MERGE_WGS");
-    if (ev != NULL && atoi(ev) > 0) wgs = atoi(ev);
-    int grid = dev->ncu * wgs;
-    if (grid > A.ntiles) grid = A.ntiles;
-    if (self)
-      hipLaunchKernelGGL(seed_merge_kernel<MODE_SELF>,dim3(grid),dim3(NT),0,dev->stream,A);
-    else if (prm->flip)
-      hipLaunchKernelGGL(seed_merge_kernel<MODE_FLIP>,dim3(grid),dim3(NT),0,dev->stream,A);
-    else
-      hipLaunchKernelGGL(seed_merge_kernel<MODE_PAIR>,dim3(grid),dim3(NT),0,dev->stream,A);
-  }
-  hipEvent_t ev2;
-  hipEventCreate(&ev2);
-  hipEventRecord(ev2,dev->stream);
+  void *work = NULL;                      // tiles + (wave kernel) pairs, holes, counters, queue, moves
   unsigned long long hc[2];
-  err = hipMemcpyAsync(hc,counters,sizeof(hc),hipMemcpyDeviceToHost,dev->stream);
-  if (err == hipSuccess) err = hipStreamSynchronize(dev->stream);
-  if (err == hipSuccess) err = hipGetLastError();
-  if (err != hipSuccess)
-    { fga_set_error("fga_seed_merge: kernel failed: %s",hipGetErrorString(err));
-      hipEventDestroy(ev2);
-      hipFree(tiles);
-      if (append == NULL)
-        { hipFree(counters); fga_dev_release(dev,SLOT_SEEDS,S->seeds); free(S); }
-      return 1;
+  int rc = 1;
+  hipEvent_t ev2 = NULL;
+  hipEventCreate(&ev2);
+
+  for (int attempt = 0; attempt < 2; attempt++)
+    { A.tile_cost = use_wave ? WTILE_COST : TILE_COST;
+      A.ntiles = (int) (total / A.tile_cost) + 1;
+      int wgs = use_wave ? 20 : 4;
+      { const char *ev = getenv(use_wave ? "FGA_MERGE_WAVES" : "FGA_MERGE_WGS");
+        if (ev != NULL && atoi(ev) > 0) wgs = atoi(ev);
+      }
+      if (use_wave && wgs > 32) wgs = 32;                    // the slack of phys_capacity covers 32 waves per CU
+      int grid = dev->ncu * wgs;
+      if (use_wave && grid > A.ntiles/8 + 1) grid = A.ntiles/8 + 1;      // small inputs: few waves, few holes
+      if (grid > A.ntiles) grid = A.ntiles;
+      const int big_cap  = use_wave ? (A.ntiles < (1<<18) ? A.ntiles : (1<<18)) : 0;
+      const int hole_cap = use_wave ? grid + 16 : 0;
+      const size_t tile_bytes = sizeof(merge_tile)*(size_t) (A.ntiles+1);
+      const size_t pair_bytes = sizeof(merge_tile)*2*(size_t) big_cap;
+      const size_t hole_bytes = sizeof(unsigned long long)*2*(size_t) hole_cap;
+      const size_t move_bytes = sizeof(seed_move)*2*(size_t) (hole_cap+1);
+      const size_t q_bytes    = sizeof(int)*(size_t) big_cap;
+      work = fga_dev_acquire(dev,SLOT_TILES,tile_bytes + pair_bytes + hole_bytes + move_bytes + q_bytes + 256);
+      if (work == NULL)
+        { fga_set_error("fga_seed_merge: device allocation failed");
+          goto done;
+        }
+      merge_tile *tiles = (merge_tile *) work;
+      merge_tile *pairs = tiles + (A.ntiles+1);
+      unsigned long long *holes = (unsigned long long *) (pairs + 2*(size_t) big_cap);
+      seed_move *moves = (seed_move *) (holes + 2*(size_t) hole_cap);
+      unsigned long long *wctr = (unsigned long long *) (moves + 2*(size_t) (hole_cap+1));
+      int *bigq = (int *) (wctr + 4);
+      A.tiles = tiles;
+
+      unsigned long long start_count = 0;           // an append starts behind the seeds already there
+      if (append != NULL)
+        start_count = (unsigned long long) S->count;
+
+      hipEventRecord(dev->ev0,dev->stream);
+      { int nb = (A.ntiles + 1 + 255) / 256;
+        hipLaunchKernelGGL(merge_partition_kernel,dim3(nb),dim3(256),0,dev->stream,A,tiles);
+      }
+      hipEventRecord(dev->ev1,dev->stream);
+      if (!use_wave)
+        { if (self)
+            hipLaunchKernelGGL(seed_merge_kernel<MODE_SELF>,dim3(grid),dim3(NT),0,dev->stream,A);
+          else if (prm->flip)
+            hipLaunchKernelGGL(seed_merge_kernel<MODE_FLIP>,dim3(grid),dim3(NT),0,dev->stream,A);
+          else
+            hipLaunchKernelGGL(seed_merge_kernel<MODE_PAIR>,dim3(grid),dim3(NT),0,dev->stream,A);
+        }
+      else
+        { wave_out W;
+          W.holes = holes; W.ctr = wctr; W.bigq = bigq; W.hole_cap = hole_cap; W.big_cap = big_cap;
+          hipMemsetAsync(wctr,0,4*sizeof(unsigned long long),dev->stream);
+          if (self)
+            hipLaunchKernelGGL(seed_merge_wave_kernel<MODE_SELF>,dim3(grid),dim3(64),0,dev->stream,A,W);
+          else if (prm->flip)
+            hipLaunchKernelGGL(seed_merge_wave_kernel<MODE_FLIP>,dim3(grid),dim3(64),0,dev->stream,A,W);
+          else
+            hipLaunchKernelGGL(seed_merge_wave_kernel<MODE_PAIR>,dim3(grid),dim3(64),0,dev->stream,A,W);
+          // the queued oversize tiles through the workgroup kernel (it reads their number from the device)
+          hipLaunchKernelGGL(gather_big_tiles_kernel,dim3((big_cap+255)/256),dim3(256),0,dev->stream,
+                             tiles,bigq,wctr+1,big_cap,pairs);
+          merge_args B = A;
+          B.tiles = pairs; B.pairs = 1; B.npairs = wctr+1; B.pair_cap = big_cap;
+          int bgrid = dev->ncu * 4;
+          if (bgrid > big_cap) bgrid = big_cap > 0 ? big_cap : 1;
+          if (self)
+            hipLaunchKernelGGL(seed_merge_kernel<MODE_SELF>,dim3(bgrid),dim3(NT),0,dev->stream,B);
+          else if (prm->flip)
+            hipLaunchKernelGGL(seed_merge_kernel<MODE_FLIP>,dim3(bgrid),dim3(NT),0,dev->stream,B);
+          else
+            hipLaunchKernelGGL(seed_merge_kernel<MODE_PAIR>,dim3(bgrid),dim3(NT),0,dev->stream,B);
+        }
+
+      unsigned long long hw[4] = {0,0,0,0};
+      err = hipMemcpyAsync(hc,counters,sizeof(hc),hipMemcpyDeviceToHost,dev->stream);
+      if (err == hipSuccess && use_wave)
+        err = hipMemcpyAsync(hw,wctr,sizeof(hw),hipMemcpyDeviceToHost,dev->stream);
+      if (err == hipSuccess) err = hipStreamSynchronize(dev->stream);
+      if (err == hipSuccess) err = hipGetLastError();
+      if (err != hipSuccess)
+        { fga_set_error("fga_seed_merge: kernel failed: %s",hipGetErrorString(err));
+          goto done;
+        }
+
+      if (use_wave && (int64_t) hw[1] > big_cap)
+        { // more oversize tiles than the queue holds (a pathologically repetitive input): redo everything with
+          // the workgroup kernel
+          hipMemcpyAsync(counters,&start_count,sizeof(unsigned long long),hipMemcpyHostToDevice,dev->stream);
+          hipStreamSynchronize(dev->stream);
+          fga_dev_release(dev,SLOT_TILES,work); work = NULL;
+          use_wave = 0;
+          continue;
+        }
+
+      if (use_wave && hw[0] > 0 && (int64_t) hc[0] <= phys)
+        { // close the holes: seeds at the end of the allocated range move into the unused chunk tails
+          const int nh = (int) hw[0];
+          std::vector<unsigned long long> hh(2*(size_t) nh);
+          if (hipMemcpy(hh.data(),holes,sizeof(unsigned long long)*2*(size_t) nh,hipMemcpyDeviceToHost) != hipSuccess)
+            { fga_set_error("fga_seed_merge: hole list download failed");
+              goto done;
+            }
+          std::vector<std::pair<int64_t,int64_t> > H((size_t) nh);
+          int64_t hsum = 0;
+          for (int i = 0; i < nh; i++)
+            { H[(size_t) i] = std::make_pair((int64_t) hh[2*(size_t) i],(int64_t) hh[2*(size_t) i+1]);
+              hsum += H[(size_t) i].second - H[(size_t) i].first;
+            }
+          std::sort(H.begin(),H.end());
+          const int64_t C = (int64_t) hc[0], D = C - hsum;          // allocated, dense
+          // sources: the occupied stretches of [D,C); destinations: the holes (clipped) below D
+          std::vector<std::pair<int64_t,int64_t> > src, dst;
+          { int64_t pos = D;
+            for (int i = 0; i < nh; i++)
+              { const int64_t hb = H[(size_t) i].first, he = H[(size_t) i].second;
+                if (he <= D) { dst.push_back(H[(size_t) i]); continue; }
+                if (hb < D) dst.push_back(std::make_pair(hb,D));
+                const int64_t b0 = hb > D ? hb : D;
+                if (b0 > pos) src.push_back(std::make_pair(pos,b0));
+                pos = he;
+              }
+            if (pos < C) src.push_back(std::make_pair(pos,C));
+          }
+          std::vector<seed_move> mv;
+          { size_t si = 0, di = 0;
+            int64_t so = 0, dof = 0;
+            while (si < src.size() && di < dst.size())
+              { const int64_t sl = src[si].second - src[si].first - so, dl = dst[di].second - dst[di].first - dof;
+                const int64_t l = sl < dl ? sl : dl;
+                seed_move m; m.src = src[si].first + so; m.dst = dst[di].first + dof; m.len = l;
+                if (l > 0) mv.push_back(m);
+                so += l; dof += l;
+                if (so == src[si].second - src[si].first) { si += 1; so = 0; }
+                if (dof == dst[di].second - dst[di].first) { di += 1; dof = 0; }
+              }
+          }
+          if (!mv.empty())
+            { if (mv.size() > 2*(size_t) (hole_cap+1))
+                { fga_set_error("fga_seed_merge: internal error, hole plan larger than its buffer");
+                  goto done;
+                }
+              if (hipMemcpyAsync(moves,mv.data(),sizeof(seed_move)*mv.size(),hipMemcpyHostToDevice,dev->stream) != hipSuccess)
+                { fga_set_error("fga_seed_merge: hole plan upload failed");
+                  goto done;
+                }
+              hipLaunchKernelGGL(hole_fill_kernel,dim3((unsigned) mv.size()),dim3(256),0,dev->stream,
+                                 S->seeds,moves,(int) mv.size());
+            }
+          hc[0] = (unsigned long long) D;
+          hipMemcpyAsync(counters,hc,sizeof(unsigned long long),hipMemcpyHostToDevice,dev->stream);
+        }
+      hipEventRecord(ev2,dev->stream);
+      if (hipStreamSynchronize(dev->stream) != hipSuccess)
+        { fga_set_error("fga_seed_merge: hole fill failed: %s",hipGetErrorString(hipGetLastError()));
+          goto done;
+        }
+      break;
     }
 #ifdef MERGE_PROF
   { unsigned long long hp[8], z[8] = {0,0,0,0,0,0,0,0};
     hipMemcpyFromSymbol(hp,HIP_SYMBOL(merge_prof),sizeof(hp));
     hipMemcpyToSymbol(HIP_SYMBOL(merge_prof),z,sizeof(z));
     double tot = 0; for (int k = 0; k < 6; k++) tot += (double) hp[k];
-    fprintf(stderr,"merge phases (%% of WG cycles): load %.1f  heads+keys %.1f  owner-scan %.1f  match %.1f  slots %.1f  emit %.1f\n",
-            100*hp[0]/tot,100*hp[1]/tot,100*hp[2]/tot,100*hp[3]/tot,100*hp[4]/tot,100*hp[5]/tot);
+    if (tot > 0)
+      fprintf(stderr,"merge phases (%% of WG cycles): load %.1f  heads+keys %.1f  owner-scan %.1f  match %.1f  slots %.1f  emit %.1f\n",
+              100*hp[0]/tot,100*hp[1]/tot,100*hp[2]/tot,100*hp[3]/tot,100*hp[4]/tot,100*hp[5]/tot);
   }
 #endif
   hipEventElapsedTime(&dev->last_ms[FGA_STAGE_MERGE_PARTITION],dev->ev0,dev->ev1);
   hipEventElapsedTime(&dev->last_ms[FGA_STAGE_MERGE],dev->ev1,ev2);
-  hipEventDestroy(ev2);
-  hipFree(tiles);
   S->count  = (int64_t) hc[0];
   S->tseed  = (int64_t) hc[1];
+  rc = 0;
+
+done:
+  if (ev2 != NULL) hipEventDestroy(ev2);
+  fga_dev_release(dev,SLOT_TILES,work);
+  if (rc != 0)
+    { if (append == NULL)
+        { hipFree(counters); fga_dev_release(dev,SLOT_SEEDS,S->seeds); free(S); }
+      return 1;
+    }
   if (out != NULL) *out = S;
   if (S->count > S->capacity)
     { fga_set_error("fga_seed_merge: %lld seeds exceed the buffer capacity %lld (re-run with a larger capacity)",
