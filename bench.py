@@ -167,7 +167,8 @@ def main():
                        "kernel_ms": {"merge": round(kavg, 3), "sort": round(last["sort_kernel_ms"], 3),
                                      "extend": round(last["extend_kernel_ms"], 3)},
                        "prep_s": round(prep_s, 1)},
-            "roofline": {"kernel": "seed_merge_kernel", "bound": "hbm", "achieved": achieved,
+            "roofline": {"kernel": "seed_merge_wave_kernel (+ seed_merge_kernel on oversize tiles, hole closing; "
+                                   "HIP events around the whole merge launch)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "algorithmic_bytes": int(alg_bytes), "kernel_ms": kavg},
         }
@@ -200,13 +201,15 @@ def pmc_traffic():
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv")))
     if not files:
         return None, None
+    # the merge is two kernels per launch: seed_merge_wave_kernel (one wavefront per tile) and seed_merge_kernel
+    # (workgroup per tile, only the oversize tiles the wave kernel queued); their traffic adds up
     fetch = write = None
     for r in csv.DictReader(open(files[-1])):
-        if "seed_merge_kernel" in r["kernel"]:
+        if "seed_merge_wave_kernel" in r["kernel"] or "seed_merge_kernel" in r["kernel"]:
             if r["counter"] == "FETCH_SIZE":
-                fetch = float(r["avg_per_launch"])
+                fetch = (fetch or 0.0) + float(r["avg_per_launch"])
             elif r["counter"] == "WRITE_SIZE":
-                write = float(r["avg_per_launch"])
+                write = (write or 0.0) + float(r["avg_per_launch"])
     if fetch is None or write is None:
         return None, None
     return int((2.0 * fetch + write) * 1024), os.path.relpath(files[-1], ROOT)

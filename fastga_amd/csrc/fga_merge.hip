@@ -731,6 +731,7 @@ static_assert(WTILE_COST == 256,"the per-lane owner scan and the owner clear ass
 #endif
 
 #define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL,"wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#define T2_LCP(j) ((rawd[(o2 + (uint32_t) (j)*E2 + 8) >> 2] >> (8*((o2 + (uint32_t) (j)*E2 + 8) & 3))) & 0xff)
 
 struct wave_out
   { unsigned long long *holes;      // [2*hole_cap] begin,end of unused slot ranges
@@ -762,14 +763,19 @@ __device__ __forceinline__ int wave_incl_scan_max_dpp(int v)      // v >= 0
   return x;
 }
 
+#ifndef WAVE_OCC
+#define WAVE_OCC 5                      // resident wavefronts per SIMD the register budget is held to
+#endif
+
 template <int MODE>
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVE_OCC,WAVE_OCC)))
 void seed_merge_wave_kernel(merge_args A, wave_out W)
 { __shared__ uint16_t la[WPCAP+1];
   __shared__ uint16_t lb[WPCAP+1];
   __shared__ __attribute__((aligned(16))) uint8_t  raw[WRAWCAP];
   __shared__ __attribute__((aligned(16))) uint64_t keyB[WTILE_COST];
   __shared__ __attribute__((aligned(16))) uint16_t own[WTILE_COST];
+  __shared__ uint8_t sown[64*16];              // seed slot -> lane of the T1 entry that emits it (fast emit path)
 
   const int lane = threadIdx.x;
   const int E1 = A.E1, E2 = A.E2;
@@ -922,12 +928,13 @@ void seed_merge_wave_kernel(merge_args A, wave_out W)
           const uint32_t oe = o1 + (uint32_t) i*E1;
           const int pb0 = q ? (int) lb[q-1] : 0, pb1 = (int) lb[q];
           const uint64_t ks = (MODE == MODE_SELF) ? keyB[i] : lds_read_key(rawd,oe);
-          int low, hgh, plen, lbnd;
+          int low, hgh, plen, lbnd, lnb, lna;       // lnb / lna: LCP with the T2 neighbour before / after (-1: none)
           if (MODE == MODE_SELF)
             { int lk  = (i > pb0)   ? lcp_key(ks,keyB[i-1]) : 0;
               int lk1 = (i+1 < pb1) ? lcp_key(ks,keyB[i+1]) : 11;
               plen = lk > lk1 ? lk : lk1;
               low = i; hgh = i+1; lbnd = i;
+              lnb = (i > pb0) ? lk : -1; lna = (i+1 < pb1) ? lk1 : -1;
             }
           else
             { int lo = pb0, hi = pb1;
@@ -940,11 +947,22 @@ void seed_merge_wave_kernel(merge_args A, wave_out W)
               int lc_ = (lo < pb1) ? lcp_key(ks,keyB[lo]) : 0;
               plen = la_ > lc_ ? la_ : lc_;
               low = hgh = lbnd = lo;
+              lnb = (lo > pb0) ? la_ : -1; lna = (lo < pb1) ? lc_ : -1;
             }
-          while (low > pb0 && lbnd-low <= freq && lcp_key(ks,keyB[low-1]) >= plen)
-            low -= 1;
-          while (hgh < pb1 && hgh-low <= freq && lcp_key(ks,keyB[hgh]) >= plen)
-            hgh += 1;
+          // run growth.  The first step on either side compares s with its T2 neighbour (lnb / lna, known already);
+          // every further step asks whether the NEXT T2 entry still shares plen bases with its own predecessor,
+          // which is the table's lcp byte (byte 8 of the entry, exact inside a panel -- the reference's vlcp[] walk,
+          // FastGA.c:760-820, relies on the same bytes): one dword read instead of a 64-bit key compare
+          if (lnb >= plen)
+            { low -= 1;
+              while (low > pb0 && lbnd-low <= freq && (int) T2_LCP(low) >= plen)
+                low -= 1;
+            }
+          if (lna >= plen && hgh < pb1 && hgh-low <= freq)
+            { hgh += 1;
+              while (hgh < pb1 && hgh-low <= freq && (int) T2_LCP(hgh) >= plen)
+                hgh += 1;
+            }
           if (hgh-low >= freq)
             continue;
           const int mlen = A.soft_mask ? plen : 41;
@@ -989,7 +1007,39 @@ void seed_merge_wave_kernel(merge_args A, wave_out W)
               const uint32_t bhi = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (b >> 32));
               nbase = (int64_t) (((uint64_t) bhi << 32) | blo);
             }
-          if (total > 0)
+          // seed-parallel emission (the common case: one match round, no per-pair filter): every lane marks its
+          // slots with its lane id, then lane = slot -- full wavefronts instead of a loop of max-count iterations
+#ifndef WAVE_FAST_EMIT        // measured: +3 % at 4 waves/SIMD, but its registers cost the 5th wave (-30 %): off by default
+          if (0)
+#else
+          if (MODE != MODE_FLIP && !A.soft_mask && nlive <= 64 && T <= 64*16)
+#endif
+            { const int cnt0 = r_cnt[0];
+              for (int q = 0; q < cnt0; q++)
+                sown[off + q] = (uint8_t) lane;
+              WSYNC();
+              const int i0 = r_i[0], low0 = r_low[0] & 0xffff, plen0 = r_plen[0];
+              for (int sb = 0; sb < T; sb += 64)           // wave-uniform trip count: __shfl needs every lane
+                { const int sl = sb + lane;
+                  const bool on = sl < T;
+                  const int ow = on ? (int) sown[sl] : 0;
+                  const int i = __shfl(i0,ow,64), lo_ = __shfl(low0,ow,64), pl = __shfl(plen0,ow,64), of = __shfl(off,ow,64);
+                  if (on)
+                    { int j = lo_ + (sl - of);
+                      if (MODE == MODE_SELF && j >= i)
+                        j += 1;
+                      uint32_t e0, e1_, e2_, e3, spos, sctg, ssign, c0, c1, c2, c3, cpos, cctg, csign;
+                      lds_read16(rawd,o1 + (uint32_t) i*E1,e0,e1_,e2_,e3);
+                      split_payload(e2_,e3,A.post1,A.cont1,spos,sctg,ssign);
+                      lds_read16(rawd,o2 + (uint32_t) j*E2,c0,c1,c2,c3);
+                      split_payload(c2,c3,A.post2,A.cont2,cpos,cctg,csign);
+                      const int64_t at = ((int64_t) sl < rem) ? chunk_pos + sl : nbase + ((int64_t) sl - rem);
+                      if (at < A.cap)
+                        A.out[at] = make_seed<MODE>(pl,spos,sctg,ssign,cpos,cctg,csign);
+                    }
+                }
+            }
+          else if (total > 0)
             { const int mfull = A.soft_mask;
               #pragma unroll
               for (int r = 0; r < WEPT; r++)
@@ -1162,7 +1212,7 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
   for (int attempt = 0; attempt < 2; attempt++)
     { A.tile_cost = use_wave ? WTILE_COST : TILE_COST;
       A.ntiles = (int) (total / A.tile_cost) + 1;
-      int wgs = use_wave ? 20 : 4;
+      int wgs = use_wave ? 4*WAVE_OCC : 4;
       { const char *ev = getenv(use_wave ? "FGA_MERGE_WAVES" : "FGA_MERGE_WGS");
         if (ev != NULL && atoi(ev) > 0) wgs = atoi(ev);
       }
