@@ -775,7 +775,9 @@ void seed_merge_wave_kernel(merge_args A, wave_out W)
   __shared__ __attribute__((aligned(16))) uint8_t  raw[WRAWCAP];
   __shared__ __attribute__((aligned(16))) uint64_t keyB[WTILE_COST];
   __shared__ __attribute__((aligned(16))) uint16_t own[WTILE_COST];
+#ifdef WAVE_FAST_EMIT
   __shared__ uint8_t sown[64*16];              // seed slot -> lane of the T1 entry that emits it (fast emit path)
+#endif
 
   const int lane = threadIdx.x;
   const int E1 = A.E1, E2 = A.E2;
@@ -783,33 +785,14 @@ void seed_merge_wave_kernel(merge_args A, wave_out W)
   unsigned long long tsum = 0;
   int64_t chunk_pos = 0, chunk_end = 0;         // this wavefront's current output chunk (wave-uniform)
 
-  uint32_t pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0, pfacc = 0;
   merge_tile nt0 = A.tiles[blockIdx.x < (unsigned) A.ntiles ? blockIdx.x : 0];
   merge_tile nt1 = A.tiles[blockIdx.x < (unsigned) A.ntiles ? blockIdx.x+1 : 0];
   for (int tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x)
     { const merge_tile t0 = nt0;
       const merge_tile t1 = nt1;
-      const uint32_t ppf = pf0 + pf1 + pf2 + pf3;
       { const int nx = tile + gridDim.x;
         if (nx < A.ntiles)
           { nt0 = A.tiles[nx]; nt1 = A.tiles[nx+1];
-            const int64_t q1 = nt0.a*E1, r1 = nt1.a*E1;
-            const int64_t q2 = ((MODE == MODE_SELF) ? nt0.a : nt0.b)*E2, r2 = ((MODE == MODE_SELF) ? nt1.a : nt1.b)*E2;
-            const int np2 = nt1.p - nt0.p;
-            int64_t off = (q1 & ~(int64_t) 63) + 64*(int64_t) lane;
-            pf0 = pf1 = pf2 = pf3 = 0;
-            if (off < r1 && r1 - q1 <= WRAWCAP)
-              pf0 = l2_touch(A.tab1 + off);
-            if (MODE != MODE_SELF)
-              { off = (q2 & ~(int64_t) 63) + 64*(int64_t) lane;
-                if (off < r2 && r2 - q2 <= WRAWCAP)
-                  pf1 = l2_touch(A.tab2 + off);
-              }
-            if (lane*8 < np2 && np2 <= WPCAP)
-              { pf2 = l2_touch((const uint8_t *) (A.idx1 + nt0.p + lane*8));
-                if (MODE != MODE_SELF)
-                  pf3 = l2_touch((const uint8_t *) (A.idx2 + nt0.p + lane*8));
-              }
           }
       }
       const int p0 = t0.p, p1 = t1.p;
@@ -854,7 +837,6 @@ void seed_merge_wave_kernel(merge_args A, wave_out W)
         { la[q] = (uint16_t) (A.idx1[p0+q] - a0);
           lb[q] = (MODE == MODE_SELF) ? la[q] : (uint16_t) (A.idx2[p0+q] - b0);
         }
-      pfacc += ppf;
       ((uint2 *) own)[lane] = make_uint2(0,0);       // WTILE_COST = 4 entries per lane
       WSYNC();
 
@@ -1009,11 +991,8 @@ void seed_merge_wave_kernel(merge_args A, wave_out W)
             }
           // seed-parallel emission (the common case: one match round, no per-pair filter): every lane marks its
           // slots with its lane id, then lane = slot -- full wavefronts instead of a loop of max-count iterations
-#ifndef WAVE_FAST_EMIT        // measured: +3 % at 4 waves/SIMD, but its registers cost the 5th wave (-30 %): off by default
-          if (0)
-#else
+#ifdef WAVE_FAST_EMIT         // measured: +3 % at 4 waves/SIMD, but its registers cost the 5th wave (-30 %): off by default
           if (MODE != MODE_FLIP && !A.soft_mask && nlive <= 64 && T <= 64*16)
-#endif
             { const int cnt0 = r_cnt[0];
               for (int q = 0; q < cnt0; q++)
                 sown[off + q] = (uint8_t) lane;
@@ -1039,7 +1018,9 @@ void seed_merge_wave_kernel(merge_args A, wave_out W)
                     }
                 }
             }
-          else if (total > 0)
+          else
+#endif
+          if (total > 0)
             { const int mfull = A.soft_mask;
               #pragma unroll
               for (int r = 0; r < WEPT; r++)
@@ -1081,7 +1062,6 @@ void seed_merge_wave_kernel(merge_args A, wave_out W)
       if ((int64_t) h < W.hole_cap)
         { W.holes[2*h] = (unsigned long long) chunk_pos; W.holes[2*h+1] = (unsigned long long) chunk_end; }
     }
-  asm volatile("" :: "v"(pfacc));
   #pragma unroll
   for (int d = 32; d >= 1; d >>= 1)
     tsum += __shfl_xor(tsum,d,64);
