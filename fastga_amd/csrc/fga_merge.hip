@@ -77,6 +77,7 @@ struct merge_args
     int64_t base;                     // cost(pbeg-1)
     int   ntiles;
     int   tile_cost;                  // cost units per tile of this launch's partition
+    int   wrawcap;                    // bytes of the wave kernel's raw-entry LDS buffer
     int   pairs;                      // tiles[] holds (begin,end) descriptor pairs of queued tiles; count in *npairs
     const unsigned long long *npairs; int pair_cap;
     const merge_tile *tiles;
@@ -772,7 +773,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVE_OCC,WAV
 void seed_merge_wave_kernel(merge_args A, wave_out W)
 { __shared__ uint16_t la[WPCAP+1];
   __shared__ uint16_t lb[WPCAP+1];
-  __shared__ __attribute__((aligned(16))) uint8_t  raw[WRAWCAP];
+  extern __shared__ __attribute__((aligned(16))) uint8_t raw[];      // A.wrawcap bytes (sized by the entry widths)
   __shared__ __attribute__((aligned(16))) uint64_t keyB[WTILE_COST];
   __shared__ __attribute__((aligned(16))) uint16_t own[WTILE_COST];
 #ifdef WAVE_FAST_EMIT
@@ -809,7 +810,7 @@ void seed_merge_wave_kernel(merge_args A, wave_out W)
       const int64_t s1a = s1 & ~(int64_t) 15, s2a = s2 & ~(int64_t) 15;
       const int64_t len1 = ((e1 - s1a) + 15) & ~(int64_t) 15;
       const int64_t len2 = (MODE == MODE_SELF) ? 0 : (((e2 - s2a) + 15) & ~(int64_t) 15);
-      if (np > WPCAP-1 || n1l + n2l > WTILE_COST || len1 + len2 > WRAWCAP - 32)
+      if (np > WPCAP-1 || n1l + n2l > WTILE_COST || len1 + len2 > A.wrawcap - 32)
         { if (lane == 0)                            // oversize: the workgroup kernel takes it afterwards
             { const unsigned long long q = atomicAdd(W.ctr+1,1ull);
               if ((int64_t) q < W.big_cap)
@@ -1182,6 +1183,9 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
   A.out = S->seeds; A.cap = phys;
   A.count = counters; A.tseed = counters+1;
   A.pairs = 0; A.npairs = NULL; A.pair_cap = 0;
+  { const int emax = A.E1 > A.E2 ? A.E1 : A.E2;           // two 16-byte-aligned ranges of <= WTILE_COST entries in all
+    A.wrawcap = ((WTILE_COST*emax + 96 + 15) / 16) * 16;
+  }
 
   void *work = NULL;                      // tiles + (wave kernel) pairs, holes, counters, queue, moves
   unsigned long long hc[2];
@@ -1196,7 +1200,7 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
       { const char *ev = getenv(use_wave ? "FGA_MERGE_WAVES" : "FGA_MERGE_WGS");
         if (ev != NULL && atoi(ev) > 0) wgs = atoi(ev);
       }
-      if (use_wave && wgs > 32) wgs = 32;                    // the slack of phys_capacity covers 32 waves per CU
+      if (use_wave && wgs > 24) wgs = 24;                    // the slack of phys_capacity covers 32 waves per CU
       int grid = dev->ncu * wgs;
       if (use_wave && grid > A.ntiles/8 + 1) grid = A.ntiles/8 + 1;      // small inputs: few waves, few holes
       if (grid > A.ntiles) grid = A.ntiles;
@@ -1242,11 +1246,11 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
           W.holes = holes; W.ctr = wctr; W.bigq = bigq; W.hole_cap = hole_cap; W.big_cap = big_cap;
           hipMemsetAsync(wctr,0,4*sizeof(unsigned long long),dev->stream);
           if (self)
-            hipLaunchKernelGGL(seed_merge_wave_kernel<MODE_SELF>,dim3(grid),dim3(64),0,dev->stream,A,W);
+            hipLaunchKernelGGL(seed_merge_wave_kernel<MODE_SELF>,dim3(grid),dim3(64),A.wrawcap,dev->stream,A,W);
           else if (prm->flip)
-            hipLaunchKernelGGL(seed_merge_wave_kernel<MODE_FLIP>,dim3(grid),dim3(64),0,dev->stream,A,W);
+            hipLaunchKernelGGL(seed_merge_wave_kernel<MODE_FLIP>,dim3(grid),dim3(64),A.wrawcap,dev->stream,A,W);
           else
-            hipLaunchKernelGGL(seed_merge_wave_kernel<MODE_PAIR>,dim3(grid),dim3(64),0,dev->stream,A,W);
+            hipLaunchKernelGGL(seed_merge_wave_kernel<MODE_PAIR>,dim3(grid),dim3(64),A.wrawcap,dev->stream,A,W);
           // the queued oversize tiles through the workgroup kernel (it reads their number from the device)
           hipLaunchKernelGGL(gather_big_tiles_kernel,dim3((big_cap+255)/256),dim3(256),0,dev->stream,
                              tiles,bigq,wctr+1,big_cap,pairs);
