@@ -53,6 +53,7 @@ enum { SLOT_SEEDS = 0, SLOT_SORT0, SLOT_SORT1, SLOT_HIST, SLOT_TILES, SLOT_CELLS
 void *fga_dev_acquire(fga_dev *dev, int slot, size_t bytes);   // NULL on failure; pair with fga_dev_release
 void  fga_dev_release(fga_dev *dev, int slot, void *ptr);
 void *fga_dev_pinned(fga_dev *dev, size_t bytes);              // host pinned staging, grow-only
+int   fga_radix_sort_u128(fga_dev *dev, uint4 *buf0, uint4 *buf1, int64_t n, int lowbit, int nbits, uint4 **sorted);
 
 struct fga_dseeds
   { fga_dev  *dev;

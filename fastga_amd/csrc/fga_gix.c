@@ -193,7 +193,7 @@ int            fga_gix_postbytes(const fga_gix *X) { return X->postbytes; }
 int            fga_gix_contbytes(const fga_gix *X) { return X->contbytes; }
 int            fga_gix_nctg(const fga_gix *X)      { return X->nctg; }
 int            fga_gix_nparts(const fga_gix *X)    { return X->nparts; }
-int64_t        fga_gix_part_begin(const fga_gix *X, int p) { return (p < 0 || p > X->nparts) ? -1 : X->partbeg[p]; }
+int64_t        fga_gix_part_begin(const fga_gix *X, int p) { return (p < 0 || p > X->nparts || X->partbeg == NULL) ? -1 : X->partbeg[p]; }
 int64_t        fga_gix_maxpre(const fga_gix *X)    { return X->maxpre; }
 const int     *fga_gix_perm(const fga_gix *X)      { return X->perm; }
 const int64_t *fga_gix_index(const fga_gix *X)     { return X->index; }
@@ -418,6 +418,106 @@ static int write_full(int fd, const void *buf, int64_t n)
   return 0;
 }
 
+/* Layout of the index of `G` for a given -T: contig order by decreasing length (ties keep the input order; the contig
+ * count is padded to >= nthreads with fake 40-base contigs, short_GDB_fix, GIXmake.c:1605-1624), payload byte widths
+ * and the number of table parts (GIXmake.c:1907-1963).  perm / invp are malloc'd. */
+int fga_gix_layout(const fga_gdb *G, int nthreads, int *nctg_out, int **perm_out, int **invp_out,
+                   int *postbytes_out, int *contbytes_out, int *nparts_out)
+{ int      nreal = G->ncontig, nctg, i;
+  int64_t *clen = NULL;
+  int     *perm = NULL, *invp = NULL;
+  int      postbytes, contbytes, nparts;
+
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 32) nthreads = 32;
+  nctg = nreal < nthreads ? nthreads : nreal;
+  clen = malloc(sizeof(int64_t)*nctg);
+  perm = malloc(sizeof(int)*nctg);
+  invp = malloc(sizeof(int)*nctg);
+  if (clen == NULL || perm == NULL || invp == NULL) goto oom;
+  for (i = 0; i < nctg; i++)
+    clen[i] = (i < nreal) ? G->contigs[i].clen : FGA_KMER;
+  for (i = 0; i < nctg; i++)
+    perm[i] = i;
+  { int a;                            /* stable merge sort */
+    int *tmp = malloc(sizeof(int)*nctg);
+    int width;
+    if (tmp == NULL) goto oom;
+    for (width = 1; width < nctg; width *= 2)
+      { for (a = 0; a < nctg; a += 2*width)
+          { int mid = a+width < nctg ? a+width : nctg;
+            int hi  = a+2*width < nctg ? a+2*width : nctg;
+            int x = a, y = mid, k = a;
+            while (x < mid && y < hi)
+              tmp[k++] = (clen[perm[y]] > clen[perm[x]]) ? perm[y++] : perm[x++];
+            while (x < mid) tmp[k++] = perm[x++];
+            while (y < hi)  tmp[k++] = perm[y++];
+          }
+        memcpy(perm,tmp,sizeof(int)*nctg);
+      }
+    free(tmp);
+  }
+  for (i = 0; i < nctg; i++)
+    invp[perm[i]] = i;
+
+  { int64_t range = 0, cum;
+    for (i = 0; i < nctg; i++)
+      if (clen[i] > range) range = clen[i];
+    postbytes = 0;
+    for (cum = 1; cum < range; cum *= 256) postbytes += 1;
+    range = 2*(int64_t) nctg;
+    contbytes = 0;
+    for (cum = 1; cum < range; cum *= 256) contbytes += 1;
+  }
+  if (postbytes + contbytes > 8)
+    { fga_set_error("payload wider than 8 bytes is not supported");
+      free(clen); free(perm); free(invp);
+      return 1;
+    }
+  { int64_t seqtot = G->seqtot + (int64_t) (nctg-nreal)*FGA_KMER;
+    int64_t nels = 0x100000000ll / (contbytes + postbytes + FGA_KMER/4 + 2);
+    int     nbit = (int) ((.81 * (seqtot - (FGA_KMER-1)*(int64_t) nctg)) / nels);
+    nparts = ((nbit-1)/nthreads+1)*nthreads;
+    if (nparts < 8) nparts = 8;
+    else if (nparts > 64) nparts = 64;
+  }
+  free(clen);
+  *nctg_out = nctg; *perm_out = perm; *invp_out = invp;
+  *postbytes_out = postbytes; *contbytes_out = contbytes; *nparts_out = nparts;
+  return 0;
+oom:
+  fga_set_error("out of memory building index");
+  free(clen); free(perm); free(invp);
+  return 1;
+}
+
+/* split of the k-mer space into parts at 5-base (10-bit) buckets from the syncmer sample histogram (GIXmake.c:655-691) */
+void fga_gix_ksplit(const int64_t *sbuck, int nparts, int *ksplit)
+{ int64_t buck[1024], t;
+  int b, n;
+  buck[0] = sbuck[0];
+  for (b = 1; b < 1024; b++)
+    buck[b] = buck[b-1] + sbuck[b];
+  ksplit[0] = 0;
+  n = 1;
+  t = buck[1023]/nparts;
+  for (b = 0; b < 1024 && n < nparts; b++)
+    if (buck[b] >= t)
+      { int64_t prev = b > 0 ? buck[b-1] : 0;
+        if (buck[b]-t > t-prev)
+          ksplit[n] = b;
+        else
+          ksplit[n] = b+1;
+        n += 1;
+        t = (n*buck[1023])/nparts;
+      }
+  while (n <= nparts)
+    ksplit[n++] = 1024;
+  ksplit[nparts] = 1024;
+}
+
+const uint8_t *fga_gix_tmap(void) { return TMap; }
+
 /* Build <root>.gix + .<root>.ktab.* for `gdb`.  `nthreads` plays the role of GIXmake's -T: it sets the
  * worker count, the number of table parts (GIXmake.c:1907-1917) and the padding of the contig count to
  * >= nthreads with fake 40-base contigs (short_GDB_fix, GIXmake.c:1605-1624).                          */
@@ -444,61 +544,13 @@ int fga_gix_build_masked(const fga_gdb *G, const char *target, int nthreads, int
 
   if (nthreads < 1) nthreads = 1;
   if (nthreads > 32) nthreads = 32;
-
-  /* contig order: length descending (GIXmake.c:1948-1963); ties keep input order */
-  nctg = nreal < nthreads ? nthreads : nreal;
+  if (fga_gix_layout(G,nthreads,&nctg,&perm,&invp,&postbytes,&contbytes,&nparts))
+    goto fail;
+  ebytes = 9 + postbytes + contbytes;
   clen = malloc(sizeof(int64_t)*nctg);
-  perm = malloc(sizeof(int)*nctg);
-  invp = malloc(sizeof(int)*nctg);
-  if (clen == NULL || perm == NULL || invp == NULL) goto oom;
+  if (clen == NULL) goto oom;
   for (i = 0; i < nctg; i++)
     clen[i] = (i < nreal) ? G->contigs[i].clen : FGA_KMER;
-  for (i = 0; i < nctg; i++)
-    perm[i] = i;
-  { int a, b;                         /* stable insertion/merge: nctg is small (<= 1e5..1e6) */
-    int *tmp = malloc(sizeof(int)*nctg);
-    int width;
-    if (tmp == NULL) goto oom;
-    for (width = 1; width < nctg; width *= 2)
-      { for (a = 0; a < nctg; a += 2*width)
-          { int mid = a+width < nctg ? a+width : nctg;
-            int hi  = a+2*width < nctg ? a+2*width : nctg;
-            int x = a, y = mid, k = a;
-            while (x < mid && y < hi)
-              tmp[k++] = (clen[perm[y]] > clen[perm[x]]) ? perm[y++] : perm[x++];
-            while (x < mid) tmp[k++] = perm[x++];
-            while (y < hi)  tmp[k++] = perm[y++];
-          }
-        memcpy(perm,tmp,sizeof(int)*nctg);
-      }
-    free(tmp);
-    (void) b;
-  }
-  for (i = 0; i < nctg; i++)
-    invp[perm[i]] = i;
-
-  { int64_t range = 0, cum;
-    for (i = 0; i < nctg; i++)
-      if (clen[i] > range) range = clen[i];
-    postbytes = 0;
-    for (cum = 1; cum < range; cum *= 256) postbytes += 1;
-    range = 2*(int64_t) nctg;
-    contbytes = 0;
-    for (cum = 1; cum < range; cum *= 256) contbytes += 1;
-  }
-  ebytes = 9 + postbytes + contbytes;
-  if (postbytes + contbytes > 8)
-    { fga_set_error("payload wider than 8 bytes is not supported");
-      goto fail;
-    }
-
-  { int64_t seqtot = G->seqtot + (int64_t) (nctg-nreal)*FGA_KMER;
-    int64_t nels = 0x100000000ll / (contbytes + postbytes + FGA_KMER/4 + 2);
-    int     nbit = (int) ((.81 * (seqtot - (FGA_KMER-1)*(int64_t) nctg)) / nels);
-    nparts = ((nbit-1)/nthreads+1)*nthreads;
-    if (nparts < 8) nparts = 8;
-    else if (nparts > 64) nparts = 64;
-  }
 
   count = calloc(FGA_NPREFIX,sizeof(uint32_t));
   index = malloc(sizeof(int64_t)*FGA_NPREFIX);
@@ -568,30 +620,10 @@ int fga_gix_build_masked(const fga_gdb *G, const char *target, int nthreads, int
   dir  = fga_path_dir(noext);
   root = fga_path_root(noext,NULL);
 
-  { int64_t buck[1024];
-    int     ksplit[65];
-    int     n, b, part;
-    int64_t t;
+  { int     ksplit[65];
+    int     part;
 
-    buck[0] = sbuck[0];                                /* cumulative sample histogram */
-    for (b = 1; b < 1024; b++)
-      buck[b] = buck[b-1] + sbuck[b];
-    ksplit[0] = 0;
-    n = 1;
-    t = buck[1023]/nparts;
-    for (b = 0; b < 1024 && n < nparts; b++)
-      if (buck[b] >= t)
-        { int64_t prev = b > 0 ? buck[b-1] : 0;
-          if (buck[b]-t > t-prev)
-            ksplit[n] = b;
-          else
-            ksplit[n] = b+1;
-          n += 1;
-          t = (n*buck[1023])/nparts;
-        }
-    while (n <= nparts)
-      ksplit[n++] = 1024;
-    ksplit[nparts] = 1024;
+    fga_gix_ksplit(sbuck,nparts,ksplit);
 
     obuf = malloc((size_t) ebytes * 65536);
     if (obuf == NULL) goto oom;

@@ -1,0 +1,491 @@
+// fga_gixdev.hip -- the genome index (GIX) built on the device, straight into HBM.
+//
+// Replaces GIXmake for the seed merge's input (reference GIXmake.c: sample / distribution / sort / merge threads and the
+// .ktab / .gix writers): every 40-mer that starts with a closed (12,8)-syncmer under the TMap 4-mer order, both strands,
+// sorted by (k-mer, payload), in the on-disk entry layout [7 suffix bytes | mask | lcp | post LE | contig|sign LE] with the
+// int64[2^24] inclusive prefix index -- byte for byte what fga_gix_build (fga_gix.c, pinned against the reference's
+// GIXmake) writes and fga_dgix_upload would load, so the merge kernels take it unchanged.  Nothing touches the disk:
+// FASTA -> GDB (host parse) -> 2-bit image in HBM -> this -> seed merge.
+//
+//   gix_scan_kernel      one workgroup per 2048 positions of a contig: unpacks the bases into LDS, canonical 8-mer codes,
+//                        sliding minimum over five codes -> syncmer starts; every (syncmer, strand) whose 40-mer fits the
+//                        contig becomes one 128-bit sort key  [80-bit k-mer | payload]  appended through one atomic per
+//                        workgroup; per-prefix counts and GIXmake's 5-base sample histogram (which decides the table
+//                        parts, hence where the lcp byte restarts at 0) by atomics
+//   fga_radix_sort_u128  the seed sort's LSD radix kernels on the significant key bits
+//   gix_index_*_kernel   inclusive scan of the 2^24 prefix counts -> the index
+//   gix_entries_kernel   one thread per sorted key: lcp with its predecessor (0 at a part start), on-disk entry bytes
+#include "fga_device.hpp"
+
+#define GCH   2048            // positions per workgroup
+#define GNT   256
+#define GPER  (GCH/GNT)
+
+__constant__ uint8_t gix_tmap[256];
+
+struct gix_item { int ctg; int j0; };
+
+struct gix_scan_args
+  { const uint8_t *img;             // 2-bit image, contigs byte aligned, base i in bits 2*(i&3) of byte i>>2
+    const int64_t *boff;            // byte offset of each contig
+    const int64_t *clen;
+    const int     *invp;            // original contig -> length-sorted index
+    const gix_item *items; int nitems;
+    int postbytes, contbytes;
+    uint4 *keys; int64_t cap;
+    unsigned long long *nkeys;
+    uint32_t *count;                // [2^24]
+    unsigned long long *sbuck;      // [1024]
+  };
+
+__device__ __forceinline__ uint32_t comp4(uint32_t x)     // reverse complement of a packed 4-mer
+{ x = ~x & 0xff;
+  return ((x & 0x03) << 6) | ((x & 0x0c) << 2) | ((x & 0x30) >> 2) | ((x & 0xc0) >> 6);
+}
+
+__global__ __launch_bounds__(GNT)
+void gix_scan_kernel(gix_scan_args A)
+{ __shared__ uint8_t  sb[GCH + 96];           // bases of [j0-28, j0+GCH+44), 4 = outside the contig
+  __shared__ uint16_t v8[GCH + 8];            // canonical 8-mer code at j0 + x
+  __shared__ uint32_t sh[1024];
+  __shared__ int      wtot[GNT/64];
+  __shared__ unsigned long long gbase;
+
+  const int tid = threadIdx.x;
+  const gix_item it = A.items[blockIdx.x];
+  const int c = it.ctg, j0 = it.j0;
+  const int64_t len = A.clen[c];
+  const uint8_t *img = A.img + A.boff[c];
+  for (int x = tid; x < 1024; x += GNT)
+    sh[x] = 0;
+  for (int x = tid; x < GCH + 96; x += GNT)
+    { const int64_t b = (int64_t) j0 - 28 + x;
+      uint8_t v = 4;
+      if (b >= 0 && b < len)
+        v = (img[b >> 2] >> (2*(b & 3))) & 3;
+      sb[x] = v;
+    }
+  __syncthreads();
+  const uint8_t *s = sb + 28;                 // s[x] = base at j0 + x
+  for (int x = tid; x < GCH + 8; x += GNT)
+    { uint16_t v = 0xffff;
+      if ((int64_t) j0 + x + 8 <= len)
+        { const uint32_t a = (s[x] << 6) | (s[x+1] << 4) | (s[x+2] << 2) | s[x+3];
+          const uint32_t b = (s[x+4] << 6) | (s[x+5] << 4) | (s[x+6] << 2) | s[x+7];
+          const uint32_t mn = ((uint32_t) gix_tmap[a] << 8) | gix_tmap[b];
+          const uint32_t mc = ((uint32_t) gix_tmap[comp4(b)] << 8) | gix_tmap[comp4(a)];
+          v = (uint16_t) (mn < mc ? mn : mc);
+        }
+      v8[x] = v;
+    }
+  __syncthreads();
+
+  // which of my positions start a syncmer, and which strands fit
+  uint32_t fmask = 0, cmask = 0;
+  int cnt = 0;
+  #pragma unroll
+  for (int r = 0; r < GPER; r++)
+    { const int x = r*GNT + tid;
+      const int64_t j = (int64_t) j0 + x;
+      if (j + 12 > len)
+        continue;
+      uint16_t m = v8[x];
+      #pragma unroll
+      for (int q = 1; q <= 4; q++)
+        m = v8[x+q] < m ? v8[x+q] : m;
+      if (v8[x] != m && v8[x+4] != m)
+        continue;
+      // GIXmake's sample: every syncmer, both strands, whether or not the 40-mer fits
+      { uint32_t f5 = 0, c5 = 0;
+        #pragma unroll
+        for (int k = 0; k < 5; k++)
+          { f5 = (f5 << 2) | s[x+k];
+            c5 = (c5 << 2) | (3u - s[x+11-k]);
+          }
+        atomicAdd(&sh[f5],1u);
+        atomicAdd(&sh[c5],1u);
+      }
+      if (j <= len - FGA_KMER) { fmask |= 1u << r; cnt += 1; }
+      if (j >= FGA_KMER - 12)  { cmask |= 1u << r; cnt += 1; }
+    }
+
+  // slots: block exclusive scan, one global atomic per workgroup
+  int inc = cnt;
+  for (int d = 1; d < 64; d <<= 1)
+    { const int y = __shfl_up(inc,d,64);
+      if ((tid & 63) >= d) inc += y;
+    }
+  if ((tid & 63) == 63)
+    wtot[tid >> 6] = inc;
+  __syncthreads();
+  int base = inc - cnt, total = 0;
+  for (int w = 0; w < GNT/64; w++)
+    { if (w < (tid >> 6)) base += wtot[w];
+      total += wtot[w];
+    }
+  if (tid == 0)
+    gbase = total > 0 ? atomicAdd(A.nkeys,(unsigned long long) total) : 0ull;
+  __syncthreads();
+  int64_t at = (int64_t) gbase + base;
+
+  const uint64_t ctg = (uint64_t) A.invp[c];
+  const uint64_t sign = 0x80ull << (8*(A.contbytes-1));
+  #pragma unroll
+  for (int r = 0; r < GPER; r++)
+    { const int x = r*GNT + tid;
+      const int64_t j = (int64_t) j0 + x;
+      #pragma unroll
+      for (int strand = 0; strand < 2; strand++)
+        { if (!(((strand ? cmask : fmask) >> r) & 1))
+            continue;
+          uint64_t hi = 0;
+          uint32_t lo16 = 0;
+          if (strand == 0)
+            { for (int k = 0; k < 32; k++) hi = (hi << 2) | s[x+k];
+              for (int k = 32; k < 40; k++) lo16 = (lo16 << 2) | s[x+k];
+            }
+          else
+            { for (int k = 0; k < 32; k++) hi = (hi << 2) | (uint64_t) (3 - s[x+11-k]);
+              for (int k = 32; k < 40; k++) lo16 = (lo16 << 2) | (uint32_t) (3 - s[x+11-k]);
+            }
+          const uint64_t pay = strand ? ((uint64_t) (j+12) | ((ctg | sign) << (8*A.postbytes)))
+                                      : ((uint64_t) j | (ctg << (8*A.postbytes)));
+          const uint64_t lo = ((uint64_t) lo16 << 48) | (pay << (48 - 8*(A.postbytes+A.contbytes)));    // payload left-aligned under the k-mer: the significant key bits are contiguous
+          atomicAdd(A.count + (uint32_t) (hi >> 40),1u);
+          if (at < A.cap)
+            A.keys[at] = make_uint4((uint32_t) lo,(uint32_t) (lo >> 32),(uint32_t) hi,(uint32_t) (hi >> 32));
+          at += 1;
+        }
+    }
+  __syncthreads();
+  for (int x = tid; x < 1024; x += GNT)
+    if (sh[x] != 0)
+      atomicAdd(A.sbuck + x,(unsigned long long) sh[x]);
+}
+
+// ---- prefix counts -> inclusive int64 index (three small kernels over 2^24 counters) ----
+#define ICH 4096
+__global__ __launch_bounds__(256)
+void gix_index_sums_kernel(const uint32_t *count, unsigned long long *sums)
+{ __shared__ unsigned long long part[256];
+  unsigned long long v = 0;
+  const uint32_t *p = count + (size_t) blockIdx.x*ICH;
+  for (int x = threadIdx.x; x < ICH; x += 256)
+    v += p[x];
+  part[threadIdx.x] = v;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1)
+    { if ((int) threadIdx.x < d) part[threadIdx.x] += part[threadIdx.x+d];
+      __syncthreads();
+    }
+  if (threadIdx.x == 0)
+    sums[blockIdx.x] = part[0];
+}
+
+__global__ __launch_bounds__(1024)
+void gix_index_scan_kernel(unsigned long long *sums, int n, unsigned long long *maxpre_unused)     // n = 4096: exclusive scan in place
+{ __shared__ unsigned long long t[4096];
+  for (int x = threadIdx.x; x < n; x += 1024) t[x] = sums[x];
+  __syncthreads();
+  if (threadIdx.x == 0)
+    { unsigned long long run = 0;
+      for (int x = 0; x < n; x++) { const unsigned long long v = t[x]; t[x] = run; run += v; }
+    }
+  __syncthreads();
+  for (int x = threadIdx.x; x < n; x += 1024) sums[x] = t[x];
+  (void) maxpre_unused;
+}
+
+__global__ __launch_bounds__(256)
+void gix_index_write_kernel(const uint32_t *count, const unsigned long long *sums, int64_t *index, unsigned int *maxpre)
+{ __shared__ unsigned long long part[256];
+  const uint32_t *p = count + (size_t) blockIdx.x*ICH;
+  int64_t *o = index + (size_t) blockIdx.x*ICH;
+  // thread t owns 16 consecutive counters
+  unsigned long long v = 0;
+  uint32_t c[16], mx = 0;
+  #pragma unroll
+  for (int q = 0; q < 16; q++)
+    { c[q] = p[threadIdx.x*16 + q]; v += c[q]; mx = c[q] > mx ? c[q] : mx; }
+  part[threadIdx.x] = v;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    { unsigned long long run = sums[blockIdx.x];
+      for (int x = 0; x < 256; x++) { const unsigned long long w = part[x]; part[x] = run; run += w; }
+    }
+  __syncthreads();
+  unsigned long long run = part[threadIdx.x];
+  #pragma unroll
+  for (int q = 0; q < 16; q++)
+    { run += c[q]; o[threadIdx.x*16 + q] = (int64_t) run; }
+  if (mx > 0)
+    atomicMax(maxpre,mx);
+}
+
+// ---- sorted keys -> on-disk entries ----
+struct gix_entries_args
+  { const uint4 *keys; int64_t n;
+    int postbytes, contbytes, ebytes;
+    uint8_t *table;
+    const uint8_t *partid;          // [1024] number of part boundaries at or below this 5-base bucket
+  };
+
+__global__ __launch_bounds__(256)
+void gix_entries_kernel(gix_entries_args A)
+{ const int64_t i = (int64_t) blockIdx.x*blockDim.x + threadIdx.x;
+  if (i >= A.n)
+    return;
+  const uint4 k = A.keys[i];
+  const uint64_t hi = ((uint64_t) k.w << 32) | k.z, lo = ((uint64_t) k.y << 32) | k.x;
+  const uint32_t lo16 = (uint32_t) (lo >> 48);
+  int lcp = 0;
+  if (i > 0)
+    { const uint4 q = A.keys[i-1];
+      const uint64_t phi = ((uint64_t) q.w << 32) | q.z;
+      const uint32_t plo16 = (uint32_t) ((((uint64_t) q.y << 32) | q.x) >> 48);
+      if (A.partid[hi >> 54] != A.partid[phi >> 54])
+        lcp = 0;                                       // first entry of a table part
+      else if (hi != phi)
+        lcp = __clzll((long long) (hi ^ phi)) >> 1;
+      else if (lo16 != plo16)
+        lcp = 32 + ((__clz((int) (lo16 ^ plo16)) - 16) >> 1);
+      else
+        lcp = FGA_KMER;
+    }
+  const uint64_t suf = ((hi & 0xffffffffffull) << 16) | lo16;           // bases 12..39
+  const uint64_t pay = (lo & 0xffffffffffffull) >> (48 - 8*(A.postbytes+A.contbytes));
+  uint8_t *o = A.table + (size_t) i*A.ebytes;
+  #pragma unroll
+  for (int q = 0; q < 7; q++)
+    o[q] = (uint8_t) (suf >> (8*(6-q)));
+  o[7] = 0;
+  o[8] = (uint8_t) lcp;
+  for (int q = 0; q < A.postbytes + A.contbytes; q++)
+    o[9+q] = (uint8_t) (pay >> (8*q));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+extern "C" int fga_dgix_build(fga_dev *dev, const fga_gdb *G, int nthreads, int want_host_copy,
+                              fga_dgix **dout, fga_gix **xout)
+{ *dout = NULL; *xout = NULL;
+  FGA_HIP(hipSetDevice(dev->device));
+  int nctg = 0, postbytes = 0, contbytes = 0, nparts = 0;
+  int *perm = NULL, *invp = NULL;
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 32) nthreads = 32;
+  if (fga_gix_layout(G,nthreads,&nctg,&perm,&invp,&postbytes,&contbytes,&nparts))
+    return 1;
+  const int ebytes = 9 + postbytes + contbytes;
+  int status = 1;
+  fga_dgix *D = NULL;
+  fga_gix  *X = NULL;
+  uint8_t *dimg = NULL, *dpartid = NULL;
+  int64_t *dboff = NULL, *dclen = NULL;
+  int *dinvp = NULL;
+  gix_item *ditems = NULL;
+  uint32_t *dcount = NULL;
+  unsigned long long *dctr = NULL;       // [0] keys, [1..1024] sbuck, then 4096 chunk sums, then maxpre
+  uint4 *buf0 = NULL, *buf1 = NULL, *sorted = NULL;
+  std::vector<gix_item> items;
+  std::vector<int64_t> boff((size_t) G->ncontig), clen((size_t) G->ncontig);
+  int64_t cap = 0, nkeys = 0;
+  hipError_t e = hipSuccess;
+  float ms = 0.f;
+
+  if (postbytes + contbytes > 6)
+    { fga_set_error("fga_dgix_build: payload of %d bytes does not fit the 128-bit sort key (use fga_gix_build)",
+                    postbytes+contbytes);
+      goto done;
+    }
+  for (int c = 0; c < G->ncontig; c++)
+    { boff[(size_t) c] = G->contigs[c].boff; clen[(size_t) c] = G->contigs[c].clen;
+      for (int64_t j = 0; j + 12 <= G->contigs[c].clen; j += GCH)
+        { gix_item it; it.ctg = c; it.j0 = (int) j; items.push_back(it); }
+      cap += G->contigs[c].clen;                      // < 1 k-mer per base and strand pair on average (2/5 per strand)
+    }
+  cap = cap + (cap >> 3) + 4096;
+  if (items.empty())
+    { fga_set_error("fga_dgix_build: no contig is long enough to hold a syncmer");
+      goto done;
+    }
+
+  if ((e = hipMalloc(&dimg,(size_t) G->bpslen + 64)) != hipSuccess ||
+      (e = hipMalloc(&dboff,sizeof(int64_t)*boff.size())) != hipSuccess ||
+      (e = hipMalloc(&dclen,sizeof(int64_t)*clen.size())) != hipSuccess ||
+      (e = hipMalloc(&dinvp,sizeof(int)*(size_t) nctg)) != hipSuccess ||
+      (e = hipMalloc(&ditems,sizeof(gix_item)*items.size())) != hipSuccess ||
+      (e = hipMalloc(&dcount,sizeof(uint32_t)*FGA_NPREFIX)) != hipSuccess ||
+      (e = hipMalloc(&dctr,sizeof(unsigned long long)*(1 + 1024 + 4096 + 1))) != hipSuccess ||
+      (e = hipMalloc(&dpartid,1024)) != hipSuccess)
+    { fga_set_error("fga_dgix_build: device allocation failed: %s",hipGetErrorString(e));
+      goto done;
+    }
+  buf0 = (uint4 *) fga_dev_acquire(dev,SLOT_SORT0,sizeof(uint4)*(size_t) cap);
+  buf1 = (uint4 *) fga_dev_acquire(dev,SLOT_SORT1,sizeof(uint4)*(size_t) cap);
+  if (buf0 == NULL || buf1 == NULL)
+    { fga_set_error("fga_dgix_build: device allocation of the key buffers failed");
+      goto done;
+    }
+  if ((e = hipMemcpyToSymbol(HIP_SYMBOL(gix_tmap),fga_gix_tmap(),256)) != hipSuccess ||
+      (e = hipMemcpyAsync(dimg,G->bps,(size_t) G->bpslen,hipMemcpyHostToDevice,dev->stream)) != hipSuccess ||
+      (e = hipMemcpyAsync(dboff,boff.data(),sizeof(int64_t)*boff.size(),hipMemcpyHostToDevice,dev->stream)) != hipSuccess ||
+      (e = hipMemcpyAsync(dclen,clen.data(),sizeof(int64_t)*clen.size(),hipMemcpyHostToDevice,dev->stream)) != hipSuccess ||
+      (e = hipMemcpyAsync(dinvp,invp,sizeof(int)*(size_t) nctg,hipMemcpyHostToDevice,dev->stream)) != hipSuccess ||
+      (e = hipMemcpyAsync(ditems,items.data(),sizeof(gix_item)*items.size(),hipMemcpyHostToDevice,dev->stream)) != hipSuccess ||
+      (e = hipMemsetAsync(dcount,0,sizeof(uint32_t)*FGA_NPREFIX,dev->stream)) != hipSuccess ||
+      (e = hipMemsetAsync(dctr,0,sizeof(unsigned long long)*(1 + 1024 + 4096 + 1),dev->stream)) != hipSuccess)
+    { fga_set_error("fga_dgix_build: upload failed: %s",hipGetErrorString(e));
+      goto done;
+    }
+
+  hipEventRecord(dev->ev0,dev->stream);
+  { gix_scan_args A;
+    A.img = dimg; A.boff = dboff; A.clen = dclen; A.invp = dinvp;
+    A.items = ditems; A.nitems = (int) items.size();
+    A.postbytes = postbytes; A.contbytes = contbytes;
+    A.keys = buf0; A.cap = cap; A.nkeys = dctr; A.count = dcount; A.sbuck = dctr + 1;
+    hipLaunchKernelGGL(gix_scan_kernel,dim3((unsigned) items.size()),dim3(GNT),0,dev->stream,A);
+  }
+  { unsigned long long hk[1025];
+    if ((e = hipMemcpyAsync(hk,dctr,sizeof(hk),hipMemcpyDeviceToHost,dev->stream)) != hipSuccess ||
+        (e = hipStreamSynchronize(dev->stream)) != hipSuccess)
+      { fga_set_error("fga_dgix_build: scan kernel failed: %s",hipGetErrorString(e));
+        goto done;
+      }
+    nkeys = (int64_t) hk[0];
+    if (nkeys > cap)
+      { // low-complexity sequence (up to two k-mers per base): the exact size is known now, go again
+        fga_dev_release(dev,SLOT_SORT0,buf0); fga_dev_release(dev,SLOT_SORT1,buf1);
+        cap = nkeys + 4096;
+        buf0 = (uint4 *) fga_dev_acquire(dev,SLOT_SORT0,sizeof(uint4)*(size_t) cap);
+        buf1 = (uint4 *) fga_dev_acquire(dev,SLOT_SORT1,sizeof(uint4)*(size_t) cap);
+        if (buf0 == NULL || buf1 == NULL)
+          { fga_set_error("fga_dgix_build: device allocation of the key buffers failed");
+            goto done;
+          }
+        hipMemsetAsync(dcount,0,sizeof(uint32_t)*FGA_NPREFIX,dev->stream);
+        hipMemsetAsync(dctr,0,sizeof(unsigned long long)*(1 + 1024 + 4096 + 1),dev->stream);
+        gix_scan_args A2;
+        A2.img = dimg; A2.boff = dboff; A2.clen = dclen; A2.invp = dinvp;
+        A2.items = ditems; A2.nitems = (int) items.size();
+        A2.postbytes = postbytes; A2.contbytes = contbytes;
+        A2.keys = buf0; A2.cap = cap; A2.nkeys = dctr; A2.count = dcount; A2.sbuck = dctr + 1;
+        hipLaunchKernelGGL(gix_scan_kernel,dim3((unsigned) items.size()),dim3(GNT),0,dev->stream,A2);
+        if ((e = hipMemcpyAsync(hk,dctr,sizeof(hk),hipMemcpyDeviceToHost,dev->stream)) != hipSuccess ||
+            (e = hipStreamSynchronize(dev->stream)) != hipSuccess)
+          { fga_set_error("fga_dgix_build: scan kernel failed: %s",hipGetErrorString(e));
+            goto done;
+          }
+        nkeys = (int64_t) hk[0];
+        if (nkeys > cap)
+          { fga_set_error("fga_dgix_build: internal error, %lld k-mers exceed the buffer of %lld",(long long) nkeys,(long long) cap);
+            goto done;
+          }
+      }
+    // table parts from the sample histogram, as a bucket -> part id map
+    int64_t sb[1024];
+    int ksplit[65];
+    uint8_t partid[1024];
+    for (int b = 0; b < 1024; b++) sb[b] = (int64_t) hk[1+b];
+    fga_gix_ksplit(sb,nparts,ksplit);
+    { int p = 0;
+      for (int b = 0; b < 1024; b++)
+        { while (p < nparts && ksplit[p+1] <= b) p += 1;
+          partid[b] = (uint8_t) p;
+        }
+    }
+    if ((e = hipMemcpyAsync(dpartid,partid,1024,hipMemcpyHostToDevice,dev->stream)) != hipSuccess)
+      { fga_set_error("fga_dgix_build: upload failed: %s",hipGetErrorString(e));
+        goto done;
+      }
+    hipStreamSynchronize(dev->stream);
+  }
+
+  { const int bits = 80 + 8*(postbytes+contbytes);
+    const int npass = (bits + 7) / 8;
+    if (fga_radix_sort_u128(dev,buf0,buf1,nkeys,128 - 8*npass,8*npass,&sorted))
+      goto done;
+  }
+
+  D = (fga_dgix *) calloc(1,sizeof(fga_dgix));
+  if (D == NULL) { fga_set_error("out of memory"); goto done; }
+  D->dev = dev; D->nents = nkeys; D->ebytes = ebytes; D->postbytes = postbytes; D->contbytes = contbytes; D->nctg = nctg;
+  if ((e = hipMalloc(&D->table,(size_t) nkeys*ebytes + 64)) != hipSuccess ||
+      (e = hipMalloc(&D->index,sizeof(int64_t)*FGA_NPREFIX)) != hipSuccess)
+    { fga_set_error("fga_dgix_build: device allocation of the table failed: %s",hipGetErrorString(e));
+      goto done;
+    }
+  hipMemsetAsync(D->table + (size_t) nkeys*ebytes,0,64,dev->stream);
+  { unsigned long long *sums = dctr + 1025;
+    hipLaunchKernelGGL(gix_index_sums_kernel,dim3(FGA_NPREFIX/ICH),dim3(256),0,dev->stream,dcount,sums);
+    hipLaunchKernelGGL(gix_index_scan_kernel,dim3(1),dim3(1024),0,dev->stream,sums,FGA_NPREFIX/ICH,sums);
+    hipLaunchKernelGGL(gix_index_write_kernel,dim3(FGA_NPREFIX/ICH),dim3(256),0,dev->stream,dcount,sums,D->index,
+                       (unsigned int *) (dctr + 1025 + 4096));
+  }
+  if (nkeys > 0)
+    { gix_entries_args E;
+      E.keys = sorted; E.n = nkeys; E.postbytes = postbytes; E.contbytes = contbytes; E.ebytes = ebytes;
+      E.table = D->table; E.partid = dpartid;
+      hipLaunchKernelGGL(gix_entries_kernel,dim3((unsigned) ((nkeys + 255)/256)),dim3(256),0,dev->stream,E);
+    }
+  hipEventRecord(dev->ev1,dev->stream);
+  { unsigned long long hm = 0;
+    if ((e = hipMemcpyAsync(&hm,dctr + 1025 + 4096,sizeof(hm),hipMemcpyDeviceToHost,dev->stream)) != hipSuccess ||
+        (e = hipStreamSynchronize(dev->stream)) != hipSuccess || (e = hipGetLastError()) != hipSuccess)
+      { fga_set_error("fga_dgix_build: kernels failed: %s",hipGetErrorString(e));
+        goto done;
+      }
+    hipEventElapsedTime(&ms,dev->ev0,dev->ev1);
+    dev->last_ms[FGA_STAGE_GIX] = ms;
+
+    X = (fga_gix *) calloc(1,sizeof(fga_gix));
+    if (X == NULL) { fga_set_error("out of memory"); goto done; }
+    X->kmer = FGA_KMER; X->nparts = nparts; X->postbytes = postbytes; X->contbytes = contbytes; X->ebytes = ebytes;
+    X->maxpre = (int64_t) (hm & 0xffffffffu); X->freq = 0; X->nctg = nctg; X->nents = nkeys;
+    X->perm = perm; perm = NULL;
+    X->partbeg = (int64_t *) malloc(sizeof(int64_t)*(nparts+1));
+    if (X->partbeg == NULL)
+      { fga_set_error("out of memory"); goto done; }
+    // part starts, from the split the device used
+    { unsigned long long hk[1025];
+      int64_t sb[1024];
+      int ksplit[65];
+      hipMemcpy(hk,dctr,sizeof(hk),hipMemcpyDeviceToHost);
+      for (int b = 0; b < 1024; b++) sb[b] = (int64_t) hk[1+b];
+      fga_gix_ksplit(sb,nparts,ksplit);
+      for (int p = 0; p <= nparts; p++)
+        { X->partbeg[p] = 0;
+          if (ksplit[p] > 0 &&
+              hipMemcpy(X->partbeg+p,D->index + (((int64_t) ksplit[p] << 14) - 1),sizeof(int64_t),hipMemcpyDeviceToHost) != hipSuccess)
+            { fga_set_error("fga_dgix_build: download failed"); goto done; }
+        }
+    }
+    if (want_host_copy)
+      { X->index = (int64_t *) malloc(sizeof(int64_t)*FGA_NPREFIX);
+        X->table = (uint8_t *) malloc((size_t) nkeys*ebytes + 64);
+        if (X->index == NULL || X->table == NULL)
+          { fga_set_error("out of memory"); goto done; }
+        if ((e = hipMemcpy(X->index,D->index,sizeof(int64_t)*FGA_NPREFIX,hipMemcpyDeviceToHost)) != hipSuccess ||
+            (e = hipMemcpy(X->table,D->table,(size_t) nkeys*ebytes + 64,hipMemcpyDeviceToHost)) != hipSuccess)
+          { fga_set_error("fga_dgix_build: download failed: %s",hipGetErrorString(e));
+            goto done;
+          }
+      }
+  }
+  status = 0;
+
+done:
+  hipFree(dimg); hipFree(dboff); hipFree(dclen); hipFree(dinvp); hipFree(ditems); hipFree(dcount); hipFree(dctr);
+  hipFree(dpartid);
+  fga_dev_release(dev,SLOT_SORT0,buf0); fga_dev_release(dev,SLOT_SORT1,buf1);
+  free(perm); free(invp);
+  if (status != 0)
+    { if (D != NULL) { hipFree(D->table); hipFree(D->index); free(D); }
+      if (X != NULL) fga_gix_close(X);
+      return 1;
+    }
+  *dout = D; *xout = X;
+  return 0;
+}

@@ -85,6 +85,10 @@ int      fga_gdb_write_skeleton(const fga_gdb *G, const char *path, const char *
 int      fga_gix_open(const char *path, fga_gix **out);
 void     fga_gix_close(fga_gix *X);
 int      fga_gix_build(const fga_gdb *G, const char *target, int nthreads);
+int      fga_gix_layout(const fga_gdb *G, int nthreads, int *nctg, int **perm, int **invp,
+                        int *postbytes, int *contbytes, int *nparts);
+void     fga_gix_ksplit(const int64_t *sbuck, int nparts, int *ksplit);
+const uint8_t *fga_gix_tmap(void);
 
 /* small helpers */
 char *fga_path_dir(const char *path);                       /* malloc'd directory part ("." if none) */

@@ -335,6 +335,40 @@ extern "C" int fga_seed_sort(fga_dev *dev, const fga_dseeds *S, const fga_sort_p
   return 0;
 }
 
+// LSD radix sort of n 128-bit keys on bits [lowbit, lowbit+nbits) with the kernels above; buf0 holds the input, buf1 is
+// scratch of the same size; *sorted is whichever of the two holds the result.  Enqueued on dev->stream, not synchronised.
+int fga_radix_sort_u128(fga_dev *dev, uint4 *buf0, uint4 *buf1, int64_t n, int lowbit, int nbits, uint4 **sorted)
+{ *sorted = buf0;
+  if (n <= 1 || nbits <= 0)
+    return 0;
+  const int npass = (nbits + 7) / 8;
+  const int ntiles = (int) ((n + STILE - 1) / STILE);
+  const int64_t hm = (int64_t) 256*ntiles;
+  const int nch = (int) ((hm + SCAN_CH - 1) / SCAN_CH);
+  uint32_t *hist = (uint32_t *) fga_dev_acquire(dev,SLOT_HIST,sizeof(uint32_t)*(256*(size_t) ntiles + nch + 1));
+  if (hist == NULL)
+    { fga_set_error("radix sort: device allocation failed");
+      return 1;
+    }
+  uint32_t *sums = hist + 256*(size_t) ntiles;
+  key_layout L;
+  memset(&L,0,sizeof(L));
+  uint4 *src = buf0, *dst = buf1;
+  for (int p = 0; p < npass; p++)
+    { const int shift = lowbit + 8*p;
+      hipLaunchKernelGGL(sort_hist_kernel<false>,dim3(ntiles),dim3(ST),0,dev->stream,(const void *) src,n,shift,L,hist,ntiles);
+      hipLaunchKernelGGL(sort_scan_local_kernel,dim3(nch),dim3(SCAN_T),0,dev->stream,hist,hm,sums);
+      hipLaunchKernelGGL(sort_scan_sums_kernel,dim3(1),dim3(SCAN_T),0,dev->stream,sums,nch);
+      hipLaunchKernelGGL(sort_scatter_kernel<false>,dim3(ntiles),dim3(ST),0,dev->stream,(const void *) src,dst,n,shift,L,hist,sums,ntiles);
+      uint4 *t = src; src = dst; dst = t;
+    }
+  // the histogram buffer is still in use by the enqueued kernels: the slot is grow-only memory of the device context and
+  // the next user is ordered behind them on the same stream, so releasing the bookkeeping here is safe
+  fga_dev_release(dev,SLOT_HIST,hist);
+  *sorted = src;
+  return 0;
+}
+
 extern "C" int64_t fga_keys_count(const fga_dkeys *K) { return K->count; }
 
 extern "C" int fga_keys_download(const fga_dkeys *K, void *host, int64_t max)

@@ -48,6 +48,18 @@ class DeviceGix:
             self.h = C.c_void_p()
 
 
+def build_gix_device(dev, gdb, nthreads=8, host_copy=False):
+    """GDB -> index on the device (fga_dgix_build); returns (DeviceGix, Gix descriptor)."""
+    from .gixio import Gix
+    dh, xh = C.c_void_p(), C.c_void_p()
+    check(dev.L.fga_dgix_build(dev.h, gdb.h, nthreads, int(host_copy), C.byref(dh), C.byref(xh)), "device GIX build")
+    x = Gix("<device>", handle=xh)
+    d = DeviceGix.__new__(DeviceGix)
+    d.dev, d.h = dev, dh
+    d.nents, d.ebytes, d.pbyte, d.postbytes, d.contbytes = x.nents, x.ebytes, x.pbyte, x.postbytes, x.contbytes
+    return d, x
+
+
 class Seeds:
     """device-resident seeds of one fga_seed_merge call."""
 

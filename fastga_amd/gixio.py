@@ -39,10 +39,15 @@ class Gdb:
 
 
 class Gix:
-    def __init__(self, path):
+    def __init__(self, path, handle=None):
+        """open <root>.gix (+ .ktab parts), or wrap a handle produced by fga_dgix_build (path is then only a label;
+        index/table are present only if the build kept a host copy)"""
         self.L = load_library()
         self.h = C.c_void_p()
-        check(self.L.fga_gix_open(path.encode(), C.byref(self.h)), f"open GIX {path}")
+        if handle is not None:
+            self.h = handle
+        else:
+            check(self.L.fga_gix_open(path.encode(), C.byref(self.h)), f"open GIX {path}")
         L, h = self.L, self.h
         self.path = path
         self.nents = L.fga_gix_nents(h)
@@ -55,8 +60,9 @@ class Gix:
         self.partbeg = np.array([L.fga_gix_part_begin(h, p) for p in range(self.nparts + 1)], dtype=np.int64)
         self.maxpre = L.fga_gix_maxpre(h)
         self.perm = np.ctypeslib.as_array(L.fga_gix_perm(h), shape=(self.nctg,)).copy()
-        self.index = np.ctypeslib.as_array(L.fga_gix_index(h), shape=(NPREFIX,))
-        self.table = np.ctypeslib.as_array(L.fga_gix_table(h), shape=(self.nents * self.ebytes,))
+        self.index = np.ctypeslib.as_array(L.fga_gix_index(h), shape=(NPREFIX,)) if L.fga_gix_index(h) else None
+        self.table = (np.ctypeslib.as_array(L.fga_gix_table(h), shape=(self.nents * self.ebytes,))
+                      if L.fga_gix_table(h) else None)
 
     def entries(self):
         return self.table.reshape(self.nents, self.ebytes)

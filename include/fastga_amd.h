@@ -75,7 +75,7 @@ typedef struct
   } fga_merge_params;
 
 enum { FGA_STAGE_MERGE_PARTITION = 0, FGA_STAGE_MERGE = 1, FGA_STAGE_SORT = 2, FGA_STAGE_CHAIN = 3,
-       FGA_STAGE_EXTEND = 4, FGA_NSTAGES = 8 };
+       FGA_STAGE_EXTEND = 4, FGA_STAGE_GIX = 5, FGA_NSTAGES = 8 };
 
 int   fga_dev_open(int device, fga_dev **out);
 void  fga_dev_close(fga_dev *dev);
@@ -84,6 +84,12 @@ float fga_dev_stage_ms(const fga_dev *dev, int stage);   /* HIP-event time of th
 
 int   fga_dgix_upload(fga_dev *dev, const fga_gix *gix, fga_dgix **out);
 void  fga_dgix_free(fga_dgix *dgix);
+/* The index built on the device straight into HBM: replaces the GIXmake run for the seed merge's input (GIXmake.c
+ * sample / distribution / sort / merge threads).  `gdb` must hold its bases (fga_gdb_open); nthreads plays GIXmake's
+ * -T for the layout (contig padding, table parts).  *dgix is what fga_dgix_upload of the fga_gix_build files would
+ * give, byte for byte; *gix is the matching host descriptor (perm, widths; with want_host_copy also index + table,
+ * for writing the files or for tests).  Not for soft-masked builds (fga_gix_build_masked). */
+int   fga_dgix_build(fga_dev *dev, const fga_gdb *gdb, int nthreads, int want_host_copy, fga_dgix **dgix, fga_gix **gix);
 
 /* Adaptive seed merge: replaces adaptamer_merge -> new_merge_thread (FastGA.c:2281, 610) and, with
  * t2 == NULL, self_adaptamer_merge -> new_self_merge_thread (FastGA.c:2496, 1616).  Returns 0, or 2 when
