@@ -118,6 +118,17 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # informational (not part of `value`): the index of genome A built on the device instead of loaded from its files
+    gix_ms = None
+    try:
+        from fastga_amd.gixio import Gdb
+        gA = Gdb(ra + ".gdb")
+        dgx, xg = D.build_gix_device(ses.dev_wrapper(), gA, 8)
+        gix_ms = ses.dev_wrapper().stage_ms(5)
+        dgx.free(); xg.close(); gA.close()
+    except Exception:
+        gix_ms = None
+
     for _ in range(args.warmup):
         step()
     barrier()
@@ -166,7 +177,8 @@ def main():
                        "stage_ms": stage_ms,
                        "kernel_ms": {"merge": round(kavg, 3), "sort": round(last["sort_kernel_ms"], 3),
                                      "extend": round(last["extend_kernel_ms"], 3)},
-                       "prep_s": round(prep_s, 1)},
+                       "prep_s": round(prep_s, 1),
+                       "gix_build_on_device_ms": None if gix_ms is None else round(gix_ms, 2)},
             "roofline": {"kernel": "seed_merge_wave_kernel (+ seed_merge_kernel on oversize tiles, hole closing; "
                                    "HIP events around the whole merge launch)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -24,6 +24,7 @@ struct fga_session
     fga_dgix *d1, *d2;
     fga_dgenome *dg1, *dg2;
     int self;
+    int devbuilt;              /* an index was built on the device (no soft-mask bytes in it) */
     double load_s, upload_s;
   };
 
@@ -38,6 +39,18 @@ void fga_session_close(fga_session *Z)
   free(Z);
 }
 
+static int gix_exists(const char *root)
+{ char *p = NULL;
+  size_t n = strlen(root);
+  int ok;
+  if (n > 4 && (strcmp(root+n-4,".gix") == 0 || strcmp(root+n-4,".gdb") == 0)) n -= 4;
+  else if (n > 5 && strcmp(root+n-5,".1gdb") == 0) n -= 5;
+  if (asprintf(&p,"%.*s.gix",(int) n,root) < 0) return 0;
+  ok = access(p,R_OK) == 0;
+  free(p);
+  return ok;
+}
+
 /* load GDB + GIX of both genomes and make them resident in HBM */
 int fga_session_open(const char *root1, const char *root2, int device, fga_session **out)
 { fga_session *Z = calloc(1,sizeof(fga_session));
@@ -49,18 +62,24 @@ int fga_session_open(const char *root1, const char *root2, int device, fga_sessi
     }
   Z->self = (root2 == NULL);
   t0 = fga_wall();
-  if (fga_gdb_open(root1,&Z->g1) || fga_gix_open(root1,&Z->x1)) goto fail;
-  if (!Z->self)
-    { if (fga_gdb_open(root2,&Z->g2) || fga_gix_open(root2,&Z->x2)) goto fail; }
+  /* an index file is loaded when it is there; otherwise the index is built on the device from the GDB, straight
+     into HBM (no .gix/.ktab files appear, like the reference without -k) */
+  { int have1 = gix_exists(root1), have2 = Z->self ? 1 : gix_exists(root2);
+    if (fga_gdb_open(root1,&Z->g1) || (have1 && fga_gix_open(root1,&Z->x1))) goto fail;
+    if (!Z->self)
+      { if (fga_gdb_open(root2,&Z->g2) || (have2 && fga_gix_open(root2,&Z->x2))) goto fail; }
+    Z->load_s = fga_wall() - t0;
+    if (fga_dev_open(device,&Z->dev)) goto fail;
+    t0 = fga_wall();
+    Z->devbuilt = !have1 || !have2;
+    if (have1 ? fga_dgix_upload(Z->dev,Z->x1,&Z->d1) : fga_dgix_build(Z->dev,Z->g1,8,0,&Z->d1,&Z->x1)) goto fail;
+    if (!Z->self && (have2 ? fga_dgix_upload(Z->dev,Z->x2,&Z->d2) : fga_dgix_build(Z->dev,Z->g2,8,0,&Z->d2,&Z->x2)))
+      goto fail;
+  }
   if (Z->x1->nctg < Z->g1->ncontig || (!Z->self && Z->x2->nctg < Z->g2->ncontig))
     { fga_set_error("genome index and genome database disagree on the number of contigs");
       goto fail;
     }
-  Z->load_s = fga_wall() - t0;
-  if (fga_dev_open(device,&Z->dev)) goto fail;
-  t0 = fga_wall();
-  if (fga_dgix_upload(Z->dev,Z->x1,&Z->d1)) goto fail;
-  if (!Z->self && fga_dgix_upload(Z->dev,Z->x2,&Z->d2)) goto fail;
   if (fga_dgenome_upload(Z->dev,Z->g1,Z->x1->perm,Z->x1->nctg,1,&Z->dg1)) goto fail;
   if (Z->self)
     Z->dg2 = Z->dg1;
@@ -103,6 +122,11 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
 
   memset(&st,0,sizeof(st));
   st.load_s = Z->load_s; st.upload_s = Z->upload_s;
+  if (P->soft_mask && Z->devbuilt)
+    { fga_set_error("soft masking (-M) needs index files built with mask bytes (fga_gix_build_masked / GIXmake #); "
+                    "the index of this session was built on the device without them");
+      return 1;
+    }
   tstart = fga_wall();
   /* ---- phase 1 ---- */
   t0 = fga_wall();

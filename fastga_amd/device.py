@@ -317,6 +317,14 @@ class Session:
     def sync(self):
         check(self.L.fga_dev_sync(self.L.fga_session_device(self.h)), "sync")
 
+    def dev_wrapper(self):
+        """the session's device context as a (non-owning) Device object"""
+        d = Device.__new__(Device)
+        d.L = self.L
+        d.h = C.c_void_p(self.L.fga_session_device(self.h))
+        d.close = lambda: None
+        return d
+
     def close(self):
         if self.h:
             self.L.fga_session_close(self.h)

@@ -66,3 +66,30 @@ def test_seed_merge_over_device_built_indices(toy_pair):
     for o in (dA, dB, xA, xB):
         o.free()
     dev.close()
+
+
+def test_end_to_end_without_index_files(toy_pair, tmp_path):
+    """only <root>.gdb + .bps present: the session builds both indices on the device; same .1aln as the reference run on
+    the complete files"""
+    import shutil
+    from tests.test_end_to_end_gpu import _compare  # noqa: F401
+    from fastga_amd import device as D
+    from oracle import harness as H
+    if not H.have_reference():
+        pytest.skip("oracle/_ref did not travel")
+    d, ra, rb = toy_pair
+    w = str(tmp_path)
+    roots = []
+    for r in (ra, rb):
+        n = os.path.basename(r)
+        shutil.copy(r + ".gdb", os.path.join(w, n + ".gdb"))
+        shutil.copy(os.path.join(os.path.dirname(r), "." + n + ".bps"), os.path.join(w, "." + n + ".bps"))
+        roots.append(os.path.join(w, n))
+    ours = os.path.join(w, "ours.1aln")
+    st = D.run(roots[0], roots[1], ours, nthreads=8)
+    assert st["nlive"] > 0 and not os.path.exists(roots[0] + ".gix")
+    H.ref_fastga(ra, rb, w, os.path.join(w, "ref"), threads=8)
+    keep = lambda lines: [ln for ln in lines if ln[0] not in "!<"]          # noqa: E731
+    assert keep(H.oneview(ours)) == keep(H.oneview(os.path.join(w, "ref.1aln")))
+    with pytest.raises(Exception):
+        D.run(roots[0], roots[1], ours, nthreads=8, soft_mask=True)

@@ -42,7 +42,7 @@ static char *root_of(const char *src, int *is_fasta)
   return r;
 }
 
-static int prepare(const char *src, char **root, int nthreads, int verbose)
+static int prepare(const char *src, char **root, int nthreads, int verbose, int want_gix_files)
 { int isfa;
   char *r = root_of(src,&isfa);
   *root = r;
@@ -69,7 +69,7 @@ static int prepare(const char *src, char **root, int nthreads, int verbose)
         }
       free(fa);
     }
-  if (!exists("%s.gix",r))
+  if (!exists("%s.gix",r) && want_gix_files)        /* otherwise the index is built on the device, in HBM only */
     { fga_gdb *g;
       if (verbose) fprintf(stderr,"  Creating genome index (GIX) %s.gix\n",r);
       if (fga_gdb_open(r,&g) || fga_gix_build(g,r,nthreads))
@@ -85,7 +85,7 @@ int main(int argc, char *argv[])
 { fga_run_params P;
   fga_run_stats S;
   char *src[2] = { NULL, NULL }, *root[2] = { NULL, NULL }, *out = NULL, *outpath = NULL;
-  int nsrc = 0, verbose = 0, i;
+  int nsrc = 0, verbose = 0, keep = 0, i;
   int cmin = 85, cbreak = 1000;
   double ident = .7;
   char cmd[4096];
@@ -119,7 +119,7 @@ int main(int argc, char *argv[])
             for (f = argv[i]+1; *f; f++)
               switch (*f)
               { case 'v': verbose = 1; break;
-                case 'k': break;
+                case 'k': keep = 1; break;
                 case 'M': P.soft_mask = 1; break;
                 case 'S': P.symmetric = 1; break;
                 default:
@@ -152,7 +152,7 @@ int main(int argc, char *argv[])
     P.out_path = outpath;
   }
   for (i = 0; i < nsrc; i++)
-    if (prepare(src[i],root+i,P.nthreads,verbose))
+    if (prepare(src[i],root+i,P.nthreads,verbose,keep || P.soft_mask))
       return 1;
   if (nsrc == 2 && strcmp(root[0],root[1]) == 0)
     nsrc = 1;
