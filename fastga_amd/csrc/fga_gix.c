@@ -518,6 +518,77 @@ void fga_gix_ksplit(const int64_t *sbuck, int nparts, int *ksplit)
 
 const uint8_t *fga_gix_tmap(void) { return TMap; }
 
+/* Write <root>.gix + .<root>.ktab.N from an index held in memory (index, table, partbeg, perm: e.g. the host copy of
+ * fga_dgix_build) -- the same files fga_gix_build writes (GIXmake.c:1389-1600 for the layout). */
+int fga_gix_write_files(const fga_gix *X, const char *target)
+{ char *noext = NULL, *dir = NULL, *root = NULL, *name = NULL;
+  int status = 1, part, fd = -1;
+  if (X->index == NULL || X->table == NULL || X->partbeg == NULL || X->perm == NULL)
+    { fga_set_error("fga_gix_write_files: the index has no host copy of its table");
+      return 1;
+    }
+  noext = strdup(target);
+  if (noext == NULL) goto oom;
+  { size_t n = strlen(noext);
+    if (n > 4 && strcmp(noext+n-4,".gix") == 0) noext[n-4] = '\0';
+    else if (n > 4 && strcmp(noext+n-4,".gdb") == 0) noext[n-4] = '\0';
+    else if (n > 5 && strcmp(noext+n-5,".1gdb") == 0) noext[n-5] = '\0';
+  }
+  dir  = fga_path_dir(noext);
+  root = fga_path_root(noext,NULL);
+  for (part = 0; part < X->nparts; part++)
+    { int64_t lo = X->partbeg[part], hi = X->partbeg[part+1], nout = hi-lo;
+      int32_t k = FGA_KMER;
+      free(name); name = NULL;
+      if (asprintf(&name,"%s/.%s.ktab.%d",dir,root,part+1) < 0) { name = NULL; goto oom; }
+      fd = open(name,O_WRONLY|O_CREAT|O_TRUNC,0666);
+      if (fd < 0)
+        { fga_set_error("cannot open %s for writing",name);
+          goto done;
+        }
+      if (write_full(fd,&k,sizeof(int32_t)) || write_full(fd,&nout,sizeof(int64_t)) ||
+          write_full(fd,X->table + lo*X->ebytes,nout*X->ebytes))
+        goto ioerr;
+      close(fd); fd = -1;
+    }
+  { int32_t x;
+    int64_t y;
+    free(name); name = NULL;
+    if (asprintf(&name,"%s/%s.gix",dir,root) < 0) { name = NULL; goto oom; }
+    fd = open(name,O_WRONLY|O_CREAT|O_TRUNC,0666);
+    if (fd < 0)
+      { fga_set_error("cannot open %s for writing",name);
+        goto done;
+      }
+    x = FGA_KMER;  if (write_full(fd,&x,4)) goto ioerr;
+    x = X->nparts; if (write_full(fd,&x,4)) goto ioerr;
+    x = 1;         if (write_full(fd,&x,4)) goto ioerr;
+    x = 3;         if (write_full(fd,&x,4)) goto ioerr;
+    if (write_full(fd,X->index,sizeof(int64_t)*FGA_NPREFIX)) goto ioerr;
+    x = X->postbytes; if (write_full(fd,&x,4)) goto ioerr;
+    x = X->contbytes; if (write_full(fd,&x,4)) goto ioerr;
+    x = X->nparts;    if (write_full(fd,&x,4)) goto ioerr;
+    y = X->maxpre;    if (write_full(fd,&y,8)) goto ioerr;
+    x = 0;            if (write_full(fd,&x,4)) goto ioerr;
+    x = X->nctg;      if (write_full(fd,&x,4)) goto ioerr;
+    if (write_full(fd,X->perm,sizeof(int)*X->nctg)) goto ioerr;
+    y = -1;           if (write_full(fd,&y,8)) goto ioerr;
+    close(fd); fd = -1;
+  }
+  status = 0;
+  goto done;
+ioerr:
+  fga_set_error("IO error writing %s",name);
+  goto done;
+oom:
+  fga_set_error("out of memory");
+done:
+  if (fd >= 0) close(fd);
+  free(noext); free(dir); free(root); free(name);
+  return status;
+}
+
+
 /* Build <root>.gix + .<root>.ktab.* for `gdb`.  `nthreads` plays the role of GIXmake's -T: it sets the
  * worker count, the number of table parts (GIXmake.c:1907-1917) and the padding of the contig count to
  * >= nthreads with fake 40-base contigs (short_GDB_fix, GIXmake.c:1605-1624).                          */

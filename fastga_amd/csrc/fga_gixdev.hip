@@ -228,6 +228,9 @@ struct gix_entries_args
     int postbytes, contbytes, ebytes;
     uint8_t *table;
     const uint8_t *partid;          // [1024] number of part boundaries at or below this 5-base bucket
+    // soft mask (optional): lower-case intervals per original contig, and the sorted -> original contig map
+    const int64_t *moff, *mbeg, *mend;
+    const int     *perm;
   };
 
 __global__ __launch_bounds__(256)
@@ -258,7 +261,26 @@ void gix_entries_kernel(gix_entries_args A)
   #pragma unroll
   for (int q = 0; q < 7; q++)
     o[q] = (uint8_t) (suf >> (8*(6-q)));
-  o[7] = 0;
+  // soft-mask byte of the k-mers whose syncmer starts at j: bases from j to the end of the lower-case interval that
+  // holds j, capped at 40; 0 outside intervals (setup_thread_with_masks, GIXmake.c:1100-1108)
+  uint32_t pbg = 0;
+  if (A.moff != NULL)
+    { const uint64_t pm = (A.postbytes >= 8) ? ~0ull : ((1ull << (8*A.postbytes)) - 1);
+      const uint64_t cw = pay >> (8*A.postbytes);
+      const uint64_t sb = 0x80ull << (8*(A.contbytes-1));
+      const int c = A.perm[(int) (cw & (sb-1))];
+      const int64_t j = (int64_t) (pay & pm) - ((cw & sb) ? 12 : 0);
+      int64_t lo_ = A.moff[c], hi_ = A.moff[c+1];            // first interval with mend > j
+      while (lo_ < hi_)
+        { const int64_t m = (lo_ + hi_) >> 1;
+          if (A.mend[m] > j) hi_ = m; else lo_ = m+1;
+        }
+      if (lo_ < A.moff[c+1] && j >= A.mbeg[lo_])
+        { const int64_t dd = A.mend[lo_] - j;
+          pbg = (uint32_t) (dd > FGA_KMER ? FGA_KMER : dd);
+        }
+    }
+  o[7] = (uint8_t) pbg;
   o[8] = (uint8_t) lcp;
   for (int q = 0; q < A.postbytes + A.contbytes; q++)
     o[9+q] = (uint8_t) (pay >> (8*q));
@@ -267,9 +289,13 @@ void gix_entries_kernel(gix_entries_args A)
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
-extern "C" int fga_dgix_build(fga_dev *dev, const fga_gdb *G, int nthreads, int want_host_copy,
+extern "C" int fga_dgix_build(fga_dev *dev, const fga_gdb *G, int nthreads, int flags,
                               fga_dgix **dout, fga_gix **xout)
 { *dout = NULL; *xout = NULL;
+  const int want_host_copy = (flags & FGA_GIX_HOST_COPY) != 0;
+  const int use_mask = (flags & FGA_GIX_SOFT_MASK) != 0 && G->nmask > 0;
+  int64_t *dmoff = NULL, *dmbeg = NULL, *dmend = NULL;
+  int *dperm = NULL;
   FGA_HIP(hipSetDevice(dev->device));
   int nctg = 0, postbytes = 0, contbytes = 0, nparts = 0;
   int *perm = NULL, *invp = NULL;
@@ -428,6 +454,25 @@ extern "C" int fga_dgix_build(fga_dev *dev, const fga_gdb *G, int nthreads, int 
     { gix_entries_args E;
       E.keys = sorted; E.n = nkeys; E.postbytes = postbytes; E.contbytes = contbytes; E.ebytes = ebytes;
       E.table = D->table; E.partid = dpartid;
+      E.moff = NULL; E.mbeg = E.mend = NULL; E.perm = NULL;
+      if (use_mask)
+        { if ((e = hipMalloc(&dmoff,sizeof(int64_t)*(size_t) (nctg+1))) != hipSuccess ||
+              (e = hipMalloc(&dmbeg,sizeof(int64_t)*(size_t) G->nmask)) != hipSuccess ||
+              (e = hipMalloc(&dmend,sizeof(int64_t)*(size_t) G->nmask)) != hipSuccess ||
+              (e = hipMalloc(&dperm,sizeof(int)*(size_t) nctg)) != hipSuccess)
+            { fga_set_error("fga_dgix_build: device allocation failed: %s",hipGetErrorString(e));
+              goto done;
+            }
+          std::vector<int64_t> mo((size_t) nctg+1);
+          for (int c = 0; c <= nctg; c++)
+            mo[(size_t) c] = c <= G->ncontig ? G->moff[c] : G->moff[G->ncontig];
+          hipMemcpyAsync(dmoff,mo.data(),sizeof(int64_t)*mo.size(),hipMemcpyHostToDevice,dev->stream);
+          hipMemcpyAsync(dmbeg,G->mbeg,sizeof(int64_t)*(size_t) G->nmask,hipMemcpyHostToDevice,dev->stream);
+          hipMemcpyAsync(dmend,G->mend,sizeof(int64_t)*(size_t) G->nmask,hipMemcpyHostToDevice,dev->stream);
+          hipMemcpyAsync(dperm,perm,sizeof(int)*(size_t) nctg,hipMemcpyHostToDevice,dev->stream);
+          hipStreamSynchronize(dev->stream);
+          E.moff = dmoff; E.mbeg = dmbeg; E.mend = dmend; E.perm = dperm;
+        }
       hipLaunchKernelGGL(gix_entries_kernel,dim3((unsigned) ((nkeys + 255)/256)),dim3(256),0,dev->stream,E);
     }
   hipEventRecord(dev->ev1,dev->stream);
@@ -479,6 +524,7 @@ extern "C" int fga_dgix_build(fga_dev *dev, const fga_gdb *G, int nthreads, int 
 done:
   hipFree(dimg); hipFree(dboff); hipFree(dclen); hipFree(dinvp); hipFree(ditems); hipFree(dcount); hipFree(dctr);
   hipFree(dpartid);
+  hipFree(dmoff); hipFree(dmbeg); hipFree(dmend); hipFree(dperm);
   fga_dev_release(dev,SLOT_SORT0,buf0); fga_dev_release(dev,SLOT_SORT1,buf1);
   free(perm); free(invp);
   if (status != 0)

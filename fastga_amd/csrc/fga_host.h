@@ -89,6 +89,7 @@ int      fga_gix_layout(const fga_gdb *G, int nthreads, int *nctg, int **perm, i
                         int *postbytes, int *contbytes, int *nparts);
 void     fga_gix_ksplit(const int64_t *sbuck, int nparts, int *ksplit);
 const uint8_t *fga_gix_tmap(void);
+int      fga_gix_write_files(const fga_gix *X, const char *target);
 
 /* small helpers */
 char *fga_path_dir(const char *path);                       /* malloc'd directory part ("." if none) */

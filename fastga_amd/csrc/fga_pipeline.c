@@ -72,8 +72,8 @@ int fga_session_open(const char *root1, const char *root2, int device, fga_sessi
     if (fga_dev_open(device,&Z->dev)) goto fail;
     t0 = fga_wall();
     Z->devbuilt = !have1 || !have2;
-    if (have1 ? fga_dgix_upload(Z->dev,Z->x1,&Z->d1) : fga_dgix_build(Z->dev,Z->g1,8,0,&Z->d1,&Z->x1)) goto fail;
-    if (!Z->self && (have2 ? fga_dgix_upload(Z->dev,Z->x2,&Z->d2) : fga_dgix_build(Z->dev,Z->g2,8,0,&Z->d2,&Z->x2)))
+    if (have1 ? fga_dgix_upload(Z->dev,Z->x1,&Z->d1) : fga_dgix_build(Z->dev,Z->g1,8,FGA_GIX_SOFT_MASK,&Z->d1,&Z->x1)) goto fail;
+    if (!Z->self && (have2 ? fga_dgix_upload(Z->dev,Z->x2,&Z->d2) : fga_dgix_build(Z->dev,Z->g2,8,FGA_GIX_SOFT_MASK,&Z->d2,&Z->x2)))
       goto fail;
   }
   if (Z->x1->nctg < Z->g1->ncontig || (!Z->self && Z->x2->nctg < Z->g2->ncontig))
@@ -122,11 +122,6 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
 
   memset(&st,0,sizeof(st));
   st.load_s = Z->load_s; st.upload_s = Z->upload_s;
-  if (P->soft_mask && Z->devbuilt)
-    { fga_set_error("soft masking (-M) needs index files built with mask bytes (fga_gix_build_masked / GIXmake #); "
-                    "the index of this session was built on the device without them");
-      return 1;
-    }
   tstart = fga_wall();
   /* ---- phase 1 ---- */
   t0 = fga_wall();

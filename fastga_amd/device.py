@@ -48,11 +48,12 @@ class DeviceGix:
             self.h = C.c_void_p()
 
 
-def build_gix_device(dev, gdb, nthreads=8, host_copy=False):
+def build_gix_device(dev, gdb, nthreads=8, host_copy=False, use_mask=False):
     """GDB -> index on the device (fga_dgix_build); returns (DeviceGix, Gix descriptor)."""
     from .gixio import Gix
     dh, xh = C.c_void_p(), C.c_void_p()
-    check(dev.L.fga_dgix_build(dev.h, gdb.h, nthreads, int(host_copy), C.byref(dh), C.byref(xh)), "device GIX build")
+    flags = (1 if host_copy else 0) | (2 if use_mask else 0)
+    check(dev.L.fga_dgix_build(dev.h, gdb.h, nthreads, flags, C.byref(dh), C.byref(xh)), "device GIX build")
     x = Gix("<device>", handle=xh)
     d = DeviceGix.__new__(DeviceGix)
     d.dev, d.h = dev, dh

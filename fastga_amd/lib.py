@@ -119,6 +119,7 @@ def _declare(L):
         "fga_dev_sync": (i32, [vp]),
         "fga_dev_stage_ms": (C.c_float, [vp, i32]),
         "fga_dgix_build": (i32, [vp, vp, i32, i32, P(vp), P(vp)]),
+        "fga_gix_write_files": (i32, [vp, cp]),
         "fga_dgix_upload": (i32, [vp, vp, P(vp)]),
         "fga_dgix_free": (None, [vp]),
         "fga_seed_merge": (i32, [vp, vp, vp, P(MergeParams), i64, P(vp)]),

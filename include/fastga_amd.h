@@ -87,9 +87,14 @@ void  fga_dgix_free(fga_dgix *dgix);
 /* The index built on the device straight into HBM: replaces the GIXmake run for the seed merge's input (GIXmake.c
  * sample / distribution / sort / merge threads).  `gdb` must hold its bases (fga_gdb_open); nthreads plays GIXmake's
  * -T for the layout (contig padding, table parts).  *dgix is what fga_dgix_upload of the fga_gix_build files would
- * give, byte for byte; *gix is the matching host descriptor (perm, widths; with want_host_copy also index + table,
- * for writing the files or for tests).  Not for soft-masked builds (fga_gix_build_masked). */
-int   fga_dgix_build(fga_dev *dev, const fga_gdb *gdb, int nthreads, int want_host_copy, fga_dgix **dgix, fga_gix **gix);
+ * give, byte for byte; *gix is the matching host descriptor (perm, widths; with FGA_GIX_HOST_COPY also index + table,
+ * for writing the files or for tests). */
+#define FGA_GIX_HOST_COPY 1     /* keep index + table on the host as well (fga_gix_write_files, tests)          */
+#define FGA_GIX_SOFT_MASK 2     /* fill the soft-mask byte from the GDB's lower-case intervals (GIXmake's '#')  */
+int   fga_dgix_build(fga_dev *dev, const fga_gdb *gdb, int nthreads, int flags, fga_dgix **dgix, fga_gix **gix);
+/* <root>.gix + .<root>.ktab.N from an index that holds a host copy of its table (fga_dgix_build with want_host_copy,
+ * or one loaded with fga_gix_open): the files fga_gix_build / GIXmake write */
+int   fga_gix_write_files(const fga_gix *gix, const char *target);
 
 /* Adaptive seed merge: replaces adaptamer_merge -> new_merge_thread (FastGA.c:2281, 610) and, with
  * t2 == NULL, self_adaptamer_merge -> new_self_merge_thread (FastGA.c:2496, 1616).  Returns 0, or 2 when

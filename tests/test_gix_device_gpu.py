@@ -91,5 +91,28 @@ def test_end_to_end_without_index_files(toy_pair, tmp_path):
     H.ref_fastga(ra, rb, w, os.path.join(w, "ref"), threads=8)
     keep = lambda lines: [ln for ln in lines if ln[0] not in "!<"]          # noqa: E731
     assert keep(H.oneview(ours)) == keep(H.oneview(os.path.join(w, "ref.1aln")))
-    with pytest.raises(Exception):
-        D.run(roots[0], roots[1], ours, nthreads=8, soft_mask=True)
+
+
+def test_device_gix_mask_bytes_and_files(tmp_path, built_library):
+    """soft-mask bytes from the device build equal the host producer's (itself pinned against `GIXmake -T1 #`), and the
+    .gix/.ktab files written from the device-built index are the host producer's files byte for byte"""
+    import filecmp
+    from fastga_amd import workload, synth, device as D
+    from fastga_amd.gixio import Gdb, Gix
+    d = str(tmp_path)
+    lens = synth.contig_lengths(9, 10, 600_000)
+    A, mA, _, _ = synth.make_pair(9, lens, 0.0, repeat_frac=0.15, self_only=True)
+    ra = workload.build_genome(d, "A", A, masks=mA, use_mask=True)
+    host = Gix(ra + ".gix")
+    g = Gdb(ra + ".gdb")
+    dev = D.Device(0)
+    dg, x = D.build_gix_device(dev, g, 8, host_copy=True, use_mask=True)
+    assert np.array_equal(x.entries(), host.entries())
+    assert int(x.entries()[:, 7].max()) > 0                      # masks really present
+    out = os.path.join(d, "dev")
+    os.makedirs(out)
+    assert dev.L.fga_gix_write_files(x.h, os.path.join(out, "A").encode()) == 0
+    names = ["A.gix"] + [f".A.ktab.{p+1}" for p in range(host.nparts)]
+    for n in names:
+        assert filecmp.cmp(os.path.join(out, n), os.path.join(d, n), shallow=False), n
+    dg.free(); x.close(); host.close(); g.close(); dev.close()

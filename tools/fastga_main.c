@@ -152,7 +152,7 @@ int main(int argc, char *argv[])
     P.out_path = outpath;
   }
   for (i = 0; i < nsrc; i++)
-    if (prepare(src[i],root+i,P.nthreads,verbose,keep || P.soft_mask))
+    if (prepare(src[i],root+i,P.nthreads,verbose,keep))
       return 1;
   if (nsrc == 2 && strcmp(root[0],root[1]) == 0)
     nsrc = 1;
