@@ -3,7 +3,8 @@
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under
 torch.distributed.run, one rank per GPU.  A *step* is one pass of the hot path over one synthetic genome pair
-already resident in HBM (GIX tables + 2-bit genomes uploaded before the timed region).  Workload = BASELINE.json
+already resident in HBM (2-bit genomes uploaded and both GIX tables built on the device -- fga_dgix_build -- before the
+timed region; no index files are involved).  Workload = BASELINE.json
 configs[1]: synthetic 100 Mbp vs 100 Mbp, 2 % divergence, 40 contigs, repeats + rearrangements.
 Weak scaling: every rank owns its own pair (different seed) -- contig-pair work units are independent, so
 there is no data-path collective; only the per-rank record counts are gathered.
@@ -42,8 +43,9 @@ def parse():
 
 def cpu_baseline(args, ra, rb, workdir, verify_against=None):
     """The REAL reference FastGA (oracle/_ref, built from /root/reference by oracle/Makefile) on this box's host
-    cores, on the bench's own pair (prebuilt GDB/GIX from our producers); falls back to a smaller pair if the bench
-    pair is large, and to the oracle's seed-merge port if the reference binaries did not travel."""
+    cores, on the bench's own pair (GDB from our FASTA producer, .gix/.ktab files written from the device index build, so
+    the reference does not spend its wall time in GIXmake); falls back to a smaller pair if the bench pair is large, and
+    to the oracle's seed-merge port if the reference binaries did not travel."""
     from oracle import harness as H
     ncores = os.cpu_count() or 1
     threads = max(1, min(32, ncores))
@@ -99,9 +101,10 @@ def main():
     total = int(args.mbp * 1e6)
     threads = max(1, min(32, (os.cpu_count() or 8) // max(1, world)))
     t0 = time.time()
+    # FASTA -> GDB on the host; the two indices are built on the device when the session opens (no .gix files)
     ra, rb = workload.build_pair(workdir, seed=1 + rank, ncontig=args.contigs, total=total,
                                  divergence=args.div, repeat_frac=0.05, inv_frac=0.02, swap_frac=0.02,
-                                 threads=threads)
+                                 threads=threads, gix=False)
     prep_s = time.time() - t0
 
     # inputs resident in HBM before the timed region: both GIX tables + both 2-bit genomes
@@ -118,16 +121,18 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # informational (not part of `value`): the index of genome A built on the device instead of loaded from its files
-    gix_ms = None
-    try:
+    # informational (not part of `value`): kernel time of one device index build (HIP events of the session's own build
+    # of genome B); rank 0 also writes the .gix/.ktab files of both genomes from device builds, for the reference
+    # FastGA of the cpu_baseline leg
+    gix_ms = ses.dev_wrapper().stage_ms(5)
+    if rank == 0 and not args.no_cpu:
         from fastga_amd.gixio import Gdb
-        gA = Gdb(ra + ".gdb")
-        dgx, xg = D.build_gix_device(ses.dev_wrapper(), gA, 8)
-        gix_ms = ses.dev_wrapper().stage_ms(5)
-        dgx.free(); xg.close(); gA.close()
-    except Exception:
-        gix_ms = None
+        for r in (ra, rb):
+            g = Gdb(r + ".gdb")
+            dgx, xg = D.build_gix_device(ses.dev_wrapper(), g, 8, host_copy=True)
+            if ses.L.fga_gix_write_files(xg.h, r.encode()) != 0:
+                raise RuntimeError("cannot write index files for the CPU baseline")
+            dgx.free(); xg.close(); g.close()
 
     for _ in range(args.warmup):
         step()
