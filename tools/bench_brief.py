@@ -18,4 +18,4 @@ for ln in r.stdout.splitlines():
         print("kernel_ms", c["kernel_ms"], "seeds", c["seeds"], "hits", c["hits"], "alns", c["alignments"], "records", c["records"])
         if "cpu_baseline" in d:
             b = d["cpu_baseline"]
-            print("cpu", b.get("value"), b.get("kind"), "identical_1aln", b.get("identical_1aln"))
+            print("cpu", b.get("value"), b.get("kind"), "identical_1aln", b.get("identical_1aln"), "strict", b.get("identical_1aln_strict"))
