@@ -71,7 +71,7 @@ struct ext_shared
 __shared__ ext_shared ext_lds;     // the one LDS block of a (single-wavefront) workgroup
 
 struct ext_prof
-  { unsigned long long t_steps, t_unwind, t_total, nsteps, ph[6]; };
+  { unsigned long long t_steps, t_unwind, t_total, nsteps; };
 
 struct ext_state              // wave-uniform alignment state (the reference's Path + trace pointer)
   { int abpos, bbpos, aepos, bepos, diffs, tlen;
@@ -90,7 +90,7 @@ struct ext_args
     const int      *order;               // units by decreasing estimated work
     int            *next;                // work-queue head
     // alignment parameters
-    int   tspace, path_ave, self, aln_min, mscore, force_lds, dbg_unit;
+    int   tspace, path_ave, self, aln_min, mscore, force_lds;
     double aln_rate;
     const int16_t *table, *score;
     // scratch (per workgroup)
@@ -1269,7 +1269,6 @@ void extend_kernel(ext_args G)
   const int64_t tmid = G.trace_cap/2;
   unsigned long long ncalls = 0, nwaves = 0;
   ext_prof PF; PF.t_steps = PF.t_unwind = PF.t_total = PF.nsteps = 0;
-  for (int q = 0; q < 6; q++) PF.ph[q] = 0;
   const unsigned long long tk0 = clock64();
 
   while (1)
@@ -1544,7 +1543,6 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
   A.aln_min = prm->aln_min; A.aln_rate = prm->aln_rate;
   A.mscore = prm->score[0x7fff] / 15;      // SCORE[all matches] = 15 * mscore
   A.force_lds = getenv("FGA_EXTEND_FORCE_LDS") != NULL;
-  A.dbg_unit = getenv("FGA_EXTEND_DEBUG_UNIT") ? atoi(getenv("FGA_EXTEND_DEBUG_UNIT")) : -1;
   A.cell_cap = cell_cap; A.trace_cap = trace_cap; A.aln_cap = aln_cap; A.tbytes_cap = tb_cap;
 
   fga_unit *d_units = NULL; fga_hit *d_hits = NULL; int *d_order = NULL, *d_next = NULL;

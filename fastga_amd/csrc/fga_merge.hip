@@ -776,9 +776,6 @@ void seed_merge_wave_kernel(merge_args A, wave_out W)
   extern __shared__ __attribute__((aligned(16))) uint8_t raw[];      // A.wrawcap bytes (sized by the entry widths)
   __shared__ __attribute__((aligned(16))) uint64_t keyB[WTILE_COST];
   __shared__ __attribute__((aligned(16))) uint16_t own[WTILE_COST];
-#ifdef WAVE_FAST_EMIT
-  __shared__ uint8_t sown[64*16];              // seed slot -> lane of the T1 entry that emits it (fast emit path)
-#endif
 
   const int lane = threadIdx.x;
   const int E1 = A.E1, E2 = A.E2;
@@ -992,35 +989,6 @@ void seed_merge_wave_kernel(merge_args A, wave_out W)
             }
           // seed-parallel emission (the common case: one match round, no per-pair filter): every lane marks its
           // slots with its lane id, then lane = slot -- full wavefronts instead of a loop of max-count iterations
-#ifdef WAVE_FAST_EMIT         // measured: +3 % at 4 waves/SIMD, but its registers cost the 5th wave (-30 %): off by default
-          if (MODE != MODE_FLIP && !A.soft_mask && nlive <= 64 && T <= 64*16)
-            { const int cnt0 = r_cnt[0];
-              for (int q = 0; q < cnt0; q++)
-                sown[off + q] = (uint8_t) lane;
-              WSYNC();
-              const int i0 = r_i[0], low0 = r_low[0] & 0xffff, plen0 = r_plen[0];
-              for (int sb = 0; sb < T; sb += 64)           // wave-uniform trip count: __shfl needs every lane
-                { const int sl = sb + lane;
-                  const bool on = sl < T;
-                  const int ow = on ? (int) sown[sl] : 0;
-                  const int i = __shfl(i0,ow,64), lo_ = __shfl(low0,ow,64), pl = __shfl(plen0,ow,64), of = __shfl(off,ow,64);
-                  if (on)
-                    { int j = lo_ + (sl - of);
-                      if (MODE == MODE_SELF && j >= i)
-                        j += 1;
-                      uint32_t e0, e1_, e2_, e3, spos, sctg, ssign, c0, c1, c2, c3, cpos, cctg, csign;
-                      lds_read16(rawd,o1 + (uint32_t) i*E1,e0,e1_,e2_,e3);
-                      split_payload(e2_,e3,A.post1,A.cont1,spos,sctg,ssign);
-                      lds_read16(rawd,o2 + (uint32_t) j*E2,c0,c1,c2,c3);
-                      split_payload(c2,c3,A.post2,A.cont2,cpos,cctg,csign);
-                      const int64_t at = ((int64_t) sl < rem) ? chunk_pos + sl : nbase + ((int64_t) sl - rem);
-                      if (at < A.cap)
-                        A.out[at] = make_seed<MODE>(pl,spos,sctg,ssign,cpos,cctg,csign);
-                    }
-                }
-            }
-          else
-#endif
           if (total > 0)
             { const int mfull = A.soft_mask;
               #pragma unroll
