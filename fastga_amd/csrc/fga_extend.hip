@@ -303,6 +303,8 @@ __device__ __forceinline__ bool win_track(ext_seq &s, int pos)
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 typedef int v4i __attribute__((ext_vector_type(4)));      // a pebble cell as a plain 16-byte vector (int4 layout)
 #define UNI(v) __builtin_amdgcn_readfirstlane((int) (v))
+#define LIKELY(c)   __builtin_expect(!!(c),1)      // block placement: the common path of a wave step falls through,
+#define UNLIKELY(c) __builtin_expect(!!(c),0)      // a taken branch costs a single wavefront an instruction refetch
 #define BALLOT(p) __builtin_amdgcn_ballot_w64(p)
 __device__ __forceinline__ int64_t uni64(int64_t v)
 { const uint32_t lo = (uint32_t) UNI((uint32_t) v), hi = (uint32_t) UNI((uint32_t) ((uint64_t) v >> 32));
@@ -769,7 +771,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
             else       cnt = (x <= na) ? (na-x)/ts+1 : 0;
           }
         int tot, off = wscan_add_excl(act ? 1+cnt : 0,tot);
-        if (avail + tot > cell_cap)
+        if (UNLIKELY(avail + tot > cell_cap))
           BAIL(1)
         int ha = -1, hm = 0;
         if (act)
@@ -814,7 +816,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
   // sequence ends reached: drop the clipped diagonals, go on unless the best point itself sits on an end
   // (align.c:755-780; the "more" tip is only used with reach = 1, which FastGA never sets, FastGA.c:3757)
 #define CLIP_UPDATE()                                                                 \
-  if (more == 0)                                                                      \
+  if (UNLIKELY(more == 0))                                                            \
     { int cb = (S > 0) ? base_at(B,besta-bestx) : base_at(B,besta-bestx-1);           \
       int ca = (S > 0) ? base_at(A,bestx) : base_at(A,bestx-1);                       \
       if (cb != 4 && ca != 4)                                                         \
@@ -842,13 +844,13 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
       const bool newlow = low >= minp, newhgh = hgh <= maxp;
       if (!newlow) low += 1;
       if (!newhgh) hgh -= 1;
-      if (hgh-low+8 >= RC)
+      if (UNLIKELY(hgh-low+8 >= RC))
         BAIL(2)
       dif += 1;
       const int width = hgh-low+1;
 
       // ---- representation switch ----
-      if (regmode && width > REG_MAXW)
+      if (UNLIKELY(regmode && width > REG_MAXW))
         { const int k = KOF(lane);
           if (k >= olow && k <= ohgh)
             { shp->V[cur][k & RMASK] = V;
@@ -861,7 +863,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
           nspill += 1;
           WAVE_SYNC();
         }
-      else if (!regmode && width <= REG_BACK && !force_lds)
+      else if (UNLIKELY(!regmode && width <= REG_BACK && !force_lds))
         { const int l0 = (64 - width) >> 1;
           kref = (S > 0) ? hgh + l0 : low - l0;
           const int k = KOF(lane);
@@ -876,17 +878,17 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
           regmode = true;
         }
 
-      if ((dif & 3) == 0)       // fetches outside the window fall back to HBM, so tracking may lag a few steps
+      if (UNLIKELY((dif & 3) == 0))       // fetches outside the window fall back to HBM, so tracking may lag a few steps
         { wseq_track<S>(A,bestx);
           wseq_track<S>(B,besta-bestx);
         }
 
       uint64_t anyA = 0, anyB = 0;
 
-      if (regmode)
+      if (LIKELY(regmode))
         { // keep the active lanes inside [1,62]: rotate every register when the wave has drifted
           { const int la = LOF((S > 0) ? hgh : low), lb = LOF((S > 0) ? low : hgh);     // first / last active lane
-            if (la < 1 || lb > 62)
+            if (UNLIKELY(la < 1 || lb > 62))
               { const int want = (64 - (lb-la+1)) >> 1;
                 const int delta = want - la;                    // new lane = old lane + delta
                 const int srcl = lane - delta;
@@ -962,7 +964,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
           const bool tok = act ? trim_ok(shp,b,mscore) : false;
           int tot = 0, off = 0;
           uint64_t cm = BALLOT(ncreate > 0);
-          if (cm)
+          if (LIKELY(cm != 0))
             { const bool single = (BALLOT(ncreate > 1) == 0);
               if (single)                            // the usual case, one pebble per crossing lane: slots by mbcnt
                 { off = (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (cm >> 32),__builtin_amdgcn_mbcnt_lo((uint32_t) cm,0u));
@@ -970,9 +972,9 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                 }
               else
                 off = wscan_add_excl(ncreate,tot);
-              if (avail + tot > cell_cap)
+              if (UNLIKELY(avail + tot > cell_cap))
                 BAIL(1)
-              if (single)
+              if (LIKELY(single))
                 { if (ncreate > 0)
                     { const int idx = avail + off;
                       hm = na + S*ts*(cross-1);
@@ -1003,18 +1005,18 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
           const int pm = wscan_max_excl_nn(cn);
           bool rec = act && ((S > 0) ? c > besta : c < besta) && cn > pm;
           uint64_t rm = BALLOT(rec);
-          if (rm)
+          if (LIKELY(rm != 0))
             { int l = last_lane(rm);
               besta = rdlane(c,l);
               bestx = rdlane(x,l);
               int m = __popcll(b & WIN61);
               bool good = rec && m >= path_ave;
               uint64_t gm = BALLOT(good);
-              if (gm)
+              if (LIKELY(gm != 0))
                 { lasta = rdlane(c,last_lane(gm));
                   const bool trimok = good && tok;
                   uint64_t tm = BALLOT(trimok);
-                  if (tm)
+                  if (LIKELY(tm != 0))
                     { int l2 = last_lane(tm);
                       trima = rdlane(c,l2);
                       trimx = rdlane(x,l2);
@@ -1112,7 +1114,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
               uint64_t cm = BALLOT(ncreate > 0);
               if (cm)
                 { off = wscan_add_excl(ncreate,tot);
-                  if (avail + tot > cell_cap)
+                  if (UNLIKELY(avail + tot > cell_cap))
                     BAIL(1)
                 }
               if (act)
