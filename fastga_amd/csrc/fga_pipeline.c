@@ -154,6 +154,7 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
   { fga_sort_params sp;
     sp.amxpos = g1->maxctg; sp.bmxpos = self ? g1->maxctg : g2->maxctg;
     sp.nctg_a = x1->nctg;   sp.nctg_b = self ? x1->nctg : x2->nctg;
+    sp.anti_order_only = 1;          /* chains do not depend on the order inside an (anti-diagonal) tie */
     if (fga_seed_sort(dev,seeds,&sp,&keys)) goto done;
     fga_seeds_free(seeds); seeds = NULL;
     st.sort_kernel_ms = fga_dev_stage_ms(dev,FGA_STAGE_SORT);

@@ -272,7 +272,8 @@ extern "C" int fga_seed_sort(fga_dev *dev, const fga_dseeds *S, const fga_sort_p
   K->dev = dev; K->count = n;
   K->wa = L.wa; K->wb = L.wb; K->wd = L.wd; K->wt = L.wt;
   K->amxpos = prm->amxpos; K->bmxpos = prm->bmxpos;
-  const int npass = (tbits + 7) / 8;
+  const int lowbit = prm->anti_order_only ? 12 : 0;       // diag&63 and lcp: the chain scan does not need them ordered
+  const int npass = (tbits - lowbit + 7) / 8;
   const int ntiles = (int) ((n + STILE - 1) / STILE);
   dev->last_ms[FGA_STAGE_SORT] = 0.f;
   if (n == 0)
@@ -300,7 +301,7 @@ extern "C" int fga_seed_sort(fga_dev *dev, const fga_dseeds *S, const fga_sort_p
   const void *src = S->seeds;
   int cur = 0;
   for (int p = 0; p < npass; p++)
-    { const int shift = 8*p;
+    { const int shift = lowbit + 8*p;
       uint4 *dst = buf[cur];
       if (p == 0)
         { hipLaunchKernelGGL(sort_hist_kernel<true>,dim3(ntiles),dim3(ST),0,dev->stream,src,n,shift,L,hist,ntiles);

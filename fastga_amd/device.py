@@ -164,8 +164,8 @@ class Keys:
             self.h = C.c_void_p()
 
 
-def seed_sort(dev, seeds, amxpos, bmxpos, nctg_a, nctg_b):
-    prm = SortParams(amxpos, bmxpos, nctg_a, nctg_b)
+def seed_sort(dev, seeds, amxpos, bmxpos, nctg_a, nctg_b, anti_order_only=False):
+    prm = SortParams(amxpos, bmxpos, nctg_a, nctg_b, int(anti_order_only))
     h = C.c_void_p()
     check(dev.L.fga_seed_sort(dev.h, seeds.h, C.byref(prm), C.byref(h)), "seed sort")
     return Keys(dev, h)

@@ -78,7 +78,8 @@ class RunStats(C.Structure):
 
 
 class SortParams(C.Structure):
-    _fields_ = [("amxpos", C.c_int64), ("bmxpos", C.c_int64), ("nctg_a", C.c_int), ("nctg_b", C.c_int)]
+    _fields_ = [("amxpos", C.c_int64), ("bmxpos", C.c_int64), ("nctg_a", C.c_int), ("nctg_b", C.c_int),
+                ("anti_order_only", C.c_int)]
 
 
 STAGE_MERGE_PARTITION, STAGE_MERGE, STAGE_SORT, STAGE_CHAIN, STAGE_EXTEND = 0, 1, 2, 3, 4

@@ -114,6 +114,9 @@ typedef struct fga_dkeys fga_dkeys;
 typedef struct
   { int64_t amxpos, bmxpos;    /* longest contig of genome 1 / genome 2 (FastGA.c:5020-5041)  */
     int     nctg_a, nctg_b;    /* contig counts (bounds of the contig fields)                 */
+    int     anti_order_only;   /* 1: leave records of equal (strand, contigs, diag>>6, anti) in arrival order, i.e. do
+                                  not sort on diag&63 and lcp (two radix passes fewer).  The chain scan's result does not
+                                  depend on the order inside such a tie; 0 gives the reference's full record order.   */
   } fga_sort_params;
 
 int     fga_seed_sort(fga_dev *dev, const fga_dseeds *seeds, const fga_sort_params *prm, fga_dkeys **out);
