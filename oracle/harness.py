@@ -238,6 +238,49 @@ class RefAligner:
         tr = np.ctypeslib.as_array(C.cast(path.trace, C.POINTER(C.c_uint16)), shape=(max(n, 1),))[:n].copy()
         return (path.abpos, path.bbpos, path.aepos, path.bepos, path.diffs, tr)
 
+    def trace_pts(self, abuf, bbuf, path, tspace=100, selfie=False):
+        """the real reference's Compute_Trace_PTS (align.c:6171) in GREEDIEST mode on an alignment given as
+        (abpos, bbpos, aepos, bepos, diffs, uint16 trace points); returns (diffs, int32 edit trace)"""
+        abpos, bbpos, aepos, bepos, diffs, tr = path
+        pts = np.ascontiguousarray(tr, dtype=np.uint16).copy()
+        rp = _RPath()
+        rp.trace = pts.ctypes.data
+        rp.tlen, rp.diffs = len(pts), diffs
+        rp.abpos, rp.bbpos, rp.aepos, rp.bepos = abpos, bbpos, aepos, bepos
+        al = _RAlign()
+        al.path = C.pointer(rp)
+        al.flags = 0
+        al.aseq = abuf.ctypes.data + 1
+        al.bseq = (abuf.ctypes.data + 1) if selfie else (bbuf.ctypes.data + 1)
+        al.alen = len(abuf) - 2
+        al.blen = (len(abuf) if selfie else len(bbuf)) - 2
+        self.L.Compute_Trace_PTS.argtypes = [C.POINTER(_RAlign), C.c_void_p] + [C.c_int] * 4
+        st = self.L.Compute_Trace_PTS(C.byref(al), self.work, tspace, 0, 1, -1)
+        if st != 0:
+            raise RuntimeError("reference Compute_Trace_PTS failed")
+        n = rp.tlen
+        out = np.ctypeslib.as_array(C.cast(rp.trace, C.POINTER(C.c_int32)), shape=(max(n, 1),))[:n].copy()
+        return rp.diffs, out
+
     def close(self):
         self.L.Free_Work_Data(self.work)
         self.L.Free_Align_Spec(self.spec)
+
+
+def oracle_trace_pts(abuf, bbuf, path, tspace=100, selfie=False):
+    """oracle/trace_oracle.c: (diffs, int32 edit trace) of an alignment given by its trace points"""
+    L = oracle_lib()
+    abpos, bbpos, aepos, bepos, diffs, tr = path
+    pts = np.ascontiguousarray(tr, dtype=np.uint16)
+    cap = int(pts[0::2].sum()) + 16
+    out = np.zeros(cap, dtype=np.int32)
+    n, d = C.c_int(), C.c_int()
+    b = abuf if selfie else bbuf
+    st = L.oracle_trace_pts(C.c_void_p(abuf.ctypes.data + 1), C.c_int(len(abuf) - 2),
+                            C.c_void_p(b.ctypes.data + 1), C.c_int(len(b) - 2), C.c_int(int(selfie)),
+                            C.c_int(abpos), C.c_int(bbpos), C.c_int(aepos), C.c_int(bepos),
+                            C.c_void_p(pts.ctypes.data), C.c_int(len(pts)), C.c_int(tspace),
+                            C.c_void_p(out.ctypes.data), C.byref(n), C.byref(d))
+    if st != 0:
+        raise RuntimeError("oracle_trace_pts failed")
+    return d.value, out[:n.value].copy()

@@ -186,3 +186,44 @@ def test_soft_mask_bytes_match_single_thread_reference(tmp_path, built_library):
     for cols in (list(range(8)) + list(range(9, a.shape[1])), list(range(7)) + [8]):
         x, y = a[:, cols], b[:, cols]
         assert np.array_equal(x[np.lexsort(x.T[::-1])], y[np.lexsort(y.T[::-1])])
+
+
+@needs_ref
+def test_trace_pts_oracle_matches_reference_call_by_call():
+    """oracle/trace_oracle.c against the reference's Compute_Trace_PTS (align.c:6171, GREEDIEST) on the alignments the
+    reference's Local_Alignment finds: same edit script, same difference count"""
+    from fastga_amd import synth
+    rng = np.random.default_rng(20260927)
+    ref = H.RefAligner()
+    done = 0
+    for _ in range(400):
+        A, B, acomp, low, hgh, anti, lb, hb = _random_case(rng)
+        if acomp:
+            continue
+        abuf, bbuf = H.pad_seq(A), H.pad_seq(B)
+        p = ref.align(abuf, bbuf, low, hgh, anti, lb, hb, False)
+        if p[2] <= p[0]:
+            continue
+        rd, rt = ref.trace_pts(abuf, bbuf, p)
+        od, ot = H.oracle_trace_pts(abuf, bbuf, p)
+        assert rd == od
+        assert np.array_equal(rt, ot)
+        done += 1
+    assert done > 100
+    for trial in range(4):                       # self comparisons: the edit script may not touch the main diagonal
+        n = 40000
+        A = rng.integers(0, 4, n, dtype=np.uint8)
+        cp = synth.mutate(rng, A[1000:6000], 0.08)
+        A[n // 2:n // 2 + len(cp)] = cp
+        abuf = H.pad_seq(A)
+        a, b = n // 2 + 2500, 3500
+        if trial & 1:
+            a, b = b, a
+        low, hgh, anti = a - b - 20, a - b + 20, a + b
+        lb, hb = (low - 1, -1) if a > b else (-1, hgh + 1)
+        p = ref.align(abuf, abuf, low, hgh, anti, lb, hb, selfie=True)
+        assert p[2] - p[0] > 1000
+        rd, rt = ref.trace_pts(abuf, abuf, p, selfie=True)
+        od, ot = H.oracle_trace_pts(abuf, abuf, p, selfie=True)
+        assert rd == od and np.array_equal(rt, ot) and len(rt) > 50
+    ref.close()
