@@ -1,0 +1,529 @@
+// fga_trace.hip -- edit scripts of finished alignments from their trace points, on the device (gfx950).
+//
+// Replaces Compute_Trace_PTS (reference align.c:6171-6308) as every reader of a .1aln calls it (ALNtoPAF.c:278,
+// ALNshow.c:524, ALNtoPSL.c:193, ONEaln.c:1011: mode GREEDIEST, no band) and the O(NP) comparison it runs between
+// successive trace points, iter_np (align.c:5584-5903).  An alignment is cut by its trace points into panels of at
+// most `tspace` bases of A against at most 255 bases of B, each with a known number of differences; the panels are
+// independent, so the unit of work is one panel and one lane solves one panel:
+//
+//   trace_size_kernel   lane per alignment: number of raw output slots and of scratch cells its panels need
+//   trace_plan_kernel   lane per alignment: one 32-byte descriptor per panel
+//   trace_panel_kernel  lane per panel:     the furthest-reaching wave rows (16-bit cells: reach + move code), pointer
+//                                           reversal, forward walk emitting the indels into the panel's raw slots
+//   trace_count_kernel  wave per alignment: indels and differences of the alignment
+//   trace_scan_kernel   one workgroup:      exclusive prefix of the per-alignment counts
+//   trace_pack_kernel   wave per alignment: raw slots -> the dense int stream
+//
+// Cells: cost row d = -2..D, diagonal k (A index = B index + k); a cell holds reach+2 in its low 12 bits and the
+// move that produced it (code+1) above them.  The rows are swept exactly in the reference's order (above the target
+// diagonal downwards, below it upwards, then the target), because moves towards the target diagonal are free and
+// read the row being written.  A panel's row budget is its own difference count minus |M-N| (the reference allows
+// the largest count of the whole alignment; on a consistent trace the optimum never needs more than its own).
+#include "fga_device.hpp"
+
+namespace {
+
+struct trace_panel
+  { int32_t  aln;
+    int32_t  ab, bb;          // start of the panel in the (possibly complemented) contigs
+    uint16_t M, N;            // bases of A and B
+    uint16_t budget;          // cost rows 0..budget
+    uint16_t flags;           // 1: budget < 0, the trace is inconsistent
+    int64_t  scr;             // first scratch cell
+    int64_t  raw;             // first raw output slot
+  };                          // 40 bytes
+
+struct trace_args
+  { const fga_aln *alns;
+    const uint8_t *tbytes;
+    int64_t        naln;
+    int            tspace, self;
+    const uint32_t *imgA, *imgB, *imgBr;
+    const int64_t  *boffA, *boffB;
+    int64_t        padA, padB;
+    // per alignment
+    int64_t       *need;      // [2*naln]: raw slots, scratch cells
+    const int64_t *pbase, *rbase, *sbase;
+    int32_t       *atlen, *adiffs, *astat;
+    int64_t       *toff;
+    // per panel
+    trace_panel   *panels;
+    int32_t       *pcnt, *pdiff;
+    uint16_t      *cells;
+    int32_t       *raw, *dense;
+    int64_t        a0, a1;    // alignment range of this batch
+    int64_t        p0, np;    // panel range of this batch
+    int64_t        s0;        // scratch base of this batch
+  };
+
+__device__ __forceinline__ int panel_count(const fga_aln &a)
+{ return a.tlen >= 2 ? a.tlen >> 1 : 1; }
+
+// geometry of panel p of alignment a given the running (ab,bb): fills M, N, diffs; advances nothing
+__device__ __forceinline__ void panel_geom(const fga_aln &a, const uint8_t *t, int np, int p, int tspace,
+                                           int ab, int bb, int &M, int &N, int &pd)
+{ int ae, be;
+  if (p == np-1)
+    { ae = a.aepos; be = a.bepos; }
+  else
+    { ae = (ab/tspace)*tspace + tspace; be = bb + t[2*p+1]; }
+  pd = a.tlen >= 2 ? t[2*p] : a.diffs;
+  M = ae-ab; N = be-bb;
+}
+
+__device__ __forceinline__ void panel_need(int M, int N, int pd, int &budget, int &W, int &rows)
+{ const int del = M-N, adel = del < 0 ? -del : del;
+  budget = pd-adel;
+  const int b = budget < 0 ? 0 : budget;
+  W = adel + 2*(b >> 1) + 3;
+  rows = b+3;
+}
+
+__global__ void trace_size_kernel(trace_args T)
+{ const int64_t i = (int64_t) blockIdx.x*blockDim.x + threadIdx.x;
+  if (i >= T.naln) return;
+  const fga_aln a = T.alns[i];
+  const uint8_t *t = T.tbytes + a.toff;
+  const int np = panel_count(a);
+  int ab = a.abpos, bb = a.bbpos;
+  int64_t raw = 0, cells = 0;
+  for (int p = 0; p < np; p++)
+    { int M, N, pd, budget, W, rows;
+      panel_geom(a,t,np,p,T.tspace,ab,bb,M,N,pd);
+      panel_need(M,N,pd,budget,W,rows);
+      raw += pd;
+      cells += (int64_t) W*rows;
+      ab += M; bb += N;
+    }
+  T.need[2*i] = raw;
+  T.need[2*i+1] = cells;
+}
+
+__global__ void trace_plan_kernel(trace_args T)
+{ const int64_t i = T.a0 + (int64_t) blockIdx.x*blockDim.x + threadIdx.x;
+  if (i >= T.a1) return;
+  const fga_aln a = T.alns[i];
+  const uint8_t *t = T.tbytes + a.toff;
+  const int np = panel_count(a);
+  int ab = a.abpos, bb = a.bbpos;
+  int64_t raw = T.rbase[i], scr = T.sbase[i] - T.s0;
+  trace_panel *out = T.panels + (T.pbase[i] - T.p0);
+  for (int p = 0; p < np; p++)
+    { int M, N, pd, budget, W, rows;
+      panel_geom(a,t,np,p,T.tspace,ab,bb,M,N,pd);
+      panel_need(M,N,pd,budget,W,rows);
+      trace_panel P;
+      P.aln = (int32_t) i; P.ab = ab; P.bb = bb;
+      P.M = (uint16_t) M; P.N = (uint16_t) N;
+      P.budget = (uint16_t) (budget < 0 ? 0 : budget);
+      P.flags = (uint16_t) ((budget < 0 || M < 0 || N < 0 || M > 4000 || N > 4000) ? 1 : 0);
+      P.scr = scr; P.raw = raw;
+      out[p] = P;
+      raw += pd;
+      scr += (int64_t) W*rows;
+      ab += M; bb += N;
+    }
+}
+
+// 16 bases starting at 2-bit index `idx` of a packed image, base t in bits 2t
+__device__ __forceinline__ uint32_t window16(const uint32_t *img, int64_t idx)
+{ const int64_t w = idx >> 4;
+  const int s = (int) (idx & 15) << 1;
+  const uint64_t two = (uint64_t) img[w] | ((uint64_t) img[w+1] << 32);
+  return (uint32_t) (two >> s);
+}
+
+#define CELL_REACH(c)  ((int) ((c) & 0xfff) - 2)
+#define CELL_MOVE(c)   ((int) ((c) >> 12) - 1)
+#define MAKE_CELL(j,e) ((uint16_t) (((j)+2) | (((e)+1) << 12)))
+
+__global__ void __launch_bounds__(64) trace_panel_kernel(trace_args T)
+{ const int64_t q = (int64_t) blockIdx.x*blockDim.x + threadIdx.x;
+  if (q >= T.np) return;
+  const trace_panel P = T.panels[q];
+  const int64_t gq = T.p0 + q;
+  if (P.flags)
+    { T.pcnt[gq] = 0; T.pdiff[gq] = -1;
+      return;
+    }
+  const fga_aln a = T.alns[P.aln];
+  const int M = P.M, N = P.N, del = M-N, dmax = P.budget;
+  const int kmin = (del < 0 ? del : 0) - (dmax >> 1) - 1;
+  const int W = (del < 0 ? -del : del) + 2*(dmax >> 1) + 3;
+  uint16_t *C = T.cells + P.scr;
+#define AT(d,k) C[((d)+2)*W + ((k)-kmin)]
+
+  const bool comp = (a.flags & 0x1) != 0;
+  const uint32_t *imgB = comp ? T.imgBr : T.imgB;
+  const int64_t abase = (T.padA + T.boffA[a.aread])*4 + P.ab;
+  const int64_t bbase = (T.padB + T.boffB[a.bread])*4 + P.bb;
+
+  int posl = -0x3fffffff, posh = 0x3fffffff;         // a self comparison stays on its side of the main diagonal
+  if (T.self && a.aread == a.bread && !comp)
+    { const int db = P.ab-P.bb;
+      if (a.abpos-a.bbpos < 0) posh = -1-db; else posl = 1-db;
+    }
+
+  int low = del < 0 ? del : 0, hgh = del < 0 ? 0 : del;
+  for (int k = low-1; k <= hgh+1; k++)
+    { AT(-2,k) = MAKE_CELL(-2,0); AT(-1,k) = MAKE_CELL(-2,0); }
+  AT(-1,0) = MAKE_CELL(-1,0);
+  low += 1;
+  hgh -= 1;
+
+  int d;
+  for (d = 0; ; d++)
+    { if (d > dmax)
+        { T.pcnt[gq] = 0; T.pdiff[gq] = -1;
+          return;
+        }
+      if ((d & 1) == 0)
+        { if (low > posl) low -= 1;
+          if (hgh < posh) hgh += 1;
+        }
+      AT(d,hgh+1) = MAKE_CELL(-2,0);
+      AT(d,low-1) = MAKE_CELL(-2,0);
+
+      int j, e;
+#define CHOOSE(k,am,ap,mcode,pcode)                             \
+      { const int ac = CELL_REACH(AT(d-1,k)) + 1;               \
+        if (ac < (am))                                          \
+          { if ((ap) < (am)) { e = (mcode); j = (am); }         \
+            else             { e = (pcode); j = (ap); }         \
+          }                                                     \
+        else                                                    \
+          { if ((ap) < ac)   { e = 0;       j = ac;   }         \
+            else             { e = (pcode); j = (ap); }         \
+          }                                                     \
+      }
+#define SLIDE(k)                                                \
+      { const int lim = N < M-(k) ? N : M-(k);                  \
+        if (j >= 0 && j < lim)                                  \
+          { do                                                  \
+              { const uint32_t x = window16(T.imgA,abase+(k)+j) ^ window16(imgB,bbase+j);  \
+                if (x != 0)                                     \
+                  { j += __builtin_ctz(x) >> 1;                 \
+                    break;                                      \
+                  }                                             \
+                j += 16;                                        \
+              }                                                 \
+            while (j < lim);                                    \
+            if (j > lim) j = lim;                               \
+          }                                                     \
+        AT(d,k) = MAKE_CELL(j,e);                               \
+      }
+
+      j = -2;
+      for (int k = hgh; k > del; k--)
+        { const int ap = j+1, am = CELL_REACH(AT(d-2,k-1));
+          CHOOSE(k,am,ap,-1,4)
+          SLIDE(k)
+        }
+      j = -2;
+      for (int k = low; k < del; k++)
+        { const int ap = CELL_REACH(AT(d-2,k+1)) + 1, am = j;
+          CHOOSE(k,am,ap,2,1)
+          SLIDE(k)
+        }
+      { const int ap = CELL_REACH(AT(d,del+1)) + 1, am = j;
+        CHOOSE(del,am,ap,2,4)
+        SLIDE(del)
+      }
+      if (j >= N)
+        break;
+    }
+
+  // reverse the move list from (d,del) back to (0,0), then walk it forwards emitting the indels
+  { int k = del, e, h, m;
+    uint16_t c;
+    c = AT(0,0); AT(0,0) = (uint16_t) ((c & 0xfff) | (4 << 12));
+    c = AT(d,k); e = CELL_MOVE(c); AT(d,k) = (uint16_t) ((c & 0xfff) | (4 << 12));
+    if (d == 0 && k == 0) e = 3;
+    while (e != 3)
+      { h = k+e;
+        if (e > 1)       h -= 3;
+        else if (e == 0) d -= 1;
+        else             d -= 2;
+        c = AT(d,h);
+        m = CELL_MOVE(c);
+        AT(d,h) = (uint16_t) ((c & 0xfff) | ((e+1) << 12));
+        e = m;
+        k = h;
+      }
+    int32_t *out = T.raw + P.raw;
+    int n = 0;
+    k = d = 0;
+    e = CELL_MOVE(AT(0,0));
+    while (e != 3)
+      { const int r = CELL_REACH(AT(d,k));
+        h = k-e;
+        if (e > 1)       h += 3;
+        else if (e == 0) d += 1;
+        else             d += 2;
+        if (h > k)
+          out[n++] = P.bb + 1 + r;
+        else if (h < k)
+          out[n++] = -(P.ab + 1 + r + k);
+        k = h;
+        e = CELL_MOVE(AT(d,h));
+      }
+    T.pcnt[gq] = n;
+    T.pdiff[gq] = d + (del < 0 ? -del : del);
+  }
+#undef AT
+}
+
+__device__ __forceinline__ int wave_sum(int v)
+{ for (int o = 32; o > 0; o >>= 1)
+    v += __shfl_xor(v,o);
+  return v;
+}
+
+__global__ void __launch_bounds__(64) trace_count_kernel(trace_args T)
+{ const int64_t i = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int np = panel_count(T.alns[i]);
+  const int64_t pb = T.pbase[i];
+  int cnt = 0, dif = 0, bad = 0;
+  for (int p = lane; p < np; p += 64)
+    { const int pdv = T.pdiff[pb+p];
+      cnt += T.pcnt[pb+p];
+      if (pdv < 0) bad = 1; else dif += pdv;
+    }
+  cnt = wave_sum(cnt); dif = wave_sum(dif); bad = wave_sum(bad);
+  if (lane == 0)
+    { T.atlen[i] = cnt; T.adiffs[i] = dif; T.astat[i] = bad; }
+}
+
+// exclusive prefix of n 32-bit counts into 64-bit offsets; out[n] = total.  One workgroup of 1024.
+__global__ void __launch_bounds__(1024) trace_scan_kernel(const int32_t *cnt, int64_t *out, int64_t n)
+{ __shared__ int64_t part[1024];
+  const int t = threadIdx.x;
+  const int64_t per = (n + 1023) / 1024;
+  const int64_t lo = t*per < n ? t*per : n, hi = lo+per < n ? lo+per : n;
+  int64_t s = 0;
+  for (int64_t i = lo; i < hi; i++)
+    s += cnt[i];
+  part[t] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1)
+    { const int64_t v = t >= o ? part[t-o] : 0;
+      __syncthreads();
+      part[t] += v;
+      __syncthreads();
+    }
+  s = t > 0 ? part[t-1] : 0;
+  for (int64_t i = lo; i < hi; i++)
+    { out[i] = s;
+      s += cnt[i];
+    }
+  if (t == 1023)
+    out[n] = part[1023];
+}
+
+__global__ void __launch_bounds__(64) trace_pack_kernel(trace_args T)
+{ const int64_t i = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int np = panel_count(T.alns[i]);
+  const int64_t pb = T.pbase[i];
+  int32_t *dst = T.dense + T.toff[i];
+  int base = 0;
+  for (int p0 = 0; p0 < np; p0 += 64)
+    { const int p = p0+lane;
+      const int c = p < np ? T.pcnt[pb+p] : 0;
+      int inc = c;
+      for (int o = 1; o < 64; o <<= 1)
+        { const int v = __shfl_up(inc,o);
+          if (lane >= o) inc += v;
+        }
+      if (p < np)
+        { const int32_t *src = T.raw + T.panels[pb+p].raw;
+          int32_t *d = dst + base + (inc-c);
+          for (int x = 0; x < c; x++)
+            d[x] = src[x];
+        }
+      base += __shfl(inc,63);
+    }
+}
+
+}  // namespace
+
+extern "C" void fga_traces_free(fga_traces *t)
+{ if (t == NULL) return;
+  free(t->toff); free(t->tlen); free(t->diffs); free(t->trace);
+  free(t);
+}
+
+extern "C" int fga_trace_pts(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome *GB, const fga_alns *alns,
+                             int tspace, int self, fga_traces **out)
+{ *out = NULL;
+  FGA_HIP(hipSetDevice(dev->device));
+  fga_traces *R = (fga_traces *) calloc(1,sizeof(fga_traces));
+  if (R == NULL)
+    { fga_set_error("out of memory");
+      return 1;
+    }
+  const int64_t n = alns->naln;
+  R->naln = n;
+  dev->last_ms[FGA_STAGE_TRACE] = 0.f;
+  if (n == 0)
+    { *out = R;
+      return 0;
+    }
+  int any_comp = 0;
+  int64_t npan = 0;
+  std::vector<int64_t> pbase(n+1);
+  for (int64_t i = 0; i < n; i++)
+    { const fga_aln &a = alns->alns[i];
+      if (a.flags & 0x1) any_comp = 1;
+      pbase[i] = npan;
+      npan += a.tlen >= 2 ? a.tlen >> 1 : 1;
+      if (a.tlen & 1)
+        { fga_set_error("fga_trace_pts: alignment %lld has an odd trace length",(long long) i);
+          free(R);
+          return 1;
+        }
+    }
+  pbase[n] = npan;
+  if (any_comp && GB->img_rc == NULL)
+    { fga_set_error("fga_trace_pts: genome 2 was uploaded without its reverse-complement image");
+      free(R);
+      return 1;
+    }
+
+  int rc = 1;
+  hipError_t e = hipSuccess;
+  fga_aln *d_alns = NULL; uint8_t *d_tb = NULL;
+  int64_t *d_need = NULL, *d_pbase = NULL, *d_rbase = NULL, *d_sbase = NULL, *d_toff = NULL;
+  int32_t *d_atlen = NULL, *d_adiffs = NULL, *d_astat = NULL, *d_pcnt = NULL, *d_pdiff = NULL;
+  int32_t *d_raw = NULL, *d_dense = NULL;
+  trace_panel *d_panels = NULL; uint16_t *d_cells = NULL;
+  std::vector<int64_t> need(2*n), rbase(n+1), sbase(n+1);
+  trace_args T;
+  memset(&T,0,sizeof(T));
+  int64_t total = 0, rawtot = 0;
+  const int64_t cell_cap = (int64_t) 4 << 30;          // scratch cells per batch (8 GB)
+  const size_t tbbytes = (size_t) (alns->ntrace > 0 ? alns->ntrace : 1);
+
+#define TRY(call) do { if ((e = (call)) != hipSuccess) goto fail; } while (0)
+  TRY(hipMalloc(&d_alns,sizeof(fga_aln)*n));
+  TRY(hipMalloc(&d_tb,tbbytes+16));
+  TRY(hipMalloc(&d_need,sizeof(int64_t)*2*n));
+  TRY(hipMalloc(&d_pbase,sizeof(int64_t)*(n+1)));
+  TRY(hipMalloc(&d_rbase,sizeof(int64_t)*(n+1)));
+  TRY(hipMalloc(&d_sbase,sizeof(int64_t)*(n+1)));
+  TRY(hipMalloc(&d_toff,sizeof(int64_t)*(n+1)));
+  TRY(hipMalloc(&d_atlen,sizeof(int32_t)*n));
+  TRY(hipMalloc(&d_adiffs,sizeof(int32_t)*n));
+  TRY(hipMalloc(&d_astat,sizeof(int32_t)*n));
+  TRY(hipMalloc(&d_pcnt,sizeof(int32_t)*npan));
+  TRY(hipMalloc(&d_pdiff,sizeof(int32_t)*npan));
+  TRY(hipMemcpyAsync(d_alns,alns->alns,sizeof(fga_aln)*n,hipMemcpyHostToDevice,dev->stream));
+  if (alns->ntrace > 0)
+    TRY(hipMemcpyAsync(d_tb,alns->tbytes,alns->ntrace,hipMemcpyHostToDevice,dev->stream));
+  TRY(hipMemcpyAsync(d_pbase,pbase.data(),sizeof(int64_t)*(n+1),hipMemcpyHostToDevice,dev->stream));
+
+  T.alns = d_alns; T.tbytes = d_tb; T.naln = n; T.tspace = tspace; T.self = self;
+  T.imgA = (const uint32_t *) GA->img; T.imgB = (const uint32_t *) GB->img; T.imgBr = (const uint32_t *) GB->img_rc;
+  T.boffA = GA->boff; T.boffB = GB->boff; T.padA = GA->pad; T.padB = GB->pad;
+  T.need = d_need; T.pbase = d_pbase; T.rbase = d_rbase; T.sbase = d_sbase; T.toff = d_toff;
+  T.atlen = d_atlen; T.adiffs = d_adiffs; T.astat = d_astat; T.pcnt = d_pcnt; T.pdiff = d_pdiff;
+
+  hipEventRecord(dev->ev0,dev->stream);
+  hipLaunchKernelGGL(trace_size_kernel,dim3((unsigned) ((n+255)/256)),dim3(256),0,dev->stream,T);
+  TRY(hipMemcpyAsync(need.data(),d_need,sizeof(int64_t)*2*n,hipMemcpyDeviceToHost,dev->stream));
+  TRY(hipStreamSynchronize(dev->stream));
+  { int64_t r = 0, s = 0;
+    for (int64_t i = 0; i < n; i++)
+      { rbase[i] = r; sbase[i] = s;
+        r += need[2*i]; s += need[2*i+1];
+      }
+    rbase[n] = r; sbase[n] = s;
+    rawtot = r;
+  }
+  TRY(hipMalloc(&d_raw,sizeof(int32_t)*(rawtot+1)));
+  TRY(hipMemcpyAsync(d_rbase,rbase.data(),sizeof(int64_t)*(n+1),hipMemcpyHostToDevice,dev->stream));
+  TRY(hipMemcpyAsync(d_sbase,sbase.data(),sizeof(int64_t)*(n+1),hipMemcpyHostToDevice,dev->stream));
+  T.raw = d_raw;
+
+  { // batches of whole alignments bounded by scratch cells
+    int64_t maxcells = 0, maxpan = 0;
+    std::vector<int64_t> cut(1,0);
+    for (int64_t i = 0; i < n; )
+      { int64_t j = i+1;
+        while (j < n && sbase[j+1]-sbase[i] <= cell_cap) j++;
+        cut.push_back(j);
+        if (sbase[j]-sbase[i] > maxcells) maxcells = sbase[j]-sbase[i];
+        if (pbase[j]-pbase[i] > maxpan) maxpan = pbase[j]-pbase[i];
+        i = j;
+      }
+    TRY(hipMalloc(&d_cells,sizeof(uint16_t)*(maxcells+1)));
+    TRY(hipMalloc(&d_panels,sizeof(trace_panel)*npan));
+    T.cells = d_cells;
+    for (size_t b = 0; b+1 < cut.size(); b++)
+      { T.a0 = cut[b]; T.a1 = cut[b+1];
+        T.p0 = pbase[T.a0]; T.np = pbase[T.a1]-T.p0;
+        T.s0 = sbase[T.a0];
+        T.panels = d_panels + T.p0;
+        const int64_t na = T.a1-T.a0;
+        hipLaunchKernelGGL(trace_plan_kernel,dim3((unsigned) ((na+63)/64)),dim3(64),0,dev->stream,T);
+        hipLaunchKernelGGL(trace_panel_kernel,dim3((unsigned) ((T.np+63)/64)),dim3(64),0,dev->stream,T);
+      }
+    T.panels = d_panels; T.p0 = 0;
+    (void) maxpan;
+  }
+  hipLaunchKernelGGL(trace_count_kernel,dim3((unsigned) n),dim3(64),0,dev->stream,T);
+  hipLaunchKernelGGL(trace_scan_kernel,dim3(1),dim3(1024),0,dev->stream,d_atlen,d_toff,n);
+  R->toff = (int64_t *) malloc(sizeof(int64_t)*(n+1));
+  R->tlen = (int32_t *) malloc(sizeof(int32_t)*n);
+  R->diffs = (int32_t *) malloc(sizeof(int32_t)*n);
+  if (R->toff == NULL || R->tlen == NULL || R->diffs == NULL)
+    { fga_set_error("out of memory");
+      goto done;
+    }
+  TRY(hipMemcpyAsync(R->toff,d_toff,sizeof(int64_t)*(n+1),hipMemcpyDeviceToHost,dev->stream));
+  TRY(hipStreamSynchronize(dev->stream));
+  total = R->toff[n];
+  TRY(hipMalloc(&d_dense,sizeof(int32_t)*(total+1)));
+  T.dense = d_dense;
+  hipLaunchKernelGGL(trace_pack_kernel,dim3((unsigned) n),dim3(64),0,dev->stream,T);
+  hipEventRecord(dev->ev1,dev->stream);
+  R->trace = (int32_t *) malloc(sizeof(int32_t)*(total+1));
+  if (R->trace == NULL)
+    { fga_set_error("out of memory");
+      goto done;
+    }
+  TRY(hipMemcpyAsync(R->trace,d_dense,sizeof(int32_t)*total,hipMemcpyDeviceToHost,dev->stream));
+  TRY(hipMemcpyAsync(R->tlen,d_atlen,sizeof(int32_t)*n,hipMemcpyDeviceToHost,dev->stream));
+  TRY(hipMemcpyAsync(R->diffs,d_adiffs,sizeof(int32_t)*n,hipMemcpyDeviceToHost,dev->stream));
+  { std::vector<int32_t> stat(n);
+    TRY(hipMemcpyAsync(stat.data(),d_astat,sizeof(int32_t)*n,hipMemcpyDeviceToHost,dev->stream));
+    TRY(hipStreamSynchronize(dev->stream));
+    TRY(hipGetLastError());
+    hipEventElapsedTime(&dev->last_ms[FGA_STAGE_TRACE],dev->ev0,dev->ev1);
+    for (int64_t i = 0; i < n; i++)
+      if (stat[i] != 0)
+        { fga_set_error("fga_trace_pts: alignment %lld: trace points are inconsistent with the sequences "
+                        "(Compute_Trace_PTS would fail)",(long long) i);
+          goto done;
+        }
+  }
+  R->ntrace = total;
+  R->npanels = npan;
+  rc = 0;
+  goto done;
+#undef TRY
+
+fail:
+  fga_set_error("fga_trace_pts: %s",hipGetErrorString(e));
+done:
+  hipFree(d_alns); hipFree(d_tb); hipFree(d_need); hipFree(d_pbase); hipFree(d_rbase); hipFree(d_sbase);
+  hipFree(d_toff); hipFree(d_atlen); hipFree(d_adiffs); hipFree(d_astat); hipFree(d_pcnt); hipFree(d_pdiff);
+  hipFree(d_raw); hipFree(d_dense); hipFree(d_panels); hipFree(d_cells);
+  if (rc != 0)
+    { fga_traces_free(R);
+      return 1;
+    }
+  *out = R;
+  return 0;
+}

@@ -282,6 +282,28 @@ def extend(dev, ga, gb, hitlist, path_ave, table, score, tspace=100, self_cmp=Fa
     return alns, tb, stats
 
 
+def trace_pts(dev, ga, gb, alns, tb, tspace=100, self_cmp=False):
+    """fga_trace_pts: Compute_Trace_PTS (align.c:6171, GREEDIEST) of every alignment of a set on the device.
+    alns: ALN_DTYPE records, tb: their trace bytes.  Returns (toff[n+1], tlen[n], diffs[n], ints)."""
+    from .lib import Traces
+    alns = np.ascontiguousarray(alns)
+    tb = np.ascontiguousarray(tb, dtype=np.uint8)
+    a = Alns(len(alns), len(tb), 0, 0, alns.ctypes.data, tb.ctypes.data)
+    out = C.POINTER(Traces)()
+    check(dev.L.fga_trace_pts(dev.h, ga.h, gb.h, C.byref(a), tspace, int(self_cmp), C.byref(out)), "trace_pts")
+    t = out.contents
+    n, nt = t.naln, t.ntrace
+
+    def take(ptr, count, dt):
+        if count == 0:
+            return np.zeros(0, dtype=dt)
+        return np.frombuffer((C.c_char * (count * np.dtype(dt).itemsize)).from_address(ptr), dtype=dt).copy()
+    res = (take(t.toff, n + 1 if n else 0, np.int64), take(t.tlen, n, np.int32), take(t.diffs, n, np.int32),
+           take(t.trace, nt, np.int32), {"panels": t.npanels})
+    dev.L.fga_traces_free(out)
+    return res
+
+
 def run(root1, root2=None, out_path=None, device=0, freq=10, soft_mask=False, symmetric=False, chain_break=1000,
         chain_min=85, align_min=100, identity=0.7, nthreads=8, command_line="FastGA"):
     """The whole hot path (fga_run): prebuilt GDB/GIX roots in, .1aln out.  Returns the stats as a dict."""

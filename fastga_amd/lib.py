@@ -62,6 +62,11 @@ class Alns(C.Structure):
                 ("alns", C.c_void_p), ("tbytes", C.c_void_p)]
 
 
+class Traces(C.Structure):
+    _fields_ = [("naln", C.c_int64), ("ntrace", C.c_int64), ("npanels", C.c_int64), ("toff", C.c_void_p),
+                ("tlen", C.c_void_p), ("diffs", C.c_void_p), ("trace", C.c_void_p)]
+
+
 class RunParams(C.Structure):
     _fields_ = [("device", C.c_int), ("freq", C.c_int), ("soft_mask", C.c_int), ("symmetric", C.c_int),
                 ("chain_break", C.c_int), ("chain_min", C.c_int), ("align_min", C.c_int),
@@ -83,6 +88,7 @@ class SortParams(C.Structure):
 
 
 STAGE_MERGE_PARTITION, STAGE_MERGE, STAGE_SORT, STAGE_CHAIN, STAGE_EXTEND = 0, 1, 2, 3, 4
+STAGE_GIX, STAGE_TRACE = 5, 6
 
 
 def _declare(L):
@@ -151,6 +157,8 @@ def _declare(L):
         "fga_filter_alignments": (i32, [P(Alns), P(P(Alns))]),
         "fga_write_1aln": (i32, [cp, vp, vp, P(Alns), i32, cp, cp, cp]),
         "fga_write_1aln_binary": (i32, [cp, vp, vp, P(Alns), i32, cp, cp, cp]),
+        "fga_trace_pts": (i32, [vp, vp, vp, P(Alns), i32, i32, P(P(Traces))]),
+        "fga_traces_free": (None, [P(Traces)]),
         "fga_run": (i32, [cp, cp, P(RunParams), P(RunStats)]),
         "fga_session_open": (i32, [cp, cp, i32, P(vp)]),
         "fga_session_run": (i32, [vp, P(RunParams), P(RunStats)]),

@@ -75,7 +75,7 @@ typedef struct
   } fga_merge_params;
 
 enum { FGA_STAGE_MERGE_PARTITION = 0, FGA_STAGE_MERGE = 1, FGA_STAGE_SORT = 2, FGA_STAGE_CHAIN = 3,
-       FGA_STAGE_EXTEND = 4, FGA_STAGE_GIX = 5, FGA_NSTAGES = 8 };
+       FGA_STAGE_EXTEND = 4, FGA_STAGE_GIX = 5, FGA_STAGE_TRACE = 6, FGA_NSTAGES = 8 };
 
 int   fga_dev_open(int device, fga_dev **out);
 void  fga_dev_close(fga_dev *dev);
@@ -218,6 +218,25 @@ int  fga_write_1aln(const char *path, const fga_gdb *g1, const fga_gdb *g2 /* NU
  * reference's seeking readers -- ALNtoPAF, ALNshow -- accept it); fga_write_1aln is the ASCII form */
 int  fga_write_1aln_binary(const char *path, const fga_gdb *g1, const fga_gdb *g2 /* NULL: self */, const fga_alns *alns,
                            int tspace, const char *db1_name, const char *db2_name, const char *command_line);
+
+/* ---- edit scripts from trace points: replaces Compute_Trace_PTS (align.h:341-342, align.c:6171-6308) in the mode every
+ *      reader of a .1aln uses it (ALNtoPAF.c:278, ALNshow.c:524, ALNtoPSL.c:193, ONEaln.c:1011: GREEDIEST, dlow > dhgh)
+ *      for all alignments of a set at once.  The result is Path.trace / Path.tlen / Path.diffs of each alignment after
+ *      the call: one int per indel, -(p) = gap in A before its p-th base, +(q) = gap in B before its q-th base (1-based
+ *      contig coordinates, B complemented when COMP_FLAG is set).  genome 2 needs its reverse-complement image when
+ *      the set holds complement alignments.  self != 0 reproduces the reference's aseq == bseq rule (align.c:6256-6265)
+ *      for same-contig forward alignments; the reference's readers load A and B into separate buffers, i.e. self = 0. */
+typedef struct
+  { int64_t  naln, ntrace, npanels;
+    int64_t *toff;             /* [naln+1] offset of each alignment's ints in trace */
+    int32_t *tlen;             /* [naln]   Path.tlen after Compute_Trace_PTS        */
+    int32_t *diffs;            /* [naln]   Path.diffs after Compute_Trace_PTS       */
+    int32_t *trace;            /* [ntrace]                                          */
+  } fga_traces;
+
+int  fga_trace_pts(fga_dev *dev, const fga_dgenome *ga, const fga_dgenome *gb, const fga_alns *alns,
+                   int tspace, int self, fga_traces **out);
+void fga_traces_free(fga_traces *t);
 
 /* ---- the whole hot path: what `FastGA -1:<out> <root1> [<root2>]` does between "GIX present" and ".1aln closed" */
 typedef struct

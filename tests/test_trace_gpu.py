@@ -1,0 +1,113 @@
+"""GPU parity: fga_trace_pts (edit scripts from trace points, Compute_Trace_PTS align.c:6171 in GREEDIEST mode) against
+the CPU oracle oracle/trace_oracle.c, which tests/test_oracle_vs_reference.py pins call by call against the reference."""
+import ctypes as C
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _alignments(dev, ra, rb, self_cmp=False, aln_rate=0.35):
+    """merge -> sort -> chain -> extend on a prebuilt pair; returns everything the trace stage needs"""
+    from fastga_amd.gixio import Gix, Gdb
+    from fastga_amd import device as D
+    A, B = Gix(ra + ".gix"), Gix(rb + ".gix")
+    ga, gb = Gdb(ra + ".gdb"), Gdb(rb + ".gdb")
+    amx, bmx = int(ga.maxctg), int(gb.maxctg)
+    dA, dB = dev.upload(A), dev.upload(B)
+    seeds = D.seed_merge(dev, dA, None if self_cmp else dB)
+    keys = D.seed_sort(dev, seeds, amx, bmx, A.nctg, B.nctg)
+    clen = np.zeros(A.nctg, dtype=np.int64)               # the index pads the contig table to the thread count
+    clen[:len(ga.clen)] = ga.clen
+    hl = D.chain_scan_device(dev, keys, 2000, 170, amx, bmx, clen[A.perm])
+    f4 = (C.c_float * 4)()
+    ga.L.fga_gdb_freq(ga.h, f4)
+    pa, table, score = D.align_spec(0.7, 100, list(f4))
+    dga = D.DeviceGenome(dev, ga, A.perm, True)
+    dgb = D.DeviceGenome(dev, gb, B.perm, True)
+    alns, tb, _ = D.extend(dev, dga, dgb, hl, pa, table, score, aln_min=50, aln_rate=aln_rate, self_cmp=self_cmp)
+    keys.free(); seeds.free(); dA.free(); dB.free()
+    return ga, gb, dga, dgb, alns, tb
+
+
+def _check_against_oracle(ga, gb, alns, tb, res, self_cmp=False):
+    from fastga_amd import synth
+    from oracle import harness as H
+    toff, tlen, diffs, ints, _ = res
+    assert len(tlen) == len(alns) and len(toff) == len(alns) + 1
+    cache = {}
+    nindel = 0
+    for i, a in enumerate(alns):
+        c1, c2, comp = int(a["aread"]), int(a["bread"]), int(a["flags"]) & 1
+        if ("a", c1) not in cache:
+            cache[("a", c1)] = H.pad_seq(ga.contig(c1))
+        if ("b", c2, comp) not in cache:
+            s = gb.contig(c2)
+            cache[("b", c2, comp)] = H.pad_seq(synth.revcomp(s) if comp else s)
+        t = tb[int(a["toff"]):int(a["toff"]) + int(a["tlen"])].astype(np.uint16)
+        path = (int(a["abpos"]), int(a["bbpos"]), int(a["aepos"]), int(a["bepos"]), int(a["diffs"]), t)
+        selfie = bool(self_cmp and c1 == c2 and not comp)
+        od, ot = H.oracle_trace_pts(cache[("a", c1)], cache[("b", c2, comp)], path, selfie=selfie)
+        assert int(tlen[i]) == len(ot), i
+        assert int(diffs[i]) == od, i
+        assert np.array_equal(ints[int(toff[i]):int(toff[i]) + int(tlen[i])], ot), i
+        assert od <= int(a["diffs"])                       # the rebuilt script is never worse than the wave's count
+        nindel += len(ot)
+    assert int(toff[-1]) == nindel == len(ints)
+    return nindel
+
+
+def test_trace_pts_matches_oracle_on_pipeline_alignments(toy_pair):
+    from fastga_amd import device as D
+    d, ra, rb = toy_pair
+    dev = D.Device(0)
+    ga, gb, dga, dgb, alns, tb = _alignments(dev, ra, rb)
+    assert len(alns) > 20 and (alns["flags"] & 1).any() and not (alns["flags"] & 1).all()
+    res = D.trace_pts(dev, dga, dgb, alns, tb)
+    n = _check_against_oracle(ga, gb, alns, tb, res)
+    assert n > 1000 and res[4]["panels"] == int((alns["tlen"] // 2).sum())
+    # order independence and empty input
+    perm = np.random.default_rng(3).permutation(len(alns))
+    res2 = D.trace_pts(dev, dga, dgb, alns[perm], tb)
+    for q, i in enumerate(perm[:50]):
+        assert np.array_equal(res2[3][int(res2[0][q]):int(res2[0][q + 1])], res[3][int(res[0][i]):int(res[0][i + 1])])
+    empty = D.trace_pts(dev, dga, dgb, alns[:0], tb[:0])
+    assert len(empty[1]) == 0 and len(empty[3]) == 0
+    dga.free(); dgb.free(); dev.close()
+
+
+def test_trace_pts_high_divergence_and_missing_revcomp(tmp_path, built_library):
+    from fastga_amd import device as D, workload
+    ra, rb = workload.build_pair(str(tmp_path), seed=5, ncontig=5, total=300_000, divergence=0.15, inv_frac=0.1)
+    dev = D.Device(0)
+    ga, gb, dga, dgb, alns, tb = _alignments(dev, ra, rb, aln_rate=0.45)
+    assert len(alns) > 5
+    res = D.trace_pts(dev, dga, dgb, alns, tb)
+    _check_against_oracle(ga, gb, alns, tb, res)
+    from fastga_amd.gixio import Gix
+    plain = D.DeviceGenome(dev, gb, Gix(rb + ".gix").perm, False)
+    if (alns["flags"] & 1).any():
+        with pytest.raises(RuntimeError, match="reverse-complement"):
+            D.trace_pts(dev, dga, plain, alns, tb)
+    bad = alns.copy()                                   # a trace that cannot be realised must be reported, not written
+    tb2 = tb.copy()
+    k = int(np.argmax(bad["tlen"]))
+    tb2[int(bad["toff"][k])] = 0
+    tb2[int(bad["toff"][k]) + 1] = 160
+    with pytest.raises(RuntimeError, match="inconsistent"):
+        D.trace_pts(dev, dga, dgb, bad, tb2)
+    plain.free(); dga.free(); dgb.free(); dev.close()
+
+
+def test_trace_pts_self_comparison(tmp_path, built_library):
+    from fastga_amd import device as D, workload
+    ra, _ = workload.build_pair(str(tmp_path), seed=9, ncontig=4, total=400_000, divergence=0.05, repeat_frac=0.15)
+    dev = D.Device(0)
+    ga, gb, dga, dgb, alns, tb = _alignments(dev, ra, ra, self_cmp=True)
+    assert len(alns) > 5
+    same = (alns["aread"] == alns["bread"]) & ((alns["flags"] & 1) == 0)
+    assert same.any()
+    for flag in (False, True):
+        res = D.trace_pts(dev, dga, dgb, alns, tb, self_cmp=flag)
+        _check_against_oracle(ga, gb, alns, tb, res, self_cmp=flag)
+    dga.free(); dgb.free(); dev.close()
