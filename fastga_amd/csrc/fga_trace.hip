@@ -6,8 +6,8 @@
 // most `tspace` bases of A against at most 255 bases of B, each with a known number of differences; the panels are
 // independent, so the unit of work is one panel and one lane solves one panel:
 //
-//   trace_size_kernel   lane per alignment: number of raw output slots and of scratch cells its panels need
-//   trace_plan_kernel   lane per alignment: one 32-byte descriptor per panel
+//   trace_walk_kernel   wave per alignment: <false> number of raw output slots and of scratch cells its panels need,
+//                                           <true> one 40-byte descriptor per panel (prefix scans over the trace points)
 //   trace_panel_kernel  lane per panel:     the furthest-reaching wave rows (16-bit cells: reach + move code), pointer
 //                                           reversal, forward walk emitting the indels into the panel's raw slots
 //   trace_count_kernel  wave per alignment: indels and differences of the alignment
@@ -59,18 +59,6 @@ struct trace_args
 __device__ __forceinline__ int panel_count(const fga_aln &a)
 { return a.tlen >= 2 ? a.tlen >> 1 : 1; }
 
-// geometry of panel p of alignment a given the running (ab,bb): fills M, N, diffs; advances nothing
-__device__ __forceinline__ void panel_geom(const fga_aln &a, const uint8_t *t, int np, int p, int tspace,
-                                           int ab, int bb, int &M, int &N, int &pd)
-{ int ae, be;
-  if (p == np-1)
-    { ae = a.aepos; be = a.bepos; }
-  else
-    { ae = (ab/tspace)*tspace + tspace; be = bb + t[2*p+1]; }
-  pd = a.tlen >= 2 ? t[2*p] : a.diffs;
-  M = ae-ab; N = be-bb;
-}
-
 __device__ __forceinline__ void panel_need(int M, int N, int pd, int &budget, int &W, int &rows)
 { const int del = M-N, adel = del < 0 ? -del : del;
   budget = pd-adel;
@@ -79,49 +67,61 @@ __device__ __forceinline__ void panel_need(int M, int N, int pd, int &budget, in
   rows = b+3;
 }
 
-__global__ void trace_size_kernel(trace_args T)
-{ const int64_t i = (int64_t) blockIdx.x*blockDim.x + threadIdx.x;
-  if (i >= T.naln) return;
-  const fga_aln a = T.alns[i];
-  const uint8_t *t = T.tbytes + a.toff;
-  const int np = panel_count(a);
-  int ab = a.abpos, bb = a.bbpos;
-  int64_t raw = 0, cells = 0;
-  for (int p = 0; p < np; p++)
-    { int M, N, pd, budget, W, rows;
-      panel_geom(a,t,np,p,T.tspace,ab,bb,M,N,pd);
-      panel_need(M,N,pd,budget,W,rows);
-      raw += pd;
-      cells += (int64_t) W*rows;
-      ab += M; bb += N;
+__device__ __forceinline__ int wave_scan_incl(int v, int lane)
+{ for (int o = 1; o < 64; o <<= 1)
+    { const int u = __shfl_up(v,o);
+      if (lane >= o) v += u;
     }
-  T.need[2*i] = raw;
-  T.need[2*i+1] = cells;
+  return v;
 }
 
-__global__ void trace_plan_kernel(trace_args T)
-{ const int64_t i = T.a0 + (int64_t) blockIdx.x*blockDim.x + threadIdx.x;
-  if (i >= T.a1) return;
+// One wave per alignment walks its trace points 64 panels at a time: the A side of panel p is closed form (panels
+// end on multiples of tspace), the B side, the raw output slots and the scratch cells are running prefix sums.
+// PLAN = false: totals per alignment (need[]); PLAN = true: the panel descriptors.
+template <bool PLAN>
+__global__ void __launch_bounds__(64) trace_walk_kernel(trace_args T)
+{ const int64_t i = (PLAN ? T.a0 : 0) + blockIdx.x;
+  const int lane = threadIdx.x;
   const fga_aln a = T.alns[i];
   const uint8_t *t = T.tbytes + a.toff;
   const int np = panel_count(a);
-  int ab = a.abpos, bb = a.bbpos;
-  int64_t raw = T.rbase[i], scr = T.sbase[i] - T.s0;
-  trace_panel *out = T.panels + (T.pbase[i] - T.p0);
-  for (int p = 0; p < np; p++)
-    { int M, N, pd, budget, W, rows;
-      panel_geom(a,t,np,p,T.tspace,ab,bb,M,N,pd);
+  const int a0 = (a.abpos/T.tspace)*T.tspace;
+  int     run_b = 0;
+  int64_t run_raw = 0, run_cells = 0;
+  trace_panel *out = PLAN ? T.panels + (T.pbase[i] - T.p0) : NULL;
+  const int64_t raw0 = PLAN ? T.rbase[i] : 0, scr0 = PLAN ? T.sbase[i] - T.s0 : 0;
+  for (int p0 = 0; p0 < np; p0 += 64)
+    { const int  p = p0+lane;
+      const bool valid = p < np, last = p == np-1;
+      const int  nb = (valid && !last) ? t[2*p+1] : 0;
+      const int  nbi = wave_scan_incl(nb,lane);
+      const int  bb = a.bbpos + run_b + (nbi-nb);
+      const int  ab = p == 0 ? a.abpos : a0 + p*T.tspace;
+      const int  ae = last ? a.aepos : a0 + (p+1)*T.tspace;
+      const int  M = ae-ab, N = last ? a.bepos-bb : nb;
+      const int  pd = valid ? (a.tlen >= 2 ? t[2*p] : a.diffs) : 0;
+      int budget, W, rows;
       panel_need(M,N,pd,budget,W,rows);
-      trace_panel P;
-      P.aln = (int32_t) i; P.ab = ab; P.bb = bb;
-      P.M = (uint16_t) M; P.N = (uint16_t) N;
-      P.budget = (uint16_t) (budget < 0 ? 0 : budget);
-      P.flags = (uint16_t) ((budget < 0 || M < 0 || N < 0 || M > 4000 || N > 4000) ? 1 : 0);
-      P.scr = scr; P.raw = raw;
-      out[p] = P;
-      raw += pd;
-      scr += (int64_t) W*rows;
-      ab += M; bb += N;
+      const bool bad = budget < 0 || M < 0 || N < 0 || M > 4000 || N > 4000;
+      const int  cells = (valid && !bad) ? W*rows : 0;
+      const int  ci = wave_scan_incl(cells,lane), ri = wave_scan_incl(pd,lane);
+      if (PLAN && valid)
+        { trace_panel P;
+          P.aln = (int32_t) i; P.ab = ab; P.bb = bb;
+          P.M = (uint16_t) M; P.N = (uint16_t) N;
+          P.budget = (uint16_t) (budget < 0 ? 0 : budget);
+          P.flags = (uint16_t) (bad ? 1 : 0);
+          P.scr = scr0 + run_cells + (ci-cells);
+          P.raw = raw0 + run_raw + (ri-pd);
+          out[p] = P;
+        }
+      run_b += __shfl(nbi,63);
+      run_cells += __shfl(ci,63);
+      run_raw += __shfl(ri,63);
+    }
+  if (!PLAN && lane == 0)
+    { T.need[2*i] = run_raw;
+      T.need[2*i+1] = run_cells;
     }
 }
 
@@ -430,7 +430,7 @@ extern "C" int fga_trace_pts(fga_dev *dev, const fga_dgenome *GA, const fga_dgen
   T.atlen = d_atlen; T.adiffs = d_adiffs; T.astat = d_astat; T.pcnt = d_pcnt; T.pdiff = d_pdiff;
 
   hipEventRecord(dev->ev0,dev->stream);
-  hipLaunchKernelGGL(trace_size_kernel,dim3((unsigned) ((n+255)/256)),dim3(256),0,dev->stream,T);
+  hipLaunchKernelGGL(trace_walk_kernel<false>,dim3((unsigned) n),dim3(64),0,dev->stream,T);
   TRY(hipMemcpyAsync(need.data(),d_need,sizeof(int64_t)*2*n,hipMemcpyDeviceToHost,dev->stream));
   TRY(hipStreamSynchronize(dev->stream));
   { int64_t r = 0, s = 0;
@@ -466,7 +466,7 @@ extern "C" int fga_trace_pts(fga_dev *dev, const fga_dgenome *GA, const fga_dgen
         T.s0 = sbase[T.a0];
         T.panels = d_panels + T.p0;
         const int64_t na = T.a1-T.a0;
-        hipLaunchKernelGGL(trace_plan_kernel,dim3((unsigned) ((na+63)/64)),dim3(64),0,dev->stream,T);
+        hipLaunchKernelGGL(trace_walk_kernel<true>,dim3((unsigned) na),dim3(64),0,dev->stream,T);
         hipLaunchKernelGGL(trace_panel_kernel,dim3((unsigned) ((T.np+63)/64)),dim3(64),0,dev->stream,T);
       }
     T.panels = d_panels; T.p0 = 0;
