@@ -238,7 +238,7 @@ class RefAligner:
         tr = np.ctypeslib.as_array(C.cast(path.trace, C.POINTER(C.c_uint16)), shape=(max(n, 1),))[:n].copy()
         return (path.abpos, path.bbpos, path.aepos, path.bepos, path.diffs, tr)
 
-    def trace_pts(self, abuf, bbuf, path, tspace=100, selfie=False):
+    def trace_pts(self, abuf, bbuf, path, tspace=100, selfie=False, improve=False):
         """the real reference's Compute_Trace_PTS (align.c:6171) in GREEDIEST mode on an alignment given as
         (abpos, bbpos, aepos, bepos, diffs, uint16 trace points); returns (diffs, int32 edit trace)"""
         abpos, bbpos, aepos, bepos, diffs, tr = path
@@ -258,6 +258,10 @@ class RefAligner:
         st = self.L.Compute_Trace_PTS(C.byref(al), self.work, tspace, 0, 1, -1)
         if st != 0:
             raise RuntimeError("reference Compute_Trace_PTS failed")
+        if improve:                                   # Gap_Improver (align.c:6714), as every reader calls it next
+            self.L.Gap_Improver.argtypes = [C.POINTER(_RAlign), C.c_void_p]
+            if self.L.Gap_Improver(C.byref(al), self.work) != 0:
+                raise RuntimeError("reference Gap_Improver failed")
         n = rp.tlen
         out = np.ctypeslib.as_array(C.cast(rp.trace, C.POINTER(C.c_int32)), shape=(max(n, 1),))[:n].copy()
         return rp.diffs, out
@@ -284,3 +288,18 @@ def oracle_trace_pts(abuf, bbuf, path, tspace=100, selfie=False):
     if st != 0:
         raise RuntimeError("oracle_trace_pts failed")
     return d.value, out[:n.value].copy()
+
+
+def oracle_gap_improver(abuf, bbuf, path, trace, diffs, selfie=False):
+    """oracle/gap_oracle.c on the int trace of Compute_Trace_PTS: (diffs, rewritten trace)"""
+    L = oracle_lib()
+    t = np.ascontiguousarray(trace, dtype=np.int32).copy()
+    b = abuf if selfie else bbuf
+    d = C.c_int(diffs)
+    st = L.oracle_gap_improver(C.c_void_p(abuf.ctypes.data + 1), C.c_int(len(abuf) - 2),
+                               C.c_void_p(b.ctypes.data + 1), C.c_int(len(b) - 2),
+                               C.c_int(path[0]), C.c_int(path[1]), C.c_void_p(t.ctypes.data), C.c_int(len(t)),
+                               C.byref(d))
+    if st != 0:
+        raise RuntimeError("oracle_gap_improver failed")
+    return d.value, t

@@ -227,3 +227,48 @@ def test_trace_pts_oracle_matches_reference_call_by_call():
         od, ot = H.oracle_trace_pts(abuf, abuf, p, selfie=True)
         assert rd == od and np.array_equal(rt, ot) and len(rt) > 50
     ref.close()
+
+
+@needs_ref
+def test_gap_improver_oracle_matches_reference_call_by_call():
+    """oracle/gap_oracle.c against the reference's Gap_Improver (align.c:6714) applied to its own Compute_Trace_PTS
+    output; inputs with clustered indels so that boxes form and are rewritten"""
+    from fastga_amd import synth
+    rng = np.random.default_rng(20260928)
+    ref = H.RefAligner()
+    done = changed = 0
+    for it in range(300):
+        n = int(rng.integers(1500, 12000))
+        A = rng.integers(0, 4, n, dtype=np.uint8)
+        if it % 3 == 0:                            # low-complexity stretches make shifted gaps cheap
+            for _ in range(int(rng.integers(1, 6))):
+                u = rng.integers(0, 4, int(rng.integers(1, 5)), dtype=np.uint8)
+                p0 = int(rng.integers(0, n - 200))
+                ln = int(rng.integers(20, 150))
+                A[p0:p0 + ln] = np.tile(u, ln // len(u) + 1)[:ln]
+        B = synth.mutate(rng, A, float(rng.choice([0.02, 0.05, 0.1, 0.2])))
+        if it % 2 == 0:                            # multi-base indels
+            B = list(B)
+            for _ in range(int(rng.integers(1, 12))):
+                p0 = int(rng.integers(10, len(B) - 40))
+                if rng.random() < 0.5:
+                    del B[p0:p0 + int(rng.integers(1, 9))]
+                else:
+                    B[p0:p0] = list(rng.integers(0, 4, int(rng.integers(1, 9))))
+            B = np.array(B, dtype=np.uint8)
+        abuf, bbuf = H.pad_seq(A), H.pad_seq(B)
+        a = n // 2
+        b = min(len(B) - 1, a)
+        p = ref.align(abuf, bbuf, a - b - 40, a - b + 40, a + b)
+        if p[2] - p[0] < 300:
+            continue
+        d0, t0 = ref.trace_pts(abuf, bbuf, p)
+        rd, rt = ref.trace_pts(abuf, bbuf, p, improve=True)
+        od, ot = H.oracle_gap_improver(abuf, bbuf, p, t0, d0)
+        assert rd == od
+        assert np.array_equal(rt, ot)
+        assert len(rt) == len(t0)
+        changed += int(not np.array_equal(rt, t0))
+        done += 1
+    assert done > 150 and changed > 30
+    ref.close()
