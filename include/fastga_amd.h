@@ -238,6 +238,21 @@ int  fga_trace_pts(fga_dev *dev, const fga_dgenome *ga, const fga_dgenome *gb, c
                    int tspace, int self, fga_traces **out);
 void fga_traces_free(fga_traces *t);
 
+/* ---- PAF output: replaces the ALNtoPAF process behind `FastGA -paf[m|x|s|S]` (ALNtoPAF.c:103-636; options 662-680).
+ *      One line per alignment in set order.  With a CIGAR or cs tag the edit scripts of fga_trace_pts are needed; they
+ *      are first regrouped into fewer, longer gaps exactly as Gap_Improver does (align.h:393-399, align.c:6714-7133;
+ *      the reference's readers always call it right after Compute_Trace_PTS), on the host, one alignment per task.
+ *      path NULL or "-": stdout. */
+enum { FGA_PAF_CIGAR_M = 1,    /* -m  cg:Z: with M                                */
+       FGA_PAF_CIGAR_X = 2,    /* -x  cg:Z: with = and X                          */
+       FGA_PAF_CS_SHORT = 4,   /* -s  cs:Z: short form                            */
+       FGA_PAF_CS_LONG = 8,    /* -S  cs:Z: long form                             */
+       FGA_PAF_SWAP = 16 };    /* -w  genome 2 as the query                       */
+int  fga_write_paf(const char *path, const fga_gdb *g1, const fga_gdb *g2 /* NULL: self */, const fga_alns *alns,
+                   const fga_traces *traces /* NULL without CIGAR / cs */, int flags, int nthreads);
+/* Gap_Improver alone, in place on a whole set (trace and diffs as the reference leaves them in Path) */
+int  fga_gap_improve(const fga_gdb *g1, const fga_gdb *g2 /* NULL: self */, const fga_alns *alns, fga_traces *traces);
+
 /* ---- the whole hot path: what `FastGA -1:<out> <root1> [<root2>]` does between "GIX present" and ".1aln closed" */
 typedef struct
   { int     device;
