@@ -83,7 +83,7 @@ int fga_session_open(const char *root1, const char *root2, int device, fga_sessi
   if (fga_dgenome_upload(Z->dev,Z->g1,Z->x1->perm,Z->x1->nctg,1,&Z->dg1)) goto fail;
   if (Z->self)
     Z->dg2 = Z->dg1;
-  else if (fga_dgenome_upload(Z->dev,Z->g2,Z->x2->perm,Z->x2->nctg,0,&Z->dg2)) goto fail;
+  else if (fga_dgenome_upload(Z->dev,Z->g2,Z->x2->perm,Z->x2->nctg,1,&Z->dg2)) goto fail;
   Z->upload_s = fga_wall() - t0;
   *out = Z;
   return 0;
@@ -228,6 +228,25 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
     }
   st.write_s = fga_wall() - t1;
   st.phase23_s = fga_wall() - tstart;
+
+  /* ---- PAF (what the reference leaves to a second process, ALNtoPAF): outside the .1aln clock ---- */
+  if (P->paf_path != NULL)
+    { fga_traces *tr = NULL;
+      const int bases = (P->paf_flags & (FGA_PAF_CIGAR_M|FGA_PAF_CIGAR_X|FGA_PAF_CS_SHORT|FGA_PAF_CS_LONG)) != 0;
+      int rc = 0;
+      t1 = fga_wall();
+      if (bases)
+        { rc = fga_trace_pts(dev,dg1,dg2,fin,100,0,&tr);
+          st.trace_kernel_ms = fga_dev_stage_ms(dev,FGA_STAGE_TRACE);
+        }
+      st.trace_s = fga_wall() - t1;
+      t1 = fga_wall();
+      if (rc == 0)
+        rc = fga_write_paf(P->paf_path,g1,self ? NULL : g2,fin,tr,P->paf_flags,P->nthreads);
+      st.paf_s = fga_wall() - t1;
+      fga_traces_free(tr);
+      if (rc) goto done;
+    }
   status = 0;
 
 done:

@@ -305,12 +305,13 @@ def trace_pts(dev, ga, gb, alns, tb, tspace=100, self_cmp=False):
 
 
 def run(root1, root2=None, out_path=None, device=0, freq=10, soft_mask=False, symmetric=False, chain_break=1000,
-        chain_min=85, align_min=100, identity=0.7, nthreads=8, command_line="FastGA"):
-    """The whole hot path (fga_run): prebuilt GDB/GIX roots in, .1aln out.  Returns the stats as a dict."""
+        chain_min=85, align_min=100, identity=0.7, nthreads=8, command_line="FastGA", paf_path=None, paf_flags=0):
+    """The whole hot path (fga_run): prebuilt GDB/GIX roots in, .1aln (and PAF) out.  Returns the stats as a dict."""
     from .lib import RunParams, RunStats
     L = load_library()
     prm = RunParams(device, freq, int(soft_mask), int(symmetric), 2 * chain_break, 2 * chain_min, align_min,
-                    1.0 - identity, nthreads, out_path.encode() if out_path else None, command_line.encode())
+                    1.0 - identity, nthreads, out_path.encode() if out_path else None, command_line.encode(),
+                    paf_path.encode() if paf_path else None, paf_flags)
     st = RunStats()
     check(L.fga_run(root1.encode(), root2.encode() if root2 else None, C.byref(prm), C.byref(st)), "fga_run")
     return {n: getattr(st, n) for n, _ in RunStats._fields_}
@@ -329,10 +330,11 @@ class Session:
         self.bases = (self.L.fga_session_bases(self.h, 0), self.L.fga_session_bases(self.h, 1))
 
     def run(self, out_path=None, freq=10, soft_mask=False, symmetric=False, chain_break=1000, chain_min=85,
-            align_min=100, identity=0.7, nthreads=8, command_line="FastGA"):
+            align_min=100, identity=0.7, nthreads=8, command_line="FastGA", paf_path=None, paf_flags=0):
         from .lib import RunParams, RunStats
         prm = RunParams(0, freq, int(soft_mask), int(symmetric), 2 * chain_break, 2 * chain_min, align_min,
-                        1.0 - identity, nthreads, out_path.encode() if out_path else None, command_line.encode())
+                        1.0 - identity, nthreads, out_path.encode() if out_path else None, command_line.encode(),
+                        paf_path.encode() if paf_path else None, paf_flags)
         st = RunStats()
         check(self.L.fga_session_run(self.h, C.byref(prm), C.byref(st)), "session run")
         return {n: getattr(st, n) for n, _ in RunStats._fields_}

@@ -71,15 +71,16 @@ class RunParams(C.Structure):
     _fields_ = [("device", C.c_int), ("freq", C.c_int), ("soft_mask", C.c_int), ("symmetric", C.c_int),
                 ("chain_break", C.c_int), ("chain_min", C.c_int), ("align_min", C.c_int),
                 ("align_rate", C.c_double), ("nthreads", C.c_int), ("out_path", C.c_char_p),
-                ("command_line", C.c_char_p)]
+                ("command_line", C.c_char_p), ("paf_path", C.c_char_p), ("paf_flags", C.c_int)]
 
 
 class RunStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("nseeds", "seed_len_sum", "nhits", "nunits", "nalns", "nlive", "cover",
                                          "ncalls", "nwaves")] + \
                [(n, C.c_double) for n in ("load_s", "upload_s", "merge_s", "sort_s", "download_s", "chain_s",
-                                          "extend_s", "filter_s", "write_s", "phase23_s")] + \
-               [(n, C.c_float) for n in ("merge_kernel_ms", "sort_kernel_ms", "extend_kernel_ms")]
+                                          "extend_s", "filter_s", "write_s", "phase23_s", "trace_s", "paf_s")] + \
+               [(n, C.c_float) for n in ("merge_kernel_ms", "sort_kernel_ms", "extend_kernel_ms",
+                                         "trace_kernel_ms")]
 
 
 class SortParams(C.Structure):

@@ -266,12 +266,15 @@ typedef struct
     int     nthreads;        /* host threads (-T)          */
     const char *out_path;    /* <name>.1aln (NULL: no file) */
     const char *command_line;
+    const char *paf_path;    /* PAF output after the .1aln ("-": stdout, NULL: none)      */
+    int     paf_flags;       /* FGA_PAF_* (-pafm / -pafx / -pafs / -pafS)                 */
   } fga_run_params;
 
 typedef struct
   { int64_t nseeds, seed_len_sum, nhits, nunits, nalns, nlive, cover, ncalls, nwaves;
     double  load_s, upload_s, merge_s, sort_s, download_s, chain_s, extend_s, filter_s, write_s, phase23_s;
-    float   merge_kernel_ms, sort_kernel_ms, extend_kernel_ms;
+    double  trace_s, paf_s;  /* PAF output only: edit scripts on the device, regrouping + formatting on the host */
+    float   merge_kernel_ms, sort_kernel_ms, extend_kernel_ms, trace_kernel_ms;
   } fga_run_stats;
 
 int  fga_run(const char *root1, const char *root2 /* NULL: self */, const fga_run_params *prm, fga_run_stats *stats);

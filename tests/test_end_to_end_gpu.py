@@ -156,3 +156,46 @@ def test_runs_on_the_reference_s_own_index_files(toy_pair, tmp_path):
         roots.append(H.ref_build_index(fa, w, threads=8))
     assert os.path.exists(roots[0] + ".1gdb") and not os.path.exists(roots[0] + ".gdb")
     _compare(roots[0], roots[1], w)
+
+
+def test_native_paf_equals_alntopaf_on_our_1aln(toy_pair, tmp_path):
+    """`FastGA -paf[x|S|ms]` without a second process: edit scripts on the device (fga_trace_pts), gap regrouping and
+    formatting on the host, byte-identical to what the reference's ALNtoPAF prints for the .1aln of the same run"""
+    from fastga_amd import device as D
+    from oracle import harness as H
+    if not H.have_reference():
+        pytest.skip("oracle/_ref did not travel")
+    d, ra, rb = toy_pair
+    w = str(tmp_path)
+    ours = os.path.join(w, "ours.1aln")
+    for opts, flags in (("", 0), ("x", 2), ("S", 8), ("ms", 1 | 4)):
+        paf = os.path.join(w, f"ours_{opts}.paf")
+        st = D.run(ra, rb, ours, nthreads=8, paf_path=paf, paf_flags=flags)
+        exp = H.run([H.ref_bin("ALNtoPAF"), "-T4"] + (["-" + opts] if opts else []) + [ours], cwd=w).stdout
+        got = open(paf).read()
+        assert got.count("\n") == st["nlive"] > 10
+        assert got == exp, opts
+        assert (st["trace_kernel_ms"] > 0) == (flags != 0)
+    # self comparison, complement and forward same-contig alignments included
+    ours = os.path.join(w, "self.1aln")
+    paf = os.path.join(w, "self.paf")
+    st = D.run(ra, None, ours, nthreads=8, paf_path=paf, paf_flags=2)
+    exp = H.run([H.ref_bin("ALNtoPAF"), "-T4", "-x", ours], cwd=w).stdout
+    assert open(paf).read() == exp and st["nlive"] > 0
+
+
+def test_cli_default_output_is_paf_on_stdout(toy_pair, tmp_path):
+    from oracle import harness as H
+    import subprocess
+    d, ra, rb = toy_pair
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fastga_amd", "bin", "FastGA")
+    w = str(tmp_path)
+    r = subprocess.run([exe, "-pafx", "-1:cli", ra, rb], cwd=w, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    assert len(lines) > 10 and all("\tcg:Z:" in ln and len(ln.split("\t")) >= 15 for ln in lines)
+    if H.have_reference():
+        assert r.stdout == H.run([H.ref_bin("ALNtoPAF"), "-x", os.path.join(w, "cli.1aln")], cwd=w).stdout
+    r2 = subprocess.run([exe, ra, rb], cwd=w, capture_output=True, text=True)
+    assert r2.returncode == 0 and len(r2.stdout.splitlines()) == len(lines)
+    assert all("cg:Z:" not in ln for ln in r2.stdout.splitlines())

@@ -5,7 +5,7 @@
  *          [-l<int(100)>] [-i<float(.7)>]  <source1>[.gdb|.1gdb|.gix|.fa...]  [<source2>]
  * What differs: the sub-process glue is in-process -- a missing GDB / GIX is built with this library's own
  * producers (fga_fasta_to_gdb, fga_gix_build) instead of system("FAtoGDB"/"GIXmake"), and only the .1aln output
- * (-1:<name>) is produced natively; -paf/-psl need the reference's ALNtoPAF/ALNtoPSL on the result.
+ * (-1:<name>) and PAF (-paf[mxsS]*, the default, on stdout) are produced natively; -psl needs the reference's ALNtoPSL.
  */
 #define _GNU_SOURCE
 #include <stdio.h>
@@ -85,7 +85,7 @@ int main(int argc, char *argv[])
 { fga_run_params P;
   fga_run_stats S;
   char *src[2] = { NULL, NULL }, *root[2] = { NULL, NULL }, *out = NULL, *outpath = NULL;
-  int nsrc = 0, verbose = 0, keep = 0, i;
+  int nsrc = 0, verbose = 0, keep = 0, paf = 0, i;
   int cmin = 85, cbreak = 1000;
   double ident = .7;
   char cmd[4096];
@@ -112,7 +112,22 @@ int main(int argc, char *argv[])
         case 'T': P.nthreads = atoi(argv[i]+2); break;
         case 'P': case 'L': break;
         case 'p':
-          fprintf(stderr,"FastGA: only -1:<name> (.1aln) output is produced natively; run ALNtoPAF/ALNtoPSL on it\n");
+          if (strncmp(argv[i]+1,"paf",3) == 0)
+            { const char *f;
+              paf = 1;
+              for (f = argv[i]+4; *f; f++)
+                switch (*f)
+                { case 'm': P.paf_flags |= FGA_PAF_CIGAR_M; break;
+                  case 'x': P.paf_flags |= FGA_PAF_CIGAR_X; break;
+                  case 's': P.paf_flags |= FGA_PAF_CS_SHORT; break;
+                  case 'S': P.paf_flags |= FGA_PAF_CS_LONG; break;
+                  default:
+                    fprintf(stderr,"FastGA: Just one or more of m, x, s or S can follow -paf\n");
+                    return 1;
+                }
+              break;
+            }
+          fprintf(stderr,"FastGA: -psl output is not produced natively; run ALNtoPSL on the -1:<name> result\n");
           return 1;
         default:
           { const char *f;
@@ -132,11 +147,15 @@ int main(int argc, char *argv[])
       P.soft_mask = 1;
     else if (nsrc < 2)
       src[nsrc++] = argv[i];
-  if (nsrc == 0 || out == NULL)
+  if (nsrc == 0)
     { fprintf(stderr,"Usage: FastGA [-vkMS] [-T<int(8)>] [-f<int(10)>] [-c<int(85)>] [-s<int(1000)>] [-l<int(100)>]"
-                     " [-i<float(.7)>] -1:<out> <source1> [<source2>]\n");
+                     " [-i<float(.7)>] [-paf[mxsS]* | -1:<out>] <source1> [<source2>]\n");
       return 1;
     }
+  if (out == NULL)                       /* like the reference, PAF on stdout is the default output */
+    paf = 1;
+  if (paf)
+    P.paf_path = "-";
   if (ident < .55 || ident >= 1.)
     { fprintf(stderr,"FastGA: Minimum alignment similarity %g must be in [0.55,1.0)\n",ident);
       return 1;
@@ -144,6 +163,7 @@ int main(int argc, char *argv[])
   P.chain_min = 2*cmin; P.chain_break = 2*cbreak;
   P.align_rate = 1.-ident;
   P.command_line = cmd;
+  if (out != NULL)
   { size_t n = strlen(out);
     if (n > 5 && strcmp(out+n-5,".1aln") == 0)
       outpath = strdup(out);
@@ -172,6 +192,9 @@ int main(int argc, char *argv[])
                      " (kernel %.3f ms, %lld calls, %lld waves) filter %.3fs write %.3fs\n",
                      S.sort_s,S.sort_kernel_ms,S.download_s,S.chain_s,S.extend_s,S.extend_kernel_ms,
                      (long long) S.ncalls,(long long) S.nwaves,S.filter_s,S.write_s);
+      if (paf)
+        fprintf(stderr,"  PAF: edit scripts %.3fs (kernels %.3f ms), regroup + format %.3fs\n",
+                       S.trace_s,S.trace_kernel_ms,S.paf_s);
       fprintf(stderr,"  Load %.3fs  upload %.3fs\n",S.load_s,S.upload_s);
     }
   free(outpath);
