@@ -57,6 +57,33 @@ def _check_against_oracle(ga, gb, alns, tb, res, self_cmp=False):
     return nindel
 
 
+def _replay(ga, gb, alns, res, limit=None):
+    """size-independent property: walking an edit script over the two sequences consumes exactly [abpos,aepos) and
+    [bbpos,bepos) and meets exactly `diffs` differences (indels + mismatched columns)"""
+    from fastga_amd import synth
+    toff, tlen, diffs, ints, _ = res
+    cache = {}
+    for i, a in enumerate(alns[:limit]):
+        c1, c2, comp = int(a["aread"]), int(a["bread"]), int(a["flags"]) & 1
+        if ("a", c1) not in cache:
+            cache[("a", c1)] = ga.contig(c1)
+        if ("b", c2, comp) not in cache:
+            s = gb.contig(c2)
+            cache[("b", c2, comp)] = synth.revcomp(s) if comp else s
+        A, B = cache[("a", c1)], cache[("b", c2, comp)]
+        k, h, nd = int(a["abpos"]), int(a["bbpos"]), 0           # 0-based next unaligned base of A and of B
+        for e in ints[int(toff[i]):int(toff[i + 1])]:
+            e = int(e)
+            n = (-e - 1 - k) if e < 0 else (e - 1 - h)
+            assert n >= 0
+            nd += int((A[k:k + n] != B[h:h + n]).sum()) + 1
+            k, h = (k + n, h + n + 1) if e < 0 else (k + n + 1, h + n)
+        n = int(a["aepos"]) - k
+        assert n >= 0 and h + n == int(a["bepos"])
+        nd += int((A[k:k + n] != B[h:h + n]).sum())
+        assert nd == int(diffs[i])
+
+
 def test_trace_pts_matches_oracle_on_pipeline_alignments(toy_pair):
     from fastga_amd import device as D
     d, ra, rb = toy_pair
@@ -65,6 +92,7 @@ def test_trace_pts_matches_oracle_on_pipeline_alignments(toy_pair):
     assert len(alns) > 20 and (alns["flags"] & 1).any() and not (alns["flags"] & 1).all()
     res = D.trace_pts(dev, dga, dgb, alns, tb)
     n = _check_against_oracle(ga, gb, alns, tb, res)
+    _replay(ga, gb, alns, res)
     assert n > 1000 and res[4]["panels"] == int((alns["tlen"] // 2).sum())
     # order independence and empty input
     perm = np.random.default_rng(3).permutation(len(alns))
@@ -110,4 +138,24 @@ def test_trace_pts_self_comparison(tmp_path, built_library):
     for flag in (False, True):
         res = D.trace_pts(dev, dga, dgb, alns, tb, self_cmp=flag)
         _check_against_oracle(ga, gb, alns, tb, res, self_cmp=flag)
+    dga.free(); dgb.free(); dev.close()
+
+
+def test_trace_pts_replays_at_bench_scale(tmp_path, built_library):
+    """20 Mbp pair (a fifth of the bench pair, 0.7 M panels): every script replays to its own difference count, and a
+    sample equals the oracle"""
+    from fastga_amd import device as D, workload
+    ra, rb = workload.build_pair(str(tmp_path), seed=1, ncontig=16, total=20_000_000, divergence=0.02,
+                                 repeat_frac=0.05, inv_frac=0.02, swap_frac=0.02, threads=16)
+    dev = D.Device(0)
+    ga, gb, dga, dgb, alns, tb = _alignments(dev, ra, rb)
+    assert int(alns["tlen"].sum()) // 2 > 300_000
+    res = D.trace_pts(dev, dga, dgb, alns, tb)
+    _replay(ga, gb, alns, res)
+    pick = np.random.default_rng(5).choice(len(alns), size=min(40, len(alns)), replace=False)
+    sub = alns[pick]
+    res2 = D.trace_pts(dev, dga, dgb, sub, tb)
+    _check_against_oracle(ga, gb, sub, tb, res2)
+    for q, i in enumerate(pick):
+        assert np.array_equal(res2[3][int(res2[0][q]):int(res2[0][q + 1])], res[3][int(res[0][i]):int(res[0][i + 1])])
     dga.free(); dgb.free(); dev.close()
