@@ -319,6 +319,7 @@ typedef struct
     const fga_alns *alns;
     const fga_traces *tr;
     int      flags;
+    int      psl;            /* 1: PSL lines (ALNtoPSL.c:77-405) instead of PAF */
     int64_t  beg, end;
     text     out;
     int      status;
@@ -513,9 +514,143 @@ done:
   return NULL;
 }
 
-int fga_write_paf(const char *path, const fga_gdb *g1, const fga_gdb *g2, const fga_alns *alns,
-                  const fga_traces *traces, int flags, int nthreads)
-{ const int bases = (flags & (FGA_PAF_CIGAR_M|FGA_PAF_CIGAR_X|FGA_PAF_CS_SHORT|FGA_PAF_CS_LONG)) != 0;
+
+/* One PSL line per alignment (gen_psl, ALNtoPSL.c:77-405): counts, strand, names and ranges, then the ungapped blocks.
+ * Always base-level: the edit script is regrouped first, trailing indels at the very end are trimmed off. */
+static void *psl_thread(void *arg)
+{ paf_job *J = arg;
+  const fga_gdb *g1 = J->g1, *g2 = J->g2;
+  scratch  S = { NULL, 0 };
+  text    *X = &J->out;
+  uint8_t *abuf = NULL, *bbuf = NULL;
+  int32_t *tcopy = NULL, *blk = NULL;
+  int64_t  tcap = 0, bcap = 0, kcap = 0, i;
+  int      alast = -1;
+  const uint8_t *A1 = NULL;
+
+  abuf = malloc(g1->maxctg+4);
+  if (abuf == NULL) goto oom;
+  for (i = J->beg; i < J->end; i++)
+    { fga_aln a = J->alns->alns[i];                  /* a copy: the trim moves aepos / bepos */
+      const int comp = (a.flags & 0x1) != 0;
+      const fga_contig *ca = g1->contigs+a.aread, *cb = g2->contigs+a.bread;
+      const fga_scaffold *sa = g1->scaffolds+ca->scaf, *sb = g2->scaffolds+cb->scaf;
+      const char *na = g1->headers+sa->hoff, *nb = g2->headers+sb->hoff;
+      const int n = a.bepos-a.bbpos;
+      int T = J->tr->tlen[i], diffs = J->tr->diffs[i];
+      int x, k, h, cut, nblk, prev;
+      int ngapA = 0, ngapB = 0, runA = 0, runB = 0, subs, same;
+      const uint8_t *B1;
+      int64_t boff;
+
+      if (a.aread != alast)
+        { A1 = fga_gdb_get_contig(g1,a.aread,abuf) - 1;
+          alast = a.aread;
+        }
+      if (n+4 > bcap)
+        { bcap = 2*(int64_t) n + 4096;
+          free(bbuf);
+          bbuf = malloc(bcap);
+          if (bbuf == NULL) goto oom;
+        }
+      B1 = load_piece(g2,a.bread,a.bbpos,a.bepos,comp,bbuf);
+      if (T+1 > tcap)
+        { tcap = 2*(int64_t) T + 1024;
+          free(tcopy);
+          tcopy = malloc(sizeof(int32_t)*tcap);
+          if (tcopy == NULL) goto oom;
+        }
+      memcpy(tcopy,J->tr->trace+J->tr->toff[i],sizeof(int32_t)*T);
+      if (gap_regroup(A1,(int) ca->clen,B1,(int) cb->clen,a.abpos,a.bbpos,tcopy,T,&diffs,&S)) goto oom;
+
+      for (cut = 0; T > 0 && tcopy[T-1] == -a.aepos-1; T--)       /* gaps after the last base of A */
+        cut += 1;
+      a.bepos -= cut; diffs -= cut;
+      for (cut = 0; T > 0 && tcopy[T-1] == a.bepos+1; T--)        /* gaps after the last base of B */
+        cut += 1;
+      a.aepos -= cut; diffs -= cut;
+
+      for (x = 0, prev = 0; x < T; prev = tcopy[x++])
+        if (tcopy[x] < 0)
+          { ngapA += 1; runA += (tcopy[x] != prev); }
+        else
+          { ngapB += 1; runB += (tcopy[x] != prev); }
+      subs = diffs-(ngapA+ngapB);
+      same = (a.aepos-a.abpos)-ngapB-subs;
+
+      if (T+2 > kcap)
+        { kcap = 2*(int64_t) T + 1024;
+          free(blk);
+          blk = malloc(sizeof(int32_t)*3*kcap);
+          if (blk == NULL) goto oom;
+        }
+      nblk = 0;                                      /* blocks as (length, A start, B start), 0-based */
+      k = a.abpos+1; h = a.bbpos+1;
+      for (x = 0; x <= T; x++)
+        { int len;
+          if (x == T)
+            len = a.aepos-k+1;
+          else if (tcopy[x] < 0)
+            len = -tcopy[x]-k;
+          else
+            len = tcopy[x]-h;
+          if (len > 0)
+            { blk[3*nblk] = len; blk[3*nblk+1] = k-1; blk[3*nblk+2] = h-1;
+              nblk += 1;
+            }
+          if (x < T)
+            { if (tcopy[x] < 0) { k += len; h += len+1; }
+              else              { k += len+1; h += len; }
+            }
+        }
+
+      if (tx_room(X,strlen(na)+strlen(nb)+512+(size_t) nblk*40)) goto oom;
+      tx_int(X,same); tx_char(X,'\t'); tx_int(X,subs); tx_str(X,"\t0\t0\t");
+      tx_int(X,runB); tx_char(X,'\t'); tx_int(X,ngapB); tx_char(X,'\t');
+      tx_int(X,runA); tx_char(X,'\t'); tx_int(X,ngapA); tx_char(X,'\t');
+      tx_char(X,comp ? '-' : '+'); tx_char(X,'\t');
+      tx_str(X,na); tx_char(X,'\t'); tx_int(X,sa->slen); tx_char(X,'\t');
+      tx_int(X,ca->sbeg+a.abpos); tx_char(X,'\t'); tx_int(X,ca->sbeg+a.aepos); tx_char(X,'\t');
+      tx_str(X,nb); tx_char(X,'\t'); tx_int(X,sb->slen); tx_char(X,'\t');
+      if (comp)
+        { boff = cb->sbeg+cb->clen;
+          tx_int(X,boff-a.bepos); tx_char(X,'\t'); tx_int(X,boff-a.bbpos);
+        }
+      else
+        { boff = cb->sbeg;
+          tx_int(X,boff+a.bbpos); tx_char(X,'\t'); tx_int(X,boff+a.bepos);
+        }
+      tx_char(X,'\t'); tx_int(X,nblk); tx_char(X,'\t');
+      for (x = 0; x < nblk; x++)
+        { const int32_t *b = blk + 3*(comp ? nblk-1-x : x);
+          tx_int(X,b[0]); tx_char(X,',');
+        }
+      tx_char(X,'\t');
+      for (x = 0; x < nblk; x++)
+        { const int32_t *b = blk + 3*(comp ? nblk-1-x : x);
+          tx_int(X,comp ? sa->slen-(ca->sbeg+b[1]+b[0]) : ca->sbeg+b[1]); tx_char(X,',');
+        }
+      tx_char(X,'\t');
+      for (x = 0; x < nblk; x++)
+        { const int32_t *b = blk + 3*(comp ? nblk-1-x : x);
+          tx_int(X,comp ? boff-(b[2]+b[0]) : boff+b[2]); tx_char(X,',');
+        }
+      tx_char(X,'\n');
+    }
+  J->status = 0;
+  goto done;
+
+oom:
+  fga_set_error("fga_write_psl: out of memory");
+  J->status = 1;
+done:
+  free(S.buf); free(abuf); free(bbuf); free(tcopy); free(blk);
+  return NULL;
+}
+
+static int write_lines(const char *path, const fga_gdb *g1, const fga_gdb *g2, const fga_alns *alns,
+                       const fga_traces *traces, int flags, int nthreads, int psl)
+{ const int bases = psl || (flags & (FGA_PAF_CIGAR_M|FGA_PAF_CIGAR_X|FGA_PAF_CS_SHORT|FGA_PAF_CS_LONG)) != 0;
   paf_job  *job;
   pthread_t *th;
   FILE     *f;
@@ -532,7 +667,8 @@ int fga_write_paf(const char *path, const fga_gdb *g1, const fga_gdb *g2, const 
       return 1;
     }
   if (bases && (traces == NULL || traces->naln != alns->naln))
-    { fga_set_error("fga_write_paf: a CIGAR or cs tag needs the edit scripts of fga_trace_pts for the same alignments");
+    { fga_set_error("%s: base-level output needs the edit scripts of fga_trace_pts for the same alignments",
+                    psl ? "fga_write_psl" : "fga_write_paf");
       return 1;
     }
   if (nthreads < 1) nthreads = 1;
@@ -549,7 +685,7 @@ int fga_write_paf(const char *path, const fga_gdb *g1, const fga_gdb *g2, const 
     total += alns->alns[i].aepos-alns->alns[i].abpos + 200;
   nxt = 0;
   for (t = 0, i = 0; t < nthreads; t++)
-    { job[t].g1 = g1; job[t].g2 = g2; job[t].alns = alns; job[t].tr = traces; job[t].flags = flags;
+    { job[t].g1 = g1; job[t].g2 = g2; job[t].alns = alns; job[t].tr = traces; job[t].flags = flags; job[t].psl = psl;
       job[t].beg = i;
       nxt += total/nthreads + 1;
       while (i < alns->naln && (acc < nxt || t == nthreads-1))
@@ -557,9 +693,9 @@ int fga_write_paf(const char *path, const fga_gdb *g1, const fga_gdb *g2, const 
       job[t].end = i;
     }
   for (t = 1; t < nthreads; t++)
-    if (pthread_create(th+t,NULL,paf_thread,job+t) != 0)
-      { paf_thread(job+t); th[t] = 0; }
-  paf_thread(job);
+    if (pthread_create(th+t,NULL,psl ? psl_thread : paf_thread,job+t) != 0)
+      { (psl ? psl_thread : paf_thread)(job+t); th[t] = 0; }
+  (psl ? psl_thread : paf_thread)(job);
   for (t = 1; t < nthreads; t++)
     if (th[t]) pthread_join(th[t],NULL);
   for (t = 0; t < nthreads; t++)
@@ -588,6 +724,14 @@ int fga_write_paf(const char *path, const fga_gdb *g1, const fga_gdb *g2, const 
   free(job); free(th);
   return rc;
 }
+
+int fga_write_paf(const char *path, const fga_gdb *g1, const fga_gdb *g2, const fga_alns *alns,
+                  const fga_traces *traces, int flags, int nthreads)
+{ return write_lines(path,g1,g2,alns,traces,flags,nthreads,0); }
+
+int fga_write_psl(const char *path, const fga_gdb *g1, const fga_gdb *g2, const fga_alns *alns,
+                  const fga_traces *traces, int nthreads)
+{ return write_lines(path,g1,g2,alns,traces,0,nthreads,1); }
 
 /* the regrouping alone, applied in place to a whole set: Path.trace / Path.diffs after Gap_Improver */
 int fga_gap_improve(const fga_gdb *g1, const fga_gdb *g2, const fga_alns *alns, fga_traces *traces)

@@ -232,7 +232,8 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
   /* ---- PAF (what the reference leaves to a second process, ALNtoPAF): outside the .1aln clock ---- */
   if (P->paf_path != NULL)
     { fga_traces *tr = NULL;
-      const int bases = (P->paf_flags & (FGA_PAF_CIGAR_M|FGA_PAF_CIGAR_X|FGA_PAF_CS_SHORT|FGA_PAF_CS_LONG)) != 0;
+      const int psl = (P->paf_flags & FGA_OUT_PSL) != 0;
+      const int bases = psl || (P->paf_flags & (FGA_PAF_CIGAR_M|FGA_PAF_CIGAR_X|FGA_PAF_CS_SHORT|FGA_PAF_CS_LONG)) != 0;
       int rc = 0;
       t1 = fga_wall();
       if (bases)
@@ -242,7 +243,8 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
       st.trace_s = fga_wall() - t1;
       t1 = fga_wall();
       if (rc == 0)
-        rc = fga_write_paf(P->paf_path,g1,self ? NULL : g2,fin,tr,P->paf_flags,P->nthreads);
+        rc = psl ? fga_write_psl(P->paf_path,g1,self ? NULL : g2,fin,tr,P->nthreads)
+                 : fga_write_paf(P->paf_path,g1,self ? NULL : g2,fin,tr,P->paf_flags,P->nthreads);
       st.paf_s = fga_wall() - t1;
       fga_traces_free(tr);
       if (rc) goto done;

@@ -247,9 +247,13 @@ enum { FGA_PAF_CIGAR_M = 1,    /* -m  cg:Z: with M                              
        FGA_PAF_CIGAR_X = 2,    /* -x  cg:Z: with = and X                          */
        FGA_PAF_CS_SHORT = 4,   /* -s  cs:Z: short form                            */
        FGA_PAF_CS_LONG = 8,    /* -S  cs:Z: long form                             */
-       FGA_PAF_SWAP = 16 };    /* -w  genome 2 as the query                       */
+       FGA_PAF_SWAP = 16,      /* -w  genome 2 as the query                       */
+       FGA_OUT_PSL = 32 };     /* fga_run_params.paf_flags only: PSL lines (fga_write_psl) instead of PAF */
 int  fga_write_paf(const char *path, const fga_gdb *g1, const fga_gdb *g2 /* NULL: self */, const fga_alns *alns,
                    const fga_traces *traces /* NULL without CIGAR / cs */, int flags, int nthreads);
+/* PSL output: replaces the ALNtoPSL process behind `FastGA -psl` (ALNtoPSL.c:77-405); always needs the edit scripts */
+int  fga_write_psl(const char *path, const fga_gdb *g1, const fga_gdb *g2 /* NULL: self */, const fga_alns *alns,
+                   const fga_traces *traces, int nthreads);
 /* Gap_Improver alone, in place on a whole set (trace and diffs as the reference leaves them in Path) */
 int  fga_gap_improve(const fga_gdb *g1, const fga_gdb *g2 /* NULL: self */, const fga_alns *alns, fga_traces *traces);
 

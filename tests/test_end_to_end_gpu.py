@@ -196,6 +196,10 @@ def test_cli_default_output_is_paf_on_stdout(toy_pair, tmp_path):
     assert len(lines) > 10 and all("\tcg:Z:" in ln and len(ln.split("\t")) >= 15 for ln in lines)
     if H.have_reference():
         assert r.stdout == H.run([H.ref_bin("ALNtoPAF"), "-x", os.path.join(w, "cli.1aln")], cwd=w).stdout
+    r3 = subprocess.run([exe, "-psl", "-1:cli2", ra, rb], cwd=w, capture_output=True, text=True)
+    assert r3.returncode == 0 and len(r3.stdout.splitlines()) == len(lines)
+    if H.have_reference() and os.path.exists(H.ref_bin("ALNtoPSL")):
+        assert r3.stdout == H.run([H.ref_bin("ALNtoPSL"), os.path.join(w, "cli2.1aln")], cwd=w).stdout
     r2 = subprocess.run([exe, ra, rb], cwd=w, capture_output=True, text=True)
     assert r2.returncode == 0 and len(r2.stdout.splitlines()) == len(lines)
     assert all("cg:Z:" not in ln for ln in r2.stdout.splitlines())

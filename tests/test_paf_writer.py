@@ -71,6 +71,13 @@ def test_paf_matches_alntopaf_for_every_option(toy_pair, tmp_path, built_library
         got = open(out).read()
         assert got.count("\n") == len(alns)
         assert got == exp, opts
+    # PSL (the reference's ALNtoPSL): counts, ranges and block lists
+    rc = L.fga_write_psl(out.encode(), g1.h, None if self_cmp else g2.h, C.byref(A), C.byref(T), 3)
+    assert rc == 0, L.fga_last_error()
+    exp = H.run([H.ref_bin("ALNtoPSL"), "-T2", ref], cwd=w).stdout
+    got = open(out).read()
+    assert got.count("\n") == len(alns) and got == exp
+    assert L.fga_write_psl(out.encode(), g1.h, None, C.byref(A), None, 1) != 0
     # thread count does not change the file; conflicting or incomplete requests are refused
     L.fga_write_paf(out.encode(), g1.h, None if self_cmp else g2.h, C.byref(A), C.byref(T), 2 | 8, 1)
     one = open(out).read()

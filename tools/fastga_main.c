@@ -5,7 +5,7 @@
  *          [-l<int(100)>] [-i<float(.7)>]  <source1>[.gdb|.1gdb|.gix|.fa...]  [<source2>]
  * What differs: the sub-process glue is in-process -- a missing GDB / GIX is built with this library's own
  * producers (fga_fasta_to_gdb, fga_gix_build) instead of system("FAtoGDB"/"GIXmake"), and only the .1aln output
- * (-1:<name>) and PAF (-paf[mxsS]*, the default, on stdout) are produced natively; -psl needs the reference's ALNtoPSL.
+ * (-1:<name>) PAF (-paf[mxsS]*, the default) and PSL (-psl), both on stdout, are produced natively.
  */
 #define _GNU_SOURCE
 #include <stdio.h>
@@ -127,7 +127,12 @@ int main(int argc, char *argv[])
                 }
               break;
             }
-          fprintf(stderr,"FastGA: -psl output is not produced natively; run ALNtoPSL on the -1:<name> result\n");
+          if (strcmp(argv[i]+1,"psl") == 0)
+            { paf = 1;
+              P.paf_flags = FGA_OUT_PSL;
+              break;
+            }
+          fprintf(stderr,"FastGA: -%s is an illegal option\n",argv[i]+1);
           return 1;
         default:
           { const char *f;
@@ -149,7 +154,7 @@ int main(int argc, char *argv[])
       src[nsrc++] = argv[i];
   if (nsrc == 0)
     { fprintf(stderr,"Usage: FastGA [-vkMS] [-T<int(8)>] [-f<int(10)>] [-c<int(85)>] [-s<int(1000)>] [-l<int(100)>]"
-                     " [-i<float(.7)>] [-paf[mxsS]* | -1:<out>] <source1> [<source2>]\n");
+                     " [-i<float(.7)>] [-paf[mxsS]* | -psl | -1:<out>] <source1> [<source2>]\n");
       return 1;
     }
   if (out == NULL)                       /* like the reference, PAF on stdout is the default output */
