@@ -82,6 +82,7 @@ struct fga_dgenome
   { fga_dev  *dev;
     uint8_t  *img, *img_rc;
     int64_t  *boff, *clen;
+    int64_t  *hclen;      // host copy of the contig lengths (argument checks)
     int      *perm;
     int       nctg, nperm;
     int64_t   pad, maxctg;

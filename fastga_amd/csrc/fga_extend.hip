@@ -1457,6 +1457,9 @@ extern "C" int fga_dgenome_upload(fga_dev *dev, const fga_gdb *G, const int *per
   hipMemcpy(D->img + IMG_PAD,G->bps,G->bpslen,hipMemcpyHostToDevice);
   hipMemcpy(D->boff,boff.data(),sizeof(int64_t)*G->ncontig,hipMemcpyHostToDevice);
   hipMemcpy(D->clen,clen.data(),sizeof(int64_t)*G->ncontig,hipMemcpyHostToDevice);
+  D->hclen = (int64_t *) malloc(sizeof(int64_t)*(G->ncontig > 0 ? G->ncontig : 1));
+  if (D->hclen != NULL)
+    memcpy(D->hclen,clen.data(),sizeof(int64_t)*G->ncontig);
   if (nperm > 0)
     hipMemcpy(D->perm,perm,sizeof(int)*nperm,hipMemcpyHostToDevice);
   if (want_revcomp)
@@ -1469,7 +1472,7 @@ extern "C" int fga_dgenome_upload(fga_dev *dev, const fga_gdb *G, const int *per
   if (e == hipSuccess) e = hipGetLastError();
   if (e != hipSuccess)
     { fga_set_error("fga_dgenome_upload: %s",hipGetErrorString(e));
-      hipFree(D->img); hipFree(D->boff); hipFree(D->clen); hipFree(D->perm); hipFree(D->img_rc); free(D);
+      hipFree(D->img); hipFree(D->boff); hipFree(D->clen); hipFree(D->perm); hipFree(D->img_rc); free(D->hclen); free(D);
       return 1;
     }
   *out = D;
@@ -1480,6 +1483,7 @@ extern "C" void fga_dgenome_free(fga_dgenome *D)
 { if (D == NULL) return;
   hipSetDevice(D->dev->device);
   hipFree(D->img); hipFree(D->img_rc); hipFree(D->boff); hipFree(D->clen); hipFree(D->perm);
+  free(D->hclen);
   free(D);
 }
 

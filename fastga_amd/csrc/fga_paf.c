@@ -671,6 +671,16 @@ static int write_lines(const char *path, const fga_gdb *g1, const fga_gdb *g2, c
                     psl ? "fga_write_psl" : "fga_write_paf");
       return 1;
     }
+  for (i = 0; i < alns->naln; i++)
+    { const fga_aln *a = alns->alns+i;
+      if (a->aread < 0 || a->aread >= g1->ncontig || a->bread < 0 || a->bread >= g2->ncontig ||
+          a->abpos < 0 || a->aepos < a->abpos || a->aepos > g1->contigs[a->aread].clen ||
+          a->bbpos < 0 || a->bepos < a->bbpos || a->bepos > g2->contigs[a->bread].clen)
+        { fga_set_error("%s: alignment %lld lies outside the contigs of the two genomes",
+                        psl ? "fga_write_psl" : "fga_write_paf",(long long) i);
+          return 1;
+        }
+    }
   if (nthreads < 1) nthreads = 1;
   if (nthreads > 64) nthreads = 64;
   if (alns->naln < nthreads) nthreads = alns->naln > 0 ? (int) alns->naln : 1;

@@ -378,8 +378,17 @@ extern "C" int fga_trace_pts(fga_dev *dev, const fga_dgenome *GA, const fga_dgen
       if (a.flags & 0x1) any_comp = 1;
       pbase[i] = npan;
       npan += a.tlen >= 2 ? a.tlen >> 1 : 1;
-      if (a.tlen & 1)
-        { fga_set_error("fga_trace_pts: alignment %lld has an odd trace length",(long long) i);
+      if ((a.tlen & 1) || a.tlen < 0 || a.toff < 0 || a.toff + a.tlen > alns->ntrace)
+        { fga_set_error("fga_trace_pts: alignment %lld: trace of %d bytes at offset %lld does not fit the set's %lld "
+                        "trace bytes (or is odd)",(long long) i,a.tlen,(long long) a.toff,(long long) alns->ntrace);
+          free(R);
+          return 1;
+        }
+      if (a.aread < 0 || a.aread >= GA->nctg || a.bread < 0 || a.bread >= GB->nctg ||
+          a.abpos < 0 || a.aepos < a.abpos || a.bbpos < 0 || a.bepos < a.bbpos ||
+          (GA->hclen != NULL && a.aepos > GA->hclen[a.aread]) || (GB->hclen != NULL && a.bepos > GB->hclen[a.bread]))
+        { fga_set_error("fga_trace_pts: alignment %lld refers to contigs or positions outside the two genomes",
+                        (long long) i);
           free(R);
           return 1;
         }

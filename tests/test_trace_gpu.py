@@ -124,6 +124,11 @@ def test_trace_pts_high_divergence_and_missing_revcomp(tmp_path, built_library):
     tb2[int(bad["toff"][k]) + 1] = 160
     with pytest.raises(RuntimeError, match="inconsistent"):
         D.trace_pts(dev, dga, dgb, bad, tb2)
+    for field, value in (("aread", 10**6), ("toff", len(tb)), ("aepos", 2**30)):     # arguments are checked up front
+        broken = alns.copy()
+        broken[field][0] = value
+        with pytest.raises(RuntimeError, match="alignment 0"):
+            D.trace_pts(dev, dga, dgb, broken, tb)
     plain.free(); dga.free(); dgb.free(); dev.close()
 
 
