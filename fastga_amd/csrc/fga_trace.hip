@@ -411,7 +411,10 @@ extern "C" int fga_trace_pts(fga_dev *dev, const fga_dgenome *GA, const fga_dgen
   trace_args T;
   memset(&T,0,sizeof(T));
   int64_t total = 0, rawtot = 0;
-  const int64_t cell_cap = (int64_t) 4 << 30;          // scratch cells per batch (8 GB)
+  int64_t cell_cap = (int64_t) 4 << 30;                // scratch cells per batch (8 GB)
+  { const char *ev = getenv("FGA_TRACE_CELLS");        // test hook: small batches
+    if (ev != NULL && atoll(ev) > 0) cell_cap = atoll(ev);
+  }
   const size_t tbbytes = (size_t) (alns->ntrace > 0 ? alns->ntrace : 1);
 
 #define TRY(call) do { if ((e = (call)) != hipSuccess) goto fail; } while (0)

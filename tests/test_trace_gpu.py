@@ -99,6 +99,13 @@ def test_trace_pts_matches_oracle_on_pipeline_alignments(toy_pair):
     res2 = D.trace_pts(dev, dga, dgb, alns[perm], tb)
     for q, i in enumerate(perm[:50]):
         assert np.array_equal(res2[3][int(res2[0][q]):int(res2[0][q + 1])], res[3][int(res[0][i]):int(res[0][i + 1])])
+    import os
+    os.environ["FGA_TRACE_CELLS"] = "20000"                 # many scratch batches instead of one
+    try:
+        res3 = D.trace_pts(dev, dga, dgb, alns, tb)
+    finally:
+        del os.environ["FGA_TRACE_CELLS"]
+    assert all(np.array_equal(x, y) for x, y in zip(res[:4], res3[:4]))
     empty = D.trace_pts(dev, dga, dgb, alns[:0], tb[:0])
     assert len(empty[1]) == 0 and len(empty[3]) == 0
     dga.free(); dgb.free(); dev.close()
