@@ -723,7 +723,7 @@ void seed_merge_kernel(merge_args A)
 #ifndef WTILE_COST
 #define WTILE_COST      256
 #endif
-static_assert(WTILE_COST == 256,"the per-lane owner scan and the owner clear assume 4 entries per lane");
+static_assert(WTILE_COST == 256,"the per-lane owner scan, the owner clear and the emission descriptors assume 4 entries per lane and 8-bit tile indices");
 #define WEPT            (WTILE_COST/64)
 #define WPCAP           (WTILE_COST/2 + 2)
 #define WRAWCAP         (WTILE_COST*16 + 96)
@@ -837,6 +837,9 @@ void seed_merge_wave_kernel(merge_args A, wave_out W)
         }
       ((uint2 *) own)[lane] = make_uint2(0,0);       // WTILE_COST = 4 entries per lane
       WSYNC();
+#if defined(KNOCK_AFTER_LOAD)                        // phase knock-outs: timing experiments only (wrong output)
+      continue;
+#endif
 
       const uint32_t *rawd = (const uint32_t *) raw;
       const uint32_t o1 = (uint32_t) (s1 - s1a);
@@ -892,6 +895,9 @@ void seed_merge_wave_kernel(merge_args A, wave_out W)
             clist[lbase++] = pk[e];
       }
       WSYNC();
+#if defined(KNOCK_AFTER_COMPACT)
+      continue;
+#endif
 
       // 4. match phase
       int r_low[WEPT], r_cnt[WEPT], r_plen[WEPT], r_i[WEPT];
@@ -971,6 +977,11 @@ void seed_merge_wave_kernel(merge_args A, wave_out W)
           tsum  += (unsigned long long) cnt * plen;
         }
 
+#if defined(KNOCK_AFTER_MATCH)
+      tsum += total;
+      WSYNC();
+      continue;
+#endif
       // 5. slots: the lane's seeds take slots [off, off+total) of the wavefront's T, mapped onto the rest of the
       //    current chunk and, beyond it, a freshly reserved one
       int T;
@@ -987,8 +998,55 @@ void seed_merge_wave_kernel(merge_args A, wave_out W)
               const uint32_t bhi = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (b >> 32));
               nbase = (int64_t) (((uint64_t) bhi << 32) | blo);
             }
-          // seed-parallel emission (the common case: one match round, no per-pair filter): every lane marks its
-          // slots with its lane id, then lane = slot -- full wavefronts instead of a loop of max-count iterations
+          // Emission.  Common case (no per-pair filter, at most WTILE_COST seeds in the tile): seed-parallel -- lane = output
+          // slot.  Every entry with seeds leaves a one-dword descriptor (i, low, plen, first slot) in the compaction
+          // list and marks its first slot with its rank; a wave max-scan over the slots finds each slot's entry, so the
+          // wavefront runs ceil(T/64) full iterations instead of (rounds x longest run) mostly idle ones.
+          const bool fast = (MODE != MODE_FLIP) && !A.soft_mask && T <= WTILE_COST;
+          if (fast)
+            { ((uint2 *) own)[lane] = make_uint2(0,0);
+              WSYNC();
+              { int o = off;
+                #pragma unroll
+                for (int r = 0; r < WEPT; r++)
+                  if (r_cnt[r] > 0)
+                    { clist[r*64 + lane] = (uint32_t) r_i[r] | ((uint32_t) (r_low[r] & 0xffff) << 8) |
+                                           ((uint32_t) r_plen[r] << 16) | ((uint32_t) o << 22);
+                      own[o] = (uint16_t) (lane*WEPT + r + 1);          // ranks grow with the slot number
+                      o += r_cnt[r];
+                    }
+              }
+              WSYNC();
+              int carry = 0;
+              for (int s0 = 0; s0 < T; s0 += 64)
+                { const int slot = s0 + lane;
+                  int v = slot < T ? (int) own[slot] : 0;
+                  v = wave_incl_scan_max_dpp(v);
+                  v = v > carry ? v : carry;
+                  carry = __builtin_amdgcn_readlane(v,63);
+                  if (slot < T)
+                    { const int id = v-1;
+                      const uint32_t d = clist[(id & (WEPT-1))*64 + (id >> 2)];
+                      const int i = (int) (d & 0xff), plen = (int) ((d >> 16) & 0x3f);
+                      int j = (int) ((d >> 8) & 0xff) + (slot - (int) (d >> 22));
+                      if (MODE == MODE_SELF && j >= i)
+                        j += 1;
+                      uint32_t e0, e1_, e2_, e3, spos, sctg, ssign, c0, c1, c2, c3, cpos, cctg, csign;
+                      lds_read16(rawd,o1 + (uint32_t) i*E1,e0,e1_,e2_,e3);
+                      split_payload(e2_,e3,A.post1,A.cont1,spos,sctg,ssign);
+                      lds_read16(rawd,o2 + (uint32_t) j*E2,c0,c1,c2,c3);
+                      split_payload(c2,c3,A.post2,A.cont2,cpos,cctg,csign);
+                      const int64_t at = ((int64_t) slot < rem) ? chunk_pos + slot : nbase + ((int64_t) slot - rem);
+#if defined(KNOCK_STORE)
+                      if (at == -12345)
+#else
+                      if (at < A.cap)
+#endif
+                        A.out[at] = make_seed<MODE>(plen,spos,sctg,ssign,cpos,cctg,csign);
+                    }
+                }
+            }
+          else
           if (total > 0)
             { const int mfull = A.soft_mask;
               #pragma unroll
@@ -1012,7 +1070,11 @@ void seed_merge_wave_kernel(merge_args A, wave_out W)
                       if (MODE == MODE_FLIP && csign)
                         continue;
                       const int64_t at = ((int64_t) off < rem) ? chunk_pos + off : nbase + ((int64_t) off - rem);
+#if defined(KNOCK_STORE)
+                      if (at == -12345)
+#else
                       if (at < A.cap)
+#endif
                         A.out[at] = make_seed<MODE>(plen,spos,sctg,ssign,cpos,cctg,csign);
                       off += 1;
                     }

@@ -11,7 +11,8 @@ class FgaError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libfastga_amd.so")
+    # FGA_LIBRARY: another build of this same library (kernel A/B experiments, tools/merge_knockout.sh)
+    return os.environ.get("FGA_LIBRARY") or os.path.join(_HERE, "libfastga_amd.so")
 
 
 def load_library():
