@@ -753,9 +753,8 @@ extern "C" int fga_chain_scan_device(fga_dev *dev, const fga_dkeys *K, const fga
               goto fail;
             }
           // canonical order: units by the index of their first record, hits re-laid in unit order
-          { std::vector<int64_t> ord((size_t) nu);
-            for (int64_t i = 0; i < nu; i++) ord[(size_t) i] = i;
-            std::sort(ord.begin(),ord.end(),[&](int64_t a, int64_t b) { return hd[a] < hd[b]; });
+          { std::vector<int64_t> ord;
+            fga_radix_order((const uint64_t *) hd,nu,ord);          // first-record indices are distinct and >= 0
             R = (fga_hits *) calloc(1,sizeof(fga_hits));
             if (R == NULL) { fga_set_error("out of memory"); goto fail; }
             R->nhits = nh; R->nunits = nu;

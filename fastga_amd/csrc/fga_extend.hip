@@ -1509,20 +1509,29 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
 
   // units by decreasing estimated work (sum of hit box lengths): longest first
   std::vector<int> order(H->nunits);
-  { std::vector<std::pair<int64_t,int>> w(H->nunits);
+  { std::vector<uint64_t> w((size_t) H->nunits);
+    int64_t smax = 0;
     for (int64_t u = 0; u < H->nunits; u++)
       { int64_t s = 0;
         for (int q = 0; q < H->units[u].nhits; q++)
           { const fga_hit &h = H->hits[H->units[u].first_hit + q];
             s += (h.ahgh - h.alow) + 1000;
           }
-        w[u] = std::make_pair(-s,(int) u);
+        if (s < 0) s = 0;
+        w[(size_t) u] = (uint64_t) s;
+        if (s > smax) smax = s;
       }
-    std::sort(w.begin(),w.end());
-    for (int64_t u = 0; u < H->nunits; u++) order[u] = w[u].second;
+    for (int64_t u = 0; u < H->nunits; u++)            // decreasing work, ties by unit index (the radix order is stable)
+      w[(size_t) u] = (uint64_t) smax - w[(size_t) u];
+    std::vector<int64_t> ord;
+    fga_radix_order(w.data(),H->nunits,ord);
+    for (int64_t u = 0; u < H->nunits; u++) order[u] = (int) ord[(size_t) u];
   }
 
-  int nwg = dev->ncu * 4;
+  // resident single-wavefront workgroups: the LDS block of a wavefront (26.5 KB) allows six per CU.  With few units the
+  // run time is the longest unit's serial chain, which is fastest with four (it shares its CU's issue slots, LDS and L1
+  // with fewer neighbours: 80.7 vs 83.9 ms on the bench pair); with many units throughput wins (1 M units: 792 -> 647 ms)
+  int nwg = dev->ncu * (H->nunits >= 16*(int64_t) dev->ncu*4 ? 6 : 4);
   { const char *ev = getenv("FGA_EXTEND_WGS");
     if (ev != NULL && atoi(ev) > 0) nwg = atoi(ev);
   }

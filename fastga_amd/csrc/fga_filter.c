@@ -20,6 +20,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 
 #include "fga_host.h"
 #include "fastga_amd.h"
@@ -218,12 +219,106 @@ static int filter_segment(rec **perm, int n)
   return 0;
 }
 
+/* ---- helpers for large sets: the three orderings are O(n) / run on all threads ---- */
+
+/* stable LSD radix sort of (key, value) pairs on the low `bits` bits of the key, 11 bits per pass */
+static int sort_pairs(uint64_t *key, int64_t *val, int64_t n, int bits)
+{ uint64_t *k2 = malloc(sizeof(uint64_t)*(n > 0 ? n : 1));
+  int64_t  *v2 = malloc(sizeof(int64_t)*(n > 0 ? n : 1));
+  int64_t  *cnt = malloc(sizeof(int64_t)*2048);
+  uint64_t *ka = key, *kb = k2;
+  int64_t  *va = val, *vb = v2;
+  int shift;
+  if (k2 == NULL || v2 == NULL || cnt == NULL)
+    { free(k2); free(v2); free(cnt);
+      return 1;
+    }
+  for (shift = 0; shift < bits; shift += 11)
+    { int64_t i, sum = 0;
+      memset(cnt,0,sizeof(int64_t)*2048);
+      for (i = 0; i < n; i++)
+        cnt[(ka[i] >> shift) & 0x7ff] += 1;
+      if (n > 0 && cnt[(ka[0] >> shift) & 0x7ff] == n)
+        continue;                                   /* this digit is the same everywhere */
+      for (i = 0; i < 2048; i++)
+        { int64_t c = cnt[i]; cnt[i] = sum; sum += c; }
+      for (i = 0; i < n; i++)
+        { int64_t d = cnt[(ka[i] >> shift) & 0x7ff]++;
+          kb[d] = ka[i]; vb[d] = va[i];
+        }
+      { uint64_t *t = ka; ka = kb; kb = t; }
+      { int64_t *t = va; va = vb; vb = t; }
+    }
+  if (ka != key)
+    { memcpy(key,ka,sizeof(uint64_t)*n); memcpy(val,va,sizeof(int64_t)*n); }
+  free(k2); free(v2); free(cnt);
+  return 0;
+}
+
+typedef struct
+  { rec    **perm;
+    int64_t *segbeg;          /* nseg+1 */
+    int64_t  nseg;
+    int64_t *next;            /* shared cursor */
+    pthread_mutex_t *lock;
+    int      status;
+  } seg_job;
+
+static void *seg_thread(void *arg)
+{ seg_job *J = arg;
+  for (;;)
+    { int64_t g, hi;
+      pthread_mutex_lock(J->lock);
+      g = *J->next;
+      hi = g + 16 < J->nseg ? g + 16 : J->nseg;       /* a batch of segments per grab */
+      *J->next = hi;
+      pthread_mutex_unlock(J->lock);
+      if (g >= J->nseg)
+        break;
+      for (; g < hi; g++)
+        { const int64_t b = J->segbeg[g], e = J->segbeg[g+1];
+          qsort(J->perm+b,e-b,sizeof(rec *),by_abpos);
+          if (filter_segment(J->perm+b,(int) (e-b)))
+            J->status = 1;
+        }
+    }
+  return NULL;
+}
+
+static int run_segments(rec **perm, int64_t *segbeg, int64_t nseg, int nthreads)
+{ pthread_mutex_t lock = PTHREAD_MUTEX_INITIALIZER;
+  seg_job   job[64];
+  pthread_t th[64];
+  int64_t   next = 0;
+  int t, rc = 0;
+  if (nthreads > 64) nthreads = 64;
+  if (nthreads < 1 || nseg < 64 || segbeg[nseg] < 50000) nthreads = 1;     /* starting threads costs ~1 ms */
+  for (t = 0; t < nthreads; t++)
+    { job[t].perm = perm; job[t].segbeg = segbeg; job[t].nseg = nseg; job[t].next = &next; job[t].lock = &lock;
+      job[t].status = 0;
+    }
+  for (t = 1; t < nthreads; t++)
+    if (pthread_create(th+t,NULL,seg_thread,job+t) != 0)
+      { seg_thread(job+t); th[t] = 0; }
+  seg_thread(job);
+  for (t = 1; t < nthreads; t++)
+    if (th[t]) pthread_join(th[t],NULL);
+  for (t = 0; t < nthreads; t++)
+    rc |= job[t].status;
+  return rc;
+}
+
 /* in: alignments as produced by fga_extend (any order); out: filtered + finally ordered copy */
 int fga_filter_alignments(const fga_alns *in, fga_alns **out)
+{ return fga_filter_alignments_mt(in,1,out); }
+
+int fga_filter_alignments_mt(const fga_alns *in, int nthreads, fga_alns **out)
 { fga_alns *R;
   fga_aln  *sorted = NULL;
   rec      *recs = NULL, **perm = NULL, **live = NULL;
-  int64_t   n = in->naln, i, j, nlive = 0, tbytes = 0, off;
+  uint64_t *skey = NULL;
+  int64_t  *sval = NULL, *segbeg = NULL;
+  int64_t   n = in->naln, i, j, nlive = 0, tbytes = 0, off, nseg = 0;
 
   *out = NULL;
   R = calloc(1,sizeof(fga_alns));
@@ -238,9 +333,36 @@ int fga_filter_alignments(const fga_alns *in, fga_alns **out)
   recs   = malloc(sizeof(rec)*n);
   perm   = malloc(sizeof(rec *)*n);
   live   = malloc(sizeof(rec *)*n);
-  if (sorted == NULL || recs == NULL || perm == NULL || live == NULL) goto oom;
-  memcpy(sorted,in->alns,sizeof(fga_aln)*n);
-  qsort(sorted,n,sizeof(fga_aln),by_discovery);
+  skey   = malloc(sizeof(uint64_t)*n);
+  sval   = malloc(sizeof(int64_t)*n);
+  segbeg = malloc(sizeof(int64_t)*(n+1));
+  if (sorted == NULL || recs == NULL || perm == NULL || live == NULL || skey == NULL || sval == NULL || segbeg == NULL)
+    goto oom;
+
+  /* discovery order = (unit, seq): radix sort when the two fit a 64-bit key, else the comparison sort */
+  { int64_t maxu = 0, maxs = 0;
+    int ub = 1, sb = 1, ok = 1;
+    for (i = 0; i < n; i++)
+      { if (in->alns[i].unit < 0 || in->alns[i].seq < 0) { ok = 0; break; }
+        if (in->alns[i].unit > maxu) maxu = in->alns[i].unit;
+        if (in->alns[i].seq > maxs) maxs = in->alns[i].seq;
+      }
+    while (((int64_t) 1 << ub) <= maxu) ub += 1;
+    while (((int64_t) 1 << sb) <= maxs) sb += 1;
+    if (ok)
+      { for (i = 0; i < n; i++)
+          { skey[i] = ((uint64_t) in->alns[i].unit << sb) | (uint64_t) in->alns[i].seq;
+            sval[i] = i;
+          }
+        if (sort_pairs(skey,sval,n,ub+sb)) goto oom;
+        for (i = 0; i < n; i++)
+          sorted[i] = in->alns[sval[i]];
+      }
+    else
+      { memcpy(sorted,in->alns,sizeof(fga_aln)*n);
+        qsort(sorted,n,sizeof(fga_aln),by_discovery);
+      }
+  }
   for (i = 0; i < n; i++)
     { rec *r = recs+i;
       const fga_aln *a = sorted+i;
@@ -249,24 +371,39 @@ int fga_filter_alignments(const fga_alns *in, fga_alns **out)
       r->trace = in->tbytes + a->toff; r->owns = 0; r->ord = i;
       perm[i] = r;
     }
-  /* segments = runs of equal (aread, bread, comp) in discovery order (units are key-ordered) */
+  /* segments = runs of equal (aread, bread, comp) in discovery order (units are key-ordered); independent of each other */
   for (i = 0; i < n; i = j)
     { for (j = i+1; j < n; j++)
         if (recs[j].aread != recs[i].aread || recs[j].bread != recs[i].bread ||
             (recs[j].flags & 1) != (recs[i].flags & 1))
           break;
-      qsort(perm+i,j-i,sizeof(rec *),by_abpos);
-      if (filter_segment(perm+i,(int) (j-i))) goto oom;
-      { int64_t q;
-        for (q = i; q < j; q++)
-          if (!(perm[q]->flags & ELIMINATED))
-            { perm[q]->ord = nlive;           /* order of survival = the reference's file order */
-              live[nlive++] = perm[q];
-              tbytes += perm[q]->tlen;
-            }
-      }
+      segbeg[nseg++] = i;
     }
-  qsort(live,nlive,sizeof(rec *),by_final);
+  segbeg[nseg] = n;
+  if (run_segments(perm,segbeg,nseg,nthreads)) goto oom;
+  for (i = 0; i < n; i++)
+    if (!(perm[i]->flags & ELIMINATED))
+      { perm[i]->ord = nlive;                 /* order of survival = the reference's file order */
+        live[nlive++] = perm[i];
+        tbytes += perm[i]->tlen;
+      }
+
+  /* final order (aread, abpos, bread, comp, survival): radix sort on (aread, abpos), then the few runs that tie on
+   * both are put in order by the rest of the key */
+  if (nlive > 1)
+    { for (i = 0; i < nlive; i++)
+        { skey[i] = ((uint64_t) (uint32_t) live[i]->aread << 32) | (uint32_t) live[i]->abpos; sval[i] = i; }
+      if (sort_pairs(skey,sval,nlive,64)) goto oom;
+      for (i = 0; i < nlive; i++)
+        perm[i] = live[sval[i]];
+      for (i = 0; i < nlive; i = j)
+        { for (j = i+1; j < nlive && skey[j] == skey[i]; j++)
+            ;
+          if (j-i > 1)
+            qsort(perm+i,j-i,sizeof(rec *),by_final);
+        }
+      memcpy(live,perm,sizeof(rec *)*nlive);
+    }
 
   R->naln = nlive; R->ntrace = tbytes;
   R->alns = malloc(sizeof(fga_aln)*(nlive+1));
@@ -285,13 +422,13 @@ int fga_filter_alignments(const fga_alns *in, fga_alns **out)
     }
   for (i = 0; i < n; i++)
     if (recs[i].owns) free(recs[i].trace);
-  free(sorted); free(recs); free(perm); free(live);
+  free(sorted); free(recs); free(perm); free(live); free(skey); free(sval); free(segbeg);
   *out = R;
   return 0;
 
 oom:
   fga_set_error("out of memory in alignment filter");
-  free(sorted); free(recs); free(perm); free(live);
+  free(sorted); free(recs); free(perm); free(live); free(skey); free(sval); free(segbeg);
   if (R != NULL) { free(R->alns); free(R->tbytes); free(R); }
   return 1;
 }

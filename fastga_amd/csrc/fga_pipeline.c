@@ -204,7 +204,7 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
   st.extend_s = fga_wall() - t1;
 
   t1 = fga_wall();
-  if (fga_filter_alignments(raw,&fin)) goto done;
+  if (fga_filter_alignments_mt(raw,P->nthreads,&fin)) goto done;
   st.nlive = fin->naln;
   for (i = 0; i < fin->naln; i++)
     st.cover += fin->alns[i].aepos - fin->alns[i].abpos;

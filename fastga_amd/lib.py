@@ -157,6 +157,7 @@ def _declare(L):
         "fga_alns_free": (None, [P(Alns)]),
         "fga_seed_merge_append": (i32, [vp, vp, vp, P(MergeParams), vp]),
         "fga_filter_alignments": (i32, [P(Alns), P(P(Alns))]),
+        "fga_filter_alignments_mt": (i32, [P(Alns), i32, P(P(Alns))]),
         "fga_write_1aln": (i32, [cp, vp, vp, P(Alns), i32, cp, cp, cp]),
         "fga_write_1aln_binary": (i32, [cp, vp, vp, P(Alns), i32, cp, cp, cp]),
         "fga_trace_pts": (i32, [vp, vp, vp, P(Alns), i32, i32, P(P(Traces))]),

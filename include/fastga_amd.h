@@ -212,6 +212,7 @@ int  fga_seed_merge_append(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
 
 /* ---- redundancy filter + final order (FastGA.c:3405-3694, 3800-3835) and .1aln emission (alncode.c:239-305) ---- */
 int  fga_filter_alignments(const fga_alns *in, fga_alns **out);
+int  fga_filter_alignments_mt(const fga_alns *in, int nthreads, fga_alns **out);   /* same result, contig pairs in parallel */
 int  fga_write_1aln(const char *path, const fga_gdb *g1, const fga_gdb *g2 /* NULL: self */, const fga_alns *alns,
                     int tspace, const char *db1_name, const char *db2_name, const char *command_line);
 /* the same content in the binary ONEcode container the reference writes (object index in the footer, so the

@@ -14,14 +14,15 @@ ap.add_argument("--repeats", type=float, default=0.30)
 ap.add_argument("--self", dest="self_", action="store_true")
 ap.add_argument("--mask", action="store_true")
 ap.add_argument("--threads", type=int, default=32)
+ap.add_argument("--host-gix", action="store_true", help="build .gix files on the host instead of on the device")
 a = ap.parse_args()
 d = tempfile.mkdtemp(prefix="fga_scale_")
 t = time.time()
 lens = synth.contig_lengths(2, a.contigs, int(a.mbp * 1e6))
 A, mA, B, mB = synth.make_pair(2, lens, a.div, repeat_frac=a.repeats, inv_frac=0.02, swap_frac=0.02, self_only=a.self_)
 print(f"synth {time.time()-t:.1f}s", flush=True); t = time.time()
-ra = workload.build_genome(d, "A", A, masks=mA if a.mask else None, threads=a.threads, use_mask=a.mask)
-rb = None if a.self_ else workload.build_genome(d, "B", B, threads=a.threads)
+ra = workload.build_genome(d, "A", A, masks=mA if a.mask else None, threads=a.threads, use_mask=a.mask, gix=a.host_gix)
+rb = None if a.self_ else workload.build_genome(d, "B", B, threads=a.threads, gix=a.host_gix)
 print(f"GDB+GIX build {time.time()-t:.1f}s", flush=True); t = time.time()
 ses = D.Session(ra, rb)
 print(f"load+upload {time.time()-t:.1f}s  table bytes {ses.table_bytes/1e9:.2f} GB", flush=True)
