@@ -195,19 +195,48 @@ static inline int base_at(const fga_gdb *G, int c, int64_t i)
   return (src[i>>2] >> (2*(i&3))) & 3;
 }
 
+/* the four bases of a packed byte as four numeric bytes: in order, and reverse-complemented */
+static uint32_t unpack_fwd[256], unpack_rc[256];
+
+static void unpack_tables(void)
+{ int b, q;
+  for (b = 0; b < 256; b++)
+    { uint8_t f[4], r[4];
+      for (q = 0; q < 4; q++)
+        { f[q] = (uint8_t) ((b >> (2*q)) & 3);
+          r[3-q] = (uint8_t) (3 - f[q]);
+        }
+      memcpy(unpack_fwd+b,f,4);
+      memcpy(unpack_rc+b,r,4);
+    }
+}
+
 /* B piece [bb,be) of contig c in the alignment's orientation; out[0] and out[n+1] = 4; returns a pointer such that
- * ptr[q] is the q-th base (1-based) of the (complemented) contig for q in bb+1..be */
+ * ptr[q] is the q-th base (1-based) of the (complemented) contig for q in bb+1..be.  out needs n+8 bytes. */
 static const uint8_t *load_piece(const fga_gdb *G, int c, int bb, int be, int comp, uint8_t *out)
-{ const int64_t len = G->contigs[c].clen;
+{ const uint8_t *src = G->bps + G->contigs[c].boff;
+  const int64_t len = G->contigs[c].clen;
   const int n = be-bb;
-  int i;
+  int i = 0;
   out[0] = 4;
   if (comp)
-    for (i = 0; i < n; i++)
-      out[1+i] = (uint8_t) (3 - base_at(G,c,len-1-(bb+i)));
+    { int64_t q = len-1-bb;                          /* source position of out[1], walking down */
+      for (; i < n && (q & 3) != 3; i++, q--)
+        out[1+i] = (uint8_t) (3 - base_at(G,c,q));
+      for (; i+4 <= n; i += 4, q -= 4)
+        memcpy(out+1+i,unpack_rc + src[q>>2],4);
+      for (; i < n; i++, q--)
+        out[1+i] = (uint8_t) (3 - base_at(G,c,q));
+    }
   else
-    for (i = 0; i < n; i++)
-      out[1+i] = (uint8_t) base_at(G,c,bb+i);
+    { int64_t q = bb;
+      for (; i < n && (q & 3) != 0; i++, q++)
+        out[1+i] = (uint8_t) base_at(G,c,q);
+      for (; i+4 <= n; i += 4, q += 4)
+        memcpy(out+1+i,unpack_fwd + src[q>>2],4);
+      for (; i < n; i++, q++)
+        out[1+i] = (uint8_t) base_at(G,c,q);
+    }
   out[n+1] = 4;
   return out - bb;
 }
@@ -283,9 +312,27 @@ static int op_block(oplist *L, const uint8_t *A1, const uint8_t *B1, int k, int 
 { int i;
   if (!eqx)
     return op_add(L,'M',len);
-  for (i = 0; i < len; i++)
-    if (op_add(L,A1[k+i] == B1[h+i] ? '=' : 'X',1))
-      return 1;
+  for (i = 0; i < len; )
+    { const uint8_t *a = A1+k, *b = B1+h;
+      int j = i;
+      while (j+8 <= len)                          /* equal columns eight at a time */
+        { uint64_t x, y;
+          memcpy(&x,a+j,8); memcpy(&y,b+j,8);
+          if ((x ^= y) != 0)
+            { j += __builtin_ctzll(x) >> 3;
+              break;
+            }
+          j += 8;
+        }
+      while (j < len && a[j] == b[j])
+        j += 1;
+      if (op_add(L,'=',j-i)) return 1;
+      i = j;
+      while (j < len && a[j] != b[j])
+        j += 1;
+      if (op_add(L,'X',j-i)) return 1;
+      i = j;
+    }
   return 0;
 }
 
@@ -547,7 +594,7 @@ static void *psl_thread(void *arg)
         { A1 = fga_gdb_get_contig(g1,a.aread,abuf) - 1;
           alast = a.aread;
         }
-      if (n+4 > bcap)
+      if (n+16 > bcap)
         { bcap = 2*(int64_t) n + 4096;
           free(bbuf);
           bbuf = malloc(bcap);
@@ -681,6 +728,7 @@ static int write_lines(const char *path, const fga_gdb *g1, const fga_gdb *g2, c
           return 1;
         }
     }
+  unpack_tables();
   if (nthreads < 1) nthreads = 1;
   if (nthreads > 64) nthreads = 64;
   if (alns->naln < nthreads) nthreads = alns->naln > 0 ? (int) alns->naln : 1;
@@ -756,6 +804,7 @@ int fga_gap_improve(const fga_gdb *g1, const fga_gdb *g2, const fga_alns *alns, 
     { fga_set_error("fga_gap_improve: the edit scripts do not belong to this alignment set");
       return 1;
     }
+  unpack_tables();
   abuf = malloc(g1->maxctg+4);
   if (abuf == NULL) goto oom;
   for (i = 0; i < alns->naln; i++)
@@ -767,7 +816,7 @@ int fga_gap_improve(const fga_gdb *g1, const fga_gdb *g2, const fga_alns *alns, 
         { A1 = fga_gdb_get_contig(g1,a->aread,abuf) - 1;
           alast = a->aread;
         }
-      if (n+4 > bcap)
+      if (n+16 > bcap)
         { bcap = 2*(int64_t) n + 4096;
           free(bbuf);
           bbuf = malloc(bcap);
