@@ -909,14 +909,24 @@ void    fga_gdb_freq(const fga_gdb *G, float *f4)    { memcpy(f4,G->freq,4*sizeo
 /* Unpack contig c into numeric form (0..3), buf must hold clen+2 bytes; buf[0] and buf[clen+1] get the
  * sentinel 4 the aligner needs either side (GDB.c:1718-1727, gene_core.c:397); returns buf+1. */
 uint8_t *fga_gdb_get_contig(const fga_gdb *G, int c, uint8_t *buf)
-{ const uint8_t *src = G->bps + G->contigs[c].boff;
+{ static uint32_t quad[256];            /* the four bases of a packed byte as four numeric bytes */
+  static volatile int quad_ready = 0;
+  const uint8_t *src = G->bps + G->contigs[c].boff;
   int64_t len = G->contigs[c].clen, i;
   uint8_t *s = buf+1;
+  if (!quad_ready)                      /* every writer stores the same values, so a race here is harmless */
+    { int b, q;
+      for (b = 0; b < 256; b++)
+        { uint8_t f[4];
+          for (q = 0; q < 4; q++)
+            f[q] = (uint8_t) ((b >> (2*q)) & 3);
+          memcpy(quad+b,f,4);
+        }
+      quad_ready = 1;
+    }
   buf[0] = 4;
   for (i = 0; i+4 <= len; i += 4)
-    { uint8_t b = src[i>>2];
-      s[i] = b & 3; s[i+1] = (b>>2) & 3; s[i+2] = (b>>4) & 3; s[i+3] = (b>>6) & 3;
-    }
+    memcpy(s+i,quad + src[i>>2],4);
   for (; i < len; i++)
     s[i] = (src[i>>2] >> (2*(i&3))) & 3;
   s[len] = 4;
