@@ -459,14 +459,13 @@ extern "C" int fga_trace_pts(fga_dev *dev, const fga_dgenome *GA, const fga_dgen
   T.raw = d_raw;
 
   { // batches of whole alignments bounded by scratch cells
-    int64_t maxcells = 0, maxpan = 0;
+    int64_t maxcells = 0;
     std::vector<int64_t> cut(1,0);
     for (int64_t i = 0; i < n; )
       { int64_t j = i+1;
         while (j < n && sbase[j+1]-sbase[i] <= cell_cap) j++;
         cut.push_back(j);
         if (sbase[j]-sbase[i] > maxcells) maxcells = sbase[j]-sbase[i];
-        if (pbase[j]-pbase[i] > maxpan) maxpan = pbase[j]-pbase[i];
         i = j;
       }
     TRY(hipMalloc(&d_cells,sizeof(uint16_t)*(maxcells+1)));
@@ -482,7 +481,6 @@ extern "C" int fga_trace_pts(fga_dev *dev, const fga_dgenome *GA, const fga_dgen
         hipLaunchKernelGGL(trace_panel_kernel,dim3((unsigned) ((T.np+63)/64)),dim3(64),0,dev->stream,T);
       }
     T.panels = d_panels; T.p0 = 0;
-    (void) maxpan;
   }
   hipLaunchKernelGGL(trace_count_kernel,dim3((unsigned) n),dim3(64),0,dev->stream,T);
   hipLaunchKernelGGL(trace_scan_kernel,dim3(1),dim3(1024),0,dev->stream,d_atlen,d_toff,n);

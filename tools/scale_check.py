@@ -15,6 +15,7 @@ ap.add_argument("--self", dest="self_", action="store_true")
 ap.add_argument("--mask", action="store_true")
 ap.add_argument("--threads", type=int, default=32)
 ap.add_argument("--host-gix", action="store_true", help="build .gix files on the host instead of on the device")
+ap.add_argument("--pafx", action="store_true", help="also write PAF with CIGARs (edit scripts on the device)")
 a = ap.parse_args()
 d = tempfile.mkdtemp(prefix="fga_scale_")
 t = time.time()
@@ -28,12 +29,16 @@ ses = D.Session(ra, rb)
 print(f"load+upload {time.time()-t:.1f}s  table bytes {ses.table_bytes/1e9:.2f} GB", flush=True)
 for rep in range(2):
     t = time.time()
-    st = ses.run(out_path=os.path.join(d, "out.1aln"), nthreads=a.threads, soft_mask=a.mask)
+    st = ses.run(out_path=os.path.join(d, "out.1aln"), nthreads=a.threads, soft_mask=a.mask,
+                 paf_path=os.path.join(d, "out.paf") if a.pafx else None, paf_flags=2 if a.pafx else 0)
     dt = time.time() - t
     print(f"run {rep}: {dt*1000:.0f} ms  seeds {st['nseeds']} hits {st['nhits']} units {st['nunits']} alns {st['nalns']} "
           f"live {st['nlive']} calls {st['ncalls']} waves {st['nwaves']}", flush=True)
     print("   stages ms:", {k: round(1000*st[k], 1) for k in ("merge_s","sort_s","download_s","chain_s","extend_s","filter_s","write_s")},
           "kernels ms:", {k: round(st[k], 2) for k in ("merge_kernel_ms","sort_kernel_ms","extend_kernel_ms")}, flush=True)
+    if a.pafx:
+        print(f"   PAF -x: edit scripts {1000*st['trace_s']:.1f} ms (kernels {st['trace_kernel_ms']:.1f} ms), regroup+format "
+              f"{1000*st['paf_s']:.1f} ms, {os.path.getsize(os.path.join(d, 'out.paf'))/1e6:.0f} MB", flush=True)
     alg = ses.table_bytes + st["nseeds"] * (2 if a.self_ else 1) * ses.seed_bytes
     print(f"   merge kernel {alg/st['merge_kernel_ms']/1e6:.0f} GB/s algorithmic", flush=True)
 ses.close()
