@@ -125,7 +125,8 @@ def main():
     # of genome B); rank 0 also writes the .gix/.ktab files of both genomes from device builds, for the reference
     # FastGA of the cpu_baseline leg
     gix_ms = ses.dev_wrapper().stage_ms(5)
-    if rank == 0 and not args.no_cpu:
+    do_cpu = (not args.no_cpu) and world == 1          # the CPU baseline leg runs on rank 0 at N=1 only
+    if rank == 0 and do_cpu:
         from fastga_amd.gixio import Gdb
         for r in (ra, rb):
             g = Gdb(r + ".gdb")
@@ -194,7 +195,7 @@ def main():
             if tr is not None:
                 out["roofline"]["traffic"] = tr
                 out["roofline"]["traffic_source"] = src
-        if not args.no_cpu:
+        if do_cpu:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, ra, rb, workdir,
                                                    verify_against=out1aln if args.verify else None)
