@@ -484,14 +484,16 @@ void seed_merge_kernel(merge_args A)
       { const uint4 *g1 = (const uint4 *) (A.tab1 + s1a);
         uint4 *l1 = (uint4 *) raw;
         const int n16 = (int) (len1 >> 4);
-        for (int x = tid; x < n16; x += NT)
-          l1[x] = g1[x];
+        for (int x = tid; x < n16; x += NT)           // global_load_lds: a wavefront's 64 lanes write 1 KB in lane order
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (g1 + x),
+                                           (__attribute__((address_space(3))) void *) (l1 + x),16,0,0);
         if (MODE != MODE_SELF)
           { const uint4 *g2 = (const uint4 *) (A.tab2 + s2a);
             uint4 *l2 = (uint4 *) (raw + len1);
             const int m16 = (int) (len2 >> 4);
             for (int x = tid; x < m16; x += NT)
-              l2[x] = g2[x];
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (g2 + x),
+                                               (__attribute__((address_space(3))) void *) (l2 + x),16,0,0);
           }
       }
       for (int q = tid; q < np; q += NT)
@@ -818,17 +820,20 @@ void seed_merge_wave_kernel(merge_args A, wave_out W)
       const int n1 = (int) n1l, n2 = (int) n2l;
 
       // 1. raw bytes HBM -> LDS, index slices, owner array cleared
+      // straight into LDS (global_load_lds_dwordx4: destination = the first lane's address + lane x 16, no VGPR staging)
       { const uint4 *g1 = (const uint4 *) (A.tab1 + s1a);
         uint4 *l1 = (uint4 *) raw;
         const int n16 = (int) (len1 >> 4);
         for (int x = lane; x < n16; x += 64)
-          l1[x] = g1[x];
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (g1 + x),
+                                           (__attribute__((address_space(3))) void *) (l1 + x),16,0,0);
         if (MODE != MODE_SELF)
           { const uint4 *g2 = (const uint4 *) (A.tab2 + s2a);
             uint4 *l2 = (uint4 *) (raw + len1);
             const int m16 = (int) (len2 >> 4);
             for (int x = lane; x < m16; x += 64)
-              l2[x] = g2[x];
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (g2 + x),
+                                               (__attribute__((address_space(3))) void *) (l2 + x),16,0,0);
           }
       }
       for (int q = lane; q < np; q += 64)
