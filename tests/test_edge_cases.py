@@ -74,3 +74,30 @@ def test_reference_binary_1gdb_is_read_directly(tmp_path, built_library):
     ref = [ln for ln in H.oneview(os.path.join(rd, "E.1gdb")) if ln[0] in "SGC"]
     assert [ln for ln in skel if ln[0] != "g"] == ref
     a.close(); b.close()
+
+
+@needs_ref
+def test_reads_codec_compressed_1gdb(tmp_path, built_library):
+    """a .1gdb of a fragmented assembly: after ~100 KB of scaffold names the reference's writer trains a Huffman code
+    and compresses the remaining S lines (code in the footer).  Our reader must return the same skeleton the
+    reference's ONEview prints."""
+    import random
+    from fastga_amd.gixio import Gdb
+    w = str(tmp_path)
+    rnd = random.Random(3)
+    fa = os.path.join(w, "many.fa")
+    with open(fa, "w") as f:
+        for i in range(6000):
+            f.write(f">scaffold_{i:06d}_len_{rnd.randint(100, 999)} some description text\n")
+            f.write("".join(rnd.choice("ACGT") for _ in range(rnd.randint(60, 140))) + "\n")
+    H.run([H.ref_bin("FAtoGDB"), fa], cwd=w)
+    raw = open(os.path.join(w, "many.1gdb"), "rb").read()
+    assert raw.count(b"\xa5") > 1000                       # type byte of a compressed S line
+    g = Gdb(os.path.join(w, "many.1gdb"))
+    assert g.ncontig == 6000
+    out = os.path.join(w, "ours.gdb")
+    assert g.L.fga_gdb_write_skeleton(g.h, out.encode(), b"test", b"cmd") == 0
+    ours = [ln for ln in open(out).read().splitlines() if ln[:1] in "SGCf"]
+    ref = [ln for ln in H.oneview(os.path.join(w, "many.1gdb")) if ln[:1] in "SGCf"]
+    assert ours == ref and len(ours) == 12001
+    g.close()
