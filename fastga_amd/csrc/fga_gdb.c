@@ -542,193 +542,14 @@ static int ascii_string(const char *p, const char **str, int64_t *len)
 /* ---- binary ONEcode (the container ONElib writes; see fga_aln.c for the layout) ---- */
 enum { F_INT = 1, F_REAL, F_CHAR, F_STRING, F_INT_LIST, F_REAL_LIST, F_STRING_LIST, F_DNA };
 
-static int ltf_get(const uint8_t *u, const uint8_t *end, int64_t *val)   /* bytes used, 0 on overrun */
-{ int n;
-  uint64_t v = 0;
-  if (u >= end) return 0;
-  switch (u[0] >> 5)
-  { case 2: case 3: *val = u[0] & 0x3f; return 1;
-    case 6: case 7: *val = (int64_t) (int8_t) u[0]; return 1;
-    case 1: if (u+1 >= end) return 0;
-            *val = ((int64_t) (u[0] & 0x1f) << 8) | u[1]; return 2;
-    case 0: case 4:
-      n = (u[0] & 7) + 1;                         /* payload bytes */
-      if (n < 2 || u+n >= end) return 0;
-      memcpy(&v,u+1,(size_t) n);
-      if ((u[0] >> 5) == 4 && n < 8)              /* negative: sign extend */
-        v |= ~(uint64_t) 0 << (8*n);
-      *val = (int64_t) v;
-      return n+1;
-    default: return 0;
-  }
-}
-
-/* ---- list codecs of binary ONEcode files -------------------------------------------------------------------------
- * Once a writer has seen ~100 KB of some line type's lists it trains a length-limited Huffman code for them; later
- * lines of that type carry bit 0 in their type byte and, instead of the list bytes, a bit count and the code stream.
- * The code itself travels in the footer as a ';' line (ONElib.c:2641-2660, 3305-3420).  A stream (ONElib.c:3621-3725) is
- * a sequence of 64-bit words, most significant bit first, each stored in the writer's byte order, followed by the last
- * < 64 bits byte by byte; bytes 0 and 7 of the first word are exchanged on a little-endian writer so that the two flag
- * bits (0x80: always, 0x40: big-endian writer) can be read from byte 0; a first byte 0xff means "stored as is".
- * Symbols are looked up through their 16-bit prefix; the escape code is followed by a literal byte. */
-typedef struct
-  { int      have;
-    int      esc, esclen;
-    uint8_t  len[256];
-    uint8_t *look;           /* 65536 entries: symbol of every 16-bit prefix */
-  } list_codec;
-
-static int codec_parse(list_codec *c, const uint8_t *in, int64_t n)
-{ const uint8_t *q = in, *end = in+n;
-  uint16_t bits[256];
-  int i;
-  if (n < 9 || in[0] != 0)                       /* [0]: the writer was big-endian -- not produced on the machines we run on */
-    return 1;
-  memcpy(&c->esc,in+1,4);
-  memcpy(&c->esclen,in+5,4);
-  q = in+9;
-  for (i = 0; i < 256; i++)
-    { if (q >= end) return 1;
-      c->len[i] = *q++;
-      bits[i] = 0;
-      if (c->len[i] > 0 || i == c->esc)
-        { if (q+2 > end) return 1;
-          memcpy(bits+i,q,2);
-          q += 2;
-        }
-    }
-  c->look = malloc(0x10000);
-  if (c->look == NULL) return 1;
-  memset(c->look,0,0x10000);
-  for (i = 0; i < 256; i++)
-    { const int l = (i == c->esc) ? c->esclen : c->len[i];
-      if (l > 0 && l <= 16)
-        { const uint32_t base = ((uint32_t) bits[i] << (16-l)) & 0xffff, span = 1u << (16-l);
-          uint32_t j;
-          for (j = 0; j < span && base+j < 0x10000; j++)
-            c->look[base+j] = (uint8_t) i;
-        }
-    }
-  c->have = 1;
-  return 0;
-}
-
-/* decode nbits of stream into out (capacity cap); returns the number of bytes produced, -1 on a malformed stream */
-static int64_t codec_decode(const list_codec *c, const uint8_t *in, int64_t nbits, uint8_t *out, int64_t cap)
-{ const int64_t nbytes = (nbits+7) >> 3;
-  uint8_t *canon;
-  int64_t pos, o = 0, w;
-  if (nbytes > 0 && in[0] == 0xff)               /* stored */
-    { const int64_t m = (nbits >> 3) - 1;
-      if (m < 0 || m > cap) return -1;
-      memcpy(out,in+1,(size_t) m);
-      return m;
-    }
-  canon = malloc((size_t) nbytes + 8);
-  if (canon == NULL) return -1;
-  memcpy(canon,in,(size_t) nbytes);
-  memset(canon+nbytes,0,8);
-  if (nbits >= 64)
-    { uint8_t x = canon[0]; canon[0] = canon[7]; canon[7] = x; }
-  for (w = 0; (w+1)*64 <= nbits; w++)            /* little-endian words -> most significant byte first */
-    { uint8_t *b = canon + 8*w, t;
-      int k;
-      for (k = 0; k < 4; k++)
-        { t = b[k]; b[k] = b[7-k]; b[7-k] = t; }
-    }
-  if (canon[0] & 0x40)                           /* written on a big-endian machine */
-    { free(canon);
-      return -1;
-    }
-  pos = 2;
-  while (pos < nbits)
-    { uint32_t look = 0;
-      int k, sym, l;
-      for (k = 0; k < 3; k++)                    /* the next 16 bits (zero padded beyond the end) */
-        look = (look << 8) | canon[(pos >> 3) + k];
-      look = (look >> (8 - (pos & 7))) & 0xffff;
-      sym = c->look[look];
-      if (sym == c->esc)
-        { uint32_t lit = 0;
-          pos += c->esclen;
-          for (k = 0; k < 2; k++)
-            lit = (lit << 8) | canon[(pos >> 3) + k];
-          sym = (int) ((lit >> (8 - (pos & 7))) & 0xff);
-          l = 8;
-        }
-      else
-        l = c->len[sym];
-      if (l <= 0 || o >= cap)
-        { free(canon);
-          return -1;
-        }
-      pos += l;
-      out[o++] = (uint8_t) sym;
-    }
-  free(canon);
-  return o;
-}
-
-/* the footer of a binary file: count lines in ASCII, index ('&') and codec (';') lines in binary, closed by "^" */
-static int read_footer_codecs(const uint8_t *buf, size_t size, list_codec *codec)
-{ int64_t off;
-  const uint8_t *p, *end;
-  if (size < 16) return 0;
-  memcpy(&off,buf+size-8,8);
-  if (off <= 0 || (size_t) off >= size-8) return 0;
-  p = buf+off; end = buf+size-8;
-  while (p < end && *p != '^')
-    { if (!(*p & 0x80))                           /* an ASCII line */
-        { const uint8_t *e = memchr(p,'\n',(size_t) (end-p));
-          if (e == NULL) return 0;
-          p = e+1;
-          continue;
-        }
-      { const uint8_t x = *p++;
-        const int k = (x & 0x7f) >> 1;
-        int64_t v, f0;
-        int u, t;
-        if (p >= end) return 1;
-        t = *p++;                                 /* both footer line types start with the CHAR of a line type */
-        if ((u = ltf_get(p,end,&v)) == 0 || v < 0) return 1;
-        p += u;
-        if (k == 53)                              /* '&': INT_LIST, possibly compressed itself */
-          { if (v > 0)
-              { if ((u = ltf_get(p,end,&f0)) == 0) return 1;
-                p += u;
-                if (v > 1)
-                  { int w;
-                    if (p >= end) return 1;
-                    w = *p++;
-                    if (x & 1)
-                      { int64_t nb;
-                        if ((u = ltf_get(p,end,&nb)) == 0 || nb < 0) return 1;
-                        p += u + ((nb+7) >> 3);
-                      }
-                    else
-                      p += (v-1)*w;
-                  }
-              }
-          }
-        else if (k == 52)                         /* ';': the serialized code of line type t */
-          { if ((x & 1) || p+v > end) return 1;
-            if (t >= 0 && t < 128 && codec_parse(codec+t,p,v)) return 1;
-            p += v;
-          }
-        else
-          return 1;
-        if (p > end) return 1;
-      }
-    }
-  return 0;
-}
+/* packed integers, list codes and the footer scan live in fga_one.c */
 
 static int read_binary_skeleton(skel_ctx *X, const uint8_t *buf, size_t size, const char *spath)
 { /* field lists per line type from the '~' schema lines of the header */
   uint8_t nfld[128], fld[128][8];
   const uint8_t *p = buf, *end = buf + size;
   int seen_dollar = 0, rc = 1, ci;
-  list_codec *codec = calloc(128,sizeof(list_codec));
+  fga_one_codec *codec = calloc(128,sizeof(fga_one_codec));
   uint8_t *dec = NULL;
   int64_t deccap = 0;
   if (codec == NULL) { fga_set_error("out of memory"); return 1; }
@@ -774,7 +595,7 @@ static int read_binary_skeleton(skel_ctx *X, const uint8_t *buf, size_t size, co
     { fga_set_error("%s: binary ONEcode header has no $ line",spath);
       goto done;
     }
-  if (read_footer_codecs(buf,size,codec))
+  if (fga_one_footer_codecs(buf,size,codec))
     { fga_set_error("%s: malformed ONEcode footer",spath);
       goto done;
     }
@@ -800,7 +621,7 @@ static int read_binary_skeleton(skel_ctx *X, const uint8_t *buf, size_t size, co
           int u;
           switch (fld[t][i])
           { case F_INT:
-              if ((u = ltf_get(p,end,&v)) == 0) goto trunc;
+              if ((u = fga_one_int(p,end,&v)) == 0) goto trunc;
               p += u;
               if (first_int) { ival = v; first_int = 0; }
               break;
@@ -814,12 +635,12 @@ static int read_binary_skeleton(skel_ctx *X, const uint8_t *buf, size_t size, co
               p += 1;
               break;
             default:                              /* a list: its length first */
-              if ((u = ltf_get(p,end,&v)) == 0 || v < 0) goto trunc;
+              if ((u = fga_one_int(p,end,&v)) == 0 || v < 0) goto trunc;
               p += u;
               if (fld[t][i] == F_INT_LIST)
                 { int64_t f0;
                   if (v > 0)
-                    { if ((u = ltf_get(p,end,&f0)) == 0) goto trunc;
+                    { if ((u = fga_one_int(p,end,&f0)) == 0) goto trunc;
                       p += u;
                       if (v > 1)
                         { int w;
@@ -827,7 +648,7 @@ static int read_binary_skeleton(skel_ctx *X, const uint8_t *buf, size_t size, co
                           w = *p++;
                           if (x & 1)                  /* compressed differences: not needed, skipped */
                             { int64_t nb;
-                              if ((u = ltf_get(p,end,&nb)) == 0 || nb < 0 || p+u+((nb+7)>>3) > end) goto trunc;
+                              if ((u = fga_one_int(p,end,&nb)) == 0 || nb < 0 || p+u+((nb+7)>>3) > end) goto trunc;
                               p += u + ((nb+7) >> 3);
                             }
                           else
@@ -839,7 +660,7 @@ static int read_binary_skeleton(skel_ctx *X, const uint8_t *buf, size_t size, co
                 }
               else if ((x & 1) && v > 0)              /* a codec-compressed list: bit count, then the code stream */
                 { int64_t nb, got;
-                  if ((u = ltf_get(p,end,&nb)) == 0 || nb < 0 || p+u+((nb+7)>>3) > end) goto trunc;
+                  if ((u = fga_one_int(p,end,&nb)) == 0 || nb < 0 || p+u+((nb+7)>>3) > end) goto trunc;
                   p += u;
                   if (fld[t][i] != F_STRING)
                     { p += (nb+7) >> 3;               /* only the scaffold names are read from a GDB */
@@ -855,7 +676,7 @@ static int read_binary_skeleton(skel_ctx *X, const uint8_t *buf, size_t size, co
                       dec = malloc((size_t) deccap);
                       if (dec == NULL) { fga_set_error("out of memory"); goto done; }
                     }
-                  got = codec_decode(codec+t,p,nb,dec,deccap);
+                  got = fga_one_codec_decode(codec+t,p,nb,dec,deccap);
                   if (got != v)
                     { fga_set_error("%s: a compressed %c line does not decode to its %lld bytes",spath,t,(long long) v);
                       goto done;

@@ -81,6 +81,18 @@ void     fga_gdb_close(fga_gdb *G);
 uint8_t *fga_gdb_get_contig(const fga_gdb *G, int c, uint8_t *buf);
 int      fga_gdb_write_skeleton(const fga_gdb *G, const char *path, const char *prog, const char *command);
 
+/* binary ONEcode pieces shared by the GDB and the .1aln readers (fga_one.c) */
+typedef struct
+  { int      have;
+    int      esc, esclen;
+    uint8_t  len[256];
+    uint8_t *look;           /* 65536 entries: symbol of every 16-bit prefix */
+  } fga_one_codec;
+int     fga_one_int(const uint8_t *u, const uint8_t *end, int64_t *val);
+int     fga_one_codec_parse(fga_one_codec *c, const uint8_t *in, int64_t n);
+int64_t fga_one_codec_decode(const fga_one_codec *c, const uint8_t *in, int64_t nbits, uint8_t *out, int64_t cap);
+int     fga_one_footer_codecs(const uint8_t *buf, size_t size, fga_one_codec *codec /* [128] */);
+
 /* GIX (fga_gix.c) */
 int      fga_gix_open(const char *path, fga_gix **out);
 void     fga_gix_close(fga_gix *X);

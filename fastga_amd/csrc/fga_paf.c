@@ -297,6 +297,12 @@ static void tx_str(text *X, const char *s)
   X->n += l;
 }
 
+/* a scaffold name as the reference's converters print it: up to the first white space (ALNtoPAF.c:763-783) */
+static void tx_name(text *X, const char *s)
+{ while (*s != '\0' && !(*s == ' ' || (*s >= '\t' && *s <= '\r')))
+    tx_char(X,*s++);
+}
+
 static void tx_int(text *X, int64_t v)
 { char b[24];
   int  k = 0;
@@ -417,16 +423,16 @@ static void *paf_thread(void *arg)
       else
         { bs = cb->sbeg+a->bbpos; be = cb->sbeg+a->bepos; }
       if (swap)
-        { tx_str(X,nb); tx_char(X,'\t'); tx_int(X,sb->slen); tx_char(X,'\t'); tx_int(X,bs); tx_char(X,'\t'); tx_int(X,be);
+        { tx_name(X,nb); tx_char(X,'\t'); tx_int(X,sb->slen); tx_char(X,'\t'); tx_int(X,bs); tx_char(X,'\t'); tx_int(X,be);
           tx_char(X,'\t'); tx_char(X,comp ? '-' : '+'); tx_char(X,'\t');
-          tx_str(X,na); tx_char(X,'\t'); tx_int(X,sa->slen); tx_char(X,'\t'); tx_int(X,ca->sbeg+a->abpos);
+          tx_name(X,na); tx_char(X,'\t'); tx_int(X,sa->slen); tx_char(X,'\t'); tx_int(X,ca->sbeg+a->abpos);
           tx_char(X,'\t'); tx_int(X,ca->sbeg+a->aepos);
         }
       else
-        { tx_str(X,na); tx_char(X,'\t'); tx_int(X,sa->slen); tx_char(X,'\t'); tx_int(X,ca->sbeg+a->abpos);
+        { tx_name(X,na); tx_char(X,'\t'); tx_int(X,sa->slen); tx_char(X,'\t'); tx_int(X,ca->sbeg+a->abpos);
           tx_char(X,'\t'); tx_int(X,ca->sbeg+a->aepos);
           tx_char(X,'\t'); tx_char(X,comp ? '-' : '+'); tx_char(X,'\t');
-          tx_str(X,nb); tx_char(X,'\t'); tx_int(X,sb->slen); tx_char(X,'\t'); tx_int(X,bs); tx_char(X,'\t'); tx_int(X,be);
+          tx_name(X,nb); tx_char(X,'\t'); tx_int(X,sb->slen); tx_char(X,'\t'); tx_int(X,bs); tx_char(X,'\t'); tx_int(X,be);
         }
 
       if (!bases)                     /* without base-level work the two counts are estimates (ALNtoPAF.c:596-621) */
@@ -656,9 +662,9 @@ static void *psl_thread(void *arg)
       tx_int(X,runB); tx_char(X,'\t'); tx_int(X,ngapB); tx_char(X,'\t');
       tx_int(X,runA); tx_char(X,'\t'); tx_int(X,ngapA); tx_char(X,'\t');
       tx_char(X,comp ? '-' : '+'); tx_char(X,'\t');
-      tx_str(X,na); tx_char(X,'\t'); tx_int(X,sa->slen); tx_char(X,'\t');
+      tx_name(X,na); tx_char(X,'\t'); tx_int(X,sa->slen); tx_char(X,'\t');
       tx_int(X,ca->sbeg+a.abpos); tx_char(X,'\t'); tx_int(X,ca->sbeg+a.aepos); tx_char(X,'\t');
-      tx_str(X,nb); tx_char(X,'\t'); tx_int(X,sb->slen); tx_char(X,'\t');
+      tx_name(X,nb); tx_char(X,'\t'); tx_int(X,sb->slen); tx_char(X,'\t');
       if (comp)
         { boff = cb->sbeg+cb->clen;
           tx_int(X,boff-a.bepos); tx_char(X,'\t'); tx_int(X,boff-a.bbpos);

@@ -164,6 +164,7 @@ def _declare(L):
         "fga_traces_free": (None, [P(Traces)]),
         "fga_write_paf": (i32, [cp, vp, vp, P(Alns), P(Traces), i32, i32]),
         "fga_write_psl": (i32, [cp, vp, vp, P(Alns), P(Traces), i32]),
+        "fga_read_1aln": (i32, [cp, P(P(Alns)), P(i32), P(cp), P(cp)]),
         "fga_gap_improve": (i32, [vp, vp, P(Alns), P(Traces)]),
         "fga_run": (i32, [cp, cp, P(RunParams), P(RunStats)]),
         "fga_session_open": (i32, [cp, cp, i32, P(vp)]),

@@ -1,0 +1,91 @@
+"""fga_read_1aln (host C): the reference's own binary .1aln files -- small ones with plain lists and a larger one whose
+T / X lists are Huffman-coded (ONElib trains a list code after ~100 KB of list data) -- must come back as exactly the
+records ONEview prints; our own binary and the db paths of the header likewise."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import harness as H
+from tests.test_aln_writer import _parse_records
+
+needs_ref = pytest.mark.skipif(not H.have_reference(), reason="oracle/_ref (real reference build) not present")
+
+
+def read_1aln(L, path):
+    from fastga_amd.lib import Alns
+    from fastga_amd.device import ALN_DTYPE
+    out = C.POINTER(Alns)()
+    ts = C.c_int()
+    d1, d2 = C.c_char_p(), C.c_char_p()
+    rc = L.fga_read_1aln(path.encode(), C.byref(out), C.byref(ts), C.byref(d1), C.byref(d2))
+    assert rc == 0, L.fga_last_error()
+    o = out.contents
+    a = np.frombuffer((C.c_char * (o.naln * ALN_DTYPE.itemsize)).from_address(o.alns), dtype=ALN_DTYPE).copy() \
+        if o.naln else np.zeros(0, ALN_DTYPE)
+    t = np.frombuffer((C.c_char * max(o.ntrace, 1)).from_address(o.tbytes), dtype=np.uint8)[:o.ntrace].copy()
+    L.fga_alns_free(out)
+    return a, t, ts.value, d1.value, d2.value
+
+
+def _same_records(a, t, alns, tb):
+    assert len(a) == len(alns) and np.array_equal(t, tb)
+    for f in ("tlen", "diffs", "abpos", "bbpos", "aepos", "bepos", "flags", "aread", "bread", "toff"):
+        assert np.array_equal(a[f], alns[f]), f
+
+
+@needs_ref
+@pytest.mark.parametrize("self_cmp", [False, True])
+def test_reads_reference_1aln(toy_pair, tmp_path, built_library, self_cmp):
+    d, ra, rb = toy_pair
+    w = str(tmp_path)
+    H.ref_fastga(ra, None if self_cmp else rb, w, os.path.join(w, "ref"), threads=4)
+    ref = os.path.join(w, "ref.1aln")
+    alns, tb = _parse_records(H.oneview(ref))
+    a, t, ts, d1, d2 = read_1aln(built_library, ref)
+    _same_records(a, t, alns, tb)
+    assert ts == 100 and os.path.basename(d1.decode()).startswith("A")
+    assert (d2 is None) == self_cmp
+    # our own binary writer's file reads back the same way
+    from fastga_amd.lib import Alns
+    from fastga_amd.gixio import Gdb
+    g1 = Gdb(ra + ".gdb")
+    g2 = None if self_cmp else Gdb(rb + ".gdb")
+    A = Alns(len(alns), len(tb), 0, 0, alns.ctypes.data, tb.ctypes.data)
+    ours = os.path.join(w, "ours.1aln")
+    assert built_library.fga_write_1aln_binary(ours.encode(), g1.h, g2.h if g2 else None, C.byref(A), 100,
+                                               (ra + ".gdb").encode(), None if self_cmp else (rb + ".gdb").encode(),
+                                               b"t") == 0
+    a2, t2, _, e1, e2 = read_1aln(built_library, ours)
+    _same_records(a2, t2, alns, tb)
+    assert e1.decode().endswith("A.gdb")
+
+
+@needs_ref
+def test_reads_compressed_lists(tmp_path, built_library):
+    from fastga_amd import workload
+    w = str(tmp_path)
+    ra, rb = workload.build_pair(w, seed=3, ncontig=8, total=12_000_000, divergence=0.03, inv_frac=0.02, threads=8)
+    H.ref_fastga(ra, rb, w, os.path.join(w, "ref"), threads=8)
+    ref = os.path.join(w, "ref.1aln")
+    raw = open(ref, "rb").read()
+    tbyte = 0x80 | ((ord("T") - 65) << 1) | 1
+    assert bytes([tbyte]) in raw                           # some T lines carry the compression flag
+    alns, tb = _parse_records(H.oneview(ref))
+    assert int(alns["tlen"].sum()) > 150_000
+    a, t, ts, d1, d2 = read_1aln(built_library, ref)
+    _same_records(a, t, alns, tb)
+
+
+def test_rejects_other_files(tmp_path, built_library, toy_pair):
+    from fastga_amd.lib import Alns
+    d, ra, rb = toy_pair
+    out = C.POINTER(Alns)()
+    L = built_library
+    p = os.path.join(str(tmp_path), "x.1aln")
+    open(p, "w").write("1 3 aln 2 1\n" + "A 0 0 10 0 0 10\nD 1\n" * 4)        # ASCII form: not a binary container
+    assert L.fga_read_1aln(p.encode(), C.byref(out), None, None, None) != 0
+    assert b"binary" in L.fga_last_error()
+    assert L.fga_read_1aln((ra + ".fa").encode(), C.byref(out), None, None, None) != 0
+    assert L.fga_read_1aln(b"/nonexistent.1aln", C.byref(out), None, None, None) != 0
