@@ -89,3 +89,29 @@ def test_rejects_other_files(tmp_path, built_library, toy_pair):
     assert b"binary" in L.fga_last_error()
     assert L.fga_read_1aln((ra + ".fa").encode(), C.byref(out), None, None, None) != 0
     assert L.fga_read_1aln(b"/nonexistent.1aln", C.byref(out), None, None, None) != 0
+
+
+def _tool(name):
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fastga_amd", "bin", name)
+
+
+@needs_ref
+def test_alntopaf_tool_plain_needs_no_gpu(toy_pair, tmp_path, built_library):
+    """our ALNtoPAF on the reference's own .1aln: plain PAF is host-only and equals the reference's; base-level output
+    asks for the device and, without one, fails loudly instead of falling back"""
+    import subprocess
+    d, ra, rb = toy_pair
+    w = str(tmp_path)
+    H.ref_fastga(ra, rb, w, os.path.join(w, "ref"), threads=4)
+    exp = H.run([H.ref_bin("ALNtoPAF"), "-T2", os.path.join(w, "ref.1aln")], cwd=w).stdout
+    r = subprocess.run([_tool("ALNtoPAF"), "-T3", "ref"], cwd=w, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == exp
+    exp = H.run([H.ref_bin("ALNtoPAF"), "-w", os.path.join(w, "ref.1aln")], cwd=w).stdout
+    assert subprocess.run([_tool("ALNtoPAF"), "-w", "ref.1aln"], cwd=w, capture_output=True, text=True).stdout == exp
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([_tool("ALNtoPAF"), "-x", "ref"], cwd=w, capture_output=True, text=True)
+        assert r.returncode != 0 and "no CPU fallback" in r.stderr and r.stdout == ""
+    r = subprocess.run([_tool("ALNtoPAF"), "-mx", "ref"], cwd=w, capture_output=True, text=True)
+    assert r.returncode != 0 and "Only one of -m or -x" in r.stderr

@@ -203,3 +203,26 @@ def test_cli_default_output_is_paf_on_stdout(toy_pair, tmp_path):
     r2 = subprocess.run([exe, ra, rb], cwd=w, capture_output=True, text=True)
     assert r2.returncode == 0 and len(r2.stdout.splitlines()) == len(lines)
     assert all("cg:Z:" not in ln for ln in r2.stdout.splitlines())
+
+
+def test_converter_tools_on_reference_files(toy_pair, tmp_path):
+    """bin/ALNtoPAF and bin/ALNtoPSL (fga_read_1aln -> fga_trace_pts -> writers) on a .1aln made by the REFERENCE FastGA:
+    byte-identical to the reference's converters, pair and self"""
+    import subprocess
+    from oracle import harness as H
+    if not H.have_reference():
+        pytest.skip("oracle/_ref did not travel")
+    d, ra, rb = toy_pair
+    w = str(tmp_path)
+    bindir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fastga_amd", "bin")
+    for tag, b in (("pair", rb), ("self", None)):
+        H.ref_fastga(ra, b, w, os.path.join(w, tag), threads=4)
+        aln = os.path.join(w, tag + ".1aln")
+        for opts in ("-x", "-mS", "-xsw"):
+            exp = H.run([H.ref_bin("ALNtoPAF"), "-T4", opts, aln], cwd=w).stdout
+            r = subprocess.run([os.path.join(bindir, "ALNtoPAF"), "-T4", opts, aln], cwd=w, capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+            assert r.stdout == exp, (tag, opts)
+        exp = H.run([H.ref_bin("ALNtoPSL"), "-T4", aln], cwd=w).stdout
+        r = subprocess.run([os.path.join(bindir, "ALNtoPSL"), "-T4", aln], cwd=w, capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout == exp, tag
