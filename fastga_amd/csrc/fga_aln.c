@@ -347,9 +347,132 @@ static void bb_bytes(bbuf *B, const void *src, size_t n)
   memcpy(B->p+B->len,src,n); B->len += n;
 }
 
-/* INT_LIST of n values v[0], v[stride], ...: length, first value, difference width, differences */
-static void bb_bytelist(bbuf *B, const uint8_t *v, int n, int stride)
+/* ---- list codes: ONElib compresses the difference bytes of long INT_LIST streams with a Huffman code per line type
+ *      (trained by the writer, stored in a ';' footer line, ONElib.c:2412-2506, 3305-3336, 3470-3575).  Here the code of
+ *      a line type is built from ALL its difference bytes (the whole set is in memory), limited to 16 bits, canonical. */
+typedef struct
+  { int      have;
+    uint8_t  len[256];
+    uint16_t bits[256];
+  } wcodec;
+
+static void wcodec_build(const uint64_t *hist, wcodec *C)
+{ uint64_t f[256];
+  int i, nsym = 0, maxlen;
+  memset(C,0,sizeof(*C));
+  for (i = 0; i < 256; i++)
+    { f[i] = hist[i];
+      nsym += (hist[i] > 0);
+    }
+  if (nsym == 0)
+    return;
+  do
+    { uint64_t w[512];
+      int parent[512], alive[512], n = 0, na, a, b;
+      for (i = 0; i < 256; i++)
+        if (f[i] > 0)
+          { w[n] = f[i]; parent[n] = -1; alive[n] = 1; n += 1; }
+      na = n;
+      while (na > 1)                               /* plain Huffman: join the two lightest live nodes */
+        { a = b = -1;
+          for (i = 0; i < n; i++)
+            if (alive[i])
+              { if (a < 0 || w[i] < w[a]) { b = a; a = i; }
+                else if (b < 0 || w[i] < w[b]) b = i;
+              }
+          w[n] = w[a]+w[b]; parent[n] = -1; alive[n] = 1;
+          parent[a] = parent[b] = n; alive[a] = alive[b] = 0;
+          n += 1; na -= 1;
+        }
+      maxlen = 0;
+      { int k = 0;
+        for (i = 0; i < 256; i++)
+          if (f[i] > 0)
+            { int l = 0, q = k++;
+              while (parent[q] >= 0) { q = parent[q]; l += 1; }
+              if (l == 0) l = 1;                   /* a single symbol still needs one bit */
+              C->len[i] = (uint8_t) (l > 255 ? 255 : l);
+              if (l > maxlen) maxlen = l;
+            }
+          else
+            C->len[i] = 0;
+      }
+      if (maxlen > 16)                             /* flatten the distribution and try again */
+        for (i = 0; i < 256; i++)
+          if (f[i] > 0) f[i] = (f[i] >> 1) + 1;
+    }
+  while (maxlen > 16);
+  { uint32_t code = 0;
+    int l;
+    for (l = 1; l <= 16; l++)                      /* canonical codes: by length, then by symbol */
+      { for (i = 0; i < 256; i++)
+          if (C->len[i] == l)
+            C->bits[i] = (uint16_t) code++;
+        code <<= 1;
+      }
+  }
+  C->have = 1;
+}
+
+/* the code in ONElib's serialised form (vcSerialize): endian byte, escape code (-1: none) and length, then per symbol
+ * its length and, if non-zero, its right-aligned code */
+static size_t wcodec_blob(const wcodec *C, uint8_t *out)
+{ uint8_t *o = out;
+  int esc = -1, esclen = 0, i;
+  *o++ = 0;
+  memcpy(o,&esc,4); o += 4;
+  memcpy(o,&esclen,4); o += 4;
+  for (i = 0; i < 256; i++)
+    { *o++ = C->len[i];
+      if (C->len[i] > 0)
+        { memcpy(o,C->bits+i,2); o += 2; }
+    }
+  return (size_t) (o-out);
+}
+
+/* n bytes -> code stream in ONElib's layout (vcEncode): two zero flag bits, codes most significant bit first, 64-bit
+ * words stored little endian, the last partial word byte by byte, bytes 0 and 7 exchanged once the stream has a full
+ * word.  Returns the bit count, or -1 when the stream would not be smaller than the n bytes. */
+static int64_t wcodec_encode(const wcodec *C, const uint8_t *in, int n, uint8_t *out)
+{ int64_t nbits = 2, w;
+  int i;
+  for (i = 0; i < n; i++)
+    { if (C->len[in[i]] == 0) return -1;
+      nbits += C->len[in[i]];
+    }
+  if (nbits >= 8*(int64_t) n)
+    return -1;
+  memset(out,0,(size_t) ((nbits+7) >> 3) + 8);
+  { int64_t pos = 2;
+    for (i = 0; i < n; i++)
+      { const int l = C->len[in[i]];
+        uint32_t c = (uint32_t) C->bits[in[i]] << (24-l);        /* code left-aligned in 24 bits */
+        const int sh = (int) (pos & 7);
+        uint8_t *o = out + (pos >> 3);
+        c >>= sh;                                                /* l <= 16, sh <= 7: fits 24 bits */
+        o[0] |= (uint8_t) (c >> 16); o[1] |= (uint8_t) (c >> 8); o[2] |= (uint8_t) c;
+        pos += l;
+      }
+  }
+  for (w = 0; (w+1)*64 <= nbits; w++)
+    { uint8_t *b = out + 8*w, t;
+      int k;
+      for (k = 0; k < 4; k++)
+        { t = b[k]; b[k] = b[7-k]; b[7-k] = t; }
+    }
+  if (nbits >= 64)
+    { uint8_t t = out[0]; out[0] = out[7]; out[7] = t; }
+  return nbits;
+}
+
+/* INT_LIST line of type t with the n values v[0], v[stride], ...: type byte (bit 0: compressed), length, first value,
+ * difference width, then the differences -- as they are, or as a code stream preceded by its bit count */
+static void bb_listline(bbuf *B, char t, const uint8_t *v, int n, int stride, const wcodec *C, uint8_t *tmp)
 { int i, w = 1;
+  size_t tpos;
+  bb_need(B,1); if (B->fail) return;
+  tpos = B->len;
+  B->p[B->len++] = TYPE_BYTE(t);
   bb_int(B,n);
   if (n <= 0) return;
   bb_int(B,v[0]);
@@ -357,6 +480,22 @@ static void bb_bytelist(bbuf *B, const uint8_t *v, int n, int stride)
   for (i = 1; i < n; i++)
     { int d = (int) v[i*stride] - (int) v[(i-1)*stride];
       if (d >= 128 || d < -128) { w = 2; break; }
+    }
+  if (w == 1 && C != NULL && C->have && n > 8)
+    { uint8_t *d = tmp, *e = tmp + n;
+      int64_t nbits;
+      for (i = 1; i < n; i++)
+        d[i-1] = (uint8_t) ((int) v[i*stride] - (int) v[(i-1)*stride]);
+      nbits = wcodec_encode(C,d,n-1,e);
+      if (nbits > 0)
+        { bb_need(B,12 + (size_t) ((nbits+7) >> 3)); if (B->fail) return;
+          B->p[tpos] |= 1;
+          B->p[B->len++] = 1;
+          B->len += ltf_put(B->p+B->len,nbits);
+          memcpy(B->p+B->len,e,(size_t) ((nbits+7) >> 3));
+          B->len += (size_t) ((nbits+7) >> 3);
+          return;
+        }
     }
   bb_need(B,1 + (size_t) (n-1)*w); if (B->fail) return;
   B->p[B->len++] = (uint8_t) w;
@@ -417,6 +556,8 @@ typedef struct
     int64_t i0, i1;
     bbuf    B;
     int64_t *rel;            /* start of record i relative to the job's buffer */
+    const wcodec *ct, *cx;   /* list codes of the T and X lines (NULL: none)     */
+    uint8_t *tmp;            /* 3 * (longest list) + 32 bytes                    */
   } bin_job;
 
 static void *bin_thread(void *arg)
@@ -433,8 +574,8 @@ static void *bin_thread(void *arg)
       if (a->flags & 1)
         bb_type(&J->B,'R');
       bb_type(&J->B,'D'); bb_int(&J->B,a->diffs);
-      bb_type(&J->B,'T'); bb_bytelist(&J->B,tr+1,a->tlen/2,2);
-      bb_type(&J->B,'X'); bb_bytelist(&J->B,tr,a->tlen/2,2);
+      bb_listline(&J->B,'T',tr+1,a->tlen/2,2,J->ct,J->tmp);
+      bb_listline(&J->B,'X',tr,a->tlen/2,2,J->cx,J->tmp);
     }
   return NULL;
 }
@@ -452,6 +593,7 @@ int fga_write_1aln_binary(const char *path, const fga_gdb *g1, const fga_gdb *g2
   int nth = 8, q, rc = 1;
   bin_job job[8];
   pthread_t th[8];
+  wcodec ct, cx;
 
   memset(&H,0,sizeof(H)); memset(&B,0,sizeof(B)); memset(&F,0,sizeof(F));
   memset(job,0,sizeof(job));
@@ -464,6 +606,31 @@ int fga_write_1aln_binary(const char *path, const fga_gdb *g1, const fga_gdb *g2
       if (A->alns[i].flags & 1) nR += 1;
       if (tl > maxT) maxT = tl;
       totT += tl;
+    }
+  /* list codes for the T and X lines, like the reference's files carry them once a type has > ~100 KB of list data.
+   * Opt-in (FGA_ALN_CODEC=1): training + encoding doubles the writer's time (it is inside the timed hot path) for a
+   * file 2.4x smaller; from 16 K trace points on, trained on all of the data */
+  memset(&ct,0,sizeof(ct)); memset(&cx,0,sizeof(cx));
+  if (totT >= 16384 && getenv("FGA_ALN_CODEC") != NULL && atoi(getenv("FGA_ALN_CODEC")) != 0)
+    { uint64_t ht[256], hx[256];
+      int64_t k;
+      memset(ht,0,sizeof(ht)); memset(hx,0,sizeof(hx));
+      for (i = 0; i < A->naln; i++)
+        { const uint8_t *tr = A->tbytes + A->alns[i].toff;
+          const int64_t n = A->alns[i].tlen/2;
+          int okt = 1, okx = 1;
+          for (k = 1; k < n && (okt || okx); k++)
+            { const int dt = (int) tr[2*k+1] - (int) tr[2*k-1], dx = (int) tr[2*k] - (int) tr[2*k-2];
+              if (dt >= 128 || dt < -128) okt = 0;
+              if (dx >= 128 || dx < -128) okx = 0;
+            }
+          for (k = 1; k < n; k++)
+            { if (okt) ht[(uint8_t) ((int) tr[2*k+1] - (int) tr[2*k-1])] += 1;
+              if (okx) hx[(uint8_t) ((int) tr[2*k] - (int) tr[2*k-2])] += 1;
+            }
+        }
+      wcodec_build(ht,&ct);
+      wcodec_build(hx,&cx);
     }
   nscaf = g1->nscaff + (g2 != NULL ? g2->nscaff : 0);
   goff = malloc(sizeof(int64_t)*4);
@@ -514,7 +681,9 @@ int fga_write_1aln_binary(const char *path, const fga_gdb *g1, const fga_gdb *g2
     { job[q].A = A;
       job[q].i0 = (A->naln*q)/nth; job[q].i1 = (A->naln*(q+1))/nth;
       job[q].rel = malloc(sizeof(int64_t)*(job[q].i1-job[q].i0+1));
-      if (job[q].rel == NULL) goto oom;
+      job[q].tmp = malloc((size_t) (3*maxT + 64));
+      job[q].ct = ct.have ? &ct : NULL; job[q].cx = cx.have ? &cx : NULL;
+      if (job[q].rel == NULL || job[q].tmp == NULL) goto oom;
     }
   for (q = 1; q < nth; q++)
     if (pthread_create(th+q,NULL,bin_thread,job+q) != 0)
@@ -566,6 +735,19 @@ int fga_write_1aln_binary(const char *path, const fga_gdb *g1, const fga_gdb *g2
       FPRINT("# X %lld\n",(long long) A->naln)
       if (maxT > 0) FPRINT("@ X %lld\n",(long long) maxT)
       if (totT > 0) FPRINT("+ X %lld\n",(long long) totT)
+      { const wcodec *cc[2] = { &ct, &cx };           /* ';' lines: CHAR line type, STRING serialised code */
+        int z;
+        for (z = 0; z < 2; z++)
+          if (cc[z]->have)
+            { uint8_t blob[1024];
+              const size_t bl = wcodec_blob(cc[z],blob);
+              bb_need(&F,2); if (F.fail) goto oom;
+              F.p[F.len++] = (uint8_t) (0x80 | (52 << 1));
+              F.p[F.len++] = (uint8_t) (z == 0 ? 'T' : 'X');
+              bb_int(&F,(int64_t) bl);
+              bb_bytes(&F,blob,bl);
+            }
+      }
     }
   FPRINT("^\n")
 #undef FPRINT
@@ -599,7 +781,7 @@ int fga_write_1aln_binary(const char *path, const fga_gdb *g1, const fga_gdb *g2
 oom:
   fga_set_error("out of memory");
 done:
-  for (q = 0; q < 8; q++) { free(job[q].B.p); free(job[q].rel); }
+  for (q = 0; q < 8; q++) { free(job[q].B.p); free(job[q].rel); free(job[q].tmp); }
   free(H.p); free(B.p); free(F.p);
   free(goff); free(soff); free(aoff);
   return rc;

@@ -76,6 +76,32 @@ def test_reads_compressed_lists(tmp_path, built_library):
     assert int(alns["tlen"].sum()) > 150_000
     a, t, ts, d1, d2 = read_1aln(built_library, ref)
     _same_records(a, t, alns, tb)
+    # our writer can train list codes too (FGA_ALN_CODEC=1): the reference's tools must read such a file like their own
+    from fastga_amd.lib import Alns
+    from fastga_amd.gixio import Gdb
+    g1, g2 = Gdb(ra + ".gdb"), Gdb(rb + ".gdb")
+    A = Alns(len(alns), len(tb), 0, 0, alns.ctypes.data, tb.ctypes.data)
+    sizes = {}
+    for name, env in (("coded", "1"), ("plain", None)):
+        if env:
+            os.environ["FGA_ALN_CODEC"] = env
+        try:
+            out = os.path.join(w, name + ".1aln")
+            assert built_library.fga_write_1aln_binary(out.encode(), g1.h, g2.h, C.byref(A), 100,
+                                                       (ra + ".gdb").encode(), (rb + ".gdb").encode(), b"t") == 0
+        finally:
+            os.environ.pop("FGA_ALN_CODEC", None)
+        sizes[name] = os.path.getsize(out)
+        keep = lambda lines: [ln for ln in lines if ln[0] not in "!<"]          # noqa: E731
+        assert keep(H.oneview(out)) == keep(H.oneview(ref)), name
+        a2, t2, _, _, _ = read_1aln(built_library, out)
+        _same_records(a2, t2, alns, tb)
+    coded = open(os.path.join(w, "coded.1aln"), "rb").read()
+    assert bytes([tbyte]) in coded and sizes["coded"] < 0.8 * sizes["plain"]
+    exp = H.run([H.ref_bin("ALNtoPAF"), "-T4", "-x", ref], cwd=w).stdout
+    got = H.run([H.ref_bin("ALNtoPAF"), "-T4", "-x", os.path.join(w, "coded.1aln")], cwd=w).stdout
+    assert got == exp
+    print("sizes", sizes, "reference", os.path.getsize(ref))
 
 
 def test_rejects_other_files(tmp_path, built_library, toy_pair):
