@@ -464,6 +464,135 @@ static char *join_path(const char *cwd, const char *p)
   return r;
 }
 
+/* a "$ <n>" line in the ASCII header marks the binary container */
+static int has_binary_marker(const uint8_t *buf, size_t size)
+{ const uint8_t *p = buf, *end = buf+size;
+  while (p < end && !(*p & 0x80))
+    { const uint8_t *e = memchr(p,'\n',(size_t) (end-p));
+      if (p[0] == '$' && p+1 < end && p[1] == ' ')
+        return 1;
+      if (e == NULL) break;
+      p = e+1;
+    }
+  return 0;
+}
+
+/* the text form of a .1aln: one line per ONEcode line, "<type> <fields...>", lists as "<n> v1 ... vn" */
+static int read_ascii_1aln(const char *txt, size_t size, const char *path, fga_alns **out, int *tspace,
+                           char **db1, char **db2)
+{ const char *p = txt, *end = txt+size;
+  fga_alns *R = calloc(1,sizeof(fga_alns));
+  int64_t acap = 0, tcap = 0, toff = 0;
+  fga_aln *cur = NULL;
+  char *ref[4] = { NULL, NULL, NULL, NULL };
+  int first = 1, rc = 1, i;
+
+  if (R == NULL) goto oom;
+  R->alns = malloc(sizeof(fga_aln)); R->tbytes = malloc(16);
+  if (R->alns == NULL || R->tbytes == NULL) goto oom;
+  while (p < end)
+    { const char *e = memchr(p,'\n',(size_t) (end-p));
+      const size_t n = e ? (size_t) (e-p) : (size_t) (end-p);
+      if (first)
+        { char ftype[16];
+          int major;
+          first = 0;
+          if (n > 200 || sscanf(p,"1 %d %15s",&major,ftype) != 2 || strcmp(ftype,"aln") != 0)
+            { fga_set_error("%s is neither a binary nor a text .1aln",path);
+              goto done;
+            }
+        }
+      else if (n >= 1)
+        switch (p[0])
+        { case 't':
+            if (tspace) *tspace = atoi(p+1);
+            break;
+          case '<':
+            { int len = 0, used = 0, num = 0;
+              if (sscanf(p+1," %d %n",&len,&used) >= 1 && (size_t) (1+used+len) <= n &&
+                  sscanf(p+1+used+len," %d",&num) == 1 && num >= 1 && num <= 3 && ref[num] == NULL)
+                ref[num] = strndup(p+1+used,(size_t) len);
+            }
+            break;
+          case 'A':
+            { long long v[6];
+              if (sscanf(p+1," %lld %lld %lld %lld %lld %lld",v,v+1,v+2,v+3,v+4,v+5) != 6)
+                { fga_set_error("%s: malformed A line",path);
+                  goto done;
+                }
+              if (R->naln >= acap)
+                { fga_aln *a;
+                  acap = 2*acap + 1024;
+                  a = realloc(R->alns,sizeof(fga_aln)*(size_t) acap);
+                  if (a == NULL) goto oom;
+                  R->alns = a;
+                }
+              cur = R->alns + R->naln++;
+              memset(cur,0,sizeof(*cur));
+              cur->aread = (int32_t) v[0]; cur->abpos = (int32_t) v[1]; cur->aepos = (int32_t) v[2];
+              cur->bread = (int32_t) v[3]; cur->bbpos = (int32_t) v[4]; cur->bepos = (int32_t) v[5];
+              cur->unit = -1; cur->seq = (int32_t) (R->naln-1); cur->toff = toff;
+            }
+            break;
+          case 'R':
+            if (cur) cur->flags |= 0x1;
+            break;
+          case 'D':
+            if (cur) cur->diffs = atoi(p+1);
+            break;
+          case 'T': case 'X':
+            if (cur != NULL)
+              { char *q;
+                long long cnt = strtoll(p+1,&q,10), k;
+                if (cnt < 0 || (p[0] == 'X' && 2*cnt != cur->tlen && cur->tlen != 0))
+                  { fga_set_error("%s: T and X lists of alignment %lld differ in length",path,(long long) R->naln);
+                    goto done;
+                  }
+                if (cur->tlen == 0)
+                  { if (toff + 2*cnt + 16 > tcap)
+                      { uint8_t *b;
+                        tcap = 2*(toff + 2*cnt) + 4096;
+                        b = realloc(R->tbytes,(size_t) tcap);
+                        if (b == NULL) goto oom;
+                        R->tbytes = b;
+                      }
+                    memset(R->tbytes+toff,0,(size_t) (2*cnt));
+                    cur->tlen = (int32_t) (2*cnt);
+                    toff += 2*cnt;
+                    R->ntrace = toff;
+                  }
+                for (k = 0; k < cnt; k++)
+                  { const long long val = strtoll(q,&q,10);
+                    R->tbytes[cur->toff + 2*k + (p[0] == 'T' ? 1 : 0)] = (uint8_t) val;
+                  }
+              }
+            break;
+          default:
+            break;
+        }
+      p += n + (e ? 1 : 0);
+    }
+  if (first)
+    { fga_set_error("%s is empty",path);
+      goto done;
+    }
+  if (db1) *db1 = join_path(ref[3],ref[1]);
+  if (db2) *db2 = join_path(ref[3],ref[2]);
+  rc = 0;
+  goto done;
+
+oom:
+  fga_set_error("out of memory reading %s",path);
+done:
+  for (i = 0; i < 4; i++) free(ref[i]);
+  if (rc != 0)
+    { fga_alns_free(R);
+      return 1;
+    }
+  *out = R;
+  return 0;
+}
+
 int fga_read_1aln(const char *path, fga_alns **out, int *tspace, char **db1, char **db2)
 { FILE *f = fopen(path,"rb");
   uint8_t *buf = NULL;
@@ -488,6 +617,12 @@ int fga_read_1aln(const char *path, fga_alns **out, int *tspace, char **db1, cha
       (buf = malloc((size_t) size)) == NULL || fread(buf,1,(size_t) size,f) != (size_t) size)
     { fga_set_error("cannot read %s",path);
       goto done;
+    }
+  if (!has_binary_marker(buf,(size_t) size))      /* the text form (ours with FGA_ALN_ASCII=1, or ONEview's output) */
+    { rc = read_ascii_1aln((const char *) buf,(size_t) size,path,out,tspace,db1,db2);
+      free(buf);
+      fclose(f);
+      return rc;
     }
   opened = 1;
   if (one_open(&F,buf,(size_t) size,path)) goto done;

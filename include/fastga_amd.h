@@ -253,7 +253,8 @@ enum { FGA_PAF_CIGAR_M = 1,    /* -m  cg:Z: with M                              
 int  fga_write_paf(const char *path, const fga_gdb *g1, const fga_gdb *g2 /* NULL: self */, const fga_alns *alns,
                    const fga_traces *traces /* NULL without CIGAR / cs */, int flags, int nthreads);
 /* ---- reading a .1aln back: replaces open_Aln_Read + Read_Aln_Overlap + Read_Aln_Trace (alncode.c:62-237) for a whole
- *      file -- the reference's own binary files (list codecs included) or ours.  db1 / db2 receive the GDB paths of the
+ *      file -- the reference's own binary files (list codecs included), ours, or the text form (ours, or what ONEview
+ *      prints; the reference's seeking readers refuse text).  db1 / db2 receive the GDB paths of the
  *      file's reference lines, resolved against its directory line (db2 NULL for a self comparison); free() them.
  *      With fga_trace_pts + fga_write_paf / fga_write_psl this is the in-process ALNtoPAF / ALNtoPSL
  *      (fastga_amd/bin/ALNtoPAF, ALNtoPSL). */

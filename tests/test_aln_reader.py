@@ -60,6 +60,17 @@ def test_reads_reference_1aln(toy_pair, tmp_path, built_library, self_cmp):
     a2, t2, _, e1, e2 = read_1aln(built_library, ours)
     _same_records(a2, t2, alns, tb)
     assert e1.decode().endswith("A.gdb")
+    # the text forms: our ASCII writer's file and what ONEview prints for the reference's file
+    txt = os.path.join(w, "ours.txt.1aln")
+    assert built_library.fga_write_1aln(txt.encode(), g1.h, g2.h if g2 else None, C.byref(A), 100,
+                                        (ra + ".gdb").encode(), None if self_cmp else (rb + ".gdb").encode(), b"t") == 0
+    a3, t3, ts3, f1, _ = read_1aln(built_library, txt)
+    _same_records(a3, t3, alns, tb)
+    assert ts3 == 100 and f1.decode().endswith("A.gdb")
+    view = os.path.join(w, "view.1aln")
+    open(view, "w").write(H.run([H.ref_bin("ONEview"), ref]).stdout)
+    a4, t4, _, _, _ = read_1aln(built_library, view)
+    _same_records(a4, t4, alns, tb)
 
 
 @needs_ref
@@ -110,9 +121,9 @@ def test_rejects_other_files(tmp_path, built_library, toy_pair):
     out = C.POINTER(Alns)()
     L = built_library
     p = os.path.join(str(tmp_path), "x.1aln")
-    open(p, "w").write("1 3 aln 2 1\n" + "A 0 0 10 0 0 10\nD 1\n" * 4)        # ASCII form: not a binary container
+    open(p, "w").write("1 3 seq 2 1\n" + "S 4 acgt\n" * 8)                    # another ONEcode file type
     assert L.fga_read_1aln(p.encode(), C.byref(out), None, None, None) != 0
-    assert b"binary" in L.fga_last_error()
+    assert b"neither" in L.fga_last_error()
     assert L.fga_read_1aln((ra + ".fa").encode(), C.byref(out), None, None, None) != 0
     assert L.fga_read_1aln(b"/nonexistent.1aln", C.byref(out), None, None, None) != 0
 
