@@ -58,10 +58,13 @@ int fga_one_codec_parse(fga_one_codec *c, const uint8_t *in, int64_t n)
     return 1;
   memcpy(&c->esc,in+1,4);
   memcpy(&c->esclen,in+5,4);
+  if (c->esc < -1 || c->esc > 255 || c->esclen < 0 || c->esclen > 16)      /* a code word is at most 16 bits */
+    return 1;
   q = in+9;
   for (i = 0; i < 256; i++)
     { if (q >= end) return 1;
       c->len[i] = *q++;
+      if (c->len[i] > 16) return 1;
       bits[i] = 0;
       if (c->len[i] > 0 || i == c->esc)
         { if (q+2 > end) return 1;
@@ -123,6 +126,10 @@ int64_t fga_one_codec_decode(const fga_one_codec *c, const uint8_t *in, int64_t 
       if (sym == c->esc)
         { uint32_t lit = 0;
           pos += c->esclen;
+          if (c->esclen <= 0 || pos + 8 > nbits)          /* the literal byte must lie inside the stream */
+            { free(canon);
+              return -1;
+            }
           for (k = 0; k < 2; k++)
             lit = (lit << 8) | canon[(pos >> 3) + k];
           sym = (int) ((lit >> (8 - (pos & 7))) & 0xff);
@@ -477,6 +484,25 @@ static int has_binary_marker(const uint8_t *buf, size_t size)
   return 0;
 }
 
+/* bounded number scanning for the text form: never looks beyond `e` (the buffer need not be NUL-terminated and a
+   line costs its own length -- glibc's sscanf would measure the whole rest of the buffer on every call) */
+static int scan_ll(const char **q, const char *e, long long *val)
+{ const char *p = *q;
+  int neg = 0, nd = 0;
+  unsigned long long v = 0;
+  while (p < e && (*p == ' ' || *p == '\t' || *p == '\r')) p++;
+  if (p < e && (*p == '-' || *p == '+')) neg = (*p++ == '-');
+  while (p < e && *p >= '0' && *p <= '9')
+    { if (v > (unsigned long long) 0x7fffffffffffffffLL/10 - 1) return 0;
+      v = 10*v + (unsigned) (*p++ - '0');
+      nd += 1;
+    }
+  if (nd == 0) return 0;
+  *val = neg ? -(long long) v : (long long) v;
+  *q = p;
+  return 1;
+}
+
 /* the text form of a .1aln: one line per ONEcode line, "<type> <fields...>", lists as "<n> v1 ... vn" */
 static int read_ascii_1aln(const char *txt, size_t size, const char *path, fga_alns **out, int *tspace,
                            char **db1, char **db2)
@@ -485,19 +511,22 @@ static int read_ascii_1aln(const char *txt, size_t size, const char *path, fga_a
   int64_t acap = 0, tcap = 0, toff = 0;
   fga_aln *cur = NULL;
   char *ref[4] = { NULL, NULL, NULL, NULL };
-  int first = 1, rc = 1, i;
+  int first = 1, rc = 1, i, have_t = 0, have_x = 0;
 
   if (R == NULL) goto oom;
   R->alns = malloc(sizeof(fga_aln)); R->tbytes = malloc(16);
   if (R->alns == NULL || R->tbytes == NULL) goto oom;
   while (p < end)
     { const char *e = memchr(p,'\n',(size_t) (end-p));
-      const size_t n = e ? (size_t) (e-p) : (size_t) (end-p);
+      const char *le = e ? e : end;                      /* end of this line */
+      const size_t n = (size_t) (le-p);
+      const char *q = p+1;
+      long long v[6];
       if (first)
-        { char ftype[16];
-          int major;
-          first = 0;
-          if (n > 200 || sscanf(p,"1 %d %15s",&major,ftype) != 2 || strcmp(ftype,"aln") != 0)
+        { first = 0;
+          q = p;
+          if (!(scan_ll(&q,le,v) && v[0] == 1 && scan_ll(&q,le,v+1) && le-q >= 4 && memcmp(q," aln",4) == 0 &&
+                (q+4 == le || q[4] == ' ' || q[4] == '\r')))
             { fga_set_error("%s is neither a binary nor a text .1aln",path);
               goto done;
             }
@@ -505,50 +534,58 @@ static int read_ascii_1aln(const char *txt, size_t size, const char *path, fga_a
       else if (n >= 1)
         switch (p[0])
         { case 't':
-            if (tspace) *tspace = atoi(p+1);
+            if (scan_ll(&q,le,v) && tspace) *tspace = (int) v[0];
             break;
-          case '<':
-            { int len = 0, used = 0, num = 0;
-              if (sscanf(p+1," %d %n",&len,&used) >= 1 && (size_t) (1+used+len) <= n &&
-                  sscanf(p+1+used+len," %d",&num) == 1 && num >= 1 && num <= 3 && ref[num] == NULL)
-                ref[num] = strndup(p+1+used,(size_t) len);
-            }
+          case '<':                                       /* "< <len> <string> <number>" */
+            if (scan_ll(&q,le,v) && v[0] >= 0 && q < le && (long long) (le-q-1) >= v[0])
+              { const char *s = q+1, *r = q+1+v[0];
+                if (scan_ll(&r,le,v+1) && v[1] >= 1 && v[1] <= 3 && ref[v[1]] == NULL)
+                  ref[v[1]] = strndup(s,(size_t) v[0]);
+              }
             break;
           case 'A':
-            { long long v[6];
-              if (sscanf(p+1," %lld %lld %lld %lld %lld %lld",v,v+1,v+2,v+3,v+4,v+5) != 6)
+            for (i = 0; i < 6; i++)
+              if (!scan_ll(&q,le,v+i))
                 { fga_set_error("%s: malformed A line",path);
                   goto done;
                 }
-              if (R->naln >= acap)
-                { fga_aln *a;
-                  acap = 2*acap + 1024;
-                  a = realloc(R->alns,sizeof(fga_aln)*(size_t) acap);
-                  if (a == NULL) goto oom;
-                  R->alns = a;
-                }
-              cur = R->alns + R->naln++;
-              memset(cur,0,sizeof(*cur));
-              cur->aread = (int32_t) v[0]; cur->abpos = (int32_t) v[1]; cur->aepos = (int32_t) v[2];
-              cur->bread = (int32_t) v[3]; cur->bbpos = (int32_t) v[4]; cur->bepos = (int32_t) v[5];
-              cur->unit = -1; cur->seq = (int32_t) (R->naln-1); cur->toff = toff;
-            }
+            if (R->naln >= acap)
+              { fga_aln *a;
+                acap = 2*acap + 1024;
+                a = realloc(R->alns,sizeof(fga_aln)*(size_t) acap);
+                if (a == NULL) goto oom;
+                R->alns = a;
+              }
+            cur = R->alns + R->naln++;
+            memset(cur,0,sizeof(*cur));
+            cur->aread = (int32_t) v[0]; cur->abpos = (int32_t) v[1]; cur->aepos = (int32_t) v[2];
+            cur->bread = (int32_t) v[3]; cur->bbpos = (int32_t) v[4]; cur->bepos = (int32_t) v[5];
+            cur->unit = -1; cur->seq = (int32_t) (R->naln-1); cur->toff = toff;
+            have_t = have_x = 0;
             break;
           case 'R':
             if (cur) cur->flags |= 0x1;
             break;
           case 'D':
-            if (cur) cur->diffs = atoi(p+1);
+            if (cur && scan_ll(&q,le,v)) cur->diffs = (int32_t) v[0];
             break;
           case 'T': case 'X':
             if (cur != NULL)
-              { char *q;
-                long long cnt = strtoll(p+1,&q,10), k;
-                if (cnt < 0 || (p[0] == 'X' && 2*cnt != cur->tlen && cur->tlen != 0))
+              { const int isT = (p[0] == 'T');
+                long long cnt, k;
+                if (!scan_ll(&q,le,&cnt) || cnt < 0 || cnt > 0x3fffffff)
+                  { fga_set_error("%s: malformed %c line of alignment %lld",path,p[0],(long long) R->naln);
+                    goto done;
+                  }
+                if (isT ? have_t : have_x)
+                  { fga_set_error("%s: alignment %lld has two %c lines",path,(long long) R->naln,p[0]);
+                    goto done;
+                  }
+                if ((have_t || have_x) && 2*cnt != cur->tlen)
                   { fga_set_error("%s: T and X lists of alignment %lld differ in length",path,(long long) R->naln);
                     goto done;
                   }
-                if (cur->tlen == 0)
+                if (!have_t && !have_x)
                   { if (toff + 2*cnt + 16 > tcap)
                       { uint8_t *b;
                         tcap = 2*(toff + 2*cnt) + 4096;
@@ -561,19 +598,34 @@ static int read_ascii_1aln(const char *txt, size_t size, const char *path, fga_a
                     toff += 2*cnt;
                     R->ntrace = toff;
                   }
+                if (isT) have_t = 1; else have_x = 1;
                 for (k = 0; k < cnt; k++)
-                  { const long long val = strtoll(q,&q,10);
-                    R->tbytes[cur->toff + 2*k + (p[0] == 'T' ? 1 : 0)] = (uint8_t) val;
+                  { long long val;
+                    if (!scan_ll(&q,le,&val))
+                      { fga_set_error("%s: a %c line of alignment %lld holds fewer than its %lld values",path,p[0],
+                                      (long long) R->naln,cnt);
+                        goto done;
+                      }
+                    if (val < 0 || val > 255)
+                      { fga_set_error("%s: trace value %lld of alignment %lld does not fit the 8-bit trace form",path,
+                                      val,(long long) R->naln);
+                        goto done;
+                      }
+                    R->tbytes[cur->toff + 2*k + (isT ? 1 : 0)] = (uint8_t) val;
                   }
               }
             break;
           default:
             break;
         }
-      p += n + (e ? 1 : 0);
+      p = le + (e ? 1 : 0);
     }
   if (first)
     { fga_set_error("%s is empty",path);
+      goto done;
+    }
+  if (tspace && *tspace > 125)
+    { fga_set_error("%s: trace spacing %d > 125 means 16-bit traces, which this reader does not hold",path,*tspace);
       goto done;
     }
   if (db1) *db1 = join_path(ref[3],ref[1]);
@@ -679,6 +731,16 @@ int fga_read_1aln(const char *path, fga_alns **out, int *tspace, char **db1, cha
             break;
           }
         { int64_t n = L.llen, i;
+          for (i = 0; i < n; i++)
+            if (L.list[i] < 0 || L.list[i] > 255)
+              { fga_set_error("%s: trace value %lld of alignment %lld does not fit the 8-bit trace form",path,
+                              (long long) L.list[i],(long long) R->naln);
+                goto done;
+              }
+          if (n > 0x3fffffff || (L.type == 'T' && have_t))
+            { fga_set_error("%s: malformed %c line of alignment %lld",path,L.type,(long long) R->naln);
+              goto done;
+            }
           if (L.type == 'T')
             { if (toff + 2*n + 16 > tcap)
                 { uint8_t *b;
@@ -691,9 +753,19 @@ int fga_read_1aln(const char *path, fga_alns **out, int *tspace, char **db1, cha
                 { R->tbytes[toff+2*i] = 0; R->tbytes[toff+2*i+1] = (uint8_t) L.list[i]; }
               cur->tlen = (int32_t) (2*n);
               have_t = 1;
+              if (xlen >= 0 && xlen != n)
+                { fga_set_error("%s: T and X lists of alignment %lld differ in length",path,(long long) R->naln);
+                  goto done;
+                }
               if (xlen == n)
                 for (i = 0; i < n; i++)
-                  R->tbytes[toff+2*i] = (uint8_t) xlist[i];
+                  { if (xlist[i] < 0 || xlist[i] > 255)
+                      { fga_set_error("%s: trace value %lld of alignment %lld does not fit the 8-bit trace form",path,
+                                      (long long) xlist[i],(long long) R->naln);
+                        goto done;
+                      }
+                    R->tbytes[toff+2*i] = (uint8_t) xlist[i];
+                  }
               toff += 2*n;
               R->ntrace = toff;
             }

@@ -380,7 +380,7 @@ typedef struct
 
 static void put_divergence(text *X, const fga_aln *a, int64_t iid)
 { const int64_t len = a->aepos-a->abpos;
-  const int64_t v = 10000 + (10000ll*(len-iid))/len;
+  const int64_t v = 10000 + (len > 0 ? (10000ll*(len-iid))/len : 0);      /* an empty A interval: dv 0 */
   tx_str(X,"\tdv:f:0.");
   tx_char(X,(char) ('0'+(v/1000)%10));
   tx_char(X,(char) ('0'+(v/100)%10));
@@ -701,6 +701,21 @@ done:
   return NULL;
 }
 
+/* every record must lie inside the contigs it names (the sets come from arbitrary .1aln files through bin/ALNtoPAF) */
+static int check_records(const char *who, const fga_gdb *g1, const fga_gdb *g2, const fga_alns *alns)
+{ int64_t i;
+  for (i = 0; i < alns->naln; i++)
+    { const fga_aln *a = alns->alns+i;
+      if (a->aread < 0 || a->aread >= g1->ncontig || a->bread < 0 || a->bread >= g2->ncontig ||
+          a->abpos < 0 || a->aepos < a->abpos || a->aepos > g1->contigs[a->aread].clen ||
+          a->bbpos < 0 || a->bepos < a->bbpos || a->bepos > g2->contigs[a->bread].clen)
+        { fga_set_error("%s: alignment %lld lies outside the contigs of the two genomes",who,(long long) i);
+          return 1;
+        }
+    }
+  return 0;
+}
+
 static int write_lines(const char *path, const fga_gdb *g1, const fga_gdb *g2, const fga_alns *alns,
                        const fga_traces *traces, int flags, int nthreads, int psl)
 { const int bases = psl || (flags & (FGA_PAF_CIGAR_M|FGA_PAF_CIGAR_X|FGA_PAF_CS_SHORT|FGA_PAF_CS_LONG)) != 0;
@@ -724,16 +739,8 @@ static int write_lines(const char *path, const fga_gdb *g1, const fga_gdb *g2, c
                     psl ? "fga_write_psl" : "fga_write_paf");
       return 1;
     }
-  for (i = 0; i < alns->naln; i++)
-    { const fga_aln *a = alns->alns+i;
-      if (a->aread < 0 || a->aread >= g1->ncontig || a->bread < 0 || a->bread >= g2->ncontig ||
-          a->abpos < 0 || a->aepos < a->abpos || a->aepos > g1->contigs[a->aread].clen ||
-          a->bbpos < 0 || a->bepos < a->bbpos || a->bepos > g2->contigs[a->bread].clen)
-        { fga_set_error("%s: alignment %lld lies outside the contigs of the two genomes",
-                        psl ? "fga_write_psl" : "fga_write_paf",(long long) i);
-          return 1;
-        }
-    }
+  if (check_records(psl ? "fga_write_psl" : "fga_write_paf",g1,g2,alns))
+    return 1;
   unpack_tables();
   if (nthreads < 1) nthreads = 1;
   if (nthreads > 64) nthreads = 64;
@@ -810,6 +817,8 @@ int fga_gap_improve(const fga_gdb *g1, const fga_gdb *g2, const fga_alns *alns, 
     { fga_set_error("fga_gap_improve: the edit scripts do not belong to this alignment set");
       return 1;
     }
+  if (check_records("fga_gap_improve",g1,g2,alns))
+    return 1;
   unpack_tables();
   abuf = malloc(g1->maxctg+4);
   if (abuf == NULL) goto oom;

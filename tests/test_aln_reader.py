@@ -152,3 +152,75 @@ def test_alntopaf_tool_plain_needs_no_gpu(toy_pair, tmp_path, built_library):
         assert r.returncode != 0 and "no CPU fallback" in r.stderr and r.stdout == ""
     r = subprocess.run([_tool("ALNtoPAF"), "-mx", "ref"], cwd=w, capture_output=True, text=True)
     assert r.returncode != 0 and "Only one of -m or -x" in r.stderr
+
+
+def _try_read(L, path):
+    from fastga_amd.lib import Alns
+    out = C.POINTER(Alns)()
+    ts = C.c_int()
+    rc = L.fga_read_1aln(path.encode(), C.byref(out), C.byref(ts), None, None)
+    if rc == 0:
+        n = out.contents.naln
+        L.fga_alns_free(out)
+        return 0, n
+    return rc, L.fga_last_error().decode()
+
+
+def test_text_form_is_parsed_within_its_bounds(tmp_path, built_library):
+    """the text reader never scans beyond a line (no trailing newline, short lists, duplicate or over-long T / X lines,
+    16-bit trace forms are errors, not overruns) and its cost is linear in the file size"""
+    import time
+    head = "1 3 aln 2 1\nt 100\n"
+    ok = head + "A 0 10 250 1 20 262\nD 3\nT 3 90 100 52\nX 3 1 1 1"           # no newline at the end
+    p = str(tmp_path / "a.1aln")
+    open(p, "w").write(ok)
+    assert _try_read(built_library, p) == (0, 1)
+    bad = {
+        "short": head + "A 0 10 250 1 20 262\nT 5 90 100\nA 1 0 100 1 0 100\n",
+        "twice": head + "A 0 10 250 1 20 262\nT 2 90 100\nT 4 1 2 3 4\n",
+        "longer": head + "A 0 10 250 1 20 262\nX 2 1 1\nT 3 90 100 52\n",
+        "wide": head + "A 0 10 250 1 20 262\nT 2 90 300\n",
+        "tspace": "1 3 aln 2 1\nt 200\nA 0 10 250 1 20 262\n",
+        "aline": head + "A 0 10 250 1\n",
+    }
+    for name, txt in bad.items():
+        q = str(tmp_path / (name + ".1aln"))
+        open(q, "w").write(txt)
+        rc, msg = _try_read(built_library, q)
+        assert rc != 0, name
+    # linear time: 200k alignments (about 9 MB of text) in well under a second per MB
+    big = [head]
+    for i in range(200_000):
+        big.append(f"A 0 {i} {i+300} 1 {i} {i+300}\nD 2\nT 3 100 100 100\nX 3 0 1 1\n")
+    q = str(tmp_path / "big.1aln")
+    open(q, "w").write("".join(big))
+    t = time.time()
+    assert _try_read(built_library, q) == (0, 200_000)
+    assert time.time() - t < 5.0
+
+
+def test_rejects_crafted_list_codes(built_library):
+    """a footer list code with an escape length outside [0,16] or a code length > 16 must be refused by the parser, and
+    a stream whose escape runs off its end by the decoder (reachable from .1aln and .1gdb files)"""
+    L = built_library
+    import struct
+    if not hasattr(L, "fga_one_codec_parse"):
+        pytest.skip("codec entry points are internal in this build")
+    # struct fga_one_codec { int have; int esc, esclen; uint8_t len[256]; uint8_t *look; } -- opaque here: a zeroed blob
+    codec = (C.c_uint8 * 4096)()
+    def ser(esc, esclen, lens):
+        b = bytes([0]) + struct.pack("<ii", esc, esclen)
+        for i, l in enumerate(lens):
+            b += bytes([l])
+            if l > 0 or i == esc:
+                b += struct.pack("<H", 0)
+        return b
+    lens = [0] * 256
+    L.fga_one_codec_parse.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    L.fga_one_codec_parse.restype = C.c_int
+    for esc, esclen, mod in ((3, -5, None), (3, 1 << 20, None), (300, 4, None), (3, 4, 40)):
+        ll = list(lens)
+        if mod is not None:
+            ll[7] = mod
+        blob = ser(esc, esclen, ll)
+        assert L.fga_one_codec_parse(codec, blob, len(blob)) != 0
