@@ -38,66 +38,64 @@ typedef struct
     int64_t ord;            /* discovery order */
   } rec;
 
-static int entwine(const rec *jp, const uint8_t *jtrace, const rec *kp, const uint8_t *ktrace, int *where)
-{ int ac, b2, y2, yp, ae;
-  int i, j, k;
-  int min;
+/* ---- how close two overlapping paths come, and whether they meet on a trace point ----------------------------------
+ *
+ * Restatement of what the reference's entwine (FastGA.c:2818-2941) computes, for `lo` starting at or before `hi` in A.
+ * Both traces are sampled on the common TSPACE grid of A.  Between two consecutive grid lines each path advances by one
+ * panel, so the signed B-separation (hi minus lo) is a running sum of per-panel deltas
+ *
+ *        sep(g+1) = sep(g) + ( hi.b[g] - lo.b[skip+g] ),        skip = panels of lo that lie before hi's first cell,
+ *
+ * framed by two interpolated samples: at hi's start (lo interpolated inside its current panel) and at the A coordinate
+ * where the first of the two ends (the other interpolated -- always over a full TSPACE, which is what the reference's
+ * arithmetic amounts to, its shorter-panel branch being unreachable).  The result is the separation of smallest
+ * magnitude with its sign, 0 as soon as the paths touch or change sides; *meet is the last interior grid line on which
+ * both paths pass through the same point (-1: none).
+ */
+static inline int nearer_zero(int best, int sep)
+{ if (best > 0)
+    return sep >= best ? best : (sep > 0 ? sep : 0);
+  if (best < 0)
+    return sep <= best ? best : (sep < 0 ? sep : 0);
+  return 0;
+}
 
-  *where = -1;
-  y2 = jp->bbpos;
-  b2 = kp->bbpos;
-  j  = jp->abpos/TSPACE;
-  k  = kp->abpos/TSPACE;
-  ac = k*TSPACE;
-  j = 1 + 2*(k-j);
-  k = 1;
-  for (i = 1; i < j; i += 2)
-    y2 += jtrace[i];
-  if (j == 1)
-    yp = y2 + (jtrace[j] * (kp->abpos - jp->abpos)) / (ac+TSPACE - jp->abpos);
+static inline int panel_b(const rec *r, int panel)      /* B length of a trace panel */
+{ return r->trace[2*panel+1]; }
+
+static int path_gap(const rec *lo, const rec *hi, int *meet)
+{ const int cell  = (hi->abpos/TSPACE)*TSPACE;                    /* grid line at or before hi's start           */
+  const int skip  = hi->abpos/TSPACE - lo->abpos/TSPACE;          /* lo's panels that end at or before `cell`    */
+  const int stop  = lo->aepos < hi->aepos ? lo->aepos : hi->aepos;
+  const int lines = stop > cell ? (stop-cell-1)/TSPACE : 0;       /* grid lines strictly inside (cell, stop)      */
+  int lob = lo->bbpos, hib = hi->bbpos;                           /* B coordinates of the two paths on the grid   */
+  int best, g, last;
+
+  for (g = 0; g < skip; g++)
+    lob += panel_b(lo,g);
+  /* first sample: at hi's start, lo interpolated within the panel it is in (its first panel may be a short one) */
+  { const int span = skip == 0 ? cell+TSPACE - lo->abpos : TSPACE;
+    const int from = skip == 0 ? lo->abpos : cell;
+    best = hib - (lob + (panel_b(lo,skip) * (hi->abpos - from)) / span);
+  }
+  *meet = -1;
+  for (g = 0; g < lines; g++)
+    { const int sep = (hib += panel_b(hi,g)) - (lob += panel_b(lo,skip+g));
+      best = nearer_zero(best,sep);
+      if (sep == 0)
+        *meet = cell + (g+1)*TSPACE;
+    }
+  /* last sample: where the first path ends; the other one is taken part of the way through its current panel */
+  last = cell + lines*TSPACE;
+  if (stop == lo->aepos)
+    { hib += (panel_b(hi,lines) * (stop-last)) / TSPACE;
+      lob  = lo->bepos;
+    }
   else
-    yp = y2 + (jtrace[j] * (kp->abpos - ac)) / TSPACE;
-
-  min = b2-yp;
-  ae = jp->aepos;
-  if (ae > kp->aepos)
-    ae = kp->aepos;
-
-  for (ac += TSPACE; ac < ae; ac += TSPACE)
-    { y2 += jtrace[j];
-      b2 += ktrace[k];
-      j += 2;
-      k += 2;
-      i = b2-y2;
-      if (min < 0 && min < i)
-        min = (i >= 0) ? 0 : i;
-      else if (min > 0 && min > i)
-        min = (i <= 0) ? 0 : i;
-      if (i == 0)
-        *where = ac;
+    { lob += (panel_b(lo,skip+lines) * (stop-last)) / TSPACE;
+      hib  = hi->bepos;
     }
-
-  ac -= TSPACE;
-  if (ae == jp->aepos)
-    { y2 = jp->bepos;
-      if (kp->aepos >= ac)
-        b2 += (ktrace[k] * (ae - ac)) / TSPACE;
-      else
-        b2 += (ktrace[k] * (ae - ac)) / (kp->aepos - ac);
-    }
-  else
-    { b2 = kp->bepos;
-      if (jp->aepos >= ac)
-        y2 += (jtrace[j] * (ae - ac)) / TSPACE;
-      else
-        y2 += (jtrace[j] * (ae - ac)) / (jp->aepos - ac);
-    }
-  i = b2-y2;
-  if (min < 0 && min < i)
-    min = (i >= 0) ? 0 : i;
-  else if (min > 0 && min > i)
-    min = (i <= 0) ? 0 : i;
-  return min;
+  return nearer_zero(best,hib-lob);
 }
 
 static int by_abpos(const void *l, const void *r)
@@ -121,101 +119,91 @@ static int by_discovery(const void *l, const void *r)
   return a->seq - b->seq;
 }
 
-/* filter one contig pair / strand: perm[0..n) sorted by abpos */
-static int filter_segment(rec **perm, int n)
-{ int j, k, where, dist;
+/* ---- the elimination rules (FastGA.c:3440-3585) as predicates over a pair (lo, hi), lo.abpos <= hi.abpos ---------- */
+enum { KEEP_BOTH = 0, DROP_HI, DROP_LO };
 
-  for (j = n-1; j >= 0; j--)
-    { rec *o = perm[j];
-      for (k = j+1; k < n; k++)
-        { rec *w = perm[k];
-          if (o->aepos <= w->abpos)
-            break;
-          if (w->flags & ELIMINATED)
-            continue;
-          if (o->abpos == w->abpos && o->bbpos == w->bbpos)
-            { if (o->aepos == w->aepos && o->bepos == w->bepos)
-                { if (o->diffs < w->aepos)
-                    { w->flags |= ELIMINATED; continue; }
-                  else
-                    { o->flags |= ELIMINATED; break; }
-                }
-              else
-                { if (o->aepos > w->aepos)
-                    { w->flags |= ELIMINATED; continue; }
-                  else
-                    { o->flags |= ELIMINATED; break; }
-                }
-            }
-          else if (o->aepos == w->aepos && o->bepos == w->bepos)
-            { if (o->abpos < w->abpos)
-                { w->flags |= ELIMINATED; continue; }
-              else
-                { o->flags |= ELIMINATED; break; }
-            }
-        }
-    }
+/* rule set 1: two records that share an end point.  Same start: the one reaching further in A stays (same box: the
+ * reference compares lo's diffs with hi's aepos -- FastGA.c:3456 -- kept as it is); same end: the earlier start stays. */
+static int shared_endpoint_rule(const rec *lo, const rec *hi)
+{ const int same_start = lo->abpos == hi->abpos && lo->bbpos == hi->bbpos;
+  const int same_end   = lo->aepos == hi->aepos && lo->bepos == hi->bepos;
+  if (same_start)
+    return ((same_end ? lo->diffs < hi->aepos : lo->aepos > hi->aepos)) ? DROP_HI : DROP_LO;
+  if (same_end)
+    return lo->abpos < hi->abpos ? DROP_HI : DROP_LO;
+  return KEEP_BOTH;
+}
 
-  for (j = n-1; j >= 0; j--)
-    { rec *o = perm[j];
-      if (o->flags & ELIMINATED)
-        continue;
-      for (k = j+1; k < n; k++)
-        { rec *w = perm[k];
-          if (o->aepos <= w->abpos)
-            break;
-          if (w->flags & ELIMINATED)
-            continue;
-          if (o->bepos <= w->bbpos || o->bbpos >= w->bepos)
-            continue;
-          dist = entwine(o,o->trace,w,w->trace,&where);
-          if (where != -1)
-            { int ocut = 2 * (((where-o->abpos)-1)/TSPACE+1);
-              int wcut = 2 * (((where-w->abpos)-1)/TSPACE+1);
-              int ntlen = ocut + (w->tlen-wcut);
-              uint8_t *nt = malloc(ntlen > 0 ? ntlen : 1);
-              int d = 0, h = 0, g;
-              if (nt == NULL)
-                return 1;
-              for (g = 0; g < ocut; g += 2)
-                { d += (nt[h] = o->trace[g]);
-                  nt[h+1] = o->trace[g+1];
-                  h += 2;
-                }
-              for (g = wcut; g < w->tlen; g += 2)
-                { d += (nt[h] = w->trace[g]);
-                  nt[h+1] = w->trace[g+1];
-                  h += 2;
-                }
-              if (o->owns) free(o->trace);
-              if (w->owns) { free(w->trace); w->owns = 0; w->trace = NULL; }
-              o->tlen  = ntlen;
-              o->diffs = d;
-              o->aepos = w->aepos;
-              o->bepos = w->bepos;
-              w->flags |= ELIMINATED;
-              o->owns  = 1;
-              o->trace = nt;
+/* rule set 2, for paths that stay apart: a record whose box lies inside the other's box grown by BOX_FUZZ goes; the
+ * candidate is hi unless it is the longer of the two by more than the fuzz */
+static int inside(const rec *in, const rec *box, int test_start)
+{ return in->aepos <= box->aepos+BOX_FUZZ && in->bbpos >= box->bbpos-BOX_FUZZ && in->bepos <= box->bepos+BOX_FUZZ &&
+         (!test_start || in->abpos >= box->abpos-BOX_FUZZ);
+}
+
+static int containment_rule(const rec *lo, const rec *hi)
+{ if ((lo->aepos - lo->abpos) + BOX_FUZZ >= hi->aepos - hi->abpos)
+    return inside(hi,lo,0) ? DROP_HI : KEEP_BOTH;       /* hi starts at or after lo: its start needs no test */
+  return inside(lo,hi,1) ? DROP_LO : KEEP_BOTH;
+}
+
+/* lo and hi pass through the trace point at A = meet: lo continues along hi from there and hi goes */
+static int fuse_at(rec *lo, rec *hi, int meet)
+{ const int keep = 2 * ((meet - lo->abpos + TSPACE-1)/TSPACE);      /* bytes of lo's trace up to the meeting point  */
+  const int from = 2 * ((meet - hi->abpos + TSPACE-1)/TSPACE);      /* first byte of hi's trace after it             */
+  const int tlen = keep + (hi->tlen - from);
+  uint8_t *t = malloc(tlen > 0 ? tlen : 1);
+  int g, diffs = 0;
+  if (t == NULL)
+    return 1;
+  memcpy(t,lo->trace,keep);
+  memcpy(t+keep,hi->trace+from,hi->tlen-from);
+  for (g = 0; g < tlen; g += 2)
+    diffs += t[g];
+  if (lo->owns) free(lo->trace);
+  if (hi->owns) { free(hi->trace); hi->owns = 0; hi->trace = NULL; }
+  lo->trace = t; lo->owns = 1;
+  lo->tlen = tlen; lo->diffs = diffs;
+  lo->aepos = hi->aepos; lo->bepos = hi->bepos;
+  hi->flags |= ELIMINATED;
+  return 0;
+}
+
+/* One contig pair and strand, seg[0..n) in abpos order.  Both sweeps take the records from the last to the first and
+ * pair each with its live successors while their A intervals overlap; dropping the earlier record of a pair ends its
+ * turn in the first sweep only (the reference's loops do the same). */
+static int filter_segment(rec **seg, int n)
+{ int sweep, at, nx;
+  for (sweep = 0; sweep < 2; sweep++)
+    for (at = n-1; at >= 0; at--)
+      { rec *lo = seg[at];
+        if (sweep == 1 && (lo->flags & ELIMINATED))
+          continue;
+        for (nx = at+1; nx < n && seg[nx]->abpos < lo->aepos; nx++)
+          { rec *hi = seg[nx];
+            int verdict, meet;
+            if (hi->flags & ELIMINATED)
               continue;
-            }
-          if (dist != 0)
-            { if ((o->aepos - o->abpos) + BOX_FUZZ >= w->aepos - w->abpos)
-                { if (w->aepos <= o->aepos+BOX_FUZZ && w->bbpos >= o->bbpos-BOX_FUZZ &&
-                      w->bepos <= o->bepos+BOX_FUZZ)
-                    { w->flags |= ELIMINATED;
-                      continue;
-                    }
-                }
-              else
-                { if (o->aepos <= w->aepos+BOX_FUZZ && o->bbpos >= w->bbpos-BOX_FUZZ &&
-                      o->bepos <= w->bepos+BOX_FUZZ && o->abpos >= w->abpos-BOX_FUZZ)
-                    { o->flags |= ELIMINATED;
-                      continue;
-                    }
-                }
-            }
-        }
-    }
+            if (sweep == 0)
+              verdict = shared_endpoint_rule(lo,hi);
+            else
+              { if (lo->bepos <= hi->bbpos || lo->bbpos >= hi->bepos)        /* disjoint in B */
+                  continue;
+                verdict = KEEP_BOTH;
+                if (path_gap(lo,hi,&meet) != 0 && meet < 0)
+                  verdict = containment_rule(lo,hi);
+                if (meet >= 0 && fuse_at(lo,hi,meet))
+                  return 1;
+              }
+            if (verdict == DROP_HI)
+              hi->flags |= ELIMINATED;
+            else if (verdict == DROP_LO)
+              { lo->flags |= ELIMINATED;
+                if (sweep == 0)
+                  break;
+              }
+          }
+      }
   return 0;
 }
 
