@@ -84,6 +84,74 @@ typedef struct
     int           status;
   } targ;
 
+/* The chains of one unit: bucket run [b,m) (diag>>6 = d, side 1) and, if any, run [m,e) (d+1, side 2).
+ *
+ * Closed form of the reference's scan (FastGA.c:3086-3176, 3353-3368; the same form fga_chain.hip evaluates with wave
+ * scans).  Take the records of both runs in anti-diagonal order, run d first on ties.  With
+ *     top(i)   = anti(i) + 2 lcp(i)                 reach(i) = max top(j), j < i        (-CHAIN_BREAK before the first)
+ * record i OPENS a chain iff anti(i) >= reach(i) + CHAIN_BREAK (reach is a plain prefix maximum: a chain's first top
+ * already exceeds everything before it), otherwise it extends the open one and adds max(0, top(i) - max(reach(i),anti(i)))
+ * to its coverage.  A chain is reported when the next one opens or the unit ends, if its coverage reaches CHAIN_MIN
+ * and it is not a pure run-d chain already seen as the d+1 half of the previous unit (sides == 1 && !isnew).
+ */
+typedef struct
+  { int64_t alow, reach, cov;
+    int     dgmin, dgmax, sides, open;
+  } chain_acc;
+
+static int chain_close(targ *T, const chain_acc *C, const fga_unit *U, int isnew)
+{ const fga_chain_params *P = T->prm;
+  fga_hit H;
+  int64_t dlo, dhi, alo = C->alow, ahi = C->reach;
+  if (!C->open || C->cov < P->chain_min || (C->sides == 1 && !isnew))
+    return 0;
+  dlo = C->dgmin + (U->bucket << BUCK_SHIFT);
+  dhi = C->dgmax + (U->bucket << BUCK_SHIFT);
+  if (U->comp)                         /* back to contig coordinates (FastGA.c:3205-3216) */
+    { const int64_t alen = P->alen[U->actg];
+      dlo += alen - (P->amxpos + P->bmxpos); dhi += alen - (P->amxpos + P->bmxpos);
+      alo += alen - P->amxpos;               ahi += alen - P->amxpos;
+    }
+  else
+    { dlo -= P->bmxpos; dhi -= P->bmxpos; }
+  H.dgmin = (int32_t) dlo; H.dgmax = (int32_t) dhi;
+  H.alow = alo; H.ahgh = ahi;
+  H.cov = (int32_t) C->cov; H.pad = 0;
+  return push_hit(&T->out,&H);
+}
+
+static int unit_chains(targ *T, int64_t b, int64_t m, int64_t e, const fga_unit *U, int isnew)
+{ const key128 *K = T->keys;
+  const layout *L = &T->L;
+  const int64_t gap = T->prm->chain_break;
+  int64_t s = b, t = m;
+  chain_acc C;
+  memset(&C,0,sizeof(C));
+  C.reach = -gap;
+  while (s < m || t < e)
+    { /* next record of the anti-diagonal merge */
+      const int from2 = (s >= m) || (t < e && field(K+t,L->s_anti,L->wt) < field(K+s,L->s_anti,L->wt));
+      const int64_t x = from2 ? t++ : s++;
+      const int64_t anti = (int64_t) field(K+x,L->s_anti,L->wt);
+      const int64_t span = 2 * (int64_t) field(K+x,0,6);
+      const int     dg   = (int) field(K+x,6,6) + (from2 ? BUCK_WIDTH : 0);
+      if (anti >= C.reach + gap)
+        { if (chain_close(T,&C,U,isnew)) return 1;
+          C.open = 1; C.alow = anti; C.cov = span; C.reach = anti + span;
+          C.sides = from2 ? 2 : 1; C.dgmin = C.dgmax = dg;
+        }
+      else
+        { const int64_t top = anti + span, floor_ = C.reach > anti ? C.reach : anti;
+          if (top > floor_) C.cov += top - floor_;
+          if (top > C.reach) C.reach = top;
+          C.sides |= from2 ? 2 : 1;
+          if (dg < C.dgmin) C.dgmin = dg;
+          if (dg > C.dgmax) C.dgmax = dg;
+        }
+    }
+  return chain_close(T,&C,U,isnew);
+}
+
 /* Scan the units whose first bucket starts inside [c0,c1).  Units are independent: a unit is the bucket run d
  * starting at a "bucket head" plus the directly following run when it is bucket d+1 of the same segment (aux);
  * `isnew` only needs to know whether the run just before the head is bucket d-1 of the same segment.  So any
@@ -127,96 +195,16 @@ static int scan_range(targ *T, int64_t c0, int64_t c1)
       isnew = !(b > 0 && SAMEBK(b-1,sid,cdiag-1));
 
       if (isnew || aux)
-        { const int comp = (int) field(K+b,L->s_strand,1);
-          const int actg = (int) field(K+b,L->s_a,L->wa);
-          const int bctg = (int) field(K+b,L->s_b,L->wb);
-          const int64_t alen = P->alen[actg];
-          const int64_t doffset = alen - (P->amxpos + P->bmxpos);
-          const int64_t aoffset = alen - P->amxpos;
-          int64_t s = b, t = m;
-          int64_t ipost = ANTI(s);
-          int64_t apost = aux ? ANTI(t) : INT64_MAX;
-          int64_t ahgh = -CHAIN_BREAK, alow = (apost < ipost) ? apost : ipost, anti;
-          int64_t cov = 0;
-          int     dgmin = 2*BUCK_WIDTH, dgmax = 0, dg, lcp, wch, mix = 0, go = 1;
-          fga_unit U;
-          int64_t  first = T->out.nhit;
-
-          while (go)
-            { if (apost < ipost)
-                { lcp  = LCP(t);
-                  dg   = DREM(t) + BUCK_WIDTH;
-                  anti = apost;
-                  t += 1;
-                  apost = (t >= e) ? INT64_MAX : ANTI(t);
-                  wch = 0x2;
-                }
-              else
-                { anti = ipost;
-                  if (s < m)
-                    { lcp = LCP(s);
-                      dg  = DREM(s);
-                    }
-                  else
-                    lcp = dg = 0;            /* flush step: the values are never used (go becomes 0) */
-                  s += 1;
-                  if (s >= m)
-                    { if (s > m)
-                        go = 0;
-                      else
-                        ipost = INT64_MAX;
-                    }
-                  else
-                    ipost = ANTI(s);
-                  wch = 0x1;
-                }
-              lcp <<= 1;
-
-              if (anti < ahgh + CHAIN_BREAK)
-                { int64_t cps = anti + lcp;
-                  if (cps > ahgh)
-                    { if (anti >= ahgh)
-                        cov += lcp;
-                      else
-                        cov += cps-ahgh;
-                      ahgh = cps;
-                    }
-                  mix |= wch;
-                  if (dg < dgmin)
-                    dgmin = dg;
-                  else if (dg > dgmax)
-                    dgmax = dg;
-                }
-              else
-                { if (cov >= CHAIN_MIN && (mix != 1 || isnew))
-                    { fga_hit H;
-                      int64_t gmin = dgmin + (cdiag << BUCK_SHIFT);
-                      int64_t gmax = dgmax + (cdiag << BUCK_SHIFT);
-                      int64_t lo_ = alow, hi_ = ahgh;
-                      if (comp)
-                        { gmin += doffset; gmax += doffset;
-                          lo_  += aoffset; hi_  += aoffset;
-                        }
-                      else
-                        { gmin -= P->bmxpos; gmax -= P->bmxpos; }
-                      H.dgmin = (int32_t) gmin; H.dgmax = (int32_t) gmax;
-                      H.alow = lo_; H.ahgh = hi_;
-                      H.cov = (int32_t) cov; H.pad = 0;
-                      if (push_hit(&T->out,&H)) return 1;
-                    }
-                  if (go)
-                    { cov  = lcp;
-                      ahgh = anti + lcp;
-                      mix  = wch;
-                      alow = anti;
-                      dgmin = dgmax = dg;
-                    }
-                }
-            }
+        { fga_unit U;
+          const int64_t first = T->out.nhit;
+          U.comp = (int) field(K+b,L->s_strand,1);
+          U.actg = (int) field(K+b,L->s_a,L->wa);
+          U.bctg = (int) field(K+b,L->s_b,L->wb);
+          U.bucket = cdiag;
+          if (unit_chains(T,b,m,e,&U,isnew)) return 1;
           if (T->out.nhit > first)
-            { U.actg = actg; U.bctg = bctg; U.comp = comp; U.nhits = (int32_t) (T->out.nhit - first);
+            { U.nhits = (int32_t) (T->out.nhit - first);
               U.first_hit = first;
-              U.bucket = cdiag;
               if (push_unit(&T->out,&U)) return 1;
             }
         }

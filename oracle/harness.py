@@ -303,3 +303,127 @@ def oracle_gap_improver(abuf, bbuf, path, trace, diffs, selfie=False):
     if st != 0:
         raise RuntimeError("oracle_gap_improver failed")
     return d.value, t
+
+
+# ------------------------------------------------------------------ chain scan: oracle port and the reference's hit boxes
+
+def ref_hit_boxes(a, b, workdir, threads=4, flags=()):
+    """Run the DEBUG_HIT build of the reference (oracle/_ref/FastGA_hits, oracle/Makefile) and parse what it prints per
+    chain that passes the coverage test (FastGA.c:3165-3225): rows (ctg1, ctg2, bucket, aux, cov, dgmin, dgmax, alow,
+    ahgh) with ctg1/ctg2 the ORIGINAL contig indices, in print order (N pass before C pass inside every A part)."""
+    import re
+    exe = ref_bin("FastGA_hits")
+    cmd = [exe, "-k", f"-T{threads}", f"-P{workdir}", "-1:" + os.path.join(workdir, "_hits_out"), *flags, a]
+    if b is not None:
+        cmd.append(b)
+    r = run(cmd, cwd=workdir)
+    rows, c1, c2, cur = [], -1, -1, None
+    pc = re.compile(r"^\s+Contig (\d+) vs Contig (\d+)")
+    ph = re.compile(r"^Hit on bucket (-?\d+)(\+1)? Coverage = (-?\d+)")
+    pb = re.compile(r"^\s+Box:\s+Diag = (-?\d+):(-?\d+)\s+Anti = (-?\d+):(-?\d+):(-?\d+)")
+    for ln in r.stdout.splitlines():
+        m = pc.match(ln)
+        if m:
+            c1, c2 = int(m.group(1)), int(m.group(2))
+            continue
+        m = ph.match(ln)
+        if m:
+            cur = (int(m.group(1)), 1 if m.group(2) else 0, int(m.group(3)))
+            continue
+        m = pb.match(ln)
+        if m and cur is not None:
+            rows.append((c1, c2, cur[0], cur[1], cur[2], int(m.group(1)), int(m.group(2)), int(m.group(3)),
+                         int(m.group(5))))
+            cur = None
+    return rows
+
+
+def records_from_seed_bytes(nbytes, cbytes, ipost, icont, jpost, jcont, amxpos, bmxpos):
+    """The reference's seed temp records (FastGA.c:961-966) -> the fields of its sort record (reimport_thread,
+    FastGA.c:2703-2721) in its sort order (rmsd_sort: jcont, diag>>6, anti, diag&63, lcp inside an A contig; A contigs
+    and the two strands are separate panels): dict of int64 arrays strand, actg, bctg, bucket, anti, drem, lcp."""
+    w = 1 + ipost + icont + jpost + jcont
+    cols = {k: [] for k in ("strand", "actg", "bctg", "bucket", "anti", "drem", "lcp")}
+    for comp, buf in ((0, nbytes), (1, cbytes)):
+        a = np.frombuffer(buf, dtype=np.uint8).reshape(-1, w).astype(np.int64)
+
+        def le(c0, nb):
+            v = np.zeros(len(a), dtype=np.int64)
+            for k in range(nb):
+                v |= a[:, c0 + k] << (8 * k)
+            return v
+        lcp = a[:, 0]
+        i = le(1, ipost)
+        actg = le(1 + ipost, icont)
+        j = le(1 + ipost + icont, jpost)
+        bc = le(1 + ipost + icont + jpost, jcont)
+        bctg = bc & ((1 << (8 * jcont - 1)) - 1)              # bit 7 of the last byte is the B entry's own sign
+        if comp:
+            diag = (amxpos + bmxpos) - (i + j)
+            anti = amxpos - (i - j)
+        else:
+            diag = bmxpos + (i - j)
+            anti = i + j
+        for k, v in (("strand", np.full(len(a), comp, dtype=np.int64)), ("actg", actg), ("bctg", bctg),
+                     ("bucket", diag >> 6), ("anti", anti), ("drem", diag & 63), ("lcp", lcp)):
+            cols[k].append(v)
+    f = {k: np.concatenate(v) for k, v in cols.items()}
+    order = np.lexsort((f["lcp"], f["drem"], f["anti"], f["bucket"], f["bctg"], f["actg"], f["strand"]))
+    return {k: np.ascontiguousarray(v[order]) for k, v in f.items()}
+
+
+def oracle_chain_scan(f, chain_break, chain_min, amxpos, bmxpos, alen_sorted):
+    """oracle/chain_oracle.c over sorted record fields (records_from_seed_bytes / decoded device keys).  Returns an
+    int64 array of rows (strand, actg, bctg, bucket, aux, cov, dgmin, dgmax, alow, ahgh), contig indices SORTED."""
+    L = oracle_lib()
+    n = len(f["anti"])
+    arrs = [np.ascontiguousarray(f[k], dtype=np.int64) for k in ("strand", "actg", "bctg", "bucket", "anti", "drem",
+                                                                  "lcp")]
+    al = np.ascontiguousarray(alen_sorted, dtype=np.int64)
+    out = C.POINTER(C.c_int64)()
+    L.oracle_chain_scan.restype = C.c_int64
+    nh = L.oracle_chain_scan(C.c_int64(n), *[x.ctypes.data_as(C.c_void_p) for x in arrs], C.c_int64(chain_break),
+                             C.c_int64(chain_min), C.c_int64(amxpos), C.c_int64(bmxpos),
+                             al.ctypes.data_as(C.c_void_p), C.byref(out))
+    if nh < 0:
+        raise MemoryError("oracle_chain_scan")
+    rows = np.ctypeslib.as_array(out, shape=(max(nh, 1), 10))[:nh].copy() if nh else np.zeros((0, 10), np.int64)
+    L.oracle_chain_free(out)
+    return rows
+
+
+def pack_keys(f, wa, wb, wd, wt):
+    """sorted record fields -> the 128-bit keys of fga_seed_sort (lo64, hi64), LSB first: lcp(6) drem(6) anti(wt)
+    bucket(wd) bctg(wb) actg(wa) strand(1)"""
+    n = len(f["anti"])
+    lo = np.zeros(n, dtype=np.uint64)
+    hi = np.zeros(n, dtype=np.uint64)
+    sh = 0
+    for name, w in (("lcp", 6), ("drem", 6), ("anti", wt), ("bucket", wd), ("bctg", wb), ("actg", wa), ("strand", 1)):
+        v = f[name].astype(np.uint64)
+        if sh < 64:
+            lo |= (v << np.uint64(sh)) if sh else v
+            if sh + w > 64 and sh > 0:
+                hi |= v >> np.uint64(64 - sh)
+        else:
+            hi |= v << np.uint64(sh - 64)
+        sh += w
+    out = np.empty(n, dtype=np.dtype([("lo", "<u8"), ("hi", "<u8")]))
+    out["lo"], out["hi"] = lo, hi
+    return out
+
+
+def unpack_keys(k, wa, wb, wd, wt):
+    """inverse of pack_keys (vectorised; Keys.fields of fastga_amd.device does the same with Python integers)"""
+    lo, hi = k["lo"].astype(np.uint64), k["hi"].astype(np.uint64)
+    out, sh = {}, 0
+    for name, w in (("lcp", 6), ("drem", 6), ("anti", wt), ("bucket", wd), ("bctg", wb), ("actg", wa), ("strand", 1)):
+        if sh >= 64:
+            v = hi >> np.uint64(sh - 64)
+        else:
+            v = lo >> np.uint64(sh)
+            if sh + w > 64 and sh > 0:
+                v = v | (hi << np.uint64(64 - sh))
+        out[name] = (v & np.uint64((1 << w) - 1)).astype(np.int64)
+        sh += w
+    return out

@@ -1,6 +1,8 @@
-"""GPU parity: the device chain scan (thread-per-bucket + wave-parallel kernels) against the host restatement of
-the reference's scan (align_contigs, FastGA.c:3016-3176) on the same sorted records -- bit-exact hits and units.
-The small/long unit threshold is varied so that every unit also goes through the wave-parallel kernel."""
+"""GPU parity: the device chain scan (thread-per-bucket + wave-parallel kernels) against oracle/chain_oracle.c -- the
+sequential restatement of the reference's scan (align_contigs, FastGA.c:3016-3176) that tests/test_chain_oracle.py pins
+to the hit boxes a DEBUG_HIT build of the reference prints -- on the same sorted records: bit-exact hits and units (the
+product's host scan, fga_chain_scan, is compared too).  The small/long unit threshold is varied so that every unit also
+goes through the wave-parallel kernel."""
 import os
 
 import numpy as np
@@ -24,6 +26,7 @@ def _scan_both(ra, rb, limits, chain_min=170, chain_break=2000):
     ref = D.chain_scan(keys.download(), (keys.wa, keys.wb, keys.wd, keys.wt), chain_break, chain_min, amx, bmx,
                        alen_sorted, nthreads=4)
     ru, rh = ref.units, ref.hits
+    _equals_oracle(keys, ru, rh, chain_break, chain_min, amx, bmx, alen_sorted)
     out = []
     for lim in limits:
         if lim is None:
@@ -38,6 +41,22 @@ def _scan_both(ra, rb, limits, chain_min=170, chain_break=2000):
         got.free()
     ref.free(); keys.free(); dA.free(); dB.free(); dev.close()
     return ru, rh, out
+
+
+def _equals_oracle(keys, units, hits, chain_break, chain_min, amx, bmx, alen_sorted):
+    """units + hits (device or host product scan) == the pinned oracle's rows on the device's own sorted keys"""
+    from oracle import harness as H
+    f = H.unpack_keys(keys.download(), keys.wa, keys.wb, keys.wd, keys.wt)
+    rows = H.oracle_chain_scan(f, chain_break, chain_min, amx, bmx, alen_sorted)
+    exp = [(int(r[0]), int(r[1]), int(r[2]), int(r[3]), int(r[5]), int(r[6]), int(r[7]), int(r[8]), int(r[9]))
+           for r in rows]
+    got = []
+    for x in units:
+        for q in range(int(x["nhits"])):
+            y = hits[int(x["first_hit"]) + q]
+            got.append((int(x["comp"]), int(x["actg"]), int(x["bctg"]), int(x["bucket"]), int(y["cov"]),
+                        int(y["dgmin"]), int(y["dgmax"]), int(y["alow"]), int(y["ahgh"])))
+    assert len(exp) > 0 and got == exp
 
 
 @pytest.mark.parametrize("chain_min", [170, 100])
