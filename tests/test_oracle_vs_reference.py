@@ -84,6 +84,103 @@ def test_self_seed_merge_oracle_matches_reference(toy_pair, tmp_path):
     assert np.array_equal(H.sorted_records(seeds[1], w), H.sorted_records(c, w))
 
 
+@pytest.fixture(scope="module")
+def family_pair(tmp_path_factory, built_library):
+    """0.4 Mbp pair with a 2 kbp family planted 20 times at 1 % divergence: its k-mers have 10-25 partners, so the
+    frequency cutoff decides their fate at -f3, the default 10 and -f30 alike"""
+    from fastga_amd import workload, synth
+    d = str(tmp_path_factory.mktemp("family"))
+    rng = np.random.default_rng(77)
+    lens = synth.contig_lengths(21, 8, 400_000)
+    A = [rng.integers(0, 4, int(L), dtype=np.uint8) for L in lens]
+    fam = rng.integers(0, 4, 2000, dtype=np.uint8)
+    for k in range(20):
+        c = A[k % len(A)]
+        cp = synth.mutate(rng, fam, 0.01)
+        if k % 3 == 0:
+            cp = synth.revcomp(cp)
+        p0 = int(rng.integers(0, len(c) - len(cp) - 1))
+        c[p0:p0 + len(cp)] = cp
+    B = [synth.mutate(rng, c, 0.02) for c in A]
+    return d, workload.build_genome(d, "A", A), workload.build_genome(d, "B", B)
+
+
+@needs_ref
+@pytest.mark.parametrize("freq", [3, 30])
+def test_seed_merge_oracle_freq_branch_matches_reference(family_pair, tmp_path, freq):
+    """-f: the |R| >= FREQ drop (FastGA.c:799-823) at a cutoff below and above the default"""
+    d, ra, rb = family_pair
+    from fastga_amd.gixio import Gix
+    r, seeds = H.ref_fastga(ra, rb, str(tmp_path), os.path.join(str(tmp_path), "out"), threads=4,
+                            flags=(f"-f{freq}",), capture_seeds=True)
+    A, B = Gix(ra + ".gix"), Gix(rb + ".gix")
+    w = 1 + A.pbyte + B.pbyte
+    n, c, nh, ts = H.oracle_seed_merge(A.table, A.index, A.pbyte, B.table, B.index, B.pbyte, freq=freq)
+    n10, c10, nh10, _ = H.oracle_seed_merge(A.table, A.index, A.pbyte, B.table, B.index, B.pbyte)
+    assert (nh < nh10) if freq < 10 else (nh > nh10)    # the cutoff really changes the seed set on this pair
+    assert len(seeds[0]) + len(seeds[1]) == nh * w
+    assert np.array_equal(H.sorted_records(seeds[0], w), H.sorted_records(n, w))
+    assert np.array_equal(H.sorted_records(seeds[1], w), H.sorted_records(c, w))
+
+
+@pytest.fixture(scope="module")
+def masked_pair(tmp_path_factory, built_library):
+    """~0.6 Mbp pair whose repeat copies are lower case in BOTH genomes; indices carry the mask bytes (host producer,
+    pinned against `GIXmake -T1 ... #` by tests/test_edge_cases.py)"""
+    from fastga_amd import workload, synth
+    d = str(tmp_path_factory.mktemp("masked"))
+    lens = synth.contig_lengths(9, 10, 600_000)
+    A, mA, B, mB = synth.make_pair(9, lens, 0.03, repeat_frac=0.15, inv_frac=0.05, swap_frac=0.05)
+    rng = np.random.default_rng(3)
+    for m in mB:                                        # B: arbitrary lower-case stretches as well
+        for _ in range(6):
+            s0 = int(rng.integers(0, max(1, len(m) - 3000)))
+            m[s0:s0 + int(rng.integers(200, 3000))] = True
+    ra = workload.build_genome(d, "A", A, masks=mA, use_mask=True)
+    rb = workload.build_genome(d, "B", B, masks=mB, use_mask=True)
+    return d, ra, rb
+
+
+@needs_ref
+def test_seed_merge_oracle_soft_mask_branch_matches_reference(masked_pair, tmp_path):
+    """-M: mlen = plen; T1 entries and T2 partners whose mask byte reaches mlen are dropped (FastGA.c:824-832, 954)"""
+    d, ra, rb = masked_pair
+    from fastga_amd.gixio import Gix
+    A, B = Gix(ra + ".gix"), Gix(rb + ".gix")
+    assert A.entries()[:, 7].any() and B.entries()[:, 7].any()          # the tables do carry mask bytes
+    w = 1 + A.pbyte + B.pbyte
+    r, seeds = H.ref_fastga(ra, rb, str(tmp_path), os.path.join(str(tmp_path), "out"), threads=4, flags=("-M",),
+                            capture_seeds=True)
+    n, c, nh, ts = H.oracle_seed_merge(A.table, A.index, A.pbyte, B.table, B.index, B.pbyte, soft_mask=True)
+    _, _, nh_plain, _ = H.oracle_seed_merge(A.table, A.index, A.pbyte, B.table, B.index, B.pbyte)
+    assert 0 < nh < nh_plain
+    assert np.array_equal(H.sorted_records(seeds[0], w), H.sorted_records(n, w))
+    assert np.array_equal(H.sorted_records(seeds[1], w), H.sorted_records(c, w))
+    # -M -S: the flipped pass tests the masks of both sides the other way round (FastGA.c:833-892)
+    r, seeds = H.ref_fastga(ra, rb, str(tmp_path), os.path.join(str(tmp_path), "out2"), threads=4,
+                            flags=("-M", "-S"), capture_seeds=True)
+    n2, c2, nh2, _ = H.oracle_seed_merge(B.table, B.index, B.pbyte, A.table, A.index, A.pbyte, soft_mask=True,
+                                         flip=True)
+    assert np.array_equal(H.sorted_records(seeds[0], w), H.sorted_records(n + n2, w))
+    assert np.array_equal(H.sorted_records(seeds[1], w), H.sorted_records(c + c2, w))
+
+
+@needs_ref
+def test_self_seed_merge_oracle_soft_mask_matches_reference(masked_pair, tmp_path):
+    """self comparison with -M (new_self_merge_thread with mlen = plen, FastGA.c:1791-1799): BASELINE config 3's mode"""
+    d, ra, rb = masked_pair
+    from fastga_amd.gixio import Gix
+    A = Gix(ra + ".gix")
+    w = 1 + 2 * A.pbyte
+    r, seeds = H.ref_fastga(ra, None, str(tmp_path), os.path.join(str(tmp_path), "out"), threads=4, flags=("-M",),
+                            capture_seeds=True)
+    n, c, nh, ts = H.oracle_self_seed_merge(A.table, A.index, A.pbyte, soft_mask=True)
+    _, _, nh_plain, _ = H.oracle_self_seed_merge(A.table, A.index, A.pbyte)
+    assert 0 < nh < nh_plain
+    assert np.array_equal(H.sorted_records(seeds[0], w), H.sorted_records(n, w))
+    assert np.array_equal(H.sorted_records(seeds[1], w), H.sorted_records(c, w))
+
+
 def _random_case(rng):
     from fastga_amd import synth
     n = int(rng.integers(300, 6000))
