@@ -159,15 +159,10 @@ static int unit_chains(targ *T, int64_t b, int64_t m, int64_t e, const fga_unit 
 static int scan_range(targ *T, int64_t c0, int64_t c1)
 { const key128 *K = T->keys;
   const layout *L = &T->L;
-  const fga_chain_params *P = T->prm;
   const int64_t n = T->n;
-  const int64_t CHAIN_BREAK = P->chain_break, CHAIN_MIN = P->chain_min;
   int64_t b, m, e;
 
 #define BUCK(x)  ((int64_t) field(K+(x),L->s_buck,L->wd))
-#define ANTI(x)  ((int64_t) field(K+(x),L->s_anti,L->wt))
-#define DREM(x)  ((int) field(K+(x),6,6))
-#define LCP(x)   ((int) field(K+(x),0,6))
 #define SAMEBK(x,sid,bk) (segid(K+(x),L) == (sid) && BUCK(x) == (bk))
 
   /* first bucket head at or after c0 */

@@ -78,6 +78,24 @@ void *fga_dev_pinned(fga_dev *dev, size_t bytes)
   return dev->pinned;
 }
 
+extern "C" int fga_dev_malloc(fga_dev *dev, size_t bytes, void **out)
+{ *out = NULL;
+  FGA_HIP(hipSetDevice(dev->device));
+  hipError_t e = hipMalloc(out,bytes > 0 ? bytes : 16);
+  if (e != hipSuccess)
+    { fga_set_error("device allocation of %zu bytes failed: %s",bytes,hipGetErrorString(e));
+      *out = NULL;
+      return 1;
+    }
+  return 0;
+}
+
+extern "C" void fga_dev_free(fga_dev *dev, void *ptr)
+{ if (ptr == NULL) return;
+  hipSetDevice(dev->device);
+  hipFree(ptr);
+}
+
 extern "C" void fga_dev_close(fga_dev *d)
 { if (d == NULL) return;
   hipSetDevice(d->device);

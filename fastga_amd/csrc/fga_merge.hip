@@ -1419,6 +1419,58 @@ done:
   return 0;
 }
 
+// cuts[0..nshards]: 12-mer prefix ranges [cuts[r], cuts[r+1]) of equal merge cost (entries of both tables + prefixes), the
+// phase-1 shards of a multi-GPU run -- the reference splits its merge threads the same way (FastGA.c:2291-2321)
+__global__ void prefix_cut_kernel(const int64_t *idx1, const int64_t *idx2, int64_t total, int nshards, int64_t *cuts)
+{ const int w = blockIdx.x*blockDim.x + threadIdx.x;
+  if (w > nshards)
+    return;
+  int64_t p = 0;
+  if (w == nshards)
+    p = FGA_NPREFIX;
+  else if (w > 0)
+    { const int64_t target = (total / nshards) * w;
+      int lo = 0, hi = FGA_NPREFIX;
+      while (lo < hi)                                  // smallest p whose inclusive cost exceeds the target
+        { const int mid = lo + ((hi-lo) >> 1);
+          const int64_t c = idx1[mid] + idx2[mid] + 2*((int64_t) mid+1);
+          if (c > target) hi = mid; else lo = mid+1;
+        }
+      p = lo;
+    }
+  cuts[w] = p;
+}
+
+extern "C" int fga_merge_prefix_cuts(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2, int nshards, int64_t *cuts)
+{ if (dev == NULL || t1 == NULL || cuts == NULL || nshards < 1 || nshards > 4096)
+    { fga_set_error("fga_merge_prefix_cuts: bad argument");
+      return 1;
+    }
+  if (t2 == NULL) t2 = t1;
+  FGA_HIP(hipSetDevice(dev->device));
+  int64_t c1e, c2e;
+  FGA_HIP(hipMemcpy(&c1e,t1->index + (FGA_NPREFIX-1),8,hipMemcpyDeviceToHost));
+  FGA_HIP(hipMemcpy(&c2e,t2->index + (FGA_NPREFIX-1),8,hipMemcpyDeviceToHost));
+  const int64_t total = c1e + c2e + 2*(int64_t) FGA_NPREFIX;
+  int64_t *d = (int64_t *) fga_dev_acquire(dev,SLOT_MISC,sizeof(int64_t)*(size_t) (nshards+1));
+  if (d == NULL)
+    { fga_set_error("fga_merge_prefix_cuts: device allocation failed");
+      return 1;
+    }
+  hipLaunchKernelGGL(prefix_cut_kernel,dim3((nshards+1+63)/64),dim3(64),0,dev->stream,t1->index,t2->index,total,nshards,d);
+  hipError_t e = hipMemcpyAsync(cuts,d,sizeof(int64_t)*(size_t) (nshards+1),hipMemcpyDeviceToHost,dev->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
+  if (e == hipSuccess) e = hipGetLastError();
+  fga_dev_release(dev,SLOT_MISC,d);
+  if (e != hipSuccess)
+    { fga_set_error("fga_merge_prefix_cuts: %s",hipGetErrorString(e));
+      return 1;
+    }
+  for (int w = 1; w <= nshards; w++)
+    if (cuts[w] < cuts[w-1]) cuts[w] = cuts[w-1];
+  return 0;
+}
+
 extern "C" int fga_seed_merge(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
                               const fga_merge_params *prm, int64_t capacity, fga_dseeds **out)
 { return merge_impl(dev,t1,t2,prm,capacity,out,NULL); }

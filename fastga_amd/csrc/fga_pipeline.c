@@ -101,55 +101,75 @@ int      fga_session_seed_bytes(const fga_session *Z)
 int64_t  fga_session_bases(const fga_session *Z, int which)
 { return which == 0 ? Z->g1->seqtot : (Z->self ? Z->g1->seqtot : Z->g2->seqtot); }
 
-/* one pass of the hot path over the resident inputs: phases 1-3 */
-int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
+/* ---- the hot path in three stages, so that one comparison can be cut at the two places where the reference itself
+ *      re-partitions its data: between phase 1 and phase 2 (seeds are regrouped from k-mer prefix ranges to A-contig
+ *      parts, FastGA.c:5097-5134, 5160-5184) and before phase 3 (the records of all parts are merged, FastGA.c:3991-4133).
+ *      One GPU runs them back to back (fga_session_run); N GPUs run merge on their prefix range, exchange seeds by part
+ *      (fga_seeds_split_to / RCCL all-to-all-v / fga_seeds_import), run align on their part, and rank 0 runs finish on
+ *      the gathered records (bench.py, fastga_amd/parallel.py). ------------------------------------------------------- */
+
+/* phase 1 over the 12-mer prefix range [prefix_begin, prefix_end) (0,0 = all): adaptive seeds in HBM */
+int fga_session_merge(fga_session *Z, const fga_run_params *P, int64_t prefix_begin, int64_t prefix_end,
+                      fga_dseeds **out, fga_run_stats *S)
+{ fga_gix *x1 = Z->x1, *x2 = Z->x2;
+  fga_dev *dev = Z->dev;
+  const int self = Z->self;
+  fga_dseeds *seeds = NULL;
+  fga_merge_params mp;
+  double t0 = fga_wall();
+  int rc;
+
+  *out = NULL;
+  memset(&mp,0,sizeof(mp));
+  mp.freq = P->freq; mp.soft_mask = P->soft_mask; mp.flip = 0;
+  mp.prefix_begin = prefix_begin; mp.prefix_end = prefix_end;
+  rc = fga_seed_merge(dev,Z->d1,self ? NULL : Z->d2,&mp,
+                      (P->symmetric && !self) ? 2*(x1->nents + x2->nents) + (1<<20) : 0,&seeds);
+  if (rc == 2)
+    { int64_t need = fga_seeds_count(seeds) + 1024;
+      if (P->symmetric && !self) need += x2->nents + x1->nents;
+      fga_seeds_free(seeds); seeds = NULL;
+      rc = fga_seed_merge(dev,Z->d1,self ? NULL : Z->d2,&mp,need,&seeds);
+    }
+  if (rc) goto fail;
+  if (S != NULL) S->merge_kernel_ms += fga_dev_stage_ms(dev,FGA_STAGE_MERGE);
+  if (P->symmetric && !self)
+    { mp.flip = 1;
+      rc = fga_seed_merge_append(dev,Z->d2,Z->d1,&mp,seeds);
+      if (rc) goto fail;
+      if (S != NULL) S->merge_kernel_ms += fga_dev_stage_ms(dev,FGA_STAGE_MERGE);
+    }
+  if (S != NULL)
+    { int64_t n = fga_seeds_count(seeds), l = fga_seeds_plen_sum(seeds);
+      if (self) { n /= 2; l /= 2; }
+      S->nseeds += n; S->seed_len_sum += l;
+      S->merge_s += fga_wall() - t0;
+    }
+  *out = seeds;
+  return 0;
+fail:
+  fga_seeds_free(seeds);
+  return 1;
+}
+
+/* phase 2 on a set of seeds (all of them, or one A-contig part): diagonal records, sort, chain scan, wave extension.
+   The seed buffer is consumed.  *raw: the accepted alignments in discovery order (unit, seq), before the redundancy
+   filter, which needs all records of a contig pair -- they all come from the part that owns the A contig. */
+int fga_session_align(fga_session *Z, const fga_run_params *P, fga_dseeds *seeds, fga_alns **raw, fga_run_stats *S)
 { fga_gdb *g1 = Z->g1, *g2 = Z->g2;
   fga_gix *x1 = Z->x1, *x2 = Z->x2;
   fga_dev *dev = Z->dev;
-  fga_dgix *d1 = Z->d1, *d2 = Z->d2;
-  fga_dgenome *dg1 = Z->dg1, *dg2 = Z->dg2;
-  fga_dseeds *seeds = NULL;
   fga_dkeys *keys = NULL;
   fga_hits *hits = NULL;
-  fga_alns *raw = NULL, *fin = NULL;
-  void *hkeys = NULL;
   int64_t *alen = NULL;
   int16_t *table = NULL;
   const int self = Z->self;
   int status = 1, i;
-  double t0, t1, tstart;
+  double t0, t1;
   fga_run_stats st;
 
+  *raw = NULL;
   memset(&st,0,sizeof(st));
-  st.load_s = Z->load_s; st.upload_s = Z->upload_s;
-  tstart = fga_wall();
-  /* ---- phase 1 ---- */
-  t0 = fga_wall();
-  { fga_merge_params mp;
-    int rc;
-    memset(&mp,0,sizeof(mp));
-    mp.freq = P->freq; mp.soft_mask = P->soft_mask; mp.flip = 0;
-    rc = fga_seed_merge(dev,d1,self ? NULL : d2,&mp,
-                        (P->symmetric && !self) ? 2*(x1->nents + x2->nents) + (1<<20) : 0,&seeds);
-    if (rc == 2)
-      { int64_t need = fga_seeds_count(seeds) + 1024;
-        fga_seeds_free(seeds); seeds = NULL;
-        rc = fga_seed_merge(dev,d1,self ? NULL : d2,&mp,need,&seeds);
-      }
-    if (rc) goto done;
-    if (P->symmetric && !self)
-      { mp.flip = 1;
-        rc = fga_seed_merge_append(dev,d2,d1,&mp,seeds);
-        if (rc) goto done;
-      }
-    st.nseeds = fga_seeds_count(seeds);
-    st.seed_len_sum = fga_seeds_plen_sum(seeds);
-    if (self) { st.nseeds /= 2; st.seed_len_sum /= 2; }
-  }
-  st.merge_s = fga_wall() - t0;
-  st.merge_kernel_ms = fga_dev_stage_ms(dev,FGA_STAGE_MERGE);
-
-  /* ---- phase 2 ---- */
   t0 = fga_wall();
   { fga_sort_params sp;
     sp.amxpos = g1->maxctg; sp.bmxpos = self ? g1->maxctg : g2->maxctg;
@@ -162,12 +182,8 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
   t1 = fga_wall();
   st.sort_s = t1 - t0;
 
-  { int64_t n = fga_keys_count(keys);
-    int wa, wb, wd, wt;
-    fga_chain_params cp;
-    fga_keys_layout(keys,&wa,&wb,&wd,&wt);
-    (void) n;
-    alen  = malloc(sizeof(int64_t)*x1->nctg);
+  { fga_chain_params cp;
+    alen = malloc(sizeof(int64_t)*x1->nctg);
     if (alen == NULL)
       { fga_set_error("out of memory");
         goto done;
@@ -177,8 +193,7 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
     cp.chain_break = P->chain_break; cp.chain_min = P->chain_min;
     cp.amxpos = g1->maxctg; cp.bmxpos = self ? g1->maxctg : g2->maxctg;
     cp.alen = alen; cp.nalen = x1->nctg;
-    st.download_s = 0.;                              /* the sorted records never leave HBM any more */
-    if (fga_chain_scan_device(dev,keys,&cp,&hits)) goto done;
+    if (fga_chain_scan_device(dev,keys,&cp,&hits)) goto done;      /* the sorted records never leave HBM */
     fga_keys_free(keys); keys = NULL;
     st.nhits = hits->nhits;
     st.nunits = hits->nunits;
@@ -197,14 +212,85 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
     fga_align_spec(1.-P->align_rate,100,g1->freq,&path_ave,table,table+32768);
     ep.tspace = 100; ep.path_ave = path_ave; ep.table = table; ep.score = table+32768;
     ep.self = self; ep.aln_min = P->align_min - 50; ep.aln_rate = P->align_rate + .05;
-    if (fga_extend(dev,dg1,dg2,hits,&ep,&raw)) goto done;
-    st.nalns = raw->naln; st.ncalls = raw->ncalls; st.nwaves = raw->nwaves;
+    if (fga_extend(dev,Z->dg1,Z->dg2,hits,&ep,raw)) goto done;
+    st.nalns = (*raw)->naln; st.ncalls = (*raw)->ncalls; st.nwaves = (*raw)->nwaves;
     st.extend_kernel_ms = fga_dev_stage_ms(dev,FGA_STAGE_EXTEND);
   }
   st.extend_s = fga_wall() - t1;
+  status = 0;
 
+done:
+  if (S != NULL)
+    { S->sort_s += st.sort_s; S->chain_s += st.chain_s; S->extend_s += st.extend_s;
+      S->sort_kernel_ms += st.sort_kernel_ms; S->extend_kernel_ms += st.extend_kernel_ms;
+      S->nhits += st.nhits; S->nunits += st.nunits; S->nalns += st.nalns; S->ncalls += st.ncalls; S->nwaves += st.nwaves;
+    }
+  free(alen); free(table);
+  fga_hits_free(hits);
+  fga_keys_free(keys);
+  fga_seeds_free(seeds);
+  return status;
+}
+
+/* the records of several parts as one set, unit numbers made distinct (discovery order is (part, unit, seq)) */
+int fga_alns_concat(const fga_alns *const *raw, int nraw, fga_alns **out)
+{ fga_alns *R = calloc(1,sizeof(fga_alns));
+  int64_t at = 0, tat = 0;
+  int32_t ubase = 0;
+  int k;
+  *out = NULL;
+  if (R == NULL) goto oom;
+  for (k = 0; k < nraw; k++)
+    if (raw[k] != NULL)
+      { R->naln += raw[k]->naln; R->ntrace += raw[k]->ntrace; R->ncalls += raw[k]->ncalls; R->nwaves += raw[k]->nwaves; }
+  R->alns = malloc(sizeof(fga_aln)*(R->naln+1));
+  R->tbytes = malloc(R->ntrace+16);
+  if (R->alns == NULL || R->tbytes == NULL) goto oom;
+  for (k = 0; k < nraw; k++)
+    if (raw[k] != NULL)
+      { int64_t i;
+        int32_t umax = -1;
+        for (i = 0; i < raw[k]->naln; i++)
+          { fga_aln a = raw[k]->alns[i];
+            if (a.unit > umax) umax = a.unit;
+            if (a.unit >= 0) a.unit += ubase;
+            a.toff += tat;
+            R->alns[at++] = a;
+          }
+        if (raw[k]->ntrace > 0)
+          memcpy(R->tbytes+tat,raw[k]->tbytes,raw[k]->ntrace);
+        tat += raw[k]->ntrace;
+        ubase += umax+1;
+      }
+  *out = R;
+  return 0;
+oom:
+  fga_set_error("out of memory");
+  if (R != NULL) { free(R->alns); free(R->tbytes); free(R); }
+  return 1;
+}
+
+/* redundancy filter + phase 3 over the records of all parts: order, .1aln, PAF / PSL */
+int fga_session_finish(fga_session *Z, const fga_run_params *P, const fga_alns *const *raw, int nraw, fga_run_stats *S)
+{ fga_gdb *g1 = Z->g1, *g2 = Z->g2;
+  fga_dev *dev = Z->dev;
+  fga_alns *all = NULL, *fin = NULL;
+  const fga_alns *in;
+  const int self = Z->self;
+  int status = 1;
+  int64_t i;
+  double t1;
+  fga_run_stats st;
+
+  memset(&st,0,sizeof(st));
   t1 = fga_wall();
-  if (fga_filter_alignments_mt(raw,P->nthreads,&fin)) goto done;
+  if (nraw == 1 && raw[0] != NULL)
+    in = raw[0];
+  else
+    { if (fga_alns_concat(raw,nraw,&all)) goto done;
+      in = all;
+    }
+  if (fga_filter_alignments_mt(in,P->nthreads,&fin)) goto done;
   st.nlive = fin->naln;
   for (i = 0; i < fin->naln; i++)
     st.cover += fin->alns[i].aepos - fin->alns[i].abpos;
@@ -227,7 +313,6 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
       if (rc) goto done;
     }
   st.write_s = fga_wall() - t1;
-  st.phase23_s = fga_wall() - tstart;
 
   /* ---- PAF (what the reference leaves to a second process, ALNtoPAF): outside the .1aln clock ---- */
   if (P->paf_path != NULL)
@@ -237,7 +322,7 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
       int rc = 0;
       t1 = fga_wall();
       if (bases)
-        { rc = fga_trace_pts(dev,dg1,dg2,fin,100,0,&tr);
+        { rc = fga_trace_pts(dev,Z->dg1,Z->dg2,fin,100,0,&tr);
           st.trace_kernel_ms = fga_dev_stage_ms(dev,FGA_STAGE_TRACE);
         }
       st.trace_s = fga_wall() - t1;
@@ -252,11 +337,87 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
   status = 0;
 
 done:
+  if (S != NULL)
+    { S->nlive = st.nlive; S->cover = st.cover; S->filter_s += st.filter_s; S->write_s += st.write_s;
+      S->trace_s = st.trace_s; S->paf_s = st.paf_s; S->trace_kernel_ms = st.trace_kernel_ms;
+    }
+  fga_alns_free(all); fga_alns_free(fin);
+  return status;
+}
+
+/* A-contig parts of the seeds of this session (weights: seeds per A contig, summed over ranks by the caller when there
+   are several): see fga_partition_contigs */
+int fga_session_nctg(const fga_session *Z) { return Z->x1->nctg; }
+
+int fga_session_prefix_cuts(fga_session *Z, int nshards, int64_t *cuts)
+{ return fga_merge_prefix_cuts(Z->dev,Z->d1,Z->self ? NULL : Z->d2,nshards,cuts); }
+
+/* one pass of the hot path over the resident inputs: phases 1-3.  When the merge finds more seeds than one sort pass
+   should take (P->pass_seeds, default 1.5 G: the sort's tile counters are 32-bit and three 16-byte buffers per seed are
+   live), phase 2 runs part by part over an A-contig partition -- the reference's own NPARTS loop (FastGA.c:5186-5204). */
+int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
+{ fga_dev *dev = Z->dev;
+  fga_dseeds *seeds = NULL;
+  fga_alns **raw = NULL;
+  int nparts = 1, p, status = 1;
+  int64_t limit = P->pass_seeds > 0 ? P->pass_seeds : (int64_t) 1500000000;
+  int64_t *cnt = NULL, *poff = NULL;
+  int *select = NULL;
+  void *stage = NULL;
+  double tstart = fga_wall();
+  fga_run_stats st;
+
+  memset(&st,0,sizeof(st));
+  st.load_s = Z->load_s; st.upload_s = Z->upload_s;
+  if (fga_session_merge(Z,P,0,0,&seeds,&st)) goto done;
+  { int64_t n = fga_seeds_count(seeds);
+    if (n > limit)
+      nparts = (int) ((n + limit - 1) / limit);
+    if (nparts > 64) nparts = 64;
+    if (nparts > Z->x1->nctg) nparts = Z->x1->nctg;
+  }
+  raw = calloc(nparts,sizeof(fga_alns *));
+  if (raw == NULL)
+    { fga_set_error("out of memory");
+      goto done;
+    }
+  if (nparts == 1)
+    { if (fga_session_align(Z,P,seeds,&raw[0],&st)) { seeds = NULL; goto done; }
+      seeds = NULL;
+    }
+  else
+    { const int nctg = Z->x1->nctg;
+      const int64_t n = fga_seeds_count(seeds);
+      cnt = malloc(sizeof(int64_t)*nctg); poff = malloc(sizeof(int64_t)*(nparts+1)); select = malloc(sizeof(int)*nctg);
+      if (cnt == NULL || poff == NULL || select == NULL)
+        { fga_set_error("out of memory");
+          goto done;
+        }
+      if (fga_seeds_contig_histogram(dev,seeds,nctg,cnt) || fga_partition_contigs(cnt,nctg,nparts,select))
+        goto done;
+      if (fga_dev_malloc(dev,(size_t) n*sizeof(fga_seed) + 64,&stage)) goto done;
+      if (fga_seeds_split_to(dev,seeds,select,nctg,nparts,stage,poff)) goto done;
+      fga_seeds_free(seeds); seeds = NULL;
+      for (p = 0; p < nparts; p++)
+        { const void *src = (const char *) stage + (size_t) poff[p]*sizeof(fga_seed);
+          const int64_t c = poff[p+1] - poff[p];
+          fga_dseeds *part = NULL;
+          if (fga_seeds_import(dev,&src,&c,1,&part)) goto done;
+          if (fga_session_align(Z,P,part,&raw[p],&st)) goto done;
+        }
+      fga_dev_free(dev,stage); stage = NULL;
+    }
+  if (fga_session_finish(Z,P,(const fga_alns *const *) raw,nparts,&st)) goto done;
+  st.phase23_s = fga_wall() - tstart - st.trace_s - st.paf_s;
+  st.nparts = nparts;
+  status = 0;
+
+done:
   if (S != NULL) *S = st;
-  free(hkeys); free(alen); free(table);
-  fga_alns_free(raw); fga_alns_free(fin);
-  fga_hits_free(hits);
-  fga_keys_free(keys);
+  if (raw != NULL)
+    for (p = 0; p < nparts; p++) fga_alns_free(raw[p]);
+  free(raw); free(cnt); free(poff); free(select);
+  if (stage != NULL) fga_dev_free(dev,stage);
   fga_seeds_free(seeds);
   return status;
 }

@@ -305,13 +305,14 @@ def trace_pts(dev, ga, gb, alns, tb, tspace=100, self_cmp=False):
 
 
 def run(root1, root2=None, out_path=None, device=0, freq=10, soft_mask=False, symmetric=False, chain_break=1000,
-        chain_min=85, align_min=100, identity=0.7, nthreads=8, command_line="FastGA", paf_path=None, paf_flags=0):
+        chain_min=85, align_min=100, identity=0.7, nthreads=8, command_line="FastGA", paf_path=None, paf_flags=0,
+        pass_seeds=0):
     """The whole hot path (fga_run): prebuilt GDB/GIX roots in, .1aln (and PAF) out.  Returns the stats as a dict."""
     from .lib import RunParams, RunStats
     L = load_library()
     prm = RunParams(device, freq, int(soft_mask), int(symmetric), 2 * chain_break, 2 * chain_min, align_min,
                     1.0 - identity, nthreads, out_path.encode() if out_path else None, command_line.encode(),
-                    paf_path.encode() if paf_path else None, paf_flags)
+                    paf_path.encode() if paf_path else None, paf_flags, pass_seeds)
     st = RunStats()
     check(L.fga_run(root1.encode(), root2.encode() if root2 else None, C.byref(prm), C.byref(st)), "fga_run")
     return {n: getattr(st, n) for n, _ in RunStats._fields_}
@@ -330,14 +331,86 @@ class Session:
         self.bases = (self.L.fga_session_bases(self.h, 0), self.L.fga_session_bases(self.h, 1))
 
     def run(self, out_path=None, freq=10, soft_mask=False, symmetric=False, chain_break=1000, chain_min=85,
-            align_min=100, identity=0.7, nthreads=8, command_line="FastGA", paf_path=None, paf_flags=0):
+            align_min=100, identity=0.7, nthreads=8, command_line="FastGA", paf_path=None, paf_flags=0,
+            pass_seeds=0):
         from .lib import RunParams, RunStats
         prm = RunParams(0, freq, int(soft_mask), int(symmetric), 2 * chain_break, 2 * chain_min, align_min,
                         1.0 - identity, nthreads, out_path.encode() if out_path else None, command_line.encode(),
-                        paf_path.encode() if paf_path else None, paf_flags)
+                        paf_path.encode() if paf_path else None, paf_flags, pass_seeds)
         st = RunStats()
         check(self.L.fga_session_run(self.h, C.byref(prm), C.byref(st)), "session run")
         return {n: getattr(st, n) for n, _ in RunStats._fields_}
+
+    # ---- the three stages of run(), for one comparison cut into A-contig parts (fastga_amd/parallel.py) ----
+    def params(self, out_path=None, freq=10, soft_mask=False, symmetric=False, chain_break=1000, chain_min=85,
+               align_min=100, identity=0.7, nthreads=8, command_line="FastGA", paf_path=None, paf_flags=0,
+               pass_seeds=0):
+        from .lib import RunParams
+        return RunParams(0, freq, int(soft_mask), int(symmetric), 2 * chain_break, 2 * chain_min, align_min,
+                         1.0 - identity, nthreads, out_path.encode() if out_path else None, command_line.encode(),
+                         paf_path.encode() if paf_path else None, paf_flags, pass_seeds)
+
+    def new_stats(self):
+        from .lib import RunStats
+        return RunStats()
+
+    @staticmethod
+    def stats_dict(st):
+        from .lib import RunStats
+        return {n: getattr(st, n) for n, _ in RunStats._fields_}
+
+    @property
+    def nctg(self):
+        return self.L.fga_session_nctg(self.h)
+
+    def merge(self, prm, stats, prefix_begin=0, prefix_end=0):
+        """phase 1 over a 12-mer prefix range -> Seeds (device resident)"""
+        h = C.c_void_p()
+        check(self.L.fga_session_merge(self.h, C.byref(prm), prefix_begin, prefix_end, C.byref(h), C.byref(stats)),
+              "session merge")
+        return Seeds(self.dev_wrapper(), h)
+
+    def contig_histogram(self, seeds):
+        cnt = np.zeros(self.nctg, dtype=np.int64)
+        check(self.L.fga_seeds_contig_histogram(self.L.fga_session_device(self.h), seeds.h, self.nctg,
+                                                cnt.ctypes.data_as(C.POINTER(C.c_int64))), "contig histogram")
+        return cnt
+
+    def split_to(self, seeds, select, nparts, dst_device_ptr):
+        """regroup `seeds` by select[A contig] into the device buffer at dst_device_ptr; returns part offsets"""
+        sel = np.ascontiguousarray(select, dtype=np.int32)
+        off = np.zeros(nparts + 1, dtype=np.int64)
+        check(self.L.fga_seeds_split_to(self.L.fga_session_device(self.h), seeds.h,
+                                        sel.ctypes.data_as(C.POINTER(C.c_int)), len(sel), nparts,
+                                        C.c_void_p(dst_device_ptr), off.ctypes.data_as(C.POINTER(C.c_int64))),
+              "seed split")
+        return off
+
+    def import_seeds(self, pieces):
+        """pieces: [(device pointer, record count)] -> Seeds"""
+        n = len(pieces)
+        ptrs = (C.c_void_p * max(n, 1))(*[C.c_void_p(p) for p, _ in pieces])
+        cnts = (C.c_int64 * max(n, 1))(*[int(c) for _, c in pieces])
+        h = C.c_void_p()
+        check(self.L.fga_seeds_import(self.L.fga_session_device(self.h), ptrs, cnts, n, C.byref(h)), "seed import")
+        return Seeds(self.dev_wrapper(), h)
+
+    def align(self, prm, stats, seeds):
+        """phase 2 on `seeds` (consumed) -> pointer to the raw fga_alns (free with free_alns)"""
+        from .lib import Alns
+        out = C.POINTER(Alns)()
+        h, seeds.h = seeds.h, C.c_void_p()
+        check(self.L.fga_session_align(self.h, C.byref(prm), h, C.byref(out), C.byref(stats)), "session align")
+        return out
+
+    def free_alns(self, a):
+        self.L.fga_alns_free(a)
+
+    def finish(self, prm, stats, raws):
+        """redundancy filter + phase 3 over the record sets `raws` (POINTER(Alns) each)"""
+        from .lib import Alns
+        arr = (C.POINTER(Alns) * max(len(raws), 1))(*raws)
+        check(self.L.fga_session_finish(self.h, C.byref(prm), arr, len(raws), C.byref(stats)), "session finish")
 
     def sync(self):
         check(self.L.fga_dev_sync(self.L.fga_session_device(self.h)), "sync")

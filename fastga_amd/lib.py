@@ -72,7 +72,8 @@ class RunParams(C.Structure):
     _fields_ = [("device", C.c_int), ("freq", C.c_int), ("soft_mask", C.c_int), ("symmetric", C.c_int),
                 ("chain_break", C.c_int), ("chain_min", C.c_int), ("align_min", C.c_int),
                 ("align_rate", C.c_double), ("nthreads", C.c_int), ("out_path", C.c_char_p),
-                ("command_line", C.c_char_p), ("paf_path", C.c_char_p), ("paf_flags", C.c_int)]
+                ("command_line", C.c_char_p), ("paf_path", C.c_char_p), ("paf_flags", C.c_int),
+                ("pass_seeds", C.c_int64)]
 
 
 class RunStats(C.Structure):
@@ -81,7 +82,7 @@ class RunStats(C.Structure):
                [(n, C.c_double) for n in ("load_s", "upload_s", "merge_s", "sort_s", "download_s", "chain_s",
                                           "extend_s", "filter_s", "write_s", "phase23_s", "trace_s", "paf_s")] + \
                [(n, C.c_float) for n in ("merge_kernel_ms", "sort_kernel_ms", "extend_kernel_ms",
-                                         "trace_kernel_ms")]
+                                         "trace_kernel_ms")] + [("nparts", C.c_int)]
 
 
 class SortParams(C.Structure):
@@ -174,6 +175,18 @@ def _declare(L):
         "fga_session_table_bytes": (i64, [vp]),
         "fga_session_seed_bytes": (i32, [vp]),
         "fga_session_bases": (i64, [vp, i32]),
+        "fga_session_nctg": (i32, [vp]),
+        "fga_session_merge": (i32, [vp, P(RunParams), i64, i64, P(vp), P(RunStats)]),
+        "fga_session_align": (i32, [vp, P(RunParams), vp, P(P(Alns)), P(RunStats)]),
+        "fga_session_finish": (i32, [vp, P(RunParams), P(P(Alns)), i32, P(RunStats)]),
+        "fga_seeds_contig_histogram": (i32, [vp, vp, i32, P(i64)]),
+        "fga_partition_contigs": (i32, [P(i64), i32, i32, P(i32)]),
+        "fga_seeds_split_to": (i32, [vp, vp, P(i32), i32, i32, vp, P(i64)]),
+        "fga_seeds_import": (i32, [vp, P(vp), P(i64), i32, P(vp)]),
+        "fga_seeds_device_ptr": (vp, [vp]),
+        "fga_merge_prefix_cuts": (i32, [vp, vp, vp, i32, P(i64)]),
+        "fga_session_prefix_cuts": (i32, [vp, i32, P(i64)]),
+        "fga_alns_concat": (i32, [P(P(Alns)), i32, P(P(Alns))]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -1,17 +1,36 @@
-"""Multi-GPU sharding of the hot path (one process per GPU, torch.distributed; nccl = RCCL over xGMI, gloo on CPU).
+"""One comparison over several GPUs (one process per GPU, torch.distributed: "nccl" = RCCL over xGMI; "gloo" on CPU).
 
-Phase 1 shards by contiguous ranges of the 2^24 12-mer prefixes, balanced on cost(p) = idx1[p] + idx2[p] exactly like
-the reference splits its merge threads on prefix quantiles (FastGA.c:2291-2321).  Panels are independent, so the
-union of the per-shard seed sets is the full seed set and no data-path collective is needed; only counts (and, for
-phase 2, the seed records keyed by A-contig part -- SURVEY.md 8e) ever cross ranks.
+The cut follows the reference's own two partitions:
+
+  phase 1  every rank merges ONE 12-mer prefix range of the two tables (equal merge cost per range; the reference splits
+           its merge threads the same way, FastGA.c:2291-2321).  Panels are independent: the union of the ranges' seeds
+           is the seed set.
+  exchange seeds per A contig are counted (the reference's buck[]), all-reduced, and every rank derives the SAME map
+           A contig -> part from the totals (fga_partition_contigs: heaviest contig to the lightest part).  Each rank
+           regroups its seeds by part on the device (fga_seeds_split_to, straight into the send buffer) and ONE
+           all-to-all-v moves the 16-byte records: what the N_Units / C_Units file matrix and its transpose do in the
+           reference (FastGA.c:5097-5134, 5160-5184).
+  phase 2  every rank sorts / chain-scans / extends the seeds of its part: contig pairs are independent work units.
+  gather   the accepted alignments (56-byte records + trace bytes, tens of MB) go to rank 0, which runs the redundancy
+           filter (needs all records of a contig pair -- they all come from the part owning the A contig), orders and
+           writes the .1aln once: the reference's la_merge (FastGA.c:3991-4133).
+
+Everything on the data path is the C-ABI of include/fastga_amd.h; torch provides the exchange buffers and the
+collectives, nothing else.  `run_parts_on_one_gpu` drives the same C-ABI calls with the transport replaced by local
+slicing, so that results can be checked for any number of parts on a single GPU.
 """
+import ctypes as C
+
 import numpy as np
 
 NPREFIX = 1 << 24
 
 
+# ------------------------------------------------------------------------------------------------ host-side pieces
+
 def prefix_shards(idx1, idx2, nshards):
-    """[(begin,end)] * nshards covering [0, 2^24), equal cumulative entry count of both tables per shard."""
+    """[(begin,end)] * nshards covering [0, 2^24), equal cumulative entry count of both tables per shard (host copy of
+    the prefix indices; fga_session_prefix_cuts does the same on the device-resident indices)."""
     total = int(idx1[-1]) + (int(idx2[-1]) if idx2 is not None else 0)
     cuts = [0]
     for s in range(1, nshards):
@@ -32,10 +51,164 @@ def prefix_shards(idx1, idx2, nshards):
     return [(cuts[i], cuts[i + 1]) for i in range(nshards)]
 
 
-def gather_counts(dist, value, device=None):
-    """all-gather one integer per rank (the only cross-rank traffic of bench.py's weak-scaling run)."""
+def partition_contigs(weights, nparts):
+    """fga_partition_contigs: part of every A contig from its weight (seed count); same result on every rank"""
+    from .lib import load_library, check
+    L = load_library()
+    w = np.ascontiguousarray(weights, dtype=np.int64)
+    sel = np.zeros(len(w), dtype=np.int32)
+    check(L.fga_partition_contigs(w.ctypes.data_as(C.POINTER(C.c_int64)), len(w), nparts,
+                                  sel.ctypes.data_as(C.POINTER(C.c_int))), "partition")
+    return sel
+
+
+def alns_to_arrays(ptr):
+    """POINTER(Alns) -> (records as ALN_DTYPE array, trace bytes, (ncalls, nwaves)); copies"""
+    from .device import ALN_DTYPE
+    a = ptr.contents
+    n, nt = a.naln, a.ntrace
+    recs = np.frombuffer((C.c_char * (n * ALN_DTYPE.itemsize)).from_address(a.alns), dtype=ALN_DTYPE).copy() \
+        if n > 0 else np.zeros(0, dtype=ALN_DTYPE)
+    tb = np.frombuffer((C.c_char * nt).from_address(a.tbytes), dtype=np.uint8).copy() if nt > 0 \
+        else np.zeros(0, dtype=np.uint8)
+    return recs, tb, (a.ncalls, a.nwaves)
+
+
+def arrays_to_alns(recs, tb, counts=(0, 0)):
+    """(records, trace bytes) -> (Alns struct, keep-alive tuple); the struct points into the arrays"""
+    from .lib import Alns
+    recs = np.ascontiguousarray(recs)
+    tb = np.ascontiguousarray(tb, dtype=np.uint8)
+    a = Alns(len(recs), len(tb), counts[0], counts[1], recs.ctypes.data, tb.ctypes.data)
+    return a, (recs, tb)
+
+
+def all_reduce_counts(dist, counts, device):
     import torch
-    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
-    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
-    dist.all_gather(out, t)
-    return [int(x.item()) for x in out]
+    t = torch.from_numpy(np.ascontiguousarray(counts, dtype=np.int64)).to(device)
+    dist.all_reduce(t)
+    return t.cpu().numpy()
+
+
+def gather_records(dist, recs, tb, counts, device, dst=0):
+    """all ranks' (records, trace bytes) on rank `dst` as a list indexed by rank (None elsewhere).  Sizes first (one
+    small all-gather), then one padded gather per array: tens of MB over xGMI."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    from .device import ALN_DTYPE
+    meta = torch.tensor([len(recs), len(tb), int(counts[0]), int(counts[1])], dtype=torch.int64, device=device)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta)
+    metas = [m.cpu().tolist() for m in metas]
+    out = None
+    for which, arr, unit in ((0, recs.view(np.uint8).reshape(-1), ALN_DTYPE.itemsize), (1, tb, 1)):
+        cap = max(max(m[which] for m in metas) * unit, 1)
+        buf = torch.zeros(cap, dtype=torch.uint8, device=device)
+        if arr.size:
+            buf[:arr.size] = torch.from_numpy(np.ascontiguousarray(arr)).to(device)
+        got = [torch.zeros_like(buf) for _ in range(world)] if rank == dst else None
+        dist.gather(buf, got, dst=dst)
+        if rank == dst:
+            if out is None:
+                out = [[None, None, (m[2], m[3])] for m in metas]
+            for r in range(world):
+                raw = got[r][:metas[r][which] * unit].cpu().numpy()
+                out[r][which] = raw.view(ALN_DTYPE).copy() if which == 0 else raw.copy()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ the sharded run
+
+def run_sharded(ses, dist, prm_kwargs, device):
+    """One pass of the hot path over the session's resident inputs, cut over dist's ranks.  Every rank holds both
+    tables and genomes (replicated: 2 x 33 GB at 3 Gbp fits each GPU's 288 GB several times over).  Returns the stats
+    dict on every rank; rank 0's has the totals of the finished run (nlive, cover) and wrote the output."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    out_path = prm_kwargs.get("out_path")
+    kw = dict(prm_kwargs)
+    if rank != 0:
+        kw["out_path"] = None
+        kw["paf_path"] = None
+    prm = ses.params(**kw)
+    st = ses.new_stats()
+    cuts = prefix_cuts(ses, world)
+    seeds = ses.merge(prm, st, int(cuts[rank]), int(cuts[rank + 1]))
+    n = seeds.count
+    hist = all_reduce_counts(dist, ses.contig_histogram(seeds), device)
+    select = partition_contigs(hist, world)
+    send = torch.empty((max(n, 1), 4), dtype=torch.int32, device=device)
+    off = ses.split_to(seeds, select, world, send.data_ptr())
+    seeds.free()
+    in_splits = np.diff(off).astype(np.int64)
+    t_in = torch.from_numpy(in_splits).to(device)
+    t_out = torch.zeros_like(t_in)
+    dist.all_to_all_single(t_out, t_in)
+    out_splits = t_out.cpu().numpy()
+    total = int(out_splits.sum())
+    recv = torch.empty((max(total, 1), 4), dtype=torch.int32, device=device)
+    dist.all_to_all_single(recv[:total], send[:n], output_split_sizes=out_splits.tolist(),
+                           input_split_sizes=in_splits.tolist())
+    if device != "cpu":
+        torch.cuda.synchronize()
+    del send
+    part = ses.import_seeds([(recv.data_ptr(), total)])
+    del recv
+    raw = ses.align(prm, st, part)
+    recs, tb, counts = alns_to_arrays(raw)
+    ses.free_alns(raw)
+    allr = gather_records(dist, recs, tb, counts, device)
+    if rank == 0:
+        keep, structs = [], []
+        for r in range(world):
+            a, k = arrays_to_alns(allr[r][0], allr[r][1], allr[r][2])
+            keep.append(k)
+            structs.append(C.pointer(a))
+        ses.finish(prm, st, structs)
+    d = ses.stats_dict(st)
+    d["exchange_seeds_out"] = int(n - in_splits[rank])
+    d["part_seeds"] = total
+    d["out_path"] = out_path if rank == 0 else None
+    return d
+
+
+def prefix_cuts(ses, nshards):
+    cuts = np.zeros(nshards + 1, dtype=np.int64)
+    from .lib import check
+    check(ses.L.fga_session_prefix_cuts(ses.h, nshards, cuts.ctypes.data_as(C.POINTER(C.c_int64))), "prefix cuts")
+    return cuts
+
+
+def run_parts_on_one_gpu(ses, nparts, **prm_kwargs):
+    """The sharded run's C-ABI calls on ONE GPU, rank by rank in sequence (merge of each prefix range, histogram,
+    partition, split, import of each part's pieces, align, finish over all parts): the parity check of the multi-GPU
+    path for any number of parts.  Needs torch only for the staging buffers."""
+    import torch
+    prm = ses.params(**prm_kwargs)
+    st = ses.new_stats()
+    cuts = prefix_cuts(ses, nparts)
+    sends, offs, hist = [], [], np.zeros(ses.nctg, dtype=np.int64)
+    merged = []
+    for r in range(nparts):                                   # "rank r": phase 1 on its prefix range
+        seeds = ses.merge(prm, st, int(cuts[r]), int(cuts[r + 1]))
+        hist += ses.contig_histogram(seeds)
+        buf = torch.empty((max(seeds.count, 1), 4), dtype=torch.int32, device="cuda")
+        merged.append((seeds, buf))
+    select = partition_contigs(hist, nparts)
+    for seeds, buf in merged:
+        offs.append(ses.split_to(seeds, select, nparts, buf.data_ptr()))
+        seeds.free()
+        sends.append(buf)
+    raws = []
+    for p in range(nparts):                                   # "rank p": its part's pieces from every rank, phase 2
+        pieces = [(sends[r].data_ptr() + 16 * int(offs[r][p]), int(offs[r][p + 1] - offs[r][p]))
+                  for r in range(nparts)]
+        part = ses.import_seeds(pieces)
+        raws.append(ses.align(prm, st, part))
+    del sends
+    ses.finish(prm, st, raws)
+    for r in raws:
+        ses.free_alns(r)
+    d = ses.stats_dict(st)
+    d["part_seed_counts"] = [int(sum(offs[r][p + 1] - offs[r][p] for r in range(nparts))) for p in range(nparts)]
+    return d

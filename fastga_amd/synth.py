@@ -40,9 +40,10 @@ def mutate(rng, s, rate):
     return res
 
 
-def plant_repeats(rng, contigs, frac, fam_lens=(300, 1000, 3000, 6000), div_lo=0.01, div_hi=0.15):
+def plant_repeats(rng, contigs, frac, fam_lens=(300, 1000, 3000, 6000), div_lo=0.01, div_hi=0.15, mask_frac=1.0):
     """Overwrite ~frac of the bases with diverged copies (both strands) of a few repeat families.
-    Returns a parallel list of boolean masks marking repeat-copy bases."""
+    Returns a parallel list of boolean masks marking repeat-copy bases (every copy with mask_frac = 1, else that
+    fraction of the copies -- an annotation that misses some)."""
     masks = [np.zeros(len(c), dtype=bool) for c in contigs]
     if frac <= 0:
         return masks
@@ -61,9 +62,32 @@ def plant_repeats(rng, contigs, frac, fam_lens=(300, 1000, 3000, 6000), div_lo=0
             continue
         pos = int(rng.integers(0, len(contigs[c]) - len(copy)))
         contigs[c][pos:pos + len(copy)] = copy
-        masks[c][pos:pos + len(copy)] = True
+        if mask_frac >= 1.0 or rng.random() < mask_frac:
+            masks[c][pos:pos + len(copy)] = True
         placed += len(copy)
     return masks
+
+
+def plant_tandem_arrays(rng, contigs, masks, frac, unit_lo=20, unit_hi=400, copies_lo=10, copies_hi=200,
+                        div=0.03, mask_frac=1.0):
+    """Overwrite ~frac of the bases with tandem arrays (a random unit repeated head to tail, every copy diverged by
+    `div`), masked like plant_repeats' copies."""
+    total = sum(len(c) for c in contigs)
+    target = int(frac * total)
+    lens = np.array([len(c) for c in contigs], dtype=np.float64)
+    placed = 0
+    while placed < target:
+        unit = rng.integers(0, 4, int(rng.integers(unit_lo, unit_hi)), dtype=np.uint8)
+        n = int(rng.integers(copies_lo, copies_hi))
+        arr = mutate(rng, np.tile(unit, n), div)
+        c = int(rng.choice(len(contigs), p=lens / lens.sum()))
+        if len(contigs[c]) <= len(arr) + 1:
+            continue
+        pos = int(rng.integers(0, len(contigs[c]) - len(arr)))
+        contigs[c][pos:pos + len(arr)] = arr
+        if mask_frac >= 1.0 or rng.random() < mask_frac:
+            masks[c][pos:pos + len(arr)] = True
+        placed += len(arr)
 
 
 def rearrange(rng, s, inv_frac, swap_frac, mean_block=40000):

@@ -1,6 +1,8 @@
 """Build synthetic inputs end to end with the product's own producers (FASTA -> GDB -> GIX)."""
 import os
 
+import numpy as np
+
 from . import synth
 from .gixio import Gdb, Gix, fasta_to_gdb, build_gix  # noqa: F401
 
@@ -26,3 +28,45 @@ def build_pair(workdir, seed, ncontig, total, divergence, repeat_frac=0.0, inv_f
     ra = build_genome(workdir, names[0], A, None, threads, gix=gix)
     rb = build_genome(workdir, names[1], B, None, threads, gix=gix)
     return ra, rb
+
+
+# ---- BASELINE.json configs as concrete inputs -------------------------------------------------------
+
+def build_config2(workdir, mbp=100.0, seed=1, divergence=0.02, ncontig=40, threads=8, gix=False):
+    """configs[1]: synthetic pair, 2 % divergence, 40 contigs, 5 % repeats, 2 % of 40-kbp blocks inverted / swapped"""
+    return build_pair(workdir, seed=seed, ncontig=ncontig, total=int(mbp * 1e6), divergence=divergence,
+                      repeat_frac=0.05, inv_frac=0.02, swap_frac=0.02, threads=threads, gix=gix)
+
+
+def build_config3(workdir, mbp=1000.0, seed=2, ncontig=40, repeat_frac=0.30, tandem_frac=0.02, mask_frac=0.85,
+                  threads=8, gix=False, name="S"):
+    """configs[2]: one repeat-heavy genome for a self comparison with -M: 30 % of the bases in copies of four repeat
+    families (1-15 % diverged, both strands) plus tandem arrays; mask_frac of the copies are lower case (soft mask), the
+    rest are left for the comparison to find.  Returns the root; the GDB carries the mask intervals."""
+    rng_lens = synth.contig_lengths(seed, ncontig, int(mbp * 1e6))
+    rng = np.random.default_rng(seed)
+    A = [rng.integers(0, 4, int(L), dtype=np.uint8) for L in rng_lens]
+    masks = synth.plant_repeats(rng, A, repeat_frac, mask_frac=mask_frac)
+    synth.plant_tandem_arrays(rng, A, masks, tandem_frac, mask_frac=mask_frac)
+    return build_genome(workdir, name, A, masks=masks, threads=threads, use_mask=True, gix=gix)
+
+
+def digest_1aln(lines):
+    """A digest of a .1aln as ONEview prints it that does not depend on how ties on (aread, abpos) are ordered (the
+    reference orders them by the thread slot that held the record, FastGA.c:3906-3918): record count, md5 of the
+    header lines, md5 of the records as a sorted multiset, md5 of the (aread, abpos) sequence."""
+    import hashlib
+    lines = [ln for ln in lines if ln[:1] not in ("!", "<")]
+    first = next((i for i, ln in enumerate(lines) if ln.startswith("A ")), len(lines))
+    recs, cur = [], []
+    for ln in lines[first:]:
+        if ln.startswith("A ") and cur:
+            recs.append("\n".join(cur))
+            cur = []
+        cur.append(ln)
+    if cur:
+        recs.append("\n".join(cur))
+    order = " ".join(" ".join(r.split("\n", 1)[0].split()[1:3]) for r in recs)
+    md5 = lambda t: hashlib.md5(t.encode()).hexdigest()      # noqa: E731
+    return {"records": len(recs), "header_md5": md5("\n".join(lines[:first])),
+            "records_md5": md5("\n".join(sorted(recs))), "order_md5": md5(order)}

@@ -281,6 +281,8 @@ typedef struct
     const char *command_line;
     const char *paf_path;    /* PAF output after the .1aln ("-": stdout, NULL: none)      */
     int     paf_flags;       /* FGA_PAF_* (-pafm / -pafx / -pafs / -pafS)                 */
+    int64_t pass_seeds;      /* most seeds one sort / search pass takes (0: 1.5 G); more -> phase 2 runs over A-contig
+                                parts, the reference's NPARTS loop (FastGA.c:5186-5204)  */
   } fga_run_params;
 
 typedef struct
@@ -288,9 +290,36 @@ typedef struct
     double  load_s, upload_s, merge_s, sort_s, download_s, chain_s, extend_s, filter_s, write_s, phase23_s;
     double  trace_s, paf_s;  /* PAF output only: edit scripts on the device, regrouping + formatting on the host */
     float   merge_kernel_ms, sort_kernel_ms, extend_kernel_ms, trace_kernel_ms;
+    int     nparts;          /* A-contig parts phase 2 was run over */
   } fga_run_stats;
 
 int  fga_run(const char *root1, const char *root2 /* NULL: self */, const fga_run_params *prm, fga_run_stats *stats);
+
+/* ---- one comparison cut into A-contig parts: several GPUs, or several passes of one --------------------
+ *      Replaces the reference's partition glue -- Select[] / IDBsplit[] / NPARTS (FastGA.c:5057-5095), the seed file
+ *      matrix N_Units / C_Units + buck[] counts and its transpose (FastGA.c:5097-5134, 5160-5184, 4160-4187) -- and the
+ *      final merge of the per-thread record files (la_merge, FastGA.c:3991-4133; here fga_session_finish).
+ *      Phase 1 shards by 12-mer prefix range (fga_merge_params.prefix_begin/end, the reference's thread split
+ *      FastGA.c:2291-2321), phase 2 by A-contig part: contig pairs are independent work units, the redundancy filter
+ *      needs all records of a contig pair together, and those all come from the part that owns the A contig.          */
+/* seeds per A contig (length-sorted index) of a seed buffer: the reference's buck[] counts */
+int  fga_seeds_contig_histogram(fga_dev *dev, const fga_dseeds *seeds, int nctg, int64_t *counts /* host, nctg */);
+/* select[c] = part of A contig c: heaviest contig first, each to the lightest part so far.  A pure function of its
+   arguments (every rank computes the same map from the all-reduced counts) */
+int  fga_partition_contigs(const int64_t *weight, int nctg, int nparts, int *select);
+/* the seeds regrouped by part into a caller-provided DEVICE buffer of fga_seeds_count x 16 bytes (e.g. the send buffer
+   of an all-to-all-v); part p occupies records [part_off[p], part_off[p+1]) */
+int  fga_seeds_split_to(fga_dev *dev, const fga_dseeds *seeds, const int *select, int nctg, int nparts /* <= 64 */,
+                        void *dst_device, int64_t *part_off /* host, nparts+1 */);
+/* a seed buffer made of `npieces` runs of 16-byte records that already are in DEVICE memory (the receive buffer) */
+int  fga_seeds_import(fga_dev *dev, const void *const *src_device, const int64_t *counts, int npieces, fga_dseeds **out);
+const void *fga_seeds_device_ptr(const fga_dseeds *seeds);
+/* 12-mer prefix ranges [cuts[r], cuts[r+1]) of equal merge cost: the phase-1 shards (FastGA.c:2291-2321) */
+int  fga_merge_prefix_cuts(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2 /* NULL: self */, int nshards,
+                           int64_t *cuts /* host, nshards+1 */);
+/* the record sets of several parts as one set in (part, unit, seq) discovery order, unit numbers made distinct: what
+   the gathering rank hands to the redundancy filter (host only) */
+int  fga_alns_concat(const fga_alns *const *raw, int nraw, fga_alns **out);
 
 /* the same with the inputs kept resident in HBM between passes (what bench.py times) */
 typedef struct fga_session fga_session;
@@ -301,6 +330,18 @@ fga_dev *fga_session_device(fga_session *s);
 int64_t  fga_session_table_bytes(const fga_session *s);   /* N1*E1 + N2*E2                          */
 int      fga_session_seed_bytes(const fga_session *s);    /* 1 + IBYTE + JBYTE of the reference seed */
 int64_t  fga_session_bases(const fga_session *s, int which);
+int      fga_session_nctg(const fga_session *s);          /* A contigs of the index (the partition's domain) */
+int      fga_session_prefix_cuts(fga_session *s, int nshards, int64_t *cuts /* nshards+1 */);
+/* fga_session_run in its three stages (stats are accumulated into *stats, which the caller zeroes once):
+ *   merge  : phase 1 over a 12-mer prefix range (0,0 = all)                      -> seeds in HBM
+ *   align  : phase 2 on a set of seeds (consumed): sort, chain scan, extension   -> accepted alignments, unfiltered
+ *   finish : redundancy filter + phase 3 over the record sets of all parts      -> .1aln (and PAF / PSL)          */
+int      fga_session_merge(fga_session *s, const fga_run_params *prm, int64_t prefix_begin, int64_t prefix_end,
+                           fga_dseeds **out, fga_run_stats *stats);
+int      fga_session_align(fga_session *s, const fga_run_params *prm, fga_dseeds *seeds, fga_alns **raw,
+                           fga_run_stats *stats);
+int      fga_session_finish(fga_session *s, const fga_run_params *prm, const fga_alns *const *raw, int nraw,
+                            fga_run_stats *stats);
 
 #ifdef __cplusplus
 }

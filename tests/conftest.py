@@ -1,6 +1,7 @@
 import os
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,4 +30,43 @@ def toy_pair(tmp_path_factory, built_library):
     d = str(tmp_path_factory.mktemp("toy"))
     ra, rb = workload.build_pair(d, seed=11, ncontig=12, total=600_000, divergence=0.03,
                                  repeat_frac=0.05, inv_frac=0.05, swap_frac=0.05)
+    return d, ra, rb
+
+
+@pytest.fixture(scope="session")
+def family_pair(tmp_path_factory, built_library):
+    """0.4 Mbp pair with a 2 kbp family planted 20 times at 1 % divergence: its k-mers have 10-25 partners, so the
+    frequency cutoff decides their fate at -f3, the default 10 and -f30 alike"""
+    from fastga_amd import workload, synth
+    d = str(tmp_path_factory.mktemp("family"))
+    rng = np.random.default_rng(77)
+    lens = synth.contig_lengths(21, 8, 400_000)
+    A = [rng.integers(0, 4, int(L), dtype=np.uint8) for L in lens]
+    fam = rng.integers(0, 4, 2000, dtype=np.uint8)
+    for k in range(20):
+        c = A[k % len(A)]
+        cp = synth.mutate(rng, fam, 0.01)
+        if k % 3 == 0:
+            cp = synth.revcomp(cp)
+        p0 = int(rng.integers(0, len(c) - len(cp) - 1))
+        c[p0:p0 + len(cp)] = cp
+    B = [synth.mutate(rng, c, 0.02) for c in A]
+    return d, workload.build_genome(d, "A", A), workload.build_genome(d, "B", B)
+
+
+@pytest.fixture(scope="session")
+def masked_pair(tmp_path_factory, built_library):
+    """~0.6 Mbp pair whose repeat copies are lower case in BOTH genomes; indices carry the mask bytes (host producer,
+    pinned against `GIXmake -T1 ... #` by tests/test_edge_cases.py)"""
+    from fastga_amd import workload, synth
+    d = str(tmp_path_factory.mktemp("masked"))
+    lens = synth.contig_lengths(9, 10, 600_000)
+    A, mA, B, mB = synth.make_pair(9, lens, 0.03, repeat_frac=0.15, inv_frac=0.05, swap_frac=0.05)
+    rng = np.random.default_rng(3)
+    for m in mB:                                        # B: arbitrary lower-case stretches as well
+        for _ in range(6):
+            s0 = int(rng.integers(0, max(1, len(m) - 3000)))
+            m[s0:s0 + int(rng.integers(200, 3000))] = True
+    ra = workload.build_genome(d, "A", A, masks=mA, use_mask=True)
+    rb = workload.build_genome(d, "B", B, masks=mB, use_mask=True)
     return d, ra, rb

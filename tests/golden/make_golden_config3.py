@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""tests/golden/make_golden_config3.py -- golden digest for BASELINE.json configs[2] (1 Gbp repeat-heavy self comparison,
+soft mask on), produced with the REAL reference (oracle/_ref/FastGA -M).  The genome is not committed (1 Gbp); it is
+regenerated bit for bit from fastga_amd.workload.build_config3 and its seed, index files from the product's host
+producer (whose mask bytes tests/test_edge_cases.py pins against `GIXmake -T1 ... #`; the reference's own masked GIXmake
+races for -T > 1).  Output: config3_<mbp>m_digest.json = fastga_amd.workload.digest_1aln of what ONEview prints for the
+reference's .1aln + the totals of `FastGA -v`.
+
+  python tests/golden/make_golden_config3.py [--mbp 1000] [--threads 8] [--workdir DIR]
+"""
+import argparse, json, os, re, sys, tempfile, time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from fastga_amd import workload                                 # noqa: E402
+from oracle import harness as H                                 # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--mbp", type=float, default=1000.0)
+ap.add_argument("--threads", type=int, default=8)
+ap.add_argument("--workdir", default=None)
+a = ap.parse_args()
+d = a.workdir or tempfile.mkdtemp(prefix="fga_golden_c3_")
+os.makedirs(d, exist_ok=True)
+t = time.time()
+root = workload.build_config3(d, mbp=a.mbp, threads=a.threads, gix=True)
+print(f"genome + GDB + masked GIX: {time.time()-t:.0f} s", flush=True)
+t = time.time()
+r, _ = H.ref_fastga(root, None, d, os.path.join(d, "ref"), threads=a.threads, flags=("-M",))
+print(f"reference FastGA -M -T{a.threads}: {time.time()-t:.0f} s", flush=True)
+err = r.stderr.replace("\r", "\n")
+dig = workload.digest_1aln(H.oneview(os.path.join(d, "ref.1aln")))
+m = re.search(r"Total seeds = (\d+)", err)
+dig["total_seeds"] = int(m.group(1)) if m else None
+m = re.search(r"Total hits over \d+bp = (\d+), (\d+) aln's, (\d+) non-redundant", err)
+dig["hits"], dig["alignments"], dig["nonredundant"] = (int(m.group(k)) for k in (1, 2, 3)) if m else (None,) * 3
+dig["generator"] = f"fastga_amd.workload.build_config3(mbp={a.mbp:g}) + oracle/_ref/FastGA -M -T{a.threads}"
+out = os.path.join(HERE, f"config3_{a.mbp:g}m_digest.json")
+json.dump(dig, open(out, "w"), indent=1)
+print(json.dumps(dig), "->", out)

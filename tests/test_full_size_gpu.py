@@ -1,0 +1,108 @@
+"""Full-size parity on the GPU (BASELINE.json configs at the sizes the bench quotes), through the C-ABI, against the
+REAL reference FastGA run on the same box and the same index files (oracle/_ref travels prebuilt), or -- for the 1 Gbp
+self comparison, which the reference needs minutes for -- against a digest produced with the reference by
+tests/golden/make_golden_config3.py.  Covers what the toy-size tests cannot: contig-long alignments (tens of thousands
+of wave steps), sequence windows falling back to HBM, arena growth, seed-buffer re-runs, the self + soft-mask mode.
+
+Identity is judged on ONEview's text: strict line equality where the reference's own order is deterministic, and
+fastga_amd.workload.digest_1aln (header, records as a multiset, (aread, abpos) order) where records of different
+reference threads tie on (aread, abpos) (la_merge orders those by thread slot, FastGA.c:3906-3918)."""
+import ctypes as C
+import json
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+T = max(4, min(32, os.cpu_count() or 8))
+
+
+def _write_index_files(roots, use_mask=False):
+    """<root>.gix + .ktab.N for the reference, from index builds on the device (byte-identical to the host producer's
+    and to GIXmake's: tests/test_gix_device_gpu.py, tests/test_oracle_vs_reference.py)"""
+    from fastga_amd import device as D
+    from fastga_amd.gixio import Gdb
+    dev = D.Device(0)
+    for r in roots:
+        g = Gdb(r + ".gdb")
+        dgx, xg = D.build_gix_device(dev, g, 8, host_copy=True, use_mask=use_mask)
+        assert dev.L.fga_gix_write_files(xg.h, r.encode()) == 0, dev.L.fga_last_error()
+        dgx.free(); xg.close(); g.close()
+    dev.close()
+
+
+def _compare_with_reference(ra, rb, d, flags=(), strict=True, pafx=False, **kw):
+    from fastga_amd import device as D, workload
+    from oracle import harness as H
+    if not H.have_reference():
+        pytest.skip("oracle/_ref did not travel")
+    ours = os.path.join(d, "ours.1aln")
+    paf = os.path.join(d, "ours.paf") if pafx else None
+    st = D.run(ra, rb, ours, nthreads=T, paf_path=paf, paf_flags=2 if pafx else 0, **kw)
+    H.ref_fastga(ra, rb, d, os.path.join(d, "ref"), threads=T, flags=flags)
+    a, b = H.oneview(ours), H.oneview(os.path.join(d, "ref.1aln"))
+    da, db = workload.digest_1aln(a), workload.digest_1aln(b)
+    assert da == db, (da, db, st)
+    if strict:
+        assert a == b
+    if pafx:
+        exp = H.run([H.ref_bin("ALNtoPAF"), f"-T{T}", "-x", os.path.join(d, "ref.1aln" if a == b else "ours.1aln")],
+                    cwd=d).stdout
+        assert open(paf).read() == exp
+    return st, da
+
+
+def test_config2_100mbp_pair_is_identical_to_the_reference(tmp_path_factory, built_library):
+    """configs[1] at full size: 100 Mbp x 100 Mbp, 2 %: strict .1aln identity and -pafx identity"""
+    from fastga_amd import workload
+    d = str(tmp_path_factory.mktemp("c2"))
+    ra, rb = workload.build_config2(d, mbp=100.0, threads=T)
+    _write_index_files((ra, rb))
+    st, dg = _compare_with_reference(ra, rb, d, strict=True, pafx=True)
+    assert dg["records"] > 1500 and st["nwaves"] > 5_000_000        # contig-long alignments were really extended
+
+
+def test_divergent_50mbp_pair_is_identical_to_the_reference(tmp_path_factory, built_library):
+    """the 10 % shape of configs[4] on one GPU: deep waves, WAVE_LAG pruning, wide waves in the LDS ring"""
+    from fastga_amd import workload
+    d = str(tmp_path_factory.mktemp("c5"))
+    ra, rb = workload.build_pair(d, seed=5, ncontig=40, total=50_000_000, divergence=0.10, repeat_frac=0.05,
+                                 inv_frac=0.02, swap_frac=0.02, threads=T, gix=False)
+    _write_index_files((ra, rb))
+    st, dg = _compare_with_reference(ra, rb, d, strict=True)
+    assert dg["records"] > 500
+
+
+def test_config3_150mbp_self_soft_masked_is_identical_to_the_reference(tmp_path_factory, built_library):
+    """configs[2]'s shape against the live reference: repeat-heavy self comparison with -M (new_self_merge_thread with
+    mlen = plen, FastGA.c:1791-1799; borders at the main diagonal, FastGA.c:3245-3258)"""
+    from fastga_amd import workload
+    d = str(tmp_path_factory.mktemp("c3"))
+    root = workload.build_config3(d, mbp=150.0, threads=T)
+    _write_index_files((root,), use_mask=True)
+    st, dg = _compare_with_reference(root, None, d, flags=("-M",), strict=False, soft_mask=True)
+    assert dg["records"] > 5000
+
+
+@pytest.mark.skipif(os.environ.get("FGA_SKIP_1G") == "1", reason="FGA_SKIP_1G=1")
+def test_config3_1gbp_self_soft_masked_matches_the_reference_digest(tmp_path_factory, built_library):
+    """configs[2] at full size, index built on the device; expected digest: tests/golden/config3_1000m_digest.json, made
+    with the real reference by tests/golden/make_golden_config3.py"""
+    from fastga_amd import device as D, workload
+    from oracle import harness as H
+    gold = os.path.join(HERE, "golden", "config3_1000m_digest.json")
+    if not os.path.exists(gold):
+        pytest.skip("golden digest not generated")
+    exp = json.load(open(gold))
+    if not os.path.exists(H.ref_bin("ONEview")):
+        pytest.skip("oracle/_ref/ONEview did not travel")
+    d = str(tmp_path_factory.mktemp("c3g"))
+    root = workload.build_config3(d, mbp=1000.0, threads=T)
+    ours = os.path.join(d, "ours.1aln")
+    st = D.run(root, None, ours, nthreads=T, soft_mask=True)
+    got = workload.digest_1aln(H.oneview(ours))
+    assert st["nseeds"] == exp["total_seeds"]
+    for k in ("records", "header_md5", "records_md5", "order_md5"):
+        assert got[k] == exp[k], (k, got, exp, st)

@@ -84,27 +84,6 @@ def test_self_seed_merge_oracle_matches_reference(toy_pair, tmp_path):
     assert np.array_equal(H.sorted_records(seeds[1], w), H.sorted_records(c, w))
 
 
-@pytest.fixture(scope="module")
-def family_pair(tmp_path_factory, built_library):
-    """0.4 Mbp pair with a 2 kbp family planted 20 times at 1 % divergence: its k-mers have 10-25 partners, so the
-    frequency cutoff decides their fate at -f3, the default 10 and -f30 alike"""
-    from fastga_amd import workload, synth
-    d = str(tmp_path_factory.mktemp("family"))
-    rng = np.random.default_rng(77)
-    lens = synth.contig_lengths(21, 8, 400_000)
-    A = [rng.integers(0, 4, int(L), dtype=np.uint8) for L in lens]
-    fam = rng.integers(0, 4, 2000, dtype=np.uint8)
-    for k in range(20):
-        c = A[k % len(A)]
-        cp = synth.mutate(rng, fam, 0.01)
-        if k % 3 == 0:
-            cp = synth.revcomp(cp)
-        p0 = int(rng.integers(0, len(c) - len(cp) - 1))
-        c[p0:p0 + len(cp)] = cp
-    B = [synth.mutate(rng, c, 0.02) for c in A]
-    return d, workload.build_genome(d, "A", A), workload.build_genome(d, "B", B)
-
-
 @needs_ref
 @pytest.mark.parametrize("freq", [3, 30])
 def test_seed_merge_oracle_freq_branch_matches_reference(family_pair, tmp_path, freq):
@@ -121,24 +100,6 @@ def test_seed_merge_oracle_freq_branch_matches_reference(family_pair, tmp_path, 
     assert len(seeds[0]) + len(seeds[1]) == nh * w
     assert np.array_equal(H.sorted_records(seeds[0], w), H.sorted_records(n, w))
     assert np.array_equal(H.sorted_records(seeds[1], w), H.sorted_records(c, w))
-
-
-@pytest.fixture(scope="module")
-def masked_pair(tmp_path_factory, built_library):
-    """~0.6 Mbp pair whose repeat copies are lower case in BOTH genomes; indices carry the mask bytes (host producer,
-    pinned against `GIXmake -T1 ... #` by tests/test_edge_cases.py)"""
-    from fastga_amd import workload, synth
-    d = str(tmp_path_factory.mktemp("masked"))
-    lens = synth.contig_lengths(9, 10, 600_000)
-    A, mA, B, mB = synth.make_pair(9, lens, 0.03, repeat_frac=0.15, inv_frac=0.05, swap_frac=0.05)
-    rng = np.random.default_rng(3)
-    for m in mB:                                        # B: arbitrary lower-case stretches as well
-        for _ in range(6):
-            s0 = int(rng.integers(0, max(1, len(m) - 3000)))
-            m[s0:s0 + int(rng.integers(200, 3000))] = True
-    ra = workload.build_genome(d, "A", A, masks=mA, use_mask=True)
-    rb = workload.build_genome(d, "B", B, masks=mB, use_mask=True)
-    return d, ra, rb
 
 
 @needs_ref

@@ -1,0 +1,94 @@
+"""GPU: one comparison cut into A-contig parts (the reference's Select[] / seed file matrix / la_merge,
+FastGA.c:5057-5134, 5160-5184, 3991-4133).  The multi-GPU run's C-ABI calls are driven on ONE GPU for 1, 2, 4 and 8 parts
+(fastga_amd.parallel.run_parts_on_one_gpu: the RCCL all-to-all-v replaced by local slicing) and must give the
+reference's .1aln every time; fga_session_run's own multi-pass mode (pass_seeds) likewise; the routing kernels are
+checked record for record."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _view(path):
+    from oracle import harness as H
+    return H.oneview(path)
+
+
+def test_routing_kernels_histogram_split_import(toy_pair):
+    import torch
+    from fastga_amd import device as D
+    from fastga_amd.parallel import partition_contigs
+    d, ra, rb = toy_pair
+    ses = D.Session(ra, rb)
+    prm, st = ses.params(), ses.new_stats()
+    seeds = ses.merge(prm, st)
+    host = seeds.download()
+    actg = (host["actg"] >> 8).astype(np.int64)
+    hist = ses.contig_histogram(seeds)
+    assert np.array_equal(hist, np.bincount(actg, minlength=ses.nctg))
+    for nparts in (1, 3, 8):
+        sel = partition_contigs(hist, nparts)
+        buf = torch.empty((len(host), 4), dtype=torch.int32, device="cuda")
+        off = ses.split_to(seeds, sel, nparts, buf.data_ptr())
+        got = buf.cpu().numpy().view(D.SEED_DTYPE).reshape(-1)
+        assert off[0] == 0 and off[-1] == len(host)
+        void = np.dtype((np.void, 16))
+        for p in range(nparts):
+            piece = got[off[p]:off[p + 1]]
+            assert np.all(sel[(piece["actg"] >> 8).astype(np.int64)] == p)
+            exp = host[sel[actg] == p]
+            assert np.array_equal(np.sort(piece.view(void)), np.sort(exp.view(void)))
+        # import: pieces from two "ranks" become one seed buffer
+        mid = len(host) // 2
+        imp = ses.import_seeds([(buf.data_ptr(), mid), (buf.data_ptr() + 16 * mid, len(host) - mid)])
+        assert np.array_equal(imp.download().view(void), got.view(void))
+        imp.free()
+    seeds.free()
+    ses.close()
+
+
+def _reference(ra, rb, w, flags=()):
+    from oracle import harness as H
+    if not H.have_reference():
+        pytest.skip("oracle/_ref did not travel")
+    H.ref_fastga(ra, rb, w, os.path.join(w, "ref"), threads=8, flags=flags)
+    return H.oneview(os.path.join(w, "ref.1aln"))
+
+
+@pytest.mark.parametrize("mode", ["pair", "symmetric", "self"])
+def test_any_number_of_parts_gives_the_reference_1aln(toy_pair, tmp_path, mode):
+    from fastga_amd import device as D, workload
+    from fastga_amd.parallel import run_parts_on_one_gpu
+    d, ra, rb = toy_pair
+    w = str(tmp_path)
+    b = None if mode == "self" else rb
+    kw = dict(symmetric=True, freq=6) if mode == "symmetric" else {}
+    ref = _reference(ra, b, w, flags=("-S", "-f6") if mode == "symmetric" else ())
+    ses = D.Session(ra, b)
+    whole = ses.run(out_path=os.path.join(w, "whole.1aln"), nthreads=8, **kw)
+    base = _view(os.path.join(w, "whole.1aln"))
+    assert workload.digest_1aln(base) == workload.digest_1aln(ref)
+    for nparts in (1, 2, 4, 8):
+        out = os.path.join(w, f"parts{nparts}.1aln")
+        st = run_parts_on_one_gpu(ses, nparts, out_path=out, nthreads=8, **kw)
+        assert _view(out) == base, nparts                         # identical to the undivided run, line for line
+        assert st["nseeds"] == whole["nseeds"] and st["nalns"] == whole["nalns"] and st["nlive"] == whole["nlive"]
+        assert sum(st["part_seed_counts"]) == whole["nseeds"] * (2 if mode == "self" else 1)
+        if nparts > 1:
+            assert min(st["part_seed_counts"]) > 0
+    ses.close()
+
+
+def test_session_run_in_several_passes(toy_pair, tmp_path):
+    """fga_session_run cuts phase 2 into A-contig parts by itself when the merge finds more seeds than one pass should
+    take (pass_seeds): the reference's NPARTS loop (FastGA.c:5186-5204)"""
+    from fastga_amd import device as D
+    d, ra, rb = toy_pair
+    w = str(tmp_path)
+    one = D.run(ra, rb, os.path.join(w, "one.1aln"), nthreads=8)
+    many = D.run(ra, rb, os.path.join(w, "many.1aln"), nthreads=8, pass_seeds=max(1, one["nseeds"] // 5))
+    assert one["nparts"] == 1 and many["nparts"] >= 5
+    assert _view(os.path.join(w, "many.1aln")) == _view(os.path.join(w, "one.1aln"))
+    assert many["nseeds"] == one["nseeds"] and many["nhits"] == one["nhits"] and many["nlive"] == one["nlive"]

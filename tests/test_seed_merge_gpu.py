@@ -60,6 +60,39 @@ def test_pair_merge_freq_and_mask(loaded):
     _compare(dev, A, B, dA, dB, freq=50, soft_mask=True)
 
 
+def test_soft_mask_modes_with_real_mask_bytes(masked_pair):
+    """-M on tables that carry mask bytes: pair, the flipped pass of -S, and the self comparison (BASELINE config 3's
+    mode, new_self_merge_thread with mlen = plen, FastGA.c:1791-1799); the oracle's branches are pinned to the
+    reference's seed files in tests/test_oracle_vs_reference.py"""
+    from fastga_amd.gixio import Gix
+    from fastga_amd import device as D
+    d, ra, rb = masked_pair
+    A, B = Gix(ra + ".gix"), Gix(rb + ".gix")
+    dev = D.Device(0)
+    dA, dB = dev.upload(A), dev.upload(B)
+    plain = _compare(dev, A, B, dA, dB)
+    assert 0 < _compare(dev, A, B, dA, dB, soft_mask=True) < plain
+    _compare(dev, B, A, dB, dA, flip=True, soft_mask=True)
+    sp = _compare(dev, A, None, dA, None)
+    assert 0 < _compare(dev, A, None, dA, None, soft_mask=True) < sp
+    _compare(dev, A, None, dA, None, soft_mask=True, freq=4)
+    dA.free(); dB.free(); dev.close()
+
+
+def test_frequency_cutoff_on_a_repeat_family(family_pair):
+    from fastga_amd.gixio import Gix
+    from fastga_amd import device as D
+    d, ra, rb = family_pair
+    A, B = Gix(ra + ".gix"), Gix(rb + ".gix")
+    dev = D.Device(0)
+    dA, dB = dev.upload(A), dev.upload(B)
+    n3, n10, n30 = (_compare(dev, A, B, dA, dB, freq=f) for f in (3, 10, 30))
+    assert n3 < n10 < n30
+    _compare(dev, A, None, dA, None, freq=30)
+    _compare(dev, B, A, dB, dA, flip=True, freq=30)
+    dA.free(); dB.free(); dev.close()
+
+
 def test_self_merge(loaded):
     dev, A, B, dA, dB = loaded
     _compare(dev, A, None, dA, None)
