@@ -53,6 +53,11 @@ static int gix_exists(const char *root)
 
 /* load GDB + GIX of both genomes and make them resident in HBM */
 int fga_session_open(const char *root1, const char *root2, int device, fga_session **out)
+{ return fga_session_open_threads(root1,root2,device,8,out); }
+
+/* nthreads: GIXmake's -T for an index the session has to build itself -- it decides the contig padding of a short GDB
+   and the table parts (SURVEY.md hard part 9), i.e. the layout FastGA -T<n> would have got from its GIXmake call */
+int fga_session_open_threads(const char *root1, const char *root2, int device, int nthreads, fga_session **out)
 { fga_session *Z = calloc(1,sizeof(fga_session));
   double t0;
   *out = NULL;
@@ -72,8 +77,11 @@ int fga_session_open(const char *root1, const char *root2, int device, fga_sessi
     if (fga_dev_open(device,&Z->dev)) goto fail;
     t0 = fga_wall();
     Z->devbuilt = !have1 || !have2;
-    if (have1 ? fga_dgix_upload(Z->dev,Z->x1,&Z->d1) : fga_dgix_build(Z->dev,Z->g1,8,FGA_GIX_SOFT_MASK,&Z->d1,&Z->x1)) goto fail;
-    if (!Z->self && (have2 ? fga_dgix_upload(Z->dev,Z->x2,&Z->d2) : fga_dgix_build(Z->dev,Z->g2,8,FGA_GIX_SOFT_MASK,&Z->d2,&Z->x2)))
+    if (nthreads < 1) nthreads = 1;
+    if (have1 ? fga_dgix_upload(Z->dev,Z->x1,&Z->d1)
+              : fga_dgix_build(Z->dev,Z->g1,nthreads,FGA_GIX_SOFT_MASK,&Z->d1,&Z->x1)) goto fail;
+    if (!Z->self && (have2 ? fga_dgix_upload(Z->dev,Z->x2,&Z->d2)
+                           : fga_dgix_build(Z->dev,Z->g2,nthreads,FGA_GIX_SOFT_MASK,&Z->d2,&Z->x2)))
       goto fail;
   }
   if (Z->x1->nctg < Z->g1->ncontig || (!Z->self && Z->x2->nctg < Z->g2->ncontig))
@@ -410,6 +418,7 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
   if (fga_session_finish(Z,P,(const fga_alns *const *) raw,nparts,&st)) goto done;
   st.phase23_s = fga_wall() - tstart - st.trace_s - st.paf_s;
   st.nparts = nparts;
+  st.bases1 = Z->g1->seqtot; st.bases2 = Z->self ? Z->g1->seqtot : Z->g2->seqtot;
   status = 0;
 
 done:
@@ -425,7 +434,7 @@ done:
 int fga_run(const char *root1, const char *root2, const fga_run_params *P, fga_run_stats *S)
 { fga_session *Z;
   int rc;
-  if (fga_session_open(root1,root2,P->device,&Z))
+  if (fga_session_open_threads(root1,root2,P->device,P->nthreads > 0 ? P->nthreads : 8,&Z))
     return 1;
   rc = fga_session_run(Z,P,S);
   fga_session_close(Z);

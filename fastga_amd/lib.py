@@ -82,7 +82,7 @@ class RunStats(C.Structure):
                [(n, C.c_double) for n in ("load_s", "upload_s", "merge_s", "sort_s", "download_s", "chain_s",
                                           "extend_s", "filter_s", "write_s", "phase23_s", "trace_s", "paf_s")] + \
                [(n, C.c_float) for n in ("merge_kernel_ms", "sort_kernel_ms", "extend_kernel_ms",
-                                         "trace_kernel_ms")] + [("nparts", C.c_int)]
+                                         "trace_kernel_ms")] + [("nparts", C.c_int), ("bases1", C.c_int64), ("bases2", C.c_int64)]
 
 
 class SortParams(C.Structure):
@@ -169,6 +169,7 @@ def _declare(L):
         "fga_gap_improve": (i32, [vp, vp, P(Alns), P(Traces)]),
         "fga_run": (i32, [cp, cp, P(RunParams), P(RunStats)]),
         "fga_session_open": (i32, [cp, cp, i32, P(vp)]),
+        "fga_session_open_threads": (i32, [cp, cp, i32, i32, P(vp)]),
         "fga_session_run": (i32, [vp, P(RunParams), P(RunStats)]),
         "fga_session_close": (None, [vp]),
         "fga_session_device": (vp, [vp]),

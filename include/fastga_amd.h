@@ -291,6 +291,7 @@ typedef struct
     double  trace_s, paf_s;  /* PAF output only: edit scripts on the device, regrouping + formatting on the host */
     float   merge_kernel_ms, sort_kernel_ms, extend_kernel_ms, trace_kernel_ms;
     int     nparts;          /* A-contig parts phase 2 was run over */
+    int64_t bases1, bases2;  /* bases of the two genomes (the reference's "seeds per G1 position") */
   } fga_run_stats;
 
 int  fga_run(const char *root1, const char *root2 /* NULL: self */, const fga_run_params *prm, fga_run_stats *stats);
@@ -324,6 +325,8 @@ int  fga_alns_concat(const fga_alns *const *raw, int nraw, fga_alns **out);
 /* the same with the inputs kept resident in HBM between passes (what bench.py times) */
 typedef struct fga_session fga_session;
 int      fga_session_open(const char *root1, const char *root2, int device, fga_session **out);
+/* nthreads = the -T the reference would hand to the GIXmake it runs for a missing index (fga_session_open: 8) */
+int      fga_session_open_threads(const char *root1, const char *root2, int device, int nthreads, fga_session **out);
 int      fga_session_run(fga_session *s, const fga_run_params *prm, fga_run_stats *stats);
 void     fga_session_close(fga_session *s);
 fga_dev *fga_session_device(fga_session *s);

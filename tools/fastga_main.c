@@ -1,20 +1,82 @@
 /* FastGA -- drop-in command line for the MI355X hot path (links libfastga_amd.so).
  *
- * Accepts the reference grammar (FastGA.c:62-66, README "FastGA"):
- *   FastGA [-vkMS] [-L:<log>] [-T<int(8)>] [-P<dir>] [-1:<out>] [-f<int(10)>] [-c<int(85)>] [-s<int(1000)>]
+ * Accepts the reference grammar (FastGA.c:62-66, 4444-4637; README "FastGA"):
+ *   FastGA [-vkMS] [-L:<log>] [-T<int(8)>] [-P<dir>] [<format(-paf)>] [-f<int(10)>] [-c<int(85)>] [-s<int(1000)>]
  *          [-l<int(100)>] [-i<float(.7)>]  <source1>[.gdb|.1gdb|.gix|.fa...]  [<source2>]
- * What differs: the sub-process glue is in-process -- a missing GDB / GIX is built with this library's own
- * producers (fga_fasta_to_gdb, fga_gix_build) instead of system("FAtoGDB"/"GIXmake"), and only the .1aln output
- * (-1:<name>) PAF (-paf[mxsS]*, the default) and PSL (-psl), both on stdout, are produced natively.
+ *          <format> = -paf[mxsS]* | -psl | -1:<align:path>[.1aln]
+ * and honours its process-level contract: -v statistics on stderr and -L:<log> the same lines appended to a log file,
+ * both with the reference's "Resources for phase" / "Total Resources" lines (gene_core.c:514-593); -T threads (also the
+ * layout of an index that has to be built: the -T the reference hands to GIXmake, FastGA.c:4757-4760); -P / $TMPDIR must
+ * name a usable directory (FastGA.c:4456-4458, 4561) although nothing is spilled to it -- seeds and sort panels stay in
+ * HBM; a GDB created from a FASTA source is removed again unless -k (Clean_Exit, FastGA.c:152-196).
+ * What differs: the sub-process glue is in-process -- a missing GDB / GIX is built with this library's own producers
+ * (fga_fasta_to_gdb; the index on the device, or as files with -k) instead of system("FAtoGDB"/"GIXmake"), PAF / PSL are
+ * written natively instead of through ALNtoPAF / ALNtoPSL, and "#<mask>" arguments (external .1bed / .1ano mask files
+ * for GIXmake) are refused with a message: soft masks come from lower-case FASTA (-M).
  */
 #define _GNU_SOURCE
 #include <stdio.h>
 #include <stdlib.h>
+#include <stdarg.h>
 #include <string.h>
 #include <unistd.h>
+#include <time.h>
+#include <sys/time.h>
+#include <sys/resource.h>
 
 #include "fastga_amd.h"
 
+static FILE *Log = NULL;
+static int   Verbose = 0;
+
+/* a statistics line: stderr with -v, the log with -L */
+static void say(const char *fmt, ...)
+{ va_list ap;
+  if (Verbose)
+    { va_start(ap,fmt); vfprintf(stderr,fmt,ap); va_end(ap); fflush(stderr); }
+  if (Log != NULL)
+    { va_start(ap,fmt); vfprintf(Log,fmt,ap); va_end(ap); fflush(Log); }
+}
+
+/* ---- the reference's resource lines: "<user>u  <system>s  <wall>w  <cpu %>" since the start / the last phase ---- */
+typedef struct { struct rusage ru; struct timespec wall; } stamp;
+static stamp Start, Phase;
+
+static void stamp_now(stamp *s)
+{ getrusage(RUSAGE_SELF,&s->ru);
+  clock_gettime(CLOCK_MONOTONIC,&s->wall);
+}
+
+static void put_span(FILE *f, double secs, char unit)
+{ const long ms = (long) (secs*1000. + .5);
+  if (ms >= 60000)
+    fprintf(f,"  %ld:%02ld.%03ld%c",ms/60000,(ms/1000)%60,ms%1000,unit);
+  else
+    fprintf(f,"  %ld.%03ld%c",ms/1000,ms%1000,unit);
+}
+
+static void resources_to(FILE *f, const stamp *from, const stamp *now, int total)
+{ const double u = (now->ru.ru_utime.tv_sec - from->ru.ru_utime.tv_sec) + 1e-6*(now->ru.ru_utime.tv_usec - from->ru.ru_utime.tv_usec);
+  const double s = (now->ru.ru_stime.tv_sec - from->ru.ru_stime.tv_sec) + 1e-6*(now->ru.ru_stime.tv_usec - from->ru.ru_stime.tv_usec);
+  const double w = (now->wall.tv_sec - from->wall.tv_sec) + 1e-9*(now->wall.tv_nsec - from->wall.tv_nsec);
+  fprintf(f,total ? "\n  Total Resources:" : "\n  Resources for phase:");
+  put_span(f,u,'u'); put_span(f,s,'s'); put_span(f,w,'w');
+  fprintf(f,"  %.1f%%",w > 0. ? 100.*(u+s)/w : 0.);
+  if (total)
+    fprintf(f,"  %ldMB",(long) (now->ru.ru_maxrss/1000000));
+  fprintf(f,"\n");
+  fflush(f);
+}
+
+static void resources(int total)
+{ stamp now;
+  stamp_now(&now);
+  if (Verbose) resources_to(stderr,total ? &Start : &Phase,&now,total);
+  if (Log != NULL) resources_to(Log,total ? &Start : &Phase,&now,total);
+  if (!total) Phase = now;
+}
+
+/* ---- sources ---- */
 static int exists(const char *fmt, const char *root)
 { char *p;
   int r;
@@ -42,10 +104,34 @@ static char *root_of(const char *src, int *is_fasta)
   return r;
 }
 
-static int prepare(const char *src, char **root, int nthreads, int verbose, int want_gix_files)
+typedef struct
+  { char *root;
+    int   made_gdb;        /* this run created <root>.gdb + .<root>.bps: they go again unless -k */
+  } source;
+
+static source Src[2];
+static int    Keep = 0;
+
+/* what Clean_Exit does (FastGA.c:152-196): drop the GDB this run created, unless it succeeded with -k */
+static void clean_exit(int status)
+{ int i;
+  if (!(status == 0 && Keep))
+    for (i = 0; i < 2; i++)
+      if (Src[i].root != NULL && Src[i].made_gdb)
+        { char *p, *slash = strrchr(Src[i].root,'/');
+          if (asprintf(&p,"%s.gdb",Src[i].root) >= 0) { unlink(p); free(p); }
+          if (slash != NULL)
+            { if (asprintf(&p,"%.*s/.%s.bps",(int) (slash-Src[i].root),Src[i].root,slash+1) >= 0) { unlink(p); free(p); } }
+          else if (asprintf(&p,".%s.bps",Src[i].root) >= 0) { unlink(p); free(p); }
+        }
+  if (Log != NULL) fclose(Log);
+  exit(status);
+}
+
+static int prepare(const char *src, source *S, int nthreads, int want_gix_files)
 { int isfa;
   char *r = root_of(src,&isfa);
-  *root = r;
+  S->root = r;
   if (!exists("%s.1gdb",r) && !exists("%s.gdb",r))          /* both ONEcode forms of the skeleton are read */
     { static const char *fext[] = { ".fa", ".fna", ".fasta", ".fa.gz", ".fna.gz", ".fasta.gz", NULL };
       char *fa = NULL;
@@ -59,10 +145,11 @@ static int prepare(const char *src, char **root, int nthreads, int verbose, int 
               { if (access(p,R_OK) == 0) fa = p; else free(p); }
           }
       if (fa == NULL)
-        { fprintf(stderr,"FastGA: cannot find a GDB or FASTA for %s\n",src);
+        { fprintf(stderr,"FastGA: Cannot find a GDB or FASTA for %s\n",src);
           return 1;
         }
-      if (verbose) fprintf(stderr,"  Creating genome data base (GDB) %s.gdb\n",r);
+      say("\n  Creating genome data base (GDB) %s.gdb\n",r);
+      S->made_gdb = 1;
       if (fga_fasta_to_gdb(fa,r,0))
         { fprintf(stderr,"FastGA: %s\n",fga_last_error());
           return 1;
@@ -71,8 +158,8 @@ static int prepare(const char *src, char **root, int nthreads, int verbose, int 
     }
   if (!exists("%s.gix",r) && want_gix_files)        /* otherwise the index is built on the device, in HBM only */
     { fga_gdb *g;
-      if (verbose) fprintf(stderr,"  Creating genome index (GIX) %s.gix\n",r);
-      if (fga_gdb_open(r,&g) || fga_gix_build(g,r,nthreads))
+      say("\n  Creating genome index (GIX) %s.gix\n",r);
+      if (fga_gdb_open(r,&g) || fga_gix_build_masked(g,r,nthreads,fga_gdb_nmask(g) > 0))
         { fprintf(stderr,"FastGA: %s\n",fga_last_error());
           return 1;
         }
@@ -81,11 +168,27 @@ static int prepare(const char *src, char **root, int nthreads, int verbose, int 
   return 0;
 }
 
+static int arg_int(const char *arg, const char *what, int *val)
+{ char *e;
+  long v = strtol(arg+2,&e,10);
+  if (e == arg+2 || *e != '\0')
+    { fprintf(stderr,"FastGA: -%c '%s' argument is not an integer\n",arg[1],arg+2);
+      return 1;
+    }
+  if (v < 0)
+    { fprintf(stderr,"FastGA: %s must be non-negative (%ld)\n",what,v);
+      return 1;
+    }
+  *val = (int) v;
+  return 0;
+}
+
 int main(int argc, char *argv[])
 { fga_run_params P;
   fga_run_stats S;
-  char *src[2] = { NULL, NULL }, *root[2] = { NULL, NULL }, *out = NULL, *outpath = NULL;
-  int nsrc = 0, verbose = 0, keep = 0, paf = 0, i;
+  char *src[2] = { NULL, NULL }, *out = NULL, *outpath = NULL;
+  const char *tmpdir, *logpath = NULL;
+  int nsrc = 0, paf = 0, i;
   int cmin = 85, cbreak = 1000;
   double ident = .7;
   char cmd[4096];
@@ -96,21 +199,35 @@ int main(int argc, char *argv[])
   cmd[0] = '\0';
   for (i = 0; i < argc && cl < sizeof(cmd)-2; i++)
     cl += snprintf(cmd+cl,sizeof(cmd)-cl,"%s%s",i ? " " : "",argv[i]);
+  tmpdir = getenv("TMPDIR");
+  if (tmpdir == NULL) tmpdir = ".";
 
   for (i = 1; i < argc; i++)
     if (argv[i][0] == '-')
       switch (argv[i][1])
       { case '1':
-          if (argv[i][2] != ':') { fprintf(stderr,"FastGA: -1 must be followed by :<name>\n"); return 1; }
+          if (argv[i][2] != ':' || argv[i][3] == '\0')
+            { fprintf(stderr,"FastGA: option -1 must be followed by :<filename>\n"); return 1; }
           out = argv[i]+3;
           break;
-        case 'f': P.freq = atoi(argv[i]+2); break;
-        case 'c': cmin = atoi(argv[i]+2); break;
-        case 's': cbreak = atoi(argv[i]+2); break;
-        case 'l': P.align_min = atoi(argv[i]+2); break;
-        case 'i': ident = atof(argv[i]+2); break;
-        case 'T': P.nthreads = atoi(argv[i]+2); break;
-        case 'P': case 'L': break;
+        case 'f': if (arg_int(argv[i],"maximum seed frequency",&P.freq)) return 1; break;
+        case 'c': if (arg_int(argv[i],"minimum seed cover",&cmin)) return 1; break;
+        case 's': if (arg_int(argv[i],"seed chain break threshold",&cbreak)) return 1; break;
+        case 'l': if (arg_int(argv[i],"minimum alignment length",&P.align_min)) return 1; break;
+        case 'T': if (arg_int(argv[i],"number of threads to use",&P.nthreads)) return 1; break;
+        case 'i':
+          { char *e;
+            ident = strtod(argv[i]+2,&e);
+            if (e == argv[i]+2 || *e != '\0')
+              { fprintf(stderr,"FastGA: -i '%s' argument is not a real number\n",argv[i]+2); return 1; }
+          }
+          break;
+        case 'P': tmpdir = argv[i]+2; break;
+        case 'L':
+          if (argv[i][2] != ':' || argv[i][3] == '\0')
+            { fprintf(stderr,"FastGA: option -L must be followed by :<filename>\n"); return 1; }
+          logpath = argv[i]+3;
+          break;
         case 'p':
           if (strncmp(argv[i]+1,"paf",3) == 0)
             { const char *f;
@@ -138,8 +255,8 @@ int main(int argc, char *argv[])
           { const char *f;
             for (f = argv[i]+1; *f; f++)
               switch (*f)
-              { case 'v': verbose = 1; break;
-                case 'k': keep = 1; break;
+              { case 'v': Verbose = 1; break;
+                case 'k': Keep = 1; break;
                 case 'M': P.soft_mask = 1; break;
                 case 'S': P.symmetric = 1; break;
                 default:
@@ -149,59 +266,80 @@ int main(int argc, char *argv[])
           }
       }
     else if (argv[i][0] == '#')
-      P.soft_mask = 1;
+      { fprintf(stderr,"FastGA: mask file arguments (%s) are not supported by this build: the index is made from the GDB's\n"
+                       "        own lower-case intervals; soft-mask the FASTA and use -M\n",argv[i]);
+        return 1;
+      }
     else if (nsrc < 2)
       src[nsrc++] = argv[i];
-  if (nsrc == 0)
-    { fprintf(stderr,"Usage: FastGA [-vkMS] [-T<int(8)>] [-f<int(10)>] [-c<int(85)>] [-s<int(1000)>] [-l<int(100)>]"
-                     " [-i<float(.7)>] [-paf[mxsS]* | -psl | -1:<out>] <source1> [<source2>]\n");
+    else
+      nsrc = 3;
+  if (nsrc == 0 || nsrc > 2)
+    { fprintf(stderr,"\nUsage: FastGA [-vkMS] [-L:<log:path>] [-T<int(8)>] [-P<dir($TMPDIR)>] [<format(-paf)>]\n"
+                     "              [-f<int(10)>] [-c<int(85)>] [-s<int(1000)>] [-l<int(100)>] [-i<float(.7)>]\n"
+                     "              <source1:path>[<precursor>] [<source2:path>[<precursor>]]\n\n"
+                     "         <format> = -paf[mxsS]* | -psl | -1:<align:path>[.1aln]\n\n");
       return 1;
     }
+  if ((P.paf_flags & FGA_PAF_CIGAR_M) && (P.paf_flags & FGA_PAF_CIGAR_X))
+    { fprintf(stderr,"FastGA: Only one of -paf[m] or -paf[x] can be set\n"); return 1; }
+  if ((P.paf_flags & FGA_PAF_CS_SHORT) && (P.paf_flags & FGA_PAF_CS_LONG))
+    { fprintf(stderr,"FastGA: Only one of -paf[s] or -paf[S] can be set\n"); return 1; }
+  if (P.freq < 1 || P.freq > 255)
+    { fprintf(stderr,"FastGA: The adaptive seed count cutoff must be in [1,255]\n"); return 1; }
+  if (ident < .55 || ident >= 1.)
+    { fprintf(stderr,"FastGA: '-i' minimum alignment similarity must be in [0.55,1.0)\n"); return 1; }
+  if (P.nthreads < 1) P.nthreads = 1;
+  if (access(tmpdir,W_OK|X_OK) != 0)
+    { fprintf(stderr,"FastGA: Cannot create temporary files in directory %s\n",tmpdir); return 1; }
+  if (logpath != NULL && (Log = fopen(logpath,"a")) == NULL)
+    { fprintf(stderr,"FastGA: Cannot open logfile %s for output\n",logpath); return 1; }
+
   if (out == NULL)                       /* like the reference, PAF on stdout is the default output */
     paf = 1;
   if (paf)
     P.paf_path = "-";
-  if (ident < .55 || ident >= 1.)
-    { fprintf(stderr,"FastGA: Minimum alignment similarity %g must be in [0.55,1.0)\n",ident);
-      return 1;
-    }
   P.chain_min = 2*cmin; P.chain_break = 2*cbreak;
   P.align_rate = 1.-ident;
   P.command_line = cmd;
   if (out != NULL)
-  { size_t n = strlen(out);
-    if (n > 5 && strcmp(out+n-5,".1aln") == 0)
-      outpath = strdup(out);
-    else if (asprintf(&outpath,"%s.1aln",out) < 0)
-      return 1;
-    P.out_path = outpath;
-  }
+    { size_t n = strlen(out);
+      if (n > 5 && strcmp(out+n-5,".1aln") == 0)
+        outpath = strdup(out);
+      else if (asprintf(&outpath,"%s.1aln",out) < 0)
+        clean_exit(1);
+      P.out_path = outpath;
+    }
   for (i = 0; i < nsrc; i++)
-    if (prepare(src[i],root+i,P.nthreads,verbose,keep))
-      return 1;
-  if (nsrc == 2 && strcmp(root[0],root[1]) == 0)
+    if (prepare(src[i],Src+i,P.nthreads,Keep))
+      clean_exit(1);
+  if (nsrc == 2 && strcmp(Src[0].root,Src[1].root) == 0)
     nsrc = 1;
-  if (verbose) fprintf(stderr,"\n  Using GPU %d and %d host threads\n",P.device,P.nthreads);
-  if (fga_run(root[0],nsrc == 2 ? root[1] : NULL,&P,&S))
+
+  stamp_now(&Start);
+  Phase = Start;
+  if (Log != NULL) fprintf(Log,"\n%s\n",cmd);
+  say("\n  Using GPU %d and %d host threads\n",P.device,P.nthreads);
+  if (fga_run(Src[0].root,nsrc == 2 ? Src[1].root : NULL,&P,&S))
     { fprintf(stderr,"FastGA: %s\n",fga_last_error());
-      return 1;
+      clean_exit(1);
     }
-  if (verbose)
-    { fprintf(stderr,"\n  Total seeds = %lld, ave. len = %.1f\n",(long long) S.nseeds,
-                     S.nseeds ? (1.*S.seed_len_sum)/S.nseeds : 0.);
-      fprintf(stderr,"  Resources for phase:  merge %.3fs (kernel %.3f ms)\n",S.merge_s,S.merge_kernel_ms);
-      fprintf(stderr,"\n  Total hits over %dbp = %lld, %lld aln's, %lld non-redundant aln's of ave len %lld\n",
-                     cmin,(long long) S.nhits,(long long) S.nalns,(long long) S.nlive,
-                     (long long) (S.nlive ? S.cover/S.nlive : 0));
-      fprintf(stderr,"  Resources for phase:  sort %.3fs (kernel %.3f ms) download %.3fs chain %.3fs extend %.3fs"
-                     " (kernel %.3f ms, %lld calls, %lld waves) filter %.3fs write %.3fs\n",
-                     S.sort_s,S.sort_kernel_ms,S.download_s,S.chain_s,S.extend_s,S.extend_kernel_ms,
-                     (long long) S.ncalls,(long long) S.nwaves,S.filter_s,S.write_s);
-      if (paf)
-        fprintf(stderr,"  PAF: edit scripts %.3fs (kernels %.3f ms), regroup + format %.3fs\n",
-                       S.trace_s,S.trace_kernel_ms,S.paf_s);
-      fprintf(stderr,"  Load %.3fs  upload %.3fs\n",S.load_s,S.upload_s);
-    }
+  say("\n  Total seeds = %lld, ave. len = %.1f, seeds per G1 position = %.1f\n",(long long) S.nseeds,
+      S.nseeds ? (1.*S.seed_len_sum)/S.nseeds : 0.,S.bases1 > 0 ? (1.*S.nseeds)/S.bases1 : 0.);
+  say("  Phase 1 on the device: merge %.3fs (kernel %.3f ms); index + genomes to HBM %.3fs + %.3fs\n",
+      S.merge_s,S.merge_kernel_ms,S.load_s,S.upload_s);
+  say("\n  Total hits over %dbp = %lld, %lld aln's, %lld non-redundant aln's of ave len %lld\n",
+      cmin,(long long) S.nhits,(long long) S.nalns,(long long) S.nlive,(long long) (S.nlive ? S.cover/S.nlive : 0));
+  say("  Phase 2 on the device (%d part%s): sort %.3fs (kernel %.3f ms) chain %.3fs extend %.3fs (kernel %.3f ms, %lld calls,"
+      " %lld waves) filter %.3fs write %.3fs\n",S.nparts,S.nparts == 1 ? "" : "s",
+      S.sort_s,S.sort_kernel_ms,S.chain_s,S.extend_s,S.extend_kernel_ms,
+      (long long) S.ncalls,(long long) S.nwaves,S.filter_s,S.write_s);
+  if (paf)
+    say("  %s: edit scripts %.3fs (kernels %.3f ms), regroup + format %.3fs\n",(P.paf_flags & FGA_OUT_PSL) ? "PSL" : "PAF",
+        S.trace_s,S.trace_kernel_ms,S.paf_s);
+  resources(0);
+  resources(1);
   free(outpath);
+  clean_exit(0);
   return 0;
 }
