@@ -2,16 +2,31 @@
 """bench.py -- throughput of the FastGA seed-and-extend hot path on MI355X.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under
-torch.distributed.run, one rank per GPU.  A *step* is one pass of the hot path over one synthetic genome pair
-already resident in HBM (2-bit genomes uploaded and both GIX tables built on the device -- fga_dgix_build -- before the
-timed region; no index files are involved).  Workload = BASELINE.json
-configs[1]: synthetic 100 Mbp vs 100 Mbp, 2 % divergence, 40 contigs, repeats + rearrangements.
-Weak scaling: every rank owns its own pair (different seed) -- contig-pair work units are independent, so
-there is no data-path collective; only the per-rank record counts are gathered.
+torch.distributed.run, one rank per GPU.  A *step* is one pass of the hot path -- seed merge -> sort -> chain scan ->
+wave extension -> redundancy filter -> .1aln written -- over ONE synthetic genome pair whose 2-bit genomes and GIX
+tables are already resident in HBM (uploaded / built on the device before the timed region; no index files).
 
-Rank 0 prints ONE JSON line with `roofline` (dominant kernel = seed merge, algorithmic bytes / HIP-event time)
-and `cpu_baseline` (the real reference FastGA from oracle/_ref, or the oracle port, timed on this box's cores on
-a bounded sample).
+Workload = BASELINE.json configs[1]: synthetic pair, 2 % divergence, 2.5-Mbp contigs, 5 % repeats,
+2 % rearranged blocks, 100 Mbp per genome PER GPU:
+  N = 1   100 Mbp x 100 Mbp, 40 contigs -- the configuration the metric is quoted on.
+  N > 1   ONE comparison of (N x 100 Mbp) x (N x 100 Mbp), 40 N contigs, cut over the N ranks the way the reference cuts
+          it over parts and threads (fastga_amd/parallel.py): every rank merges one 12-mer prefix range of the two
+          (replicated) tables, the seeds go to the rank that owns their A contig in one RCCL all-to-all-v, every rank
+          sorts / chains / extends its A-contig part, rank 0 gathers the records, filters, orders and writes the .1aln.
+          Per-GPU work is fixed as N grows ("scaling": "weak"); `value` = whole-comparison Gbp-pair per second.
+`--strong-mbp M` instead fixes the comparison at M Mbp per genome for every N (strong scaling; the extension's critical
+path -- the longest contig's serial wave chain -- bounds it).
+
+Rank 0 prints ONE JSON line with, beside the contract's fields:
+  roofline      dominant kernel = seed merge: algorithmic bytes (N1 E1 + N2 E2 + S x seed bytes) / HIP-event time of the
+                launch, against 8 TB/s; `traffic` = HBM bytes per launch from the rocprofv3 PMC pass of this round
+                (profiles/rNN_pmc_summary.csv, written by tools/profile_round.sh with the commit it was taken at)
+  extend        the wave-extension kernel (87 % of the step): B_ext = 2 (bases compared + diagonal probes) + 2 trace
+                elements, GB/s, wave steps / s, G cell updates / s, wavefronts busy on average
+  cold          the same comparison on the span of the reference's "Total Resources" line: GDB files on disk -> genomes
+                to HBM -> both indices built on the device -> one step -> .1aln closed (N = 1 only)
+  cpu_baseline  the REAL reference FastGA (oracle/_ref) on this box's host cores on the same pair, and -- the parity
+                gate -- whether its .1aln is identical to ours (`identical_1aln`; N = 1 only)
 """
 import argparse
 import json
@@ -32,33 +47,28 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--mbp", type=float, default=100.0, help="size of each genome of the pair, Mbp")
+    ap.add_argument("--mbp", type=float, default=100.0, help="size of each genome per GPU, Mbp")
+    ap.add_argument("--strong-mbp", type=float, default=0.0, help="fixed genome size for every N (strong scaling)")
     ap.add_argument("--div", type=float, default=0.02)
-    ap.add_argument("--contigs", type=int, default=40)
+    ap.add_argument("--contigs", type=int, default=40, help="contigs per 100 Mbp")
     ap.add_argument("--workdir", default=None)
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--verify", action="store_true", help="also compare our .1aln with the reference's (ONEview)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the reference leg (cpu_baseline + parity)")
+    ap.add_argument("--no-cold", action="store_true")
     return ap.parse_args()
 
 
-def cpu_baseline(args, ra, rb, workdir, verify_against=None):
+def cpu_baseline(args, mbp, ra, rb, workdir, ours_1aln):
     """The REAL reference FastGA (oracle/_ref, built from /root/reference by oracle/Makefile) on this box's host
     cores, on the bench's own pair (GDB from our FASTA producer, .gix/.ktab files written from the device index build, so
-    the reference does not spend its wall time in GIXmake); falls back to a smaller pair if the bench pair is large, and
-    to the oracle's seed-merge port if the reference binaries did not travel."""
+    the reference does not spend its wall time in GIXmake), and the comparison of its .1aln with ours; falls back to the
+    oracle's seed-merge port if the reference binaries did not travel."""
     from oracle import harness as H
+    from fastga_amd import workload
     ncores = os.cpu_count() or 1
     threads = max(1, min(32, ncores))
-    mbp = args.mbp
     if H.have_reference():
         d = os.path.join(workdir, "cpu")
         os.makedirs(d, exist_ok=True)
-        if mbp > 150:                       # keep the baseline leg to tens of seconds
-            from fastga_amd import workload
-            mbp = 100.0
-            ra, rb = workload.build_pair(d, seed=4242, ncontig=max(threads, 40), total=int(mbp * 1e6),
-                                         divergence=args.div, repeat_frac=0.05, inv_frac=0.02, swap_frac=0.02,
-                                         threads=threads)
         t = time.time()
         r, _ = H.ref_fastga(ra, rb, d, os.path.join(d, "ref"), threads=threads)
         dt = time.time() - t
@@ -66,11 +76,11 @@ def cpu_baseline(args, ra, rb, workdir, verify_against=None):
         out = {"value": mbp * 1e-3 / dt, "unit": "Gbp-pair/s", "cores": threads, "kind": "reference",
                "sample": f"oracle/_ref/FastGA -T{threads} -1:ref on the bench pair ({mbp:g} Mbp x {mbp:g} Mbp, "
                          f"prebuilt GDB/GIX, tmp on local disk): {dt:.2f} s wall; " + " | ".join(phases)}
-        if verify_against is not None and mbp == args.mbp:
-            a = H.oneview(verify_against)
-            b = H.oneview(os.path.join(d, "ref.1aln"))
-            out["identical_1aln"], out["identical_1aln_strict"] = same_1aln(a, b)
-            out["records"] = sum(1 for ln in b if ln.startswith("A "))
+        a = H.oneview(ours_1aln)
+        b = H.oneview(os.path.join(d, "ref.1aln"))
+        out["identical_1aln"] = workload.digest_1aln(a) == workload.digest_1aln(b)
+        out["identical_1aln_strict"] = a == b
+        out["records"] = sum(1 for ln in b if ln.startswith("A "))
         return out
     from fastga_amd.gixio import Gix
     A, B = Gix(ra + ".gix"), Gix(rb + ".gix")
@@ -89,6 +99,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     if world > 1:
+        # torch FIRST: one HIP runtime per process (fastga_amd/lib.py::load_library)
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local)
@@ -96,23 +107,34 @@ def main():
 
     from fastga_amd import workload, device as D
 
-    workdir = args.workdir or tempfile.mkdtemp(prefix=f"fga_bench_r{rank}_")
-    os.makedirs(workdir, exist_ok=True)
-    total = int(args.mbp * 1e6)
+    shared = args.workdir or os.path.join(tempfile.gettempdir(), f"fga_bench_{os.environ.get('MASTER_PORT', os.getpid())}")
+    os.makedirs(shared, exist_ok=True)
+    mbp = args.strong_mbp if args.strong_mbp > 0 else args.mbp * world
+    ncontig = max(world, int(round(args.contigs * mbp / 100.0)))
     threads = max(1, min(32, (os.cpu_count() or 8) // max(1, world)))
     t0 = time.time()
-    # FASTA -> GDB on the host; the two indices are built on the device when the session opens (no .gix files)
-    ra, rb = workload.build_pair(workdir, seed=1 + rank, ncontig=args.contigs, total=total,
-                                 divergence=args.div, repeat_frac=0.05, inv_frac=0.02, swap_frac=0.02,
-                                 threads=threads, gix=False)
+    ra, rb = os.path.join(shared, "A"), os.path.join(shared, "B")
+    if rank == 0:
+        # FASTA -> GDB on the host, once; the two indices are built on the device when a session opens (no .gix files)
+        workload.build_config2(shared, mbp=mbp, seed=1, divergence=args.div, ncontig=ncontig, threads=threads, gix=False)
+    if dist is not None:
+        dist.barrier()
     prep_s = time.time() - t0
 
-    # inputs resident in HBM before the timed region: both GIX tables + both 2-bit genomes
+    # inputs resident in HBM before the timed region: both GIX tables + both 2-bit genomes (every rank holds all of them)
     ses = D.Session(ra, rb, device=local)
-    out1aln = os.path.join(workdir, f"bench_r{rank}.1aln")
+    out1aln = os.path.join(shared, "bench.1aln")
+    kw = dict(out_path=out1aln, nthreads=threads, command_line="bench.py FastGA hot path")
 
-    def step():
-        return ses.run(out_path=out1aln, nthreads=threads, command_line="bench.py FastGA hot path")
+    if dist is None:
+        def step():
+            return ses.run(**kw)
+    else:
+        from fastga_amd.parallel import run_sharded
+        dev = f"cuda:{local}"
+
+        def step():
+            return run_sharded(ses, dist, kw, dev)
 
     def barrier():
         ses.sync()
@@ -121,19 +143,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # informational (not part of `value`): kernel time of one device index build (HIP events of the session's own build
-    # of genome B); rank 0 also writes the .gix/.ktab files of both genomes from device builds, for the reference
-    # FastGA of the cpu_baseline leg
-    gix_ms = ses.dev_wrapper().stage_ms(5)
-    do_cpu = (not args.no_cpu) and world == 1          # the CPU baseline leg runs on rank 0 at N=1 only
-    if rank == 0 and do_cpu:
-        from fastga_amd.gixio import Gdb
-        for r in (ra, rb):
-            g = Gdb(r + ".gdb")
-            dgx, xg = D.build_gix_device(ses.dev_wrapper(), g, 8, host_copy=True)
-            if ses.L.fga_gix_write_files(xg.h, r.encode()) != 0:
-                raise RuntimeError("cannot write index files for the CPU baseline")
-            dgx.free(); xg.close(); g.close()
+    gix_ms = ses.dev_wrapper().stage_ms(5)            # kernel time of the session's own device build of genome B's index
+    do_cpu = (not args.no_cpu) and world == 1          # the reference leg runs on rank 0 at N=1 only
 
     for _ in range(args.warmup):
         step()
@@ -145,60 +156,94 @@ def main():
     barrier()
     elapsed = time.time() - t
 
-    nrec = stats[-1]["nlive"]
     if dist is not None:
         import torch
         tt = torch.tensor([elapsed], device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        # the only cross-rank traffic of the path: gather the per-rank record counts (RCCL over xGMI)
-        cnt = torch.tensor([nrec], device="cuda", dtype=torch.int64)
-        allc = [torch.zeros_like(cnt) for _ in range(world)]
-        dist.all_gather(allc, cnt)
-        nrec = int(sum(int(c.item()) for c in allc))
+        # totals over the ranks (counts only; the records themselves were gathered inside the step)
+        keys = ("nseeds", "nhits", "nalns", "ncalls", "nwaves", "ext_cells", "ext_bases", "ext_trace", "part_seeds",
+                "exchange_seeds_out")
+        v = torch.tensor([int(stats[-1][k]) for k in keys], device="cuda", dtype=torch.int64)
+        allv = [torch.zeros_like(v) for _ in range(world)]
+        dist.all_gather(allv, v)
+        tot = {k: [int(a[i].item()) for a in allv] for i, k in enumerate(keys)}
+        km = torch.tensor([sum(s["merge_kernel_ms"] for s in stats) / len(stats),
+                           sum(s["extend_kernel_ms"] for s in stats) / len(stats)], device="cuda")
+        dist.all_reduce(km, op=dist.ReduceOp.MAX)
+        kavg, kext = float(km[0].item()), float(km[1].item())
+    else:
+        tot = None
+        kavg = sum(s["merge_kernel_ms"] for s in stats) / len(stats)
+        kext = sum(s["extend_kernel_ms"] for s in stats) / len(stats)
 
     if rank == 0:
+        last = stats[-1]
         ms_per_step = 1000.0 * elapsed / args.steps
         pair_gbp = 0.5 * (ses.bases[0] + ses.bases[1]) * 1e-9
-        value = world * pair_gbp / (ms_per_step / 1000.0)
-        last = stats[-1]
-        nseeds = last["nseeds"]
+        value = pair_gbp / (ms_per_step / 1000.0)
+        S = (lambda k: sum(tot[k])) if tot is not None else (lambda k: int(last[k]))
+        nseeds = S("nseeds")
+        # algorithmic bytes of the merge launches of one step: every table entry once in its on-disk width, every seed
+        # once in the reference's record width (with N ranks each launch covers 1/N of the prefix space)
         alg_bytes = ses.table_bytes + nseeds * ses.seed_bytes
-        kavg = sum(s["merge_kernel_ms"] for s in stats) / len(stats)
-        achieved = alg_bytes / (kavg * 1e-3) / 1e9
+        achieved = alg_bytes / max(1, world) / (kavg * 1e-3) / 1e9          # per GPU, slowest rank's launch time
         stage_ms = {k: round(1000 * sum(s[k] for s in stats) / len(stats), 2)
-                    for k in ("merge_s", "sort_s", "download_s", "chain_s", "extend_s", "filter_s", "write_s")}
+                    for k in ("merge_s", "sort_s", "chain_s", "extend_s", "filter_s", "write_s")}
+        b_ext = 2 * (S("ext_bases") + S("ext_cells")) + 2 * S("ext_trace")
         out = {
             "metric": "Gbp-pair aligned/sec", "value": value, "unit": "Gbp-pair/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32/u64",
-            "data": "synthetic",
-            "config": {"workload": f"synthetic {args.mbp:g} Mbp vs {args.mbp:g} Mbp, {args.div*100:g}% divergence, "
-                                   f"{args.contigs} contigs, 5% repeats, 2% inversions/swaps (BASELINE configs[1]); "
-                                   f"one pair per GPU",
+            "higher_is_better": True, "scaling": "strong" if args.strong_mbp > 0 else "weak", "vs_baseline": None,
+            "dtype": "u8/int32/u64", "data": "synthetic",
+            "config": {"workload": f"synthetic {mbp:g} Mbp vs {mbp:g} Mbp, {args.div*100:g}% divergence, {ncontig} contigs, "
+                                   f"5% repeats, 2% inversions/swaps (BASELINE configs[1]"
+                                   + (")" if world == 1 else f" x {world}: ONE comparison over {world} GPUs, "
+                                      f"{args.mbp:g} Mbp per genome per GPU)"),
                        "step": "seed merge -> sort -> chain scan -> wave extension -> redundancy filter -> .1aln "
-                               "written; GIX tables + genomes resident in HBM",
-                       "seeds": int(nseeds), "hits": int(last["nhits"]), "alignments": int(last["nalns"]),
-                       "records": int(nrec), "la_calls": int(last["ncalls"]), "waves": int(last["nwaves"]),
+                               "written; GIX tables + genomes resident in HBM"
+                               + ("" if world == 1 else "; phase 1 by k-mer prefix range, seeds all-to-all-v by A-contig "
+                                  "part (RCCL), phase 2 by part, records gathered to rank 0"),
+                       "seeds": int(nseeds), "hits": S("nhits"), "alignments": S("nalns"),
+                       "records": int(last["nlive"]), "la_calls": S("ncalls"), "waves": S("nwaves"),
                        "stage_ms": stage_ms,
                        "kernel_ms": {"merge": round(kavg, 3), "sort": round(last["sort_kernel_ms"], 3),
-                                     "extend": round(last["extend_kernel_ms"], 3)},
+                                     "extend": round(kext, 3)},
                        "prep_s": round(prep_s, 1),
                        "gix_build_on_device_ms": None if gix_ms is None else round(gix_ms, 2)},
-            "roofline": {"kernel": "seed_merge_wave_kernel (+ seed_merge_kernel on oversize tiles, hole closing; "
-                                   "HIP events around the whole merge launch)", "bound": "hbm", "achieved": achieved,
+            "roofline": {"kernel": "seed merge launch (HIP events around fga_seed_merge's kernels on the library's stream)",
+                         "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes": int(alg_bytes), "kernel_ms": kavg},
+                         "traffic": None, "algorithmic_bytes": int(alg_bytes // max(1, world)), "kernel_ms": kavg},
+            "extend": {"kernel": "extend_kernel", "bound": "latency (one wavefront per unit; longest unit's serial chain)",
+                       "kernel_ms": kext, "algorithmic_bytes": int(b_ext),
+                       "achieved_GBps": b_ext / (kext * 1e-3) / 1e9 if kext > 0 else None,
+                       "frac_of_hbm_peak": b_ext / (kext * 1e-3) / 1e9 / HBM_PEAK_GBS / max(1, world) if kext > 0 else None,
+                       "wave_steps_per_s": S("nwaves") / (kext * 1e-3) if kext > 0 else None,
+                       "gcell_updates_per_s": S("ext_cells") / (kext * 1e-3) / 1e9 if kext > 0 else None,
+                       "avg_wave_width": S("ext_cells") / max(1, S("nwaves")),
+                       "avg_busy_wavefronts": round(float(last["ext_busy_waves"]), 1)},
         }
-        if abs(args.mbp - 100.0) < 1e-9 and abs(args.div - 0.02) < 1e-9:    # the profiled configuration
+        if tot is not None:
+            out["config"]["per_rank"] = {"part_seeds": tot["part_seeds"], "seeds_sent": tot["exchange_seeds_out"],
+                                         "alignments": tot["nalns"], "waves": tot["nwaves"]}
+        if world == 1 and abs(mbp - 100.0) < 1e-9 and abs(args.div - 0.02) < 1e-9:    # the profiled configuration
             tr, src = pmc_traffic()
             if tr is not None:
                 out["roofline"]["traffic"] = tr
                 out["roofline"]["traffic_source"] = src
+        if world == 1 and not args.no_cold:
+            out["cold"] = cold_run(D, ra, rb, shared, threads, pair_gbp)
         if do_cpu:
             try:
-                out["cpu_baseline"] = cpu_baseline(args, ra, rb, workdir,
-                                                   verify_against=out1aln if args.verify else None)
+                from fastga_amd.gixio import Gdb
+                for r in (ra, rb):                    # index files for the reference, from device builds
+                    g = Gdb(r + ".gdb")
+                    dgx, xg = D.build_gix_device(ses.dev_wrapper(), g, 8, host_copy=True)
+                    if ses.L.fga_gix_write_files(xg.h, r.encode()) != 0:
+                        raise RuntimeError("cannot write index files for the CPU baseline")
+                    dgx.free(); xg.close(); g.close()
+                out["cpu_baseline"] = cpu_baseline(args, mbp, ra, rb, shared, out1aln)
             except Exception as e:      # the baseline leg must never take the bench line down
                 out["cpu_baseline"] = {"value": None, "unit": "Gbp-pair/s", "cores": 0, "kind": "reference",
                                        "sample": f"failed: {e}"}
@@ -210,66 +255,53 @@ def main():
         dist.destroy_process_group()
 
 
-def same_1aln(a, b):
-    """(same, strictly same) for two ONEview texts.  The reference's la_merge breaks ties on (aread, abpos) by the memory
-    address of the record, i.e. by the thread slot whose file held it (MAPARE, FastGA.c:3906-3918), so its own output
-    order on such ties changes with -T; `same` therefore means: identical header, identical records as a multiset and
-    identical (aread, abpos) sequence.  `strict` is line-by-line equality."""
-    keep = lambda lines: [ln for ln in lines if ln[0] not in "!<"]      # noqa: E731
-    a, b = keep(a), keep(b)
-    if a == b:
-        return True, True
-
-    def split(lines):
-        first = next((i for i, ln in enumerate(lines) if ln.startswith("A ")), len(lines))
-        recs, cur = [], []
-        for ln in lines[first:]:
-            if ln.startswith("A ") and cur:
-                recs.append(tuple(cur))
-                cur = []
-            cur.append(ln)
-        if cur:
-            recs.append(tuple(cur))
-        return lines[:first], recs
-
-    ha, ra = split(a)
-    hb, rb = split(b)
-    if ha != hb or sorted(ra) != sorted(rb):
-        return False, False
-    ka = [tuple(int(v) for v in r[0].split()[1:3]) for r in ra]
-    kb = [tuple(int(v) for v in r[0].split()[1:3]) for r in rb]
-    return ka == kb, False
+def cold_run(D, ra, rb, workdir, threads, pair_gbp):
+    """One comparison from files on disk to the .1aln closed -- the span of the reference's "Total Resources" line
+    (FastGA.c:4828-4829, 5263-5264), which starts with GDB (+ GIX) present: here the two GDBs are read, the bases go to
+    HBM, both indices are BUILT on the device (no .gix files exist yet), one step runs, the .1aln is written and
+    everything is released again (fga_run).  The files are in the page cache, as they are for the reference leg."""
+    out = os.path.join(workdir, "cold.1aln")
+    best = None
+    for _ in range(2):                  # the second run no longer pays the one-off HIP module / allocator warm-up
+        t = time.time()
+        st = D.run(ra, rb, out, nthreads=threads, command_line="bench.py FastGA cold")
+        dt = time.time() - t
+        if best is None or dt < best[0]:
+            best = (dt, st)
+    dt, st = best
+    return {"value": pair_gbp / dt, "unit": "Gbp-pair/s", "ms": round(1000 * dt, 1),
+            "span": "GDB on disk -> genomes to HBM -> 2 index builds on the device -> merge/sort/chain/extend/filter -> "
+                    ".1aln closed -> resources released (fga_run; best of 2)",
+            "load_ms": round(1000 * st["load_s"], 1), "upload_and_index_ms": round(1000 * st["upload_s"], 1),
+            "phases_ms": round(1000 * st["phase23_s"], 1)}
 
 
 def pmc_traffic():
-    """HBM bytes per seed_merge_kernel launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/r*_pmc_summary.csv): FETCH_SIZE is in KiB and reads exactly half of a wide coalesced stream on
-    gfx950 (MI355X_MICROARCH.md, HBM section) -> x2; WRITE_SIZE in KiB."""
+    """HBM bytes per merge launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/r*_pmc_summary.csv, regenerated each round by tools/profile_round.sh, which records the commit):
+    FETCH_SIZE is in KiB and reads exactly half of a wide coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM section)
+    -> x2; WRITE_SIZE in KiB.  All kernels of the merge launch are added up."""
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv")))
     if not files:
         return None, None
-    # the merge is two kernels per launch: seed_merge_wave_kernel (one wavefront per tile) and seed_merge_kernel
-    # (workgroup per tile, only the oversize tiles the wave kernel queued); their traffic adds up
     fetch = write = None
-    for r in csv.DictReader(open(files[-1])):
-        if "seed_merge_wave_kernel" in r["kernel"] or "seed_merge_kernel" in r["kernel"]:
+    commit = ""
+    for r in csv.DictReader(ln for ln in open(files[-1]) if not ln.startswith("#")):
+        k = r["kernel"]
+        if "seed_merge" in k or "merge_partition" in k or "hole_fill" in k or "gather_big" in k or "merge_" in k:
             if r["counter"] == "FETCH_SIZE":
                 fetch = (fetch or 0.0) + float(r["avg_per_launch"])
             elif r["counter"] == "WRITE_SIZE":
                 write = (write or 0.0) + float(r["avg_per_launch"])
+    for ln in open(files[-1]):
+        if ln.startswith("# commit"):
+            commit = ln.split(":", 1)[1].strip()
     if fetch is None or write is None:
         return None, None
-    return int((2.0 * fetch + write) * 1024), os.path.relpath(files[-1], ROOT)
-
-
-def A_seqtot(root):
-    from fastga_amd.gixio import Gdb
-    g = Gdb(root + ".gdb")
-    n = g.seqtot
-    g.close()
-    return n
+    src = os.path.relpath(files[-1], ROOT) + (f" @ {commit}" if commit else "")
+    return int((2.0 * fetch + write) * 1024), src
 
 
 if __name__ == "__main__":

@@ -96,6 +96,13 @@ extern "C" void fga_dev_free(fga_dev *dev, void *ptr)
   hipFree(ptr);
 }
 
+extern "C" int fga_dev_download(fga_dev *dev, void *host_dst, const void *device_src, size_t bytes)
+{ FGA_HIP(hipSetDevice(dev->device));
+  if (bytes > 0)
+    FGA_HIP(hipMemcpy(host_dst,device_src,bytes,hipMemcpyDeviceToHost));
+  return 0;
+}
+
 extern "C" void fga_dev_close(fga_dev *d)
 { if (d == NULL) return;
   hipSetDevice(d->device);

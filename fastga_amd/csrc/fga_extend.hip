@@ -71,7 +71,10 @@ struct ext_shared
 __shared__ ext_shared ext_lds;     // the one LDS block of a (single-wavefront) workgroup
 
 struct ext_prof
-  { unsigned long long t_steps, t_unwind, t_total, nsteps; };
+  { unsigned long long t_steps, t_unwind, t_total, nsteps;
+    unsigned long long ncells;        // diagonal updates: sum over wave steps of the wave width (cell updates)
+    unsigned long long nbases;        // bases compared by the snakes (each counts once per sequence in B_ext)
+  };
 
 struct ext_state              // wave-uniform alignment state (the reference's Path + trace pointer)
   { int abpos, bbpos, aepos, bepos, diffs, tlen;
@@ -700,7 +703,8 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
   wseq_from(B,Bin,(LDS_PTR uint32_t *) shp->winB);
   GLB_PTR v4i *cells = (GLB_PTR v4i *) uni64((int64_t) cells_in);
   const int maxd = UNI(maxd_in), mida = UNI(mida_in), minp = UNI(minp_in), maxp = UNI(maxp_in), aoff = UNI(aoff_in);
-  unsigned long long nwaves = 0, nspill = 0;
+  unsigned long long nwaves = 0, nspill = 0, ncells = 0;
+  unsigned int lsum = 0;                   // this lane's snake bases (wave-reduced once, at the end of the call)
   const int ts = TS, path_ave = UNI(G.path_ave), mscore = UNI(G.mscore);
   const int64_t cell_cap64 = uni64(G.cell_cap);
   const int cell_cap = (int) (cell_cap64 < (1ll << 30) ? cell_cap64 : (1ll << 30));     // 32-bit arena arithmetic
@@ -735,6 +739,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
 
   // ---- wave 0 (align.c:425-512 / 949-1035) ---------------------------------------------------------
   { const int span = hgh-low+1;
+    ncells += (unsigned long long) span;
     for (int j0 = 0; j0 < span; j0 += 64)
       { int k; bool act;
         if (regmode) { k = KOF(lane); act = k >= low && k <= hgh; }
@@ -766,6 +771,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                 if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
                 x -= L;
               }
+            lsum += (unsigned int) L;
             c = (x << 1) - k;
             if (S > 0) cnt = (x >= na) ? (x-na)/ts+1 : 0;
             else       cnt = (x <= na) ? (na-x)/ts+1 : 0;
@@ -848,6 +854,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
         BAIL(2)
       dif += 1;
       const int width = hgh-low+1;
+      ncells += (unsigned long long) width;
 
       // ---- representation switch ----
       if (UNLIKELY(regmode && width > REG_MAXW))
@@ -950,6 +957,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                     x -= L;
                   }
                 b = (L >= 61) ? ~0ull : ((b << L) | ((1ull << L) - 1));
+                lsum += (unsigned int) L;
                 c = (x << 1) - k;
                 { const int dx = (S > 0) ? x-na : na-x, dh = (S > 0) ? hm-na : na-hm;
                   cross = (dx >= 0) ? dx/ts+1 : 0;
@@ -1101,6 +1109,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                     }
                   if (L > 0)
                     b = (L >= 61) ? ~0ull : ((b << L) | ((1ull << L) - 1));
+                  lsum += (unsigned int) L;
                   c = (x << 1) - k;
                   na = shp->NA[k & RMASK];
                   { const int dx = (S > 0) ? x-na : na-x, dh = (S > 0) ? hm-na : na-hm;
@@ -1201,6 +1210,11 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
 
   PF.t_steps += clock64() - tstart;
   PF.nsteps += nspill;
+  PF.ncells += ncells;
+  { int tot;                                // one wave reduction per call (lsum < 2^31: a call touches < 2^31 bases per lane)
+    wscan_add_excl((int) lsum,tot);
+    PF.nbases += (unsigned long long) (unsigned int) tot;
+  }
   nwaves_out += nwaves;
   WIN_BACK()
   ext_unwind<S>(G,cells_in,trace,P,PF,mida,aoff,trima,trimx,trimd,trimha,mind);
@@ -1270,7 +1284,7 @@ void extend_kernel(ext_args G)
   uint16_t *trace = G.trace + (int64_t) blockIdx.x * G.trace_cap;
   const int64_t tmid = G.trace_cap/2;
   unsigned long long ncalls = 0, nwaves = 0;
-  ext_prof PF; PF.t_steps = PF.t_unwind = PF.t_total = PF.nsteps = 0;
+  ext_prof PF; PF.t_steps = PF.t_unwind = PF.t_total = PF.nsteps = 0; PF.ncells = PF.nbases = 0;
   const unsigned long long tk0 = clock64();
 
   while (1)
@@ -1393,6 +1407,8 @@ void extend_kernel(ext_args G)
       atomicAdd(G.counters+9,PF.t_unwind);
       atomicMax(G.counters+10,nwaves);
       atomicAdd(G.counters+11,PF.nsteps);
+      atomicAdd(G.counters+12,PF.ncells);
+      atomicAdd(G.counters+13,PF.nbases);
     }
 }
 
@@ -1611,6 +1627,9 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
               (long long) H->nunits,hc[11]);
 
     R->naln = (int64_t) hc[0]; R->ntrace = (int64_t) hc[1]; R->ncalls = (int64_t) hc[2]; R->nwaves = (int64_t) hc[3];
+    R->ncells = (int64_t) hc[12]; R->nbases = (int64_t) hc[13];
+    // wavefronts busy on average = wave time spent in steps + unwinds, over the longest wavefront's lifetime
+    R->busy_waves = hc[7] > 0 ? (double) (hc[8] + hc[9]) / (double) hc[7] : 0.;
     if (hc[4] != 0)
       { fga_set_error("fga_extend: %s",hc[4] == 1 ? "trace-point arena exhausted (raise cell_cap)"
                                                    : "wave wider than the LDS ring (512 diagonals)");

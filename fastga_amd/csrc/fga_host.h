@@ -81,11 +81,6 @@ void     fga_gdb_close(fga_gdb *G);
 uint8_t *fga_gdb_get_contig(const fga_gdb *G, int c, uint8_t *buf);
 int      fga_gdb_write_skeleton(const fga_gdb *G, const char *path, const char *prog, const char *command);
 
-/* plain device allocations for host C code (fga_device.hip) */
-struct fga_dev;
-int  fga_dev_malloc(struct fga_dev *dev, size_t bytes, void **out);
-void fga_dev_free(struct fga_dev *dev, void *ptr);
-
 /* binary ONEcode pieces shared by the GDB and the .1aln readers (fga_one.c) */
 typedef struct
   { int      have;

@@ -222,6 +222,8 @@ int fga_session_align(fga_session *Z, const fga_run_params *P, fga_dseeds *seeds
     ep.self = self; ep.aln_min = P->align_min - 50; ep.aln_rate = P->align_rate + .05;
     if (fga_extend(dev,Z->dg1,Z->dg2,hits,&ep,raw)) goto done;
     st.nalns = (*raw)->naln; st.ncalls = (*raw)->ncalls; st.nwaves = (*raw)->nwaves;
+    st.ext_cells = (*raw)->ncells; st.ext_bases = (*raw)->nbases; st.ext_trace = (*raw)->ntrace;
+    st.ext_busy_waves = (*raw)->busy_waves;
     st.extend_kernel_ms = fga_dev_stage_ms(dev,FGA_STAGE_EXTEND);
   }
   st.extend_s = fga_wall() - t1;
@@ -232,6 +234,8 @@ done:
     { S->sort_s += st.sort_s; S->chain_s += st.chain_s; S->extend_s += st.extend_s;
       S->sort_kernel_ms += st.sort_kernel_ms; S->extend_kernel_ms += st.extend_kernel_ms;
       S->nhits += st.nhits; S->nunits += st.nunits; S->nalns += st.nalns; S->ncalls += st.ncalls; S->nwaves += st.nwaves;
+      S->ext_cells += st.ext_cells; S->ext_bases += st.ext_bases; S->ext_trace += st.ext_trace;
+      if (st.ext_busy_waves > 0.) S->ext_busy_waves = st.ext_busy_waves;
     }
   free(alen); free(table);
   fga_hits_free(hits);

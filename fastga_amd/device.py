@@ -415,6 +415,20 @@ class Session:
     def sync(self):
         check(self.L.fga_dev_sync(self.L.fga_session_device(self.h)), "sync")
 
+    def dev_malloc(self, nbytes):
+        p = C.c_void_p()
+        check(self.L.fga_dev_malloc(self.L.fga_session_device(self.h), max(int(nbytes), 16), C.byref(p)), "device malloc")
+        return p.value
+
+    def dev_free(self, ptr):
+        self.L.fga_dev_free(self.L.fga_session_device(self.h), C.c_void_p(ptr))
+
+    def dev_download(self, ptr, nbytes):
+        out = np.empty(int(nbytes), dtype=np.uint8)
+        check(self.L.fga_dev_download(self.L.fga_session_device(self.h), out.ctypes.data_as(C.c_void_p),
+                                      C.c_void_p(ptr), int(nbytes)), "device download")
+        return out
+
     def dev_wrapper(self):
         """the session's device context as a (non-owning) Device object"""
         d = Device.__new__(Device)

@@ -16,10 +16,19 @@ def lib_path():
 
 
 def load_library():
-    """Load the in-tree shared library; raise loudly if it has not been built (no fallback)."""
+    """Load the in-tree shared library; raise loudly if it has not been built (no fallback).
+
+    One HIP runtime per process: the PyTorch wheel brings its own libamdhip64 / libhsa-runtime64, and a process that
+    first loads this library (ROCm's runtime under /opt/rocm) and then initialises torch.cuda ends up with two HSA
+    runtimes -- torch then reports "No HIP GPUs are available".  A process that needs torch.cuda beside this library
+    (bench.py under torchrun: RCCL collectives on device buffers) must therefore import torch FIRST; the library's
+    libamdhip64.so.7 dependency then resolves to the runtime torch loaded and device pointers are interchangeable.
+    FGA_TORCH_RUNTIME=1 makes this function do that import itself."""
     global _LIB
     if _LIB is not None:
         return _LIB
+    if os.environ.get("FGA_TORCH_RUNTIME") == "1":
+        import torch  # noqa: F401
     path = lib_path()
     if not os.path.exists(path):
         raise FgaError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -60,7 +69,8 @@ class ExtendParams(C.Structure):
 
 class Alns(C.Structure):
     _fields_ = [("naln", C.c_int64), ("ntrace", C.c_int64), ("ncalls", C.c_int64), ("nwaves", C.c_int64),
-                ("alns", C.c_void_p), ("tbytes", C.c_void_p)]
+                ("alns", C.c_void_p), ("tbytes", C.c_void_p),
+                ("ncells", C.c_int64), ("nbases", C.c_int64), ("busy_waves", C.c_double)]
 
 
 class Traces(C.Structure):
@@ -82,7 +92,9 @@ class RunStats(C.Structure):
                [(n, C.c_double) for n in ("load_s", "upload_s", "merge_s", "sort_s", "download_s", "chain_s",
                                           "extend_s", "filter_s", "write_s", "phase23_s", "trace_s", "paf_s")] + \
                [(n, C.c_float) for n in ("merge_kernel_ms", "sort_kernel_ms", "extend_kernel_ms",
-                                         "trace_kernel_ms")] + [("nparts", C.c_int), ("bases1", C.c_int64), ("bases2", C.c_int64)]
+                                         "trace_kernel_ms")] + [("nparts", C.c_int), ("bases1", C.c_int64), ("bases2", C.c_int64), ("ext_cells", C.c_int64),
+                                                     ("ext_bases", C.c_int64), ("ext_trace", C.c_int64),
+                                                     ("ext_busy_waves", C.c_double)]
 
 
 class SortParams(C.Structure):
@@ -128,6 +140,9 @@ def _declare(L):
         "fga_dev_close": (None, [vp]),
         "fga_dev_sync": (i32, [vp]),
         "fga_dev_stage_ms": (C.c_float, [vp, i32]),
+        "fga_dev_malloc": (i32, [vp, C.c_size_t, P(vp)]),
+        "fga_dev_free": (None, [vp, vp]),
+        "fga_dev_download": (i32, [vp, vp, vp, C.c_size_t]),
         "fga_dgix_build": (i32, [vp, vp, i32, i32, P(vp), P(vp)]),
         "fga_gix_write_files": (i32, [vp, cp]),
         "fga_dgix_upload": (i32, [vp, vp, P(vp)]),

@@ -182,8 +182,7 @@ def prefix_cuts(ses, nshards):
 def run_parts_on_one_gpu(ses, nparts, **prm_kwargs):
     """The sharded run's C-ABI calls on ONE GPU, rank by rank in sequence (merge of each prefix range, histogram,
     partition, split, import of each part's pieces, align, finish over all parts): the parity check of the multi-GPU
-    path for any number of parts.  Needs torch only for the staging buffers."""
-    import torch
+    path for any number of parts.  The staging buffers come from fga_dev_malloc (no torch in this process)."""
     prm = ses.params(**prm_kwargs)
     st = ses.new_stats()
     cuts = prefix_cuts(ses, nparts)
@@ -192,20 +191,19 @@ def run_parts_on_one_gpu(ses, nparts, **prm_kwargs):
     for r in range(nparts):                                   # "rank r": phase 1 on its prefix range
         seeds = ses.merge(prm, st, int(cuts[r]), int(cuts[r + 1]))
         hist += ses.contig_histogram(seeds)
-        buf = torch.empty((max(seeds.count, 1), 4), dtype=torch.int32, device="cuda")
-        merged.append((seeds, buf))
+        merged.append((seeds, ses.dev_malloc(16 * seeds.count)))
     select = partition_contigs(hist, nparts)
     for seeds, buf in merged:
-        offs.append(ses.split_to(seeds, select, nparts, buf.data_ptr()))
+        offs.append(ses.split_to(seeds, select, nparts, buf))
         seeds.free()
         sends.append(buf)
     raws = []
     for p in range(nparts):                                   # "rank p": its part's pieces from every rank, phase 2
-        pieces = [(sends[r].data_ptr() + 16 * int(offs[r][p]), int(offs[r][p + 1] - offs[r][p]))
-                  for r in range(nparts)]
+        pieces = [(sends[r] + 16 * int(offs[r][p]), int(offs[r][p + 1] - offs[r][p])) for r in range(nparts)]
         part = ses.import_seeds(pieces)
         raws.append(ses.align(prm, st, part))
-    del sends
+    for buf in sends:
+        ses.dev_free(buf)
     ses.finish(prm, st, raws)
     for r in raws:
         ses.free_alns(r)

@@ -9,6 +9,7 @@
 #ifndef FASTGA_AMD_H
 #define FASTGA_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -81,6 +82,13 @@ int   fga_dev_open(int device, fga_dev **out);
 void  fga_dev_close(fga_dev *dev);
 int   fga_dev_sync(fga_dev *dev);
 float fga_dev_stage_ms(const fga_dev *dev, int stage);   /* HIP-event time of the stage's last launch */
+
+/* plain device memory for callers that stage records themselves (exchange buffers of a multi-GPU run when the caller does
+   not bring its own allocator); a pointer from any allocator of the same HIP runtime is equally acceptable wherever this
+   header says "device buffer" */
+int   fga_dev_malloc(fga_dev *dev, size_t bytes, void **out);
+void  fga_dev_free(fga_dev *dev, void *ptr);
+int   fga_dev_download(fga_dev *dev, void *host_dst, const void *device_src, size_t bytes);
 
 int   fga_dgix_upload(fga_dev *dev, const fga_gix *gix, fga_dgix **out);
 void  fga_dgix_free(fga_dgix *dgix);
@@ -196,6 +204,10 @@ typedef struct
   { int64_t  naln, ntrace, ncalls, nwaves;
     fga_aln *alns;             /* host copies */
     uint8_t *tbytes;
+    /* accounting of the extension launch that produced the set (B_ext = 2 (nbases + ncells) + 2 ntrace) */
+    int64_t  ncells;           /* diagonal updates: sum over wave steps of the wave width                   */
+    int64_t  nbases;           /* bases compared by the snakes (per sequence; + one probe per cell update)  */
+    double   busy_waves;       /* wavefronts busy on average over the launch                                */
   } fga_alns;
 
 int  fga_align_spec(double ave_corr, int tspace, const float *freq4, int *path_ave, int16_t *table, int16_t *score);
@@ -292,6 +304,8 @@ typedef struct
     float   merge_kernel_ms, sort_kernel_ms, extend_kernel_ms, trace_kernel_ms;
     int     nparts;          /* A-contig parts phase 2 was run over */
     int64_t bases1, bases2;  /* bases of the two genomes (the reference's "seeds per G1 position") */
+    int64_t ext_cells, ext_bases, ext_trace;   /* extension accounting summed over the parts (fga_alns)         */
+    double  ext_busy_waves;                    /* wavefronts busy on average (last part)                        */
   } fga_run_stats;
 
 int  fga_run(const char *root1, const char *root2 /* NULL: self */, const fga_run_params *prm, fga_run_stats *stats);

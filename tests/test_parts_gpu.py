@@ -17,7 +17,6 @@ def _view(path):
 
 
 def test_routing_kernels_histogram_split_import(toy_pair):
-    import torch
     from fastga_amd import device as D
     from fastga_amd.parallel import partition_contigs
     d, ra, rb = toy_pair
@@ -30,9 +29,9 @@ def test_routing_kernels_histogram_split_import(toy_pair):
     assert np.array_equal(hist, np.bincount(actg, minlength=ses.nctg))
     for nparts in (1, 3, 8):
         sel = partition_contigs(hist, nparts)
-        buf = torch.empty((len(host), 4), dtype=torch.int32, device="cuda")
-        off = ses.split_to(seeds, sel, nparts, buf.data_ptr())
-        got = buf.cpu().numpy().view(D.SEED_DTYPE).reshape(-1)
+        buf = ses.dev_malloc(16 * len(host))
+        off = ses.split_to(seeds, sel, nparts, buf)
+        got = ses.dev_download(buf, 16 * len(host)).view(D.SEED_DTYPE).reshape(-1)
         assert off[0] == 0 and off[-1] == len(host)
         void = np.dtype((np.void, 16))
         for p in range(nparts):
@@ -42,9 +41,10 @@ def test_routing_kernels_histogram_split_import(toy_pair):
             assert np.array_equal(np.sort(piece.view(void)), np.sort(exp.view(void)))
         # import: pieces from two "ranks" become one seed buffer
         mid = len(host) // 2
-        imp = ses.import_seeds([(buf.data_ptr(), mid), (buf.data_ptr() + 16 * mid, len(host) - mid)])
+        imp = ses.import_seeds([(buf, mid), (buf + 16 * mid, len(host) - mid)])
         assert np.array_equal(imp.download().view(void), got.view(void))
         imp.free()
+        ses.dev_free(buf)
     seeds.free()
     ses.close()
 

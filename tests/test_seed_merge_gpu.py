@@ -16,7 +16,9 @@ def _compare(dev, A, B, dA, dB, **kw):
         n, c, nh, ts = H.oracle_self_seed_merge(A.table, A.index, A.pbyte, freq=kw.get("freq", 10),
                                                 soft_mask=kw.get("soft_mask", False))
         G1, G2 = A, A
-        assert len(got) == 2 * nh
+        # the oracle reports the reference's halved total; a seed and its mirror need not both exist (plen and the
+        # frequency test are taken from the T1 entry's point of view), so the full count can be odd
+        assert len(got) in (2 * nh, 2 * nh + 1)
     else:
         n, c, nh, ts = H.oracle_seed_merge(A.table, A.index, A.pbyte, B.table, B.index, B.pbyte,
                                            freq=kw.get("freq", 10), soft_mask=kw.get("soft_mask", False),

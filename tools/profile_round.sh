@@ -5,12 +5,13 @@
 #                                       pmc_fetch = FETCH_SIZE, pmc_write = WRITE_SIZE (KiB; gfx950: FETCH_SIZE counts
 #                                       half of a wide coalesced stream, see MI355X_MICROARCH.md), pmc_sq = SQ issue/wait
 # Copy the two files into profiles/ afterwards.
-tag=${1:-r01}
+tag=${1:-r02}
+commit=${2:-unknown}          # the commit the snapshot was taken at (gpurun ships no .git): pass `git rev-parse --short HEAD`
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out
 mkdir -p $out/prof_$tag
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $root/bench.py --steps 5 --warmup 2 --no-cpu"
+BENCH="python $root/bench.py --steps 5 --warmup 2 --no-cpu --no-cold"
 rocprofv3 --kernel-trace --stats -d $out/prof_$tag/kt -o kt --output-format csv -- $BENCH > $out/prof_$tag/kt.log 2>&1
 cp $out/prof_$tag/kt/kt_kernel_stats.csv $out/${tag}_kernel_stats.csv
 grep -a '"metric"' $out/prof_$tag/kt.log | tail -1 > $out/${tag}_bench_under_rocprof.json
@@ -21,7 +22,7 @@ pass pmc_fetch FETCH_SIZE
 pass pmc_write WRITE_SIZE
 pass pmc_sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES
 pass pmc_sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES
-python - "$out/prof_$tag" "$out/${tag}_pmc_summary.csv" <<'PY'
+python - "$out/prof_$tag" "$out/${tag}_pmc_summary.csv" "$commit" <<'PY'
 import csv, glob, sys, collections
 src, dst = sys.argv[1], sys.argv[2]
 rows = []
@@ -34,6 +35,8 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
     for (k, c), (v, d) in sorted(agg.items()):
         rows.append((name, k, c, len(d), v / max(1, len(d))))
 with open(dst, "w") as f:
+    f.write("# commit: %s\n" % (sys.argv[3] if len(sys.argv) > 3 else "unknown"))
+    f.write("# command: bench.py --steps 5 --warmup 2 --no-cpu --no-cold under rocprofv3 --pmc <counters> (one pass per counter group)\n")
     f.write("pass,kernel,counter,launches,avg_per_launch\n")
     for r in rows:
         f.write("%s,%s,%s,%d,%.6g\n" % r)
