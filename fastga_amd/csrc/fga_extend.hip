@@ -21,6 +21,9 @@
 
 #include "fga_device.hpp"
 
+#ifndef EXT_ACCOUNT
+#define EXT_ACCOUNT 1                   // per-lane snake-base accounting for bench.py's `extend` block (B_ext)
+#endif
 #define RC          512                 // diagonals in the LDS ring
 #define RMASK       (RC-1)
 #define PATH_LEN    60
@@ -40,6 +43,19 @@
 #define WINB        (WDW*16)
 
 #define LDS_PTR __attribute__((address_space(3)))
+
+// Trace-point ("pebble") arena of a wavefront.  A wave extension numbers its cells 0,1,2,... (the pebble pointers are
+// these logical indices) and starts again at 0 with the next call.  The cells live in ONE pool shared by all wavefronts
+// of the launch; a wavefront is given levels of geometrically growing size on demand -- level l holds the logical cells
+// [(2^l - 1) C0, (2^(l+1) - 1) C0) -- by one atomic on the pool head, and keeps them for the rest of the launch.  So the
+// pool holds what the launch really uses (a 2-kbp repeat copy needs ~500 cells, a 94-Mbp contig 2 x 10^7) instead of
+// the worst case times the number of wavefronts, and the number of resident wavefronts no longer depends on the
+// contig size.  (The reference grows one array per thread: enlarge_points / enlarge_vector, align.c:52-149.)
+#define ARENA_L0    14                  // level 0: 16384 cells = 256 KB
+#define ARENA_NLEV  16                  // levels 0..15 cover 2^30 logical cells (32-bit arena arithmetic)
+#define ARENA_LEVEL(i)  (31 - __builtin_clz((((unsigned) (i)) >> ARENA_L0) + 1u))
+#define ARENA_START(l)  ((int) (((1u << (l)) - 1u) << ARENA_L0))
+#define ARENA_END(l)    ((int) (((2u << (l)) - 1u) << ARENA_L0))       // level 15: 2^30 - 2^14, fits an int
 
 struct ext_seq
   { const uint32_t *img;      // padded 2-bit image as dwords (16 bases per dword, base i in bits 2*(i&15))
@@ -66,6 +82,8 @@ struct ext_shared
     int      tsum[32];        // 5-column groups of the trim tables: sum, max prefix incl. / excl. the full group
     int      tmaxi[32];
     int      tmaxe[32];
+    long long lvl_off[ARENA_NLEV];   // trace-point arena: pool cell of logical cell 0 of level l, minus the level's start
+    int      nlev;                   // levels this wavefront has been given so far
   };
 
 __shared__ ext_shared ext_lds;     // the one LDS block of a (single-wavefront) workgroup
@@ -97,8 +115,8 @@ struct ext_args
     double aln_rate;
     const int16_t *table, *score;
     // scratch (per workgroup)
-    int4     *cells;  int64_t cell_cap;
-    uint16_t *trace;  int64_t trace_cap;     // uint16 per workgroup; trace[0] of a call sits in the middle
+    int4     *pool;   int64_t pool_cells;    // the launch's cell pool (pebble levels and trace scratch of all wavefronts)
+    unsigned long long *pool_next;           // its head
     // output
     fga_aln  *alns; int64_t aln_cap;
     uint8_t  *tbytes; int64_t tbytes_cap;
@@ -454,17 +472,56 @@ __device__ __forceinline__ bool trim_ok(LDS_PTR ext_shared *sh, uint64_t b, int 
 // wave steps earlier, i.e. a few cells lower in the arena.  So the wavefront loads a coalesced window of 64
 // consecutive cells (lane l holds cells[base+l]) and follows the chain inside it with v_readlane -- about twenty
 // links per memory round trip instead of one.
+// take `ncell` cells off the pool (wave-uniform; lane 0 does the atomic): first cell, or -1 when the pool is exhausted
+__device__ __forceinline__ long long pool_take(const ext_args &G, long long ncell)
+{ unsigned long long b = 0;
+  if ((threadIdx.x & 63) == 0)
+    b = atomicAdd(G.pool_next,(unsigned long long) ncell);
+  const uint32_t lo = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) b);
+  const uint32_t hi = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (b >> 32));
+  const long long at = (long long) (((unsigned long long) hi << 32) | lo);
+  return (at + ncell <= G.pool_cells) ? at : -1;
+}
+
+// make sure levels 0..need exist for this wavefront; false: pool exhausted (or level beyond the 32-bit arena)
+__device__ __attribute__((noinline)) bool arena_ensure(const ext_args &G, int need)
+{ LDS_PTR ext_shared *sh = (LDS_PTR ext_shared *) &ext_lds;
+  int have = __builtin_amdgcn_readfirstlane(sh->nlev);
+  if (need >= ARENA_NLEV)
+    return false;
+  while (have <= need)
+    { const long long at = pool_take(G,(long long) (ARENA_END(have) - ARENA_START(have)));
+      if (at < 0)
+        return false;
+      if ((threadIdx.x & 63) == 0)
+        { sh->lvl_off[have] = at - ARENA_START(have);
+          sh->nlev = have+1;
+        }
+      have += 1;
+    }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL,"wavefront"); __builtin_amdgcn_wave_barrier();
+  return true;
+}
+
+// the cell with logical index i (any level this wavefront holds); one LDS read for the level's offset
+#define ARENA_CELL(pool,i)  ((pool) + (((LDS_PTR ext_shared *) &ext_lds)->lvl_off[ARENA_LEVEL(i)] + (long long) (i)))
+
 struct cell_window
-  { const GLB_PTR v4i *cells;
-    int base;                 // window = cells[base .. base+64)
+  { const GLB_PTR v4i *pool;
+    int base, lim;            // window = logical cells [base, base+lim), lim <= 64, all inside one level
     v4i w;
   };
 
 template <int DIR>             // DIR < 0: the walk goes to lower indices, DIR > 0: to higher ones
 __device__ __forceinline__ v4i cw_get(cell_window &W, int idx)      // idx is wave-uniform
-{ if (idx < W.base || idx >= W.base + 64)
-    { W.base = (DIR < 0) ? (idx > 63 ? idx-63 : 0) : idx;
-      W.w = W.cells[W.base + (int) (threadIdx.x & 63)];
+{ if (idx < W.base || idx >= W.base + W.lim)
+    { // a window never straddles two levels (they are different pool stretches): it is clamped at the level's start
+      // when walking down and cut at the level's end when walking up (the lanes beyond read padding / foreign cells)
+      const int lv = ARENA_LEVEL(idx), ls = ARENA_START(lv), le = ARENA_END(lv);
+      W.base = (DIR < 0) ? (idx-63 > ls ? idx-63 : ls) : idx;
+      W.lim  = le - W.base < 64 ? le - W.base : 64;
+      const long long off = ((LDS_PTR ext_shared *) &ext_lds)->lvl_off[lv];
+      W.w = W.pool[off + (long long) W.base + (int) (threadIdx.x & 63)];
     }
   const int l = idx - W.base;
   v4i r;
@@ -494,22 +551,22 @@ __device__ __forceinline__ void lb_flush_desc(lane_batch &B, GLB_PTR uint32_t *d
   B.n = 0;
 }
 // scattered: the j-th value goes to the first dword of cell key_j
-__device__ __forceinline__ void lb_flush_cells(lane_batch &B, GLB_PTR v4i *cells)
+__device__ __forceinline__ void lb_flush_cells(lane_batch &B, GLB_PTR v4i *pool)
 { const int lane = threadIdx.x & 63;
   if (lane < B.n)
-    ((GLB_PTR int *) (cells + B.key))[0] = (int) B.val;
+    ((GLB_PTR int *) ARENA_CELL(pool,B.key))[0] = (int) B.val;
   B.n = 0;
 }
 
 template <int S>
-__device__ __attribute__((noinline)) void ext_unwind(const ext_args &G, int4 *cells_in, uint16_t *trace_in, ext_state &P,
+__device__ __attribute__((noinline)) void ext_unwind(const ext_args &G, uint16_t *trace_in, int tcap_in, ext_state &P,
                                                      ext_prof &PF, int mida_in, int aoff_in, int trima_in, int trimx_in,
                                                      int trimd_in, int trimha_in, int &mind)
 { const int lane = threadIdx.x & 63;
   const int ts = TS;
   const int mida = UNI(mida_in), aoff = UNI(aoff_in), trima = UNI(trima_in), trimx = UNI(trimx_in);
   const int trimd = UNI(trimd_in), trimha = UNI(trimha_in);
-  GLB_PTR v4i *cells = (GLB_PTR v4i *) uni64((int64_t) cells_in);
+  GLB_PTR v4i *cells = (GLB_PTR v4i *) uni64((int64_t) G.pool);
   GLB_PTR uint16_t *trace = (GLB_PTR uint16_t *) uni64((int64_t) trace_in);
   const bool l0 = (lane == 0);
   // the reference picks the "more" tip only when spec->reach is set; FastGA always passes reach = 0 (FastGA.c:3757)
@@ -519,12 +576,12 @@ __device__ __attribute__((noinline)) void ext_unwind(const ext_args &G, int4 *ce
   const unsigned long long tun = clock64();
   __syncthreads();          // once per call: all pebble stores of the wave are complete before the pointer chase
   cell_window W;
-  W.cells = cells; W.base = -1000; W.w = (v4i) { 0,0,0,0 };
+  W.pool = cells; W.base = -1000; W.lim = 0; W.w = (v4i) { 0,0,0,0 };
 
   if (S > 0)
     { // single walk tip -> root; the pairs come out last-to-first and are stored downwards from the top of the
       // scratch, so no count pass is needed (the reverse wave prepends below tpos afterwards)
-      int pos = (int) UNI((int) G.trace_cap) - 8;
+      int pos = UNI(tcap_in) - 8;
       const int tend = pos;
       GLB_PTR uint32_t *tr32 = (GLB_PTR uint32_t *) trace;      // trace is dword aligned and every pos is even
       lane_batch LB; LB.val = 0; LB.key = 0; LB.n = 0;
@@ -586,7 +643,7 @@ __device__ __attribute__((noinline)) void ext_unwind(const ext_args &G, int4 *ce
       lb_flush_cells(LB,cells);
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST,"workgroup");       // the reversed pointers are visible to pass 2
       __builtin_amdgcn_s_waitcnt(0);
-      W.base = -1000;
+      W.base = -1000; W.lim = 0;
       h = a;
       GLB_PTR uint16_t *at = trace + tpos;
       int atlen = 0;
@@ -689,7 +746,7 @@ __device__ __attribute__((noinline)) void ext_unwind(const ext_args &G, int4 *ce
 #define BAIL(code) { WIN_BACK() return code; }
 
 template <int S>
-__device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext_shared *shp_in, int4 *cells_in, uint16_t *trace,
+__device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext_shared *shp_in, uint16_t *trace, int tcap,
                         ext_seq &Ain, ext_seq &Bin, ext_state &P,
                         int &mind, int maxd_in, int mida_in, int minp_in, int maxp_in, int aoff_in,
                         unsigned long long &nwaves_out, ext_prof &PF)
@@ -701,13 +758,28 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
   wseq A, B;
   wseq_from(A,Ain,(LDS_PTR uint32_t *) shp->winA);
   wseq_from(B,Bin,(LDS_PTR uint32_t *) shp->winB);
-  GLB_PTR v4i *cells = (GLB_PTR v4i *) uni64((int64_t) cells_in);
+  GLB_PTR v4i *pool = (GLB_PTR v4i *) uni64((int64_t) G.pool);
+  // the level the next cells go to: logical [.., cur_hi) at `cells`; every call starts over in level 0
+  GLB_PTR v4i *cells = pool + uni64((int64_t) shp->lvl_off[0]);
+  int cur_hi = ARENA_END(0);
   const int maxd = UNI(maxd_in), mida = UNI(mida_in), minp = UNI(minp_in), maxp = UNI(maxp_in), aoff = UNI(aoff_in);
   unsigned long long nwaves = 0, nspill = 0, ncells = 0;
   unsigned int lsum = 0;                   // this lane's snake bases (wave-reduced once, at the end of the call)
   const int ts = TS, path_ave = UNI(G.path_ave), mscore = UNI(G.mscore);
-  const int64_t cell_cap64 = uni64(G.cell_cap);
-  const int cell_cap = (int) (cell_cap64 < (1ll << 30) ? cell_cap64 : (1ll << 30));     // 32-bit arena arithmetic
+  // `tot` more cells at [avail, avail+tot): when they do not fit the current level, a batch of at most 64 moves to the
+  // start of the next level (the skipped tail is never referenced), a larger one may span levels and is stored through
+  // ARENA_CELL; either way the levels are taken from the pool first.  Out of line: the common step only compares.
+#define ARENA_GROW(tot)                                                                       \
+  { int lv_ = ARENA_LEVEL(avail);                                                             \
+    if ((tot) <= 64)                                                                          \
+      { if (avail + (tot) > ARENA_END(lv_)) { lv_ += 1; avail = ARENA_START(lv_); }           \
+        if (!arena_ensure(G,lv_)) BAIL(1)                                                     \
+      }                                                                                       \
+    else if ((unsigned) avail + (unsigned) (tot) >= (1u << 30) || !arena_ensure(G,ARENA_LEVEL(avail + (tot) - 1))) \
+      BAIL(1)                                                                                 \
+    cells = pool + uni64((int64_t) shp->lvl_off[lv_]);                                        \
+    cur_hi = ARENA_END(lv_);                                                                  \
+  }
   const bool force_lds = UNI(G.force_lds) != 0;
   const int VNEW = (S > 0) ? -1 : BIGI;
   int low = UNI(mind), hgh = maxd, dif = 0, cur = 0;
@@ -771,22 +843,22 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                 if (L == rb) hitB = 1; else if (L == ra) hitA = 1;
                 x -= L;
               }
-            lsum += (unsigned int) L;
+            if (EXT_ACCOUNT) lsum += (unsigned int) L;
             c = (x << 1) - k;
             if (S > 0) cnt = (x >= na) ? (x-na)/ts+1 : 0;
             else       cnt = (x <= na) ? (na-x)/ts+1 : 0;
           }
         int tot, off = wscan_add_excl(act ? 1+cnt : 0,tot);
-        if (UNLIKELY(avail + tot > cell_cap))
-          BAIL(1)
+        if (UNLIKELY(avail + tot > cur_hi))
+          ARENA_GROW(tot)
         int ha = -1, hm = 0;
         if (act)
           { int idx = avail + off;
-            cells[idx] = (v4i) { -1,k,0,mark0 };
+            *ARENA_CELL(pool,idx) = (v4i) { -1,k,0,mark0 };
             ha = idx; hm = mark0;
             for (int q = 0; q < cnt; q++)
               { idx += 1;
-                cells[idx] = (v4i) { ha,k,0,na };
+                *ARENA_CELL(pool,idx) = (v4i) { ha,k,0,na };
                 ha = idx; hm = na;
                 na += S*ts;
               }
@@ -854,7 +926,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
         BAIL(2)
       dif += 1;
       const int width = hgh-low+1;
-      ncells += (unsigned long long) width;
+      if (EXT_ACCOUNT) ncells += (unsigned long long) width;
 
       // ---- representation switch ----
       if (UNLIKELY(regmode && width > REG_MAXW))
@@ -957,7 +1029,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                     x -= L;
                   }
                 b = (L >= 61) ? ~0ull : ((b << L) | ((1ull << L) - 1));
-                lsum += (unsigned int) L;
+                if (EXT_ACCOUNT) lsum += (unsigned int) L;
                 c = (x << 1) - k;
                 { const int dx = (S > 0) ? x-na : na-x, dh = (S > 0) ? hm-na : na-hm;
                   cross = (dx >= 0) ? dx/ts+1 : 0;
@@ -980,8 +1052,8 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                 }
               else
                 off = wscan_add_excl(ncreate,tot);
-              if (UNLIKELY(avail + tot > cell_cap))
-                BAIL(1)
+              if (UNLIKELY(avail + tot > cur_hi))
+                ARENA_GROW(tot)
               if (LIKELY(single))
                 { if (ncreate > 0)
                     { const int idx = avail + off;
@@ -994,7 +1066,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                 { int idx = avail + off;
                   int v = na + S*ts*(cross-ncreate);
                   for (int q = 0; q < ncreate; q++)
-                    { cells[idx] = (v4i) { ha,k,dif,v };
+                    { *ARENA_CELL(pool,idx) = (v4i) { ha,k,dif,v };
                       ha = idx;
                       hm = v;
                       idx += 1;
@@ -1109,7 +1181,7 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
                     }
                   if (L > 0)
                     b = (L >= 61) ? ~0ull : ((b << L) | ((1ull << L) - 1));
-                  lsum += (unsigned int) L;
+                  if (EXT_ACCOUNT) lsum += (unsigned int) L;
                   c = (x << 1) - k;
                   na = shp->NA[k & RMASK];
                   { const int dx = (S > 0) ? x-na : na-x, dh = (S > 0) ? hm-na : na-hm;
@@ -1123,15 +1195,15 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
               uint64_t cm = BALLOT(ncreate > 0);
               if (cm)
                 { off = wscan_add_excl(ncreate,tot);
-                  if (UNLIKELY(avail + tot > cell_cap))
-                    BAIL(1)
+                  if (UNLIKELY(avail + tot > cur_hi))
+                    ARENA_GROW(tot)
                 }
               if (act)
                 { if (ncreate > 0)
                     { int idx = avail + off;
                       int v = na + S*ts*(cross-ncreate);
                       for (int q = 0; q < ncreate; q++)
-                        { cells[idx] = (v4i) { ha,k,dif,v };
+                        { *ARENA_CELL(pool,idx) = (v4i) { ha,k,dif,v };
                           ha = idx;
                           hm = v;
                           idx += 1;
@@ -1217,19 +1289,19 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
   }
   nwaves_out += nwaves;
   WIN_BACK()
-  ext_unwind<S>(G,cells_in,trace,P,PF,mida,aoff,trima,trimx,trimd,trimha,mind);
+  ext_unwind<S>(G,trace,tcap,P,PF,mida,aoff,trima,trimx,trimd,trimha,mind);
   return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------
 // Local_Alignment (align.c:1423-1576), wave-uniform
 // ---------------------------------------------------------------------------------------------------
-__device__ int local_alignment(const ext_args &G, LDS_PTR ext_shared *sh, int4 *cells, uint16_t *trace, int64_t tmid,
+__device__ int local_alignment(const ext_args &G, LDS_PTR ext_shared *sh, uint16_t *trace, int tcap,
                                ext_seq &A, ext_seq &B, int acomp,
                                int low, int hgh, int anti, int lbord, int hbord,
                                ext_state &P, unsigned long long &nwaves, ext_prof &PF)
 { int minp, maxp, aoff, st;
-  P.tpos = (int) tmid;
+  P.tpos = tcap/2;
   P.tlen = 0;
   while (((anti-hgh)>>1) < 0)
     hgh -= 1;
@@ -1237,10 +1309,10 @@ __device__ int local_alignment(const ext_args &G, LDS_PTR ext_shared *sh, int4 *
   maxp = (hbord < 0) ?  BIGI : hgh+hbord;
   aoff = acomp ? A.len % TS : 0;
 
-  if ((st = ext_wave<+1>(G,sh,cells,trace,A,B,P,low,hgh,anti,minp,maxp,aoff,nwaves,PF)) != 0) return st;
+  if ((st = ext_wave<+1>(G,sh,trace,tcap,A,B,P,low,hgh,anti,minp,maxp,aoff,nwaves,PF)) != 0) return st;
   int fshort = ((P.aepos + P.bepos) - anti < DUB_TRIM);
   { int l2 = low;
-    if ((st = ext_wave<-1>(G,sh,cells,trace,A,B,P,l2,low,anti,minp,maxp,aoff,nwaves,PF)) != 0) return st;
+    if ((st = ext_wave<-1>(G,sh,trace,tcap,A,B,P,l2,low,anti,minp,maxp,aoff,nwaves,PF)) != 0) return st;
   }
   int rshort = (anti - (P.abpos + P.bbpos) < DUB_TRIM);
   if (fshort)
@@ -1253,7 +1325,7 @@ __device__ int local_alignment(const ext_args &G, LDS_PTR ext_shared *sh, int4 *
         { low  = P.abpos - P.bbpos;
           anti = P.abpos + P.bbpos;
           P.tlen = 0;
-          if ((st = ext_wave<+1>(G,sh,cells,trace,A,B,P,low,low,anti,minp,maxp,aoff,nwaves,PF)) != 0) return st;
+          if ((st = ext_wave<+1>(G,sh,trace,tcap,A,B,P,low,low,anti,minp,maxp,aoff,nwaves,PF)) != 0) return st;
         }
     }
   else if (rshort)
@@ -1261,7 +1333,7 @@ __device__ int local_alignment(const ext_args &G, LDS_PTR ext_shared *sh, int4 *
       anti = P.aepos + P.bepos;
       P.tlen = 0;
       P.diffs = 0;
-      if ((st = ext_wave<-1>(G,sh,cells,trace,A,B,P,low,low,anti,minp,maxp,aoff,nwaves,PF)) != 0) return st;
+      if ((st = ext_wave<-1>(G,sh,trace,tcap,A,B,P,low,low,anti,minp,maxp,aoff,nwaves,PF)) != 0) return st;
     }
   if (acomp)
     { int i = P.abpos; P.abpos = A.len - P.aepos; P.aepos = A.len - i;
@@ -1280,9 +1352,12 @@ void extend_kernel(ext_args G)
   trim_fill(sh,G.mscore);
   __syncthreads();
   const int lane = threadIdx.x;
-  int4     *cells = G.cells + (int64_t) blockIdx.x * G.cell_cap;
-  uint16_t *trace = G.trace + (int64_t) blockIdx.x * G.trace_cap;
-  const int64_t tmid = G.trace_cap/2;
+  // arena level 0 and -- per unit, sized by its A contig -- the trace scratch come from the launch's pool
+  if (lane == 0) sh->nlev = 0;
+  __syncthreads();
+  bool pool_ok = arena_ensure(G,0);
+  uint16_t *trace = NULL;
+  int tcap = 0;                             // uint16 elements of the scratch; trace[0] of a call sits in the middle
   unsigned long long ncalls = 0, nwaves = 0;
   ext_prof PF; PF.t_steps = PF.t_unwind = PF.t_total = PF.nsteps = 0; PF.ncells = PF.nbases = 0;
   const unsigned long long tk0 = clock64();
@@ -1315,7 +1390,21 @@ void extend_kernel(ext_args G)
       int64_t alast = -1;
       int seq = 0;
       ext_state P;
-      P.abpos = P.bbpos = P.aepos = P.bepos = P.diffs = P.tlen = 0; P.tpos = (int) tmid;
+      P.abpos = P.bbpos = P.aepos = P.bepos = P.diffs = P.tlen = 0; P.tpos = 0;
+      { // forward pairs are stored down from the top, reverse pairs below the middle: 4 (len/100 + 2) elements each
+        const int need = 8*(A.len/TS + 8) + 64;
+        if (pool_ok && need > tcap)
+          { const int ncap = need > 2*tcap ? need : 2*tcap;
+            const long long at = pool_take(G,((long long) ncap*2 + 15) / 16 + 1);
+            if (at < 0) pool_ok = false;
+            else { trace = (uint16_t *) (G.pool + at); tcap = ncap; }
+          }
+        if (!pool_ok)
+          { if (lane == 0)
+              atomicMax(G.counters+4,1ull);
+            break;
+          }
+      }
       for (int hi = 0; hi < U.nhits; hi++)
         { const fga_hit H = G.hits[U.first_hit + hi];
           int dgmin = H.dgmin, dgmax = H.dgmax;
@@ -1338,14 +1427,14 @@ void extend_kernel(ext_args G)
               int st = 0, called = 1;
               if (self)
                 { if (dgmin > 0)
-                    st = local_alignment(G,sh,cells,trace,tmid,A,B,comp,dgmin,dgmax,(int) amid,dgmin-1,-1,P,nwaves,PF);
+                    st = local_alignment(G,sh,trace,tcap,A,B,comp,dgmin,dgmax,(int) amid,dgmin-1,-1,P,nwaves,PF);
                   else if (dgmax < 0)
-                    st = local_alignment(G,sh,cells,trace,tmid,A,B,comp,dgmin,dgmax,(int) amid,-1,-(dgmax+1),P,nwaves,PF);
+                    st = local_alignment(G,sh,trace,tcap,A,B,comp,dgmin,dgmax,(int) amid,-1,-(dgmax+1),P,nwaves,PF);
                   else
                     { P.abpos = P.aepos = 0; called = 0; }
                 }
               else
-                st = local_alignment(G,sh,cells,trace,tmid,A,B,comp,dgmin,dgmax,(int) amid,-1,-1,P,nwaves,PF);
+                st = local_alignment(G,sh,trace,tcap,A,B,comp,dgmin,dgmax,(int) amid,-1,-1,P,nwaves,PF);
               ncalls += called;
               if (st != 0)
                 { if (lane == 0)
@@ -1553,16 +1642,23 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
   }
   if (nwg > H->nunits) nwg = (int) H->nunits;
   const int64_t maxa = GA->maxctg > GB->maxctg ? GA->maxctg : GB->maxctg;
-  int64_t cell_cap  = prm->cell_cap  > 0 ? prm->cell_cap  : 24*(maxa/prm->tspace + 64) + 4096;
-  int64_t trace_cap = 8*(maxa/prm->tspace + 8) + 64;
-  { // bound the per-wavefront scratch to ~24 GB in total: long contigs get fewer concurrent wavefronts
-    int64_t per = (int64_t) sizeof(int4)*cell_cap + (int64_t) sizeof(uint16_t)*trace_cap;
-    int64_t maxwg = ((int64_t) 24 << 30) / per;
-    if (maxwg < 64) maxwg = 64;
-    if (nwg > maxwg) nwg = (int) maxwg;
-  }
+  // Scratch and output are sized by what the hits suggest, not by the worst case times the number of wavefronts; the
+  // kernel counts what it would have needed, so a launch that runs out is repeated once with exactly that
+  // (prm->cell_cap: pool cells; prm->aln_cap / prm->trace_cap: output records / trace bytes).
+  int64_t span = 0;
+  for (int64_t h = 0; h < H->nhits; h++)
+    span += (H->hits[h].ahgh - H->hits[h].alow) / 2 + 200;
+  int64_t pool_cells = prm->cell_cap > 0 ? prm->cell_cap
+                                         : (int64_t) nwg*((1 << ARENA_L0) + 8*(maxa/prm->tspace + 72)/8 + 64) + 2*24*(span/prm->tspace)
+                                           + ((int64_t) 64 << 20);
   int64_t aln_cap   = prm->aln_cap   > 0 ? prm->aln_cap   : 4*H->nhits + 1024;
-  int64_t tb_cap    = prm->trace_cap > 0 ? prm->trace_cap : aln_cap * (2*(maxa/prm->tspace) / 8 + 64);
+  int64_t tb_cap    = prm->trace_cap > 0 ? prm->trace_cap : 4*(span/prm->tspace) + 64*aln_cap + (1 << 20);
+  { size_t fr = 0, tot = 0;                  // never ask for more than half of what is free
+    if (hipMemGetInfo(&fr,&tot) == hipSuccess && fr > 0)
+      { const int64_t lim = (int64_t) (fr/2) / (int64_t) sizeof(int4);
+        if (pool_cells > lim) pool_cells = lim;
+      }
+  }
 
   ext_args A;
   memset(&A,0,sizeof(A));
@@ -1574,7 +1670,6 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
   A.aln_min = prm->aln_min; A.aln_rate = prm->aln_rate;
   A.mscore = prm->score[0x7fff] / 15;      // SCORE[all matches] = 15 * mscore
   A.force_lds = getenv("FGA_EXTEND_FORCE_LDS") != NULL;
-  A.cell_cap = cell_cap; A.trace_cap = trace_cap; A.aln_cap = aln_cap; A.tbytes_cap = tb_cap;
 
   fga_unit *d_units = NULL; fga_hit *d_hits = NULL; int *d_order = NULL, *d_next = NULL;
   int16_t *d_tab = NULL;
@@ -1589,77 +1684,90 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
     { fga_set_error("fga_extend: device allocation failed: %s",hipGetErrorString(e));
       goto fail;
     }
-  A.cells  = (int4 *)     fga_dev_acquire(dev,SLOT_CELLS,sizeof(int4)*((size_t) cell_cap*nwg + 64));     // + one unwind window
-  A.trace  = (uint16_t *) fga_dev_acquire(dev,SLOT_TRACE,sizeof(uint16_t)*(size_t) trace_cap*nwg);
-  A.alns   = (fga_aln *)  fga_dev_acquire(dev,SLOT_ALNS,sizeof(fga_aln)*(size_t) aln_cap);
-  A.tbytes = (uint8_t *)  fga_dev_acquire(dev,SLOT_TBYTES,(size_t) tb_cap);
-  if (A.cells == NULL || A.trace == NULL || A.alns == NULL || A.tbytes == NULL)
-    { fga_set_error("fga_extend: device allocation failed (%lld MB of trace-point cells)",
-                    (long long) (sizeof(int4)*(size_t) cell_cap*nwg >> 20));
-      goto fail;
-    }
   hipMemcpy(d_units,H->units,sizeof(fga_unit)*H->nunits,hipMemcpyHostToDevice);
   hipMemcpy(d_hits,H->hits,sizeof(fga_hit)*H->nhits,hipMemcpyHostToDevice);
   hipMemcpy(d_order,order.data(),sizeof(int)*H->nunits,hipMemcpyHostToDevice);
   hipMemcpy(d_tab,prm->table,sizeof(int16_t)*32768,hipMemcpyHostToDevice);
   hipMemcpy(d_tab+32768,prm->score,sizeof(int16_t)*32768,hipMemcpyHostToDevice);
-  hipMemset(d_next,0,sizeof(int));
-  hipMemset(d_cnt,0,sizeof(unsigned long long)*32);
   A.units = d_units; A.hits = d_hits; A.order = d_order; A.next = d_next;
   A.table = d_tab; A.score = d_tab+32768; A.counters = d_cnt;
 
-  hipEventRecord(dev->ev0,dev->stream);
-  hipLaunchKernelGGL(extend_kernel,dim3(nwg),dim3(64),0,dev->stream,A);
-  hipEventRecord(dev->ev1,dev->stream);
-  e = hipStreamSynchronize(dev->stream);
-  if (e == hipSuccess) e = hipGetLastError();
-  if (e != hipSuccess)
-    { fga_set_error("fga_extend: kernel failed: %s",hipGetErrorString(e));
+  for (int attempt = 0; ; attempt++)
+    { A.pool_cells = pool_cells; A.aln_cap = aln_cap; A.tbytes_cap = tb_cap;
+      A.pool   = (int4 *)     fga_dev_acquire(dev,SLOT_CELLS,sizeof(int4)*((size_t) pool_cells + 128));   // + a window of padding
+      A.alns   = (fga_aln *)  fga_dev_acquire(dev,SLOT_ALNS,sizeof(fga_aln)*(size_t) aln_cap);
+      A.tbytes = (uint8_t *)  fga_dev_acquire(dev,SLOT_TBYTES,(size_t) tb_cap);
+      if (A.pool == NULL || A.alns == NULL || A.tbytes == NULL)
+        { fga_set_error("fga_extend: device allocation failed (%lld MB trace-point pool, %lld MB trace bytes)",
+                        (long long) (sizeof(int4)*(size_t) pool_cells >> 20),(long long) (tb_cap >> 20));
+          goto fail;
+        }
+      A.pool_next = d_cnt + 16;
+      hipMemsetAsync(d_next,0,sizeof(int),dev->stream);
+      hipMemsetAsync(d_cnt,0,sizeof(unsigned long long)*32,dev->stream);
+
+      hipEventRecord(dev->ev0,dev->stream);
+      hipLaunchKernelGGL(extend_kernel,dim3(nwg),dim3(64),0,dev->stream,A);
+      hipEventRecord(dev->ev1,dev->stream);
+      e = hipStreamSynchronize(dev->stream);
+      if (e == hipSuccess) e = hipGetLastError();
+      if (e != hipSuccess)
+        { fga_set_error("fga_extend: kernel failed: %s",hipGetErrorString(e));
+          goto fail;
+        }
+      hipEventElapsedTime(&dev->last_ms[FGA_STAGE_EXTEND],dev->ev0,dev->ev1);
+      unsigned long long hc[32];
+      hipMemcpy(hc,d_cnt,sizeof(hc),hipMemcpyDeviceToHost);
+      if (getenv("FGA_EXTEND_PROFILE") != NULL)
+        fprintf(stderr,"extend profile: max per wavefront: steps %.2f Mcyc, unwind %.2f Mcyc, total %.2f Mcyc, waves %llu; "
+                       "sum: steps %.1f Mcyc unwind %.1f Mcyc; kernel %.2f ms, %d workgroups, %lld units, %llu register->ring spills, "
+                       "pool %.1f of %.1f MB\n",
+                hc[5]*1e-6,hc[6]*1e-6,hc[7]*1e-6,hc[10],hc[8]*1e-6,hc[9]*1e-6,dev->last_ms[FGA_STAGE_EXTEND],nwg,
+                (long long) H->nunits,hc[11],hc[16]*16e-6,pool_cells*16e-6);
+
+      R->naln = (int64_t) hc[0]; R->ntrace = (int64_t) hc[1]; R->ncalls = (int64_t) hc[2]; R->nwaves = (int64_t) hc[3];
+      R->ncells = (int64_t) hc[12]; R->nbases = (int64_t) hc[13];
+      // wavefronts busy on average = wave time spent in steps + unwinds, over the longest wavefront's lifetime
+      R->busy_waves = hc[7] > 0 ? (double) (hc[8] + hc[9]) / (double) hc[7] : 0.;
+      const bool pool_out = (hc[4] == 1), out_full = (R->naln > aln_cap || R->ntrace > tb_cap);
+      if (hc[4] > 1)
+        { fga_set_error("fga_extend: wave wider than the LDS ring (512 diagonals)");
+          goto fail;
+        }
+      if (!pool_out && !out_full)
+        break;
+      fga_dev_release(dev,SLOT_CELLS,A.pool); fga_dev_release(dev,SLOT_ALNS,A.alns); fga_dev_release(dev,SLOT_TBYTES,A.tbytes);
+      A.pool = NULL; A.alns = NULL; A.tbytes = NULL;
+      if (attempt >= 3 || prm->cell_cap > 0 || prm->aln_cap > 0 || prm->trace_cap > 0)
+        { fga_set_error("fga_extend: %s",pool_out ? "trace-point pool exhausted (raise cell_cap)"
+                                                  : "output buffers too small (raise aln_cap / trace_cap)");
+          goto fail;
+        }
+      // the counters kept counting: the demand of the part that ran is known.  A pool that ran out stopped wavefronts
+      // early, so it is at least doubled
+      if (pool_out)  pool_cells = 2*pool_cells > (int64_t) hc[16] ? 2*pool_cells : (int64_t) hc[16] + pool_cells;
+      if (R->naln > aln_cap)  aln_cap = R->naln + R->naln/8 + 1024;
+      if (R->ntrace > tb_cap) tb_cap = R->ntrace + R->ntrace/8 + (1 << 20);
+    }
+  R->alns = (fga_aln *) malloc(sizeof(fga_aln)*(R->naln+1));
+  R->tbytes = (uint8_t *) malloc(R->ntrace+16);
+  if (R->alns == NULL || R->tbytes == NULL)
+    { fga_set_error("out of memory");
       goto fail;
     }
-  hipEventElapsedTime(&dev->last_ms[FGA_STAGE_EXTEND],dev->ev0,dev->ev1);
-  { unsigned long long hc[32];
-    hipMemcpy(hc,d_cnt,sizeof(hc),hipMemcpyDeviceToHost);
-    if (getenv("FGA_EXTEND_PROFILE") != NULL)
-      fprintf(stderr,"extend profile: max per wavefront: steps %.2f Mcyc, unwind %.2f Mcyc, total %.2f Mcyc, waves %llu; "
-                     "sum: steps %.1f Mcyc unwind %.1f Mcyc; kernel %.2f ms, %d workgroups, %lld units, %llu register->ring spills\n",
-              hc[5]*1e-6,hc[6]*1e-6,hc[7]*1e-6,hc[10],hc[8]*1e-6,hc[9]*1e-6,dev->last_ms[FGA_STAGE_EXTEND],nwg,
-              (long long) H->nunits,hc[11]);
-
-    R->naln = (int64_t) hc[0]; R->ntrace = (int64_t) hc[1]; R->ncalls = (int64_t) hc[2]; R->nwaves = (int64_t) hc[3];
-    R->ncells = (int64_t) hc[12]; R->nbases = (int64_t) hc[13];
-    // wavefronts busy on average = wave time spent in steps + unwinds, over the longest wavefront's lifetime
-    R->busy_waves = hc[7] > 0 ? (double) (hc[8] + hc[9]) / (double) hc[7] : 0.;
-    if (hc[4] != 0)
-      { fga_set_error("fga_extend: %s",hc[4] == 1 ? "trace-point arena exhausted (raise cell_cap)"
-                                                   : "wave wider than the LDS ring (512 diagonals)");
-        goto fail;
-      }
-    if (R->naln > aln_cap || R->ntrace > tb_cap)
-      { fga_set_error("fga_extend: output buffers too small (%lld alignments, %lld trace bytes)",
-                      (long long) R->naln,(long long) R->ntrace);
-        goto fail;
-      }
-    R->alns = (fga_aln *) malloc(sizeof(fga_aln)*(R->naln+1));
-    R->tbytes = (uint8_t *) malloc(R->ntrace+16);
-    if (R->alns == NULL || R->tbytes == NULL)
-      { fga_set_error("out of memory");
-        goto fail;
-      }
-    if (R->naln > 0)
-      hipMemcpy(R->alns,A.alns,sizeof(fga_aln)*R->naln,hipMemcpyDeviceToHost);
-    if (R->ntrace > 0)
-      hipMemcpy(R->tbytes,A.tbytes,R->ntrace,hipMemcpyDeviceToHost);
-  }
+  if (R->naln > 0)
+    hipMemcpy(R->alns,A.alns,sizeof(fga_aln)*R->naln,hipMemcpyDeviceToHost);
+  if (R->ntrace > 0)
+    hipMemcpy(R->tbytes,A.tbytes,R->ntrace,hipMemcpyDeviceToHost);
   hipFree(d_units); hipFree(d_hits); hipFree(d_order); hipFree(d_next); hipFree(d_tab); hipFree(d_cnt);
-  fga_dev_release(dev,SLOT_CELLS,A.cells); fga_dev_release(dev,SLOT_TRACE,A.trace);
+  fga_dev_release(dev,SLOT_CELLS,A.pool);
   fga_dev_release(dev,SLOT_ALNS,A.alns); fga_dev_release(dev,SLOT_TBYTES,A.tbytes);
   *out = R;
   return 0;
 
 fail:
   hipFree(d_units); hipFree(d_hits); hipFree(d_order); hipFree(d_next); hipFree(d_tab); hipFree(d_cnt);
-  fga_dev_release(dev,SLOT_CELLS,A.cells); fga_dev_release(dev,SLOT_TRACE,A.trace);
+  fga_dev_release(dev,SLOT_CELLS,A.pool);
   fga_dev_release(dev,SLOT_ALNS,A.alns); fga_dev_release(dev,SLOT_TBYTES,A.tbytes);
   free(R->alns); free(R->tbytes); free(R);
   return 1;

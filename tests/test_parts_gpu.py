@@ -74,8 +74,12 @@ def test_any_number_of_parts_gives_the_reference_1aln(toy_pair, tmp_path, mode):
         out = os.path.join(w, f"parts{nparts}.1aln")
         st = run_parts_on_one_gpu(ses, nparts, out_path=out, nthreads=8, **kw)
         assert _view(out) == base, nparts                         # identical to the undivided run, line for line
-        assert st["nseeds"] == whole["nseeds"] and st["nalns"] == whole["nalns"] and st["nlive"] == whole["nlive"]
-        assert sum(st["part_seed_counts"]) == whole["nseeds"] * (2 if mode == "self" else 1)
+        assert st["nalns"] == whole["nalns"] and st["nlive"] == whole["nlive"]
+        if mode == "self":      # self totals are halved per merge launch (FastGA.c:1906): floors add up differently
+            assert 0 <= whole["nseeds"] - st["nseeds"] <= nparts
+            assert 0 <= sum(st["part_seed_counts"]) - 2 * whole["nseeds"] <= 1
+        else:
+            assert st["nseeds"] == whole["nseeds"] and sum(st["part_seed_counts"]) == whole["nseeds"]
         if nparts > 1:
             assert min(st["part_seed_counts"]) > 0
     ses.close()
