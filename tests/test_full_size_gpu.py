@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 T = max(4, min(32, os.cpu_count() or 8))
 
 
-def _write_index_files(roots, use_mask=False):
+def _write_index_files(roots, use_mask=False, nthreads=8):
     """<root>.gix + .ktab.N for the reference, from index builds on the device (byte-identical to the host producer's
     and to GIXmake's: tests/test_gix_device_gpu.py, tests/test_oracle_vs_reference.py)"""
     from fastga_amd import device as D
@@ -27,13 +27,13 @@ def _write_index_files(roots, use_mask=False):
     dev = D.Device(0)
     for r in roots:
         g = Gdb(r + ".gdb")
-        dgx, xg = D.build_gix_device(dev, g, 8, host_copy=True, use_mask=use_mask)
+        dgx, xg = D.build_gix_device(dev, g, nthreads, host_copy=True, use_mask=use_mask)
         assert dev.L.fga_gix_write_files(xg.h, r.encode()) == 0, dev.L.fga_last_error()
         dgx.free(); xg.close(); g.close()
     dev.close()
 
 
-def _compare_with_reference(ra, rb, d, flags=(), strict=True, pafx=False, **kw):
+def _compare_with_reference(ra, rb, d, flags=(), strict=True, pafx=False, ref_threads=T, **kw):
     from fastga_amd import device as D, workload
     from oracle import harness as H
     if not H.have_reference():
@@ -41,7 +41,7 @@ def _compare_with_reference(ra, rb, d, flags=(), strict=True, pafx=False, **kw):
     ours = os.path.join(d, "ours.1aln")
     paf = os.path.join(d, "ours.paf") if pafx else None
     st = D.run(ra, rb, ours, nthreads=T, paf_path=paf, paf_flags=2 if pafx else 0, **kw)
-    H.ref_fastga(ra, rb, d, os.path.join(d, "ref"), threads=T, flags=flags)
+    H.ref_fastga(ra, rb, d, os.path.join(d, "ref"), threads=ref_threads, flags=flags)
     a, b = H.oneview(ours), H.oneview(os.path.join(d, "ref.1aln"))
     da, db = workload.digest_1aln(a), workload.digest_1aln(b)
     assert da == db, (da, db, st)
@@ -84,6 +84,24 @@ def test_config3_150mbp_self_soft_masked_is_identical_to_the_reference(tmp_path_
     _write_index_files((root,), use_mask=True)
     st, dg = _compare_with_reference(root, None, d, flags=("-M",), strict=False, soft_mask=True)
     assert dg["records"] > 5000
+
+
+@pytest.mark.skipif(os.environ.get("FGA_SKIP_1G") == "1", reason="FGA_SKIP_1G=1")
+def test_human_scale_contigs_3x94mbp_pair_is_identical_to_the_reference(tmp_path_factory, built_library):
+    """the per-GPU shard shape of configs[3]: three 94-Mbp contigs against their 1 % diverged copies.  One alignment
+    spans a whole contig (~10^6 wave steps, ~2 x 10^7 trace-point cells: arena levels up to 2^24 cells), the trace
+    scratch is sized per unit, and the number of resident wavefronts must not depend on the contig size."""
+    from fastga_amd import workload
+    d = str(tmp_path_factory.mktemp("c4"))
+    ra, rb = workload.build_pair(d, seed=3, ncontig=3, total=282_000_000, divergence=0.01, repeat_frac=0.05,
+                                 inv_frac=0.02, swap_frac=0.02, threads=T, gix=False)
+    _write_index_files((ra, rb), nthreads=3)            # the reference wants -T <= the number of contigs
+    os.environ["FGA_EXTEND_PROFILE"] = "1"
+    try:
+        st, dg = _compare_with_reference(ra, rb, d, strict=False, ref_threads=3)
+    finally:
+        os.environ.pop("FGA_EXTEND_PROFILE", None)
+    assert dg["records"] > 1000 and st["nwaves"] > 3_000_000
 
 
 @pytest.mark.skipif(os.environ.get("FGA_SKIP_1G") == "1", reason="FGA_SKIP_1G=1")
