@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--workdir", default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the reference leg (cpu_baseline + parity)")
     ap.add_argument("--no-cold", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="take the multi-GPU code path (process group, exchange, gather) even with one rank")
     return ap.parse_args()
 
 
@@ -98,11 +100,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if world > 1 or args.force_sharded:
         # torch FIRST: one HIP runtime per process (fastga_amd/lib.py::load_library)
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local)
+        if "MASTER_ADDR" not in os.environ:                  # --force-sharded without a launcher
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29517"
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from fastga_amd import workload, device as D
