@@ -1105,6 +1105,523 @@ void seed_merge_wave_kernel(merge_args A, wave_out W)
     atomicAdd(A.tseed,tsum);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// the range-walking wave kernel (v3)
+// ---------------------------------------------------------------------------------------------------
+// One launch does the whole merge.  A wavefront takes RANGES of consecutive 12-mer prefixes off a queue (equal merge
+// cost per range, a few per wavefront) and walks each one tile by tile: it reads the next 64 entries of both prefix
+// indices (one per lane, fetched one tile ahead), a ballot over the running cost finds how many prefixes fit a tile of
+// XT cost units, and the tile is processed exactly as before -- raw bytes HBM -> LDS, T2 keys, panel owners,
+// compaction, match, seed-parallel emission.  So there is no partition kernel and there are no tile descriptors.
+// A single k-mer panel that exceeds a tile (a repeat family) is cut into sub-tiles IN the wavefront: a run of T1
+// entries together with the stretch of the T2 panel its members can reach -- the lower bounds of its first and last
+// key (a 64-ary search, the whole wavefront probing) widened by FREQ+2 entries, which is as far as the run growth of
+// the merge ever looks; for a self comparison the stretch is the run itself plus that margin.  So there is no second
+// kernel for oversize tiles either.
+#ifndef XT
+#define XT 256                       // cost units per tile
+#endif
+#define XEPT   (XT/64)               // T1 entries per lane in the owner / compaction pass; match rounds
+#define XPC    64                    // prefixes per tile at most (one index entry per lane)
+static_assert(XT == 256 || XT == 512,"descriptor packing: 9-bit tile indices, 4 or 8 entries per lane");
+
+#ifndef RANGES_PER_WAVE
+#define RANGES_PER_WAVE 4
+#endif
+struct walk_args
+  { const int64_t *cuts;             // [nranges+1] prefix boundaries
+    int            nranges;
+    int           *next;             // range queue head
+    unsigned long long *holes;       // [2*hole_cap] unused chunk tails (begin,end)
+    unsigned long long *nhole;
+    int            hole_cap;
+  };
+
+__global__ void range_cut_kernel(const int64_t *idx1, const int64_t *idx2, int pbeg, int pend, int64_t base,
+                                 int64_t total, int nranges, int64_t *cuts)
+{ const int w = blockIdx.x*blockDim.x + threadIdx.x;
+  if (w > nranges)
+    return;
+  int64_t p = pbeg;
+  if (w == nranges)
+    p = pend;
+  else if (w > 0)
+    { const int64_t target = base + (total / nranges) * w;
+      int lo = pbeg, hi = pend;
+      while (lo < hi)
+        { const int mid = lo + ((hi-lo) >> 1);
+          const int64_t c = idx1[mid] + idx2[mid] + 2*((int64_t) mid+1);
+          if (c > target) hi = mid; else lo = mid+1;
+        }
+      p = lo;
+    }
+  cuts[w] = p;
+}
+
+// key of table entry j straight from HBM: three aligned dwords, v_alignbyte, byte swap (the entry is >= 11 bytes)
+__device__ __forceinline__ uint64_t glb_key3(const uint8_t *tab, int64_t j, int E)
+{ const uint64_t addr = (uint64_t) (tab + j*E);
+  const uint32_t *w = (const uint32_t *) (addr & ~(uint64_t) 3);
+  const uint32_t sh = (uint32_t) (addr & 3);
+  const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
+  const uint32_t e0 = __builtin_amdgcn_alignbyte(d1,d0,sh), e1 = __builtin_amdgcn_alignbyte(d2,d1,sh);
+  return ((uint64_t) bswap32(e0) << 32) | bswap32(e1);
+}
+
+// smallest j in [lo,hi] whose key is >= kq (mask byte ignored), all 64 lanes probing: the range shrinks 64-fold a round
+__device__ __forceinline__ int64_t wave_lower_bound(const uint8_t *tab, int E, int64_t lo, int64_t hi, uint64_t kq)
+{ const int lane = threadIdx.x;
+  while (hi > lo)
+    { const int64_t step = ((hi - lo) + 63) >> 6;
+      const int64_t pos = lo + (int64_t) lane*step;
+      bool below = false;
+      if (pos < hi)
+        below = (glb_key3(tab,pos,E) & ~0xffull) < kq;
+      const int t = __popcll(__builtin_amdgcn_ballot_w64(below));        // sorted: the first t probes are below
+      if (t == 0)
+        return lo;
+      const int64_t nhi = lo + (int64_t) t*step;
+      lo = lo + (int64_t) (t-1)*step + 1;
+      if (nhi < hi) hi = nhi;
+    }
+  return lo;
+}
+
+// key and lcp byte (byte 8) of the entry at byte offset o of the staged bytes
+__device__ __forceinline__ uint64_t lds_read_key_lcp(const uint32_t *rawd, uint32_t o, uint32_t &lcp)
+{ const uint32_t w = o >> 2, sh = o & 3;
+  const uint32_t d0 = rawd[w], d1 = rawd[w+1], d2 = rawd[w+2];
+  const uint32_t e0 = __builtin_amdgcn_alignbyte(d1,d0,sh);
+  const uint32_t e1 = __builtin_amdgcn_alignbyte(d2,d1,sh);
+  lcp = (d2 >> (8*sh)) & 0xff;
+  return ((uint64_t) bswap32(e0) << 32) | bswap32(e1);
+}
+
+// payload (position, contig, sign) of the entry at byte offset o of the staged bytes: bytes 9.. of it, three dwords
+__device__ __forceinline__ void lds_payload(const uint32_t *rawd, uint32_t o, int post, int cont,
+                                            uint32_t &pos, uint32_t &ctg, uint32_t &sign)
+{ const uint32_t w = (o + 9) >> 2, sh = (o + 9) & 3;
+  const uint32_t d0 = rawd[w], d1 = rawd[w+1], d2 = rawd[w+2];
+  const uint32_t lo = __builtin_amdgcn_alignbyte(d1,d0,sh), hi = __builtin_amdgcn_alignbyte(d2,d1,sh);
+  const uint64_t pv = ((uint64_t) hi << 32) | lo;
+  const uint32_t pm = post >= 4 ? 0xffffffffu : ((1u << (8*post)) - 1);
+  pos = lo & pm;
+  const uint32_t c  = (uint32_t) (pv >> (8*post)) & ((1u << (8*cont)) - 1);
+  const uint32_t sb = 0x80u << (8*(cont-1));
+  sign = (c & sb) != 0;
+  ctg  = c & (sb-1);
+}
+
+struct walk_out                      // a wavefront's current output chunk and statistics (wave-uniform)
+  { int64_t chunk_pos, chunk_end;
+    unsigned long long tsum;
+  };
+
+// One tile: T1 entries [a0, a0+n1) and T2 entries [b0, b0+n2) (self: the same stretch) in np <= 64 panels whose
+// cumulative sizes are already in la[] / lb[]; only the T1 entries [t1_lo, t1_hi) of the stretch emit.
+template <int MODE>
+__device__ __forceinline__ void walk_tile(const merge_args &A, uint16_t *la, uint16_t *lb, uint8_t *raw, uint64_t *keyB,
+                                          uint16_t *own, uint8_t *lcpB, int64_t a0, int n1, int64_t b0, int n2, int np,
+                                          int t1_lo, int t1_hi, walk_out &O)
+{ const int lane = threadIdx.x;
+  const int E1 = A.E1, E2 = A.E2;
+  const int freq = A.freq;
+  uint32_t *own32 = (uint32_t *) keyB;           // the seed-parallel emission reuses the key array (keys are done with by then)
+  const int64_t s1 = a0*E1, e1 = (a0+n1)*E1;
+  const int64_t s2 = b0*E2, e2 = (b0+n2)*E2;
+  const int64_t s1a = s1 & ~(int64_t) 15, s2a = s2 & ~(int64_t) 15;
+  const int64_t len1 = ((e1 - s1a) + 15) & ~(int64_t) 15;
+  const int64_t len2 = (MODE == MODE_SELF) ? 0 : (((e2 - s2a) + 15) & ~(int64_t) 15);
+
+  // 1. raw bytes HBM -> LDS (global_load_lds_dwordx4), head-flag array cleared
+  { const uint4 *g1 = (const uint4 *) (A.tab1 + s1a);
+    uint4 *l1 = (uint4 *) raw;
+    const int n16 = (int) (len1 >> 4);
+    for (int x = lane; x < n16; x += 64)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (g1 + x),
+                                       (__attribute__((address_space(3))) void *) (l1 + x),16,0,0);
+    if (MODE != MODE_SELF)
+      { const uint4 *g2 = (const uint4 *) (A.tab2 + s2a);
+        uint4 *l2 = (uint4 *) (raw + len1);
+        const int m16 = (int) (len2 >> 4);
+        for (int x = lane; x < m16; x += 64)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (g2 + x),
+                                           (__attribute__((address_space(3))) void *) (l2 + x),16,0,0);
+      }
+  }
+  #pragma unroll
+  for (int x = 0; x < XT/256; x++)
+    ((uint2 *) own)[x*64 + lane] = make_uint2(0,0);
+  // the direct-to-LDS loads are asynchronous and nothing below depends on a VGPR they return: wait for them by hand
+  // (vmcnt(0); the counters of the other queues are left alone)
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  WSYNC();
+#if defined(XKNOCK) && XKNOCK == 1                   // phase knock-outs: timing experiments only (wrong output)
+  return;
+#endif
+
+  const uint32_t *rawd = (const uint32_t *) raw;
+  const uint32_t o1 = (uint32_t) (s1 - s1a);
+  const uint32_t o2 = (MODE == MODE_SELF) ? o1 : (uint32_t) (len1 + (s2 - s2a));
+
+  // 2. head flags of the non-empty T1 panels; T2 keys
+  if (lane < np)
+    { const uint32_t s = lane ? la[lane-1] : 0;
+      if (la[lane] > s)
+        own[s] = (uint16_t) lane;
+    }
+  for (int j = lane; j < n2; j += 64)
+    { uint32_t lc;
+      keyB[j] = lds_read_key_lcp(rawd,o2 + (uint32_t) j*E2,lc);
+      lcpB[j] = (uint8_t) lc;                          // the run growth below walks these bytes
+    }
+  WSYNC();
+#if defined(XKNOCK) && XKNOCK == 2
+  return;
+#endif
+
+  // 3. owner of every T1 entry (XEPT consecutive entries per lane + wave max-scan); compaction of those that can emit
+  int nlive;
+  uint32_t *clist = (uint32_t *) (keyB + n2);
+  { int xs[XEPT];
+    { const uint2 v = ((const uint2 *) own)[lane*(XEPT/4)];
+      xs[0] = v.x & 0xffff; xs[1] = v.x >> 16; xs[2] = v.y & 0xffff; xs[3] = v.y >> 16;
+    }
+    if (XEPT == 8)
+      { const uint2 v = ((const uint2 *) own)[lane*2+1];
+        xs[XEPT-4] = v.x & 0xffff; xs[XEPT-3] = v.x >> 16; xs[XEPT-2] = v.y & 0xffff; xs[XEPT-1] = v.y >> 16;
+      }
+    #pragma unroll
+    for (int e = 1; e < XEPT; e++)
+      xs[e] = xs[e] > xs[e-1] ? xs[e] : xs[e-1];
+    const int inc = wave_incl_scan_max_dpp(xs[XEPT-1]);
+    const int prev = __builtin_amdgcn_update_dpp(0,inc,0x138,0xf,0xf,false);      // lane-1's inclusive value, 0 for lane 0
+    int live = 0;
+    uint32_t pk[XEPT];
+    #pragma unroll
+    for (int e = 0; e < XEPT; e++)
+      { const int i = lane*XEPT + e;
+        const int q = xs[e] > prev ? xs[e] : prev;
+        bool ok = i >= t1_lo && i < t1_hi;
+        if (ok)
+          { const int pb0 = q ? (int) lb[q-1] : 0, pb1 = (int) lb[q];
+            ok = pb1 > pb0;
+            if (ok && MODE == MODE_PAIR)
+              { const uint32_t sb = o1 + (uint32_t) i*E1 + E1 - 1;
+                ok = !((rawd[sb >> 2] >> (8*(sb & 3))) & 0x80);
+              }
+          }
+        pk[e] = ok ? ((uint32_t) i | ((uint32_t) q << 16)) : 0xffffffffu;
+        live += ok;
+      }
+    int lbase = wave_excl_scan_add_dpp(live,nlive);
+    #pragma unroll
+    for (int e = 0; e < XEPT; e++)
+      if (pk[e] != 0xffffffffu)
+        clist[lbase++] = pk[e];
+  }
+  WSYNC();
+#if defined(XKNOCK) && XKNOCK == 3
+  O.tsum += nlive;
+  return;
+#endif
+
+  // 4. match phase; result per round packed: i (9 bits) | low << 9 | plen << 18 | seeds << 24
+  uint32_t res[XEPT];
+  int total = 0;
+  #pragma unroll
+  for (int r = 0; r < XEPT; r++)
+    { const int c = r*64 + lane;
+      res[r] = 0;
+      if (c >= nlive)
+        continue;
+      const uint32_t ce = clist[c];
+      const int i = (int) (ce & 0xffff), q = (int) (ce >> 16);
+      const uint32_t oe = o1 + (uint32_t) i*E1;
+      const int pb0 = q ? (int) lb[q-1] : 0, pb1 = (int) lb[q];
+      const uint64_t ks = (MODE == MODE_SELF) ? keyB[i] : lds_read_key(rawd,oe);
+      int low, hgh, plen, lbnd, lnb, lna;       // lnb / lna: LCP with the T2 neighbour before / after (-1: none)
+      if (MODE == MODE_SELF)
+        { int lk  = (i > pb0)   ? lcp_key(ks,keyB[i-1]) : 0;
+          int lk1 = (i+1 < pb1) ? lcp_key(ks,keyB[i+1]) : 11;
+          plen = lk > lk1 ? lk : lk1;
+          low = i; hgh = i+1; lbnd = i;
+          lnb = (i > pb0) ? lk : -1; lna = (i+1 < pb1) ? lk1 : -1;
+        }
+      else
+        { int lo = pb0, hi = pb1;
+          const uint64_t kq = ks & ~0xffull;
+          while (lo < hi)
+            { int m = (lo+hi) >> 1;
+              if (keyB[m] < kq) lo = m+1; else hi = m;
+            }
+          int la_ = (lo > pb0) ? lcp_key(ks,keyB[lo-1]) : 0;
+          int lc_ = (lo < pb1) ? lcp_key(ks,keyB[lo]) : 0;
+          plen = la_ > lc_ ? la_ : lc_;
+          low = hgh = lbnd = lo;
+          lnb = (lo > pb0) ? la_ : -1; lna = (lo < pb1) ? lc_ : -1;
+        }
+      // run growth on the table's own lcp bytes (see the wave kernel above), here from their own byte array
+      if (lnb >= plen)
+        { low -= 1;
+          while (low > pb0 && lbnd-low <= freq && (int) lcpB[low] >= plen)
+            low -= 1;
+        }
+      if (lna >= plen && hgh < pb1 && hgh-low <= freq)
+        { hgh += 1;
+          while (hgh < pb1 && hgh-low <= freq && (int) lcpB[hgh] >= plen)
+            hgh += 1;
+        }
+      if (hgh-low >= freq)
+        continue;
+      const int mlen = A.soft_mask ? plen : 41;
+      if ((int) (ks & 0xff) >= mlen)
+        continue;
+      int cnt;
+      if (MODE == MODE_FLIP || A.soft_mask)
+        { cnt = 0;
+          for (int j = low; j < hgh; j++)
+            { if ((int) (keyB[j] & 0xff) >= mlen)
+                continue;
+              if (MODE == MODE_FLIP)
+                { uint32_t sb = o2 + (uint32_t) j*E2 + E2 - 1;
+                  if ((rawd[sb >> 2] >> (8*(sb & 3))) & 0x80)
+                    continue;
+                }
+              if (MODE == MODE_SELF && j == i)
+                continue;
+              cnt += 1;
+            }
+        }
+      else
+        cnt = (hgh-low) - (MODE == MODE_SELF ? 1 : 0);
+      res[r] = (uint32_t) i | ((uint32_t) low << 9) | ((uint32_t) plen << 18) | ((uint32_t) cnt << 24);
+      total += cnt;
+      O.tsum += (unsigned long long) cnt * plen;
+    }
+
+#if defined(XKNOCK) && XKNOCK == 4
+  O.tsum += total;
+  WSYNC();
+  return;
+#endif
+  // 5. slots and emission
+  int T;
+  int off = wave_excl_scan_add_dpp(total,T);
+  if (T > 0)
+    { const int64_t rem = O.chunk_end - O.chunk_pos;
+      int64_t nbase = 0, nsize = 0;
+      if ((int64_t) T > rem)
+        { nsize = ((int64_t) T - rem) > CHUNK_SEEDS ? ((int64_t) T - rem) : CHUNK_SEEDS;
+          unsigned long long b = 0;
+          if (lane == 0)
+            b = atomicAdd(A.count,(unsigned long long) nsize);
+          const uint32_t blo = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) b);
+          const uint32_t bhi = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (b >> 32));
+          nbase = (int64_t) (((uint64_t) bhi << 32) | blo);
+        }
+      const bool fast = (MODE != MODE_FLIP) && !A.soft_mask && T <= XT;
+      if (fast)
+        { // seed-parallel: every entry with seeds leaves its descriptor at its first slot; a wave max-scan over
+          // "slot+1 where a descriptor sits" tells every slot where its entry's run of slots begins
+          #pragma unroll
+          for (int x = 0; x < XT/128; x++)
+            ((uint2 *) own32)[x*64 + lane] = make_uint2(0,0);
+          WSYNC();
+          { int o = off;
+            #pragma unroll
+            for (int r = 0; r < XEPT; r++)
+              { const int cnt = (int) (res[r] >> 24);
+                if (cnt > 0)
+                  { own32[o] = (res[r] & 0xffffffu) | 0x80000000u;
+                    o += cnt;
+                  }
+              }
+          }
+          WSYNC();
+          int carry = 0;
+          for (int s0 = 0; s0 < T; s0 += 64)
+            { const int slot = s0 + lane;
+              int v = (slot < T && own32[slot] != 0) ? slot+1 : 0;
+              v = wave_incl_scan_max_dpp(v);
+              v = v > carry ? v : carry;
+              carry = __builtin_amdgcn_readlane(v,63);
+              if (slot < T)
+                { const int start = v-1;
+                  const uint32_t d = own32[start];
+                  const int i = (int) (d & 0x1ff), plen = (int) ((d >> 18) & 0x3f);
+                  int j = (int) ((d >> 9) & 0x1ff) + (slot - start);
+                  if (MODE == MODE_SELF && j >= i)
+                    j += 1;
+                  uint32_t spos, sctg, ssign, cpos, cctg, csign;
+                  lds_payload(rawd,o1 + (uint32_t) i*E1,A.post1,A.cont1,spos,sctg,ssign);
+                  lds_payload(rawd,o2 + (uint32_t) j*E2,A.post2,A.cont2,cpos,cctg,csign);
+                  const int64_t at = ((int64_t) slot < rem) ? O.chunk_pos + slot : nbase + ((int64_t) slot - rem);
+#if defined(XKNOCK) && XKNOCK == 5
+                  if (at == -12345)
+#else
+                  if (at < A.cap)
+#endif
+                    A.out[at] = make_seed<MODE>(plen,spos,sctg,ssign,cpos,cctg,csign);
+                }
+            }
+        }
+      else if (total > 0)
+        { const int mfull = A.soft_mask;
+          #pragma unroll
+          for (int r = 0; r < XEPT; r++)
+            { int left = (int) (res[r] >> 24);
+              if (left == 0)
+                continue;
+              const int i = (int) (res[r] & 0x1ff), plen = (int) ((res[r] >> 18) & 0x3f);
+              const int mlen = mfull ? plen : 41;
+              uint32_t spos, sctg, ssign;
+              lds_payload(rawd,o1 + (uint32_t) i*E1,A.post1,A.cont1,spos,sctg,ssign);
+              for (int j = (int) ((res[r] >> 9) & 0x1ff); left > 0; j++)
+                { if ((int) (keyB[j] & 0xff) >= mlen)
+                    continue;
+                  if (MODE == MODE_SELF && j == i)
+                    continue;
+                  uint32_t cpos, cctg, csign;
+                  lds_payload(rawd,o2 + (uint32_t) j*E2,A.post2,A.cont2,cpos,cctg,csign);
+                  if (MODE == MODE_FLIP && csign)
+                    continue;
+                  const int64_t at = ((int64_t) off < rem) ? O.chunk_pos + off : nbase + ((int64_t) off - rem);
+                  if (at < A.cap)
+                    A.out[at] = make_seed<MODE>(plen,spos,sctg,ssign,cpos,cctg,csign);
+                  off += 1;
+                  left -= 1;
+                }
+            }
+        }
+      if ((int64_t) T > rem)
+        { O.chunk_pos = nbase + ((int64_t) T - rem); O.chunk_end = nbase + nsize; }
+      else
+        O.chunk_pos += T;
+    }
+  WSYNC();      // the tile buffers are reused by the next tile
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVE_OCC,WAVE_OCC)))
+void seed_merge_walk_kernel(merge_args A, walk_args W)
+{ __shared__ uint16_t la[XPC+1];
+  __shared__ uint16_t lb[XPC+1];
+  extern __shared__ __attribute__((aligned(16))) uint8_t raw[];      // A.wrawcap bytes (sized by the entry widths)
+  __shared__ __attribute__((aligned(16))) uint64_t keyB[XT];
+  __shared__ __attribute__((aligned(16))) uint16_t own16[XT];
+  __shared__ __attribute__((aligned(16))) uint8_t  lcpB[XT];
+
+  const int lane = threadIdx.x;
+  const int E1 = A.E1, E2 = A.E2;
+  const int64_t *idx2 = (MODE == MODE_SELF) ? A.idx1 : A.idx2;
+  const uint8_t *tab2 = (MODE == MODE_SELF) ? A.tab1 : A.tab2;
+  const int margin = A.freq + 2;
+  walk_out O;
+  O.chunk_pos = O.chunk_end = 0; O.tsum = 0;
+
+  for (;;)
+    { int r = 0;
+      if (lane == 0)
+        r = atomicAdd(W.next,1);
+      r = __builtin_amdgcn_readfirstlane(r);
+      if (r >= W.nranges)
+        break;
+      int p = (int) W.cuts[r];
+      const int pe = (int) W.cuts[r+1];
+      if (p >= pe)
+        continue;
+      int64_t a = idx_at(A.idx1,p-1), b = idx_at(idx2,p-1);
+      // index entries of the next 64 prefixes, one per lane (clamped at the range end)
+      int64_t ca = A.idx1[p + (lane < pe-p ? lane : pe-p-1)];
+      int64_t cb = (MODE == MODE_SELF) ? ca : idx2[p + (lane < pe-p ? lane : pe-p-1)];
+      while (p < pe)
+        { const int navail = pe - p < XPC ? pe - p : XPC;
+          const int64_t cost = (ca - a) + (cb - b) + 2*((int64_t) lane+1);
+          const bool fits = lane < navail && cost <= XT;
+          const int q = __popcll(__builtin_amdgcn_ballot_w64(fits));     // cost grows with the lane: a prefix mask
+          const int adv = q > 0 ? q : 1;
+          // end of the tile (or of the single oversize panel): totals up to prefix p+adv-1
+          const uint32_t alo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) ca,adv-1);
+          const uint32_t ahi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) ((uint64_t) ca >> 32),adv-1);
+          const uint32_t blo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) cb,adv-1);
+          const uint32_t bhi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) ((uint64_t) cb >> 32),adv-1);
+          const int64_t a1 = (int64_t) (((uint64_t) ahi << 32) | alo), b1 = (int64_t) (((uint64_t) bhi << 32) | blo);
+          const int64_t n1 = a1 - a, n2 = b1 - b;
+          if (q > 0 && n1 > 0 && n2 > 0 && lane < q)
+            { la[lane] = (uint16_t) (ca - a);
+              lb[lane] = (uint16_t) (cb - b);
+            }
+          // the index entries of the tile after this one are on their way while this one is processed
+          const int pn = p + adv;
+          int64_t na = 0, nb = 0;
+          if (pn < pe)
+            { na = A.idx1[pn + (lane < pe-pn ? lane : pe-pn-1)];
+              nb = (MODE == MODE_SELF) ? na : idx2[pn + (lane < pe-pn ? lane : pe-pn-1)];
+            }
+          if (n1 > 0 && n2 > 0)
+            { if (q > 0)
+                walk_tile<MODE>(A,la,lb,raw,keyB,own16,lcpB,a,(int) n1,b,(int) n2,q,0,(int) n1,O);
+#ifdef SKIP_BIG                      // timing experiments only (wrong output): oversize panels dropped
+              else if (true) ;
+#endif
+              else if (MODE == MODE_SELF)
+                { // one oversize panel against itself: runs of T1 entries with `margin` neighbours either side
+                  const int C = XT/2 - 2*margin;
+                  for (int64_t i0 = 0; i0 < n1; i0 += C)
+                    { const int64_t i1 = i0 + C < n1 ? i0 + C : n1;
+                      const int64_t s0 = i0 - margin > 0 ? i0 - margin : 0, s1 = i1 + margin < n1 ? i1 + margin : n1;
+                      if (lane == 0)
+                        la[0] = lb[0] = (uint16_t) (s1 - s0);
+                      walk_tile<MODE>(A,la,lb,raw,keyB,own16,lcpB,a+s0,(int) (s1-s0),a+s0,(int) (s1-s0),1,
+                                      (int) (i0-s0),(int) (i1-s0),O);
+                    }
+                }
+              else
+                { // one oversize panel: runs of T1 entries, each with the stretch of the T2 panel its keys can reach
+                  int64_t from = b;
+                  for (int64_t i = 0; i < n1; )
+                    { int c1 = (int) (n1 - i < XT/2 ? n1 - i : XT/2);
+                      int64_t s0, s1, l1;
+                      const uint64_t k0 = glb_key3(A.tab1,a+i,E1) & ~0xffull;
+                      const int64_t l0 = wave_lower_bound(tab2,E2,from,b1,k0);
+                      for (;;)
+                        { const uint64_t k1 = glb_key3(A.tab1,a+i+c1-1,E1) & ~0xffull;
+                          l1 = wave_lower_bound(tab2,E2,l0,b1,k1);
+                          s0 = l0 - margin > b ? l0 - margin : b;
+                          s1 = l1 + margin < b1 ? l1 + margin : b1;
+                          if (c1 + (s1 - s0) <= XT-2 || c1 == 1)
+                            break;
+                          c1 = c1 > 1 ? c1/2 : 1;
+                        }
+                      if (s1 > s0)
+                        { if (lane == 0)
+                            { la[0] = (uint16_t) c1; lb[0] = (uint16_t) (s1 - s0); }
+                          walk_tile<MODE>(A,la,lb,raw,keyB,own16,lcpB,a+i,c1,s0,(int) (s1-s0),1,0,c1,O);
+                        }
+                      from = l1;
+                      i += c1;
+                    }
+                }
+            }
+          a = a1; b = b1; p = pn;
+          ca = na; cb = nb;
+        }
+    }
+
+  if (lane == 0 && O.chunk_end > O.chunk_pos)          // the unused tail of the last chunk
+    { const unsigned long long h = atomicAdd(W.nhole,1ull);
+      if ((int64_t) h < W.hole_cap)
+        { W.holes[2*h] = (unsigned long long) O.chunk_pos; W.holes[2*h+1] = (unsigned long long) O.chunk_end; }
+    }
+  unsigned long long tsum = O.tsum;
+  #pragma unroll
+  for (int d = 32; d >= 1; d >>= 1)
+    tsum += __shfl_xor(tsum,d,64);
+  if (lane == 0 && tsum != 0)
+    atomicAdd(A.tseed,tsum);
+}
+
 // tile descriptor pairs of the queued oversize tiles, for the workgroup kernel in pair mode
 __global__ void gather_big_tiles_kernel(const merge_tile *tiles, const int *bigq, const unsigned long long *nbig,
                                         int big_cap, merge_tile *pairs)
@@ -1181,6 +1698,15 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
     if (e != NULL && atoi(e) != 0) use_wave = 0;
   }
 
+  // the range-walking kernel (v3) does the whole merge in one launch; FGA_MERGE_V2=1 selects the previous wave kernel
+  // (partition kernel + tile queue + workgroup kernel for oversize tiles), which also takes over when the frequency
+  // cutoff is too large for the in-wavefront sub-tiles of an oversize panel (margin FREQ+2 on both sides)
+  int use_walk = use_wave;
+  { const char *e = getenv("FGA_MERGE_V2");
+    if (e != NULL && atoi(e) != 0) use_walk = 0;
+    if (prm->freq + 2 >= XT/4 - 1) use_walk = 0;
+  }
+
   fga_dseeds *S = append;
   if (S == NULL)
     { S = (fga_dseeds *) calloc(1,sizeof(fga_dseeds));
@@ -1218,8 +1744,8 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
   A.out = S->seeds; A.cap = phys;
   A.count = counters; A.tseed = counters+1;
   A.pairs = 0; A.npairs = NULL; A.pair_cap = 0;
-  { const int emax = A.E1 > A.E2 ? A.E1 : A.E2;           // two 16-byte-aligned ranges of <= WTILE_COST entries in all
-    A.wrawcap = ((WTILE_COST*emax + 96 + 15) / 16) * 16;
+  { const int emax = A.E1 > A.E2 ? A.E1 : A.E2;           // two 16-byte-aligned ranges of <= tile-cost entries in all
+    A.wrawcap = (((use_walk ? XT : WTILE_COST)*emax + 96 + 15) / 16) * 16;
   }
 
   void *work = NULL;                      // tiles + (wave kernel) pairs, holes, counters, queue, moves
@@ -1235,7 +1761,8 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
       { const char *ev = getenv(use_wave ? "FGA_MERGE_WAVES" : "FGA_MERGE_WGS");
         if (ev != NULL && atoi(ev) > 0) wgs = atoi(ev);
       }
-      if (use_wave && wgs > 24) wgs = 24;                    // the slack of phys_capacity covers 32 waves per CU
+      if (use_walk) wgs = 4*WAVE_OCC;
+      if (use_wave && wgs > 28) wgs = 28;                    // the slack of phys_capacity covers 32 waves per CU
       int grid = dev->ncu * wgs;
       if (use_wave && grid > A.ntiles/8 + 1) grid = A.ntiles/8 + 1;      // small inputs: few waves, few holes
       if (grid > A.ntiles) grid = A.ntiles;
@@ -1264,11 +1791,44 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
         start_count = (unsigned long long) S->count;
 
       hipEventRecord(dev->ev0,dev->stream);
+      if (use_walk)
+        { // every wavefront of the launch is resident (they are persistent): as many as the LDS of a CU holds, at most
+          // the register budget's 4 x WAVE_OCC
+          { const int lds = ((2*(XPC+1)*2 + XT*8 + XT*2 + XT + A.wrawcap + 64 + 511) / 512) * 512;
+            int per_cu = (160*1024) / lds;
+            if (per_cu > 4*WAVE_OCC) per_cu = 4*WAVE_OCC;
+            const char *ev = getenv("FGA_MERGE_WAVES");
+            if (ev != NULL && atoi(ev) > 0 && atoi(ev) < per_cu) per_cu = atoi(ev);
+            if (grid > dev->ncu*per_cu) grid = dev->ncu*per_cu;
+          }
+          // ranges of equal merge cost, a few per wavefront, taken off a queue; cuts / queue head live in the tile area
+          int nranges = grid*RANGES_PER_WAVE;
+          if ((int64_t) nranges > total/(8*XT) + 1) nranges = (int) (total/(8*XT)) + 1;
+          if (grid > nranges) grid = nranges;
+          int64_t *cuts = (int64_t *) tiles;
+          int *qhead = (int *) (wctr + 2);
+          walk_args WA;
+          WA.cuts = cuts; WA.nranges = nranges; WA.next = qhead;
+          WA.holes = holes; WA.nhole = wctr; WA.hole_cap = hole_cap;
+          hipMemsetAsync(wctr,0,4*sizeof(unsigned long long),dev->stream);
+          hipLaunchKernelGGL(range_cut_kernel,dim3((nranges+1+255)/256),dim3(256),0,dev->stream,
+                             A.idx1,A.idx2,A.pbeg,A.pend,A.base,total,nranges,cuts);
+          hipEventRecord(dev->ev1,dev->stream);
+          if (self)
+            hipLaunchKernelGGL(seed_merge_walk_kernel<MODE_SELF>,dim3(grid),dim3(64),A.wrawcap,dev->stream,A,WA);
+          else if (prm->flip)
+            hipLaunchKernelGGL(seed_merge_walk_kernel<MODE_FLIP>,dim3(grid),dim3(64),A.wrawcap,dev->stream,A,WA);
+          else
+            hipLaunchKernelGGL(seed_merge_walk_kernel<MODE_PAIR>,dim3(grid),dim3(64),A.wrawcap,dev->stream,A,WA);
+        }
+      else
       { int nb = (A.ntiles + 1 + 255) / 256;
         hipLaunchKernelGGL(merge_partition_kernel,dim3(nb),dim3(256),0,dev->stream,A,tiles);
+        hipEventRecord(dev->ev1,dev->stream);
       }
-      hipEventRecord(dev->ev1,dev->stream);
-      if (!use_wave)
+      if (use_walk)
+        ;
+      else if (!use_wave)
         { if (self)
             hipLaunchKernelGGL(seed_merge_kernel<MODE_SELF>,dim3(grid),dim3(NT),0,dev->stream,A);
           else if (prm->flip)
@@ -1301,16 +1861,27 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
             hipLaunchKernelGGL(seed_merge_kernel<MODE_PAIR>,dim3(bgrid),dim3(NT),0,dev->stream,B);
         }
 
+      // one round trip: counters, wave counters and the whole hole list land in pinned memory together
       unsigned long long hw[4] = {0,0,0,0};
-      err = hipMemcpyAsync(hc,counters,sizeof(hc),hipMemcpyDeviceToHost,dev->stream);
+      unsigned long long *pin = (unsigned long long *) fga_dev_pinned(dev,sizeof(unsigned long long)*(8 + 2*(size_t) hole_cap)
+                                                                          + sizeof(seed_move)*2*(size_t) (hole_cap+1));
+      if (pin == NULL)
+        { fga_set_error("fga_seed_merge: pinned staging allocation failed");
+          goto done;
+        }
+      err = hipMemcpyAsync(pin,counters,2*sizeof(unsigned long long),hipMemcpyDeviceToHost,dev->stream);
       if (err == hipSuccess && use_wave)
-        err = hipMemcpyAsync(hw,wctr,sizeof(hw),hipMemcpyDeviceToHost,dev->stream);
+        err = hipMemcpyAsync(pin+2,wctr,4*sizeof(unsigned long long),hipMemcpyDeviceToHost,dev->stream);
+      if (err == hipSuccess && use_wave && hole_cap > 0)
+        err = hipMemcpyAsync(pin+8,holes,sizeof(unsigned long long)*2*(size_t) hole_cap,hipMemcpyDeviceToHost,dev->stream);
       if (err == hipSuccess) err = hipStreamSynchronize(dev->stream);
       if (err == hipSuccess) err = hipGetLastError();
       if (err != hipSuccess)
         { fga_set_error("fga_seed_merge: kernel failed: %s",hipGetErrorString(err));
           goto done;
         }
+      hc[0] = pin[0]; hc[1] = pin[1];
+      if (use_wave) { hw[0] = pin[2]; hw[1] = pin[3]; }
 
       if (use_wave && (int64_t) hw[1] > big_cap)
         { // more oversize tiles than the queue holds (a pathologically repetitive input): redo everything with
@@ -1318,66 +1889,64 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
           hipMemcpyAsync(counters,&start_count,sizeof(unsigned long long),hipMemcpyHostToDevice,dev->stream);
           hipStreamSynchronize(dev->stream);
           fga_dev_release(dev,SLOT_TILES,work); work = NULL;
-          use_wave = 0;
+          use_wave = 0; use_walk = 0;
           continue;
         }
 
       if (use_wave && hw[0] > 0 && (int64_t) hc[0] <= phys)
         { // close the holes: seeds at the end of the allocated range move into the unused chunk tails
-          const int nh = (int) hw[0];
-          std::vector<unsigned long long> hh(2*(size_t) nh);
-          if (hipMemcpy(hh.data(),holes,sizeof(unsigned long long)*2*(size_t) nh,hipMemcpyDeviceToHost) != hipSuccess)
-            { fga_set_error("fga_seed_merge: hole list download failed");
-              goto done;
-            }
-          std::vector<std::pair<int64_t,int64_t> > H((size_t) nh);
+          const int nh = (int) (hw[0] < (unsigned long long) hole_cap ? hw[0] : (unsigned long long) hole_cap);
+          const unsigned long long *hh = pin + 8;
           int64_t hsum = 0;
           for (int i = 0; i < nh; i++)
-            { H[(size_t) i] = std::make_pair((int64_t) hh[2*(size_t) i],(int64_t) hh[2*(size_t) i+1]);
-              hsum += H[(size_t) i].second - H[(size_t) i].first;
-            }
-          std::sort(H.begin(),H.end());
+            hsum += (int64_t) (hh[2*(size_t) i+1] - hh[2*(size_t) i]);
           const int64_t C = (int64_t) hc[0], D = C - hsum;          // allocated, dense
-          // sources: the occupied stretches of [D,C); destinations: the holes (clipped) below D
-          std::vector<std::pair<int64_t,int64_t> > src, dst;
+          // destinations: the holes (clipped) below D, in any order; sources: the occupied stretches of [D,C), which
+          // needs the few holes that reach above D in order
+          std::vector<std::pair<int64_t,int64_t> > src, dst, above;
+          for (int i = 0; i < nh; i++)
+            { const int64_t hb = (int64_t) hh[2*(size_t) i], he = (int64_t) hh[2*(size_t) i+1];
+              if (hb < D) dst.push_back(std::make_pair(hb,he < D ? he : D));
+              if (he > D) above.push_back(std::make_pair(hb > D ? hb : D,he));
+            }
+          std::sort(above.begin(),above.end());
           { int64_t pos = D;
-            for (int i = 0; i < nh; i++)
-              { const int64_t hb = H[(size_t) i].first, he = H[(size_t) i].second;
-                if (he <= D) { dst.push_back(H[(size_t) i]); continue; }
-                if (hb < D) dst.push_back(std::make_pair(hb,D));
-                const int64_t b0 = hb > D ? hb : D;
-                if (b0 > pos) src.push_back(std::make_pair(pos,b0));
-                pos = he;
+            for (size_t i = 0; i < above.size(); i++)
+              { if (above[i].first > pos) src.push_back(std::make_pair(pos,above[i].first));
+                pos = above[i].second;
               }
             if (pos < C) src.push_back(std::make_pair(pos,C));
           }
-          std::vector<seed_move> mv;
+          seed_move *mv = (seed_move *) (pin + 8 + 2*(size_t) hole_cap);
+          size_t nmv = 0;
           { size_t si = 0, di = 0;
             int64_t so = 0, dof = 0;
-            while (si < src.size() && di < dst.size())
+            while (si < src.size() && di < dst.size() && nmv < 2*(size_t) (hole_cap+1))
               { const int64_t sl = src[si].second - src[si].first - so, dl = dst[di].second - dst[di].first - dof;
                 const int64_t l = sl < dl ? sl : dl;
-                seed_move m; m.src = src[si].first + so; m.dst = dst[di].first + dof; m.len = l;
-                if (l > 0) mv.push_back(m);
+                if (l > 0)
+                  { mv[nmv].src = src[si].first + so; mv[nmv].dst = dst[di].first + dof; mv[nmv].len = l;
+                    nmv += 1;
+                  }
                 so += l; dof += l;
                 if (so == src[si].second - src[si].first) { si += 1; so = 0; }
                 if (dof == dst[di].second - dst[di].first) { di += 1; dof = 0; }
               }
+            if (si < src.size() && di < dst.size())
+              { fga_set_error("fga_seed_merge: internal error, hole plan larger than its buffer");
+                goto done;
+              }
           }
-          if (!mv.empty())
-            { if (mv.size() > 2*(size_t) (hole_cap+1))
-                { fga_set_error("fga_seed_merge: internal error, hole plan larger than its buffer");
-                  goto done;
-                }
-              if (hipMemcpyAsync(moves,mv.data(),sizeof(seed_move)*mv.size(),hipMemcpyHostToDevice,dev->stream) != hipSuccess)
+          if (nmv > 0)
+            { if (hipMemcpyAsync(moves,mv,sizeof(seed_move)*nmv,hipMemcpyHostToDevice,dev->stream) != hipSuccess)
                 { fga_set_error("fga_seed_merge: hole plan upload failed");
                   goto done;
                 }
-              hipLaunchKernelGGL(hole_fill_kernel,dim3((unsigned) mv.size()),dim3(256),0,dev->stream,
-                                 S->seeds,moves,(int) mv.size());
+              hipLaunchKernelGGL(hole_fill_kernel,dim3((unsigned) nmv),dim3(256),0,dev->stream,S->seeds,moves,(int) nmv);
             }
           hc[0] = (unsigned long long) D;
-          hipMemcpyAsync(counters,hc,sizeof(unsigned long long),hipMemcpyHostToDevice,dev->stream);
+          pin[0] = hc[0];
+          hipMemcpyAsync(counters,pin,sizeof(unsigned long long),hipMemcpyHostToDevice,dev->stream);
         }
       hipEventRecord(ev2,dev->stream);
       if (hipStreamSynchronize(dev->stream) != hipSuccess)
@@ -1397,7 +1966,8 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
   }
 #endif
   hipEventElapsedTime(&dev->last_ms[FGA_STAGE_MERGE_PARTITION],dev->ev0,dev->ev1);
-  hipEventElapsedTime(&dev->last_ms[FGA_STAGE_MERGE],dev->ev1,ev2);
+  // the merge stage = everything the launch runs: range cuts / tile partition, the merge kernels, hole closing
+  hipEventElapsedTime(&dev->last_ms[FGA_STAGE_MERGE],dev->ev0,ev2);
   S->count  = (int64_t) hc[0];
   S->tseed  = (int64_t) hc[1];
   rc = 0;
