@@ -168,11 +168,30 @@ extern "C" int64_t fga_seeds_count(const fga_dseeds *S)    { return S->count; }
 extern "C" int64_t fga_seeds_plen_sum(const fga_dseeds *S) { return S->tseed; }
 
 extern "C" int fga_seeds_download(const fga_dseeds *S, fga_seed *host, int64_t max)
-{ int64_t n = S->count < S->capacity ? S->count : S->capacity;
-  if (n > max) n = max;
-  FGA_HIP(hipSetDevice(S->dev->device));
-  if (n > 0)
-    FGA_HIP(hipMemcpy(host,S->seeds,sizeof(fga_seed)*(size_t) n,hipMemcpyDeviceToHost));
+{ FGA_HIP(hipSetDevice(S->dev->device));
+  if (S->valid == NULL)
+    { int64_t n = S->count < S->capacity ? S->count : S->capacity;
+      if (n > max) n = max;
+      if (n > 0)
+        FGA_HIP(hipMemcpy(host,S->seeds,sizeof(fga_seed)*(size_t) n,hipMemcpyDeviceToHost));
+      return 0;
+    }
+  // a buffer with holes: block by block, the valid head of each
+  const int64_t ext = fga_seeds_extent(S), nb = (ext + FGA_SEED_BLOCK - 1) / FGA_SEED_BLOCK;
+  std::vector<uint16_t> v((size_t) nb + 1);
+  std::vector<fga_seed> all((size_t) ext + 1);
+  FGA_HIP(hipMemcpy(v.data(),S->valid,sizeof(uint16_t)*(size_t) nb,hipMemcpyDeviceToHost));
+  if (ext > 0)
+    FGA_HIP(hipMemcpy(all.data(),S->seeds,sizeof(fga_seed)*(size_t) ext,hipMemcpyDeviceToHost));
+  int64_t o = 0;
+  for (int64_t b = 0; b < nb && o < max; b++)
+    { int64_t k = v[(size_t) b];
+      if (b*FGA_SEED_BLOCK + k > ext) k = ext - b*FGA_SEED_BLOCK;
+      if (o + k > max) k = max - o;
+      if (k > 0)
+        memcpy(host+o,all.data() + b*FGA_SEED_BLOCK,sizeof(fga_seed)*(size_t) k);
+      o += k;
+    }
   return 0;
 }
 
@@ -180,6 +199,7 @@ extern "C" void fga_seeds_free(fga_dseeds *S)
 { if (S == NULL) return;
   hipSetDevice(S->dev->device);
   fga_dev_release(S->dev,S->slot,S->seeds);
+  fga_dev_release(S->dev,SLOT_VALID,S->valid);
   hipFree(S->dcount);
   free(S);
 }

@@ -49,7 +49,7 @@ struct fga_dgix
 //   actg       : A contig (length-sorted index) << 8 | plen
 //   bctg       : B contig | (B entry's own sign bit) << 30 | (C-stream flag) << 31
 enum { SLOT_SEEDS = 0, SLOT_SORT0, SLOT_SORT1, SLOT_HIST, SLOT_TILES, SLOT_CELLS, SLOT_TRACE, SLOT_ALNS,
-       SLOT_TBYTES, SLOT_MISC, SLOT_COUNT };
+       SLOT_TBYTES, SLOT_MISC, SLOT_VALID, SLOT_COUNT };
 void *fga_dev_acquire(fga_dev *dev, int slot, size_t bytes);   // NULL on failure; pair with fga_dev_release
 void  fga_dev_release(fga_dev *dev, int slot, void *ptr);
 void *fga_dev_pinned(fga_dev *dev, size_t bytes);              // host pinned staging, grow-only
@@ -63,8 +63,19 @@ struct fga_dseeds
     int       slot;       // workspace slot the seed buffer came from (-1: own allocation)
     int64_t   tseed;      // sum of plen over all seeds
     int64_t   count;      // seeds produced (may exceed capacity -> overflow, buffer holds `capacity`)
-    int64_t  *dcount;     // device counter
+    int64_t  *dcount;     // device counters: [0] slots handed out, [1] sum of plen, [2] slots left unused (holes)
+    // The range-walking merge kernel hands out the buffer in 1024-seed blocks and never closes the unused tail of a
+    // wavefront's last block: valid[b] = seeds in block b (1024 unless it is such a tail); every consumer -- the sort's
+    // first pass, the routing kernels, the download -- skips the rest.  NULL: the buffer is dense.
+    uint16_t *valid;
+    int64_t   phys_count; // slots in use including the holes (== count for a dense buffer)
   };
+#define FGA_SEED_BLOCK 1024
+// slots a consumer has to look at
+static inline int64_t fga_seeds_extent(const fga_dseeds *S)
+{ const int64_t n = S->valid != NULL ? S->phys_count : S->count;
+  return n < S->phys_capacity ? n : S->phys_capacity;
+}
 
 // sorted 128-bit diagonal records (fga_sort.hip)
 struct fga_dkeys

@@ -84,6 +84,9 @@ struct merge_args
     fga_seed *out; int64_t cap;
     unsigned long long *count;        // seeds produced
     unsigned long long *tseed;        // sum of plen (the reference's "ave. len" statistic)
+    uint16_t *valid;                  // v3: seeds per 1024-slot block of `out` (holes are left open, consumers skip them)
+    int64_t   nblocks;
+    unsigned long long *hslots;       // v3: slots left unused
   };
 
 __device__ __forceinline__ int64_t idx_at(const int64_t *idx, int p)     // inclusive cumulative, idx[-1] = 0
@@ -1132,9 +1135,6 @@ struct walk_args
   { const int64_t *cuts;             // [nranges+1] prefix boundaries
     int            nranges;
     int           *next;             // range queue head
-    unsigned long long *holes;       // [2*hole_cap] unused chunk tails (begin,end)
-    unsigned long long *nhole;
-    int            hole_cap;
   };
 
 __global__ void range_cut_kernel(const int64_t *idx1, const int64_t *idx2, int pbeg, int pend, int64_t base,
@@ -1412,7 +1412,7 @@ __device__ __forceinline__ void walk_tile(const merge_args &A, uint16_t *la, uin
     { const int64_t rem = O.chunk_end - O.chunk_pos;
       int64_t nbase = 0, nsize = 0;
       if ((int64_t) T > rem)
-        { nsize = ((int64_t) T - rem) > CHUNK_SEEDS ? ((int64_t) T - rem) : CHUNK_SEEDS;
+        { nsize = (((int64_t) T - rem) + FGA_SEED_BLOCK-1) & ~(int64_t) (FGA_SEED_BLOCK-1);    // whole blocks, block aligned
           unsigned long long b = 0;
           if (lane == 0)
             b = atomicAdd(A.count,(unsigned long long) nsize);
@@ -1609,10 +1609,13 @@ void seed_merge_walk_kernel(merge_args A, walk_args W)
         }
     }
 
-  if (lane == 0 && O.chunk_end > O.chunk_pos)          // the unused tail of the last chunk
-    { const unsigned long long h = atomicAdd(W.nhole,1ull);
-      if ((int64_t) h < W.hole_cap)
-        { W.holes[2*h] = (unsigned long long) O.chunk_pos; W.holes[2*h+1] = (unsigned long long) O.chunk_end; }
+  if (O.chunk_end > O.chunk_pos)                       // the unused tail of the last chunk stays open: its blocks say so
+    { const int64_t b0 = O.chunk_pos >> 10, b1 = (O.chunk_end - 1) >> 10;
+      for (int64_t bk = b0 + lane; bk <= b1; bk += 64)
+        if (bk < A.nblocks)
+          A.valid[bk] = (uint16_t) (bk == b0 ? (O.chunk_pos & (FGA_SEED_BLOCK-1)) : 0);
+      if (lane == 0)
+        atomicAdd(A.hslots,(unsigned long long) (O.chunk_end - O.chunk_pos));
     }
   unsigned long long tsum = O.tsum;
   #pragma unroll
@@ -1731,7 +1734,7 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
   if (append != NULL)
     counters = (unsigned long long *) S->dcount;
   else
-    { if ((err = hipMalloc(&counters,2*sizeof(unsigned long long))) != hipSuccess ||
+    { if ((err = hipMalloc(&counters,4*sizeof(unsigned long long))) != hipSuccess ||
           (S->seeds = (fga_seed *) fga_dev_acquire(dev,SLOT_SEEDS,sizeof(fga_seed)*(size_t) S->phys_capacity)) == NULL)
         { fga_set_error("fga_seed_merge: device allocation failed: %s",hipGetErrorString(err));
           hipFree(counters); free(S);
@@ -1739,10 +1742,22 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
         }
       S->slot = SLOT_SEEDS;
       S->dcount = (int64_t *) counters;
-      hipMemsetAsync(counters,0,2*sizeof(unsigned long long),dev->stream);
+      hipMemsetAsync(counters,0,4*sizeof(unsigned long long),dev->stream);
+      if (use_walk)
+        { const int64_t nb = (S->phys_capacity + FGA_SEED_BLOCK-1) / FGA_SEED_BLOCK + 2;
+          S->valid = (uint16_t *) fga_dev_acquire(dev,SLOT_VALID,sizeof(uint16_t)*(size_t) nb);
+          if (S->valid == NULL)
+            { fga_set_error("fga_seed_merge: device allocation failed");
+              hipFree(counters); fga_dev_release(dev,SLOT_SEEDS,S->seeds); free(S);
+              return 1;
+            }
+          hipMemsetD16Async((hipDeviceptr_t) S->valid,(unsigned short) FGA_SEED_BLOCK,(size_t) nb,dev->stream);
+        }
     }
+  if (S->valid == NULL) use_walk = 0;            // appending to a dense buffer of the previous kernels
   A.out = S->seeds; A.cap = phys;
-  A.count = counters; A.tseed = counters+1;
+  A.count = counters; A.tseed = counters+1; A.hslots = counters+2;
+  A.valid = S->valid; A.nblocks = (S->phys_capacity + FGA_SEED_BLOCK-1) / FGA_SEED_BLOCK + 2;
   A.pairs = 0; A.npairs = NULL; A.pair_cap = 0;
   { const int emax = A.E1 > A.E2 ? A.E1 : A.E2;           // two 16-byte-aligned ranges of <= tile-cost entries in all
     A.wrawcap = (((use_walk ? XT : WTILE_COST)*emax + 96 + 15) / 16) * 16;
@@ -1750,6 +1765,7 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
 
   void *work = NULL;                      // tiles + (wave kernel) pairs, holes, counters, queue, moves
   unsigned long long hc[2];
+  int64_t hslots = 0;                     // v3: slots the launch (and earlier ones into the same buffer) left unused
   int rc = 1;
   hipEvent_t ev2 = NULL;
   hipEventCreate(&ev2);
@@ -1788,7 +1804,7 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
 
       unsigned long long start_count = 0;           // an append starts behind the seeds already there
       if (append != NULL)
-        start_count = (unsigned long long) S->count;
+        start_count = (unsigned long long) (S->valid != NULL ? S->phys_count : S->count);
 
       hipEventRecord(dev->ev0,dev->stream);
       if (use_walk)
@@ -1809,7 +1825,6 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
           int *qhead = (int *) (wctr + 2);
           walk_args WA;
           WA.cuts = cuts; WA.nranges = nranges; WA.next = qhead;
-          WA.holes = holes; WA.nhole = wctr; WA.hole_cap = hole_cap;
           hipMemsetAsync(wctr,0,4*sizeof(unsigned long long),dev->stream);
           hipLaunchKernelGGL(range_cut_kernel,dim3((nranges+1+255)/256),dim3(256),0,dev->stream,
                              A.idx1,A.idx2,A.pbeg,A.pend,A.base,total,nranges,cuts);
@@ -1862,6 +1877,9 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
         }
 
       // one round trip: counters, wave counters and the whole hole list land in pinned memory together
+      const bool tm = getenv("FGA_MERGE_TIMING") != NULL;
+      const double tm0 = tm ? fga_wall() : 0.;
+      double tm1 = 0., tm2 = 0.;
       unsigned long long hw[4] = {0,0,0,0};
       unsigned long long *pin = (unsigned long long *) fga_dev_pinned(dev,sizeof(unsigned long long)*(8 + 2*(size_t) hole_cap)
                                                                           + sizeof(seed_move)*2*(size_t) (hole_cap+1));
@@ -1870,9 +1888,11 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
           goto done;
         }
       err = hipMemcpyAsync(pin,counters,2*sizeof(unsigned long long),hipMemcpyDeviceToHost,dev->stream);
-      if (err == hipSuccess && use_wave)
+      if (err == hipSuccess && use_walk)
+        err = hipMemcpyAsync(pin+6,counters+2,sizeof(unsigned long long),hipMemcpyDeviceToHost,dev->stream);
+      if (err == hipSuccess && use_wave && !use_walk)
         err = hipMemcpyAsync(pin+2,wctr,4*sizeof(unsigned long long),hipMemcpyDeviceToHost,dev->stream);
-      if (err == hipSuccess && use_wave && hole_cap > 0)
+      if (err == hipSuccess && use_wave && !use_walk && hole_cap > 0)
         err = hipMemcpyAsync(pin+8,holes,sizeof(unsigned long long)*2*(size_t) hole_cap,hipMemcpyDeviceToHost,dev->stream);
       if (err == hipSuccess) err = hipStreamSynchronize(dev->stream);
       if (err == hipSuccess) err = hipGetLastError();
@@ -1881,7 +1901,9 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
           goto done;
         }
       hc[0] = pin[0]; hc[1] = pin[1];
-      if (use_wave) { hw[0] = pin[2]; hw[1] = pin[3]; }
+      if (use_wave && !use_walk) { hw[0] = pin[2]; hw[1] = pin[3]; }
+      if (use_walk) hslots = (int64_t) pin[6];
+      if (tm) tm1 = fga_wall();
 
       if (use_wave && (int64_t) hw[1] > big_cap)
         { // more oversize tiles than the queue holds (a pathologically repetitive input): redo everything with
@@ -1901,40 +1923,38 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
           for (int i = 0; i < nh; i++)
             hsum += (int64_t) (hh[2*(size_t) i+1] - hh[2*(size_t) i]);
           const int64_t C = (int64_t) hc[0], D = C - hsum;          // allocated, dense
-          // destinations: the holes (clipped) below D, in any order; sources: the occupied stretches of [D,C), which
-          // needs the few holes that reach above D in order
-          std::vector<std::pair<int64_t,int64_t> > src, dst, above;
+          // destinations: the holes (clipped) below D, taken as they come; sources: the occupied stretches of [D,C),
+          // which needs the few holes that reach above D in order.  Both lists are walked in step, no intermediate copies.
+          static thread_local std::vector<std::pair<int64_t,int64_t> > above;
+          above.clear();
           for (int i = 0; i < nh; i++)
-            { const int64_t hb = (int64_t) hh[2*(size_t) i], he = (int64_t) hh[2*(size_t) i+1];
-              if (hb < D) dst.push_back(std::make_pair(hb,he < D ? he : D));
-              if (he > D) above.push_back(std::make_pair(hb > D ? hb : D,he));
-            }
+            if ((int64_t) hh[2*(size_t) i+1] > D)
+              above.push_back(std::make_pair((int64_t) hh[2*(size_t) i] > D ? (int64_t) hh[2*(size_t) i] : D,
+                                             (int64_t) hh[2*(size_t) i+1]));
           std::sort(above.begin(),above.end());
-          { int64_t pos = D;
-            for (size_t i = 0; i < above.size(); i++)
-              { if (above[i].first > pos) src.push_back(std::make_pair(pos,above[i].first));
-                pos = above[i].second;
-              }
-            if (pos < C) src.push_back(std::make_pair(pos,C));
-          }
+          above.push_back(std::make_pair(C,C));                     // sentinel: the stretch after the last hole ends at C
           seed_move *mv = (seed_move *) (pin + 8 + 2*(size_t) hole_cap);
           size_t nmv = 0;
-          { size_t si = 0, di = 0;
-            int64_t so = 0, dof = 0;
-            while (si < src.size() && di < dst.size() && nmv < 2*(size_t) (hole_cap+1))
-              { const int64_t sl = src[si].second - src[si].first - so, dl = dst[di].second - dst[di].first - dof;
-                const int64_t l = sl < dl ? sl : dl;
-                if (l > 0)
-                  { mv[nmv].src = src[si].first + so; mv[nmv].dst = dst[di].first + dof; mv[nmv].len = l;
+          { size_t ai = 0;
+            int64_t spos = D, send = above[0].first;               // current source stretch [spos,send)
+            for (int i = 0; i < nh; i++)
+              { int64_t db = (int64_t) hh[2*(size_t) i], de = (int64_t) hh[2*(size_t) i+1];
+                if (db >= D) continue;
+                if (de > D) de = D;
+                while (db < de)
+                  { while (spos >= send && ai+1 < above.size())     // next occupied stretch above D
+                      { spos = above[ai].second; ai += 1; send = above[ai].first; }
+                    if (spos >= send)
+                      break;
+                    const int64_t l = (de-db) < (send-spos) ? (de-db) : (send-spos);
+                    if (nmv >= 2*(size_t) (hole_cap+1))
+                      { fga_set_error("fga_seed_merge: internal error, hole plan larger than its buffer");
+                        goto done;
+                      }
+                    mv[nmv].src = spos; mv[nmv].dst = db; mv[nmv].len = l;
                     nmv += 1;
+                    spos += l; db += l;
                   }
-                so += l; dof += l;
-                if (so == src[si].second - src[si].first) { si += 1; so = 0; }
-                if (dof == dst[di].second - dst[di].first) { di += 1; dof = 0; }
-              }
-            if (si < src.size() && di < dst.size())
-              { fga_set_error("fga_seed_merge: internal error, hole plan larger than its buffer");
-                goto done;
               }
           }
           if (nmv > 0)
@@ -1949,10 +1969,14 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
           hipMemcpyAsync(counters,pin,sizeof(unsigned long long),hipMemcpyHostToDevice,dev->stream);
         }
       hipEventRecord(ev2,dev->stream);
+      if (tm) tm2 = fga_wall();
       if (hipStreamSynchronize(dev->stream) != hipSuccess)
         { fga_set_error("fga_seed_merge: hole fill failed: %s",hipGetErrorString(hipGetLastError()));
           goto done;
         }
+      if (tm)
+        fprintf(stderr,"merge host timing: launch->first sync %.1f us, plan+enqueue %.1f us, final sync %.1f us (%llu holes)\n",
+                1e6*(tm1-tm0),1e6*(tm2-tm1),1e6*(fga_wall()-tm2),hw[0]);
       break;
     }
 #ifdef MERGE_PROF
@@ -1968,7 +1992,8 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
   hipEventElapsedTime(&dev->last_ms[FGA_STAGE_MERGE_PARTITION],dev->ev0,dev->ev1);
   // the merge stage = everything the launch runs: range cuts / tile partition, the merge kernels, hole closing
   hipEventElapsedTime(&dev->last_ms[FGA_STAGE_MERGE],dev->ev0,ev2);
-  S->count  = (int64_t) hc[0];
+  S->phys_count = (int64_t) hc[0];
+  S->count  = (int64_t) hc[0] - hslots;
   S->tseed  = (int64_t) hc[1];
   rc = 0;
 
@@ -1977,11 +2002,13 @@ done:
   fga_dev_release(dev,SLOT_TILES,work);
   if (rc != 0)
     { if (append == NULL)
-        { hipFree(counters); fga_dev_release(dev,SLOT_SEEDS,S->seeds); free(S); }
+        { hipFree(counters); fga_dev_release(dev,SLOT_SEEDS,S->seeds); fga_dev_release(dev,SLOT_VALID,S->valid); free(S); }
       return 1;
     }
   if (out != NULL) *out = S;
-  if (S->count > S->capacity)
+  if (S->valid != NULL && S->phys_count > S->phys_capacity)
+    S->count = S->phys_count;              // overflow of a block-allocated buffer: an upper bound of what is needed
+  if (S->count > S->capacity || S->phys_count > S->phys_capacity)
     { fga_set_error("fga_seed_merge: %lld seeds exceed the buffer capacity %lld (re-run with a larger capacity)",
                     (long long) S->count,(long long) S->capacity);
       return 2;

@@ -18,7 +18,7 @@
 #define SH_MAXP  64                  // parts
 
 __global__ __launch_bounds__(SH_T)
-void seed_contig_hist_kernel(const fga_seed *seeds, int64_t n, int nctg, unsigned long long *counts)
+void seed_contig_hist_kernel(const fga_seed *seeds, int64_t n, int nctg, unsigned long long *counts, const uint16_t *valid)
 { __shared__ unsigned int h[SH_LDSH];
   const bool lds = nctg <= SH_LDSH;
   if (lds)
@@ -27,7 +27,9 @@ void seed_contig_hist_kernel(const fga_seed *seeds, int64_t n, int nctg, unsigne
     }
   // a workgroup takes consecutive 16 KB stretches; its LDS counters cannot overflow (< 2^32 seeds per workgroup)
   for (int64_t i = (int64_t) blockIdx.x*SH_T + threadIdx.x; i < n; i += (int64_t) gridDim.x*SH_T)
-    { const uint32_t c = seeds[i].actg >> 8;
+    { if (valid != NULL && (int) (i & 1023) >= (int) valid[i >> 10])       // a hole of the merge kernel's block allocation
+        continue;
+      const uint32_t c = seeds[i].actg >> 8;
       if (c < (uint32_t) nctg)
         { if (lds) atomicAdd(h+c,1u);
           else     atomicAdd(counts+c,1ull);
@@ -43,14 +45,14 @@ void seed_contig_hist_kernel(const fga_seed *seeds, int64_t n, int nctg, unsigne
 // pass 1: seeds of tile b per part -> tilecnt[b*nparts + p]
 __global__ __launch_bounds__(SH_T)
 void seed_part_count_kernel(const fga_seed *seeds, int64_t n, const int *select, int nctg, int nparts,
-                            unsigned int *tilecnt)
+                            unsigned int *tilecnt, const uint16_t *valid)
 { __shared__ unsigned int c[SH_MAXP];
   if (threadIdx.x < SH_MAXP) c[threadIdx.x] = 0;
   __syncthreads();
   const int64_t base = (int64_t) blockIdx.x*SH_TILE;
   for (int k = threadIdx.x; k < SH_TILE; k += SH_T)
     { const int64_t i = base + k;
-      if (i < n)
+      if (i < n && (valid == NULL || (int) (i & 1023) < (int) valid[i >> 10]))
         { const uint32_t a = seeds[i].actg >> 8;
           const int p = a < (uint32_t) nctg ? select[a] : 0;
           atomicAdd(c+p,1u);
@@ -64,7 +66,7 @@ void seed_part_count_kernel(const fga_seed *seeds, int64_t n, const int *select,
 // pass 2: tileoff[b*nparts + p] = first slot of (part p, tile b) in dst; order inside is arbitrary (the sort follows)
 __global__ __launch_bounds__(SH_T)
 void seed_part_scatter_kernel(const fga_seed *seeds, int64_t n, const int *select, int nctg, int nparts,
-                              const int64_t *tileoff, fga_seed *dst)
+                              const int64_t *tileoff, fga_seed *dst, const uint16_t *valid)
 { __shared__ unsigned int cur[SH_MAXP];
   __shared__ int64_t off[SH_MAXP];
   if (threadIdx.x < SH_MAXP)
@@ -75,7 +77,7 @@ void seed_part_scatter_kernel(const fga_seed *seeds, int64_t n, const int *selec
   const int64_t base = (int64_t) blockIdx.x*SH_TILE;
   for (int k = threadIdx.x; k < SH_TILE; k += SH_T)
     { const int64_t i = base + k;
-      if (i < n)
+      if (i < n && (valid == NULL || (int) (i & 1023) < (int) valid[i >> 10]))
         { const fga_seed s = seeds[i];
           const uint32_t a = s.actg >> 8;
           const int p = a < (uint32_t) nctg ? select[a] : 0;
@@ -93,7 +95,7 @@ extern "C" int fga_seeds_contig_histogram(fga_dev *dev, const fga_dseeds *S, int
       return 1;
     }
   FGA_HIP(hipSetDevice(dev->device));
-  const int64_t n = S->count < S->capacity ? S->count : S->capacity;
+  const int64_t n = fga_seeds_extent(S);
   unsigned long long *d = (unsigned long long *) fga_dev_acquire(dev,SLOT_MISC,sizeof(unsigned long long)*(size_t) nctg);
   if (d == NULL)
     { fga_set_error("fga_seeds_contig_histogram: device allocation failed");
@@ -103,7 +105,7 @@ extern "C" int fga_seeds_contig_histogram(fga_dev *dev, const fga_dseeds *S, int
   if (n > 0)
     { int64_t wg = (n + SH_TILE - 1) / SH_TILE;
       if (wg > (int64_t) dev->ncu*8) wg = (int64_t) dev->ncu*8;
-      hipLaunchKernelGGL(seed_contig_hist_kernel,dim3((unsigned) wg),dim3(SH_T),0,dev->stream,S->seeds,n,nctg,d);
+      hipLaunchKernelGGL(seed_contig_hist_kernel,dim3((unsigned) wg),dim3(SH_T),0,dev->stream,S->seeds,n,nctg,d,S->valid);
     }
   hipError_t e = hipMemcpyAsync(counts,d,sizeof(int64_t)*(size_t) nctg,hipMemcpyDeviceToHost,dev->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
@@ -123,7 +125,7 @@ extern "C" int fga_seeds_split_to(fga_dev *dev, const fga_dseeds *S, const int *
       return 1;
     }
   FGA_HIP(hipSetDevice(dev->device));
-  const int64_t n = S->count < S->capacity ? S->count : S->capacity;
+  const int64_t n = fga_seeds_extent(S);
   for (int p = 0; p <= nparts; p++) part_off[p] = 0;
   if (n == 0)
     return 0;
@@ -145,7 +147,7 @@ extern "C" int fga_seeds_split_to(fga_dev *dev, const fga_dseeds *S, const int *
   std::vector<unsigned int> cnt((size_t) nt*nparts);
   std::vector<int64_t> off((size_t) nt*nparts);
   hipError_t e = hipMemcpyAsync(d_sel,select,sbytes,hipMemcpyHostToDevice,dev->stream);
-  hipLaunchKernelGGL(seed_part_count_kernel,dim3((unsigned) nt),dim3(SH_T),0,dev->stream,S->seeds,n,d_sel,nctg,nparts,d_cnt);
+  hipLaunchKernelGGL(seed_part_count_kernel,dim3((unsigned) nt),dim3(SH_T),0,dev->stream,S->seeds,n,d_sel,nctg,nparts,d_cnt,S->valid);
   if (e == hipSuccess) e = hipMemcpyAsync(cnt.data(),d_cnt,cbytes,hipMemcpyDeviceToHost,dev->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
   if (e == hipSuccess)
@@ -161,7 +163,7 @@ extern "C" int fga_seeds_split_to(fga_dev *dev, const fga_dseeds *S, const int *
       part_off[nparts] = run;
       e = hipMemcpyAsync(d_off,off.data(),obytes,hipMemcpyHostToDevice,dev->stream);
       hipLaunchKernelGGL(seed_part_scatter_kernel,dim3((unsigned) nt),dim3(SH_T),0,dev->stream,S->seeds,n,d_sel,nctg,nparts,
-                         d_off,(fga_seed *) dst_device);
+                         d_off,(fga_seed *) dst_device,S->valid);
       if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
       if (e == hipSuccess) e = hipGetLastError();
     }
@@ -194,16 +196,16 @@ extern "C" int fga_seeds_import(fga_dev *dev, const void *const *src_device, con
     { fga_set_error("out of memory");
       return 1;
     }
-  S->dev = dev; S->capacity = S->phys_capacity = total + 16; S->count = total; S->tseed = 0;
+  S->dev = dev; S->capacity = S->phys_capacity = total + 16; S->count = S->phys_count = total; S->tseed = 0;
   S->seeds = (fga_seed *) fga_dev_acquire(dev,SLOT_SEEDS,sizeof(fga_seed)*(size_t) S->phys_capacity);
   S->slot = SLOT_SEEDS;
-  hipError_t e = hipMalloc(&S->dcount,2*sizeof(unsigned long long));
+  hipError_t e = hipMalloc(&S->dcount,4*sizeof(unsigned long long));
   if (S->seeds == NULL || e != hipSuccess)
     { fga_set_error("fga_seeds_import: device allocation failed");
       fga_dev_release(dev,SLOT_SEEDS,S->seeds); hipFree(S->dcount); free(S);
       return 1;
     }
-  { unsigned long long hc[2] = { (unsigned long long) total, 0ull };
+  { unsigned long long hc[4] = { (unsigned long long) total, 0ull, 0ull, 0ull };
     e = hipMemcpyAsync(S->dcount,hc,sizeof(hc),hipMemcpyHostToDevice,dev->stream);
   }
   int64_t at = 0;

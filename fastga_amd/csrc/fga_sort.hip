@@ -80,9 +80,10 @@ __device__ __forceinline__ u128 load_key(const void *in, int64_t i, const key_la
 }
 
 // (1) per-tile digit histogram -> hist[digit*ntiles + tile]
+// `valid` (first pass over a seed buffer with holes only): seeds in each 1024-slot block, the rest of the block is skipped
 template <bool FROM_SEEDS>
 __global__ __launch_bounds__(ST)
-void sort_hist_kernel(const void *in, int64_t n, int shift, key_layout L, uint32_t *hist, int ntiles)
+void sort_hist_kernel(const void *in, int64_t n, int shift, key_layout L, uint32_t *hist, int ntiles, const uint16_t *valid)
 { __shared__ uint32_t h[256];
   const int tile = blockIdx.x;
   h[threadIdx.x] = 0;
@@ -91,7 +92,7 @@ void sort_hist_kernel(const void *in, int64_t n, int shift, key_layout L, uint32
   #pragma unroll 4
   for (int r = 0; r < SITEMS; r++)
     { int64_t i = base + r*ST + threadIdx.x;
-      if (i < n)
+      if (i < n && (!FROM_SEEDS || valid == NULL || (int) (i & 1023) < (int) valid[i >> 10]))
         { u128 k = load_key<FROM_SEEDS>(in,i,L);
           atomicAdd(&h[digit_of(k,shift)],1u);
         }
@@ -176,7 +177,7 @@ void sort_scan_sums_kernel(uint32_t *sums, int nch)        // exclusive scan, si
 template <bool FROM_SEEDS>
 __global__ __launch_bounds__(ST)
 void sort_scatter_kernel(const void *in, uint4 *out, int64_t n, int shift, key_layout L,
-                         const uint32_t *hist, const uint32_t *sums, int ntiles)
+                         const uint32_t *hist, const uint32_t *sums, int ntiles, const uint16_t *valid)
 { __shared__ uint32_t wcnt[SWAVES][256];      // per-wave digit counts, then per-wave digit bases
   const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int x = tid; x < SWAVES*256; x += ST)
@@ -185,13 +186,16 @@ void sort_scatter_kernel(const void *in, uint4 *out, int64_t n, int shift, key_l
 
   // item order inside the tile: wave-major, then round, then lane  (coalesced 64-key loads per round)
   const int64_t wbase = (int64_t) tile * STILE + (int64_t) wave * (64*SITEMS);
+  // a wavefront's 1024 items are exactly one block of the seed buffer
+  static_assert(64*SITEMS == 1024,"one seed block per wavefront");
+  const int vcount = (FROM_SEEDS && valid != NULL && wbase < n) ? (int) valid[wbase >> 10] : 64*SITEMS;
   u128     key[SITEMS];
   uint16_t rank[SITEMS];
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64-lane));
   #pragma unroll
   for (int r = 0; r < SITEMS; r++)
     { int64_t i = wbase + r*64 + lane;
-      bool ok = i < n;
+      bool ok = i < n && r*64 + lane < vcount;
       uint32_t d = 256;
       if (ok)
         { key[r] = load_key<FROM_SEEDS>(in,i,L);
@@ -228,7 +232,7 @@ void sort_scatter_kernel(const void *in, uint4 *out, int64_t n, int shift, key_l
   #pragma unroll
   for (int r = 0; r < SITEMS; r++)
     { int64_t i = wbase + r*64 + lane;
-      if (i < n)
+      if (i < n && r*64 + lane < vcount)
         { uint32_t d = digit_of(key[r],shift);
           int64_t pos = (int64_t) wcnt[wave][d] + rank[r];
           uint4 v;
@@ -252,7 +256,8 @@ extern "C" int fga_seed_sort(fga_dev *dev, const fga_dseeds *S, const fga_sort_p
       return 1;
     }
   FGA_HIP(hipSetDevice(dev->device));
-  const int64_t n = S->count < S->capacity ? S->count : S->capacity;
+  const int64_t next = fga_seeds_extent(S);                                   // slots of the seed buffer to look at
+  const int64_t n = S->valid != NULL ? S->count : next;                        // keys that come out
   key_layout L;
   L.amx = prm->amxpos; L.bmx = prm->bmxpos;
   L.wa = bits_for(prm->nctg_a > 0 ? prm->nctg_a-1 : 0);
@@ -274,7 +279,9 @@ extern "C" int fga_seed_sort(fga_dev *dev, const fga_dseeds *S, const fga_sort_p
   K->amxpos = prm->amxpos; K->bmxpos = prm->bmxpos;
   const int lowbit = prm->anti_order_only ? 12 : 0;       // diag&63 and lcp: the chain scan does not need them ordered
   const int npass = (tbits - lowbit + 7) / 8;
-  const int ntiles = (int) ((n + STILE - 1) / STILE);
+  // the first pass walks the seed buffer (holes included), the others the keys
+  const int ntiles0 = (int) ((next + STILE - 1) / STILE), ntilesk = (int) ((n + STILE - 1) / STILE);
+  const int ntiles = ntiles0 > ntilesk ? ntiles0 : ntilesk;
   dev->last_ms[FGA_STAGE_SORT] = 0.f;
   if (n == 0)
     { *out = K;
@@ -304,16 +311,23 @@ extern "C" int fga_seed_sort(fga_dev *dev, const fga_dseeds *S, const fga_sort_p
     { const int shift = lowbit + 8*p;
       uint4 *dst = buf[cur];
       if (p == 0)
-        { hipLaunchKernelGGL(sort_hist_kernel<true>,dim3(ntiles),dim3(ST),0,dev->stream,src,n,shift,L,hist,ntiles);
-          hipLaunchKernelGGL(sort_scan_local_kernel,dim3(nch),dim3(SCAN_T),0,dev->stream,hist,hm,sums);
-          hipLaunchKernelGGL(sort_scan_sums_kernel,dim3(1),dim3(SCAN_T),0,dev->stream,sums,nch);
-          hipLaunchKernelGGL(sort_scatter_kernel<true>,dim3(ntiles),dim3(ST),0,dev->stream,src,dst,n,shift,L,hist,sums,ntiles);
+        { const int64_t hm0 = (int64_t) 256*ntiles0;
+          const int nch0 = (int) ((hm0 + SCAN_CH - 1) / SCAN_CH);
+          hipLaunchKernelGGL(sort_hist_kernel<true>,dim3(ntiles0),dim3(ST),0,dev->stream,src,next,shift,L,hist,ntiles0,S->valid);
+          hipLaunchKernelGGL(sort_scan_local_kernel,dim3(nch0),dim3(SCAN_T),0,dev->stream,hist,hm0,sums);
+          hipLaunchKernelGGL(sort_scan_sums_kernel,dim3(1),dim3(SCAN_T),0,dev->stream,sums,nch0);
+          hipLaunchKernelGGL(sort_scatter_kernel<true>,dim3(ntiles0),dim3(ST),0,dev->stream,src,dst,next,shift,L,hist,sums,ntiles0,
+                             S->valid);
         }
       else
-        { hipLaunchKernelGGL(sort_hist_kernel<false>,dim3(ntiles),dim3(ST),0,dev->stream,src,n,shift,L,hist,ntiles);
-          hipLaunchKernelGGL(sort_scan_local_kernel,dim3(nch),dim3(SCAN_T),0,dev->stream,hist,hm,sums);
-          hipLaunchKernelGGL(sort_scan_sums_kernel,dim3(1),dim3(SCAN_T),0,dev->stream,sums,nch);
-          hipLaunchKernelGGL(sort_scatter_kernel<false>,dim3(ntiles),dim3(ST),0,dev->stream,src,dst,n,shift,L,hist,sums,ntiles);
+        { const int64_t hmk = (int64_t) 256*ntilesk;
+          const int nchk = (int) ((hmk + SCAN_CH - 1) / SCAN_CH);
+          hipLaunchKernelGGL(sort_hist_kernel<false>,dim3(ntilesk),dim3(ST),0,dev->stream,src,n,shift,L,hist,ntilesk,
+                             (const uint16_t *) NULL);
+          hipLaunchKernelGGL(sort_scan_local_kernel,dim3(nchk),dim3(SCAN_T),0,dev->stream,hist,hmk,sums);
+          hipLaunchKernelGGL(sort_scan_sums_kernel,dim3(1),dim3(SCAN_T),0,dev->stream,sums,nchk);
+          hipLaunchKernelGGL(sort_scatter_kernel<false>,dim3(ntilesk),dim3(ST),0,dev->stream,src,dst,n,shift,L,hist,sums,ntilesk,
+                             (const uint16_t *) NULL);
         }
       src = dst;
       cur ^= 1;
@@ -357,10 +371,12 @@ int fga_radix_sort_u128(fga_dev *dev, uint4 *buf0, uint4 *buf1, int64_t n, int l
   uint4 *src = buf0, *dst = buf1;
   for (int p = 0; p < npass; p++)
     { const int shift = lowbit + 8*p;
-      hipLaunchKernelGGL(sort_hist_kernel<false>,dim3(ntiles),dim3(ST),0,dev->stream,(const void *) src,n,shift,L,hist,ntiles);
+      hipLaunchKernelGGL(sort_hist_kernel<false>,dim3(ntiles),dim3(ST),0,dev->stream,(const void *) src,n,shift,L,hist,ntiles,
+                         (const uint16_t *) NULL);
       hipLaunchKernelGGL(sort_scan_local_kernel,dim3(nch),dim3(SCAN_T),0,dev->stream,hist,hm,sums);
       hipLaunchKernelGGL(sort_scan_sums_kernel,dim3(1),dim3(SCAN_T),0,dev->stream,sums,nch);
-      hipLaunchKernelGGL(sort_scatter_kernel<false>,dim3(ntiles),dim3(ST),0,dev->stream,(const void *) src,dst,n,shift,L,hist,sums,ntiles);
+      hipLaunchKernelGGL(sort_scatter_kernel<false>,dim3(ntiles),dim3(ST),0,dev->stream,(const void *) src,dst,n,shift,L,hist,sums,ntiles,
+                         (const uint16_t *) NULL);
       uint4 *t = src; src = dst; dst = t;
     }
   // the histogram buffer is still in use by the enqueued kernels: the slot is grow-only memory of the device context and
