@@ -1299,14 +1299,16 @@ __device__ __attribute__((noinline)) int ext_wave(const ext_args &G, LDS_PTR ext
 __device__ int local_alignment(const ext_args &G, LDS_PTR ext_shared *sh, uint16_t *trace, int tcap,
                                ext_seq &A, ext_seq &B, int acomp,
                                int low, int hgh, int anti, int lbord, int hbord,
-                               ext_state &P, unsigned long long &nwaves, ext_prof &PF)
+                               ext_state &P, unsigned long long &nwaves, ext_prof &PF, int selfie = 0)
 { int minp, maxp, aoff, st;
   P.tpos = tcap/2;
   P.tlen = 0;
   while (((anti-hgh)>>1) < 0)
     hgh -= 1;
-  minp = (lbord < 0) ? -BIGI : low-lbord;
-  maxp = (hbord < 0) ?  BIGI : hgh+hbord;
+  // selfie: the reference's `aseq == bseq` rule (align.c:1461-1481) -- never the case in FastGA's own calls, which load
+  // the two contigs into separate buffers; the exact-signature shim passes it through
+  minp = (lbord < 0) ? ((selfie && low >= 0) ? 1 : -BIGI) : low-lbord;
+  maxp = (hbord < 0) ? ((selfie && hgh <= 0) ? -1 : BIGI) : hgh+hbord;
   aoff = acomp ? A.len % TS : 0;
 
   if ((st = ext_wave<+1>(G,sh,trace,tcap,A,B,P,low,hgh,anti,minp,maxp,aoff,nwaves,PF)) != 0) return st;
@@ -1498,6 +1500,61 @@ void extend_kernel(ext_args G)
       atomicAdd(G.counters+11,PF.nsteps);
       atomicAdd(G.counters+12,PF.ncells);
       atomicAdd(G.counters+13,PF.nbases);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// one Local_Alignment call on two packed sequences: the device side of the exact-signature shim (fga_shim_Local_Alignment)
+// ---------------------------------------------------------------------------------------------------
+struct la_one_args
+  { ext_args G;
+    int alen, blen, acomp, selfie, low, hgh, anti, lbord, hbord;
+    int *out;                  // status, abpos, bbpos, aepos, bepos, diffs, tlen
+    uint16_t *trace_out; int trace_cap;
+  };
+
+__global__ __launch_bounds__(64)
+void local_alignment_one_kernel(la_one_args L)
+{ LDS_PTR ext_shared *sh = (LDS_PTR ext_shared *) &ext_lds;
+  const ext_args &G = L.G;
+  trim_fill(sh,G.mscore);
+  const int lane = threadIdx.x;
+  if (lane == 0) sh->nlev = 0;
+  __syncthreads();
+  int st = arena_ensure(G,0) ? 0 : 1;
+  ext_seq A, B;
+  A.len = L.alen; B.len = L.blen;
+  A.win = (LDS_PTR uint32_t *) sh->winA; A.p0 = -1; A.w0 = 0;
+  B.win = (LDS_PTR uint32_t *) sh->winB; B.p0 = -1; B.w0 = 0;
+  A.img = G.imgA; A.base = G.padA * 4; A.bsh = (int) (A.base & 15);
+  B.img = G.imgB; B.base = G.padB * 4; B.bsh = (int) (B.base & 15);
+  const int maxlen = L.alen > L.blen ? L.alen : L.blen;
+  const int tcap = 8*(maxlen/TS + 8) + 64;
+  uint16_t *trace = NULL;
+  if (st == 0)
+    { const long long at = pool_take(G,((long long) tcap*2 + 15) / 16 + 1);
+      if (at < 0) st = 1; else trace = (uint16_t *) (G.pool + at);
+    }
+  ext_state P;
+  P.abpos = P.bbpos = P.aepos = P.bepos = P.diffs = P.tlen = 0; P.tpos = 0;
+  unsigned long long nwaves = 0;
+  ext_prof PF; PF.t_steps = PF.t_unwind = PF.t_total = PF.nsteps = 0; PF.ncells = PF.nbases = 0;
+  if (st == 0)
+    st = local_alignment(G,sh,trace,tcap,A,B,L.acomp,L.low,L.hgh,L.anti,L.lbord,L.hbord,P,nwaves,PF,L.selfie);
+  if (st == 0 && P.tlen > L.trace_cap)
+    st = 3;
+  if (st == 0)
+    { const uint16_t *src = trace + P.tpos;
+      const int np = P.tlen >> 1;
+      for (int q = lane; q < np; q += 64)             // pairs come out reversed for a complemented A (align.c:1534-1555)
+        { const int sp = L.acomp ? (np-1-q) : q;
+          L.trace_out[2*q]   = src[2*sp];
+          L.trace_out[2*q+1] = src[2*sp+1];
+        }
+    }
+  if (lane == 0)
+    { L.out[0] = st;
+      L.out[1] = P.abpos; L.out[2] = P.bbpos; L.out[3] = P.aepos; L.out[4] = P.bepos; L.out[5] = P.diffs; L.out[6] = P.tlen;
     }
 }
 
@@ -1771,4 +1828,163 @@ fail:
   fga_dev_release(dev,SLOT_ALNS,A.alns); fga_dev_release(dev,SLOT_TBYTES,A.tbytes);
   free(R->alns); free(R->tbytes); free(R);
   return 1;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// exact-signature shims of the reference's module seams: Local_Alignment with New/Free_Work_Data and
+// New/Free_Align_Spec (align.h:166-168, 196-198, 235-236).  They let a maintainer swap ONE call inside the unmodified
+// pipeline (FastGA.c:3247-3260) or A/B it against align.c: same argument meaning, same result fields, the trace lives in
+// storage of the Work_Data and is overwritten by the next call, 1 is returned on failure (message: fga_last_error).
+// Every call packs the two NUMERIC sequences to 2 bits, uploads them and runs one wavefront: a parity device, not a
+// fast path -- the fast path is fga_extend, which keeps genomes resident and runs thousands of units at once.
+// ---------------------------------------------------------------------------------------------------
+struct shim_work
+  { fga_dev *dev;
+    uint8_t *dA, *dB; size_t capA, capB;          // packed images on the device
+    int4    *pool;    int64_t pool_cells;
+    uint16_t *dtrace; int dtrace_cap;
+    int     *dout;
+    unsigned long long *dcnt;
+    std::vector<uint8_t>  pack;
+    std::vector<uint16_t> trace;                  // result trace (the reference's work->points)
+  };
+
+struct shim_spec
+  { double ave_corr; int tspace, reach; float freq[4];
+    int path_ave, mscore;
+  };
+
+extern "C" void *fga_shim_New_Work_Data(void)
+{ shim_work *W = new (std::nothrow) shim_work();
+  if (W == NULL) { fga_set_error("out of memory"); return NULL; }
+  W->dev = NULL; W->dA = W->dB = NULL; W->capA = W->capB = 0; W->pool = NULL; W->pool_cells = 0;
+  W->dtrace = NULL; W->dtrace_cap = 0; W->dout = NULL; W->dcnt = NULL;
+  const char *e = getenv("FGA_DEVICE");
+  if (fga_dev_open(e != NULL ? atoi(e) : 0,&W->dev))
+    { delete W; return NULL; }
+  if (hipMalloc(&W->dout,sizeof(int)*8) != hipSuccess || hipMalloc(&W->dcnt,sizeof(unsigned long long)*32) != hipSuccess)
+    { fga_set_error("fga_shim_New_Work_Data: device allocation failed");
+      hipFree(W->dout); fga_dev_close(W->dev); delete W;
+      return NULL;
+    }
+  return W;
+}
+
+extern "C" void fga_shim_Free_Work_Data(void *work)
+{ shim_work *W = (shim_work *) work;
+  if (W == NULL) return;
+  hipSetDevice(W->dev->device);
+  hipFree(W->dA); hipFree(W->dB); hipFree(W->pool); hipFree(W->dtrace); hipFree(W->dout); hipFree(W->dcnt);
+  fga_dev_close(W->dev);
+  delete W;
+}
+
+extern "C" void *fga_shim_New_Align_Spec(double ave_corr, int trace_space, float *freq, int reach)
+{ shim_spec *S = (shim_spec *) calloc(1,sizeof(shim_spec));
+  if (S == NULL) { fga_set_error("out of memory"); return NULL; }
+  std::vector<int16_t> tab(2*32768);
+  S->ave_corr = ave_corr; S->tspace = trace_space; S->reach = reach;
+  for (int k = 0; k < 4; k++) S->freq[k] = freq[k];
+  if (fga_align_spec(ave_corr,trace_space,freq,&S->path_ave,tab.data(),tab.data()+32768))
+    { free(S); return NULL; }
+  S->mscore = tab[32768 + 0x7fff] / 15;
+  return S;
+}
+
+extern "C" void fga_shim_Free_Align_Spec(void *spec) { free(spec); }
+
+// NUMERIC bytes (0..3) -> the .bps packing (base i in bits 2(i&3) of byte i>>2), zero padding either side
+static int shim_upload(shim_work *W, const char *seq, int len, uint8_t **dbuf, size_t *cap)
+{ const size_t bytes = (size_t) ((len+3) >> 2) + 2*IMG_PAD + 16;
+  W->pack.assign(bytes,0);
+  uint8_t *p = W->pack.data() + IMG_PAD;
+  for (int i = 0; i < len; i++)
+    p[i >> 2] |= (uint8_t) ((seq[i] & 3) << (2*(i & 3)));
+  if (*cap < bytes)
+    { hipFree(*dbuf); *dbuf = NULL; *cap = 0;
+      if (hipMalloc(dbuf,bytes + bytes/4) != hipSuccess)
+        { fga_set_error("fga_shim_Local_Alignment: device allocation failed");
+          return 1;
+        }
+      *cap = bytes + bytes/4;
+    }
+  FGA_HIP(hipMemcpy(*dbuf,W->pack.data(),bytes,hipMemcpyHostToDevice));
+  return 0;
+}
+
+typedef struct { void *trace; int tlen, diffs, abpos, bbpos, aepos, bepos; } shim_path;            // = Path, align.h:89-95
+typedef struct { shim_path *path; uint32_t flags; char *aseq, *bseq; int alen, blen; } shim_alignment;   // = Alignment, 145-152
+
+extern "C" int fga_shim_Local_Alignment(void *align_, void *work, void *spec_, int low, int hgh, int anti, int lbord, int hbord)
+{ shim_alignment *align = (shim_alignment *) align_;
+  shim_work *W = (shim_work *) work;
+  shim_spec *S = (shim_spec *) spec_;
+  if (align == NULL || W == NULL || S == NULL || align->path == NULL)
+    { fga_set_error("fga_shim_Local_Alignment: null argument");
+      return 1;
+    }
+  if (S->tspace != TS || S->reach != 0)
+    { fga_set_error("fga_shim_Local_Alignment: only trace spacing 100 and reach 0 (what FastGA uses, FastGA.c:46, 3757)");
+      return 1;
+    }
+  FGA_HIP(hipSetDevice(W->dev->device));
+  const int selfie = (align->aseq == align->bseq);
+  if (shim_upload(W,align->aseq,align->alen,&W->dA,&W->capA)) return 1;
+  if (!selfie && shim_upload(W,align->bseq,align->blen,&W->dB,&W->capB)) return 1;
+  const int maxlen = align->alen > align->blen ? align->alen : align->blen;
+  // pool: up to ~64 cells per 100 bases (wide waves) + the trace scratch
+  const int64_t need = 64*((int64_t) maxlen/TS + 64) + (1 << ARENA_L0) + 4096;
+  if (W->pool_cells < need)
+    { hipFree(W->pool); W->pool = NULL; W->pool_cells = 0;
+      if (hipMalloc(&W->pool,sizeof(int4)*((size_t) need + 128)) != hipSuccess)
+        { fga_set_error("fga_shim_Local_Alignment: device allocation failed");
+          return 1;
+        }
+      W->pool_cells = need;
+    }
+  const int tcap = 4*(align->alen/TS + 4) + 16;
+  if (W->dtrace_cap < tcap)
+    { hipFree(W->dtrace); W->dtrace = NULL; W->dtrace_cap = 0;
+      if (hipMalloc(&W->dtrace,sizeof(uint16_t)*(size_t) tcap) != hipSuccess)
+        { fga_set_error("fga_shim_Local_Alignment: device allocation failed");
+          return 1;
+        }
+      W->dtrace_cap = tcap;
+    }
+  la_one_args L;
+  memset(&L,0,sizeof(L));
+  L.G.imgA = (const uint32_t *) W->dA; L.G.imgAr = L.G.imgA;
+  L.G.imgB = (const uint32_t *) (selfie ? W->dA : W->dB);
+  L.G.padA = L.G.padB = IMG_PAD;
+  L.G.tspace = TS; L.G.path_ave = S->path_ave; L.G.mscore = S->mscore;
+  L.G.force_lds = getenv("FGA_EXTEND_FORCE_LDS") != NULL;
+  L.G.pool = W->pool; L.G.pool_cells = W->pool_cells; L.G.pool_next = W->dcnt + 16; L.G.counters = W->dcnt;
+  L.alen = align->alen; L.blen = selfie ? align->alen : align->blen;
+  L.acomp = (align->flags & 0x2) != 0;           // ACOMP_FLAG (align.h:128)
+  L.selfie = selfie;
+  L.low = low; L.hgh = hgh; L.anti = anti; L.lbord = lbord; L.hbord = hbord;
+  L.out = W->dout; L.trace_out = W->dtrace; L.trace_cap = W->dtrace_cap;
+  hipMemsetAsync(W->dcnt,0,sizeof(unsigned long long)*32,W->dev->stream);
+  hipLaunchKernelGGL(local_alignment_one_kernel,dim3(1),dim3(64),0,W->dev->stream,L);
+  int out[8];
+  hipError_t e = hipMemcpyAsync(out,W->dout,sizeof(int)*7,hipMemcpyDeviceToHost,W->dev->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(W->dev->stream);
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e != hipSuccess)
+    { fga_set_error("fga_shim_Local_Alignment: kernel failed: %s",hipGetErrorString(e));
+      return 1;
+    }
+  if (out[0] != 0)
+    { fga_set_error("fga_shim_Local_Alignment: %s",out[0] == 1 ? "trace-point pool exhausted"
+                                                    : out[0] == 2 ? "wave wider than the LDS ring (512 diagonals)"
+                                                                  : "trace longer than its buffer");
+      return 1;
+    }
+  shim_path *P = align->path;
+  P->abpos = out[1]; P->bbpos = out[2]; P->aepos = out[3]; P->bepos = out[4]; P->diffs = out[5]; P->tlen = out[6];
+  W->trace.resize((size_t) (P->tlen > 0 ? P->tlen : 1));
+  if (P->tlen > 0)
+    FGA_HIP(hipMemcpy(W->trace.data(),W->dtrace,sizeof(uint16_t)*(size_t) P->tlen,hipMemcpyDeviceToHost));
+  P->trace = W->trace.data();
+  return 0;
 }

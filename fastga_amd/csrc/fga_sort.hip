@@ -422,3 +422,106 @@ extern "C" const void *fga_keys_download_pinned(const fga_dkeys *K)
     }
   return h;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// exact-signature shim of rmsd_sort (declared FastGA.c:149-150, defined RSDsort.c:292; called once per (strand, part) at
+// FastGA.c:4320): `array` holds nparts consecutive panels of part[p] BYTES each, made of rsize-byte records; every
+// panel is sorted ascending on the ksize bytes at the END of the record, last byte most significant (the record read
+// backwards); range[] receives the panel ranges the reference's sort threads would have been given -- the search threads
+// reuse them (FastGA.c:4336-4345) -- and the number of ranges in use is returned.  The records go to the device as
+// 128-bit keys [panel | record], one LSD radix sort orders all panels at once (fga_radix_sort_u128), and the low rsize
+// bytes come back.  A parity device for A/B runs inside the unmodified pipeline; like the reference's, not re-entrant.
+// Returns -1 on failure (message: fga_last_error).
+// ---------------------------------------------------------------------------------------------------
+typedef struct { int beg, end; int64_t off; } shim_range;       // = Range, FastGA.c:143-147 / RSDsort.c:254-258
+
+static fga_dev *shim_sort_dev = NULL;
+
+extern "C" int fga_shim_rmsd_sort(uint8_t *array, int64_t nelem, int rsize, int ksize, int nparts, int64_t *part,
+                                  int nthreads, void *range_)
+{ shim_range *range = (shim_range *) range_;
+  if (array == NULL || part == NULL || range == NULL || rsize < 1 || ksize < 1 || ksize > rsize || nparts < 1 || nthreads < 1)
+    { fga_set_error("fga_shim_rmsd_sort: bad argument");
+      return -1;
+    }
+  int pbits = 1;
+  while (((int64_t) 1 << pbits) < nparts) pbits += 1;
+  if (8*rsize + pbits > 128)
+    { fga_set_error("fga_shim_rmsd_sort: %d-byte records of %d panels do not fit a 128-bit key",rsize,nparts);
+      return -1;
+    }
+  const int64_t asize = nelem*rsize;
+  // the reference's thread ranges: consecutive panels of about asize/nthreads bytes each (RSDsort.c:318-343)
+  int n = 0;
+  { int64_t thr = asize / nthreads, sum = 0, off = 0;
+    int x = 0, beg;
+    while (x < nparts && part[x] <= 0) x += 1;
+    beg = x;
+    for (; x < nparts; x++)
+      if (part[x] > 0)
+        { sum += part[x];
+          if (sum >= thr && n < nthreads)
+            { range[n].beg = beg; range[n].end = x+1; range[n].off = off;
+              n += 1;
+              thr = (asize * (n+1)) / nthreads;
+              beg = x+1;
+              off = sum;
+            }
+        }
+    for (x = n; x < nthreads; x++)
+      { range[x].beg = range[x].end = (n > 0 ? range[n-1].end : 0); range[x].off = asize; }
+  }
+  if (nelem == 0)
+    return n;
+  if (shim_sort_dev == NULL)
+    { const char *e = getenv("FGA_DEVICE");
+      if (fga_dev_open(e != NULL ? atoi(e) : 0,&shim_sort_dev))
+        return -1;
+    }
+  fga_dev *dev = shim_sort_dev;
+  if (hipSetDevice(dev->device) != hipSuccess)
+    { fga_set_error("fga_shim_rmsd_sort: cannot select the device");
+      return -1;
+    }
+  std::vector<uint4> keys((size_t) nelem);
+  { int64_t i = 0;
+    for (int p = 0; p < nparts; p++)
+      for (int64_t b = 0; b < part[p] && i < nelem; b += rsize, i++)
+        { unsigned __int128 k = 0;
+          const uint8_t *r = array + i*rsize;
+          for (int q = rsize-1; q >= 0; q--)
+            k = (k << 8) | r[q];
+          k |= (unsigned __int128) (unsigned) p << (8*rsize);
+          keys[(size_t) i] = make_uint4((uint32_t) k,(uint32_t) (k >> 32),(uint32_t) (k >> 64),(uint32_t) (k >> 96));
+        }
+    if (i != nelem)
+      { fga_set_error("fga_shim_rmsd_sort: the panel sizes do not add up to nelem records");
+        return -1;
+      }
+  }
+  uint4 *b0 = (uint4 *) fga_dev_acquire(dev,SLOT_SORT0,sizeof(uint4)*(size_t) nelem);
+  uint4 *b1 = (uint4 *) fga_dev_acquire(dev,SLOT_SORT1,sizeof(uint4)*(size_t) nelem);
+  uint4 *sorted = NULL;
+  int rc = -1;
+  if (b0 == NULL || b1 == NULL)
+    fga_set_error("fga_shim_rmsd_sort: device allocation failed");
+  else if (hipMemcpy(b0,keys.data(),sizeof(uint4)*(size_t) nelem,hipMemcpyHostToDevice) != hipSuccess)
+    fga_set_error("fga_shim_rmsd_sort: upload failed");
+  else if (fga_radix_sort_u128(dev,b0,b1,nelem,8*(rsize-ksize),8*ksize + pbits,&sorted) ||
+           hipStreamSynchronize(dev->stream) != hipSuccess ||
+           hipMemcpy(keys.data(),sorted,sizeof(uint4)*(size_t) nelem,hipMemcpyDeviceToHost) != hipSuccess)
+    fga_set_error("fga_shim_rmsd_sort: device sort failed: %s",hipGetErrorString(hipGetLastError()));
+  else
+    { for (int64_t i = 0; i < nelem; i++)
+        { const uint4 v = keys[(size_t) i];
+          unsigned __int128 k = ((unsigned __int128) v.w << 96) | ((unsigned __int128) v.z << 64) |
+                                ((unsigned __int128) v.y << 32) | v.x;
+          uint8_t *r = array + i*rsize;
+          for (int q = 0; q < rsize; q++, k >>= 8)
+            r[q] = (uint8_t) k;
+        }
+      rc = n;
+    }
+  fga_dev_release(dev,SLOT_SORT0,b0); fga_dev_release(dev,SLOT_SORT1,b1);
+  return rc;
+}

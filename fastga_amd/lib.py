@@ -203,6 +203,12 @@ def _declare(L):
         "fga_merge_prefix_cuts": (i32, [vp, vp, vp, i32, P(i64)]),
         "fga_session_prefix_cuts": (i32, [vp, i32, P(i64)]),
         "fga_alns_concat": (i32, [P(P(Alns)), i32, P(P(Alns))]),
+        "fga_shim_New_Work_Data": (vp, []),
+        "fga_shim_Free_Work_Data": (None, [vp]),
+        "fga_shim_New_Align_Spec": (vp, [C.c_double, i32, P(C.c_float), i32]),
+        "fga_shim_Free_Align_Spec": (None, [vp]),
+        "fga_shim_Local_Alignment": (i32, [vp, vp, vp, i32, i32, i32, i32, i32]),
+        "fga_shim_rmsd_sort": (i32, [vp, i64, i32, i32, i32, P(i64), i32, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

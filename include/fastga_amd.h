@@ -278,6 +278,22 @@ int  fga_write_psl(const char *path, const fga_gdb *g1, const fga_gdb *g2 /* NUL
 /* Gap_Improver alone, in place on a whole set (trace and diffs as the reference leaves them in Path) */
 int  fga_gap_improve(const fga_gdb *g1, const fga_gdb *g2 /* NULL: self */, const fga_alns *alns, fga_traces *traces);
 
+/* ---- exact-signature shims of the reference's module seams ------------------------------------------------
+ *      The same prototypes as the reference's cross-file functions, so that ONE call inside the unmodified pipeline can
+ *      be pointed at the device (or A/B-ed against align.c / RSDsort.c): argument meaning, result fields, ownership (the
+ *      trace lives in the Work_Data and is overwritten by the next call) and the 1-on-failure convention are the
+ *      reference's.  Opaque arguments are `void *` exactly as align.h declares Work_Data and Align_Spec; `align` points at
+ *      an Alignment (align.h:145-152) whose path is a Path (align.h:89-95); `range` at Range[nthreads] (FastGA.c:143-147).
+ *      Parity devices (each call uploads its inputs), not the fast path.                                              */
+void *fga_shim_New_Work_Data(void);                                                   /* align.h:166  New_Work_Data   */
+void  fga_shim_Free_Work_Data(void *work);                                            /* align.h:168  Free_Work_Data  */
+void *fga_shim_New_Align_Spec(double ave_corr, int trace_space, float *freq, int reach);   /* align.h:196 New_Align_Spec  */
+void  fga_shim_Free_Align_Spec(void *spec);                                           /* align.h:198  Free_Align_Spec */
+int   fga_shim_Local_Alignment(void *align, void *work, void *spec,                   /* align.h:235-236              */
+                               int low, int hgh, int anti, int lbord, int hbord);
+int   fga_shim_rmsd_sort(uint8_t *array, int64_t nelem, int rsize, int ksize,         /* FastGA.c:149-150, RSDsort.c:292 */
+                         int nparts, int64_t *part, int nthreads, void *range);
+
 /* ---- the whole hot path: what `FastGA -1:<out> <root1> [<root2>]` does between "GIX present" and ".1aln closed" */
 typedef struct
   { int     device;
