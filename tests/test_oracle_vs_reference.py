@@ -142,7 +142,27 @@ def test_self_seed_merge_oracle_soft_mask_matches_reference(masked_pair, tmp_pat
     assert np.array_equal(H.sorted_records(seeds[1], w), H.sorted_records(c, w))
 
 
+def _starts_in_range(A, B, low, hgh, anti):
+    """every start point (anti+k)/2, (anti-k)/2 of Local_Alignment lies inside the two sequences -- what FastGA's own
+    calls guarantee (hit boxes come from seeds inside the contigs); outside, the reference reads past its buffers and
+    its result depends on whatever lies there"""
+    while ((anti - hgh) >> 1) < 0:              # Local_Alignment's own adjustment (align.c:1463-1464)
+        hgh -= 1
+    for k in (low, hgh):
+        x = (anti + k) >> 1
+        if not (0 <= x <= len(A) and 0 <= x - k <= len(B)):
+            return False
+    return hgh >= low
+
+
 def _random_case(rng):
+    while True:
+        c = _random_case_any(rng)
+        if _starts_in_range(c[0], c[1], c[3], c[4], c[5]):
+            return c
+
+
+def _random_case_any(rng):
     from fastga_amd import synth
     n = int(rng.integers(300, 6000))
     A = rng.integers(0, 4, n, dtype=np.uint8)
