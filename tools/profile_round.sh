@@ -12,21 +12,22 @@ out=$root/gpurun_out
 mkdir -p $out/prof_$tag
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $root/bench.py --steps 5 --warmup 2 --no-cpu --no-cold"
-rocprofv3 --kernel-trace --stats -d $out/prof_$tag/kt -o kt --output-format csv -- $BENCH > $out/prof_$tag/kt.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats -d $out/prof_$tag/kt -o kt --output-format csv -- $BENCH > $out/prof_$tag/kt.log 2>&1
 cp $out/prof_$tag/kt/kt_kernel_stats.csv $out/${tag}_kernel_stats.csv
 grep -a '"metric"' $out/prof_$tag/kt.log | tail -1 > $out/${tag}_bench_under_rocprof.json
-pass() { name=$1; shift
-  rocprofv3 --pmc "$@" -d $out/prof_$tag/$name -o pmc --output-format csv -- $BENCH > $out/prof_$tag/$name.log 2>&1
+pass() { name=$1; shift; echo "pass $name" >&2
+  timeout 120 rocprofv3 --pmc "$@" -d $out/prof_$tag/$name -o pmc --output-format csv -- $BENCH > $out/prof_$tag/$name.log 2>&1
 }
 pass pmc_fetch FETCH_SIZE
 pass pmc_write WRITE_SIZE
 pass pmc_sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES
 pass pmc_sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES
+pass pmc_lds SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT
 python - "$out/prof_$tag" "$out/${tag}_pmc_summary.csv" "$commit" <<'PY'
 import csv, glob, sys, collections
 src, dst = sys.argv[1], sys.argv[2]
 rows = []
-for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_lds"):
     agg = collections.defaultdict(lambda: [0.0, set()])
     for f in glob.glob(f"{src}/{name}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
