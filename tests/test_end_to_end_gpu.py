@@ -226,3 +226,35 @@ def test_converter_tools_on_reference_files(toy_pair, tmp_path):
         exp = H.run([H.ref_bin("ALNtoPSL"), "-T4", aln], cwd=w).stdout
         r = subprocess.run([os.path.join(bindir, "ALNtoPSL"), "-T4", aln], cwd=w, capture_output=True, text=True)
         assert r.returncode == 0 and r.stdout == exp, tag
+
+
+def test_cli_process_contract_log_threads_cleanup(tmp_path, built_library):
+    """-L:<log> gets the -v lines and the reference's resource lines; -T reaches the device index build; a GDB made from
+    a FASTA source is removed again unless -k, and with -k the index files are written too (FastGA.c:152-196, 4444-4637)"""
+    import gzip
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fastga_amd", "bin", "FastGA")
+    w = str(tmp_path)
+    for n in ("toy_A", "toy_B"):
+        with gzip.open(os.path.join(root, "tests", "golden", n + ".fa.gz"), "rb") as f:
+            open(os.path.join(w, n + ".fa"), "wb").write(f.read())
+    r = subprocess.run([exe, "-v", "-T4", "-L:run.log", "-1:out", "toy_A.fa", "toy_B.fa"], cwd=w, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert os.path.getsize(os.path.join(w, "out.1aln")) > 0
+    log = open(os.path.join(w, "run.log")).read()
+    for key in ("Creating genome data base (GDB)", "Total seeds =", "non-redundant aln's", "Resources for phase:",
+                "Total Resources:"):
+        assert key in log and key in r.stderr, key
+    assert "FastGA -v -T4" in log                                       # the command line opens the log entry
+    assert not os.path.exists(os.path.join(w, "toy_A.gdb")) and not os.path.exists(os.path.join(w, ".toy_B.bps"))
+    r = subprocess.run([exe, "-k", "-1:out2", "toy_A.fa", "toy_B.fa"], cwd=w, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for f in ("toy_A.gdb", ".toy_A.bps", "toy_A.gix", "toy_B.gdb", "toy_B.gix"):
+        assert os.path.exists(os.path.join(w, f)), f
+    from oracle import harness as H
+    if H.have_reference():
+        keep = lambda p: [ln for ln in H.oneview(p) if ln[0] not in "!<"]      # noqa: E731
+        assert keep(os.path.join(w, "out.1aln")) == keep(os.path.join(w, "out2.1aln"))
+        golden = [ln.rstrip("\n") for ln in open(os.path.join(root, "tests", "golden", "toy_AvB.1aln.txt"))]
+        assert keep(os.path.join(w, "out.1aln")) == [ln for ln in golden if ln[0] not in "!<"]
