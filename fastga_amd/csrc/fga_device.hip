@@ -96,6 +96,22 @@ extern "C" void fga_dev_free(fga_dev *dev, void *ptr)
   hipFree(ptr);
 }
 
+// free device memory right now, remembered as a low-water mark: with the grow-only workspace slots, the difference to
+// the device's total is the peak footprint of the process on this GPU (fga_run_stats.hbm_peak_bytes)
+void fga_dev_note_memory(fga_dev *dev)
+{ size_t fr = 0, tot = 0;
+  if (hipMemGetInfo(&fr,&tot) == hipSuccess && (dev->hbm_low_water == 0 || fr < dev->hbm_low_water))
+    dev->hbm_low_water = fr;
+}
+
+extern "C" int64_t fga_dev_peak_bytes(fga_dev *dev)
+{ size_t fr = 0, tot = 0;
+  if (hipSetDevice(dev->device) != hipSuccess || hipMemGetInfo(&fr,&tot) != hipSuccess)
+    return -1;
+  fga_dev_note_memory(dev);
+  return (int64_t) (tot - dev->hbm_low_water);
+}
+
 extern "C" int fga_dev_download(fga_dev *dev, void *host_dst, const void *device_src, size_t bytes)
 { FGA_HIP(hipSetDevice(dev->device));
   if (bytes > 0)

@@ -33,7 +33,12 @@ struct fga_dev
     int          slot_busy[16];
     void        *pinned;          // pinned host staging buffer (key download)
     size_t       pinned_bytes;
+    // what the last extension launch really needed (cells of the trace-point pool per hit-box base, output trace bytes
+    // per base): the next launch over similar inputs starts from there instead of finding out by a repeated launch
+    double       ext_cells_per_base, ext_tbytes_per_base;
+    size_t       hbm_low_water;   // smallest free device memory seen at the stage boundaries (fga_dev_note_memory)
   };
+void fga_dev_note_memory(fga_dev *dev);
 
 // device-resident genome index: the on-disk bytes, unchanged
 struct fga_dgix

@@ -49,6 +49,8 @@
 // contig size.  (The reference grows one array per thread: enlarge_points / enlarge_vector, align.c:52-149.)
 #define ARENA_L0    14                  // level 0: 16384 cells = 256 KB
 #define ARENA_NLEV  16                  // levels 0..15 cover 2^30 logical cells (32-bit arena arithmetic)
+#define ARENA_KEEP  4                   // levels 0..3 (245 k cells, 3.9 MB) stay with the wavefront; larger ones are returned
+#define ARENA_LIST_CAP 1024             // returned levels remembered per size
 #define ARENA_LEVEL(i)  (31 - __builtin_clz((((unsigned) (i)) >> ARENA_L0) + 1u))
 #define ARENA_START(l)  ((int) (((1u << (l)) - 1u) << ARENA_L0))
 #define ARENA_END(l)    ((int) (((2u << (l)) - 1u) << ARENA_L0))       // level 15: 2^30 - 2^14, fits an int
@@ -62,6 +64,12 @@ struct ext_prof
 struct ext_state              // wave-uniform alignment state (the reference's Path + trace pointer)
   { int abpos, bbpos, aepos, bepos, diffs, tlen;
     int tpos;                 // index of trace[0] inside the per-wave trace scratch
+  };
+
+struct arena_lists            // returned arena levels by size, each list behind its own spin lock (fga_extend_kernel.inc)
+  { int       lock[ARENA_NLEV];
+    int       nfree[ARENA_NLEV];
+    long long cell[ARENA_NLEV][ARENA_LIST_CAP];
   };
 
 struct ext_args
@@ -83,6 +91,7 @@ struct ext_args
     // scratch (per workgroup)
     int4     *pool;   int64_t pool_cells;    // the launch's cell pool (pebble levels and trace scratch of all wavefronts)
     unsigned long long *pool_next;           // its head
+    arena_lists *lists;                      // levels returned by finished units
     // output
     fga_aln  *alns; int64_t aln_cap;
     uint8_t  *tbytes; int64_t tbytes_cap;
@@ -99,8 +108,8 @@ struct la_one_args
 // The device code is compiled twice (fga_extend_kernel.inc):
 //   ext_full  512-diagonal ring, 8192-base windows: 27 KB of LDS per wavefront, six wavefronts per CU.  The latency regime
 //             (few long units: the run time is the longest unit's serial chain) and the refuge of units handed over by
-//   ext_mid   256-diagonal ring, 4096-base windows, the register budget of three wavefronts per SIMD: 14 KB of LDS,
-//             eleven resident wavefronts per CU -- the throughput regime (10^5 .. 10^6 short units; no wave of the
+//   ext_mid   256-diagonal ring, 3072-base windows, the register budget of three wavefronts per SIMD: 13.3 KB of LDS,
+//             twelve resident wavefronts per CU -- the throughput regime (10^5 .. 10^6 short units; no wave of the
 //             150-Mbp repeat-heavy self comparison, the 2 % or the 10 % pair is wider than 248 diagonals).
 #define RC  512
 #define WDW 512
@@ -115,7 +124,7 @@ struct la_one_args
 #undef EXT_HANDOFF
 
 #define RC  256
-#define WDW 256
+#define WDW 192
 #define EXT_NS ext_mid
 #define EXT_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(3,3)))
 #define EXT_HANDOFF 1
@@ -270,7 +279,7 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
     if (ev != NULL) narrow = atoi(ev) != 0;
     if (getenv("FGA_EXTEND_FORCE_LDS") != NULL) narrow = false;
   }
-  int nwg = dev->ncu * (narrow ? 11 : (many ? 6 : 4));
+  int nwg = dev->ncu * (narrow ? 12 : (many ? 6 : 4));
   { const char *ev = getenv("FGA_EXTEND_WGS");
     if (ev != NULL && atoi(ev) > 0) nwg = atoi(ev);
   }
@@ -282,15 +291,20 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
   int64_t span = 0;
   for (int64_t h = 0; h < H->nhits; h++)
     span += (H->hits[h].ahgh - H->hits[h].alow) / 2 + 200;
+  // cells / trace bytes per hit-box base: 0.48 / 0.04 to begin with (24 diagonals x 2 / 100; 4 / 100), afterwards what the
+  // device context's last launch needed plus a quarter
+  const double cpb = dev->ext_cells_per_base > 0. ? 1.25*dev->ext_cells_per_base : 0.48;
+  const double tpb = dev->ext_tbytes_per_base > 0. ? 1.25*dev->ext_tbytes_per_base : 0.04;
   int64_t pool_cells = prm->cell_cap > 0 ? prm->cell_cap
-                                         : (int64_t) nwg*((1 << ARENA_L0) + 8*(maxa/prm->tspace + 72)/8 + 64) + 2*24*(span/prm->tspace)
+                                         : (int64_t) nwg*((1 << ARENA_L0) + 256) + (int64_t) (cpb*span)
                                            + ((int64_t) 64 << 20);
   int64_t aln_cap   = prm->aln_cap   > 0 ? prm->aln_cap   : 4*H->nhits + 1024;
-  int64_t tb_cap    = prm->trace_cap > 0 ? prm->trace_cap : 4*(span/prm->tspace) + 64*aln_cap + (1 << 20);
-  { size_t fr = 0, tot = 0;                  // never ask for more than half of what is free
+  int64_t tb_cap    = prm->trace_cap > 0 ? prm->trace_cap : (int64_t) (tpb*span) + 64*aln_cap + (1 << 20);
+  { size_t fr = 0, tot = 0;                  // never ask for more than what is free (the slot's own bytes count as free)
     if (hipMemGetInfo(&fr,&tot) == hipSuccess && fr > 0)
-      { const int64_t lim = (int64_t) (fr/2) / (int64_t) sizeof(int4);
-        if (pool_cells > lim) pool_cells = lim;
+      { const int64_t have = (int64_t) dev->slot_bytes[SLOT_CELLS];
+        const int64_t lim = ((int64_t) fr + have - ((int64_t) 8 << 30)) / (int64_t) sizeof(int4);
+        if (lim > 0 && pool_cells > lim) pool_cells = lim;
       }
   }
 
@@ -310,8 +324,10 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
   std::vector<int> wide;
   int16_t *d_tab = NULL;
   unsigned long long *d_cnt = NULL;
+  arena_lists *d_lists = NULL;
   hipError_t e;
-  if ((e = hipMalloc(&d_units,sizeof(fga_unit)*H->nunits)) != hipSuccess ||
+  if ((e = hipMalloc(&d_lists,sizeof(arena_lists))) != hipSuccess ||
+      (e = hipMalloc(&d_units,sizeof(fga_unit)*H->nunits)) != hipSuccess ||
       (e = hipMalloc(&d_hits,sizeof(fga_hit)*(H->nhits+1))) != hipSuccess ||
       (e = hipMalloc(&d_order,sizeof(int)*H->nunits)) != hipSuccess ||
       (e = hipMalloc(&d_wide,sizeof(int)*H->nunits)) != hipSuccess ||
@@ -340,6 +356,9 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
           goto fail;
         }
       A.pool_next = d_cnt + 16;
+      A.lists = d_lists;
+      hipMemsetAsync(d_lists,0,sizeof(int)*2*ARENA_NLEV,dev->stream);
+      fga_dev_note_memory(dev);                  // pool + output buffers + resident inputs: a footprint peak
       hipMemsetAsync(d_next,0,sizeof(int),dev->stream);
       hipMemsetAsync(d_cnt,0,sizeof(unsigned long long)*32,dev->stream);
 
@@ -366,6 +385,7 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
               hipMemcpy(wide.data(),d_wide,sizeof(int)*(size_t) nw,hipMemcpyDeviceToHost);
               unsigned long long zero = 0;
               hipMemcpyAsync(d_cnt+16,&zero,sizeof(zero),hipMemcpyHostToDevice,dev->stream);
+              hipMemsetAsync(d_lists,0,sizeof(int)*2*ARENA_NLEV,dev->stream);
               hipMemsetAsync(d_next,0,sizeof(int),dev->stream);
               A.order = d_wide; A.nunits = (int) nw;
               int wwg = dev->ncu * 6;
@@ -406,7 +426,13 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
           goto fail;
         }
       if (!pool_out && !out_full)
-        break;
+        { if (span > 0)                           // remember the real demand (beyond every wavefront's first level)
+            { const double used = (double) hc[16] - (double) nwg*(1 << ARENA_L0);
+              dev->ext_cells_per_base  = (used > 0. ? used : 0.) / (double) span;
+              dev->ext_tbytes_per_base = (double) R->ntrace / (double) span;
+            }
+          break;
+        }
       fga_dev_release(dev,SLOT_CELLS,A.pool); fga_dev_release(dev,SLOT_ALNS,A.alns); fga_dev_release(dev,SLOT_TBYTES,A.tbytes);
       A.pool = NULL; A.alns = NULL; A.tbytes = NULL;
       if (attempt >= 3 || prm->cell_cap > 0 || prm->aln_cap > 0 || prm->trace_cap > 0)
@@ -442,14 +468,14 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
       R->naln = o;
     }
   R->ncalls = ncalls_total;
-  hipFree(d_units); hipFree(d_hits); hipFree(d_order); hipFree(d_wide); hipFree(d_next); hipFree(d_tab); hipFree(d_cnt);
+  hipFree(d_units); hipFree(d_hits); hipFree(d_order); hipFree(d_wide); hipFree(d_next); hipFree(d_tab); hipFree(d_cnt); hipFree(d_lists);
   fga_dev_release(dev,SLOT_CELLS,A.pool);
   fga_dev_release(dev,SLOT_ALNS,A.alns); fga_dev_release(dev,SLOT_TBYTES,A.tbytes);
   *out = R;
   return 0;
 
 fail:
-  hipFree(d_units); hipFree(d_hits); hipFree(d_order); hipFree(d_wide); hipFree(d_next); hipFree(d_tab); hipFree(d_cnt);
+  hipFree(d_units); hipFree(d_hits); hipFree(d_order); hipFree(d_wide); hipFree(d_next); hipFree(d_tab); hipFree(d_cnt); hipFree(d_lists);
   fga_dev_release(dev,SLOT_CELLS,A.pool);
   fga_dev_release(dev,SLOT_ALNS,A.alns); fga_dev_release(dev,SLOT_TBYTES,A.tbytes);
   free(R->alns); free(R->tbytes); free(R);
@@ -471,6 +497,7 @@ struct shim_work
     uint16_t *dtrace; int dtrace_cap;
     int     *dout;
     unsigned long long *dcnt;
+    arena_lists *dlists;
     std::vector<uint8_t>  pack;
     std::vector<uint16_t> trace;                  // result trace (the reference's work->points)
   };
@@ -484,11 +511,12 @@ extern "C" void *fga_shim_New_Work_Data(void)
 { shim_work *W = new (std::nothrow) shim_work();
   if (W == NULL) { fga_set_error("out of memory"); return NULL; }
   W->dev = NULL; W->dA = W->dB = NULL; W->capA = W->capB = 0; W->pool = NULL; W->pool_cells = 0;
-  W->dtrace = NULL; W->dtrace_cap = 0; W->dout = NULL; W->dcnt = NULL;
+  W->dtrace = NULL; W->dtrace_cap = 0; W->dout = NULL; W->dcnt = NULL; W->dlists = NULL;
   const char *e = getenv("FGA_DEVICE");
   if (fga_dev_open(e != NULL ? atoi(e) : 0,&W->dev))
     { delete W; return NULL; }
-  if (hipMalloc(&W->dout,sizeof(int)*8) != hipSuccess || hipMalloc(&W->dcnt,sizeof(unsigned long long)*32) != hipSuccess)
+  if (hipMalloc(&W->dout,sizeof(int)*8) != hipSuccess || hipMalloc(&W->dcnt,sizeof(unsigned long long)*32) != hipSuccess ||
+      hipMalloc(&W->dlists,sizeof(arena_lists)) != hipSuccess || hipMemset(W->dlists,0,sizeof(arena_lists)) != hipSuccess)
     { fga_set_error("fga_shim_New_Work_Data: device allocation failed");
       hipFree(W->dout); fga_dev_close(W->dev); delete W;
       return NULL;
@@ -500,7 +528,7 @@ extern "C" void fga_shim_Free_Work_Data(void *work)
 { shim_work *W = (shim_work *) work;
   if (W == NULL) return;
   hipSetDevice(W->dev->device);
-  hipFree(W->dA); hipFree(W->dB); hipFree(W->pool); hipFree(W->dtrace); hipFree(W->dout); hipFree(W->dcnt);
+  hipFree(W->dA); hipFree(W->dB); hipFree(W->pool); hipFree(W->dtrace); hipFree(W->dout); hipFree(W->dcnt); hipFree(W->dlists);
   fga_dev_close(W->dev);
   delete W;
 }
@@ -585,6 +613,8 @@ extern "C" int fga_shim_Local_Alignment(void *align_, void *work, void *spec_, i
   L.G.tspace = TS; L.G.path_ave = S->path_ave; L.G.mscore = S->mscore;
   L.G.force_lds = getenv("FGA_EXTEND_FORCE_LDS") != NULL;
   L.G.pool = W->pool; L.G.pool_cells = W->pool_cells; L.G.pool_next = W->dcnt + 16; L.G.counters = W->dcnt;
+  L.G.lists = W->dlists;
+  hipMemsetAsync(W->dlists,0,sizeof(int)*2*ARENA_NLEV,W->dev->stream);
   L.alen = align->alen; L.blen = selfie ? align->alen : align->blen;
   L.acomp = (align->flags & 0x2) != 0;           // ACOMP_FLAG (align.h:128)
   L.selfie = selfie;

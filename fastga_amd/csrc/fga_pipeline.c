@@ -184,6 +184,7 @@ int fga_session_align(fga_session *Z, const fga_run_params *P, fga_dseeds *seeds
     sp.nctg_a = x1->nctg;   sp.nctg_b = self ? x1->nctg : x2->nctg;
     sp.anti_order_only = 1;          /* chains do not depend on the order inside an (anti-diagonal) tie */
     if (fga_seed_sort(dev,seeds,&sp,&keys)) goto done;
+    fga_dev_peak_bytes(dev);                 /* seeds + both key buffers are live here: the footprint's peak */
     fga_seeds_free(seeds); seeds = NULL;
     st.sort_kernel_ms = fga_dev_stage_ms(dev,FGA_STAGE_SORT);
   }
@@ -422,6 +423,7 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
   if (fga_session_finish(Z,P,(const fga_alns *const *) raw,nparts,&st)) goto done;
   st.phase23_s = fga_wall() - tstart - st.trace_s - st.paf_s;
   st.nparts = nparts;
+  st.hbm_peak_bytes = fga_dev_peak_bytes(dev);
   st.bases1 = Z->g1->seqtot; st.bases2 = Z->self ? Z->g1->seqtot : Z->g2->seqtot;
   status = 0;
 

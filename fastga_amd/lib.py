@@ -94,7 +94,7 @@ class RunStats(C.Structure):
                [(n, C.c_float) for n in ("merge_kernel_ms", "sort_kernel_ms", "extend_kernel_ms",
                                          "trace_kernel_ms")] + [("nparts", C.c_int), ("bases1", C.c_int64), ("bases2", C.c_int64), ("ext_cells", C.c_int64),
                                                      ("ext_bases", C.c_int64), ("ext_trace", C.c_int64),
-                                                     ("ext_busy_waves", C.c_double)]
+                                                     ("ext_busy_waves", C.c_double), ("hbm_peak_bytes", C.c_int64)]
 
 
 class SortParams(C.Structure):
@@ -143,6 +143,7 @@ def _declare(L):
         "fga_dev_malloc": (i32, [vp, C.c_size_t, P(vp)]),
         "fga_dev_free": (None, [vp, vp]),
         "fga_dev_download": (i32, [vp, vp, vp, C.c_size_t]),
+        "fga_dev_peak_bytes": (i64, [vp]),
         "fga_dgix_build": (i32, [vp, vp, i32, i32, P(vp), P(vp)]),
         "fga_gix_write_files": (i32, [vp, cp]),
         "fga_dgix_upload": (i32, [vp, vp, P(vp)]),

@@ -89,6 +89,7 @@ float fga_dev_stage_ms(const fga_dev *dev, int stage);   /* HIP-event time of th
 int   fga_dev_malloc(fga_dev *dev, size_t bytes, void **out);
 void  fga_dev_free(fga_dev *dev, void *ptr);
 int   fga_dev_download(fga_dev *dev, void *host_dst, const void *device_src, size_t bytes);
+int64_t fga_dev_peak_bytes(fga_dev *dev);   /* peak device memory in use by this process so far (stage-boundary samples) */
 
 int   fga_dgix_upload(fga_dev *dev, const fga_gix *gix, fga_dgix **out);
 void  fga_dgix_free(fga_dgix *dgix);
@@ -322,6 +323,7 @@ typedef struct
     int64_t bases1, bases2;  /* bases of the two genomes (the reference's "seeds per G1 position") */
     int64_t ext_cells, ext_bases, ext_trace;   /* extension accounting summed over the parts (fga_alns)         */
     double  ext_busy_waves;                    /* wavefronts busy on average (last part)                        */
+    int64_t hbm_peak_bytes;                    /* peak device memory in use by this process, sampled at the stage boundaries */
   } fga_run_stats;
 
 int  fga_run(const char *root1, const char *root2 /* NULL: self */, const fga_run_params *prm, fga_run_stats *stats);

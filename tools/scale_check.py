@@ -16,11 +16,13 @@ ap.add_argument("--mask", action="store_true")
 ap.add_argument("--threads", type=int, default=32)
 ap.add_argument("--host-gix", action="store_true", help="build .gix files on the host instead of on the device")
 ap.add_argument("--pafx", action="store_true", help="also write PAF with CIGARs (edit scripts on the device)")
+ap.add_argument("--seed", type=int, default=2)
+ap.add_argument("--inv", type=float, default=0.02, help="fraction of 40-kbp blocks inverted / swapped")
 a = ap.parse_args()
 d = tempfile.mkdtemp(prefix="fga_scale_")
 t = time.time()
-lens = synth.contig_lengths(2, a.contigs, int(a.mbp * 1e6))
-A, mA, B, mB = synth.make_pair(2, lens, a.div, repeat_frac=a.repeats, inv_frac=0.02, swap_frac=0.02, self_only=a.self_)
+lens = synth.contig_lengths(a.seed, a.contigs, int(a.mbp * 1e6))
+A, mA, B, mB = synth.make_pair(a.seed, lens, a.div, repeat_frac=a.repeats, inv_frac=a.inv, swap_frac=a.inv, self_only=a.self_)
 print(f"synth {time.time()-t:.1f}s", flush=True); t = time.time()
 ra = workload.build_genome(d, "A", A, masks=mA if a.mask else None, threads=a.threads, use_mask=a.mask, gix=a.host_gix)
 rb = None if a.self_ else workload.build_genome(d, "B", B, threads=a.threads, gix=a.host_gix)
@@ -39,6 +41,7 @@ for rep in range(2):
     if a.pafx:
         print(f"   PAF -x: edit scripts {1000*st['trace_s']:.1f} ms (kernels {st['trace_kernel_ms']:.1f} ms), regroup+format "
               f"{1000*st['paf_s']:.1f} ms, {os.path.getsize(os.path.join(d, 'out.paf'))/1e6:.0f} MB", flush=True)
+    print(f"   peak HBM in use {st['hbm_peak_bytes']/2**30:.1f} GiB", flush=True)
     alg = ses.table_bytes + st["nseeds"] * (2 if a.self_ else 1) * ses.seed_bytes
     print(f"   merge kernel {alg/st['merge_kernel_ms']/1e6:.0f} GB/s algorithmic", flush=True)
 ses.close()
