@@ -284,7 +284,6 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
     if (ev != NULL && atoi(ev) > 0) nwg = atoi(ev);
   }
   if (nwg > H->nunits) nwg = (int) H->nunits;
-  const int64_t maxa = GA->maxctg > GB->maxctg ? GA->maxctg : GB->maxctg;
   // Scratch and output are sized by what the hits suggest, not by the worst case times the number of wavefronts; the
   // kernel counts what it would have needed, so a launch that runs out is repeated once with exactly that
   // (prm->cell_cap: pool cells; prm->aln_cap / prm->trace_cap: output records / trace bytes).
