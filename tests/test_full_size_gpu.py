@@ -105,6 +105,23 @@ def test_human_scale_contigs_3x94mbp_pair_is_identical_to_the_reference(tmp_path
 
 
 @pytest.mark.skipif(os.environ.get("FGA_SKIP_1G") == "1", reason="FGA_SKIP_1G=1")
+def test_human_scale_contigs_3x94mbp_at_10_percent_is_identical_to_the_reference(tmp_path_factory, built_library):
+    """the same shape at 10 % divergence: every wave of the contig-long alignments is hundreds of diagonals wide (ring
+    spills, ~10^6 wave steps each, 2.7 x 10^8 in all); the trace-point pool must stay a small part of the HBM"""
+    import time
+    from fastga_amd import workload
+    d = str(tmp_path_factory.mktemp("c5"))
+    ra, rb = workload.build_pair(d, seed=3, ncontig=3, total=282_000_000, divergence=0.10, repeat_frac=0.05,
+                                 inv_frac=0.02, swap_frac=0.02, threads=T, gix=False)
+    _write_index_files((ra, rb), nthreads=3)
+    t = time.time()
+    st, dg = _compare_with_reference(ra, rb, d, strict=False, ref_threads=3)
+    print(f"human-scale 10 %: ours {1000*sum(st[k] for k in ('merge_s','sort_s','chain_s','extend_s','filter_s','write_s')):.0f} ms (extension kernel {st['extend_kernel_ms']:.0f} ms), "
+          f"peak HBM {st['hbm_peak_bytes']/2**30:.1f} GiB, reference + ours {time.time()-t:.0f} s, {dg['records']} records")
+    assert dg["records"] > 1000 and st["hbm_peak_bytes"] < 64 << 30
+
+
+@pytest.mark.skipif(os.environ.get("FGA_SKIP_1G") == "1", reason="FGA_SKIP_1G=1")
 def test_config3_1gbp_self_soft_masked_matches_the_reference_digest(tmp_path_factory, built_library):
     """configs[2] at full size, index built on the device; expected digest: tests/golden/config3_1000m_digest.json, made
     with the real reference by tests/golden/make_golden_config3.py"""
