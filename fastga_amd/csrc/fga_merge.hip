@@ -1212,9 +1212,17 @@ __device__ __forceinline__ void lds_payload(const uint32_t *rawd, uint32_t o, in
   ctg  = c & (sb-1);
 }
 
+#ifdef MERGE_PROF
+#define XPROF(k)   { unsigned long long _n = clock64(); O.pa[k] += _n - O.pt; O.pt = _n; }
+#else
+#define XPROF(k)
+#endif
 struct walk_out                      // a wavefront's current output chunk and statistics (wave-uniform)
   { int64_t chunk_pos, chunk_end;
     unsigned long long tsum;
+#ifdef MERGE_PROF
+    unsigned long long pt, pa[8];
+#endif
   };
 
 // One tile: T1 entries [a0, a0+n1) and T2 entries [b0, b0+n2) (self: the same stretch) in np <= 64 panels whose
@@ -1254,8 +1262,10 @@ __device__ __forceinline__ void walk_tile(const merge_args &A, uint16_t *la, uin
     ((uint2 *) own)[x*64 + lane] = make_uint2(0,0);
   // the direct-to-LDS loads are asynchronous and nothing below depends on a VGPR they return: wait for them by hand
   // (vmcnt(0); the counters of the other queues are left alone)
+  XPROF(0)
   __builtin_amdgcn_s_waitcnt(0x0F70);
   WSYNC();
+  XPROF(1)
 #if defined(XKNOCK) && XKNOCK == 1                   // phase knock-outs: timing experiments only (wrong output)
   return;
 #endif
@@ -1276,6 +1286,7 @@ __device__ __forceinline__ void walk_tile(const merge_args &A, uint16_t *la, uin
       lcpB[j] = (uint8_t) lc;                          // the run growth below walks these bytes
     }
   WSYNC();
+  XPROF(2)
 #if defined(XKNOCK) && XKNOCK == 2
   return;
 #endif
@@ -1303,15 +1314,17 @@ __device__ __forceinline__ void walk_tile(const merge_args &A, uint16_t *la, uin
       { const int i = lane*XEPT + e;
         const int q = xs[e] > prev ? xs[e] : prev;
         bool ok = i >= t1_lo && i < t1_hi;
+        int pb0 = 0, pb1 = 0;
         if (ok)
-          { const int pb0 = q ? (int) lb[q-1] : 0, pb1 = (int) lb[q];
+          { pb0 = q ? (int) lb[q-1] : 0; pb1 = (int) lb[q];
             ok = pb1 > pb0;
             if (ok && MODE == MODE_PAIR)
               { const uint32_t sb = o1 + (uint32_t) i*E1 + E1 - 1;
                 ok = !((rawd[sb >> 2] >> (8*(sb & 3))) & 0x80);
               }
           }
-        pk[e] = ok ? ((uint32_t) i | ((uint32_t) q << 16)) : 0xffffffffu;
+        // the panel bounds travel with the entry: the match needs neither the owner nor lb[] again
+        pk[e] = ok ? ((uint32_t) i | ((uint32_t) pb0 << 10) | ((uint32_t) pb1 << 20)) : 0xffffffffu;
         live += ok;
       }
     int lbase = wave_excl_scan_add_dpp(live,nlive);
@@ -1321,85 +1334,94 @@ __device__ __forceinline__ void walk_tile(const merge_args &A, uint16_t *la, uin
         clist[lbase++] = pk[e];
   }
   WSYNC();
+  XPROF(3)
 #if defined(XKNOCK) && XKNOCK == 3
   O.tsum += nlive;
   return;
 #endif
 
-  // 4. match phase; result per round packed: i (9 bits) | low << 9 | plen << 18 | seeds << 24
+  // 4. match phase; result per round packed: i (9 bits) | low << 9 | plen << 18 | seeds << 24.
+  // Written without branches around its LDS reads, so that the reads of one step are in flight together: the entry,
+  // then its key, then the lower bound of the key in its T2 panel (a wave-uniform number of halving steps), then both
+  // neighbour keys and the first lcp byte of either growth direction in one round trip.  Only runs that grow past
+  // their first step (repeats) take a loop.
   uint32_t res[XEPT];
   int total = 0;
   #pragma unroll
   for (int r = 0; r < XEPT; r++)
-    { const int c = r*64 + lane;
-      res[r] = 0;
-      if (c >= nlive)
+    { res[r] = 0;
+      if (r*64 >= nlive)                       // wave-uniform
         continue;
-      const uint32_t ce = clist[c];
-      const int i = (int) (ce & 0xffff), q = (int) (ce >> 16);
-      const uint32_t oe = o1 + (uint32_t) i*E1;
-      const int pb0 = q ? (int) lb[q-1] : 0, pb1 = (int) lb[q];
-      const uint64_t ks = (MODE == MODE_SELF) ? keyB[i] : lds_read_key(rawd,oe);
-      int low, hgh, plen, lbnd, lnb, lna;       // lnb / lna: LCP with the T2 neighbour before / after (-1: none)
+      const int c = r*64 + lane;
+      const bool act = c < nlive;
+      const uint32_t ce = act ? clist[c] : 0u;
+      const int i = (int) (ce & 0x3ff), pb0 = (int) ((ce >> 10) & 0x3ff), pb1 = (int) (ce >> 20);
+      const uint64_t ks = (MODE == MODE_SELF) ? keyB[i] : lds_read_key(rawd,o1 + (uint32_t) i*E1);
+      int nb, na, low, hgh, lbnd;              // nb / na: the T2 neighbour before / after
       if (MODE == MODE_SELF)
-        { int lk  = (i > pb0)   ? lcp_key(ks,keyB[i-1]) : 0;
-          int lk1 = (i+1 < pb1) ? lcp_key(ks,keyB[i+1]) : 11;
-          plen = lk > lk1 ? lk : lk1;
-          low = i; hgh = i+1; lbnd = i;
-          lnb = (i > pb0) ? lk : -1; lna = (i+1 < pb1) ? lk1 : -1;
-        }
+        { nb = i-1; na = i+1; low = i; hgh = i+1; lbnd = i; }
       else
-        { int lo = pb0, hi = pb1;
-          const uint64_t kq = ks & ~0xffull;
-          while (lo < hi)
-            { int m = (lo+hi) >> 1;
-              if (keyB[m] < kq) lo = m+1; else hi = m;
+        { const uint64_t kq = ks & ~0xffull;
+          int base = pb0, len = pb1 - pb0;     // first entry of [pb0,pb1) that is >= kq
+          while (__builtin_amdgcn_ballot_w64(len > 1) != 0)
+            { const int half = len >> 1;
+              const bool lt = keyB[base + half - 1] < kq && len > 1;
+              base += lt ? half : 0;
+              len  -= (len > 1) ? half : 0;
             }
-          int la_ = (lo > pb0) ? lcp_key(ks,keyB[lo-1]) : 0;
-          int lc_ = (lo < pb1) ? lcp_key(ks,keyB[lo]) : 0;
-          plen = la_ > lc_ ? la_ : lc_;
-          low = hgh = lbnd = lo;
-          lnb = (lo > pb0) ? la_ : -1; lna = (lo < pb1) ? lc_ : -1;
+          base += (len > 0 && keyB[base] < kq) ? 1 : 0;
+          nb = base-1; na = base; low = hgh = lbnd = base;
         }
-      // run growth on the table's own lcp bytes (see the wave kernel above), here from their own byte array
-      if (lnb >= plen)
+      const uint64_t kb = keyB[nb], kc = keyB[na];       // keyB[-1] and keyB[n2] exist (never used when out of the panel)
+      const int bd = (int) lcpB[nb], bu = (int) lcpB[na+1];
+      const bool hasb = nb >= pb0, hasa = na < pb1;
+      const int lkb = lcp_key(ks,kb), lka = lcp_key(ks,kc);
+      const int lnb = hasb ? lkb : -1, lna = hasa ? lka : -1;       // -1: no such neighbour
+      const int pb_ = hasb ? lkb : 0, pa_ = hasa ? lka : (MODE == MODE_SELF ? 11 : 0);
+      const int plen = pb_ > pa_ ? pb_ : pa_;
+      // run growth on the table's own lcp bytes (see the wave kernel above); the first step of either direction is
+      // decided on the bytes read above
+      const bool gd = act && lnb >= plen;
+      low -= gd ? 1 : 0;
+      if (gd && low > pb0 && lbnd-low <= freq && bd >= plen)
         { low -= 1;
           while (low > pb0 && lbnd-low <= freq && (int) lcpB[low] >= plen)
             low -= 1;
         }
-      if (lna >= plen && hgh < pb1 && hgh-low <= freq)
+      const bool gu = act && lna >= plen && hgh < pb1 && hgh-low <= freq;
+      hgh += gu ? 1 : 0;
+      if (gu && hgh < pb1 && hgh-low <= freq && bu >= plen)
         { hgh += 1;
           while (hgh < pb1 && hgh-low <= freq && (int) lcpB[hgh] >= plen)
             hgh += 1;
         }
-      if (hgh-low >= freq)
-        continue;
       const int mlen = A.soft_mask ? plen : 41;
-      if ((int) (ks & 0xff) >= mlen)
-        continue;
+      const bool pass = act && hgh-low < freq && (int) (ks & 0xff) < mlen;
       int cnt;
       if (MODE == MODE_FLIP || A.soft_mask)
         { cnt = 0;
-          for (int j = low; j < hgh; j++)
-            { if ((int) (keyB[j] & 0xff) >= mlen)
-                continue;
-              if (MODE == MODE_FLIP)
-                { uint32_t sb = o2 + (uint32_t) j*E2 + E2 - 1;
-                  if ((rawd[sb >> 2] >> (8*(sb & 3))) & 0x80)
-                    continue;
-                }
-              if (MODE == MODE_SELF && j == i)
-                continue;
-              cnt += 1;
-            }
+          if (pass)
+            for (int j = low; j < hgh; j++)
+              { if ((int) (keyB[j] & 0xff) >= mlen)
+                  continue;
+                if (MODE == MODE_FLIP)
+                  { uint32_t sb = o2 + (uint32_t) j*E2 + E2 - 1;
+                    if ((rawd[sb >> 2] >> (8*(sb & 3))) & 0x80)
+                      continue;
+                  }
+                if (MODE == MODE_SELF && j == i)
+                  continue;
+                cnt += 1;
+              }
         }
       else
-        cnt = (hgh-low) - (MODE == MODE_SELF ? 1 : 0);
-      res[r] = (uint32_t) i | ((uint32_t) low << 9) | ((uint32_t) plen << 18) | ((uint32_t) cnt << 24);
+        cnt = pass ? (hgh-low) - (MODE == MODE_SELF ? 1 : 0) : 0;
+      res[r] = pass ? ((uint32_t) i | ((uint32_t) low << 9) | ((uint32_t) plen << 18) | ((uint32_t) cnt << 24)) : 0u;
       total += cnt;
       O.tsum += (unsigned long long) cnt * plen;
     }
 
+  XPROF(4)
 #if defined(XKNOCK) && XKNOCK == 4
   O.tsum += total;
   WSYNC();
@@ -1500,6 +1522,7 @@ __device__ __forceinline__ void walk_tile(const merge_args &A, uint16_t *la, uin
         O.chunk_pos += T;
     }
   WSYNC();      // the tile buffers are reused by the next tile
+  XPROF(5)
 }
 
 template <int MODE>
@@ -1508,9 +1531,12 @@ void seed_merge_walk_kernel(merge_args A, walk_args W)
 { __shared__ uint16_t la[XPC+1];
   __shared__ uint16_t lb[XPC+1];
   extern __shared__ __attribute__((aligned(16))) uint8_t raw[];      // A.wrawcap bytes (sized by the entry widths)
-  __shared__ __attribute__((aligned(16))) uint64_t keyB[XT];
+  __shared__ __attribute__((aligned(16))) uint64_t keyB0[XT+4];      // keyB[-2 .. XT+1]: the match reads one past either end
   __shared__ __attribute__((aligned(16))) uint16_t own16[XT];
-  __shared__ __attribute__((aligned(16))) uint8_t  lcpB[XT];
+  __shared__ __attribute__((aligned(16))) uint8_t  lcpB0[XT+16];     // lcpB[-8 .. XT+7]
+  __shared__ __attribute__((aligned(16))) uint32_t ixs[4][64];       // index entries of the next 64 prefixes (lo / hi words)
+  uint64_t *keyB = keyB0 + 2;
+  uint8_t  *lcpB = lcpB0 + 8;
 
   const int lane = threadIdx.x;
   const int E1 = A.E1, E2 = A.E2;
@@ -1519,6 +1545,10 @@ void seed_merge_walk_kernel(merge_args A, walk_args W)
   const int margin = A.freq + 2;
   walk_out O;
   O.chunk_pos = O.chunk_end = 0; O.tsum = 0;
+#ifdef MERGE_PROF
+  O.pt = clock64();
+  for (int k = 0; k < 8; k++) O.pa[k] = 0;
+#endif
 
   for (;;)
     { int r = 0;
@@ -1532,14 +1562,42 @@ void seed_merge_walk_kernel(merge_args A, walk_args W)
       if (p >= pe)
         continue;
       int64_t a = idx_at(A.idx1,p-1), b = idx_at(idx2,p-1);
-      // index entries of the next 64 prefixes, one per lane (clamped at the range end)
-      int64_t ca = A.idx1[p + (lane < pe-p ? lane : pe-p-1)];
-      int64_t cb = (MODE == MODE_SELF) ? ca : idx2[p + (lane < pe-p ? lane : pe-p-1)];
+      // Index entries of the next 64 prefixes, one per lane (clamped at the range end).  They are fetched one tile
+      // ahead and travel HBM -> LDS like the tile bytes, not into registers: a register result would make the compiler
+      // wait for ALL outstanding vector-memory operations where the loop uses it, i.e. for the acknowledgements of the
+      // seed stores the tile before has just issued.  Their arrival is covered by the tile's own wait for its bytes
+      // (issued after them, completed in order); the reads below are opaque to the compiler for the same reason.
+#define IDX_ISSUE(P0)                                                                                                \
+      { const int64_t e_ = (P0) + (lane < pe-(P0) ? lane : pe-(P0)-1);                                                  \
+        const uint32_t *g_ = (const uint32_t *) (A.idx1 + e_);                                                         \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) g_,                          \
+                                         (__attribute__((address_space(3))) void *) &ixs[0][lane],4,0,0);               \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (g_+1),                      \
+                                         (__attribute__((address_space(3))) void *) &ixs[1][lane],4,0,0);               \
+        if (MODE != MODE_SELF)                                                                                         \
+          { const uint32_t *h_ = (const uint32_t *) (idx2 + e_);                                                       \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) h_,                      \
+                                             (__attribute__((address_space(3))) void *) &ixs[2][lane],4,0,0);           \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (h_+1),                  \
+                                             (__attribute__((address_space(3))) void *) &ixs[3][lane],4,0,0);           \
+          }                                                                                                            \
+      }
+      IDX_ISSUE(p)
+      __builtin_amdgcn_s_waitcnt(0x0F70);
       while (p < pe)
-        { const int navail = pe - p < XPC ? pe - p : XPC;
+        { int64_t ca, cb;
+          { const uint32_t at = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint32_t *) &ixs[0][lane];
+            uint64_t va, vb;
+            asm volatile("ds_read2st64_b32 %0, %2 offset1:1\n\tds_read2st64_b32 %1, %2 offset0:2 offset1:3\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(va), "=&v"(vb) : "v"(at) : "memory");
+            ca = (int64_t) va;
+            cb = (MODE == MODE_SELF) ? ca : (int64_t) vb;
+          }
+          const int navail = pe - p < XPC ? pe - p : XPC;
           const int64_t cost = (ca - a) + (cb - b) + 2*((int64_t) lane+1);
           const bool fits = lane < navail && cost <= XT;
           const int q = __popcll(__builtin_amdgcn_ballot_w64(fits));     // cost grows with the lane: a prefix mask
+          XPROF(6)
           const int adv = q > 0 ? q : 1;
           // end of the tile (or of the single oversize panel): totals up to prefix p+adv-1
           const uint32_t alo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) ca,adv-1);
@@ -1554,11 +1612,9 @@ void seed_merge_walk_kernel(merge_args A, walk_args W)
             }
           // the index entries of the tile after this one are on their way while this one is processed
           const int pn = p + adv;
-          int64_t na = 0, nb = 0;
           if (pn < pe)
-            { na = A.idx1[pn + (lane < pe-pn ? lane : pe-pn-1)];
-              nb = (MODE == MODE_SELF) ? na : idx2[pn + (lane < pe-pn ? lane : pe-pn-1)];
-            }
+            IDX_ISSUE(pn)
+          XPROF(7)
           if (n1 > 0 && n2 > 0)
             { if (q > 0)
                 walk_tile<MODE>(A,la,lb,raw,keyB,own16,lcpB,a,(int) n1,b,(int) n2,q,0,(int) n1,O);
@@ -1604,9 +1660,11 @@ void seed_merge_walk_kernel(merge_args A, walk_args W)
                     }
                 }
             }
+          if (!(q > 0 && n1 > 0 && n2 > 0))              // no tile, no wait of a tile: the index entries may be on their way
+            __builtin_amdgcn_s_waitcnt(0x0F70);
           a = a1; b = b1; p = pn;
-          ca = na; cb = nb;
         }
+#undef IDX_ISSUE
     }
 
   if (O.chunk_end > O.chunk_pos)                       // the unused tail of the last chunk stays open: its blocks say so
@@ -1617,6 +1675,10 @@ void seed_merge_walk_kernel(merge_args A, walk_args W)
       if (lane == 0)
         atomicAdd(A.hslots,(unsigned long long) (O.chunk_end - O.chunk_pos));
     }
+#ifdef MERGE_PROF
+  if (lane == 0)
+    for (int k = 0; k < 8; k++) atomicAdd(merge_prof+k,O.pa[k]);
+#endif
   unsigned long long tsum = O.tsum;
   #pragma unroll
   for (int d = 32; d >= 1; d >>= 1)
@@ -1777,7 +1839,7 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
       { const char *ev = getenv(use_wave ? "FGA_MERGE_WAVES" : "FGA_MERGE_WGS");
         if (ev != NULL && atoi(ev) > 0) wgs = atoi(ev);
       }
-      if (use_walk) wgs = 4*WAVE_OCC;
+      if (use_walk) wgs = 28;
       if (use_wave && wgs > 28) wgs = 28;                    // the slack of phys_capacity covers 32 waves per CU
       int grid = dev->ncu * wgs;
       if (use_wave && grid > A.ntiles/8 + 1) grid = A.ntiles/8 + 1;      // small inputs: few waves, few holes
@@ -1810,11 +1872,12 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
       if (use_walk)
         { // every wavefront of the launch is resident (they are persistent): as many as the LDS of a CU holds, at most
           // the register budget's 4 x WAVE_OCC
-          { const int lds = ((2*(XPC+1)*2 + XT*8 + XT*2 + XT + A.wrawcap + 64 + 511) / 512) * 512;
+          { const int lds = ((2*(XPC+1)*2 + (XT+4)*8 + XT*2 + XT + 16 + 1024 + A.wrawcap + 64 + 511) / 512) * 512;
             int per_cu = (160*1024) / lds;
+            const int fit = per_cu;
             if (per_cu > 4*WAVE_OCC) per_cu = 4*WAVE_OCC;
             const char *ev = getenv("FGA_MERGE_WAVES");
-            if (ev != NULL && atoi(ev) > 0 && atoi(ev) < per_cu) per_cu = atoi(ev);
+            if (ev != NULL && atoi(ev) > 0 && atoi(ev) <= fit) per_cu = atoi(ev);
             if (grid > dev->ncu*per_cu) grid = dev->ncu*per_cu;
           }
           // ranges of equal merge cost, a few per wavefront, taken off a queue; cuts / queue head live in the tile area
@@ -1983,10 +2046,10 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
   { unsigned long long hp[8], z[8] = {0,0,0,0,0,0,0,0};
     hipMemcpyFromSymbol(hp,HIP_SYMBOL(merge_prof),sizeof(hp));
     hipMemcpyToSymbol(HIP_SYMBOL(merge_prof),z,sizeof(z));
-    double tot = 0; for (int k = 0; k < 6; k++) tot += (double) hp[k];
+    double tot = 0; for (int k = 0; k < 8; k++) tot += (double) hp[k];
     if (tot > 0)
-      fprintf(stderr,"merge phases (%% of WG cycles): load %.1f  heads+keys %.1f  owner-scan %.1f  match %.1f  slots %.1f  emit %.1f\n",
-              100*hp[0]/tot,100*hp[1]/tot,100*hp[2]/tot,100*hp[3]/tot,100*hp[4]/tot,100*hp[5]/tot);
+      fprintf(stderr,"merge phases (%% of wave cycles): loop+idx wait %.1f  descriptor %.1f  issue %.1f  load wait %.1f  heads+keys %.1f  owner-scan %.1f  match %.1f  emit %.1f   (%.0f Mcycles)\n",
+              100*hp[6]/tot,100*hp[7]/tot,100*hp[0]/tot,100*hp[1]/tot,100*hp[2]/tot,100*hp[3]/tot,100*hp[4]/tot,100*hp[5]/tot,tot*1e-6);
   }
 #endif
   hipEventElapsedTime(&dev->last_ms[FGA_STAGE_MERGE_PARTITION],dev->ev0,dev->ev1);
