@@ -1128,6 +1128,9 @@ void seed_merge_wave_kernel(merge_args A, wave_out W)
 #define XPC    64                    // prefixes per tile at most (one index entry per lane)
 static_assert(XT == 256 || XT == 512,"descriptor packing: 9-bit tile indices, 4 or 8 entries per lane");
 
+#ifndef WALK_PCOST
+#define WALK_PCOST 1                 // cost units a prefix adds to a tile on top of its entries
+#endif
 #ifndef RANGES_PER_WAVE
 #define RANGES_PER_WAVE 4
 #endif
@@ -1442,43 +1445,70 @@ __device__ __forceinline__ void walk_tile(const merge_args &A, uint16_t *la, uin
           const uint32_t bhi = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (b >> 32));
           nbase = (int64_t) (((uint64_t) bhi << 32) | blo);
         }
-      const bool fast = (MODE != MODE_FLIP) && !A.soft_mask && T <= XT;
-      if (fast)
-        { // seed-parallel: every entry with seeds leaves its descriptor at its first slot; a wave max-scan over
-          // "slot+1 where a descriptor sits" tells every slot where its entry's run of slots begins
-          #pragma unroll
-          for (int x = 0; x < XT/128; x++)
-            ((uint2 *) own32)[x*64 + lane] = make_uint2(0,0);
+      // Seed-parallel, in windows of 2 XT slots (the key array's size in dwords): every entry with seeds in the window
+      // leaves a descriptor at its first slot there -- i | low << 9 | plen << 18 | (seeds of its run before the window) << 24
+      // -- and a wave max-scan over "slot+1 where a descriptor sits" tells every slot where its entry's run begins.
+      // The lane of a slot then finds its partner: the k-th T2 entry of the run, or, where mask bytes / strands / the
+      // entry itself drop members of the run, the k-th one that stays.
+      const bool plain = (MODE != MODE_FLIP) && !A.soft_mask;
+      for (int wb = 0; wb < T; wb += 2*XT)
+        { const int wn = T - wb < 2*XT ? T - wb : 2*XT;          // slots of this window
+          for (int x = lane; 4*x < wn; x += 64)
+            ((uint4 *) own32)[x] = make_uint4(0,0,0,0);
           WSYNC();
           { int o = off;
             #pragma unroll
             for (int r = 0; r < XEPT; r++)
               { const int cnt = (int) (res[r] >> 24);
-                if (cnt > 0)
-                  { own32[o] = (res[r] & 0xffffffu) | 0x80000000u;
-                    o += cnt;
+                if (cnt > 0 && o + cnt > wb && o < wb + 2*XT)
+                  { const int before = o < wb ? wb - o : 0;
+                    own32[o + before - wb] = (res[r] & 0xffffffu) | ((uint32_t) before << 24) | 0x80000000u;
                   }
+                o += cnt;
               }
           }
           WSYNC();
           int carry = 0;
-          for (int s0 = 0; s0 < T; s0 += 64)
-            { const int slot = s0 + lane;
-              int v = (slot < T && own32[slot] != 0) ? slot+1 : 0;
+          for (int s0 = 0; s0 < wn; s0 += 64)
+            { const int slot = s0 + lane;                       // within the window
+              int v = (slot < wn && own32[slot] != 0) ? slot+1 : 0;
               v = wave_incl_scan_max_dpp(v);
               v = v > carry ? v : carry;
               carry = __builtin_amdgcn_readlane(v,63);
-              if (slot < T)
+              if (slot < wn)
                 { const int start = v-1;
                   const uint32_t d = own32[start];
                   const int i = (int) (d & 0x1ff), plen = (int) ((d >> 18) & 0x3f);
-                  int j = (int) ((d >> 9) & 0x1ff) + (slot - start);
-                  if (MODE == MODE_SELF && j >= i)
-                    j += 1;
+                  int k = (slot - start) + (int) ((d >> 24) & 0x7f);
+                  int j = (int) ((d >> 9) & 0x1ff);
+                  if (plain)
+                    { j += k;
+                      if (MODE == MODE_SELF && j >= i)
+                        j += 1;
+                    }
+                  else
+                    { const int mlen = A.soft_mask ? plen : 41;
+                      for (;; j++)
+                        { const uint32_t mb = o2 + (uint32_t) j*E2 + 7;          // the entry's mask byte
+                          if ((int) ((rawd[mb >> 2] >> (8*(mb & 3))) & 0xff) >= mlen)
+                            continue;
+                          if (MODE == MODE_FLIP)
+                            { const uint32_t sb = o2 + (uint32_t) j*E2 + E2 - 1;
+                              if ((rawd[sb >> 2] >> (8*(sb & 3))) & 0x80)
+                                continue;
+                            }
+                          if (MODE == MODE_SELF && j == i)
+                            continue;
+                          if (k == 0)
+                            break;
+                          k -= 1;
+                        }
+                    }
                   uint32_t spos, sctg, ssign, cpos, cctg, csign;
                   lds_payload(rawd,o1 + (uint32_t) i*E1,A.post1,A.cont1,spos,sctg,ssign);
                   lds_payload(rawd,o2 + (uint32_t) j*E2,A.post2,A.cont2,cpos,cctg,csign);
-                  const int64_t at = ((int64_t) slot < rem) ? O.chunk_pos + slot : nbase + ((int64_t) slot - rem);
+                  const int64_t gs = (int64_t) wb + slot;
+                  const int64_t at = (gs < rem) ? O.chunk_pos + gs : nbase + (gs - rem);
 #if defined(XKNOCK) && XKNOCK == 5
                   if (at == -12345)
 #else
@@ -1487,34 +1517,7 @@ __device__ __forceinline__ void walk_tile(const merge_args &A, uint16_t *la, uin
                     A.out[at] = make_seed<MODE>(plen,spos,sctg,ssign,cpos,cctg,csign);
                 }
             }
-        }
-      else if (total > 0)
-        { const int mfull = A.soft_mask;
-          #pragma unroll
-          for (int r = 0; r < XEPT; r++)
-            { int left = (int) (res[r] >> 24);
-              if (left == 0)
-                continue;
-              const int i = (int) (res[r] & 0x1ff), plen = (int) ((res[r] >> 18) & 0x3f);
-              const int mlen = mfull ? plen : 41;
-              uint32_t spos, sctg, ssign;
-              lds_payload(rawd,o1 + (uint32_t) i*E1,A.post1,A.cont1,spos,sctg,ssign);
-              for (int j = (int) ((res[r] >> 9) & 0x1ff); left > 0; j++)
-                { if ((int) (keyB[j] & 0xff) >= mlen)
-                    continue;
-                  if (MODE == MODE_SELF && j == i)
-                    continue;
-                  uint32_t cpos, cctg, csign;
-                  lds_payload(rawd,o2 + (uint32_t) j*E2,A.post2,A.cont2,cpos,cctg,csign);
-                  if (MODE == MODE_FLIP && csign)
-                    continue;
-                  const int64_t at = ((int64_t) off < rem) ? O.chunk_pos + off : nbase + ((int64_t) off - rem);
-                  if (at < A.cap)
-                    A.out[at] = make_seed<MODE>(plen,spos,sctg,ssign,cpos,cctg,csign);
-                  off += 1;
-                  left -= 1;
-                }
-            }
+          WSYNC();
         }
       if ((int64_t) T > rem)
         { O.chunk_pos = nbase + ((int64_t) T - rem); O.chunk_end = nbase + nsize; }
@@ -1594,7 +1597,7 @@ void seed_merge_walk_kernel(merge_args A, walk_args W)
             cb = (MODE == MODE_SELF) ? ca : (int64_t) vb;
           }
           const int navail = pe - p < XPC ? pe - p : XPC;
-          const int64_t cost = (ca - a) + (cb - b) + 2*((int64_t) lane+1);
+          const int64_t cost = (ca - a) + (cb - b) + WALK_PCOST*((int64_t) lane+1);
           const bool fits = lane < navail && cost <= XT;
           const int q = __popcll(__builtin_amdgcn_ballot_w64(fits));     // cost grows with the lane: a prefix mask
           XPROF(6)
