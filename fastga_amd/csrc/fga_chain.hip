@@ -626,6 +626,19 @@ void chain_stitch_kernel(chain_args G, big_args B, int64_t nbig)
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
+struct relay_ctx { const fga_unit *hu; const fga_hit *hh; const int64_t *ord, *pos; fga_hits *R; };
+
+static void relay_slice(void *arg, int id, int64_t b, int64_t e)
+{ relay_ctx *C = (relay_ctx *) arg;
+  (void) id;
+  for (int64_t i = b; i < e; i++)
+    { fga_unit u = C->hu[C->ord[i]];
+      memcpy(C->R->hits + C->pos[i],C->hh + u.first_hit,sizeof(fga_hit)*(size_t) u.nhits);
+      u.first_hit = C->pos[i];
+      C->R->units[i] = u;
+    }
+}
+
 extern "C" int fga_chain_scan_device(fga_dev *dev, const fga_dkeys *K, const fga_chain_params *prm, fga_hits **out)
 { *out = NULL;
   FGA_HIP(hipSetDevice(dev->device));
@@ -739,6 +752,7 @@ extern "C" int fga_chain_scan_device(fga_dev *dev, const fga_dkeys *K, const fga
       hipEventElapsedTime(&dev->last_ms[FGA_STAGE_CHAIN],dev->ev0,dev->ev1);
       if ((int64_t) hc[0] <= hit_cap && (int64_t) hc[1] <= unit_cap && (int64_t) hc[5] <= stage_cap)
         { const int64_t nh = (int64_t) hc[0], nu = (int64_t) hc[1];
+          const double tq0 = fga_wall();
           hh = (fga_hit *)  malloc(sizeof(fga_hit)*(size_t) (nh+1));
           hu = (fga_unit *) malloc(sizeof(fga_unit)*(size_t) (nu+1));
           hd = (int64_t *)  malloc(sizeof(int64_t)*(size_t) (nu+1));
@@ -752,25 +766,40 @@ extern "C" int fga_chain_scan_device(fga_dev *dev, const fga_dkeys *K, const fga
             { fga_set_error("fga_chain_scan_device: download failed");
               goto fail;
             }
-          // canonical order: units by the index of their first record, hits re-laid in unit order
-          { std::vector<int64_t> ord;
-            fga_radix_order((const uint64_t *) hd,nu,ord);          // first-record indices are distinct and >= 0
+          const double tq1 = fga_wall();
+          double tq2 = 0.;
+          // canonical order: units by the index of their first record, hits re-laid in unit order (on the host team:
+          // 10^6 units in the repeat-heavy shapes)
+          { fga_team *team = fga_team_open(nu < 50000 ? 1 : (dev->host_threads > 0 ? dev->host_threads : 1));
+            int64_t *ord = (int64_t *) malloc(sizeof(int64_t)*(size_t) (nu+1));
+            int64_t *pos = (int64_t *) malloc(sizeof(int64_t)*(size_t) (nu+1));
             R = (fga_hits *) calloc(1,sizeof(fga_hits));
-            if (R == NULL) { fga_set_error("out of memory"); goto fail; }
-            R->nhits = nh; R->nunits = nu;
-            R->hits  = (fga_hit *)  malloc(sizeof(fga_hit)*(size_t) (nh+1));
-            R->units = (fga_unit *) malloc(sizeof(fga_unit)*(size_t) (nu+1));
-            if (R->hits == NULL || R->units == NULL)
-              { fga_hits_free(R); R = NULL; fga_set_error("out of memory"); goto fail; }
-            int64_t pos = 0;
-            for (int64_t i = 0; i < nu; i++)
-              { fga_unit u = hu[ord[(size_t) i]];
-                memcpy(R->hits + pos,hh + u.first_hit,sizeof(fga_hit)*(size_t) u.nhits);
-                u.first_hit = pos;
-                pos += u.nhits;
-                R->units[i] = u;
+            if (R != NULL)
+              { R->nhits = nh; R->nunits = nu;
+                R->hits  = (fga_hit *)  malloc(sizeof(fga_hit)*(size_t) (nh+1));
+                R->units = (fga_unit *) malloc(sizeof(fga_unit)*(size_t) (nu+1));
               }
+            int bits = 1;
+            while (bits < 63 && ((int64_t) 1 << bits) <= n) bits += 1;      // first-record indices are distinct, in [0,n)
+            for (int64_t i = 0; i < nu; i++) ord[i] = i;
+            if (team == NULL || ord == NULL || pos == NULL || R == NULL || R->hits == NULL || R->units == NULL ||
+                fga_team_sort_pairs(team,(uint64_t *) hd,ord,nu,bits))
+              { fga_team_close(team); free(ord); free(pos);
+                fga_hits_free(R); R = NULL; fga_set_error("out of memory"); goto fail;
+              }
+            tq2 = fga_wall();
+            int64_t at = 0;
+            for (int64_t i = 0; i < nu; i++)
+              { pos[i] = at; at += hu[ord[i]].nhits; }
+            relay_ctx RC;
+            RC.hu = hu; RC.hh = hh; RC.ord = ord; RC.pos = pos; RC.R = R;
+            fga_team_run(team,nu,relay_slice,&RC);
+            fga_team_close(team); free(ord); free(pos);
           }
+          if (getenv("FGA_HOST_TIMING") != NULL)
+            fprintf(stderr,"chain timing: kernels %.1f ms; host: download of %lld hits / %lld units %.1f ms, unit order %.1f ms, "
+                           "re-lay %.1f ms\n",dev->last_ms[FGA_STAGE_CHAIN],(long long) nh,(long long) nu,1e3*(tq1-tq0),
+                    1e3*(tq2-tq1),1e3*(fga_wall()-tq2));
           status = 0;
           break;
         }

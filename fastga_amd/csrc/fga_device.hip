@@ -104,6 +104,9 @@ void fga_dev_note_memory(fga_dev *dev)
     dev->hbm_low_water = fr;
 }
 
+extern "C" void fga_dev_set_host_threads(fga_dev *dev, int nthreads)
+{ dev->host_threads = nthreads > 0 ? nthreads : 1; }
+
 extern "C" int64_t fga_dev_peak_bytes(fga_dev *dev)
 { size_t fr = 0, tot = 0;
   if (hipSetDevice(dev->device) != hipSuccess || hipMemGetInfo(&fr,&tot) != hipSuccess)

@@ -37,6 +37,7 @@ struct fga_dev
     // per base): the next launch over similar inputs starts from there instead of finding out by a repeated launch
     double       ext_cells_per_base, ext_tbytes_per_base;
     size_t       hbm_low_water;   // smallest free device memory seen at the stage boundaries (fga_dev_note_memory)
+    int          host_threads;    // threads the host tails of the device stages may use (fga_dev_set_host_threads; 0 = 1)
   };
 void fga_dev_note_memory(fga_dev *dev);
 

@@ -123,10 +123,16 @@ struct la_one_args
 #undef EXT_KERNEL_ATTR
 #undef EXT_HANDOFF
 
-#define RC  256
-#define WDW 192
+#ifndef EXT_MID_RC
+#define EXT_MID_RC  256
+#define EXT_MID_WDW 192
+#define EXT_MID_OCC 3                  // wavefronts per SIMD the register budget is held to
+#define EXT_MID_WGS 12                 // resident wavefronts per CU (LDS)
+#endif
+#define RC  EXT_MID_RC
+#define WDW EXT_MID_WDW
 #define EXT_NS ext_mid
-#define EXT_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(3,3)))
+#define EXT_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(EXT_MID_OCC,EXT_MID_OCC)))
 #define EXT_HANDOFF 1
 #include "fga_extend_kernel.inc"
 #undef RC
@@ -226,6 +232,30 @@ extern "C" void fga_dgenome_free(fga_dgenome *D)
   free(D);
 }
 
+struct work_ctx { const fga_hits *H; uint64_t *w; int64_t *ord; int64_t smax; };
+
+static void work_slice(void *arg, int id, int64_t b, int64_t e)
+{ work_ctx *C = (work_ctx *) arg;
+  (void) id;
+  for (int64_t u = b; u < e; u++)
+    { int64_t s = 0;
+      for (int q = 0; q < C->H->units[u].nhits; q++)
+        { const fga_hit &h = C->H->hits[C->H->units[u].first_hit + q];
+          s += (h.ahgh - h.alow) + 1000;
+        }
+      if (s < 0) s = 0;
+      C->w[u] = (uint64_t) s;
+      C->ord[u] = u;
+    }
+}
+
+static void work_flip_slice(void *arg, int id, int64_t b, int64_t e)
+{ work_ctx *C = (work_ctx *) arg;
+  (void) id;
+  for (int64_t u = b; u < e; u++)
+    C->w[u] = (uint64_t) C->smax - C->w[u];
+}
+
 extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome *GB, const fga_hits *H,
                           const fga_extend_params *prm, fga_alns **out)
 { *out = NULL;
@@ -246,24 +276,34 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
       return 1;
     }
 
-  // units by decreasing estimated work (sum of hit box lengths): longest first
+  // units by decreasing estimated work (sum of hit box lengths): longest first (on the host team: 10^6 units in the
+  // repeat-heavy shapes)
   std::vector<int> order(H->nunits);
-  { std::vector<uint64_t> w((size_t) H->nunits);
+  { fga_team *team = fga_team_open(H->nunits < 50000 ? 1 : (dev->host_threads > 0 ? dev->host_threads : 1));
+    std::vector<uint64_t> w((size_t) H->nunits);
+    std::vector<int64_t> ord((size_t) H->nunits);
+    work_ctx WC;
+    WC.H = H; WC.w = w.data(); WC.ord = ord.data(); WC.smax = 0;
+    if (team == NULL)
+      { fga_set_error("out of memory");
+        free(R);
+        return 1;
+      }
+    fga_team_run(team,H->nunits,work_slice,&WC);
     int64_t smax = 0;
     for (int64_t u = 0; u < H->nunits; u++)
-      { int64_t s = 0;
-        for (int q = 0; q < H->units[u].nhits; q++)
-          { const fga_hit &h = H->hits[H->units[u].first_hit + q];
-            s += (h.ahgh - h.alow) + 1000;
-          }
-        if (s < 0) s = 0;
-        w[(size_t) u] = (uint64_t) s;
-        if (s > smax) smax = s;
+      if ((int64_t) w[(size_t) u] > smax) smax = (int64_t) w[(size_t) u];
+    WC.smax = smax;                                     // decreasing work, ties by unit index (the radix order is stable)
+    fga_team_run(team,H->nunits,work_flip_slice,&WC);
+    int bits = 1;
+    while (bits < 63 && ((int64_t) 1 << bits) <= smax) bits += 1;
+    const int bad = fga_team_sort_pairs(team,w.data(),ord.data(),H->nunits,bits);
+    fga_team_close(team);
+    if (bad)
+      { fga_set_error("out of memory");
+        free(R);
+        return 1;
       }
-    for (int64_t u = 0; u < H->nunits; u++)            // decreasing work, ties by unit index (the radix order is stable)
-      w[(size_t) u] = (uint64_t) smax - w[(size_t) u];
-    std::vector<int64_t> ord;
-    fga_radix_order(w.data(),H->nunits,ord);
     for (int64_t u = 0; u < H->nunits; u++) order[u] = (int) ord[(size_t) u];
   }
 
@@ -279,7 +319,7 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
     if (ev != NULL) narrow = atoi(ev) != 0;
     if (getenv("FGA_EXTEND_FORCE_LDS") != NULL) narrow = false;
   }
-  int nwg = dev->ncu * (narrow ? 12 : (many ? 6 : 4));
+  int nwg = dev->ncu * (narrow ? EXT_MID_WGS : (many ? 6 : 4));
   { const char *ev = getenv("FGA_EXTEND_WGS");
     if (ev != NULL && atoi(ev) > 0) nwg = atoi(ev);
   }
@@ -410,6 +450,15 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
                        "pool %.1f of %.1f MB\n",
                 hc[5]*1e-6,hc[6]*1e-6,hc[7]*1e-6,hc[10],hc[8]*1e-6,hc[9]*1e-6,dev->last_ms[FGA_STAGE_EXTEND],nwg,
                 (long long) H->nunits,hc[11],hc[16]*16e-6,pool_cells*16e-6);
+#ifdef EXT_STEP_PROF
+      { unsigned long long sp[8], z[8] = {0,0,0,0,0,0,0,0};
+        hipMemcpyFromSymbol(sp,HIP_SYMBOL(ext_full::ext_step_prof),sizeof(sp));
+        hipMemcpyToSymbol(HIP_SYMBOL(ext_full::ext_step_prof),z,sizeof(z));
+        double t = 0; for (int k = 0; k < 6; k++) t += (double) sp[k];
+        fprintf(stderr,"extend step sections (%% of step cycles, all wavefronts): top %.1f  neighbours+snake %.1f  trim+pebbles %.1f  best scan %.1f  clip+prune %.1f  loop %.1f   (%.0f cycles per step)\n",
+                100*sp[0]/t,100*sp[1]/t,100*sp[2]/t,100*sp[3]/t,100*sp[4]/t,100*sp[5]/t,t/(double) (hc[10] ? hc[10] : 1));
+      }
+#endif
 #ifdef EXT_WIDTH_HIST
       fprintf(stderr,"extend widths: calls by widest wave <=60 / <=120 / <=248 / wider: %llu %llu %llu %llu; wave steps in them: %llu %llu %llu %llu\n",
               hc[20],hc[21],hc[22],hc[23],hc[24],hc[25],hc[26],hc[27]);

@@ -104,15 +104,6 @@ static int by_abpos(const void *l, const void *r)
   return (a->ord < b->ord) ? -1 : (a->ord > b->ord);
 }
 
-static int by_final(const void *l, const void *r)
-{ const rec *a = *(rec * const *) l, *b = *(rec * const *) r;
-  if (a->aread != b->aread) return a->aread - b->aread;
-  if (a->abpos != b->abpos) return a->abpos - b->abpos;
-  if (a->bread != b->bread) return a->bread - b->bread;
-  if ((a->flags & 1) != (b->flags & 1)) return (int) (a->flags & 1) - (int) (b->flags & 1);
-  return (a->ord < b->ord) ? -1 : (a->ord > b->ord);
-}
-
 static int by_discovery(const void *l, const void *r)
 { const fga_aln *a = l, *b = r;
   if (a->unit != b->unit) return a->unit < b->unit ? -1 : 1;
@@ -209,40 +200,6 @@ static int filter_segment(rec **seg, int n)
 
 /* ---- helpers for large sets: the three orderings are O(n) / run on all threads ---- */
 
-/* stable LSD radix sort of (key, value) pairs on the low `bits` bits of the key, 11 bits per pass */
-static int sort_pairs(uint64_t *key, int64_t *val, int64_t n, int bits)
-{ uint64_t *k2 = malloc(sizeof(uint64_t)*(n > 0 ? n : 1));
-  int64_t  *v2 = malloc(sizeof(int64_t)*(n > 0 ? n : 1));
-  int64_t  *cnt = malloc(sizeof(int64_t)*2048);
-  uint64_t *ka = key, *kb = k2;
-  int64_t  *va = val, *vb = v2;
-  int shift;
-  if (k2 == NULL || v2 == NULL || cnt == NULL)
-    { free(k2); free(v2); free(cnt);
-      return 1;
-    }
-  for (shift = 0; shift < bits; shift += 11)
-    { int64_t i, sum = 0;
-      memset(cnt,0,sizeof(int64_t)*2048);
-      for (i = 0; i < n; i++)
-        cnt[(ka[i] >> shift) & 0x7ff] += 1;
-      if (n > 0 && cnt[(ka[0] >> shift) & 0x7ff] == n)
-        continue;                                   /* this digit is the same everywhere */
-      for (i = 0; i < 2048; i++)
-        { int64_t c = cnt[i]; cnt[i] = sum; sum += c; }
-      for (i = 0; i < n; i++)
-        { int64_t d = cnt[(ka[i] >> shift) & 0x7ff]++;
-          kb[d] = ka[i]; vb[d] = va[i];
-        }
-      { uint64_t *t = ka; ka = kb; kb = t; }
-      { int64_t *t = va; va = vb; vb = t; }
-    }
-  if (ka != key)
-    { memcpy(key,ka,sizeof(uint64_t)*n); memcpy(val,va,sizeof(int64_t)*n); }
-  free(k2); free(v2); free(cnt);
-  return 0;
-}
-
 typedef struct
   { rec    **perm;
     int64_t *segbeg;          /* nseg+1 */
@@ -300,32 +257,112 @@ static int run_segments(rec **perm, int64_t *segbeg, int64_t nseg, int nthreads)
 int fga_filter_alignments(const fga_alns *in, fga_alns **out)
 { return fga_filter_alignments_mt(in,1,out); }
 
+/* the O(n) passes of the driver, one slice per thread */
+typedef struct
+  { const fga_alns *in;
+    fga_aln   *sorted;
+    rec       *recs, **perm, **live;
+    uint64_t  *skey;
+    int64_t   *sval;
+    int        sb;                       /* bits of the seq field in the discovery key */
+    fga_alns  *R;
+    int64_t   *off;                      /* trace offset of every surviving record */
+    int        final_minor;              /* final order: keys of the minor part (bread, comp) / the major part */
+  } pass_ctx;
+
+static void pass_discovery_keys(void *arg, int id, int64_t b, int64_t e)
+{ pass_ctx *C = arg;
+  int64_t i;
+  (void) id;
+  for (i = b; i < e; i++)
+    { C->skey[i] = ((uint64_t) C->in->alns[i].unit << C->sb) | (uint64_t) C->in->alns[i].seq;
+      C->sval[i] = i;
+    }
+}
+
+static void pass_records(void *arg, int id, int64_t b, int64_t e)
+{ pass_ctx *C = arg;
+  int64_t i;
+  (void) id;
+  for (i = b; i < e; i++)
+    { rec *r = C->recs+i;
+      const fga_aln *a = C->sorted != NULL ? C->sorted+i : C->in->alns + C->sval[i];
+      r->tlen = a->tlen; r->diffs = a->diffs; r->abpos = a->abpos; r->bbpos = a->bbpos;
+      r->aepos = a->aepos; r->bepos = a->bepos; r->flags = a->flags; r->aread = a->aread; r->bread = a->bread;
+      r->trace = C->in->tbytes + a->toff; r->owns = 0; r->ord = i;
+      C->perm[i] = r;
+    }
+}
+
+static void pass_final_keys(void *arg, int id, int64_t b, int64_t e)
+{ pass_ctx *C = arg;
+  int64_t i;
+  (void) id;
+  for (i = b; i < e; i++)
+    { if (C->final_minor)
+        C->skey[i] = ((uint64_t) (uint32_t) C->live[i]->bread << 1) | (C->live[i]->flags & 1);
+      else
+        C->skey[i] = ((uint64_t) (uint32_t) C->live[i]->aread << 32) | (uint32_t) C->live[i]->abpos;
+      C->sval[i] = i;
+    }
+}
+
+static void pass_final_gather(void *arg, int id, int64_t b, int64_t e)
+{ pass_ctx *C = arg;
+  int64_t i;
+  (void) id;
+  for (i = b; i < e; i++)
+    C->perm[i] = C->live[C->sval[i]];
+}
+
+static void pass_copy_out(void *arg, int id, int64_t b, int64_t e)
+{ pass_ctx *C = arg;
+  int64_t i;
+  (void) id;
+  for (i = b; i < e; i++)
+    { rec *r = C->live[i];
+      fga_aln *a = C->R->alns+i;
+      memset(a,0,sizeof(*a));
+      a->tlen = r->tlen; a->diffs = r->diffs; a->abpos = r->abpos; a->bbpos = r->bbpos;
+      a->aepos = r->aepos; a->bepos = r->bepos; a->flags = r->flags & 0x3; a->aread = r->aread; a->bread = r->bread;
+      a->unit = -1; a->seq = (int32_t) i; a->toff = C->off[i];
+      memcpy(C->R->tbytes + C->off[i],r->trace,r->tlen);
+    }
+}
+
 int fga_filter_alignments_mt(const fga_alns *in, int nthreads, fga_alns **out)
 { fga_alns *R;
   fga_aln  *sorted = NULL;
   rec      *recs = NULL, **perm = NULL, **live = NULL;
   uint64_t *skey = NULL;
   int64_t  *sval = NULL, *segbeg = NULL;
-  int64_t   n = in->naln, i, j, nlive = 0, tbytes = 0, off, nseg = 0;
+  int64_t   n = in->naln, i, j, nlive = 0, tbytes = 0, nseg = 0;
+  fga_team *team = NULL;
+  pass_ctx  C;
 
+  const int timing = getenv("FGA_FILTER_TIMING") != NULL;
+  double tw[6] = {0,0,0,0,0,0};
   *out = NULL;
   R = calloc(1,sizeof(fga_alns));
   if (R == NULL) goto oom;
   R->ncalls = in->ncalls; R->nwaves = in->nwaves;
+  tw[0] = fga_wall();
   if (n == 0)
     { R->alns = malloc(sizeof(fga_aln)); R->tbytes = malloc(16);
       *out = R;
       return 0;
     }
-  sorted = malloc(sizeof(fga_aln)*n);
+  team   = fga_team_open(n < 50000 ? 1 : nthreads);         /* starting threads costs ~1 ms */
   recs   = malloc(sizeof(rec)*n);
   perm   = malloc(sizeof(rec *)*n);
   live   = malloc(sizeof(rec *)*n);
   skey   = malloc(sizeof(uint64_t)*n);
-  sval   = malloc(sizeof(int64_t)*n);
+  sval   = malloc(sizeof(int64_t)*(n+1));
   segbeg = malloc(sizeof(int64_t)*(n+1));
-  if (sorted == NULL || recs == NULL || perm == NULL || live == NULL || skey == NULL || sval == NULL || segbeg == NULL)
+  if (team == NULL || recs == NULL || perm == NULL || live == NULL || skey == NULL || sval == NULL || segbeg == NULL)
     goto oom;
+  memset(&C,0,sizeof(C));
+  C.in = in; C.recs = recs; C.perm = perm; C.live = live; C.skey = skey; C.sval = sval; C.R = R;
 
   /* discovery order = (unit, seq): radix sort when the two fit a 64-bit key, else the comparison sort */
   { int64_t maxu = 0, maxs = 0;
@@ -337,28 +374,21 @@ int fga_filter_alignments_mt(const fga_alns *in, int nthreads, fga_alns **out)
       }
     while (((int64_t) 1 << ub) <= maxu) ub += 1;
     while (((int64_t) 1 << sb) <= maxs) sb += 1;
-    if (ok)
-      { for (i = 0; i < n; i++)
-          { skey[i] = ((uint64_t) in->alns[i].unit << sb) | (uint64_t) in->alns[i].seq;
-            sval[i] = i;
-          }
-        if (sort_pairs(skey,sval,n,ub+sb)) goto oom;
-        for (i = 0; i < n; i++)
-          sorted[i] = in->alns[sval[i]];
+    if (ok && ub + sb <= 64)
+      { C.sb = sb;
+        fga_team_run(team,n,pass_discovery_keys,&C);
+        if (fga_team_sort_pairs(team,skey,sval,n,ub+sb)) goto oom;
       }
     else
-      { memcpy(sorted,in->alns,sizeof(fga_aln)*n);
+      { sorted = malloc(sizeof(fga_aln)*n);
+        if (sorted == NULL) goto oom;
+        memcpy(sorted,in->alns,sizeof(fga_aln)*n);
         qsort(sorted,n,sizeof(fga_aln),by_discovery);
+        C.sorted = sorted;
       }
   }
-  for (i = 0; i < n; i++)
-    { rec *r = recs+i;
-      const fga_aln *a = sorted+i;
-      r->tlen = a->tlen; r->diffs = a->diffs; r->abpos = a->abpos; r->bbpos = a->bbpos;
-      r->aepos = a->aepos; r->bepos = a->bepos; r->flags = a->flags; r->aread = a->aread; r->bread = a->bread;
-      r->trace = in->tbytes + a->toff; r->owns = 0; r->ord = i;
-      perm[i] = r;
-    }
+  tw[1] = fga_wall();
+  fga_team_run(team,n,pass_records,&C);
   /* segments = runs of equal (aread, bread, comp) in discovery order (units are key-ordered); independent of each other */
   for (i = 0; i < n; i = j)
     { for (j = i+1; j < n; j++)
@@ -368,55 +398,65 @@ int fga_filter_alignments_mt(const fga_alns *in, int nthreads, fga_alns **out)
       segbeg[nseg++] = i;
     }
   segbeg[nseg] = n;
-  if (run_segments(perm,segbeg,nseg,nthreads)) goto oom;
+  tw[2] = fga_wall();
+  if (run_segments(perm,segbeg,nseg,fga_team_size(team) > 1 ? nthreads : 1)) goto oom;
+  tw[3] = fga_wall();
   for (i = 0; i < n; i++)
     if (!(perm[i]->flags & ELIMINATED))
       { perm[i]->ord = nlive;                 /* order of survival = the reference's file order */
         live[nlive++] = perm[i];
-        tbytes += perm[i]->tlen;
       }
 
-  /* final order (aread, abpos, bread, comp, survival): radix sort on (aread, abpos), then the few runs that tie on
-   * both are put in order by the rest of the key */
+  /* final order (aread, abpos, bread, comp, survival): two stable radix sorts, least significant part first -- (bread,
+   * comp) over the records in survival order, then (aread, abpos).  Repeats give many records the same (aread, abpos),
+   * so no comparison sort of tie runs */
   if (nlive > 1)
-    { for (i = 0; i < nlive; i++)
-        { skey[i] = ((uint64_t) (uint32_t) live[i]->aread << 32) | (uint32_t) live[i]->abpos; sval[i] = i; }
-      if (sort_pairs(skey,sval,nlive,64)) goto oom;
+    { int32_t maxa = 0, maxb = 0;
+      int ab = 1, bb = 1;
       for (i = 0; i < nlive; i++)
-        perm[i] = live[sval[i]];
-      for (i = 0; i < nlive; i = j)
-        { for (j = i+1; j < nlive && skey[j] == skey[i]; j++)
-            ;
-          if (j-i > 1)
-            qsort(perm+i,j-i,sizeof(rec *),by_final);
+        { if (live[i]->aread > maxa) maxa = live[i]->aread;
+          if (live[i]->bread > maxb) maxb = live[i]->bread;
         }
+      while (ab < 32 && ((int64_t) 1 << ab) <= maxa) ab += 1;
+      while (bb < 32 && ((int64_t) 1 << bb) <= maxb) bb += 1;
+      C.final_minor = 1;
+      fga_team_run(team,nlive,pass_final_keys,&C);
+      if (fga_team_sort_pairs(team,skey,sval,nlive,bb+1)) goto oom;
+      fga_team_run(team,nlive,pass_final_gather,&C);            /* perm = live in (bread, comp, survival) order */
+      memcpy(live,perm,sizeof(rec *)*nlive);
+      C.final_minor = 0;
+      fga_team_run(team,nlive,pass_final_keys,&C);
+      if (fga_team_sort_pairs(team,skey,sval,nlive,32+ab)) goto oom;
+      fga_team_run(team,nlive,pass_final_gather,&C);
       memcpy(live,perm,sizeof(rec *)*nlive);
     }
 
+  tw[4] = fga_wall();
+  for (i = 0; i < nlive; i++)                 /* sval is free again: the trace offsets */
+    { sval[i] = tbytes;
+      tbytes += live[i]->tlen;
+    }
   R->naln = nlive; R->ntrace = tbytes;
   R->alns = malloc(sizeof(fga_aln)*(nlive+1));
   R->tbytes = malloc(tbytes+16);
   if (R->alns == NULL || R->tbytes == NULL) goto oom;
-  off = 0;
-  for (i = 0; i < nlive; i++)
-    { rec *r = live[i];
-      fga_aln *a = R->alns+i;
-      memset(a,0,sizeof(*a));
-      a->tlen = r->tlen; a->diffs = r->diffs; a->abpos = r->abpos; a->bbpos = r->bbpos;
-      a->aepos = r->aepos; a->bepos = r->bepos; a->flags = r->flags & 0x3; a->aread = r->aread; a->bread = r->bread;
-      a->unit = -1; a->seq = (int32_t) i; a->toff = off;
-      memcpy(R->tbytes+off,r->trace,r->tlen);
-      off += r->tlen;
-    }
+  C.off = sval;
+  fga_team_run(team,nlive,pass_copy_out,&C);
   for (i = 0; i < n; i++)
     if (recs[i].owns) free(recs[i].trace);
   free(sorted); free(recs); free(perm); free(live); free(skey); free(sval); free(segbeg);
+  if (timing)
+    fprintf(stderr,"filter timing: %lld records, %lld segments: discovery order %.1f ms, records %.1f ms, segments %.1f ms (%d threads), "
+                   "final order %.1f ms, copy out %.1f ms\n",(long long) n,(long long) nseg,1e3*(tw[1]-tw[0]),1e3*(tw[2]-tw[1]),
+            1e3*(tw[3]-tw[2]),fga_team_size(team),1e3*(tw[4]-tw[3]),1e3*(fga_wall()-tw[4]));
+  fga_team_close(team);
   *out = R;
   return 0;
 
 oom:
   fga_set_error("out of memory in alignment filter");
   free(sorted); free(recs); free(perm); free(live); free(skey); free(sval); free(segbeg);
+  fga_team_close(team);
   if (R != NULL) { free(R->alns); free(R->tbytes); free(R); }
   return 1;
 }

@@ -108,6 +108,15 @@ char *fga_path_dir(const char *path);                       /* malloc'd director
 char *fga_path_root(const char *path, const char *suffix);  /* malloc'd basename without suffix      */
 double fga_wall(void);
 
+/* a team of threads for the O(n) passes of one host stage (fga_par.c) */
+typedef struct fga_team fga_team;
+typedef void (*fga_slice_fn)(void *arg, int slice, int64_t begin, int64_t end);
+fga_team *fga_team_open(int nthreads);
+int       fga_team_size(const fga_team *T);
+void      fga_team_run(fga_team *T, int64_t n, fga_slice_fn fn, void *arg);    /* [0,n) in one contiguous slice per thread */
+int       fga_team_sort_pairs(fga_team *T, uint64_t *key, int64_t *val, int64_t n, int bits);   /* stable LSD radix sort */
+void      fga_team_close(fga_team *T);
+
 #ifdef __cplusplus
 }
 #endif

@@ -178,6 +178,7 @@ int fga_session_align(fga_session *Z, const fga_run_params *P, fga_dseeds *seeds
 
   *raw = NULL;
   memset(&st,0,sizeof(st));
+  fga_dev_set_host_threads(dev,P->nthreads);
   t0 = fga_wall();
   { fga_sort_params sp;
     sp.amxpos = g1->maxctg; sp.bmxpos = self ? g1->maxctg : g2->maxctg;

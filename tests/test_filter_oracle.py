@@ -76,3 +76,37 @@ def test_filter_equals_oracle_restatement(built_library):
         boxes = {(int(r["abpos"]), int(r["aepos"])) for r in recs}
         fused += sum(1 for g in got if (int(g["abpos"]), int(g["aepos"])) not in boxes)
     assert dropped > 1000 and fused > 100          # the stress really exercises elimination and fusing
+
+
+def test_filter_is_the_same_for_any_number_of_threads(built_library):
+    """above 50,000 records the driver's passes (discovery order, record build, final order, copy out) run on a team
+    of threads: the result must not depend on the team's size"""
+    from fastga_amd.lib import Alns
+    from fastga_amd.device import ALN_DTYPE
+    L = built_library
+    rng = np.random.default_rng(7)
+    parts, tbs, off, unit = [], [], 0, 0
+    while sum(len(p) for p in parts) < 60000:
+        recs, tb = _random_group(rng)
+        recs["aread"] = unit % 37
+        recs["bread"] = (unit // 37) % 5
+        recs["unit"] = unit
+        recs["seq"] = np.arange(len(recs))
+        recs["toff"] += off
+        parts.append(recs); tbs.append(tb); off += len(tb); unit += 1
+    recs = np.concatenate(parts)
+    tb = np.concatenate(tbs)
+    perm = rng.permutation(len(recs))              # the extension kernel delivers records in any order
+    recs = np.ascontiguousarray(recs[perm])
+    res = []
+    for nt in (1, 3, 16):
+        A = Alns(len(recs), len(tb), 0, 0, recs.ctypes.data, tb.ctypes.data)
+        out = C.POINTER(Alns)()
+        assert L.fga_filter_alignments_mt(C.byref(A), nt, C.byref(out)) == 0
+        o = out.contents
+        got = np.frombuffer((C.c_char * (o.naln * ALN_DTYPE.itemsize)).from_address(o.alns), dtype=ALN_DTYPE).copy()
+        gt = np.frombuffer((C.c_char * max(o.ntrace, 1)).from_address(o.tbytes), dtype=np.uint8)[:o.ntrace].copy()
+        L.fga_alns_free(out)
+        res.append((got.tobytes(), gt.tobytes()))
+    assert 0 < len(res[0][0]) < recs.nbytes
+    assert res[0] == res[1] == res[2]
