@@ -108,38 +108,50 @@ struct la_one_args
 // The device code is compiled twice (fga_extend_kernel.inc):
 //   ext_full  512-diagonal ring, 8192-base windows: 27 KB of LDS per wavefront, six wavefronts per CU.  The latency regime
 //             (few long units: the run time is the longest unit's serial chain) and the refuge of units handed over by
-//   ext_mid   256-diagonal ring, 3072-base windows, the register budget of three wavefronts per SIMD: 13.3 KB of LDS,
-//             twelve resident wavefronts per CU -- the throughput regime (10^5 .. 10^6 short units; no wave of the
-//             150-Mbp repeat-heavy self comparison, the 2 % or the 10 % pair is wider than 248 diagonals).
+//   ext_mid   256-diagonal ring in ONE copy that a wave step updates in place, 3072-base windows, the register budget of
+//             four wavefronts per SIMD: 8.2 KB of LDS, sixteen resident wavefronts per CU -- the throughput regime
+//             (10^5 .. 10^6 short units; no wave of the 150-Mbp repeat-heavy self comparison, the 2 % or the 10 % pair
+//             is wider than 248 diagonals).
 #define RC  512
 #define WDW 512
 #define EXT_NS ext_full
 #define EXT_KERNEL_ATTR
 #define EXT_HANDOFF 0
+#define RING_INPLACE 0
 #include "fga_extend_kernel.inc"
 #undef RC
 #undef WDW
 #undef EXT_NS
 #undef EXT_KERNEL_ATTR
 #undef EXT_HANDOFF
+#undef RING_INPLACE
+#undef RING_NB
+#undef RB
 
 #ifndef EXT_MID_RC
 #define EXT_MID_RC  256
 #define EXT_MID_WDW 192
-#define EXT_MID_OCC 3                  // wavefronts per SIMD the register budget is held to
-#define EXT_MID_WGS 12                 // resident wavefronts per CU (LDS)
+#define EXT_MID_OCC 4                  // wavefronts per SIMD the register budget is held to (128 VGPRs: ~40 spilled)
+#define EXT_MID_WGS 16                 // resident wavefronts per CU (8.2 KB of LDS each)
+#endif
+#ifndef EXT_MID_INPLACE
+#define EXT_MID_INPLACE 1              // one copy of the ring, updated in place (fga_extend_kernel.inc)
 #endif
 #define RC  EXT_MID_RC
 #define WDW EXT_MID_WDW
 #define EXT_NS ext_mid
 #define EXT_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(EXT_MID_OCC,EXT_MID_OCC)))
 #define EXT_HANDOFF 1
+#define RING_INPLACE EXT_MID_INPLACE
 #include "fga_extend_kernel.inc"
 #undef RC
 #undef WDW
 #undef EXT_NS
 #undef EXT_KERNEL_ATTR
 #undef EXT_HANDOFF
+#undef RING_INPLACE
+#undef RING_NB
+#undef RB
 
 // ---------------------------------------------------------------------------------------------------
 // reverse-complement image of a packed genome (Complement_Seq of every contig, align.c:4082-4097)
