@@ -147,6 +147,14 @@ def write_fasta(path, contigs, prefix="ctg", masks=None, width=80):
                 f.write(txt[full:].tobytes() + b"\n")
 
 
+def contig_lengths_loguniform(seed, ncontig, total, lo=0.2e6, hi=12e6):
+    """ncontig distinct lengths, log-uniform between lo and hi, scaled to sum to ~total."""
+    rng = np.random.default_rng(seed + 104729)
+    w = np.exp(rng.uniform(np.log(lo), np.log(hi), ncontig))
+    lens = np.maximum(1000, (w / w.sum() * total).astype(np.int64))
+    return lens + np.arange(ncontig)     # break ties
+
+
 def contig_lengths(seed, ncontig, total, spread=0.3):
     """ncontig distinct lengths summing to ~total (distinct so the length sort has no ties)."""
     rng = np.random.default_rng(seed + 7919)

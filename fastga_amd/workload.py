@@ -32,6 +32,17 @@ def build_pair(workdir, seed, ncontig, total, divergence, repeat_frac=0.0, inv_f
 
 # ---- BASELINE.json configs as concrete inputs -------------------------------------------------------
 
+def build_config1_s1(workdir, mbp=86.0, seed=20260926, threads=8, gix=False):
+    """configs[0]'s substitute S1 (the EXAMPLE blobs are not in the image): 86 Mbp vs 86 Mbp, 40 contigs with log-uniform
+    lengths (0.2 .. 12 Mbp before scaling), 4.5 % divergence, 15 % of the bases in repeat copies, 5 % of 40-kbp blocks
+    inverted and 5 % swapped"""
+    lens = synth.contig_lengths_loguniform(seed, 40, int(mbp * 1e6))
+    A, mA, B, mB = synth.make_pair(seed, lens, 0.045, 0.15, 0.05, 0.05)
+    ra = build_genome(workdir, "A", A, None, threads, gix=gix)
+    rb = build_genome(workdir, "B", B, None, threads, gix=gix)
+    return ra, rb
+
+
 def build_config2(workdir, mbp=100.0, seed=1, divergence=0.02, ncontig=40, threads=8, gix=False):
     """configs[1]: synthetic pair, 2 % divergence, 40 contigs, 5 % repeats, 2 % of 40-kbp blocks inverted / swapped"""
     return build_pair(workdir, seed=seed, ncontig=ncontig, total=int(mbp * 1e6), divergence=divergence,

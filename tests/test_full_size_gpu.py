@@ -64,6 +64,18 @@ def test_config2_100mbp_pair_is_identical_to_the_reference(tmp_path_factory, bui
     assert dg["records"] > 1500 and st["nwaves"] > 5_000_000        # contig-long alignments were really extended
 
 
+def test_config1_substitute_s1_86mbp_is_identical_to_the_reference(tmp_path_factory, built_library):
+    """configs[0]'s stand-in S1: 86 Mbp pair, log-uniform contig lengths, 4.5 % divergence, 15 % repeats,
+    5 % inversions / swaps -- the reference run with -T8 like the configuration asks"""
+    from fastga_amd import workload
+    d = str(tmp_path_factory.mktemp("s1"))
+    ra, rb = workload.build_config1_s1(d, threads=T, gix=False)
+    _write_index_files((ra, rb), nthreads=8)
+    st, dg = _compare_with_reference(ra, rb, d, strict=False, ref_threads=8)
+    assert dg["records"] > 5000 and st["nhits"] > 5000
+
+
+
 def test_divergent_50mbp_pair_is_identical_to_the_reference(tmp_path_factory, built_library):
     """the 10 % shape of configs[4] on one GPU: deep waves, WAVE_LAG pruning, wide waves in the LDS ring"""
     from fastga_amd import workload
