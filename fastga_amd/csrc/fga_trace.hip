@@ -137,8 +137,109 @@ __device__ __forceinline__ uint32_t window16(const uint32_t *img, int64_t idx)
 #define CELL_MOVE(c)   ((int) ((c) >> 12) - 1)
 #define MAKE_CELL(j,e) ((uint16_t) (((j)+2) | (((e)+1) << 12)))
 
+// The forward sweep of one panel.  Every cell goes to the panel's scratch in HBM (the walk back needs the cells of
+// its path); with LIVE the three rows the sweep READS (d, d-1, d-2) also live in LDS -- lane-interleaved, cell (row, kk)
+// of lane l at [(row*TRACE_WL + kk)*64 + l], which is conflict-free whatever kk the lanes are at -- so the sweep issues
+// one 2-byte store per cell to HBM and no load.  Panels wider than TRACE_WL cells sweep on the scratch alone.
+// Returns the cost row the target was reached in, or -1 (the trace is inconsistent).
+#define TRACE_WL 24
+
+template <bool LIVE>
+__device__ __forceinline__ int panel_sweep(const trace_args &T, uint16_t *C, uint16_t *L, const uint32_t *imgB,
+                                           int64_t abase, int64_t bbase, int M, int N, int dmax, int kmin, int W,
+                                           int posl, int posh)
+{ const int del = M-N;
+  int r0 = 2*TRACE_WL, r1 = TRACE_WL, r2 = 0;          // LDS rows of d, d-1, d-2 (rotated every row)
+#define AT(d,k)      C[((d)+2)*W + ((k)-kmin)]
+#define LV(r,k)      L[((r) + ((k)-kmin))*64]
+#define RD0(d,k)     (LIVE ? LV(r0,k) : AT(d,k))
+#define RD1(d,k)     (LIVE ? LV(r1,k) : AT((d)-1,k))
+#define RD2(d,k)     (LIVE ? LV(r2,k) : AT((d)-2,k))
+#define WR0(d,k,v)   { const uint16_t v_ = (v); AT(d,k) = v_; if (LIVE) LV(r0,k) = v_; }
+
+  int low = del < 0 ? del : 0, hgh = del < 0 ? 0 : del;
+  for (int k = low-1; k <= hgh+1; k++)                 // rows -2 and -1
+    { const uint16_t c1 = (k == 0) ? MAKE_CELL(-1,0) : MAKE_CELL(-2,0);
+      AT(-2,k) = MAKE_CELL(-2,0); AT(-1,k) = c1;
+      if (LIVE) { LV(r2,k) = MAKE_CELL(-2,0); LV(r1,k) = c1; }
+    }
+  low += 1;
+  hgh -= 1;
+
+  int d;
+  for (d = 0; ; d++)
+    { if (d > dmax)
+        return -1;
+      if ((d & 1) == 0)
+        { if (low > posl) low -= 1;
+          if (hgh < posh) hgh += 1;
+        }
+      WR0(d,hgh+1,MAKE_CELL(-2,0))
+      WR0(d,low-1,MAKE_CELL(-2,0))
+
+      int j, e;
+#define CHOOSE(k,am,ap,mcode,pcode)                             \
+      { const int ac = CELL_REACH(RD1(d,k)) + 1;                \
+        if (ac < (am))                                          \
+          { if ((ap) < (am)) { e = (mcode); j = (am); }         \
+            else             { e = (pcode); j = (ap); }         \
+          }                                                     \
+        else                                                    \
+          { if ((ap) < ac)   { e = 0;       j = ac;   }         \
+            else             { e = (pcode); j = (ap); }         \
+          }                                                     \
+      }
+#define SLIDE(k)                                                \
+      { const int lim = N < M-(k) ? N : M-(k);                  \
+        if (j >= 0 && j < lim)                                  \
+          { do                                                  \
+              { const uint32_t x = window16(T.imgA,abase+(k)+j) ^ window16(imgB,bbase+j);  \
+                if (x != 0)                                     \
+                  { j += __builtin_ctz(x) >> 1;                 \
+                    break;                                      \
+                  }                                             \
+                j += 16;                                        \
+              }                                                 \
+            while (j < lim);                                    \
+            if (j > lim) j = lim;                               \
+          }                                                     \
+        WR0(d,k,MAKE_CELL(j,e))                                 \
+      }
+
+      j = -2;
+      for (int k = hgh; k > del; k--)
+        { const int ap = j+1, am = CELL_REACH(RD2(d,k-1));
+          CHOOSE(k,am,ap,-1,4)
+          SLIDE(k)
+        }
+      j = -2;
+      for (int k = low; k < del; k++)
+        { const int ap = CELL_REACH(RD2(d,k+1)) + 1, am = j;
+          CHOOSE(k,am,ap,2,1)
+          SLIDE(k)
+        }
+      { const int ap = CELL_REACH(RD0(d,del+1)) + 1, am = j;
+        CHOOSE(del,am,ap,2,4)
+        SLIDE(del)
+      }
+      if (j >= N)
+        break;
+      { const int t = r2; r2 = r1; r1 = r0; r0 = t; }
+    }
+  return d;
+#undef CHOOSE
+#undef SLIDE
+#undef AT
+#undef LV
+#undef RD0
+#undef RD1
+#undef RD2
+#undef WR0
+}
+
 __global__ void __launch_bounds__(64) trace_panel_kernel(trace_args T)
-{ const int64_t q = (int64_t) blockIdx.x*blockDim.x + threadIdx.x;
+{ __shared__ uint16_t live[3*TRACE_WL*64];
+  const int64_t q = (int64_t) blockIdx.x*blockDim.x + threadIdx.x;
   if (q >= T.np) return;
   const trace_panel P = T.panels[q];
   const int64_t gq = T.p0 + q;
@@ -164,73 +265,11 @@ __global__ void __launch_bounds__(64) trace_panel_kernel(trace_args T)
       if (a.abpos-a.bbpos < 0) posh = -1-db; else posl = 1-db;
     }
 
-  int low = del < 0 ? del : 0, hgh = del < 0 ? 0 : del;
-  for (int k = low-1; k <= hgh+1; k++)
-    { AT(-2,k) = MAKE_CELL(-2,0); AT(-1,k) = MAKE_CELL(-2,0); }
-  AT(-1,0) = MAKE_CELL(-1,0);
-  low += 1;
-  hgh -= 1;
-
-  int d;
-  for (d = 0; ; d++)
-    { if (d > dmax)
-        { T.pcnt[gq] = 0; T.pdiff[gq] = -1;
-          return;
-        }
-      if ((d & 1) == 0)
-        { if (low > posl) low -= 1;
-          if (hgh < posh) hgh += 1;
-        }
-      AT(d,hgh+1) = MAKE_CELL(-2,0);
-      AT(d,low-1) = MAKE_CELL(-2,0);
-
-      int j, e;
-#define CHOOSE(k,am,ap,mcode,pcode)                             \
-      { const int ac = CELL_REACH(AT(d-1,k)) + 1;               \
-        if (ac < (am))                                          \
-          { if ((ap) < (am)) { e = (mcode); j = (am); }         \
-            else             { e = (pcode); j = (ap); }         \
-          }                                                     \
-        else                                                    \
-          { if ((ap) < ac)   { e = 0;       j = ac;   }         \
-            else             { e = (pcode); j = (ap); }         \
-          }                                                     \
-      }
-#define SLIDE(k)                                                \
-      { const int lim = N < M-(k) ? N : M-(k);                  \
-        if (j >= 0 && j < lim)                                  \
-          { do                                                  \
-              { const uint32_t x = window16(T.imgA,abase+(k)+j) ^ window16(imgB,bbase+j);  \
-                if (x != 0)                                     \
-                  { j += __builtin_ctz(x) >> 1;                 \
-                    break;                                      \
-                  }                                             \
-                j += 16;                                        \
-              }                                                 \
-            while (j < lim);                                    \
-            if (j > lim) j = lim;                               \
-          }                                                     \
-        AT(d,k) = MAKE_CELL(j,e);                               \
-      }
-
-      j = -2;
-      for (int k = hgh; k > del; k--)
-        { const int ap = j+1, am = CELL_REACH(AT(d-2,k-1));
-          CHOOSE(k,am,ap,-1,4)
-          SLIDE(k)
-        }
-      j = -2;
-      for (int k = low; k < del; k++)
-        { const int ap = CELL_REACH(AT(d-2,k+1)) + 1, am = j;
-          CHOOSE(k,am,ap,2,1)
-          SLIDE(k)
-        }
-      { const int ap = CELL_REACH(AT(d,del+1)) + 1, am = j;
-        CHOOSE(del,am,ap,2,4)
-        SLIDE(del)
-      }
-      if (j >= N)
-        break;
+  int d = (W <= TRACE_WL) ? panel_sweep<true>(T,C,live + threadIdx.x,imgB,abase,bbase,M,N,dmax,kmin,W,posl,posh)
+                          : panel_sweep<false>(T,C,live,imgB,abase,bbase,M,N,dmax,kmin,W,posl,posh);
+  if (d < 0)
+    { T.pcnt[gq] = 0; T.pdiff[gq] = -1;
+      return;
     }
 
   // reverse the move list from (d,del) back to (0,0), then walk it forwards emitting the indels
