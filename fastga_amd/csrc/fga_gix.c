@@ -65,6 +65,140 @@ static int read_full(int fd, void *buf, int64_t n)
   return 0;
 }
 
+/* The pre-v1.3 index layout (what the reference still reads through Open_Post_List / old_merge_thread, FastGA.c:206-570,
+ * 1027-1540, and what its EXAMPLE/sample_session shows): the .ktab.N parts hold every DISTINCT k-mer once -- the same
+ * 9 leading bytes as today's entries, [0..6] bases 13..40, [7] the number of positions of the k-mer (today: the soft-mask
+ * length), [8] lcp with the k-mer before -- and the positions sit, in table order, in .post.N parts (header: post
+ * bytes, contig bytes, count).  The stub's 2^24 index counts table entries and is followed by a 2^16 index of
+ * positions.  It is turned into today's in-memory table here: a k-mer with c positions becomes c entries, the first
+ * with the stored lcp, the others with lcp 40, mask byte 0 (there was no soft masking), and the prefix index is
+ * recounted -- the adaptive merge over the expanded table is the old merge over the counted one (same k-mer sets, same
+ * run sizes in positions, same pairs).  X->freq keeps the cutoff the index was built with (k-mers above it are not
+ * in an old table; the reference refuses -f above it, FastGA.c:4959-4974). */
+static int open_legacy(fga_gix *X, const char *dir, const char *root, int npost)
+{ const int pb = X->postbytes + X->contbytes;
+  const int64_t nk = X->index[FGA_NPREFIX-1];
+  uint8_t *old = NULL, *posts = NULL;
+  int64_t *kpart = NULL;               /* first table entry of every .ktab part */
+  char *name = NULL;
+  int64_t off, np = 0, npos, e, o, pre, maxpre = 0;
+  int f = -1, p;
+
+  old = malloc((size_t) (nk > 0 ? nk : 1)*9);
+  kpart = malloc(sizeof(int64_t)*(X->nparts+1));
+  if (old == NULL || kpart == NULL) goto oom;
+  off = 0;
+  for (p = 1; p <= X->nparts; p++)
+    { int32_t k;
+      int64_t n;
+      free(name);
+      if (asprintf(&name,"%s/.%s.ktab.%d",dir,root,p) < 0) { name = NULL; goto oom; }
+      f = open(name,O_RDONLY);
+      if (f < 0)
+        { fga_set_error("table part %s is missing",name);
+          goto fail;
+        }
+      if (read_full(f,&k,sizeof(int32_t)) || read_full(f,&n,sizeof(int64_t))) goto ioerr;
+      if (k != X->kmer || n < 0 || off+n > nk)
+        { fga_set_error("table part %s does not match its stub",name);
+          goto fail;
+        }
+      kpart[p-1] = off;
+      if (read_full(f,old + off*9,n*9)) goto ioerr;
+      off += n;
+      close(f); f = -1;
+    }
+  kpart[X->nparts] = off;
+  if (off != nk)
+    { fga_set_error("index %s/%s: parts hold %lld k-mers, stub says %lld",dir,root,(long long) off,(long long) nk);
+      goto fail;
+    }
+  for (p = 1; p <= npost; p++)                       /* sizes first, then the data */
+    { int32_t hb[2];
+      int64_t n;
+      free(name);
+      if (asprintf(&name,"%s/.%s.post.%d",dir,root,p) < 0) { name = NULL; goto oom; }
+      f = open(name,O_RDONLY);
+      if (f < 0)
+        { fga_set_error("position list part %s is missing",name);
+          goto fail;
+        }
+      if (read_full(f,hb,sizeof(hb)) || read_full(f,&n,sizeof(int64_t))) goto ioerr;
+      if (hb[0] + hb[1] != pb || n < 0)
+        { fga_set_error("position list part %s does not match its stub",name);
+          goto fail;
+        }
+      np += n;
+      close(f); f = -1;
+    }
+  posts = malloc((size_t) (np > 0 ? np : 1)*pb);
+  if (posts == NULL) goto oom;
+  npos = 0;
+  for (p = 1; p <= npost; p++)
+    { int32_t hb[2];
+      int64_t n;
+      free(name);
+      if (asprintf(&name,"%s/.%s.post.%d",dir,root,p) < 0) { name = NULL; goto oom; }
+      f = open(name,O_RDONLY);
+      if (f < 0 || read_full(f,hb,sizeof(hb)) || read_full(f,&n,sizeof(int64_t)) || npos+n > np ||
+          read_full(f,posts + npos*pb,n*pb))
+        goto ioerr;
+      npos += n;
+      close(f); f = -1;
+    }
+  { int64_t tot = 0;
+    for (e = 0; e < nk; e++)
+      tot += old[e*9+7];
+    if (tot != np)
+      { fga_set_error("index %s/%s: the k-mer counts add up to %lld positions, the position lists hold %lld",dir,root,
+                      (long long) tot,(long long) np);
+        goto fail;
+      }
+  }
+
+  X->ebytes  = 9 + pb;
+  X->nents   = np;
+  X->table   = malloc((size_t) np*X->ebytes + 64);
+  X->partbeg = malloc(sizeof(int64_t)*(X->nparts+1));
+  if (X->table == NULL || X->partbeg == NULL) goto oom;
+  memset(X->table + np*X->ebytes,0,64);
+  e = 0; o = 0; p = 0;
+  for (pre = 0; pre < FGA_NPREFIX; pre++)
+    { const int64_t eend = X->index[pre], obeg = o;
+      for ( ; e < eend; e++)
+        { const uint8_t *k = old + e*9;
+          int c = k[7], q;
+          while (p <= X->nparts && kpart[p] == e)
+            X->partbeg[p++] = o;
+          for (q = 0; q < c; q++, o++)
+            { uint8_t *t = X->table + o*X->ebytes;
+              memcpy(t,k,7);
+              t[7] = 0;
+              t[8] = q == 0 ? k[8] : (uint8_t) X->kmer;
+              memcpy(t+9,posts + o*pb,pb);
+            }
+        }
+      X->index[pre] = o;
+      if (o - obeg > maxpre) maxpre = o - obeg;
+    }
+  while (p <= X->nparts)
+    X->partbeg[p++] = o;
+  X->maxpre = maxpre;
+  X->legacy = 1;
+  free(old); free(posts); free(kpart); free(name);
+  return 0;
+
+ioerr:
+  fga_set_error("IO error reading %s",name);
+  goto fail;
+oom:
+  fga_set_error("out of memory loading index %s/%s",dir,root);
+fail:
+  if (f >= 0) close(f);
+  free(old); free(posts); free(kpart); free(name);
+  return 1;
+}
+
 int fga_gix_open(const char *path, fga_gix **out)
 { fga_gix *X;
   char *noext = NULL, *dir = NULL, *root = NULL, *name = NULL;
@@ -121,9 +255,14 @@ int fga_gix_open(const char *path, fga_gix **out)
   if (X->perm == NULL) goto oom;
   if (read_full(f,X->perm,sizeof(int)*nctg)) goto ioerr;
   if (read_full(f,&sentinel,sizeof(int64_t))) goto ioerr;
-  if (sentinel >= 0)
-    { fga_set_error("%s is a pre-v1.3 index with separate .post files; rebuild it with GIXmake",name);
-      goto fail;
+  if (sentinel >= 0)                    /* pre-v1.3 layout: distinct k-mers with counts + separate .post.N files */
+    { close(f);
+      f = -1;
+      if (open_legacy(X,dir,root,tail3[2]))
+        goto fail;
+      free(noext); free(dir); free(root); free(name);
+      *out = X;
+      return 0;
     }
   close(f);
   f = -1;
@@ -196,6 +335,7 @@ int            fga_gix_nparts(const fga_gix *X)    { return X->nparts; }
 int64_t        fga_gix_part_begin(const fga_gix *X, int p) { return (p < 0 || p > X->nparts || X->partbeg == NULL) ? -1 : X->partbeg[p]; }
 int64_t        fga_gix_maxpre(const fga_gix *X)    { return X->maxpre; }
 const int     *fga_gix_perm(const fga_gix *X)      { return X->perm; }
+int            fga_gix_legacy_cutoff(const fga_gix *X) { return X->legacy ? X->freq : 0; }
 const int64_t *fga_gix_index(const fga_gix *X)     { return X->index; }
 const uint8_t *fga_gix_table(const fga_gix *X)     { return X->table; }
 

@@ -65,6 +65,7 @@ struct fga_gix
     int64_t   nents;
     uint8_t  *table;       /* nents * ebytes raw on-disk entries, parts concatenated    */
     int64_t  *partbeg;     /* [nparts+1] entry offset of each part                      */
+    int       legacy;      /* read from the pre-v1.3 layout: k-mers above `freq` positions are not in it */
   };
 
 typedef struct fga_gdb fga_gdb;

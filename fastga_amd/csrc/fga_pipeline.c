@@ -128,6 +128,14 @@ int fga_session_merge(fga_session *Z, const fga_run_params *P, int64_t prefix_be
   int rc;
 
   *out = NULL;
+  { const fga_gix *xs[2] = { x1, self ? NULL : x2 };      /* an index in the old layout has a cutoff built in (FastGA.c:4959-4974) */
+    int q;
+    for (q = 0; q < 2; q++)
+      if (xs[q] != NULL && xs[q]->legacy && xs[q]->freq < P->freq)
+        { fga_set_error("genome index %d was built with a frequency cutoff of %d < the requested cutoff %d",q+1,xs[q]->freq,P->freq);
+          return 1;
+        }
+  }
   memset(&mp,0,sizeof(mp));
   mp.freq = P->freq; mp.soft_mask = P->soft_mask; mp.flip = 0;
   mp.prefix_begin = prefix_begin; mp.prefix_end = prefix_end;

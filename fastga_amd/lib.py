@@ -134,6 +134,7 @@ def _declare(L):
         "fga_gix_part_begin": (i64, [vp, i32]),
         "fga_gix_maxpre": (i64, [vp]),
         "fga_gix_perm": (P(C.c_int), [vp]),
+        "fga_gix_legacy_cutoff": (i32, [vp]),
         "fga_gix_index": (P(C.c_int64), [vp]),
         "fga_gix_table": (P(C.c_uint8), [vp]),
         "fga_dev_open": (i32, [i32, P(vp)]),

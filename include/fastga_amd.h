@@ -49,6 +49,9 @@ int            fga_gix_nparts(const fga_gix *gix);
 int64_t        fga_gix_part_begin(const fga_gix *gix, int part);   /* first entry of table part (0..nparts) */
 int64_t        fga_gix_maxpre(const fga_gix *gix);
 const int     *fga_gix_perm(const fga_gix *gix);
+int            fga_gix_legacy_cutoff(const fga_gix *gix);          /* 0: today's layout; else the index came from the
+                                                                      pre-v1.3 layout (.post.N files, FastGA.c:206-570) and holds
+                                                                      no k-mer with more positions than this: -f must not exceed it */
 const int64_t *fga_gix_index(const fga_gix *gix);
 const uint8_t *fga_gix_table(const fga_gix *gix);
 
