@@ -81,6 +81,13 @@ def test_pipeline_on_legacy_index_files_gives_the_same_alignments(toy_pair, tmp_
     assert st0["nseeds"] == st1["nseeds"] and st0["nlive"] == st1["nlive"] > 20
     if H.have_reference():
         assert H.oneview(new_out) == H.oneview(old_out)
+    # and a genome against itself (the reference: old_self_merge_thread)
+    self_new, self_old = str(tmp_path / "self_new.1aln"), str(tmp_path / "self_old.1aln")
+    st2 = D.run(ra, None, self_new, nthreads=4)
+    st3 = D.run(oa, None, self_old, nthreads=4)
+    assert st2["nseeds"] == st3["nseeds"] > 0 and st2["nlive"] == st3["nlive"]
+    if H.have_reference():
+        assert H.oneview(self_new) == H.oneview(self_old)
     X = C.c_void_p()
     L = built_library
     assert L.fga_gix_open((oa + ".gix").encode(), C.byref(X)) == 0
