@@ -65,6 +65,13 @@ def test_reference_reads_the_legacy_files_like_the_new_ones(toy_pair, tmp_path):
     b = H.oneview(str(tmp_path / "old_out") + ".1aln")
     assert len(a) > 100
     assert sorted(a) == sorted(b)
+    # a genome against itself: old_self_merge_thread against new_self_merge_thread
+    H.ref_fastga(ra, None, d, str(tmp_path / "new_self"), threads=4)
+    H.ref_fastga(oa, None, str(tmp_path / "old"), str(tmp_path / "old_self"), threads=4)
+    a = H.oneview(str(tmp_path / "new_self") + ".1aln")
+    b = H.oneview(str(tmp_path / "old_self") + ".1aln")
+    assert len(a) > 20
+    assert sorted(a) == sorted(b)
 
 
 @pytest.mark.gpu
