@@ -31,26 +31,53 @@ extern "C" int fga_dev_open(int device, fga_dev **out)
   return 0;
 }
 
+// idle workspace slots go back to the device (the slots are grow-only while in use; after an index build, or between the
+// passes of a multi-pass run, tens of GB sit in slots nobody will ask for at that size again)
+extern "C" void fga_dev_trim(fga_dev *dev)
+{ for (int q = 0; q < SLOT_COUNT; q++)
+    if (dev->slot_ptr[q] != NULL && !dev->slot_busy[q])
+      { hipFree(dev->slot_ptr[q]);
+        dev->slot_ptr[q] = NULL; dev->slot_bytes[q] = 0;
+      }
+}
+
+// device memory an allocation could get right now: free memory + what the idle slots hold
+extern "C" size_t fga_dev_available(fga_dev *dev)
+{ size_t fr = 0, tot = 0;
+  if (hipMemGetInfo(&fr,&tot) != hipSuccess)
+    return 0;
+  for (int q = 0; q < SLOT_COUNT; q++)
+    if (dev->slot_ptr[q] != NULL && !dev->slot_busy[q])
+      fr += dev->slot_bytes[q];
+  return fr;
+}
+
+static void *alloc_or_trim(fga_dev *dev, size_t bytes)
+{ void *p = NULL;
+  if (hipMalloc(&p,bytes) == hipSuccess)
+    return p;
+  (void) hipGetLastError();
+  fga_dev_trim(dev);                        // give the idle slots back and try once more
+  if (hipMalloc(&p,bytes) == hipSuccess)
+    return p;
+  (void) hipGetLastError();
+  return NULL;
+}
+
 void *fga_dev_acquire(fga_dev *dev, int slot, size_t bytes)
 { if (bytes == 0) bytes = 16;
   if (slot < 0 || slot >= SLOT_COUNT || dev->slot_busy[slot])
-    { void *p = NULL;                       // slot taken (or none asked): a private allocation
-      if (hipMalloc(&p,bytes) != hipSuccess)
-        return NULL;
-      return p;
-    }
+    return alloc_or_trim(dev,bytes);        // slot taken (or none asked): a private allocation
   if (dev->slot_ptr[slot] == NULL || dev->slot_bytes[slot] < bytes)
     { if (dev->slot_ptr[slot] != NULL)
         hipFree(dev->slot_ptr[slot]);
-      dev->slot_ptr[slot] = NULL;
-      size_t want = bytes + bytes/8;
-      if (hipMalloc(&dev->slot_ptr[slot],want) != hipSuccess)
-        { want = bytes;
-          if (hipMalloc(&dev->slot_ptr[slot],want) != hipSuccess)
-            { dev->slot_ptr[slot] = NULL; dev->slot_bytes[slot] = 0;
-              return NULL;
-            }
-        }
+      dev->slot_ptr[slot] = NULL; dev->slot_bytes[slot] = 0;
+      size_t slack = bytes/8;               // room to grow without a new allocation, bounded: a 50 GB buffer does not get 6 GB of it
+      if (slack > ((size_t) 256 << 20)) slack = (size_t) 256 << 20;
+      size_t want = bytes + slack;
+      dev->slot_ptr[slot] = alloc_or_trim(dev,want);
+      if (dev->slot_ptr[slot] == NULL)
+        return NULL;
       dev->slot_bytes[slot] = want;
     }
   dev->slot_busy[slot] = 1;

@@ -104,6 +104,11 @@ void     fga_gix_ksplit(const int64_t *sbuck, int nparts, int *ksplit);
 const uint8_t *fga_gix_tmap(void);
 int      fga_gix_write_files(const fga_gix *X, const char *target);
 
+/* device context internals the host pipeline uses (fga_device.hip) */
+struct fga_dev;
+void   fga_dev_trim(struct fga_dev *dev);          /* idle workspace slots back to the device        */
+size_t fga_dev_available(struct fga_dev *dev);     /* free device memory + what the idle slots hold  */
+
 /* small helpers */
 char *fga_path_dir(const char *path);                       /* malloc'd directory part ("." if none) */
 char *fga_path_root(const char *path, const char *suffix);  /* malloc'd basename without suffix      */

@@ -83,6 +83,8 @@ int fga_session_open_threads(const char *root1, const char *root2, int device, i
     if (!Z->self && (have2 ? fga_dgix_upload(Z->dev,Z->x2,&Z->d2)
                            : fga_dgix_build(Z->dev,Z->g2,nthreads,FGA_GIX_SOFT_MASK,&Z->d2,&Z->x2)))
       goto fail;
+    if (Z->devbuilt)
+      fga_dev_trim(Z->dev);          /* the builder's key buffers (2 x 16 B per k-mer) are of no use to the comparison */
   }
   if (Z->x1->nctg < Z->g1->ncontig || (!Z->self && Z->x2->nctg < Z->g2->ncontig))
     { fga_set_error("genome index and genome database disagree on the number of contigs");
@@ -139,8 +141,18 @@ int fga_session_merge(fga_session *Z, const fga_run_params *P, int64_t prefix_be
   memset(&mp,0,sizeof(mp));
   mp.freq = P->freq; mp.soft_mask = P->soft_mask; mp.flip = 0;
   mp.prefix_begin = prefix_begin; mp.prefix_end = prefix_end;
-  rc = fga_seed_merge(dev,Z->d1,self ? NULL : Z->d2,&mp,
-                      (P->symmetric && !self) ? 2*(x1->nents + x2->nents) + (1<<20) : 0,&seeds);
+  /* first guess of the buffer: two seeds per table-1 entry of the range (the merge reports the exact need when that is
+     not enough and is repeated once), but never more than a third of the device memory still to be had -- at human
+     scale (2.4 G entries per table) the guess would otherwise take 77 GB that the sort passes need */
+  { int64_t guess = (P->symmetric && !self) ? 2*(x1->nents + x2->nents) + (1<<20) : 0;
+    if (prefix_begin == 0 && (prefix_end <= 0 || prefix_end >= FGA_NPREFIX))
+      { const int64_t room = (int64_t) (fga_dev_available(dev) / 3 / sizeof(fga_seed));
+        if (guess == 0) guess = 2*x1->nents + (1<<20);
+        if (guess > room && room > x1->nents/2)
+          guess = room;
+      }
+    rc = fga_seed_merge(dev,Z->d1,self ? NULL : Z->d2,&mp,guess,&seeds);
+  }
   if (rc == 2)
     { int64_t need = fga_seeds_count(seeds) + 1024;
       if (P->symmetric && !self) need += x2->nents + x1->nents;
@@ -420,6 +432,7 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
       if (fga_dev_malloc(dev,(size_t) n*sizeof(fga_seed) + 64,&stage)) goto done;
       if (fga_seeds_split_to(dev,seeds,select,nctg,nparts,stage,poff)) goto done;
       fga_seeds_free(seeds); seeds = NULL;
+      fga_dev_trim(dev);               /* the undivided seed buffer's slot: the parts are a fraction of it */
       for (p = 0; p < nparts; p++)
         { const void *src = (const char *) stage + (size_t) poff[p]*sizeof(fga_seed);
           const int64_t c = poff[p+1] - poff[p];

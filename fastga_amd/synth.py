@@ -162,3 +162,30 @@ def contig_lengths(seed, ncontig, total, spread=0.3):
     lens = np.maximum(1000, (w / w.sum() * total).astype(np.int64))
     lens = lens + np.arange(ncontig)     # break ties
     return lens
+
+
+# ---- the fast generator for human-scale pairs (tools/fga_synth.c -> fastga_amd/libfga_synth.so) ----------------------
+
+def write_pair_fast(seed, contig_lens, divergence, fasta_a, fasta_b=None, repeat_frac=0.0, nfam=4, inv_frac=0.0,
+                    swap_frac=0.0, bseed=0, prefix_a="a", prefix_b="b", threads=8):
+    """FASTA files of a synthetic pair straight from C threads (same recipe as make_pair, its own random streams: one
+    per contig, so the files do not depend on `threads`).  Genome A depends on (seed, lens, repeat_frac, nfam) only;
+    B also on (bseed, divergence, inv_frac, swap_frac).  Returns B's contig lengths (None without fasta_b)."""
+    import ctypes as C
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfga_synth.so")
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: run `make -C fastga_amd/csrc`")
+    L = C.CDLL(path)
+    L.fga_synth_pair.restype = C.c_int
+    L.fga_synth_pair.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_int,
+                                 C.c_double, C.c_double, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p,
+                                 C.c_int]
+    lens = np.ascontiguousarray(contig_lens, dtype=np.int64)
+    blen = np.zeros(len(lens), dtype=np.int64)
+    rc = L.fga_synth_pair(seed, bseed, len(lens), lens.ctypes.data, divergence, repeat_frac, nfam, inv_frac, swap_frac,
+                          fasta_a.encode(), prefix_a.encode(), fasta_b.encode() if fasta_b else None,
+                          prefix_b.encode(), blen.ctypes.data, threads)
+    if rc != 0:
+        raise RuntimeError("fga_synth_pair failed (memory or file error)")
+    return blen if fasta_b else None

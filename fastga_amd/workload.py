@@ -62,6 +62,38 @@ def build_config3(workdir, mbp=1000.0, seed=2, ncontig=40, repeat_frac=0.30, tan
     return build_genome(workdir, name, A, masks=masks, threads=threads, use_mask=True, gix=gix)
 
 
+def build_config4(workdir, mbp=3000.0, divergence=0.01, seed=3, ncontig=32, repeat_frac=0.45, nfam=None, inv_frac=0.02,
+                  swap_frac=0.02, threads=8, gix=False, names=("A", "B"), reuse_a=None):
+    """configs[3] (divergence 0.01) and configs[4] (0.10): a human-scale pair, 32 contigs of ~94 Mbp at 3 Gbp, 45 % of the
+    bases in diverged copies of `nfam` repeat families (default: one family per ~234 kbp, i.e. ~40 copies of each whatever
+    the genome size -- with a fixed number of families the copy number, and with it the repeat-induced hits, would grow
+    quadratically), 2 % of 40-kbp blocks inverted / swapped, made by the C generator (synth.write_pair_fast: seconds instead of minutes).  Genome A depends on (seed, mbp, ncontig,
+    repeat_frac, nfam) only, so both configurations can share it: pass the root of an A built before as `reuse_a`.
+    Returns (rootA, rootB)."""
+    lens = synth.contig_lengths(seed, ncontig, int(mbp * 1e6))
+    if nfam is None:
+        nfam = max(4, int(round(mbp * 256 / 60)))
+    fa, fb = os.path.join(workdir, names[0] + ".fa"), os.path.join(workdir, names[1] + ".fa")
+    synth.write_pair_fast(seed, lens, divergence, fa, fb, repeat_frac=repeat_frac, nfam=nfam, inv_frac=inv_frac,
+                          swap_frac=swap_frac, bseed=int(round(divergence * 1000)), prefix_a=names[0].lower(),
+                          prefix_b=names[1].lower(), threads=threads)
+    roots = []
+    for nm, f in zip(names, (fa, fb)):
+        root = os.path.join(workdir, nm)
+        if nm == names[0] and reuse_a is not None:
+            os.unlink(f)
+            roots.append(reuse_a)
+            continue
+        fasta_to_gdb(f, root)
+        os.unlink(f)                                     # 3 GB of text each: the GDB is what everything reads
+        if gix:
+            g = Gdb(root + ".gdb")
+            build_gix(g, root, threads)
+            g.close()
+        roots.append(root)
+    return tuple(roots)
+
+
 def digest_1aln(lines):
     """A digest of a .1aln as ONEview prints it that does not depend on how ties on (aread, abpos) are ordered (the
     reference orders them by the thread slot that held the record, FastGA.c:3906-3918): record count, md5 of the
@@ -81,3 +113,43 @@ def digest_1aln(lines):
     md5 = lambda t: hashlib.md5(t.encode()).hexdigest()      # noqa: E731
     return {"records": len(recs), "header_md5": md5("\n".join(lines[:first])),
             "records_md5": md5("\n".join(sorted(recs))), "order_md5": md5(order)}
+
+
+def digest_1aln_stream(path, oneview_bin):
+    """digest_1aln for files of millions of records: ONEview's text is consumed line by line, nothing is held.  The
+    records as a multiset are digested order-independently (sum of the records' md5 values mod 2^128) instead of by
+    sorting them; header and (aread, abpos) order as in digest_1aln.  Keys are different from digest_1aln's on purpose
+    (records_sum128 instead of records_md5)."""
+    import hashlib
+    import subprocess
+    p = subprocess.Popen([oneview_bin, path], stdout=subprocess.PIPE, text=True, bufsize=1 << 20)
+    head, order = hashlib.md5(), hashlib.md5()
+    total, nrec, cur, in_head, first = 0, 0, [], True, True
+    mask = (1 << 128) - 1
+
+    def close_record():
+        nonlocal total, nrec, cur
+        if cur:
+            total = (total + int.from_bytes(hashlib.md5("\n".join(cur).encode()).digest(), "big")) & mask
+            nrec += 1
+            cur = []
+
+    for ln in p.stdout:
+        ln = ln.rstrip("\n")
+        if ln[:1] in ("!", "<"):
+            continue
+        if ln.startswith("A "):
+            in_head = False
+            close_record()
+            f = ln.split()
+            order.update((("" if first else " ") + f[1] + " " + f[2]).encode())
+            first = False
+        if in_head:
+            head.update((ln + "\n").encode())
+        else:
+            cur.append(ln)
+    close_record()
+    if p.wait() != 0:
+        raise RuntimeError(f"{oneview_bin} {path} failed")
+    return {"records": nrec, "header_md5": head.hexdigest(), "records_sum128": f"{total:032x}",
+            "order_md5": order.hexdigest()}
