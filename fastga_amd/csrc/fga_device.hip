@@ -198,6 +198,11 @@ extern "C" int fga_dgix_upload(fga_dev *dev, const fga_gix *X, fga_dgix **out)
       hipFree(D->table); hipFree(D->index); free(D);
       return 1;
     }
+  D->legacy_cutoff = X->legacy ? X->freq : 0;
+  if (fga_dgix_make_view(dev,D,0))
+    { hipFree(D->table); hipFree(D->index); free(D);
+      return 1;
+    }
   *out = D;
   return 0;
 }
@@ -205,6 +210,7 @@ extern "C" int fga_dgix_upload(fga_dev *dev, const fga_gix *X, fga_dgix **out)
 extern "C" void fga_dgix_free(fga_dgix *D)
 { if (D == NULL) return;
   hipSetDevice(D->dev->device);
+  fga_dgix_free_views(D);
   hipFree(D->table);
   hipFree(D->index);
   free(D);

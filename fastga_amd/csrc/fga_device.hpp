@@ -41,14 +41,33 @@ struct fga_dev
   };
 void fga_dev_note_memory(fga_dev *dev);
 
-// device-resident genome index: the on-disk bytes, unchanged
+// a table as the seed merge reads it: one array per field (fga_view.hip)
+struct fga_view
+  { uint64_t *K;          // (12-mer prefix & 0xff) << 56 | 56-bit suffix
+    uint8_t  *L;          // lcp byte (first entry of a panel clamped to <= 11); NULL in a forward view
+    uint8_t  *M;          // soft-mask byte
+    uint32_t *P;          // position inside the contig
+    void     *C;          // contig | sign, cw bytes each
+    uint32_t *idx;        // [2^24] inclusive cumulative entry count per 12-mer prefix
+    int64_t   n;
+    int       cw;         // 1, 2 or 4
+  };
+
+// device-resident genome index: the prefix index and the field arrays of the table (the on-disk bytes themselves only
+// while the view is being made)
 struct fga_dgix
   { fga_dev  *dev;
-    uint8_t  *table;      // nents*ebytes raw entries (+ 64 bytes slack)
+    uint8_t  *table;      // nents*ebytes raw entries (+ 64 bytes slack); NULL once the view exists
     int64_t  *index;      // [2^24] inclusive cumulative counts
     int64_t   nents;
     int       ebytes, postbytes, contbytes, nctg;
+    int       legacy_cutoff;   // > 0: read from the pre-v1.3 layout, no k-mer with more positions than this is in it
+    fga_view  view;       // all entries
+    fga_view  fview;      // forward-strand entries only (made on first use as table 1 of a pair comparison)
   };
+int  fga_dgix_make_view(fga_dev *dev, fga_dgix *D, int keep_table);
+int  fga_dgix_make_forward(fga_dev *dev, fga_dgix *D);
+void fga_dgix_free_views(fga_dgix *D);
 
 // One adaptive seed, 16 bytes (device + host layout of fga_seed in fastga_amd.h)
 //   apos, bpos : in-contig positions as stored in the index payloads

@@ -518,6 +518,9 @@ extern "C" int fga_dgix_build(fga_dev *dev, const fga_gdb *G, int nthreads, int 
             goto done;
           }
       }
+    // the merge kernel's view of the table; the on-disk bytes leave the device
+    if (fga_dgix_make_view(dev,D,0))
+      goto done;
   }
   status = 0;
 
@@ -528,7 +531,7 @@ done:
   fga_dev_release(dev,SLOT_SORT0,buf0); fga_dev_release(dev,SLOT_SORT1,buf1);
   free(perm); free(invp);
   if (status != 0)
-    { if (D != NULL) { hipFree(D->table); hipFree(D->index); free(D); }
+    { if (D != NULL) { fga_dgix_free_views(D); hipFree(D->table); hipFree(D->index); free(D); }
       if (X != NULL) fga_gix_close(X);
       return 1;
     }

@@ -55,6 +55,45 @@ def family_pair(tmp_path_factory, built_library):
 
 
 @pytest.fixture(scope="session")
+def big_family_pair(tmp_path_factory, built_library):
+    """0.5 Mbp pair with a 1.5 kbp family planted 300 times at 0.5 % divergence (both strands): its k-mers have 100-300
+    partners, their 12-mer panels exceed a merge tile (streamed windows) and cutoffs of -f64 / -f200 decide their fate
+    (the wide-window build of the merge kernel)"""
+    from fastga_amd import workload, synth
+    d = str(tmp_path_factory.mktemp("bigfam"))
+    rng = np.random.default_rng(78)
+    lens = synth.contig_lengths(22, 6, 500_000)
+    A = [rng.integers(0, 4, int(L), dtype=np.uint8) for L in lens]
+    fam = rng.integers(0, 4, 1500, dtype=np.uint8)
+    for k in range(300):
+        c = A[k % len(A)]
+        cp = synth.mutate(rng, fam, 0.005)
+        if k % 3 == 0:
+            cp = synth.revcomp(cp)
+        p0 = int(rng.integers(0, len(c) - len(cp) - 1))
+        c[p0:p0 + len(cp)] = cp
+    B = [synth.mutate(rng, c, 0.02) for c in A]
+    return d, workload.build_genome(d, "A", A), workload.build_genome(d, "B", B)
+
+
+@pytest.fixture(scope="session")
+def dense_pair(tmp_path_factory, built_library):
+    """3 Mbp of A/C-only sequence against its 3 % diverged copy: the forward-strand k-mers crowd into 4096 of the 2^24
+    12-mer panels (and the complement ones into another 4096), ~150 entries each and many beyond a tile -- the panel
+    shapes of a 3 Gbp table at toy size, so the streamed windows of the merge kernel meet the oracle entry for entry"""
+    from fastga_amd import workload, synth
+    d = str(tmp_path_factory.mktemp("dense"))
+    rng = np.random.default_rng(79)
+    lens = synth.contig_lengths(23, 6, 3_000_000)
+    A = [rng.integers(0, 2, int(L), dtype=np.uint8) for L in lens]          # a / c only
+    # a stretch of very low complexity on top: period-7 tandem, panels of thousands of near-identical k-mers
+    unit = rng.integers(0, 2, 7, dtype=np.uint8)
+    A[0][1000:41000] = synth.mutate(rng, np.tile(unit, 6000), 0.01)[:40000]
+    B = [synth.mutate(rng, c, 0.03) for c in A]
+    return d, workload.build_genome(d, "A", A), workload.build_genome(d, "B", B)
+
+
+@pytest.fixture(scope="session")
 def masked_pair(tmp_path_factory, built_library):
     """~0.6 Mbp pair whose repeat copies are lower case in BOTH genomes; indices carry the mask bytes (host producer,
     pinned against `GIXmake -T1 ... #` by tests/test_edge_cases.py)"""

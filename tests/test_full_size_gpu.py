@@ -33,6 +33,39 @@ def _write_index_files(roots, use_mask=False, nthreads=8):
     dev.close()
 
 
+def _reference_index_files_equal_device_builds(roots, d, nthreads=8):
+    """<root>.gix + .ktab.N made by the REFERENCE's GIXmake (the files the reference run then consumes), and the table a
+    device build gives for the same GDB compared with them: same prefix index, same k-mer order, same entries up to the
+    order inside runs of equal k-mers (the reference's sort is not stable there; which copy carries the run's lcp byte
+    follows) -- so the two programs of the comparison below do NOT share an index builder (SURVEY hard part 9)."""
+    import numpy as np
+    from fastga_amd import device as D
+    from fastga_amd.gixio import Gdb, Gix
+    from oracle import harness as H
+    dev = D.Device(0)
+    for r in roots:
+        H.run([H.ref_bin("GIXmake"), f"-T{nthreads}", f"-P{d}", r], cwd=d)
+        ref = Gix(r + ".gix")
+        g = Gdb(r + ".gdb")
+        dgx, xg = D.build_gix_device(dev, g, nthreads, host_copy=True)
+        assert xg.nents == ref.nents and xg.ebytes == ref.ebytes
+        assert np.array_equal(xg.index, ref.index) and np.array_equal(xg.perm, ref.perm)
+        assert np.array_equal(xg.partbeg, ref.partbeg)
+        a, b = xg.entries(), ref.entries()
+        assert np.array_equal(a[:, :7], b[:, :7])                     # k-mers in the same order
+        zero = np.nonzero(a[:, 8] == 0)[0]                            # part starts + first-base boundaries (GIXmake races there)
+        assert len(zero) <= xg.nparts + 4
+        b = b.copy()
+        b[zero, 8] = 0
+        dif = np.nonzero((a != b).any(axis=1))[0]
+        assert len(dif) < max(1000, len(a) // 100), len(dif)          # only inside runs of equal k-mers
+        for cols in (list(range(8)) + list(range(9, a.shape[1])), list(range(9))):
+            x, y = a[dif][:, cols], b[dif][:, cols]
+            assert np.array_equal(x[np.lexsort(x.T[::-1])], y[np.lexsort(y.T[::-1])])
+        dgx.free(); xg.close(); ref.close(); g.close()
+    dev.close()
+
+
 def _compare_with_reference(ra, rb, d, flags=(), strict=True, pafx=False, ref_threads=T, **kw):
     from fastga_amd import device as D, workload
     from oracle import harness as H
@@ -59,8 +92,12 @@ def test_config2_100mbp_pair_is_identical_to_the_reference(tmp_path_factory, bui
     from fastga_amd import workload
     d = str(tmp_path_factory.mktemp("c2"))
     ra, rb = workload.build_config2(d, mbp=100.0, threads=T)
-    _write_index_files((ra, rb))
-    st, dg = _compare_with_reference(ra, rb, d, strict=True, pafx=True)
+    _reference_index_files_equal_device_builds((ra, rb), d)      # the reference reads its own GIXmake's files ...
+    os.environ["FGA_IGNORE_GIX_FILES"] = "1"                     # ... and ours builds its index on the device
+    try:
+        st, dg = _compare_with_reference(ra, rb, d, strict=True, pafx=True)
+    finally:
+        os.environ.pop("FGA_IGNORE_GIX_FILES", None)
     assert dg["records"] > 1500 and st["nwaves"] > 5_000_000        # contig-long alignments were really extended
     # the work itself is pinned too, not only its outcome: the number of wave steps of the whole comparison.  (A wrong
     # root cell for the trim point of a wave that never sets one changed it by 14 in 7.9 M while every record stayed
@@ -158,3 +195,45 @@ def test_config3_1gbp_self_soft_masked_matches_the_reference_digest(tmp_path_fac
     assert 0 <= st["nseeds"] - exp["total_seeds"] <= 64
     for k in ("records", "header_md5", "records_md5", "order_md5"):
         assert got[k] == exp[k], (k, got, exp, st)
+
+
+@pytest.mark.skipif(os.environ.get("FGA_SKIP_1G") == "1", reason="FGA_SKIP_1G=1")
+@pytest.mark.parametrize("name,div", [("config4", 0.01), ("config5", 0.10)])
+def test_configs_4_and_5_at_3gbp_match_the_reference_digests(tmp_path_factory, built_library, name, div):
+    """configs[3] / configs[4] at their stated size on ONE GPU: 3 Gbp x 3 Gbp, 32 contigs of ~94 Mbp, 45 % repeats, 1 % and
+    10 % divergence.  Indices built on the device (2.4 G entries each), the seeds exceed one sort pass so phase 2 runs over
+    A-contig parts (the reference's NPARTS loop), and the same comparison cut into 8 prefix ranges x 8 parts (the 8-GPU
+    decomposition, emulated) must give the same file.  Expected digests: tests/golden/<name>_3000m_digest.json, made on
+    a 256-core box with the REAL reference (its own GIXmake -T32 index, FastGA -T32: 74 s and 123 s wall) by
+    tests/golden/make_golden_config4.py."""
+    from fastga_amd import device as D, parallel, workload
+    from oracle import harness as H
+    gold = os.path.join(HERE, "golden", f"{name}_3000m_digest.json")
+    exp = json.load(open(gold))
+    oneview = H.ref_bin("ONEview")
+    if not os.path.exists(oneview):
+        pytest.skip("oracle/_ref/ONEview did not travel")
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    import shutil, tempfile
+    d = tempfile.mkdtemp(prefix="fga_" + name + "_", dir=base)
+    try:
+        ra, rb = workload.build_config4(d, mbp=3000.0, divergence=div, threads=T)
+        ses = D.Session(ra, rb)
+        ours = os.path.join(d, "ours.1aln")
+        st = ses.run(out_path=ours, nthreads=T)
+        got = workload.digest_1aln_stream(ours, oneview)
+        assert st["nseeds"] == exp["total_seeds"] and st["nhits"] == exp["hits"] and st["nalns"] == exp["alignments"]
+        for k in ("records", "header_md5", "records_sum128", "order_md5"):
+            assert got[k] == exp[k], (k, got, exp, st)
+        assert st["nparts"] >= 2                                   # more seeds than one sort pass takes
+        assert st["hbm_peak_bytes"] < 250 << 30
+        os.unlink(ours)
+        out8 = os.path.join(d, "parts8.1aln")
+        st8 = parallel.run_parts_on_one_gpu(ses, 8, out_path=out8, nthreads=T)
+        assert st8["nseeds"] == exp["total_seeds"] and len(st8["part_seed_counts"]) == 8
+        assert max(st8["part_seed_counts"]) < 1.1 * min(st8["part_seed_counts"])       # balanced on seed counts
+        got8 = workload.digest_1aln_stream(out8, oneview)
+        assert got8 == got
+        ses.close()
+    finally:
+        shutil.rmtree(d, ignore_errors=True)

@@ -95,6 +95,61 @@ def test_frequency_cutoff_on_a_repeat_family(family_pair):
     dA.free(); dB.free(); dev.close()
 
 
+def test_large_cutoffs_on_a_300_copy_family(big_family_pair):
+    """-f64 and -f200 (the wide-window build: the sub-tile margin FREQ+2 no longer fits a 256-entry window) on panels of
+    hundreds of entries, pair / flipped / self, against the pinned oracle"""
+    from fastga_amd.gixio import Gix
+    from fastga_amd import device as D
+    d, ra, rb = big_family_pair
+    A, B = Gix(ra + ".gix"), Gix(rb + ".gix")
+    dev = D.Device(0)
+    dA, dB = dev.upload(A), dev.upload(B)
+    n10, n64, n200 = (_compare(dev, A, B, dA, dB, freq=f) for f in (10, 64, 200))
+    assert n10 < n64 < n200
+    _compare(dev, B, A, dB, dA, flip=True, freq=64)
+    _compare(dev, B, A, dB, dA, flip=True, freq=200)
+    _compare(dev, A, None, dA, None, freq=64)
+    _compare(dev, A, None, dA, None, freq=255)
+    _compare(dev, A, B, dA, dB, freq=120, soft_mask=True)
+    dA.free(); dB.free(); dev.close()
+
+
+def test_dense_panels_are_streamed_in_windows(dense_pair):
+    """every panel holds ~150 entries and many more than a tile: windows of the T2 panel, margins, the skip over windows
+    without a T1 key, the self comparison's runs with margins -- all modes against the oracle"""
+    from fastga_amd.gixio import Gix
+    from fastga_amd import device as D
+    d, ra, rb = dense_pair
+    A, B = Gix(ra + ".gix"), Gix(rb + ".gix")
+    dev = D.Device(0)
+    dA, dB = dev.upload(A), dev.upload(B)
+    assert _compare(dev, A, B, dA, dB) > 100_000
+    _compare(dev, A, B, dA, dB, freq=3)
+    _compare(dev, A, B, dA, dB, freq=40)
+    _compare(dev, A, B, dA, dB, freq=100)
+    _compare(dev, B, A, dB, dA, flip=True)
+    _compare(dev, B, A, dB, dA, flip=True, freq=100)
+    _compare(dev, A, None, dA, None)
+    _compare(dev, A, None, dA, None, freq=100)
+    dA.free(); dB.free(); dev.close()
+
+
+def test_empty_prefix_range_is_an_empty_shard(loaded):
+    """a prefix cut that repeats (one panel heavier than a shard's share) gives an empty range: no seeds, no error;
+    (0,0) stays "everything" and fga_merge_prefix_cuts never produces it as a shard"""
+    from fastga_amd import device as D
+    dev, A, B, dA, dB = loaded
+    s = D.seed_merge(dev, dA, dB, prefix_begin=5000, prefix_end=5000)
+    assert s.count == 0 and len(s.download()) == 0
+    s.free()
+    full = D.seed_merge(dev, dA, dB)
+    n = full.count
+    full.free()
+    s = D.seed_merge(dev, dA, dB, prefix_begin=0, prefix_end=0)
+    assert s.count == n
+    s.free()
+
+
 def test_self_merge(loaded):
     dev, A, B, dA, dB = loaded
     _compare(dev, A, None, dA, None)
