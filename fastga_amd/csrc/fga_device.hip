@@ -108,10 +108,9 @@ void *fga_dev_pinned(fga_dev *dev, size_t bytes)
 extern "C" int fga_dev_malloc(fga_dev *dev, size_t bytes, void **out)
 { *out = NULL;
   FGA_HIP(hipSetDevice(dev->device));
-  hipError_t e = hipMalloc(out,bytes > 0 ? bytes : 16);
-  if (e != hipSuccess)
-    { fga_set_error("device allocation of %zu bytes failed: %s",bytes,hipGetErrorString(e));
-      *out = NULL;
+  *out = alloc_or_trim(dev,bytes > 0 ? bytes : 16);        // idle workspace slots are given back before giving up
+  if (*out == NULL)
+    { fga_set_error("device allocation of %zu bytes failed: out of memory",bytes);
       return 1;
     }
   return 0;

@@ -36,10 +36,10 @@
 enum { MODE_PAIR = 0, MODE_FLIP = 1, MODE_SELF = 2 };
 
 #define T1CAP           256                  // table-1 entries per tile: four rounds of one entry per lane
-#define XPC             64                   // prefixes per tile at most (one index entry per lane)
-#define EWIN            512                  // slots per emission window (descriptor dwords in the key array)
+#define XPC             128                  // prefixes per tile at most (two index entries per lane)
+#define EWIN            1024                 // slots per emission window (descriptor dwords in the key array)
 #ifndef WAVE_OCC
-#define WAVE_OCC        5                    // resident wavefronts per SIMD the register budget is held to
+#define WAVE_OCC        4                    // resident wavefronts per SIMD the register budget is held to
 #endif
 #ifndef RANGES_PER_WAVE
 #define RANGES_PER_WAVE 4
@@ -48,25 +48,33 @@ enum { MODE_PAIR = 0, MODE_FLIP = 1, MODE_SELF = 2 };
 #define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL,"wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #define VM_WAIT() __builtin_amdgcn_s_waitcnt(0x0F70)      // vmcnt(0), the other counters left alone
 
-struct merge_args
-  { fga_view v1, v2;                  // table 1 (pair mode: its forward view) and table 2 (self: the same table)
-    uint32_t sign1, sign2;            // sign bit of the contig words
-    int   freq, soft_mask;
-    int   pbeg, pend;                 // prefix range handled by this call
-    int64_t base;                     // cost(pbeg-1)
-    fga_seed *out; int64_t cap;
-    unsigned long long *count;        // slots handed out
-    unsigned long long *tseed;        // sum of plen (the reference's "ave. len" statistic)
+struct merge_cold                     // what a wavefront needs once, at its end (read from memory, not held in registers)
+  { unsigned long long *tseed;        // sum of plen (the reference's "ave. len" statistic)
     unsigned long long *hslots;       // slots left unused
     uint16_t *valid;                  // seeds per 1024-slot block of `out` (holes are left open, consumers skip them)
     int64_t   nblocks;
-    const int64_t *cuts;              // [nranges+1] prefix boundaries
-    int       nranges;
-    int      *next;                   // range queue head
   };
 
+struct merge_args
+  { const uint64_t *K1; const uint32_t *P1; const uint8_t *C1; const uint8_t *M1; const uint32_t *idx1;
+    const uint64_t *K2; const uint32_t *P2; const uint8_t *C2; const uint8_t *M2; const uint32_t *idx2;
+    const uint8_t  *L2;
+    int   cw1, cw2;                   // bytes per contig|sign word
+    uint32_t sign1, sign2;            // sign bit of the contig words
+    int   freq, soft_mask;
+    fga_seed *out; int64_t cap;
+    unsigned long long *count;        // slots handed out
+    const int64_t *cuts;              // [nranges+1] prefix boundaries
+    int       nranges;
+    int      *next;                   // [8] queue heads, one per XCD
+    const merge_cold *cold;
+  };
+
+// ranges of the prefix space for the wavefronts' queues: `nbig` ranges of equal cost over the first five eighths of the
+// work, then `nranges - nbig` small ones over the rest (the queues are taken in order, so the launch ends on small
+// pieces: its tail is one small range, not a quarter of a wavefront's share)
 __global__ void range_cut_kernel(const uint32_t *idx1, const uint32_t *idx2, int pbeg, int pend, int64_t base,
-                                 int64_t total, int nranges, int64_t *cuts)
+                                 int64_t total, int nranges, int nbig, int64_t *cuts)
 { const int w = blockIdx.x*blockDim.x + threadIdx.x;
   if (w > nranges)
     return;
@@ -74,7 +82,8 @@ __global__ void range_cut_kernel(const uint32_t *idx1, const uint32_t *idx2, int
   if (w == nranges)
     p = pend;
   else if (w > 0)
-    { const int64_t target = base + (total / nranges) * w;
+    { const int64_t t34 = (total >> 1) + (total >> 3);
+      const int64_t target = base + (w <= nbig ? (t34 / nbig) * w : t34 + ((total - t34) / (nranges - nbig)) * (w - nbig));
       int lo = pbeg, hi = pend;
       while (lo < hi)
         { const int mid = lo + ((hi-lo) >> 1);
@@ -86,11 +95,10 @@ __global__ void range_cut_kernel(const uint32_t *idx1, const uint32_t *idx2, int
   cuts[w] = p;
 }
 
-// LCP in bases of two keys (prefix byte | 56-bit suffix): 0 when the prefixes differ, else 12 .. 40
+// LCP in bases of two keys of one panel (same prefix byte above the 56-bit suffix): 12 .. 40
 __device__ __forceinline__ int lcp_key(uint64_t a, uint64_t b)
 { const uint64_t x = a ^ b;
-  if (x >> 56) return 0;
-  return x == 0 ? 40 : 8 + (__clzll((long long) x) >> 1);       // clz >= 8; 12 + (clz - 8)/2
+  return x == 0 ? 40 : 8 + (__clzll((long long) x) >> 1);       // clz >= 8: 12 + (clz - 8)/2
 }
 
 template <int MODE>
@@ -138,8 +146,8 @@ __device__ __forceinline__ int wave_incl_scan_max_dpp(int v)      // v >= 0
   return x;
 }
 
-// smallest j in [lo,hi] with K[j] >= kq, all 64 lanes probing HBM: the range shrinks 64-fold a round (only when a window
-// of an oversize panel holds no T1 key)
+// smallest j in [lo,hi] with K[j] >= kq (one panel), all 64 lanes probing HBM: the range shrinks 64-fold a
+// round (only when a window of an oversize panel holds no T1 key)
 __device__ __forceinline__ int64_t wave_lower_bound(const uint64_t *K, int64_t lo, int64_t hi, uint64_t kq)
 { const int lane = threadIdx.x;
   while (hi > lo)
@@ -158,21 +166,32 @@ __device__ __forceinline__ int64_t wave_lower_bound(const uint64_t *K, int64_t l
   return lo;
 }
 
+#ifdef MERGE_PROF      // per-phase cycle accounting of every wavefront (tools/merge_bench.py prints it): timing builds only
+__device__ unsigned long long merge_prof[8];
+#define XPROF(k)   { unsigned long long _n = clock64(); O.pa[k] += _n - O.pt; O.pt = _n; }
+#else
+#define XPROF(k)
+#endif
+
 struct walk_out                      // a wavefront's current output chunk and statistics (wave-uniform)
   { int64_t chunk_pos, chunk_end;
     unsigned long long tsum;
+#ifdef MERGE_PROF
+    unsigned long long pt, pa[8];
+#endif
   };
 
-// the LDS of one wavefront
+// the LDS of one wavefront.  Every array is filled in 16-byte pieces from a 16-byte aligned address of its HBM array, so
+// entry 0 of a window sits (window start mod 2 / 4 / 16) entries into it.
 template <int T2CAP>
 struct tile_lds
-  { uint64_t keyB0[T2CAP + 8];       // keyB = keyB0 + 4 + (window start & 3): T2 keys, one spare either side; emission descriptors later
+  { uint64_t keyB0[T2CAP + 4];       // T2 keys; emission descriptors later
     uint32_t pB0[T2CAP + 8];         // T2 positions
     uint32_t pA0[T1CAP + 8];         // T1 positions
-    uint8_t  lcpB0[T2CAP + 24];      // T2 lcp bytes (8 spare bytes in front)
-    uint8_t  mB0[T2CAP + 8];         // T2 mask bytes  (soft mask runs only)
-    uint8_t  mA0[T1CAP + 8];         // T1 mask bytes
-    uint32_t ixs[2][64];             // index entries of the next 64 prefixes
+    uint8_t  lcpB0[T2CAP + 32];      // T2 lcp bytes
+    uint8_t  mB0[T2CAP + 32];        // T2 mask bytes  (soft mask runs only)
+    uint8_t  mA0[T1CAP + 32];        // T1 mask bytes
+    uint32_t ixs[2][2][XPC + 4];     // [buffer][table]: index entries of the next XPC prefixes from slot 4 on, slot 3 = the entry before
   };
 
 __device__ __forceinline__ uint32_t lds_c(const uint8_t *c, int cw, int i)
@@ -184,70 +203,104 @@ __device__ __forceinline__ uint32_t lds_c(const uint8_t *c, int cw, int i)
 #define G2L(gp,lp,sz) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (gp), \
                                                        (__attribute__((address_space(3))) void *) (lp),sz,0,0)
 
-// One tile: T1 entries [a0, a0+n1) against the T2 window [b0, b0+n2) (self: one window, its entries [t_lo, t_hi) emit).
-// limit: the window does not reach the end of its panel, so only the T1 entries whose lower bound is at most n2 - margin
-// are consumed (a prefix of them).  Returns their number; lb_last = lower bound (window coordinates) of the last one.
-template <int MODE, int T2CAP, int NR>
+// nbytes from the (wave-uniform, 16-byte aligned) HBM address g to the LDS address l, 16 bytes per lane and instruction
+__device__ __forceinline__ void lds_fill(const void *g, void *l, int nbytes, int lane16)
+{ const char *gc = (const char *) g;
+  char *lc = (char *) l;
+  int x0 = 0;
+  // the LDS operand is the wavefront's base (the hardware adds lane x 16 itself); the HBM address is a uniform base plus a
+  // 32-bit lane offset
+  for (; x0 + 1024 <= nbytes; x0 += 1024)
+    G2L(gc + x0 + (size_t) (uint32_t) lane16,lc + x0,16);
+  if (x0 + lane16 < nbytes)
+    G2L(gc + x0 + (size_t) (uint32_t) lane16,lc + x0,16);
+}
+
+// The match of up to NR rounds of T1 entries (entry c = r*64 + lane of the tile) side by side.  qe: the entry's panel
+// among the tile's (index into ix2, whose slot -1 holds the entries before the tile), or < 0: one panel = the window.
+template <int MODE, int NR>
 __device__ __forceinline__ void match_rounds(const merge_args &A, const uint64_t *keyB, const uint8_t *lcpB, const uint8_t *mA,
-                                             const uint8_t *mB, const uint8_t *cB, const uint64_t *k1, int n2, int na, int t_lo,
+                                             const uint8_t *mB, const uint8_t *cB, const uint64_t *k1, const uint32_t *ix2,
+                                             uint32_t b, int plo, bool panels, int n2, int na, int t_lo,
                                              uint32_t *res, int &total, unsigned long long &tsum, int &lb_last)
 { const int lane = threadIdx.x;
   const int freq = A.freq;
   uint64_t ks[NR];
-  int base[NR];
+  int base[NR], len[NR], pb0[NR], pb1[NR];
+  bool any = false;
   #pragma unroll
   for (int r = 0; r < NR; r++)
-    { ks[r] = (MODE == MODE_SELF) ? keyB[r*64 + lane < na ? t_lo + r*64 + lane : t_lo] : k1[r];
-      base[r] = 0;
+    { const int c = r*64 + lane;
+      const int i = (MODE == MODE_SELF) ? (c < na ? t_lo + c : t_lo) : c;
+      ks[r] = (MODE == MODE_SELF) ? keyB[i] : k1[r];
+      if (panels)
+        { const int qe = (int) (((uint32_t) (ks[r] >> 56) - (uint32_t) plo) & 0xff);
+          pb0[r] = (int) (ix2[qe-1] - b); pb1[r] = (int) (ix2[qe] - b);      // entries before the panel, entries up to its end
+        }
+      else
+        { pb0[r] = 0; pb1[r] = n2; }
+      base[r] = pb0[r]; len[r] = pb1[r] - pb0[r];
+      if (MODE == MODE_SELF) { base[r] = i; len[r] = 0; }
+      any = any || len[r] > 1;
     }
   if (MODE != MODE_SELF)
-    { // lower bounds over the whole window: a wave-uniform number of halving steps, the chains of all rounds in flight together
-      int len = n2;
-      while (len > 1)
-        { const int half = len >> 1;
+    { // lower bound of every key inside its own panel: halving steps, the chains of all rounds in flight together
+      while (__builtin_amdgcn_ballot_w64(any) != 0)
+        { any = false;
           #pragma unroll
           for (int r = 0; r < NR; r++)
-            base[r] += keyB[base[r] + half - 1] < ks[r] ? half : 0;
-          len -= half;
+            { const int half = len[r] >> 1;
+              const bool go = len[r] > 1;
+              const uint64_t kv = keyB[base[r] + half - (go ? 1 : 0)];                  // read by every lane: the reads of all rounds in flight together
+              const bool lt = go & (kv < ks[r]);                                        // keys of one panel: same prefix byte
+              base[r] += lt ? half : 0;
+              len[r]  -= go ? half : 0;
+              any = any || len[r] > 1;
+            }
         }
+      uint64_t kf[NR];
       #pragma unroll
       for (int r = 0; r < NR; r++)
-        base[r] += keyB[base[r]] < ks[r] ? 1 : 0;
+        kf[r] = keyB[base[r]];
+      #pragma unroll
+      for (int r = 0; r < NR; r++)
+        base[r] += ((len[r] > 0) & (kf[r] < ks[r])) ? 1 : 0;
     }
   uint64_t kb[NR], kc[NR];
   int bd[NR], bu[NR], nb[NR], na_[NR];
   #pragma unroll
   for (int r = 0; r < NR; r++)
-    { if (MODE == MODE_SELF) { const int i = r*64 + lane < na ? t_lo + r*64 + lane : t_lo; nb[r] = i-1; na_[r] = i+1; base[r] = i; }
+    { if (MODE == MODE_SELF) { nb[r] = base[r]-1; na_[r] = base[r]+1; }
       else                   { nb[r] = base[r]-1; na_[r] = base[r]; }
-      kb[r] = keyB[nb[r]]; kc[r] = keyB[na_[r]];                  // keyB[-1] and keyB[n2] hold keys of no panel
-      bd[r] = (int) lcpB[nb[r]]; bu[r] = (int) lcpB[na_[r]+1];
+      kb[r] = keyB[nb[r] >= 0 ? nb[r] : 0]; kc[r] = keyB[na_[r]];
+      bd[r] = (int) lcpB[nb[r] >= 0 ? nb[r] : 0]; bu[r] = (int) lcpB[na_[r]+1];
     }
   total = 0;
   #pragma unroll
   for (int r = 0; r < NR; r++)
     { const int c = r*64 + lane;
       const bool act = c < na;
-      const int i = (MODE == MODE_SELF) ? (act ? t_lo + c : t_lo) : c;
+      const int i = (MODE == MODE_SELF) ? base[r] : c;
       int low, hgh, lbnd;
       if (MODE == MODE_SELF) { low = i; hgh = i+1; lbnd = i; }
       else                   { low = hgh = lbnd = base[r]; }
-      const int lkb = lcp_key(ks[r],kb[r]), lka = lcp_key(ks[r],kc[r]);
+      const bool hasb = nb[r] >= pb0[r], hasa = na_[r] < pb1[r];
+      const int lkb = hasb ? lcp_key(ks[r],kb[r]) : 0, lka = hasa ? lcp_key(ks[r],kc[r]) : 0;
       const int plen = lkb > lka ? lkb : lka;                      // 0: no T2 entry of this panel next to the key
       const bool ok = act && plen >= 12;
       // run growth on the table's own lcp bytes; the first step of either direction is decided on the bytes read above
       const bool gd = ok && lkb >= plen;
       low -= gd ? 1 : 0;
-      if (gd && low > 0 && lbnd-low <= freq && bd[r] >= plen)
+      if (gd && low > pb0[r] && lbnd-low <= freq && bd[r] >= plen)
         { low -= 1;
-          while (low > 0 && lbnd-low <= freq && (int) lcpB[low] >= plen)
+          while (low > pb0[r] && lbnd-low <= freq && (int) lcpB[low] >= plen)
             low -= 1;
         }
-      const bool gu = ok && lka >= plen && hgh < n2 && hgh-low <= freq;
+      const bool gu = ok && lka >= plen && hgh < pb1[r] && hgh-low <= freq;
       hgh += gu ? 1 : 0;
-      if (gu && hgh < n2 && hgh-low <= freq && bu[r] >= plen)
+      if (gu && hgh < pb1[r] && hgh-low <= freq && bu[r] >= plen)
         { hgh += 1;
-          while (hgh < n2 && hgh-low <= freq && (int) lcpB[hgh] >= plen)
+          while (hgh < pb1[r] && hgh-low <= freq && (int) lcpB[hgh] >= plen)
             hgh += 1;
         }
       const int mlen = A.soft_mask ? plen : 41;
@@ -261,7 +314,7 @@ __device__ __forceinline__ void match_rounds(const merge_args &A, const uint64_t
             for (int j = low; j < hgh; j++)
               { if (A.soft_mask && (int) mB[j] >= mlen)
                   continue;
-                if (MODE == MODE_FLIP && (lds_c(cB,A.v2.cw,j) & A.sign2))
+                if (MODE == MODE_FLIP && (lds_c(cB,A.cw2,j) & A.sign2))
                   continue;
                 if (MODE == MODE_SELF && j == i)
                   continue;
@@ -270,7 +323,7 @@ __device__ __forceinline__ void match_rounds(const merge_args &A, const uint64_t
         }
       else
         cnt = pass ? (hgh-low) - (MODE == MODE_SELF ? 1 : 0) : 0;
-      res[r] = (pass && cnt > 0) ? ((uint32_t) i | ((uint32_t) low << 8) | ((uint32_t) plen << 18) | ((uint32_t) cnt << 24)) : 0u;
+      res[r] = (pass && cnt > 0) ? ((uint32_t) (MODE == MODE_SELF ? i - low : i) | ((uint32_t) low << 8) | ((uint32_t) plen << 18) | ((uint32_t) cnt << 24)) : 0u;
       total += cnt;
       tsum += (unsigned long long) cnt * plen;
     }
@@ -288,85 +341,59 @@ __device__ __forceinline__ void match_rounds(const merge_args &A, const uint64_t
     res[r] = 0;
 }
 
+// One tile: T1 entries [a0, a0+n1) against the T2 window [b0, b0+n2) (self: one window, its entries [t_lo, t_hi) emit).
+// panels: the window is made of whole panels, those of prefixes p0 .. whose index entries sit in ix1 / ix2 (slot -1: the
+// entries before the tile); otherwise it is a stretch of ONE panel, and with `limit` (the stretch does not reach the panel's
+// end) only the T1 entries whose lower bound is at most n2 - margin are consumed (a prefix of them).  Returns their
+// number; lb_last = lower bound (window coordinates) of the last one.
 template <int MODE, int T2CAP>
-__device__ __forceinline__ int walk_tile(const merge_args &A, tile_lds<T2CAP> &S, uint8_t *cdyn, int64_t a0, int n1,
+__device__ __forceinline__ int walk_tile(const merge_args &A, tile_lds<T2CAP> &S, uint8_t *cdyn, const uint32_t *ix1,
+                                         const uint32_t *ix2, int p0, bool panels, int64_t a0, int n1,
                                          int64_t b0, int n2, int t_lo, int t_hi, bool limit, int margin, walk_out &O,
                                          int &lb_last)
 { const int lane = threadIdx.x;
-  const fga_view &V1 = A.v1, &V2 = A.v2;
-  const int cw1 = V1.cw, cw2 = V2.cw;
-  const int ob = (int) (b0 & 3), oa = (int) (a0 & 3);
-  const int64_t b0a = b0 - ob, a0a = a0 - oa;
-  uint64_t *keyB = S.keyB0 + 4 + ob;
-  uint32_t *pB = S.pB0 + ob, *pA = S.pA0 + oa;
-  uint8_t  *lcpB = S.lcpB0 + 8 + ob, *mB = S.mB0 + ob, *mA = S.mA0 + oa;
-  uint8_t  *cB0 = cdyn, *cA0 = cdyn + (size_t) (T2CAP + 8)*cw2;
-  uint8_t  *cB = cB0 + (size_t) ob*cw2, *cA = cA0 + (size_t) oa*cw1;
+  const int lane16 = lane*16;
+  const int cw1 = A.cw1, cw2 = A.cw2;
+  const int obk = (int) (b0 & 1), obp = (int) (b0 & 3), obc = (int) (b0 & 15), oap = (int) (a0 & 3), oac = (int) (a0 & 15);
+  uint64_t *keyB = S.keyB0 + obk;
+  uint32_t *pB = S.pB0 + obp, *pA = S.pA0 + oap;
+  uint8_t  *lcpB = S.lcpB0 + obc, *mB = S.mB0 + obc, *mA = S.mA0 + oac;
+  uint8_t  *cB0 = cdyn, *cA0 = cdyn + (size_t) (T2CAP + 32)*cw2;
+  uint8_t  *cB = cB0 + (size_t) obc*cw2, *cA = cA0 + (size_t) oac*cw1;
   uint32_t *own32 = (uint32_t *) S.keyB0;          // the emission reuses the key array (keys are done with by then)
 
   // 1. HBM -> LDS (global_load_lds): T2 keys, lcp bytes, payloads; T1 payloads.  T1 keys -> registers.
-  { const int m2 = n2 + ob;                          // staged T2 entries, from the 4-entry aligned start
-    const uint4 *gk = (const uint4 *) (V2.K + b0a);
-    uint4 *lk = (uint4 *) (S.keyB0 + 4);
-    for (int x = lane; 2*x < m2; x += 64)
-      G2L(gk + x,lk + x,16);
-    const uint4 *gp = (const uint4 *) (V2.P + b0a);
-    uint4 *lp = (uint4 *) S.pB0;
-    for (int x = lane; 4*x < m2; x += 64)
-      G2L(gp + x,lp + x,16);
-    const uint32_t *gl = (const uint32_t *) (V2.L + b0a);
-    uint32_t *ll = (uint32_t *) (S.lcpB0 + 8);
-    for (int x = lane; 4*x < m2 + 2; x += 64)        // two lcp bytes beyond the window are read (never used)
-      G2L(gl + x,ll + x,4);
-    const uint32_t *gc = (const uint32_t *) ((const uint8_t *) V2.C + (size_t) b0a*cw2);
-    uint32_t *lc = (uint32_t *) cB0;
-    for (int x = lane; 4*x < m2*cw2; x += 64)
-      G2L(gc + x,lc + x,4);
-    if (A.soft_mask)
-      { const uint32_t *gm = (const uint32_t *) (V2.M + b0a);
-        uint32_t *lm = (uint32_t *) S.mB0;
-        for (int x = lane; 4*x < m2; x += 64)
-          G2L(gm + x,lm + x,4);
-      }
-    if (MODE != MODE_SELF)
-      { const int m1 = n1 + oa;
-        const uint4 *gpa = (const uint4 *) (V1.P + a0a);
-        uint4 *lpa = (uint4 *) S.pA0;
-        for (int x = lane; 4*x < m1; x += 64)
-          G2L(gpa + x,lpa + x,16);
-        const uint32_t *gca = (const uint32_t *) ((const uint8_t *) V1.C + (size_t) a0a*cw1);
-        uint32_t *lca = (uint32_t *) cA0;
-        for (int x = lane; 4*x < m1*cw1; x += 64)
-          G2L(gca + x,lca + x,4);
-        if (A.soft_mask)
-          { const uint32_t *gma = (const uint32_t *) (V1.M + a0a);
-            uint32_t *lma = (uint32_t *) S.mA0;
-            for (int x = lane; 4*x < m1; x += 64)
-              G2L(gma + x,lma + x,4);
-          }
-      }
-  }
+  lds_fill(A.K2 + (b0 - obk),S.keyB0,(n2 + obk)*8,lane16);
+  lds_fill(A.P2 + (b0 - obp),S.pB0,(n2 + obp)*4,lane16);
+  lds_fill(A.L2 + (b0 - obc),S.lcpB0,n2 + obc + 2,lane16);              // two lcp bytes beyond the window are read (never used)
+  lds_fill(A.C2 + (size_t) (b0 - obc)*cw2,cB0,(n2 + obc)*cw2,lane16);
+  if (A.soft_mask)
+    lds_fill(A.M2 + (b0 - obc),S.mB0,n2 + obc,lane16);
   uint64_t k1[4];
-  #pragma unroll
-  for (int r = 0; r < 4; r++)
-    { const int i = r*64 + lane;
-      k1[r] = (MODE != MODE_SELF) ? V1.K[a0 + (i < n1 ? i : n1-1)] : 0;
+  if (MODE != MODE_SELF)
+    { lds_fill(A.P1 + (a0 - oap),S.pA0,(n1 + oap)*4,lane16);
+      lds_fill(A.C1 + (size_t) (a0 - oac)*cw1,cA0,(n1 + oac)*cw1,lane16);
+      if (A.soft_mask)
+        lds_fill(A.M1 + (a0 - oac),S.mA0,n1 + oac,lane16);
+      const uint64_t *kg = A.K1 + a0;
+      #pragma unroll
+      for (int r = 0; r < 4; r++)
+        { const int i = r*64 + lane;
+          k1[r] = kg[i < n1 ? i : n1-1];
+        }
     }
+  else
+    { k1[0] = k1[1] = k1[2] = k1[3] = 0; }
   // the direct-to-LDS loads are asynchronous and nothing below depends on a VGPR they return: wait for them by hand
+  XPROF(1)
   VM_WAIT();
   WSYNC();
-  // keys of no panel either side of the window (the real neighbours there may share the low prefix byte)
-  if (lane == 0)
-    { const uint64_t sent = keyB[0] ^ 0x8000000000000000ull;
-      keyB[-1] = sent; keyB[n2] = sent;
-      lcpB[n2] = 0; lcpB[n2+1] = 0;
-    }
-  WSYNC();
+  XPROF(2)
 
   // 2. which T1 entries this window can finish
   int na = (MODE == MODE_SELF) ? t_hi - t_lo : n1;
   if (MODE != MODE_SELF && limit)
-    { const uint64_t kl = keyB[n2 - margin];       // lower bound <= n2 - margin  <=>  key <= this one
+    { const uint64_t kl = keyB[n2 - margin];        // lower bound <= n2 - margin  <=>  key <= this one
       na = 0;
       #pragma unroll
       for (int r = 0; r < 4; r++)
@@ -378,16 +405,21 @@ __device__ __forceinline__ int walk_tile(const merge_args &A, tile_lds<T2CAP> &S
       return 0;
     }
 
-  // 3. match: result per round packed i (8 bits) | low << 8 | plen << 18 | seeds << 24
+  XPROF(3)
+  // 3. match: result per round packed i (8 bits; self: i - low) | low << 8 | plen << 18 | seeds << 24
   uint32_t res[4];
   int total = 0;
   { const int nr = (na + 63) >> 6;
-    if (nr == 1)      match_rounds<MODE,T2CAP,1>(A,keyB,lcpB,mA,mB,cB,k1,n2,na,t_lo,res,total,O.tsum,lb_last);
-    else if (nr == 2) match_rounds<MODE,T2CAP,2>(A,keyB,lcpB,mA,mB,cB,k1,n2,na,t_lo,res,total,O.tsum,lb_last);
-    else if (nr == 3) match_rounds<MODE,T2CAP,3>(A,keyB,lcpB,mA,mB,cB,k1,n2,na,t_lo,res,total,O.tsum,lb_last);
-    else              match_rounds<MODE,T2CAP,4>(A,keyB,lcpB,mA,mB,cB,k1,n2,na,t_lo,res,total,O.tsum,lb_last);
+    const uint32_t b32 = (uint32_t) b0;
+    const int plo = p0 & 0xff;
+    const uint32_t *ixq = (MODE == MODE_SELF) ? ix1 : ix2;
+    if (nr == 1)      match_rounds<MODE,1>(A,keyB,lcpB,mA,mB,cB,k1,ixq,b32,plo,panels,n2,na,t_lo,res,total,O.tsum,lb_last);
+    else if (nr == 2) match_rounds<MODE,2>(A,keyB,lcpB,mA,mB,cB,k1,ixq,b32,plo,panels,n2,na,t_lo,res,total,O.tsum,lb_last);
+    else if (nr == 3) match_rounds<MODE,3>(A,keyB,lcpB,mA,mB,cB,k1,ixq,b32,plo,panels,n2,na,t_lo,res,total,O.tsum,lb_last);
+    else              match_rounds<MODE,4>(A,keyB,lcpB,mA,mB,cB,k1,ixq,b32,plo,panels,n2,na,t_lo,res,total,O.tsum,lb_last);
   }
 
+  XPROF(4)
   // 4. slots and emission
   int T;
   int off = wave_excl_scan_add_dpp(total,T);
@@ -396,11 +428,11 @@ __device__ __forceinline__ int walk_tile(const merge_args &A, tile_lds<T2CAP> &S
       int64_t nbase = 0, nsize = 0;
       if ((int64_t) T > rem)
         { nsize = (((int64_t) T - rem) + FGA_SEED_BLOCK-1) & ~(int64_t) (FGA_SEED_BLOCK-1);    // whole blocks, block aligned
-          unsigned long long b = 0;
+          unsigned long long bb = 0;
           if (lane == 0)
-            b = atomicAdd(A.count,(unsigned long long) nsize);
-          const uint32_t blo = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) b);
-          const uint32_t bhi = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (b >> 32));
+            bb = atomicAdd(A.count,(unsigned long long) nsize);
+          const uint32_t blo = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) bb);
+          const uint32_t bhi = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (bb >> 32));
           nbase = (int64_t) (((uint64_t) bhi << 32) | blo);
         }
       // Seed-parallel, in windows of EWIN slots: every entry with seeds in the window leaves a descriptor at its first
@@ -437,9 +469,10 @@ __device__ __forceinline__ int walk_tile(const merge_args &A, tile_lds<T2CAP> &S
               if (slot < wn)
                 { const int start = v-1;
                   const uint32_t d = own32[start];
-                  const int i = (int) (d & 0xff), plen = (int) ((d >> 18) & 0x3f);
+                  const int plen = (int) ((d >> 18) & 0x3f);
                   int k = (slot - start) + (int) (d >> 24);
                   int j = (int) ((d >> 8) & 0x3ff);
+                  const int i = (int) (d & 0xff) + (MODE == MODE_SELF ? j : 0);      // self: stored relative to the run's start
                   if (plain)
                     { j += k;
                       if (MODE == MODE_SELF && j >= i)
@@ -477,82 +510,115 @@ __device__ __forceinline__ int walk_tile(const merge_args &A, tile_lds<T2CAP> &S
         O.chunk_pos += T;
     }
   WSYNC();      // the tile buffers are reused by the next tile
+  XPROF(5)
   return na;
 }
 
 template <int MODE, int T2CAP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(T2CAP == 256 ? WAVE_OCC : 2,T2CAP == 256 ? WAVE_OCC : 2)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(T2CAP == 512 ? WAVE_OCC : 2,T2CAP == 512 ? WAVE_OCC : 2)))
 void seed_merge_walk_kernel(merge_args A)
 { __shared__ __attribute__((aligned(16))) tile_lds<T2CAP> S;
-  extern __shared__ __attribute__((aligned(16))) uint8_t cdyn[];     // contig|sign words of both sides: (T2CAP+8) cw2 + (T1CAP+8) cw1 bytes
+  extern __shared__ __attribute__((aligned(16))) uint8_t cdyn[];     // contig|sign words of both sides: (T2CAP+32) cw2 + (T1CAP+32) cw1 bytes
 
   const int lane = threadIdx.x;
-  const uint32_t *idx1 = A.v1.idx, *idx2 = (MODE == MODE_SELF) ? A.v1.idx : A.v2.idx;
+  const uint32_t *idx1 = A.idx1, *idx2 = (MODE == MODE_SELF) ? A.idx1 : A.idx2;
   const int margin = A.freq + 2;
   walk_out O;
   O.chunk_pos = O.chunk_end = 0; O.tsum = 0;
+#ifdef MERGE_PROF
+  O.pt = clock64();
+  for (int k = 0; k < 8; k++) O.pa[k] = 0;
+#endif
 
+  // Ranges come off eight queues, one per XCD (workgroup b runs on XCD b mod 8; range shard + 8 k is the k-th of its
+  // shard): one counter word sustains only ~88 atomics per microsecond, and a wavefront's request for its next range is
+  // in flight while it works on the current one.  The big ranges come first, the launch ends on the small ones.
+  const int shard = (int) (blockIdx.x & 7);
+  int knext = 0;
+  if (lane == 0)
+    knext = atomicAdd(A.next + shard,1);
   for (;;)
-    { int r = 0;
-      if (lane == 0)
-        r = atomicAdd(A.next,1);
-      r = __builtin_amdgcn_readfirstlane(r);
+    { const int r = shard + 8*__builtin_amdgcn_readfirstlane(knext);
       if (r >= A.nranges)
         break;
+      if (lane == 0)
+        knext = atomicAdd(A.next + shard,1);
       int p = (int) A.cuts[r];
       const int pe = (int) A.cuts[r+1];
       if (p >= pe)
         continue;
-      uint32_t a = p > 0 ? idx1[p-1] : 0u, b = p > 0 ? idx2[p-1] : 0u;
-      // Index entries of the next 64 prefixes, one per lane (clamped at the range end).  They are fetched one tile
+      int u = 0;                                     // index buffer in use
+      // Index entries of the next XPC prefixes, two per lane (clamped at the range end).  They are fetched one tile
       // ahead and travel HBM -> LDS like the tile data, not into registers: a register result would make the compiler
       // wait for ALL outstanding vector-memory operations where the loop uses it, i.e. for the acknowledgements of the
       // seed stores the tile before has just issued.  Their arrival is covered by the tile's own wait for its data
       // (issued after them, completed in order); the reads below are opaque to the compiler for the same reason.
-#define IDX_ISSUE(P0)                                                                                                \
-      { const int64_t e_ = (P0) + (lane < pe-(P0) ? lane : pe-(P0)-1);                                                  \
-        G2L(idx1 + e_,&S.ixs[0][lane],4);                                                                              \
+#define IDX_ISSUE(P0,U)                                                                                              \
+      { const int last_ = pe-(P0)-1;                                                                                   \
+        const int64_t e0_ = (P0) + (lane < last_ ? lane : last_), e1_ = (P0) + (lane+64 < last_ ? lane+64 : last_);    \
+        G2L(idx1 + e0_,&S.ixs[U][0][4 + lane],4);                                                                      \
+        G2L(idx1 + e1_,&S.ixs[U][0][68 + lane],4);                                                                     \
         if (MODE != MODE_SELF)                                                                                         \
-          G2L(idx2 + e_,&S.ixs[1][lane],4);                                                                            \
+          { G2L(idx2 + e0_,&S.ixs[U][1][4 + lane],4);                                                                  \
+            G2L(idx2 + e1_,&S.ixs[U][1][68 + lane],4);                                                                 \
+          }                                                                                                            \
       }
-      IDX_ISSUE(p)
+      IDX_ISSUE(p,0)
+      uint32_t a = p > 0 ? idx1[p-1] : 0u, b = p > 0 ? idx2[p-1] : 0u;
       VM_WAIT();
       while (p < pe)
-        { uint32_t ca, cb;
-          { const uint32_t at = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint32_t *) &S.ixs[0][lane];
-            uint64_t v;
-            asm volatile("ds_read2st64_b32 %0, %1 offset1:1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(at) : "memory");
-            ca = (uint32_t) v;
-            cb = (MODE == MODE_SELF) ? ca : (uint32_t) (v >> 32);
+        { uint32_t ca0, ca1, cb0, cb1;
+          { const uint32_t at = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint32_t *) &S.ixs[u][0][4 + lane];
+            uint64_t va, vb;
+            if (MODE == MODE_SELF)
+              { asm volatile("ds_read2st64_b32 %0, %1 offset1:1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(va) : "v"(at) : "memory");
+                vb = va;
+              }
+            else
+              asm volatile("ds_read2st64_b32 %0, %2 offset1:1\n\tds_read2st64_b32 %1, %3 offset1:1\n\ts_waitcnt lgkmcnt(0)"
+                           : "=&v"(va), "=&v"(vb) : "v"(at), "v"(at + 4*(XPC+4)) : "memory");
+            ca0 = (uint32_t) va; ca1 = (uint32_t) (va >> 32);
+            cb0 = (uint32_t) vb; cb1 = (uint32_t) (vb >> 32);
           }
           const int navail = pe - p < XPC ? pe - p : XPC;
-          // whole panels that fit a tile; a tile stays inside one block of 256 prefixes (key order = k-mer order)
-          const bool fits = lane < navail && (ca - a) <= (uint32_t) T1CAP && (cb - b) <= (uint32_t) (MODE == MODE_SELF ? T1CAP : T2CAP)
-                            && ((p + lane) >> 8) == (p >> 8);
-          const int q = __popcll(__builtin_amdgcn_ballot_w64(fits));     // the conditions are monotone in the lane: a prefix mask
+          // whole panels that fit a tile
+          const uint32_t cap2 = (MODE == MODE_SELF) ? T1CAP : T2CAP;
+          const bool fit0 = lane < navail && (ca0 - a) <= (uint32_t) T1CAP && (cb0 - b) <= cap2;
+          const bool fit1 = lane + 64 < navail && (ca1 - a) <= (uint32_t) T1CAP && (cb1 - b) <= cap2;
+          int q = __popcll(__builtin_amdgcn_ballot_w64(fit0));          // the conditions are monotone in the prefix: prefix masks
+          if (q == 64)
+            q += __popcll(__builtin_amdgcn_ballot_w64(fit1));
           const int adv = q > 0 ? q : 1;
-          const uint32_t a1 = (uint32_t) __builtin_amdgcn_readlane((int) ca,adv-1);
-          const uint32_t b1 = (uint32_t) __builtin_amdgcn_readlane((int) cb,adv-1);
+          uint32_t a1, b1;
+          if (adv <= 64)
+            { a1 = (uint32_t) __builtin_amdgcn_readlane((int) ca0,adv-1); b1 = (uint32_t) __builtin_amdgcn_readlane((int) cb0,adv-1); }
+          else
+            { a1 = (uint32_t) __builtin_amdgcn_readlane((int) ca1,adv-65); b1 = (uint32_t) __builtin_amdgcn_readlane((int) cb1,adv-65); }
           const int64_t n1 = (int64_t) a1 - a, n2 = (int64_t) b1 - b;
+          // the entries before the tile, for the panel bounds of its keys
+          if (lane == 0)
+            { S.ixs[u][0][3] = a; S.ixs[u][1][3] = b; }
           // the index entries of the tile after this one are on their way while this one is processed
           const int pn = p + adv;
           if (pn < pe)
-            IDX_ISSUE(pn)
+            IDX_ISSUE(pn,u^1)
+          XPROF(0)
+          const uint32_t *ix1 = &S.ixs[u][0][4], *ix2 = &S.ixs[u][1][4];
           bool tiled = false;
           if (n1 > 0 && n2 > 0)
             { int lbl;
               if (q > 0)
-                { walk_tile<MODE,T2CAP>(A,S,cdyn,a,(int) n1,b,(int) n2,0,(int) n1,false,margin,O,lbl);
+                { walk_tile<MODE,T2CAP>(A,S,cdyn,ix1,ix2,p,true,a,(int) n1,b,(int) n2,0,(int) n1,false,margin,O,lbl);
                   tiled = true;
                 }
               else if (MODE == MODE_SELF)
                 { // one oversize panel against itself: runs of T1 entries with `margin` neighbours either side
-                  const int C = T1CAP - 2*margin;
+                  const int C = (T2CAP - 2*margin) < T1CAP ? (T2CAP - 2*margin) : T1CAP;
                   for (int64_t i0 = 0; i0 < n1; i0 += C)
                     { const int64_t i1 = i0 + C < n1 ? i0 + C : n1;
                       const int64_t s0 = i0 - margin > 0 ? i0 - margin : 0, s1 = i1 + margin < n1 ? i1 + margin : n1;
-                      walk_tile<MODE,T2CAP>(A,S,cdyn,a+s0,(int) (s1-s0),a+s0,(int) (s1-s0),(int) (i0-s0),(int) (i1-s0),
-                                            false,margin,O,lbl);
+                      walk_tile<MODE,T2CAP>(A,S,cdyn,ix1,ix2,p,false,a+s0,(int) (s1-s0),a+s0,(int) (s1-s0),(int) (i0-s0),
+                                            (int) (i1-s0),false,margin,O,lbl);
                     }
                   tiled = true;
                 }
@@ -564,18 +630,17 @@ void seed_merge_walk_kernel(merge_args A)
                     { const int n1w = (int) (ae - aw < T1CAP ? ae - aw : T1CAP);
                       const int n2w = (int) (be - bw < T2CAP ? be - bw : T2CAP);
                       const bool limit = bw + n2w < be;
-                      const int na = walk_tile<MODE,T2CAP>(A,S,cdyn,aw,n1w,bw,n2w,0,n1w,limit,margin,O,lbl);
+                      const int na = walk_tile<MODE,T2CAP>(A,S,cdyn,ix1,ix2,p,false,aw,n1w,bw,n2w,0,n1w,limit,margin,O,lbl);
                       if (na == 0)
                         { // no T1 key within reach of this window: find where the next one lands
-                          const uint64_t kq = A.v1.K[aw];
-                          int64_t l = wave_lower_bound(A.v2.K,bw + n2w - margin,be,kq) - margin;
+                          const uint64_t kq = A.K1[aw];
+                          int64_t l = wave_lower_bound(A.K2,bw + n2w - margin,be,kq) - margin;
                           if (l <= bw) l = bw + 1;
                           bw = l;
-                          if (bw >= be) break;                    // cannot happen: the last window has no limit
                           continue;
                         }
                       aw += na;
-                      int64_t nbw = bw + lbl - margin;
+                      const int64_t nbw = bw + lbl - margin;
                       if (nbw > bw) bw = nbw;
                     }
                   tiled = true;
@@ -583,25 +648,31 @@ void seed_merge_walk_kernel(merge_args A)
             }
           if (!tiled)                                          // no tile, no wait of a tile: the index entries may be on their way
             VM_WAIT();
-          a = a1; b = b1; p = pn;
+          a = a1; b = b1; p = pn; u ^= 1;
         }
 #undef IDX_ISSUE
     }
 
+  const merge_cold cold = *A.cold;
   if (O.chunk_end > O.chunk_pos)                       // the unused tail of the last chunk stays open: its blocks say so
     { const int64_t b0 = O.chunk_pos >> 10, b1 = (O.chunk_end - 1) >> 10;
       for (int64_t bk = b0 + lane; bk <= b1; bk += 64)
-        if (bk < A.nblocks)
-          A.valid[bk] = (uint16_t) (bk == b0 ? (O.chunk_pos & (FGA_SEED_BLOCK-1)) : 0);
+        if (bk < cold.nblocks)
+          cold.valid[bk] = (uint16_t) (bk == b0 ? (O.chunk_pos & (FGA_SEED_BLOCK-1)) : 0);
       if (lane == 0)
-        atomicAdd(A.hslots,(unsigned long long) (O.chunk_end - O.chunk_pos));
+        atomicAdd(cold.hslots,(unsigned long long) (O.chunk_end - O.chunk_pos));
     }
+#ifdef MERGE_PROF
+  XPROF(6)
+  if (lane == 0)
+    for (int k = 0; k < 8; k++) atomicAdd(merge_prof+k,O.pa[k]);
+#endif
   unsigned long long tsum = O.tsum;
   #pragma unroll
   for (int d = 32; d >= 1; d >>= 1)
     tsum += __shfl_xor(tsum,d,64);
   if (lane == 0 && tsum != 0)
-    atomicAdd(A.tseed,tsum);
+    atomicAdd(cold.tseed,tsum);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -651,8 +722,9 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
 
   merge_args A;
   memset(&A,0,sizeof(A));
-  A.v1 = (mode == MODE_PAIR) ? t1->fview : t1->view;
-  A.v2 = t2->view;
+  const fga_view &v1 = (mode == MODE_PAIR) ? t1->fview : t1->view, &v2 = t2->view;
+  A.K1 = v1.K; A.P1 = v1.P; A.C1 = (const uint8_t *) v1.C; A.M1 = v1.M; A.idx1 = v1.idx; A.cw1 = v1.cw;
+  A.K2 = v2.K; A.P2 = v2.P; A.C2 = (const uint8_t *) v2.C; A.M2 = v2.M; A.idx2 = v2.idx; A.cw2 = v2.cw; A.L2 = v2.L;
   A.sign1 = 0x80u << (8*(t1->contbytes-1)); A.sign2 = 0x80u << (8*(t2->contbytes-1));
   A.freq = prm->freq; A.soft_mask = prm->soft_mask;
   // prefix range: (0,0) = everything; an empty range elsewhere is an empty shard (prefix cuts of a low-complexity input)
@@ -661,20 +733,20 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
   if (pe > FGA_NPREFIX) pe = FGA_NPREFIX;
   if (pb == 0 && pe <= 0) pe = FGA_NPREFIX;
   const bool empty = pb >= pe;
-  A.pbeg = (int) pb; A.pend = (int) (empty ? pb : pe);
+  const int pbeg = (int) pb, pend = (int) (empty ? pb : pe);
 
   // cost at both ends of the prefix range (4 tiny D2H copies)
   uint32_t c1e = 0, c2e = 0, c1b = 0, c2b = 0;
   if (!empty)
-    { FGA_HIP(hipMemcpy(&c1e,A.v1.idx + (A.pend-1),4,hipMemcpyDeviceToHost));
-      FGA_HIP(hipMemcpy(&c2e,A.v2.idx + (A.pend-1),4,hipMemcpyDeviceToHost));
-      if (A.pbeg > 0)
-        { FGA_HIP(hipMemcpy(&c1b,A.v1.idx + (A.pbeg-1),4,hipMemcpyDeviceToHost));
-          FGA_HIP(hipMemcpy(&c2b,A.v2.idx + (A.pbeg-1),4,hipMemcpyDeviceToHost));
+    { FGA_HIP(hipMemcpy(&c1e,v1.idx + (pend-1),4,hipMemcpyDeviceToHost));
+      FGA_HIP(hipMemcpy(&c2e,v2.idx + (pend-1),4,hipMemcpyDeviceToHost));
+      if (pbeg > 0)
+        { FGA_HIP(hipMemcpy(&c1b,v1.idx + (pbeg-1),4,hipMemcpyDeviceToHost));
+          FGA_HIP(hipMemcpy(&c2b,v2.idx + (pbeg-1),4,hipMemcpyDeviceToHost));
         }
     }
-  A.base = (int64_t) c1b + c2b + 2*(int64_t) A.pbeg;
-  const int64_t total = ((int64_t) c1e + c2e + 2*(int64_t) A.pend) - A.base;
+  const int64_t base = (int64_t) c1b + c2b + 2*(int64_t) pbeg;
+  const int64_t total = ((int64_t) c1e + c2e + 2*(int64_t) pend) - base;
 
   fga_dseeds *S = append;
   if (S == NULL)
@@ -705,7 +777,7 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
     }
   else
     { const int64_t nb = (S->phys_capacity + FGA_SEED_BLOCK-1) / FGA_SEED_BLOCK + 2;
-      if ((err = hipMalloc(&counters,8*sizeof(unsigned long long))) != hipSuccess ||
+      if ((err = hipMalloc(&counters,12*sizeof(unsigned long long))) != hipSuccess ||
           (S->seeds = (fga_seed *) fga_dev_acquire(dev,SLOT_SEEDS,sizeof(fga_seed)*(size_t) S->phys_capacity)) == NULL ||
           (S->valid = (uint16_t *) fga_dev_acquire(dev,SLOT_VALID,sizeof(uint16_t)*(size_t) nb)) == NULL)
         { fga_set_error("fga_seed_merge: device allocation failed: %s",hipGetErrorString(err));
@@ -718,8 +790,20 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
       hipMemsetD16Async((hipDeviceptr_t) S->valid,(unsigned short) FGA_SEED_BLOCK,(size_t) nb,dev->stream);
     }
   A.out = S->seeds; A.cap = phys;
-  A.count = counters; A.tseed = counters+1; A.hslots = counters+2;
-  A.valid = S->valid; A.nblocks = (S->phys_capacity + FGA_SEED_BLOCK-1) / FGA_SEED_BLOCK + 2;
+  A.count = counters;
+  { merge_cold cold;                                   // what the wavefronts read once, at their end: behind the counters
+    cold.tseed = counters+1; cold.hslots = counters+2;
+    cold.valid = S->valid; cold.nblocks = (S->phys_capacity + FGA_SEED_BLOCK-1) / FGA_SEED_BLOCK + 2;
+    static_assert(sizeof(merge_cold) <= 4*sizeof(unsigned long long),"cold arguments live in counters[8..11]");
+    if ((err = hipMemcpyAsync(counters+8,&cold,sizeof(cold),hipMemcpyHostToDevice,dev->stream)) != hipSuccess ||
+        (err = hipStreamSynchronize(dev->stream)) != hipSuccess)        // `cold` is on this stack frame
+      { fga_set_error("fga_seed_merge: upload failed: %s",hipGetErrorString(err));
+        if (append == NULL)
+          { hipFree(counters); fga_dev_release(dev,SLOT_SEEDS,S->seeds); fga_dev_release(dev,SLOT_VALID,S->valid); free(S); }
+        return 1;
+      }
+    A.cold = (const merge_cold *) (counters+8);
+  }
 
   int rc = 1;
   int64_t hslots = 0;
@@ -730,23 +814,25 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
   dev->last_ms[FGA_STAGE_MERGE] = dev->last_ms[FGA_STAGE_MERGE_PARTITION] = 0.f;
   if (!empty)
     { // the sub-tile margin FREQ+2 must leave room in a window: the wide-window build takes over for large cutoffs
-      const bool wide = 2*(prm->freq + 2) > 256 - 64;
-      const int t2cap = wide ? 1024 : 256;
-      const size_t dyn = (size_t) (t2cap + 8)*A.v2.cw + (size_t) (T1CAP + 8)*A.v1.cw + 16;
+      const bool wide = 2*(prm->freq + 2) > 512 - 128;
+      const int t2cap = wide ? 1024 : 512;
+      const size_t dyn = (size_t) (t2cap + 32)*A.cw2 + (size_t) (T1CAP + 32)*A.cw1 + 16;
       // every wavefront of the launch is resident (they are persistent): as many as the LDS of a CU holds, at most the
       // register budget's
-      const size_t lds = ((wide ? sizeof(tile_lds<1024>) : sizeof(tile_lds<256>)) + dyn + 511) / 512 * 512;
-      int per_cu = (int) ((160*1024) / lds);
+      const size_t lds = ((wide ? sizeof(tile_lds<1024>) : sizeof(tile_lds<512>)) + dyn + 2047) / 2048 * 2048;
+      int per_cu = (int) ((160*1024) / lds) - 1;       // measured: 13 x 11.6 KB are not all resident
       const int fit = per_cu;
-      const int occ = wide ? 8 : 4*WAVE_OCC;
+      const int occ = wide ? 8 : 10;                   // measured optimum (8: -7 %, 12: -4 %)
       if (per_cu > occ) per_cu = occ;
       { const char *ev = getenv("FGA_MERGE_WAVES");
         if (ev != NULL && atoi(ev) > 0 && atoi(ev) <= fit && atoi(ev) <= 28) per_cu = atoi(ev);     // phys_capacity's slack covers 32 per CU
       }
       int grid = dev->ncu * per_cu;
-      // ranges of equal merge cost, a few per wavefront, taken off a queue
-      int nranges = grid*RANGES_PER_WAVE;
-      if ((int64_t) nranges > total/2048 + 1) nranges = (int) (total/2048) + 1;
+      // ranges off the queues: two big ones per wavefront over the first five eighths of the cost, six small ones over the rest
+      int nbig = grid*2, nranges = grid*8;
+      if ((int64_t) nranges > total/2048 + 1)
+        { nranges = (int) (total/2048) + 1; nbig = nranges/4; }
+      if (nbig < 1) { nbig = 1; if (nranges < 2) nranges = 2; }
       if (grid > nranges) grid = nranges;
       work = fga_dev_acquire(dev,SLOT_TILES,sizeof(int64_t)*(size_t) (nranges+2) + 64);
       if (work == NULL)
@@ -756,13 +842,13 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
       int64_t *cuts = (int64_t *) work;
       int *qhead = (int *) (counters + 4);
       A.cuts = cuts; A.nranges = nranges; A.next = qhead;
-      hipMemsetAsync(qhead,0,sizeof(unsigned long long),dev->stream);
+      hipMemsetAsync(qhead,0,8*sizeof(int),dev->stream);
       hipEventRecord(dev->ev0,dev->stream);
       hipLaunchKernelGGL(range_cut_kernel,dim3((nranges+1+255)/256),dim3(256),0,dev->stream,
-                         A.v1.idx,A.v2.idx,A.pbeg,A.pend,A.base,total,nranges,cuts);
+                         A.idx1,A.idx2,pbeg,pend,base,total,nranges,nbig,cuts);
       hipEventRecord(dev->ev1,dev->stream);
       if (wide) launch_walk<1024>(mode,grid,dyn,dev->stream,A);
-      else      launch_walk<256>(mode,grid,dyn,dev->stream,A);
+      else      launch_walk<512>(mode,grid,dyn,dev->stream,A);
       hipEventRecord(ev2,dev->stream);
     }
   // one round trip: the three counters
@@ -786,6 +872,16 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
       // the merge stage = everything the launch runs: range cuts and the walk kernel
       hipEventElapsedTime(&dev->last_ms[FGA_STAGE_MERGE],dev->ev0,ev2);
     }
+#ifdef MERGE_PROF
+  { unsigned long long hp[8], z[8] = {0,0,0,0,0,0,0,0};
+    hipMemcpyFromSymbol(hp,HIP_SYMBOL(merge_prof),sizeof(hp));
+    hipMemcpyToSymbol(HIP_SYMBOL(merge_prof),z,sizeof(z));
+    double tot = 0; for (int k = 0; k < 8; k++) tot += (double) hp[k];
+    if (tot > 0)
+      fprintf(stderr,"merge phases (%% of wave cycles): tile select %.1f  load issue %.1f  load wait %.1f  window %.1f  match %.1f  emit %.1f  rest %.1f   (%.0f Mcycles)\n",
+              100*hp[0]/tot,100*hp[1]/tot,100*hp[2]/tot,100*hp[3]/tot,100*hp[4]/tot,100*hp[5]/tot,100*hp[6]/tot,tot*1e-6);
+  }
+#endif
   S->phys_count = (int64_t) hc[0];
   S->count  = (int64_t) hc[0] - hslots;
   S->tseed  = (int64_t) hc[1];
