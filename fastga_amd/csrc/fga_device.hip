@@ -1,5 +1,6 @@
 // fga_device.hip -- device context, index upload, seed buffers (C-ABI of include/fastga_amd.h).
 #include "fga_device.hpp"
+#include <stdio.h>
 
 extern "C" int fga_dev_open(int device, fga_dev **out)
 { *out = NULL;
@@ -52,10 +53,26 @@ extern "C" size_t fga_dev_available(fga_dev *dev)
   return fr;
 }
 
+// FGA_TIMING=1: wall-clock notes on stderr (allocations of a GB and more, the steps of an index build): where a
+// human-scale run spends its host time
+extern "C" void fga_note(const char *what, double since)
+{ static int on = -1;
+  if (on < 0) on = getenv("FGA_TIMING") != NULL && atoi(getenv("FGA_TIMING")) != 0;
+  if (on)
+    fprintf(stderr,"[fga timing] %-40s %9.1f ms\n",what,1e3*(fga_wall() - since));
+}
+
 static void *alloc_or_trim(fga_dev *dev, size_t bytes)
 { void *p = NULL;
+  const double t0 = fga_wall();
   if (hipMalloc(&p,bytes) == hipSuccess)
-    return p;
+    { if (bytes >= ((size_t) 1 << 30))
+        { char what[64];
+          snprintf(what,sizeof(what),"hipMalloc %.1f GB",bytes*1e-9);
+          fga_note(what,t0);
+        }
+      return p;
+    }
   (void) hipGetLastError();
   fga_dev_trim(dev);                        // give the idle slots back and try once more
   if (hipMalloc(&p,bytes) == hipSuccess)
@@ -69,16 +86,31 @@ void *fga_dev_acquire(fga_dev *dev, int slot, size_t bytes)
   if (slot < 0 || slot >= SLOT_COUNT || dev->slot_busy[slot])
     return alloc_or_trim(dev,bytes);        // slot taken (or none asked): a private allocation
   if (dev->slot_ptr[slot] == NULL || dev->slot_bytes[slot] < bytes)
-    { if (dev->slot_ptr[slot] != NULL)
-        hipFree(dev->slot_ptr[slot]);
-      dev->slot_ptr[slot] = NULL; dev->slot_bytes[slot] = 0;
-      size_t slack = bytes/8;               // room to grow without a new allocation, bounded: a 50 GB buffer does not get 6 GB of it
-      if (slack > ((size_t) 256 << 20)) slack = (size_t) 256 << 20;
-      size_t want = bytes + slack;
-      dev->slot_ptr[slot] = alloc_or_trim(dev,want);
-      if (dev->slot_ptr[slot] == NULL)
-        return NULL;
-      dev->slot_bytes[slot] = want;
+    { // another idle slot may hold a buffer that is large enough (the index builder's key buffers, the undivided seed
+      // buffer of a multi-pass run): take it over instead of freeing / allocating tens of GB -- a hipMalloc that follows
+      // the hipFree of such a buffer has been measured at 1-3 s
+      int best = -1;
+      for (int q = 0; q < SLOT_COUNT; q++)
+        if (q != slot && !dev->slot_busy[q] && dev->slot_ptr[q] != NULL && dev->slot_bytes[q] >= bytes &&
+            (best < 0 || dev->slot_bytes[q] < dev->slot_bytes[best]))
+          best = q;
+      if (best >= 0 && bytes >= ((size_t) 64 << 20))
+        { void *tp = dev->slot_ptr[slot]; size_t tb = dev->slot_bytes[slot];
+          dev->slot_ptr[slot] = dev->slot_ptr[best]; dev->slot_bytes[slot] = dev->slot_bytes[best];
+          dev->slot_ptr[best] = tp; dev->slot_bytes[best] = tb;
+        }
+      else
+        { if (dev->slot_ptr[slot] != NULL)
+            hipFree(dev->slot_ptr[slot]);
+          dev->slot_ptr[slot] = NULL; dev->slot_bytes[slot] = 0;
+          size_t slack = bytes/8;               // room to grow without a new allocation, bounded: a 50 GB buffer does not get 6 GB of it
+          if (slack > ((size_t) 256 << 20)) slack = (size_t) 256 << 20;
+          size_t want = bytes + slack;
+          dev->slot_ptr[slot] = alloc_or_trim(dev,want);
+          if (dev->slot_ptr[slot] == NULL)
+            return NULL;
+          dev->slot_bytes[slot] = want;
+        }
     }
   dev->slot_busy[slot] = 1;
   return dev->slot_ptr[slot];
@@ -104,6 +136,17 @@ void *fga_dev_pinned(fga_dev *dev, size_t bytes)
     }
   return dev->pinned;
 }
+
+extern "C" void *fga_dev_stage_acquire(fga_dev *dev, size_t bytes)
+{ if (hipSetDevice(dev->device) != hipSuccess) return NULL;
+  void *p = fga_dev_acquire(dev,SLOT_STAGE,bytes);
+  if (p == NULL)
+    fga_set_error("device allocation of %zu bytes (seed staging) failed",bytes);
+  return p;
+}
+
+extern "C" void fga_dev_stage_release(fga_dev *dev, void *ptr)
+{ fga_dev_release(dev,SLOT_STAGE,ptr); }
 
 extern "C" int fga_dev_malloc(fga_dev *dev, size_t bytes, void **out)
 { *out = NULL;

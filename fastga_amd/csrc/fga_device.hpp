@@ -74,7 +74,7 @@ void fga_dgix_free_views(fga_dgix *D);
 //   actg       : A contig (length-sorted index) << 8 | plen
 //   bctg       : B contig | (B entry's own sign bit) << 30 | (C-stream flag) << 31
 enum { SLOT_SEEDS = 0, SLOT_SORT0, SLOT_SORT1, SLOT_HIST, SLOT_TILES, SLOT_CELLS, SLOT_TRACE, SLOT_ALNS,
-       SLOT_TBYTES, SLOT_MISC, SLOT_VALID, SLOT_COUNT };
+       SLOT_TBYTES, SLOT_MISC, SLOT_VALID, SLOT_STAGE, SLOT_COUNT };
 void *fga_dev_acquire(fga_dev *dev, int slot, size_t bytes);   // NULL on failure; pair with fga_dev_release
 void  fga_dev_release(fga_dev *dev, int slot, void *ptr);
 void *fga_dev_pinned(fga_dev *dev, size_t bytes);              // host pinned staging, grow-only

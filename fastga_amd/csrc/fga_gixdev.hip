@@ -319,6 +319,7 @@ extern "C" int fga_dgix_build(fga_dev *dev, const fga_gdb *G, int nthreads, int 
   int64_t cap = 0, nkeys = 0;
   hipError_t e = hipSuccess;
   float ms = 0.f;
+  double tn = 0.;
 
   if (postbytes + contbytes > 6)
     { fga_set_error("fga_dgix_build: payload of %d bytes does not fit the 128-bit sort key (use fga_gix_build)",
@@ -366,6 +367,7 @@ extern "C" int fga_dgix_build(fga_dev *dev, const fga_gdb *G, int nthreads, int 
       goto done;
     }
 
+  tn = fga_wall();
   hipEventRecord(dev->ev0,dev->stream);
   { gix_scan_args A;
     A.img = dimg; A.boff = dboff; A.clen = dclen; A.invp = dinvp;
@@ -429,6 +431,7 @@ extern "C" int fga_dgix_build(fga_dev *dev, const fga_gdb *G, int nthreads, int 
     hipStreamSynchronize(dev->stream);
   }
 
+  fga_note("index build: uploads + syncmer scan",tn); tn = fga_wall();
   { const int bits = 80 + 8*(postbytes+contbytes);
     const int npass = (bits + 7) / 8;
     if (fga_radix_sort_u128(dev,buf0,buf1,nkeys,128 - 8*npass,8*npass,&sorted))
@@ -484,6 +487,7 @@ extern "C" int fga_dgix_build(fga_dev *dev, const fga_gdb *G, int nthreads, int 
       }
     hipEventElapsedTime(&ms,dev->ev0,dev->ev1);
     dev->last_ms[FGA_STAGE_GIX] = ms;
+    fga_note("index build: sort + index + entries",tn); tn = fga_wall();
 
     X = (fga_gix *) calloc(1,sizeof(fga_gix));
     if (X == NULL) { fga_set_error("out of memory"); goto done; }
@@ -521,6 +525,7 @@ extern "C" int fga_dgix_build(fga_dev *dev, const fga_gdb *G, int nthreads, int 
     // the merge kernel's view of the table; the on-disk bytes leave the device
     if (fga_dgix_make_view(dev,D,0))
       goto done;
+    fga_note("index build: view",tn);
   }
   status = 0;
 

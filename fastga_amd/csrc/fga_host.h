@@ -107,7 +107,11 @@ int      fga_gix_write_files(const fga_gix *X, const char *target);
 /* device context internals the host pipeline uses (fga_device.hip) */
 struct fga_dev;
 void   fga_dev_trim(struct fga_dev *dev);          /* idle workspace slots back to the device        */
+void  *fga_dev_stage_acquire(struct fga_dev *dev, size_t bytes);   /* the per-part staging buffer of a multi-pass run (a workspace slot) */
+void   fga_dev_stage_release(struct fga_dev *dev, void *ptr);
 size_t fga_dev_available(struct fga_dev *dev);     /* free device memory + what the idle slots hold  */
+
+void   fga_note(const char *what, double since);   /* FGA_TIMING=1: elapsed wall time since `since` on stderr */
 
 /* small helpers */
 char *fga_path_dir(const char *path);                       /* malloc'd directory part ("." if none) */

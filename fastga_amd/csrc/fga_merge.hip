@@ -822,7 +822,7 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
       const size_t lds = ((wide ? sizeof(tile_lds<1024>) : sizeof(tile_lds<512>)) + dyn + 2047) / 2048 * 2048;
       int per_cu = (int) ((160*1024) / lds) - 1;       // measured: 13 x 11.6 KB are not all resident
       const int fit = per_cu;
-      const int occ = wide ? 8 : 10;                   // measured optimum (8: -7 %, 12: -4 %)
+      const int occ = wide ? 8 : 12;                   // measured: 10-12 at 100 Mbp (8: -7 %), 12-13 at 3 Gbp
       if (per_cu > occ) per_cu = occ;
       { const char *ev = getenv("FGA_MERGE_WAVES");
         if (ev != NULL && atoi(ev) > 0 && atoi(ev) <= fit && atoi(ev) <= 28) per_cu = atoi(ev);     // phys_capacity's slack covers 32 per CU

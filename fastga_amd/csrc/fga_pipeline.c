@@ -85,8 +85,8 @@ int fga_session_open_threads(const char *root1, const char *root2, int device, i
     if (!Z->self && (have2 ? fga_dgix_upload(Z->dev,Z->x2,&Z->d2)
                            : fga_dgix_build(Z->dev,Z->g2,nthreads,FGA_GIX_SOFT_MASK,&Z->d2,&Z->x2)))
       goto fail;
-    if (Z->devbuilt)
-      fga_dev_trim(Z->dev);          /* the builder's key buffers (2 x 16 B per k-mer) are of no use to the comparison */
+    /* the builder's key buffers (2 x 16 B per k-mer) stay in their workspace slots: the comparison's first large
+       buffers (seeds, per-part staging) take them over (fga_dev_acquire) */
   }
   if (Z->x1->nctg < Z->g1->ncontig || (!Z->self && Z->x2->nctg < Z->g2->ncontig))
     { fga_set_error("genome index and genome database disagree on the number of contigs");
@@ -143,13 +143,15 @@ int fga_session_merge(fga_session *Z, const fga_run_params *P, int64_t prefix_be
   memset(&mp,0,sizeof(mp));
   mp.freq = P->freq; mp.soft_mask = P->soft_mask; mp.flip = 0;
   mp.prefix_begin = prefix_begin; mp.prefix_end = prefix_end;
-  /* first guess of the buffer: two seeds per table-1 entry of the range (the merge reports the exact need when that is
-     not enough and is repeated once), but never more than a third of the device memory still to be had -- at human
-     scale (2.4 G entries per table) the guess would otherwise take 77 GB that the sort passes need */
+  /* first guess of the buffer: two seeds per table-1 entry of the range, one per entry beyond 2^28 entries (the merge
+     reports the exact need when that is not enough and is repeated once -- tens of milliseconds at human scale, where
+     the large guess would be a fresh allocation of 77 GB instead of a take-over of the index builder's key buffer),
+     never more than a quarter of the device memory still to be had */
   { int64_t guess = (P->symmetric && !self) ? 2*(x1->nents + x2->nents) + (1<<20) : 0;
     if (prefix_begin == 0 && (prefix_end <= 0 || prefix_end >= FGA_NPREFIX))
-      { const int64_t room = (int64_t) (fga_dev_available(dev) / 3 / sizeof(fga_seed));
-        if (guess == 0) guess = 2*x1->nents + (1<<20);
+      { const int64_t room = (int64_t) (fga_dev_available(dev) / 4 / sizeof(fga_seed));
+        if (guess == 0)
+          guess = (x1->nents > ((int64_t) 1 << 28) ? x1->nents : 2*x1->nents) + (1<<20);      /* one per entry at human scale */
         if (guess > room && room > x1->nents/2)
           guess = room;
       }
@@ -406,6 +408,7 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
   memset(&st,0,sizeof(st));
   st.load_s = Z->load_s; st.upload_s = Z->upload_s;
   if (fga_session_merge(Z,P,0,0,&seeds,&st)) goto done;
+  fga_note("run: seed merge (incl. buffers)",tstart);
   { int64_t n = fga_seeds_count(seeds);
     if (n > limit)
       nparts = (int) ((n + limit - 1) / limit);
@@ -431,10 +434,9 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
         }
       if (fga_seeds_contig_histogram(dev,seeds,nctg,cnt) || fga_partition_contigs(cnt,nctg,nparts,select))
         goto done;
-      if (fga_dev_malloc(dev,(size_t) n*sizeof(fga_seed) + 64,&stage)) goto done;
+      if ((stage = fga_dev_stage_acquire(dev,(size_t) n*sizeof(fga_seed) + 64)) == NULL) goto done;
       if (fga_seeds_split_to(dev,seeds,select,nctg,nparts,stage,poff)) goto done;
-      fga_seeds_free(seeds); seeds = NULL;
-      fga_dev_trim(dev);               /* the undivided seed buffer's slot: the parts are a fraction of it */
+      fga_seeds_free(seeds); seeds = NULL;   /* its slot is taken over by the parts' buffers */
       for (p = 0; p < nparts; p++)
         { const void *src = (const char *) stage + (size_t) poff[p]*sizeof(fga_seed);
           const int64_t c = poff[p+1] - poff[p];
@@ -442,7 +444,7 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
           if (fga_seeds_import(dev,&src,&c,1,&part)) goto done;
           if (fga_session_align(Z,P,part,&raw[p],&st)) goto done;
         }
-      fga_dev_free(dev,stage); stage = NULL;
+      fga_dev_stage_release(dev,stage); stage = NULL;
     }
   if (fga_session_finish(Z,P,(const fga_alns *const *) raw,nparts,&st)) goto done;
   st.phase23_s = fga_wall() - tstart - st.trace_s - st.paf_s;
@@ -456,7 +458,7 @@ done:
   if (raw != NULL)
     for (p = 0; p < nparts; p++) fga_alns_free(raw[p]);
   free(raw); free(cnt); free(poff); free(select);
-  if (stage != NULL) fga_dev_free(dev,stage);
+  if (stage != NULL) fga_dev_stage_release(dev,stage);
   fga_seeds_free(seeds);
   return status;
 }

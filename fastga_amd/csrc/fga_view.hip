@@ -180,8 +180,10 @@ int fga_dgix_make_view(fga_dev *dev, fga_dgix *D, int keep_table)
     { fga_set_error("genome index with %d position bytes: contigs beyond 4 Gbp are not supported",D->postbytes);
       return 1;
     }
+  double t0 = fga_wall();
   if (view_alloc(&D->view,D->nents,D->contbytes,1))
     return 1;
+  fga_note("view: allocation",t0); t0 = fga_wall();
   hipLaunchKernelGGL(view_repack_kernel,dim3(FGA_NPREFIX/256),dim3(VW_T),0,dev->stream,
                      D->table,D->index,D->ebytes,D->postbytes,D->contbytes,D->view);
   hipError_t e = hipStreamSynchronize(dev->stream);
@@ -191,9 +193,11 @@ int fga_dgix_make_view(fga_dev *dev, fga_dgix *D, int keep_table)
       view_free(&D->view);
       return 1;
     }
+  fga_note("view: repack kernel",t0); t0 = fga_wall();
   if (!keep_table)
     { hipFree(D->table);
       D->table = NULL;
+      fga_note("view: on-disk bytes freed",t0);
     }
   return 0;
 }
@@ -202,6 +206,7 @@ int fga_dgix_make_view(fga_dev *dev, fga_dgix *D, int keep_table)
 int fga_dgix_make_forward(fga_dev *dev, fga_dgix *D)
 { if (D->fview.K != NULL)
     return 0;
+  const double tf0 = fga_wall();
   const fga_view &V = D->view;
   const uint32_t signbit = 0x80u << (8*(D->contbytes-1));
   const int64_t nblk = (V.n + 1023) / 1024;
@@ -248,6 +253,7 @@ int fga_dgix_make_forward(fga_dev *dev, fga_dgix *D)
     }
   D->fview = F;
   memset(&F,0,sizeof(F));
+  fga_note("forward view",tf0);
   rc = 0;
 done:
   hipFree(dcnt); hipFree(dsub); hipFree(doff);
