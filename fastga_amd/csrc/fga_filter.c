@@ -460,3 +460,104 @@ oom:
   if (R != NULL) { free(R->alns); free(R->tbytes); free(R); }
   return 1;
 }
+
+/* ---- the filtered sets of several parts as one set in final order ------------------------------------------------------
+ * Each input is an output of fga_filter_alignments[_mt]: in final order (aread, abpos, bread, comp, survival).  A-contig
+ * parts are disjoint in aread, so the final order of the union is the inputs' runs of equal aread laid out by aread --
+ * copies, no sort (what la_merge does with the per-thread files of the reference, FastGA.c:3991-4133).  Inputs that do
+ * share an A contig are merged run against run on the rest of the key, the earlier input first on ties. */
+typedef struct { int32_t aread; int set; int64_t beg, cnt; } arun;
+
+static int arun_cmp(const void *l, const void *r)
+{ const arun *a = l, *b = r;
+  if (a->aread != b->aread) return a->aread < b->aread ? -1 : 1;
+  return a->set - b->set;
+}
+
+static int aln_minor_cmp(const fga_aln *a, const fga_aln *b)
+{ if (a->abpos != b->abpos) return a->abpos < b->abpos ? -1 : 1;
+  if (a->bread != b->bread) return a->bread < b->bread ? -1 : 1;
+  if ((a->flags & 1) != (b->flags & 1)) return (a->flags & 1) < (b->flags & 1) ? -1 : 1;
+  return 0;
+}
+
+int fga_alns_merge_filtered(const fga_alns *const *fin, int nfin, fga_alns **out)
+{ fga_alns *R = calloc(1,sizeof(fga_alns));
+  arun *runs = NULL;
+  int64_t nrun = 0, caprun = 0, at = 0, tat = 0, i;
+  int k;
+  *out = NULL;
+  if (R == NULL) goto oom;
+  for (k = 0; k < nfin; k++)
+    if (fin[k] != NULL)
+      { R->naln += fin[k]->naln; R->ntrace += fin[k]->ntrace; R->ncalls += fin[k]->ncalls; R->nwaves += fin[k]->nwaves;
+        for (i = 0; i < fin[k]->naln; )
+          { int64_t j = i+1;
+            while (j < fin[k]->naln && fin[k]->alns[j].aread == fin[k]->alns[i].aread) j += 1;
+            if (nrun >= caprun)
+              { arun *nr;
+                caprun = caprun ? 2*caprun : 1024;
+                nr = realloc(runs,sizeof(arun)*caprun);
+                if (nr == NULL) goto oom;
+                runs = nr;
+              }
+            runs[nrun].aread = fin[k]->alns[i].aread; runs[nrun].set = k; runs[nrun].beg = i; runs[nrun].cnt = j-i;
+            nrun += 1;
+            i = j;
+          }
+      }
+  R->alns = malloc(sizeof(fga_aln)*(R->naln+1));
+  R->tbytes = malloc(R->ntrace+16);
+  if (R->alns == NULL || R->tbytes == NULL) goto oom;
+  if (nrun > 1)
+    qsort(runs,nrun,sizeof(arun),arun_cmp);
+  for (i = 0; i < nrun; )
+    { int64_t j = i+1;
+      while (j < nrun && runs[j].aread == runs[i].aread) j += 1;
+      if (j == i+1)                                   /* the usual case: the contig's records come from one part */
+        { const fga_alns *S = fin[runs[i].set];
+          const fga_aln *src = S->alns + runs[i].beg;
+          const int64_t t0 = src[0].toff, t1 = src[runs[i].cnt-1].toff + src[runs[i].cnt-1].tlen;
+          int64_t x;
+          memcpy(R->tbytes + tat,S->tbytes + t0,(size_t) (t1 - t0));     /* a filtered set's trace bytes are laid out in record order */
+          for (x = 0; x < runs[i].cnt; x++)
+            { fga_aln a = src[x];
+              a.toff = tat + (a.toff - t0); a.seq = (int32_t) at; a.unit = -1;
+              R->alns[at++] = a;
+            }
+          tat += t1 - t0;
+        }
+      else                                            /* several inputs hold records of this contig: merge their runs */
+        { int64_t *pos = calloc(j-i,sizeof(int64_t));
+          if (pos == NULL) goto oom;
+          for (;;)
+            { int64_t best = -1, x;
+              for (x = i; x < j; x++)
+                if (pos[x-i] < runs[x].cnt &&
+                    (best < 0 || aln_minor_cmp(fin[runs[x].set]->alns + runs[x].beg + pos[x-i],
+                                               fin[runs[best].set]->alns + runs[best].beg + pos[best-i]) < 0))
+                  best = x;
+              if (best < 0) break;
+              { const fga_alns *S = fin[runs[best].set];
+                fga_aln a = S->alns[runs[best].beg + pos[best-i]];
+                memcpy(R->tbytes + tat,S->tbytes + a.toff,(size_t) a.tlen);
+                a.toff = tat; a.seq = (int32_t) at; a.unit = -1;
+                R->alns[at++] = a;
+                tat += a.tlen;
+                pos[best-i] += 1;
+              }
+            }
+          free(pos);
+        }
+      i = j;
+    }
+  R->naln = at; R->ntrace = tat;
+  free(runs);
+  *out = R;
+  return 0;
+oom:
+  fga_set_error("out of memory merging filtered alignment sets");
+  free(runs);
+  if (R != NULL) { free(R->alns); free(R->tbytes); free(R); }
+  return 1;
+}

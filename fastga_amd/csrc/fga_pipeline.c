@@ -14,8 +14,30 @@
 #include <string.h>
 #include <unistd.h>
 
+#include <pthread.h>
+
 #include "fga_host.h"
 #include "fastga_amd.h"
+
+/* the redundancy filter of one part's records on a thread of its own, while the next part's kernels run */
+typedef struct
+  { const fga_alns *in;
+    fga_alns *out;
+    int nthreads, rc, started;
+    double seconds;
+    char *err;
+    pthread_t th;
+  } part_filter;
+
+static void *part_filter_main(void *arg)
+{ part_filter *F = arg;
+  const double t0 = fga_wall();
+  F->rc = fga_filter_alignments_mt(F->in,F->nthreads,&F->out);
+  if (F->rc != 0)
+    F->err = strdup(fga_last_error());
+  F->seconds = fga_wall() - t0;
+  return NULL;
+}
 
 struct fga_session
   { fga_gdb *g1, *g2;
@@ -308,33 +330,17 @@ oom:
   return 1;
 }
 
-/* redundancy filter + phase 3 over the records of all parts: order, .1aln, PAF / PSL */
-int fga_session_finish(fga_session *Z, const fga_run_params *P, const fga_alns *const *raw, int nraw, fga_run_stats *S)
+/* phase 3 for a set in final order: .1aln, PAF / PSL */
+static int finish_output(fga_session *Z, const fga_run_params *P, const fga_alns *fin, fga_run_stats *st)
 { fga_gdb *g1 = Z->g1, *g2 = Z->g2;
   fga_dev *dev = Z->dev;
-  fga_alns *all = NULL, *fin = NULL;
-  const fga_alns *in;
   const int self = Z->self;
-  int status = 1;
   int64_t i;
   double t1;
-  fga_run_stats st;
 
-  memset(&st,0,sizeof(st));
-  t1 = fga_wall();
-  if (nraw == 1 && raw[0] != NULL)
-    in = raw[0];
-  else
-    { if (fga_alns_concat(raw,nraw,&all)) goto done;
-      in = all;
-    }
-  if (fga_filter_alignments_mt(in,P->nthreads,&fin)) goto done;
-  st.nlive = fin->naln;
+  st->nlive = fin->naln;
   for (i = 0; i < fin->naln; i++)
-    st.cover += fin->alns[i].aepos - fin->alns[i].abpos;
-  st.filter_s = fga_wall() - t1;
-
-  /* ---- phase 3 ---- */
+    st->cover += fin->alns[i].aepos - fin->alns[i].abpos;
   t1 = fga_wall();
   if (P->out_path != NULL)
     { char *n1 = NULL, *n2 = NULL;
@@ -348,9 +354,9 @@ int fga_session_finish(fga_session *Z, const fga_run_params *P, const fga_alns *
       else
         rc = fga_write_1aln_binary(P->out_path,g1,self ? NULL : g2,fin,100,n1 ? n1 : "genome1",n2,cmd);
       free(n1); free(n2);
-      if (rc) goto done;
+      if (rc) return 1;
     }
-  st.write_s = fga_wall() - t1;
+  st->write_s = fga_wall() - t1;
 
   /* ---- PAF (what the reference leaves to a second process, ALNtoPAF): outside the .1aln clock ---- */
   if (P->paf_path != NULL)
@@ -361,25 +367,72 @@ int fga_session_finish(fga_session *Z, const fga_run_params *P, const fga_alns *
       t1 = fga_wall();
       if (bases)
         { rc = fga_trace_pts(dev,Z->dg1,Z->dg2,fin,100,0,&tr);
-          st.trace_kernel_ms = fga_dev_stage_ms(dev,FGA_STAGE_TRACE);
+          st->trace_kernel_ms = fga_dev_stage_ms(dev,FGA_STAGE_TRACE);
         }
-      st.trace_s = fga_wall() - t1;
+      st->trace_s = fga_wall() - t1;
       t1 = fga_wall();
       if (rc == 0)
         rc = psl ? fga_write_psl(P->paf_path,g1,self ? NULL : g2,fin,tr,P->nthreads)
                  : fga_write_paf(P->paf_path,g1,self ? NULL : g2,fin,tr,P->paf_flags,P->nthreads);
-      st.paf_s = fga_wall() - t1;
+      st->paf_s = fga_wall() - t1;
       fga_traces_free(tr);
-      if (rc) goto done;
+      if (rc) return 1;
     }
+  return 0;
+}
+
+static void finish_stats(fga_run_stats *S, const fga_run_stats *st)
+{ if (S == NULL) return;
+  S->nlive = st->nlive; S->cover = st->cover; S->filter_s += st->filter_s; S->write_s += st->write_s;
+  S->trace_s = st->trace_s; S->paf_s = st->paf_s; S->trace_kernel_ms = st->trace_kernel_ms;
+}
+
+/* redundancy filter + phase 3 over the records of all parts: order, .1aln, PAF / PSL */
+int fga_session_finish(fga_session *Z, const fga_run_params *P, const fga_alns *const *raw, int nraw, fga_run_stats *S)
+{ fga_alns *all = NULL, *fin = NULL;
+  const fga_alns *in;
+  int status = 1;
+  double t1;
+  fga_run_stats st;
+
+  memset(&st,0,sizeof(st));
+  t1 = fga_wall();
+  if (nraw == 1 && raw[0] != NULL)
+    in = raw[0];
+  else
+    { if (fga_alns_concat(raw,nraw,&all)) goto done;
+      in = all;
+    }
+  if (fga_filter_alignments_mt(in,P->nthreads,&fin)) goto done;
+  st.filter_s = fga_wall() - t1;
+  if (finish_output(Z,P,fin,&st)) goto done;
   status = 0;
 
 done:
-  if (S != NULL)
-    { S->nlive = st.nlive; S->cover = st.cover; S->filter_s += st.filter_s; S->write_s += st.write_s;
-      S->trace_s = st.trace_s; S->paf_s = st.paf_s; S->trace_kernel_ms = st.trace_kernel_ms;
-    }
+  finish_stats(S,&st);
   fga_alns_free(all); fga_alns_free(fin);
+  return status;
+}
+
+/* the same for record sets that went through the redundancy filter already, part by part (every contig pair's records
+   come from one part): their runs per A contig are laid out in order (fga_alns_merge_filtered) and written */
+int fga_session_finish_filtered(fga_session *Z, const fga_run_params *P, const fga_alns *const *filtered, int nsets,
+                                fga_run_stats *S)
+{ fga_alns *fin = NULL;
+  int status = 1;
+  double t1;
+  fga_run_stats st;
+
+  memset(&st,0,sizeof(st));
+  t1 = fga_wall();
+  if (fga_alns_merge_filtered(filtered,nsets,&fin)) goto done;
+  st.filter_s = fga_wall() - t1;
+  if (finish_output(Z,P,fin,&st)) goto done;
+  status = 0;
+
+done:
+  finish_stats(S,&st);
+  fga_alns_free(fin);
   return status;
 }
 
@@ -397,7 +450,8 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
 { fga_dev *dev = Z->dev;
   fga_dseeds *seeds = NULL;
   fga_alns **raw = NULL;
-  int nparts = 1, p, status = 1;
+  int nparts = 1, p, status = 1, finished = 0;
+  part_filter *pf = NULL;
   int64_t limit = P->pass_seeds > 0 ? P->pass_seeds : (int64_t) 1500000000;
   int64_t *cnt = NULL, *poff = NULL;
   int *select = NULL;
@@ -412,6 +466,11 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
   { int64_t n = fga_seeds_count(seeds);
     if (n > limit)
       nparts = (int) ((n + limit - 1) / limit);
+    /* FGA_OVERLAP_PARTS=<n>: cut a one-pass run into n parts all the same, so that the host work on one part's records
+       (redundancy filter) runs beside the next part's kernels.  Off by default: at 10^6 contig pairs (150 Mbp repeat-heavy
+       self comparison) four parts cost more in per-part tails (579 ms) than the overlap returns (536 ms in one pass) */
+    if (nparts == 1 && getenv("FGA_OVERLAP_PARTS") != NULL && atoi(getenv("FGA_OVERLAP_PARTS")) > 1)
+      nparts = atoi(getenv("FGA_OVERLAP_PARTS"));
     if (nparts > 64) nparts = 64;
     if (nparts > Z->x1->nctg) nparts = Z->x1->nctg;
   }
@@ -437,16 +496,45 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
       if ((stage = fga_dev_stage_acquire(dev,(size_t) n*sizeof(fga_seed) + 64)) == NULL) goto done;
       if (fga_seeds_split_to(dev,seeds,select,nctg,nparts,stage,poff)) goto done;
       fga_seeds_free(seeds); seeds = NULL;   /* its slot is taken over by the parts' buffers */
+      pf = calloc(nparts,sizeof(part_filter));
+      if (pf == NULL)
+        { fga_set_error("out of memory");
+          goto done;
+        }
       for (p = 0; p < nparts; p++)
         { const void *src = (const char *) stage + (size_t) poff[p]*sizeof(fga_seed);
           const int64_t c = poff[p+1] - poff[p];
           fga_dseeds *part = NULL;
           if (fga_seeds_import(dev,&src,&c,1,&part)) goto done;
           if (fga_session_align(Z,P,part,&raw[p],&st)) goto done;
+          /* this part's records through the redundancy filter in the background (every contig pair's records are in the
+             part that owns the A contig) while the next part's kernels run */
+          pf[p].in = raw[p]; pf[p].nthreads = P->nthreads > 2 ? P->nthreads/2 : 1;
+          if (pthread_create(&pf[p].th,NULL,part_filter_main,&pf[p]) == 0)
+            pf[p].started = 1;
+          else
+            part_filter_main(&pf[p]);
         }
       fga_dev_stage_release(dev,stage); stage = NULL;
+      { const fga_alns **fsets = calloc(nparts,sizeof(fga_alns *));
+        int bad = (fsets == NULL);
+        const double tj = fga_wall();
+        for (p = 0; p < nparts; p++)
+          { if (pf[p].started) { pthread_join(pf[p].th,NULL); pf[p].started = 0; }
+            if (pf[p].rc != 0 && !bad)
+              { fga_set_error("%s",pf[p].err ? pf[p].err : "alignment filter failed");
+                bad = 1;
+              }
+            if (fsets != NULL) fsets[p] = pf[p].out;
+          }
+        st.filter_s += fga_wall() - tj;                 /* what the filter added to the critical path */
+        if (!bad && fga_session_finish_filtered(Z,P,fsets,nparts,&st)) bad = 1;
+        free(fsets);
+        if (bad) goto done;
+      }
+      finished = 1;
     }
-  if (fga_session_finish(Z,P,(const fga_alns *const *) raw,nparts,&st)) goto done;
+  if (!finished && fga_session_finish(Z,P,(const fga_alns *const *) raw,nparts,&st)) goto done;
   st.phase23_s = fga_wall() - tstart - st.trace_s - st.paf_s;
   st.nparts = nparts;
   st.hbm_peak_bytes = fga_dev_peak_bytes(dev);
@@ -455,6 +543,12 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
 
 done:
   if (S != NULL) *S = st;
+  if (pf != NULL)
+    for (p = 0; p < nparts; p++)
+      { if (pf[p].started) pthread_join(pf[p].th,NULL);
+        fga_alns_free(pf[p].out); free(pf[p].err);
+      }
+  free(pf);
   if (raw != NULL)
     for (p = 0; p < nparts; p++) fga_alns_free(raw[p]);
   free(raw); free(cnt); free(poff); free(select);

@@ -412,6 +412,21 @@ class Session:
         arr = (C.POINTER(Alns) * max(len(raws), 1))(*raws)
         check(self.L.fga_session_finish(self.h, C.byref(prm), arr, len(raws), C.byref(stats)), "session finish")
 
+    def filter(self, raw, nthreads=8):
+        """the redundancy filter on ONE part's raw records (every contig pair's records come from the part that owns the
+        A contig) -> pointer to the filtered set in final order (free with free_alns)"""
+        from .lib import Alns
+        out = C.POINTER(Alns)()
+        check(self.L.fga_filter_alignments_mt(raw, nthreads, C.byref(out)), "filter")
+        return out
+
+    def finish_filtered(self, prm, stats, filtered):
+        """phase 3 over sets that were filtered part by part: merge by A contig, .1aln / PAF"""
+        from .lib import Alns
+        arr = (C.POINTER(Alns) * max(len(filtered), 1))(*filtered)
+        check(self.L.fga_session_finish_filtered(self.h, C.byref(prm), arr, len(filtered), C.byref(stats)),
+              "session finish (filtered sets)")
+
     def sync(self):
         check(self.L.fga_dev_sync(self.L.fga_session_device(self.h)), "sync")
 

@@ -11,9 +11,10 @@ The cut follows the reference's own two partitions:
            all-to-all-v moves the 16-byte records: what the N_Units / C_Units file matrix and its transpose do in the
            reference (FastGA.c:5097-5134, 5160-5184).
   phase 2  every rank sorts / chain-scans / extends the seeds of its part: contig pairs are independent work units.
-  gather   the accepted alignments (56-byte records + trace bytes, tens of MB) go to rank 0, which runs the redundancy
-           filter (needs all records of a contig pair -- they all come from the part owning the A contig), orders and
-           writes the .1aln once: the reference's la_merge (FastGA.c:3991-4133).
+  filter   every rank runs the redundancy filter on ITS records (all records of a contig pair come from the part owning
+           the A contig, so the filter needs nothing from other ranks) and orders them.
+  gather   the surviving alignments (56-byte records + trace bytes, tens of MB) go to rank 0, which lays the ranks' runs
+           per A contig out in contig order and writes the .1aln once: the reference's la_merge (FastGA.c:3991-4133).
 
 Everything on the data path is the C-ABI of include/fastga_amd.h; torch provides the exchange buffers and the
 collectives, nothing else.  `run_parts_on_one_gpu` drives the same C-ABI calls with the transport replaced by local
@@ -155,8 +156,10 @@ def run_sharded(ses, dist, prm_kwargs, device):
     part = ses.import_seeds([(recv.data_ptr(), total)])
     del recv
     raw = ses.align(prm, st, part)
-    recs, tb, counts = alns_to_arrays(raw)
+    fil = ses.filter(raw, nthreads=kw.get("nthreads", 8))        # this rank's contig pairs are complete: filter here
     ses.free_alns(raw)
+    recs, tb, counts = alns_to_arrays(fil)
+    ses.free_alns(fil)
     allr = gather_records(dist, recs, tb, counts, device)
     if rank == 0:
         keep, structs = [], []
@@ -164,7 +167,7 @@ def run_sharded(ses, dist, prm_kwargs, device):
             a, k = arrays_to_alns(allr[r][0], allr[r][1], allr[r][2])
             keep.append(k)
             structs.append(C.pointer(a))
-        ses.finish(prm, st, structs)
+        ses.finish_filtered(prm, st, structs)
     d = ses.stats_dict(st)
     d["exchange_seeds_out"] = int(n - in_splits[rank])
     d["part_seeds"] = total
@@ -201,10 +204,12 @@ def run_parts_on_one_gpu(ses, nparts, **prm_kwargs):
     for p in range(nparts):                                   # "rank p": its part's pieces from every rank, phase 2
         pieces = [(sends[r] + 16 * int(offs[r][p]), int(offs[r][p + 1] - offs[r][p])) for r in range(nparts)]
         part = ses.import_seeds(pieces)
-        raws.append(ses.align(prm, st, part))
+        raw = ses.align(prm, st, part)
+        raws.append(ses.filter(raw, nthreads=prm_kwargs.get("nthreads", 8)))      # "rank p" filters its own records
+        ses.free_alns(raw)
     for buf in sends:
         ses.dev_free(buf)
-    ses.finish(prm, st, raws)
+    ses.finish_filtered(prm, st, raws)
     for r in raws:
         ses.free_alns(r)
     d = ses.stats_dict(st)

@@ -359,6 +359,10 @@ int  fga_merge_prefix_cuts(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2 
    the gathering rank hands to the redundancy filter (host only) */
 int  fga_alns_concat(const fga_alns *const *raw, int nraw, fga_alns **out);
 
+/* filtered sets (outputs of fga_filter_alignments[_mt], one per A-contig part) as one set in final order: their runs per
+   A contig laid out by contig -- the reference's la_merge over its per-thread files (FastGA.c:3991-4133); host only */
+int  fga_alns_merge_filtered(const fga_alns *const *filtered, int nsets, fga_alns **out);
+
 /* the same with the inputs kept resident in HBM between passes (what bench.py times) */
 typedef struct fga_session fga_session;
 int      fga_session_open(const char *root1, const char *root2, int device, fga_session **out);
@@ -382,6 +386,10 @@ int      fga_session_align(fga_session *s, const fga_run_params *prm, fga_dseeds
                            fga_run_stats *stats);
 int      fga_session_finish(fga_session *s, const fga_run_params *prm, const fga_alns *const *raw, int nraw,
                             fga_run_stats *stats);
+/* finish for record sets that were filtered part by part already (fga_filter_alignments_mt on each part's raw set, e.g. on
+   the rank that produced it): merge by A contig + phase 3 */
+int      fga_session_finish_filtered(fga_session *s, const fga_run_params *prm, const fga_alns *const *filtered, int nsets,
+                                     fga_run_stats *stats);
 
 #ifdef __cplusplus
 }

@@ -215,3 +215,80 @@ def test_gathered_parts_filter_like_the_whole_world2(built_library):
     same_recs, same_trace, nlive, nraw, sel0 = res[0][1]
     assert same_recs and same_trace and 0 < nlive < nraw
     assert res[1][1][0] == sel0 and len(set(sel0)) == 2          # both ranks derived the same two-part map
+
+
+# ------------------------------------------------------------------------------------------------ filter per part, merge
+
+def _merge_filtered(L, sets):
+    """fga_alns_merge_filtered over [(records, trace bytes)]"""
+    from fastga_amd.lib import Alns
+    from fastga_amd.device import ALN_DTYPE
+    keep, ptrs = [], (C.POINTER(Alns) * max(len(sets), 1))()
+    for k, (r, t) in enumerate(sets):
+        r, t = np.ascontiguousarray(r), np.ascontiguousarray(t)
+        a = Alns(len(r), len(t), 0, 0, r.ctypes.data, t.ctypes.data)
+        keep.append((a, r, t))
+        ptrs[k] = C.pointer(a)
+    out = C.POINTER(Alns)()
+    assert L.fga_alns_merge_filtered(ptrs, len(sets), C.byref(out)) == 0
+    o = out.contents
+    got = np.frombuffer((C.c_char * (o.naln * ALN_DTYPE.itemsize)).from_address(o.alns), dtype=ALN_DTYPE).copy()
+    gt = np.frombuffer((C.c_char * max(o.ntrace, 1)).from_address(o.tbytes), dtype=np.uint8)[:o.ntrace].copy()
+    L.fga_alns_free(out)
+    return got, gt
+
+
+@pytest.mark.parametrize("nparts", [1, 2, 3, 8])
+def test_parts_filtered_on_their_own_merge_to_the_filter_of_the_whole(built_library, nparts):
+    """what fga_session_run does over A-contig parts (a background filter per part) and what every rank does before the
+    gather: filter the part's records, then lay the parts' runs per A contig out in contig order"""
+    from fastga_amd.lib import load_library
+    from fastga_amd.parallel import partition_contigs
+    L = load_library()
+    recs, tb = _raw_records(seed=5, ngroups=90)
+    exp = _filter(L, recs, tb)
+    nctg = int(recs["aread"].max()) + 1
+    select = partition_contigs(np.bincount(recs["aread"], minlength=nctg), nparts)
+    sets = []
+    for p in range(nparts):
+        sub, stb = _subset(recs, tb, select[recs["aread"]] == p)
+        sets.append(_filter(L, sub, stb))
+    got = _merge_filtered(L, sets)
+    assert len(exp[0]) > 0
+    assert got[0].tobytes() == exp[0].tobytes() and got[1].tobytes() == exp[1].tobytes()
+    # inputs that share an A contig (not what the pipeline produces) still merge by the rest of the key
+    half = np.arange(len(exp[0])) % 2 == 0
+    a, b = _subset(exp[0], exp[1], half), _subset(exp[0], exp[1], ~half)
+    m = _merge_filtered(L, [a, b])
+    for f in ("aread", "abpos", "bread", "aepos", "bepos", "diffs", "tlen"):
+        assert np.array_equal(np.sort(m[0][f]), np.sort(exp[0][f]))
+    key = m[0]["aread"].astype(np.int64) << 32 | m[0]["abpos"]
+    assert np.all(np.diff(key) >= 0)
+
+
+def _filtered_gather_worker(rank, world, port, q):
+    dist = _init(rank, world, port)
+    from fastga_amd.lib import load_library
+    from fastga_amd.parallel import partition_contigs, all_reduce_counts, gather_records
+    L = load_library()
+    recs, tb = _raw_records(seed=8, ngroups=70)
+    nctg = int(recs["aread"].max()) + 1
+    half = np.arange(len(recs)) % world == rank
+    select = partition_contigs(all_reduce_counts(dist, np.bincount(recs["aread"][half], minlength=nctg), "cpu"), world)
+    mine, mtb = _subset(recs, tb, select[recs["aread"]] == rank)
+    fil = _filter(L, mine, mtb)                                     # on the rank that owns the contig pairs
+    allr = gather_records(dist, fil[0], fil[1], (0, 0), "cpu")
+    res = None
+    if rank == 0:
+        got = _merge_filtered(L, [(allr[r][0], allr[r][1]) for r in range(world)])
+        exp = _filter(L, recs, tb)
+        res = (got[0].tobytes() == exp[0].tobytes(), got[1].tobytes() == exp[1].tobytes(), len(exp[0]))
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_filter_before_the_gather_world2(built_library):
+    res = _spawn(_filtered_gather_worker, ())
+    same_recs, same_trace, nlive = res[0][1]
+    assert same_recs and same_trace and nlive > 0
