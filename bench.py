@@ -56,6 +56,10 @@ def parse():
     ap.add_argument("--no-cold", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
                     help="take the multi-GPU code path (process group, exchange, gather) even with one rank")
+    ap.add_argument("--self", dest="self_", action="store_true",
+                    help="BASELINE configs[2]'s shape instead of the pair: repeat-heavy genome of --mbp against itself, -M")
+    ap.add_argument("--no-human-scale", action="store_true",
+                    help="skip the 3 Gbp x 3 Gbp leg (BASELINE configs[3]: one comparison, N = 1 only, ~30 s)")
     return ap.parse_args()
 
 
@@ -121,7 +125,12 @@ def main():
     ra, rb = os.path.join(shared, "A"), os.path.join(shared, "B")
     if rank == 0:
         # FASTA -> GDB on the host, once; the two indices are built on the device when a session opens (no .gix files)
-        workload.build_config2(shared, mbp=mbp, seed=1, divergence=args.div, ncontig=ncontig, threads=threads, gix=False)
+        if args.self_:
+            ra = workload.build_config3(shared, mbp=mbp, threads=threads, gix=False, name="A")
+        else:
+            workload.build_config2(shared, mbp=mbp, seed=1, divergence=args.div, ncontig=ncontig, threads=threads, gix=False)
+    if args.self_:
+        rb = None
     if dist is not None:
         dist.barrier()
     prep_s = time.time() - t0
@@ -130,6 +139,8 @@ def main():
     ses = D.Session(ra, rb, device=local)
     out1aln = os.path.join(shared, "bench.1aln")
     kw = dict(out_path=out1aln, nthreads=threads, command_line="bench.py FastGA hot path")
+    if args.self_:
+        kw["soft_mask"] = True
 
     if dist is None:
         def step():
@@ -149,7 +160,7 @@ def main():
             torch.cuda.synchronize()
 
     gix_ms = ses.dev_wrapper().stage_ms(5)            # kernel time of the session's own device build of genome B's index
-    do_cpu = (not args.no_cpu) and world == 1          # the reference leg runs on rank 0 at N=1 only
+    do_cpu = (not args.no_cpu) and world == 1 and not args.self_     # the reference leg runs on rank 0 at N=1 only
 
     for _ in range(args.warmup):
         step()
@@ -191,7 +202,7 @@ def main():
         nseeds = S("nseeds")
         # algorithmic bytes of the merge launches of one step: every table entry once in its on-disk width, every seed
         # once in the reference's record width (with N ranks each launch covers 1/N of the prefix space)
-        alg_bytes = ses.table_bytes + nseeds * ses.seed_bytes
+        alg_bytes = ses.table_bytes + nseeds * ses.seed_bytes * (2 if args.self_ else 1)    # self: the reported total is halved (FastGA.c:1906)
         achieved = alg_bytes / max(1, world) / (kavg * 1e-3) / 1e9          # per GPU, slowest rank's launch time
         stage_ms = {k: round(1000 * sum(s[k] for s in stats) / len(stats), 2)
                     for k in ("merge_s", "sort_s", "chain_s", "extend_s", "filter_s", "write_s")}
@@ -201,10 +212,12 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong" if args.strong_mbp > 0 else "weak", "vs_baseline": None,
             "dtype": "u8/int32/u64", "data": "synthetic",
-            "config": {"workload": f"synthetic {mbp:g} Mbp vs {mbp:g} Mbp, {args.div*100:g}% divergence, {ncontig} contigs, "
-                                   f"5% repeats, 2% inversions/swaps (BASELINE configs[1]"
-                                   + (")" if world == 1 else f" x {world}: ONE comparison over {world} GPUs, "
-                                      f"{args.mbp:g} Mbp per genome per GPU)"),
+            "config": {"workload": (f"synthetic repeat-heavy {mbp:g} Mbp genome against itself, soft mask on (BASELINE configs[2]'s shape)"
+                                    if args.self_ else
+                                    f"synthetic {mbp:g} Mbp vs {mbp:g} Mbp, {args.div*100:g}% divergence, {ncontig} contigs, "
+                                    f"5% repeats, 2% inversions/swaps (BASELINE configs[1]"
+                                    + (")" if world == 1 else f" x {world}: ONE comparison over {world} GPUs, "
+                                       f"{args.mbp:g} Mbp per genome per GPU)")),
                        "step": "seed merge -> sort -> chain scan -> wave extension -> redundancy filter -> .1aln "
                                "written; GIX tables + genomes resident in HBM"
                                + ("" if world == 1 else "; phase 1 by k-mer prefix range, seeds all-to-all-v by A-contig "
@@ -232,12 +245,12 @@ def main():
         if tot is not None:
             out["config"]["per_rank"] = {"part_seeds": tot["part_seeds"], "seeds_sent": tot["exchange_seeds_out"],
                                          "alignments": tot["nalns"], "waves": tot["nwaves"]}
-        if world == 1 and abs(mbp - 100.0) < 1e-9 and abs(args.div - 0.02) < 1e-9:    # the profiled configuration
+        if world == 1 and not args.self_ and abs(mbp - 100.0) < 1e-9 and abs(args.div - 0.02) < 1e-9:    # the profiled configuration
             tr, src = pmc_traffic()
             if tr is not None:
                 out["roofline"]["traffic"] = tr
                 out["roofline"]["traffic_source"] = src
-        if world == 1 and not args.no_cold:
+        if world == 1 and not args.no_cold and not args.self_:
             out["cold"] = cold_run(D, ra, rb, shared, threads, pair_gbp)
         if do_cpu:
             try:
@@ -252,12 +265,67 @@ def main():
             except Exception as e:      # the baseline leg must never take the bench line down
                 out["cpu_baseline"] = {"value": None, "unit": "Gbp-pair/s", "cores": 0, "kind": "reference",
                                        "sample": f"failed: {e}"}
+        if world == 1 and not args.self_ and not args.no_human_scale:
+            ses.close()                           # the 3 Gbp leg wants the whole device
+            ses = None
+            try:
+                out["human_scale"] = human_scale_run(D, workload, shared, threads)
+            except Exception as e:                # never takes the bench line down
+                out["human_scale"] = {"error": str(e)}
         print(json.dumps(out), flush=True)
 
-    ses.close()
+    if ses is not None:
+        ses.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def human_scale_run(D, workload, workdir, threads):
+    """BASELINE configs[3] at its stated size on this one GPU: 3 Gbp x 3 Gbp (32 contigs of ~94 Mbp, 1 % divergence, 45 %
+    repeats; fastga_amd.workload.build_config4), both indices built on the device (2.4 G entries each), ONE comparison
+    from resident inputs to the .1aln closed.  The counts are the ones the reference gives for this pair
+    (tests/golden/config4_3000m_digest.json: made with oracle/_ref/GIXmake + FastGA -T32 in 74 s wall on the GPU box's 256
+    host cores; the full record digest is compared in tests/test_full_size_gpu.py).  Seed-merge roofline at this size:
+    algorithmic bytes N1 E1 + N2 E2 + S x seed bytes over the HIP-event time of the launch."""
+    import shutil
+    d = os.path.join(workdir, "human_scale")
+    os.makedirs(d, exist_ok=True)
+    try:
+        t = time.time()
+        ra, rb = workload.build_config4(d, mbp=3000.0, divergence=0.01, threads=threads)
+        prep = time.time() - t
+        t = time.time()
+        ses = D.Session(ra, rb)
+        opened = time.time() - t
+        out = os.path.join(d, "c4.1aln")
+        t = time.time()
+        st = ses.run(out_path=out, nthreads=threads, command_line="bench.py FastGA 3 Gbp")
+        dt = time.time() - t
+        alg = ses.table_bytes + st["nseeds"] * ses.seed_bytes
+        res = {"workload": "synthetic 3 Gbp vs 3 Gbp, 1% divergence, 32 contigs, 45% repeats (BASELINE configs[3]), 1 GPU",
+               "value": 3.0 / dt, "unit": "Gbp-pair/s", "seconds": round(dt, 2), "parts": int(st["nparts"]),
+               "seeds": int(st["nseeds"]), "hits": int(st["nhits"]), "alignments": int(st["nalns"]), "records": int(st["nlive"]),
+               "stage_s": {k: round(st[k], 2) for k in ("merge_s", "sort_s", "chain_s", "extend_s", "filter_s", "write_s")},
+               "kernel_ms": {"merge": round(st["merge_kernel_ms"], 1), "sort": round(st["sort_kernel_ms"], 1),
+                             "extend": round(st["extend_kernel_ms"], 1)},
+               "roofline": {"kernel": "seed merge launch", "bound": "hbm", "algorithmic_bytes": int(alg),
+                            "kernel_ms": st["merge_kernel_ms"], "achieved": alg / (st["merge_kernel_ms"] * 1e-3) / 1e9,
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": alg / (st["merge_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+               "hbm_peak_gib": round(st["hbm_peak_bytes"] / 2**30, 1),
+               "genomes_s": round(prep, 1), "upload_and_2_index_builds_s": round(opened, 2)}
+        gold = os.path.join(ROOT, "tests", "golden", "config4_3000m_digest.json")
+        if os.path.exists(gold):
+            g = json.load(open(gold))
+            res["reference"] = {"seconds": g.get("reference_seconds"), "threads": g.get("reference_threads"),
+                                "where": "same box class (256 host cores), tests/golden/config4_3000m_digest.json"}
+            res["counts_equal_reference"] = (st["nseeds"] == g["total_seeds"] and st["nhits"] == g["hits"] and
+                                             st["nalns"] == g["alignments"] and st["nlive"] == g["records"])
+        ses.close()
+        return res
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def cold_run(D, ra, rb, workdir, threads, pair_gbp):
@@ -295,7 +363,7 @@ def pmc_traffic():
     commit = ""
     for r in csv.DictReader(ln for ln in open(files[-1]) if not ln.startswith("#")):
         k = r["kernel"]
-        if "seed_merge" in k or "merge_partition" in k or "hole_fill" in k or "gather_big" in k or "merge_" in k:
+        if "seed_merge" in k or "range_cut" in k:
             if r["counter"] == "FETCH_SIZE":
                 fetch = (fetch or 0.0) + float(r["avg_per_launch"])
             elif r["counter"] == "WRITE_SIZE":

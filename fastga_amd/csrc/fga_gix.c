@@ -156,6 +156,23 @@ static int open_legacy(fga_gix *X, const char *dir, const char *root, int npost)
       }
   }
 
+  /* the stub's prefix index drives the expansion below: it must be a cumulative count over the nk k-mers */
+  { int64_t prev = 0;
+    for (pre = 0; pre < FGA_NPREFIX; pre++)
+      { if (X->index[pre] < prev || X->index[pre] > nk)
+          { fga_set_error("index %s/%s: the prefix index of the stub is not a cumulative count over its %lld k-mers",
+                          dir,root,(long long) nk);
+            goto fail;
+          }
+        prev = X->index[pre];
+      }
+    if (prev != nk)
+      { fga_set_error("index %s/%s: the prefix index of the stub ends at %lld, the table parts hold %lld k-mers",dir,root,
+                      (long long) prev,(long long) nk);
+        goto fail;
+      }
+  }
+
   X->ebytes  = 9 + pb;
   X->nents   = np;
   X->table   = malloc((size_t) np*X->ebytes + 64);

@@ -110,6 +110,10 @@ int fga_session_open_threads(const char *root1, const char *root2, int device, i
     /* the builder's key buffers (2 x 16 B per k-mer) stay in their workspace slots: the comparison's first large
        buffers (seeds, per-part staging) take them over (fga_dev_acquire) */
   }
+  if (!Z->self && (Z->x1->legacy != 0) != (Z->x2->legacy != 0))      /* the reference refuses the mix too (FastGA.c:4882-4886) */
+    { fga_set_error("one genome index is in the pre-v1.3 layout and the other is not: rebuild the old one");
+      goto fail;
+    }
   if (Z->x1->nctg < Z->g1->ncontig || (!Z->self && Z->x2->nctg < Z->g2->ncontig))
     { fga_set_error("genome index and genome database disagree on the number of contigs");
       goto fail;

@@ -243,6 +243,207 @@ void sort_scatter_kernel(const void *in, uint4 *out, int64_t n, int shift, key_l
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// One-sweep passes (chained scan with decoupled look-back): a pass reads the keys once and writes them once.
+//   os_first_hist   digit histogram of the first pass (the only extra sweep; with FROM_SEEDS it reads the 16-byte seeds)
+//   os_scan256      exclusive scan of the 256 global digit counts -> where every digit's run starts
+//   os_pass         a workgroup takes a tile by ticket (so every earlier tile is already running), ranks its keys like
+//                   sort_scatter_kernel, publishes its 256 digit counts, looks back through the earlier tiles' entries
+//                   until it meets an inclusive prefix, publishes its own inclusive prefix, scatters -- and counts the
+//                   NEXT pass's digits of the keys it writes, so the next pass needs no histogram sweep
+// A status entry is one 8-byte word {pass stamp : 8 | state : 2 | value : 54}, written and polled with relaxed
+// agent-scope atomics (the granule hand-off of MI355X_MICROARCH.md: one sc1 store, sc1 polls; valid across XCDs).  The
+// stamp makes entries of earlier passes read as "not there yet", so the array is cleared once, not per pass.
+// Traffic per pass 2 n x 16 B instead of 3 n.
+// ---------------------------------------------------------------------------------------------------
+#define OS_LOCAL     1ull
+#define OS_INCL      2ull
+#define OS_PACK(stamp,state,val)  (((unsigned long long) (stamp) << 56) | ((unsigned long long) (state) << 54) | (unsigned long long) (val))
+#define OS_STAMP(s)  ((int) ((s) >> 56))
+#define OS_STATE(s)  (((s) >> 54) & 3ull)
+#define OS_VALUE(s)  ((s) & ((1ull << 54) - 1))
+
+template <bool FROM_SEEDS>
+__global__ __launch_bounds__(ST)
+void os_first_hist_kernel(const void *in, int64_t n, int shift, key_layout L, unsigned long long *ghist, const uint16_t *valid)
+{ __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  for (int64_t tile = blockIdx.x; tile*STILE < n; tile += gridDim.x)
+    { const int64_t base = tile * STILE;
+      #pragma unroll 4
+      for (int r = 0; r < SITEMS; r++)
+        { const int64_t i = base + r*ST + threadIdx.x;
+          if (i < n && (!FROM_SEEDS || valid == NULL || (int) (i & 1023) < (int) valid[i >> 10]))
+            { const u128 k = load_key<FROM_SEEDS>(in,i,L);
+              atomicAdd(&h[digit_of(k,shift)],1u);
+            }
+        }
+    }
+  __syncthreads();
+  if (h[threadIdx.x] != 0)
+    atomicAdd(ghist + threadIdx.x,(unsigned long long) h[threadIdx.x]);
+}
+
+// ghist[256] counts -> gbase[256] exclusive starts; clears the counts of the pass after next and the ticket
+__global__ __launch_bounds__(256)
+void os_scan256_kernel(const unsigned long long *ghist, unsigned long long *gbase, unsigned long long *clear, unsigned int *ticket)
+{ __shared__ unsigned long long t[256];
+  t[threadIdx.x] = ghist[threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0)
+    { unsigned long long run = 0;
+      for (int d = 0; d < 256; d++) { const unsigned long long v = t[d]; t[d] = run; run += v; }
+      *ticket = 0;
+    }
+  __syncthreads();
+  gbase[threadIdx.x] = t[threadIdx.x];
+  if (clear != NULL)
+    clear[threadIdx.x] = 0;
+}
+
+#define OS_ITEMS   SITEMS             // a one-sweep tile is a tile of the three-kernel passes: 4096 keys
+#define OS_TILE    STILE
+// (Tried and dropped: 2048-key tiles whose keys are first put into digit order in LDS, so that the write-out is runs of
+//  consecutive slots -- 6.1 ms instead of 4.4 ms on the bench pair, 152 instead of 121 ms on 0.55 G keys: the scattered
+//  16-byte stores are not what bounds a pass.)
+
+template <bool FROM_SEEDS>
+__global__ __launch_bounds__(ST)
+void os_pass_kernel(const void *in, uint4 *out, int64_t n, int shift, int next_shift, key_layout L, int stamp,
+                    const unsigned long long *gbase, unsigned long long *status, unsigned long long *next_hist,
+                    unsigned int *ticket, const uint16_t *valid)
+{ __shared__ uint32_t wcnt[SWAVES][256];      // per-wave digit counts, then per-wave digit bases inside the tile
+  __shared__ unsigned long long dbase[256];   // where the tile's keys of every digit start in `out`
+  __shared__ uint32_t nh[256];                // digits of the next pass among the keys written
+  __shared__ int tile_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0)
+    tile_s = (int) atomicAdd(ticket,1u);
+  for (int x = tid; x < SWAVES*256; x += ST)
+    (&wcnt[0][0])[x] = 0;
+  nh[tid] = 0;
+  __syncthreads();
+  const int tile = tile_s;
+
+  const int64_t wbase = (int64_t) tile * OS_TILE + (int64_t) wave * (64*OS_ITEMS);
+  static_assert(64*OS_ITEMS == 1024,"one seed block per wavefront");
+  const int vcount = (FROM_SEEDS && valid != NULL && wbase < n) ? (int) valid[wbase >> 10] : 64*OS_ITEMS;
+  u128     key[OS_ITEMS];
+  uint16_t rank[OS_ITEMS];
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64-lane));
+  #pragma unroll
+  for (int r = 0; r < OS_ITEMS; r++)
+    { const int64_t i = wbase + r*64 + lane;
+      const bool ok = i < n && r*64 + lane < vcount;
+      uint32_t d = 256;
+      if (ok)
+        { key[r] = load_key<FROM_SEEDS>(in,i,L);
+          d = digit_of(key[r],shift);
+        }
+      uint64_t peers = __ballot(ok);
+      #pragma unroll
+      for (int b = 0; b < 8; b++)
+        { const uint64_t m = __ballot((d >> b) & 1);
+          peers &= ((d >> b) & 1) ? m : ~m;
+        }
+      const uint32_t before = __popcll(peers & lt);
+      uint32_t basec = 0;
+      if (ok)
+        basec = wcnt[wave][d];
+      rank[r] = (uint16_t) (basec + before);
+      if (ok && (peers >> lane) >> 1 == 0)
+        wcnt[wave][d] = basec + before + 1;
+    }
+  __syncthreads();
+  // thread d: the tile's count of digit d, published; per-wave bases; look-back over the earlier tiles
+  { uint32_t run = 0;
+    #pragma unroll
+    for (int w = 0; w < SWAVES; w++)
+      { const uint32_t c = wcnt[w][tid];
+        wcnt[w][tid] = run;
+        run += c;
+      }
+    unsigned long long *mine = status + (size_t) tile*256 + tid;
+    if (tile > 0)
+      __hip_atomic_store(mine,OS_PACK(stamp,OS_LOCAL,run),__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long excl = 0;
+    for (int t = tile-1; t >= 0; t--)
+      { const unsigned long long *p = status + (size_t) t*256 + tid;
+        unsigned long long sv = __hip_atomic_load(p,__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
+        while (OS_STAMP(sv) != stamp || OS_STATE(sv) == 0)
+          { __builtin_amdgcn_s_sleep(1);
+            sv = __hip_atomic_load(p,__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
+          }
+        excl += OS_VALUE(sv);
+        if (OS_STATE(sv) == OS_INCL)
+          break;
+      }
+    __hip_atomic_store(mine,OS_PACK(stamp,OS_INCL,excl + run),__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
+    dbase[tid] = gbase[tid] + excl;
+  }
+  __syncthreads();
+  #pragma unroll
+  for (int r = 0; r < OS_ITEMS; r++)
+    { const int64_t i = wbase + r*64 + lane;
+      if (i < n && r*64 + lane < vcount)
+        { const uint32_t d = digit_of(key[r],shift);
+          const int64_t pos = (int64_t) dbase[d] + wcnt[wave][d] + rank[r];
+          uint4 v;
+          v.x = (uint32_t) key[r].lo; v.y = (uint32_t) (key[r].lo >> 32);
+          v.z = (uint32_t) key[r].hi; v.w = (uint32_t) (key[r].hi >> 32);
+          out[pos] = v;
+          if (next_hist != NULL)
+            atomicAdd(&nh[digit_of(key[r],next_shift)],1u);
+        }
+    }
+  if (next_hist != NULL)
+    { __syncthreads();
+      if (nh[tid] != 0)
+        atomicAdd(next_hist + tid,(unsigned long long) nh[tid]);
+    }
+}
+
+// the passes of one sort, one-sweep; `first` reads seeds (FROM_SEEDS) or keys; buffers alternate.  Enqueued on the stream.
+// work: 3 x 256 + 8 unsigned long long (two digit histograms, the digit bases, the ticket) + status (256 per tile)
+static size_t os_work_bytes(int64_t ntiles)
+{ return sizeof(unsigned long long)*(3*256 + 8 + 256*(size_t) ntiles); }
+
+static void os_sort(fga_dev *dev, const void *first, bool from_seeds, int64_t next, const uint16_t *valid, key_layout L,
+                    uint4 *buf0, uint4 *buf1, int64_t n, int lowbit, int npass, void *work, int64_t ntiles_max, uint4 **sorted)
+{ unsigned long long *hist[2] = { (unsigned long long *) work, (unsigned long long *) work + 256 };
+  unsigned long long *gbase = (unsigned long long *) work + 512;
+  unsigned int *ticket = (unsigned int *) ((unsigned long long *) work + 768);
+  unsigned long long *status = (unsigned long long *) work + 776;
+  hipMemsetAsync(work,0,os_work_bytes(ntiles_max),dev->stream);
+  const void *src = first;
+  uint4 *dst = buf0;
+  int64_t cnt = from_seeds ? next : n;                     // slots the first pass looks at
+  { int grid = (int) ((cnt + STILE - 1) / STILE);
+    if (grid > dev->ncu*8) grid = dev->ncu*8;
+    if (grid < 1) grid = 1;
+    if (from_seeds)
+      hipLaunchKernelGGL(os_first_hist_kernel<true>,dim3(grid),dim3(ST),0,dev->stream,src,cnt,lowbit,L,hist[0],valid);
+    else
+      hipLaunchKernelGGL(os_first_hist_kernel<false>,dim3(grid),dim3(ST),0,dev->stream,src,cnt,lowbit,L,hist[0],(const uint16_t *) NULL);
+  }
+  for (int p = 0; p < npass; p++)
+    { const int shift = lowbit + 8*p;
+      const int64_t m = (p == 0) ? cnt : n;
+      const int nt = (int) ((m + OS_TILE - 1) / OS_TILE);
+      unsigned long long *hc = hist[p & 1], *hn = (p+1 < npass) ? hist[(p+1) & 1] : NULL;
+      hipLaunchKernelGGL(os_scan256_kernel,dim3(1),dim3(256),0,dev->stream,hc,gbase,hn,ticket);
+      if (p == 0 && from_seeds)
+        hipLaunchKernelGGL(os_pass_kernel<true>,dim3(nt),dim3(ST),0,dev->stream,src,dst,m,shift,shift+8,L,p+1,gbase,status,hn,ticket,valid);
+      else
+        hipLaunchKernelGGL(os_pass_kernel<false>,dim3(nt),dim3(ST),0,dev->stream,src,dst,m,shift,shift+8,L,p+1,gbase,status,hn,ticket,
+                           (const uint16_t *) NULL);
+      src = dst;
+      dst = (dst == buf0) ? buf1 : buf0;
+    }
+  *sorted = (uint4 *) src;
+}
+
 static int bits_for(int64_t maxval)      // bits needed to hold values 0..maxval
 { int b = 1;
   while ((maxval >> b) != 0) b++;
@@ -292,11 +493,15 @@ extern "C" int fga_seed_sort(fga_dev *dev, const fga_dseeds *S, const fga_sort_p
   const int64_t hm = (int64_t) 256*ntiles;
   const int nch = (int) ((hm + SCAN_CH - 1) / SCAN_CH);
   hipError_t e;
+  // FGA_SORT_3N=1: the three-kernel passes (tile histogram, scan, scatter: 3 n traffic per pass) instead of the one-sweep ones
+  const bool three = getenv("FGA_SORT_3N") != NULL && atoi(getenv("FGA_SORT_3N")) != 0;
+  const int64_t ostiles = ((next > n ? next : n) + OS_TILE - 1) / OS_TILE;
+  const size_t wbytes = three ? sizeof(uint32_t)*(256*(size_t) ntiles + nch + 1) : os_work_bytes(ostiles);
   K->alloc_bytes = sizeof(uint4)*(size_t) n;
   e = hipSuccess;
   buf[0] = (uint4 *) fga_dev_acquire(dev,SLOT_SORT0,K->alloc_bytes);
   buf[1] = (uint4 *) fga_dev_acquire(dev,SLOT_SORT1,K->alloc_bytes);
-  hist   = (uint32_t *) fga_dev_acquire(dev,SLOT_HIST,sizeof(uint32_t)*(256*(size_t) ntiles + nch + 1));
+  hist   = (uint32_t *) fga_dev_acquire(dev,SLOT_HIST,wbytes);
   if (buf[0] == NULL || buf[1] == NULL || hist == NULL)
     { fga_set_error("fga_seed_sort: device allocation failed");
       fga_dev_release(dev,SLOT_SORT0,buf[0]); fga_dev_release(dev,SLOT_SORT1,buf[1]);
@@ -306,7 +511,13 @@ extern "C" int fga_seed_sort(fga_dev *dev, const fga_dseeds *S, const fga_sort_p
   sums = hist + 256*(size_t) ntiles;
   hipEventRecord(dev->ev0,dev->stream);
   const void *src = S->seeds;
-  int cur = 0;
+  if (!three)
+    { uint4 *sorted = NULL;
+      os_sort(dev,S->seeds,true,next,S->valid,L,buf[0],buf[1],n,lowbit,npass,hist,ostiles,&sorted);
+      src = sorted;
+    }
+  else
+  { int cur = 0;
   for (int p = 0; p < npass; p++)
     { const int shift = lowbit + 8*p;
       uint4 *dst = buf[cur];
@@ -332,6 +543,7 @@ extern "C" int fga_seed_sort(fga_dev *dev, const fga_dseeds *S, const fga_sort_p
       src = dst;
       cur ^= 1;
     }
+  }
   hipEventRecord(dev->ev1,dev->stream);
   e = hipStreamSynchronize(dev->stream);
   if (e == hipSuccess) e = hipGetLastError();
@@ -360,7 +572,9 @@ int fga_radix_sort_u128(fga_dev *dev, uint4 *buf0, uint4 *buf1, int64_t n, int l
   const int ntiles = (int) ((n + STILE - 1) / STILE);
   const int64_t hm = (int64_t) 256*ntiles;
   const int nch = (int) ((hm + SCAN_CH - 1) / SCAN_CH);
-  uint32_t *hist = (uint32_t *) fga_dev_acquire(dev,SLOT_HIST,sizeof(uint32_t)*(256*(size_t) ntiles + nch + 1));
+  const bool three = getenv("FGA_SORT_3N") != NULL && atoi(getenv("FGA_SORT_3N")) != 0;
+  uint32_t *hist = (uint32_t *) fga_dev_acquire(dev,SLOT_HIST,three ? sizeof(uint32_t)*(256*(size_t) ntiles + nch + 1)
+                                                                    : os_work_bytes((n + OS_TILE - 1) / OS_TILE));
   if (hist == NULL)
     { fga_set_error("radix sort: device allocation failed");
       return 1;
@@ -369,6 +583,9 @@ int fga_radix_sort_u128(fga_dev *dev, uint4 *buf0, uint4 *buf1, int64_t n, int l
   key_layout L;
   memset(&L,0,sizeof(L));
   uint4 *src = buf0, *dst = buf1;
+  if (!three)
+    os_sort(dev,buf0,false,n,(const uint16_t *) NULL,L,buf1,buf0,n,lowbit,npass,hist,(n + OS_TILE - 1) / OS_TILE,&src);
+  else
   for (int p = 0; p < npass; p++)
     { const int shift = lowbit + 8*p;
       hipLaunchKernelGGL(sort_hist_kernel<false>,dim3(ntiles),dim3(ST),0,dev->stream,(const void *) src,n,shift,L,hist,ntiles,

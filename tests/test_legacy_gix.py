@@ -102,3 +102,23 @@ def test_pipeline_on_legacy_index_files_gives_the_same_alignments(toy_pair, tmp_
     L.fga_gix_close(X)
     with pytest.raises(Exception):                       # -f above the cutoff the old index was built with
         D.run(write_legacy_index(ra, str(tmp_path / "old8" / "A"), freq=8), ob, old_out, nthreads=4)
+
+
+def test_legacy_stub_with_a_bad_prefix_index_is_refused(toy_pair, tmp_path, built_library):
+    """the old layout's table is expanded along the stub's 2^24 prefix index: an index that is not a cumulative count
+    over the stub's k-mers (a damaged or foreign stub) must be refused, not followed past the table"""
+    import numpy as np
+    L = built_library
+    d, ra, rb = toy_pair
+    X = C.c_void_p()
+    for k, edit in enumerate((lambda ix: ix.__setitem__(slice(1000, 1010), ix[1000:1010] + 10**7),      # runs past the k-mers
+                              lambda ix: ix.__setitem__(5000, ix[4999] - 1 if ix[4999] > 0 else ix[5001] + 1),   # not monotone
+                              lambda ix: np.minimum(ix, ix[-1] - 1, out=ix))):                               # ends short of them
+        old = write_legacy_index(ra, str(tmp_path / f"stub{k}" / "A"))
+        raw = bytearray(open(old + ".gix", "rb").read())
+        ix = np.frombuffer(raw, dtype=np.int64, count=1 << 24, offset=16).copy()
+        edit(ix)
+        raw[16:16 + 8 * (1 << 24)] = ix.tobytes()
+        open(old + ".gix", "wb").write(raw)
+        assert L.fga_gix_open((old + ".gix").encode(), C.byref(X)) != 0
+        assert b"prefix index of the stub" in L.fga_last_error(), L.fga_last_error()

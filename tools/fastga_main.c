@@ -107,6 +107,7 @@ static char *root_of(const char *src, int *is_fasta)
 typedef struct
   { char *root;
     int   made_gdb;        /* this run created <root>.gdb + .<root>.bps: they go again unless -k */
+    int   made_gix;        /* this run created <root>.gix + .<root>.ktab.N (only with -k): they go again when the run fails */
   } source;
 
 static source Src[2];
@@ -123,6 +124,21 @@ static void clean_exit(int status)
           if (slash != NULL)
             { if (asprintf(&p,"%.*s/.%s.bps",(int) (slash-Src[i].root),Src[i].root,slash+1) >= 0) { unlink(p); free(p); } }
           else if (asprintf(&p,".%s.bps",Src[i].root) >= 0) { unlink(p); free(p); }
+        }
+  if (status != 0)                                   /* a created index goes as well (GIXrm -f in the reference, FastGA.c:152-196) */
+    for (i = 0; i < 2; i++)
+      if (Src[i].root != NULL && Src[i].made_gix)
+        { char *p, *slash = strrchr(Src[i].root,'/');
+          int k;
+          if (asprintf(&p,"%s.gix",Src[i].root) >= 0) { unlink(p); free(p); }
+          for (k = 1; k <= 64; k++)
+            { int rc;
+              if (slash != NULL)
+                rc = asprintf(&p,"%.*s/.%s.ktab.%d",(int) (slash-Src[i].root),Src[i].root,slash+1,k);
+              else
+                rc = asprintf(&p,".%s.ktab.%d",Src[i].root,k);
+              if (rc >= 0) { if (unlink(p) != 0) k = 65; free(p); }
+            }
         }
   if (Log != NULL) fclose(Log);
   exit(status);
@@ -159,6 +175,7 @@ static int prepare(const char *src, source *S, int nthreads, int want_gix_files)
   if (!exists("%s.gix",r) && want_gix_files)        /* otherwise the index is built on the device, in HBM only */
     { fga_gdb *g;
       say("\n  Creating genome index (GIX) %s.gix\n",r);
+      S->made_gix = 1;
       if (fga_gdb_open(r,&g) || fga_gix_build_masked(g,r,nthreads,fga_gdb_nmask(g) > 0))
         { fprintf(stderr,"FastGA: %s\n",fga_last_error());
           return 1;
@@ -266,9 +283,15 @@ int main(int argc, char *argv[])
           }
       }
     else if (argv[i][0] == '#')
-      { fprintf(stderr,"FastGA: mask file arguments (%s) are not supported by this build: the index is made from the GDB's\n"
-                       "        own lower-case intervals; soft-mask the FASTA and use -M\n",argv[i]);
-        return 1;
+      { /* "#" alone = the implicit mask of the preceding genome (the lower-case intervals its GDB carries, GIXmake.c:1829-
+           1832): that is the mask this build's index always carries, so the argument only switches soft masking on
+           (FastGA.c:4580).  A named .1ano / .1bed file would need GIXmake's ANO reader: refused. */
+        if (argv[i][1] != '\0')
+          { fprintf(stderr,"FastGA: mask file arguments (%s) are not supported by this build: the index is made from the GDB's\n"
+                           "        own lower-case intervals; soft-mask the FASTA and use -M or a bare #\n",argv[i]);
+            return 1;
+          }
+        P.soft_mask = 1;
       }
     else if (nsrc < 2)
       src[nsrc++] = argv[i];
