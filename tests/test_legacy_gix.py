@@ -121,4 +121,5 @@ def test_legacy_stub_with_a_bad_prefix_index_is_refused(toy_pair, tmp_path, buil
         raw[16:16 + 8 * (1 << 24)] = ix.tobytes()
         open(old + ".gix", "wb").write(raw)
         assert L.fga_gix_open((old + ".gix").encode(), C.byref(X)) != 0
-        assert b"prefix index of the stub" in L.fga_last_error(), L.fga_last_error()
+        msg = L.fga_last_error()        # the last entry is also the k-mer count the table parts are checked against
+        assert b"prefix index of the stub" in msg or (k == 2 and b"does not match its stub" in msg), msg
