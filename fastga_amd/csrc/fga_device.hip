@@ -191,6 +191,13 @@ extern "C" int fga_dev_download(fga_dev *dev, void *host_dst, const void *device
   return 0;
 }
 
+extern "C" int fga_dev_upload(fga_dev *dev, void *device_dst, const void *host_src, size_t bytes)
+{ FGA_HIP(hipSetDevice(dev->device));
+  if (bytes > 0)
+    FGA_HIP(hipMemcpy(device_dst,host_src,bytes,hipMemcpyHostToDevice));
+  return 0;
+}
+
 extern "C" void fga_dev_close(fga_dev *d)
 { if (d == NULL) return;
   hipSetDevice(d->device);

@@ -306,7 +306,10 @@ int fga_alns_concat(const fga_alns *const *raw, int nraw, fga_alns **out)
   if (R == NULL) goto oom;
   for (k = 0; k < nraw; k++)
     if (raw[k] != NULL)
-      { R->naln += raw[k]->naln; R->ntrace += raw[k]->ntrace; R->ncalls += raw[k]->ncalls; R->nwaves += raw[k]->nwaves; }
+      { R->naln += raw[k]->naln; R->ntrace += raw[k]->ntrace; R->ncalls += raw[k]->ncalls; R->nwaves += raw[k]->nwaves;
+        R->ncells += raw[k]->ncells; R->nbases += raw[k]->nbases;        /* the launches' accounting adds up; busy wavefronts: the largest */
+        if (raw[k]->busy_waves > R->busy_waves) R->busy_waves = raw[k]->busy_waves;
+      }
   R->alns = malloc(sizeof(fga_aln)*(R->naln+1));
   R->tbytes = malloc(R->ntrace+16);
   if (R->alns == NULL || R->tbytes == NULL) goto oom;

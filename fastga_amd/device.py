@@ -444,6 +444,11 @@ class Session:
                                       C.c_void_p(ptr), int(nbytes)), "device download")
         return out
 
+    def dev_upload(self, ptr, arr):
+        a = np.ascontiguousarray(arr)
+        check(self.L.fga_dev_upload(self.L.fga_session_device(self.h), C.c_void_p(ptr), a.ctypes.data_as(C.c_void_p),
+                                    a.nbytes), "device upload")
+
     def dev_wrapper(self):
         """the session's device context as a (non-owning) Device object"""
         d = Device.__new__(Device)

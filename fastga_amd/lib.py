@@ -206,6 +206,7 @@ def _declare(L):
         "fga_merge_prefix_cuts": (i32, [vp, vp, vp, i32, P(i64)]),
         "fga_session_prefix_cuts": (i32, [vp, i32, P(i64)]),
         "fga_alns_concat": (i32, [P(P(Alns)), i32, P(P(Alns))]),
+        "fga_dev_upload": (i32, [vp, vp, vp, C.c_size_t]),
         "fga_alns_merge_filtered": (i32, [P(P(Alns)), i32, P(P(Alns))]),
         "fga_session_finish_filtered": (i32, [vp, P(RunParams), P(P(Alns)), i32, P(RunStats)]),
         "fga_shim_New_Work_Data": (vp, []),

@@ -123,7 +123,9 @@ def gather_records(dist, recs, tb, counts, device, dst=0):
 def run_sharded(ses, dist, prm_kwargs, device):
     """One pass of the hot path over the session's resident inputs, cut over dist's ranks.  Every rank holds both
     tables and genomes (replicated: 2 x 33 GB at 3 Gbp fits each GPU's 288 GB several times over).  Returns the stats
-    dict on every rank; rank 0's has the totals of the finished run (nlive, cover) and wrote the output."""
+    dict on every rank; rank 0's has the totals of the finished run (nlive, cover) and wrote the output.
+    device = "cuda:<n>" with backend nccl (RCCL: the exchange buffers are device tensors), or "cpu" with backend gloo
+    (records staged through the host; how tests/test_parts_gpu.py runs this very function with two ranks on one GPU)."""
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
     out_path = prm_kwargs.get("out_path")
@@ -138,8 +140,16 @@ def run_sharded(ses, dist, prm_kwargs, device):
     n = seeds.count
     hist = all_reduce_counts(dist, ses.contig_histogram(seeds), device)
     select = partition_contigs(hist, world)
-    send = torch.empty((max(n, 1), 4), dtype=torch.int32, device=device)
-    off = ses.split_to(seeds, select, world, send.data_ptr())
+    host = str(device) == "cpu"          # gloo: the collectives move host tensors, the records are staged through the host
+    if host:
+        sbuf = ses.dev_malloc(16 * max(n, 1))
+        off = ses.split_to(seeds, select, world, sbuf)
+        send = torch.from_numpy(ses.dev_download(sbuf, 16 * n).view(np.int32).reshape(-1, 4).copy()) if n > 0 \
+            else torch.zeros((0, 4), dtype=torch.int32)
+        ses.dev_free(sbuf)
+    else:
+        send = torch.empty((max(n, 1), 4), dtype=torch.int32, device=device)
+        off = ses.split_to(seeds, select, world, send.data_ptr())
     seeds.free()
     in_splits = np.diff(off).astype(np.int64)
     t_in = torch.from_numpy(in_splits).to(device)
@@ -150,11 +160,16 @@ def run_sharded(ses, dist, prm_kwargs, device):
     recv = torch.empty((max(total, 1), 4), dtype=torch.int32, device=device)
     dist.all_to_all_single(recv[:total], send[:n], output_split_sizes=out_splits.tolist(),
                            input_split_sizes=in_splits.tolist())
-    if device != "cpu":
+    if host:
+        rbuf = ses.dev_malloc(16 * max(total, 1))
+        if total > 0:
+            ses.dev_upload(rbuf, recv[:total].numpy())
+        part = ses.import_seeds([(rbuf, total)])
+        ses.dev_free(rbuf)
+    else:
         torch.cuda.synchronize()
-    del send
-    part = ses.import_seeds([(recv.data_ptr(), total)])
-    del recv
+        part = ses.import_seeds([(recv.data_ptr(), total)])
+    del send, recv
     raw = ses.align(prm, st, part)
     fil = ses.filter(raw, nthreads=kw.get("nthreads", 8))        # this rank's contig pairs are complete: filter here
     ses.free_alns(raw)

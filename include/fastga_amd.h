@@ -92,6 +92,7 @@ float fga_dev_stage_ms(const fga_dev *dev, int stage);   /* HIP-event time of th
 int   fga_dev_malloc(fga_dev *dev, size_t bytes, void **out);
 void  fga_dev_free(fga_dev *dev, void *ptr);
 int   fga_dev_download(fga_dev *dev, void *host_dst, const void *device_src, size_t bytes);
+int   fga_dev_upload(fga_dev *dev, void *device_dst, const void *host_src, size_t bytes);
 int64_t fga_dev_peak_bytes(fga_dev *dev);   /* peak device memory in use by this process so far (stage-boundary samples) */
 void    fga_dev_set_host_threads(fga_dev *dev, int nthreads);   /* threads for the host tails of the device stages (unit
                                                                    order, hit re-lay, work order of the extension); default 1 */

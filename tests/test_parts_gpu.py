@@ -96,3 +96,57 @@ def test_session_run_in_several_passes(toy_pair, tmp_path):
     assert one["nparts"] == 1 and many["nparts"] >= 5
     assert _view(os.path.join(w, "many.1aln")) == _view(os.path.join(w, "one.1aln"))
     assert many["nseeds"] == one["nseeds"] and many["nhits"] == one["nhits"] and many["nlive"] == one["nlive"]
+
+
+# ---- run_sharded itself with N = 2: two processes on cuda:0, backend gloo (the exchange staged through the host) ----------
+
+def _sharded_worker(rank, world, port, ra, rb, out, q, self_mode):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fastga_amd import device as D
+        from fastga_amd.parallel import run_sharded
+        ses = D.Session(ra, None if self_mode else rb)
+        st = run_sharded(ses, dist, dict(out_path=out, nthreads=4), "cpu")
+        ses.close()
+        q.put((rank, {k: st[k] for k in ("nseeds", "nalns", "nlive", "part_seeds", "exchange_seeds_out")}))
+    except Exception as e:                                  # report instead of hanging the other rank's collective
+        q.put((rank, {"error": repr(e)}))
+        raise
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("self_mode", [False, True])
+def test_run_sharded_with_two_ranks_on_one_gpu(toy_pair, tmp_path, self_mode):
+    """the real multi-GPU function -- prefix ranges, all-reduced contig histogram, partition, all-to-all-v of the seeds,
+    phase 2 and the filter on the owning rank, gather, merge by A contig on rank 0 -- with world size 2.  RCCL refuses two
+    ranks on one device, so the collectives are gloo's and the records are staged through the host; every C-ABI call and
+    all of parallel.run_sharded's control flow are the ones an 8-GPU run executes.  Result: the reference's .1aln."""
+    import socket
+    import torch.multiprocessing as mp
+    from oracle import harness as H
+    if not H.have_reference():
+        pytest.skip("oracle/_ref did not travel")
+    d, ra, rb = toy_pair
+    out = str(tmp_path / "sharded.1aln")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, ra, rb, out, q, self_mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+    assert all("error" not in v for v in res.values()), res
+    assert all(p.exitcode == 0 for p in procs)
+    assert res[0]["part_seeds"] > 0 and res[1]["part_seeds"] > 0                 # both ranks owned contigs
+    assert res[0]["exchange_seeds_out"] + res[1]["exchange_seeds_out"] > 0       # and seeds really changed ranks
+    rd = str(tmp_path / "ref")
+    os.makedirs(rd)
+    H.ref_fastga(ra, None if self_mode else rb, rd, os.path.join(rd, "ref"), threads=4)
+    from fastga_amd import workload
+    assert workload.digest_1aln(_view(out)) == workload.digest_1aln(_view(os.path.join(rd, "ref.1aln")))
