@@ -136,7 +136,8 @@ def main():
     prep_s = time.time() - t0
 
     # inputs resident in HBM before the timed region: both GIX tables + both 2-bit genomes (every rank holds all of them)
-    ses = D.Session(ra, rb, device=local)
+    # (with N ranks: every rank holds the genomes' bases and ITS 12-mer prefix range of the two tables only)
+    ses = D.Session(ra, rb, device=local, rank=rank if world > 1 else 0, nranks=world if world > 1 else 1, nthreads=threads)
     out1aln = os.path.join(shared, "bench.1aln")
     kw = dict(out_path=out1aln, nthreads=threads, command_line="bench.py FastGA hot path")
     if args.self_:
@@ -202,7 +203,9 @@ def main():
         nseeds = S("nseeds")
         # algorithmic bytes of the merge launches of one step: every table entry once in its on-disk width, every seed
         # once in the reference's record width (with N ranks each launch covers 1/N of the prefix space)
-        alg_bytes = ses.table_bytes + nseeds * ses.seed_bytes * (2 if args.self_ else 1)    # self: the reported total is halved (FastGA.c:1906)
+        seed_bytes = nseeds * ses.seed_bytes * (2 if args.self_ else 1)    # self: the reported total is halved (FastGA.c:1906)
+        # a sliced session's table bytes are rank 0's share already (the ranges are cut for equal cost)
+        alg_bytes = ses.table_bytes * (world if ses.nranks > 1 else 1) + seed_bytes
         achieved = alg_bytes / max(1, world) / (kavg * 1e-3) / 1e9          # per GPU, slowest rank's launch time
         stage_ms = {k: round(1000 * sum(s[k] for s in stats) / len(stats), 2)
                     for k in ("merge_s", "sort_s", "chain_s", "extend_s", "filter_s", "write_s")}

@@ -222,31 +222,54 @@ extern "C" float fga_dev_stage_ms(const fga_dev *d, int stage)
   return d->last_ms[stage];
 }
 
-extern "C" int fga_dgix_upload(fga_dev *dev, const fga_gix *X, fga_dgix **out)
+// the entries of the 12-mer prefixes [pbeg,pend) of a host-resident table (the whole table: 0, 2^24) on the device
+static int dgix_upload_impl(fga_dev *dev, const fga_gix *X, int64_t pbeg, int64_t pend, fga_dgix **out)
 { *out = NULL;
   FGA_HIP(hipSetDevice(dev->device));
+  if (X->table == NULL || X->index == NULL)
+    { fga_set_error("fga_dgix_upload: the index holds no host copy of its table");
+      return 1;
+    }
   fga_dgix *D = (fga_dgix *) calloc(1,sizeof(fga_dgix));
   if (D == NULL)
     { fga_set_error("out of memory");
       return 1;
     }
+  const bool whole = pbeg <= 0 && pend >= FGA_NPREFIX;
+  const int64_t lo = (whole || pbeg <= 0) ? 0 : X->index[pbeg-1], hi = whole ? X->nents : X->index[pend-1];
+  int64_t *sub = NULL;
+  const int64_t *hidx = X->index;
   D->dev = dev;
-  D->nents = X->nents; D->ebytes = X->ebytes; D->postbytes = X->postbytes; D->contbytes = X->contbytes;
+  D->nents = hi - lo; D->ebytes = X->ebytes; D->postbytes = X->postbytes; D->contbytes = X->contbytes;
   D->nctg = X->nctg;
-  size_t tbytes = (size_t) X->nents * X->ebytes;
+  if (!whole)                                       // the slice's own cumulative counts
+    { sub = (int64_t *) malloc(sizeof(int64_t)*FGA_NPREFIX);
+      if (sub == NULL)
+        { fga_set_error("out of memory"); free(D);
+          return 1;
+        }
+      for (int64_t p = 0; p < FGA_NPREFIX; p++)
+        { const int64_t v = X->index[p];
+          sub[p] = (v < lo ? lo : (v > hi ? hi : v)) - lo;
+        }
+      hidx = sub;
+    }
+  size_t tbytes = (size_t) D->nents * X->ebytes;
   hipError_t e;
   if ((e = hipMalloc(&D->table,tbytes + 64)) != hipSuccess ||
       (e = hipMalloc(&D->index,sizeof(int64_t)*FGA_NPREFIX)) != hipSuccess)
     { fga_set_error("fga_dgix_upload: device allocation of %zu bytes failed: %s",tbytes,hipGetErrorString(e));
-      hipFree(D->table); hipFree(D->index); free(D);
+      hipFree(D->table); hipFree(D->index); free(D); free(sub);
       return 1;
     }
-  if ((e = hipMemcpy(D->table,X->table,tbytes + 64,hipMemcpyHostToDevice)) != hipSuccess ||
-      (e = hipMemcpy(D->index,X->index,sizeof(int64_t)*FGA_NPREFIX,hipMemcpyHostToDevice)) != hipSuccess)
+  if ((e = hipMemcpy(D->table,X->table + (size_t) lo*X->ebytes,tbytes,hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemset(D->table + tbytes,0,64)) != hipSuccess ||
+      (e = hipMemcpy(D->index,hidx,sizeof(int64_t)*FGA_NPREFIX,hipMemcpyHostToDevice)) != hipSuccess)
     { fga_set_error("fga_dgix_upload: copy failed: %s",hipGetErrorString(e));
-      hipFree(D->table); hipFree(D->index); free(D);
+      hipFree(D->table); hipFree(D->index); free(D); free(sub);
       return 1;
     }
+  free(sub);
   D->legacy_cutoff = X->legacy ? X->freq : 0;
   if (fga_dgix_make_view(dev,D,0))
     { hipFree(D->table); hipFree(D->index); free(D);
@@ -255,6 +278,21 @@ extern "C" int fga_dgix_upload(fga_dev *dev, const fga_gix *X, fga_dgix **out)
   *out = D;
   return 0;
 }
+
+extern "C" int fga_dgix_upload(fga_dev *dev, const fga_gix *X, fga_dgix **out)
+{ return dgix_upload_impl(dev,X,0,FGA_NPREFIX,out); }
+
+// one rank's slice of a table read from index files (see fga_dgix_build_range)
+extern "C" int fga_dgix_upload_range(fga_dev *dev, const fga_gix *X, int64_t pbeg, int64_t pend, fga_dgix **out)
+{ if (pbeg < 0 || pend > FGA_NPREFIX || pbeg >= pend)
+    { fga_set_error("fga_dgix_upload_range: bad prefix range");
+      *out = NULL;
+      return 1;
+    }
+  return dgix_upload_impl(dev,X,pbeg,pend,out);
+}
+
+extern "C" int64_t fga_dgix_nents(const fga_dgix *D) { return D == NULL ? 0 : D->nents; }
 
 extern "C" void fga_dgix_free(fga_dgix *D)
 { if (D == NULL) return;

@@ -32,7 +32,8 @@ struct gix_scan_args
     const int     *invp;            // original contig -> length-sorted index
     const gix_item *items; int nitems;
     int postbytes, contbytes;
-    uint4 *keys; int64_t cap;
+    uint4 *keys; int64_t cap;          // keys == NULL: count only (per-prefix counts and the sample histogram)
+    uint32_t pbeg, pend;               // only k-mers whose 12-mer prefix lies in [pbeg,pend) are kept (a rank's slice)
     unsigned long long *nkeys;
     uint32_t *count;                // [2^24]
     unsigned long long *sbuck;      // [1024]
@@ -96,17 +97,22 @@ void gix_scan_kernel(gix_scan_args A)
       if (v8[x] != m && v8[x+4] != m)
         continue;
       // GIXmake's sample: every syncmer, both strands, whether or not the 40-mer fits
-      { uint32_t f5 = 0, c5 = 0;
-        #pragma unroll
-        for (int k = 0; k < 5; k++)
-          { f5 = (f5 << 2) | s[x+k];
-            c5 = (c5 << 2) | (3u - s[x+11-k]);
-          }
-        atomicAdd(&sh[f5],1u);
-        atomicAdd(&sh[c5],1u);
-      }
-      if (j <= len - FGA_KMER) { fmask |= 1u << r; cnt += 1; }
-      if (j >= FGA_KMER - 12)  { cmask |= 1u << r; cnt += 1; }
+      uint32_t f12 = 0, c12 = 0;                   // 12-mer prefix of the forward / complement k-mer of this syncmer
+      #pragma unroll
+      for (int k = 0; k < 12; k++)
+        { f12 = (f12 << 2) | s[x+k];
+          c12 = (c12 << 2) | (3u - s[x+11-k]);
+        }
+      atomicAdd(&sh[f12 >> 14],1u);
+      atomicAdd(&sh[c12 >> 14],1u);
+      if (j <= len - FGA_KMER && f12 >= A.pbeg && f12 < A.pend)
+        { fmask |= 1u << r; cnt += 1;
+          if (A.keys == NULL) atomicAdd(A.count + f12,1u);
+        }
+      if (j >= FGA_KMER - 12 && c12 >= A.pbeg && c12 < A.pend)
+        { cmask |= 1u << r; cnt += 1;
+          if (A.keys == NULL) atomicAdd(A.count + c12,1u);
+        }
     }
 
   // slots: block exclusive scan, one global atomic per workgroup
@@ -127,6 +133,12 @@ void gix_scan_kernel(gix_scan_args A)
     gbase = total > 0 ? atomicAdd(A.nkeys,(unsigned long long) total) : 0ull;
   __syncthreads();
   int64_t at = (int64_t) gbase + base;
+  if (A.keys == NULL)                               // count only: the sample histogram is all that is left to do
+    { for (int x = tid; x < 1024; x += GNT)
+        if (sh[x] != 0)
+          atomicAdd(A.sbuck + x,(unsigned long long) sh[x]);
+      return;
+    }
 
   const uint64_t ctg = (uint64_t) A.invp[c];
   const uint64_t sign = 0x80ull << (8*(A.contbytes-1));
@@ -289,9 +301,15 @@ void gix_entries_kernel(gix_entries_args A)
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
-extern "C" int fga_dgix_build(fga_dev *dev, const fga_gdb *G, int nthreads, int flags,
-                              fga_dgix **dout, fga_gix **xout)
-{ *dout = NULL; *xout = NULL;
+// the build proper.  [pbeg,pend): the 12-mer prefixes kept (a rank's slice of the table; the whole space for the whole
+// table).  counts_host != NULL: count only -- the per-prefix entry counts of the whole table come back, nothing is built.
+static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int flags, int64_t pbeg, int64_t pend,
+                           uint32_t *counts_host, fga_dgix **dout, fga_gix **xout)
+{ if (dout != NULL) *dout = NULL;
+  if (xout != NULL) *xout = NULL;
+  const bool count_only = counts_host != NULL;
+  if (pbeg < 0) pbeg = 0;
+  if (pend > FGA_NPREFIX || pend <= 0) pend = FGA_NPREFIX;
   const int want_host_copy = (flags & FGA_GIX_HOST_COPY) != 0;
   const int use_mask = (flags & FGA_GIX_SOFT_MASK) != 0 && G->nmask > 0;
   int64_t *dmoff = NULL, *dmbeg = NULL, *dmend = NULL;
@@ -333,6 +351,10 @@ extern "C" int fga_dgix_build(fga_dev *dev, const fga_gdb *G, int nthreads, int 
       cap += G->contigs[c].clen;                      // < 1 k-mer per base and strand pair on average (2/5 per strand)
     }
   cap = cap + (cap >> 3) + 4096;
+  if (pend - pbeg < FGA_NPREFIX)                          // a slice: its share of the prefix space and half as much again
+    cap = (int64_t) ((double) cap * (double) (pend - pbeg) / FGA_NPREFIX * 1.5) + 65536;
+  if (count_only)
+    cap = 0;
   if (items.empty())
     { fga_set_error("fga_dgix_build: no contig is long enough to hold a syncmer");
       goto done;
@@ -349,11 +371,13 @@ extern "C" int fga_dgix_build(fga_dev *dev, const fga_gdb *G, int nthreads, int 
     { fga_set_error("fga_dgix_build: device allocation failed: %s",hipGetErrorString(e));
       goto done;
     }
-  buf0 = (uint4 *) fga_dev_acquire(dev,SLOT_SORT0,sizeof(uint4)*(size_t) cap);
-  buf1 = (uint4 *) fga_dev_acquire(dev,SLOT_SORT1,sizeof(uint4)*(size_t) cap);
-  if (buf0 == NULL || buf1 == NULL)
-    { fga_set_error("fga_dgix_build: device allocation of the key buffers failed");
-      goto done;
+  if (!count_only)
+    { buf0 = (uint4 *) fga_dev_acquire(dev,SLOT_SORT0,sizeof(uint4)*(size_t) cap);
+      buf1 = (uint4 *) fga_dev_acquire(dev,SLOT_SORT1,sizeof(uint4)*(size_t) cap);
+      if (buf0 == NULL || buf1 == NULL)
+        { fga_set_error("fga_dgix_build: device allocation of the key buffers failed");
+          goto done;
+        }
     }
   if ((e = hipMemcpyToSymbol(HIP_SYMBOL(gix_tmap),fga_gix_tmap(),256)) != hipSuccess ||
       (e = hipMemcpyAsync(dimg,G->bps,(size_t) G->bpslen,hipMemcpyHostToDevice,dev->stream)) != hipSuccess ||
@@ -374,8 +398,18 @@ extern "C" int fga_dgix_build(fga_dev *dev, const fga_gdb *G, int nthreads, int 
     A.items = ditems; A.nitems = (int) items.size();
     A.postbytes = postbytes; A.contbytes = contbytes;
     A.keys = buf0; A.cap = cap; A.nkeys = dctr; A.count = dcount; A.sbuck = dctr + 1;
+    A.pbeg = (uint32_t) pbeg; A.pend = (uint32_t) pend;
     hipLaunchKernelGGL(gix_scan_kernel,dim3((unsigned) items.size()),dim3(GNT),0,dev->stream,A);
   }
+  if (count_only)
+    { if ((e = hipMemcpyAsync(counts_host,dcount,sizeof(uint32_t)*FGA_NPREFIX,hipMemcpyDeviceToHost,dev->stream)) != hipSuccess ||
+          (e = hipStreamSynchronize(dev->stream)) != hipSuccess || (e = hipGetLastError()) != hipSuccess)
+        { fga_set_error("fga_dgix_prefix_counts: %s",hipGetErrorString(e));
+          goto done;
+        }
+      status = 0;
+      goto done;
+    }
   { unsigned long long hk[1025];
     if ((e = hipMemcpyAsync(hk,dctr,sizeof(hk),hipMemcpyDeviceToHost,dev->stream)) != hipSuccess ||
         (e = hipStreamSynchronize(dev->stream)) != hipSuccess)
@@ -400,6 +434,7 @@ extern "C" int fga_dgix_build(fga_dev *dev, const fga_gdb *G, int nthreads, int 
         A2.items = ditems; A2.nitems = (int) items.size();
         A2.postbytes = postbytes; A2.contbytes = contbytes;
         A2.keys = buf0; A2.cap = cap; A2.nkeys = dctr; A2.count = dcount; A2.sbuck = dctr + 1;
+        A2.pbeg = (uint32_t) pbeg; A2.pend = (uint32_t) pend;
         hipLaunchKernelGGL(gix_scan_kernel,dim3((unsigned) items.size()),dim3(GNT),0,dev->stream,A2);
         if ((e = hipMemcpyAsync(hk,dctr,sizeof(hk),hipMemcpyDeviceToHost,dev->stream)) != hipSuccess ||
             (e = hipStreamSynchronize(dev->stream)) != hipSuccess)
@@ -540,6 +575,38 @@ done:
       if (X != NULL) fga_gix_close(X);
       return 1;
     }
+  if (count_only)
+    return 0;
   *dout = D; *xout = X;
   return 0;
+}
+
+extern "C" int fga_dgix_build(fga_dev *dev, const fga_gdb *G, int nthreads, int flags,
+                              fga_dgix **dout, fga_gix **xout)
+{ return dgix_build_impl(dev,G,nthreads,flags,0,FGA_NPREFIX,NULL,dout,xout); }
+
+// one rank's slice of the table: only the k-mers whose 12-mer prefix lies in [pbeg,pend) ("GPU g uploads only
+// its slice of both tables"; the reference's merge threads each read one such range, FastGA.c:2291-2321).  Layout, contig
+// order and table parts are those of the whole table; the prefix index counts the slice's entries only.
+extern "C" int fga_dgix_build_range(fga_dev *dev, const fga_gdb *G, int nthreads, int flags, int64_t pbeg, int64_t pend,
+                                    fga_dgix **dout, fga_gix **xout)
+{ if (pbeg < 0 || pend > FGA_NPREFIX || pbeg >= pend)
+    { fga_set_error("fga_dgix_build_range: bad prefix range");
+      return 1;
+    }
+  if (flags & FGA_GIX_HOST_COPY)
+    { fga_set_error("fga_dgix_build_range: a slice has no host copy");
+      return 1;
+    }
+  return dgix_build_impl(dev,G,nthreads,flags,pbeg,pend,NULL,dout,xout);
+}
+
+// entries per 12-mer prefix of the table fga_dgix_build would make (one syncmer scan on the device, nothing is built):
+// what the prefix ranges of a sliced run are cut from
+extern "C" int fga_dgix_prefix_counts(fga_dev *dev, const fga_gdb *G, int nthreads, uint32_t *counts /* host, 2^24 */)
+{ if (counts == NULL)
+    { fga_set_error("fga_dgix_prefix_counts: null argument");
+      return 1;
+    }
+  return dgix_build_impl(dev,G,nthreads,0,0,FGA_NPREFIX,counts,NULL,NULL);
 }

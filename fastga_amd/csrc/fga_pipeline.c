@@ -48,6 +48,8 @@ struct fga_session
     int self;
     int devbuilt;              /* an index was built on the device (no soft-mask bytes in it) */
     double load_s, upload_s;
+    int nranks, rank;          /* > 1: the session holds the rank's 12-mer prefix range of both tables only */
+    int64_t *cuts;             /* [nranks+1] the prefix ranges of all ranks */
   };
 
 void fga_session_close(fga_session *Z)
@@ -58,6 +60,7 @@ void fga_session_close(fga_session *Z)
   fga_dev_close(Z->dev);
   fga_gix_close(Z->x2); fga_gix_close(Z->x1);
   fga_gdb_close(Z->g2); fga_gdb_close(Z->g1);
+  free(Z->cuts);
   free(Z);
 }
 
@@ -81,7 +84,54 @@ int fga_session_open(const char *root1, const char *root2, int device, fga_sessi
 
 /* nthreads: GIXmake's -T for an index the session has to build itself -- it decides the contig padding of a short GDB
    and the table parts (SURVEY.md hard part 9), i.e. the layout FastGA -T<n> would have got from its GIXmake call */
+static int session_open_impl(const char *root1, const char *root2, int device, int nthreads, int rank, int nranks,
+                             fga_session **out);
+
 int fga_session_open_threads(const char *root1, const char *root2, int device, int nthreads, fga_session **out)
+{ return session_open_impl(root1,root2,device,nthreads,0,1,out); }
+
+int fga_session_open_sliced(const char *root1, const char *root2, int device, int nthreads, int rank, int nranks,
+                            fga_session **out)
+{ if (nranks < 1 || rank < 0 || rank >= nranks || nranks > 4096)
+    { fga_set_error("fga_session_open_sliced: rank %d of %d",rank,nranks);
+      *out = NULL;
+      return 1;
+    }
+  return session_open_impl(root1,root2,device,nthreads,rank,nranks,out);
+}
+
+/* prefix ranges of equal merge cost (entries of both tables + 2 per prefix) from the tables' per-prefix entry counts:
+   cumulative counts on the host (int64 index arrays of the files), or count arrays of a device scan */
+static void cuts_from_counts(const int64_t *idx1, const int64_t *idx2, const uint32_t *cnt1, const uint32_t *cnt2,
+                             int nranks, int64_t *cuts)
+{ int64_t total = 0, run = 0, p;
+  int w = 1;
+  if (idx1 != NULL)
+    total = idx1[FGA_NPREFIX-1] + (idx2 != NULL ? idx2[FGA_NPREFIX-1] : idx1[FGA_NPREFIX-1]);
+  else
+    for (p = 0; p < FGA_NPREFIX; p++)
+      total += (int64_t) cnt1[p] + (cnt2 != NULL ? cnt2[p] : cnt1[p]);
+  total += 2*(int64_t) FGA_NPREFIX;
+  cuts[0] = 0;
+  for (p = 0; p < FGA_NPREFIX && w < nranks; p++)
+    { int64_t c;
+      if (idx1 != NULL)
+        c = idx1[p] + (idx2 != NULL ? idx2[p] : idx1[p]) + 2*(p+1);
+      else
+        { run += (int64_t) cnt1[p] + (cnt2 != NULL ? cnt2[p] : cnt1[p]);
+          c = run + 2*(p+1);
+        }
+      while (w < nranks && c > (total / nranks) * w)      /* smallest p whose inclusive cost exceeds the target */
+        cuts[w++] = p < 1 ? 1 : p;
+    }
+  while (w <= nranks)
+    cuts[w++] = FGA_NPREFIX;
+  for (w = 1; w <= nranks; w++)
+    if (cuts[w] < cuts[w-1]) cuts[w] = cuts[w-1];
+}
+
+static int session_open_impl(const char *root1, const char *root2, int device, int nthreads, int rank, int nranks,
+                             fga_session **out)
 { fga_session *Z = calloc(1,sizeof(fga_session));
   double t0;
   *out = NULL;
@@ -102,11 +152,47 @@ int fga_session_open_threads(const char *root1, const char *root2, int device, i
     t0 = fga_wall();
     Z->devbuilt = !have1 || !have2;
     if (nthreads < 1) nthreads = 1;
-    if (have1 ? fga_dgix_upload(Z->dev,Z->x1,&Z->d1)
-              : fga_dgix_build(Z->dev,Z->g1,nthreads,FGA_GIX_SOFT_MASK,&Z->d1,&Z->x1)) goto fail;
-    if (!Z->self && (have2 ? fga_dgix_upload(Z->dev,Z->x2,&Z->d2)
-                           : fga_dgix_build(Z->dev,Z->g2,nthreads,FGA_GIX_SOFT_MASK,&Z->d2,&Z->x2)))
-      goto fail;
+    Z->nranks = nranks; Z->rank = rank;
+    if (nranks <= 1)
+      { if (have1 ? fga_dgix_upload(Z->dev,Z->x1,&Z->d1)
+                  : fga_dgix_build(Z->dev,Z->g1,nthreads,FGA_GIX_SOFT_MASK,&Z->d1,&Z->x1)) goto fail;
+        if (!Z->self && (have2 ? fga_dgix_upload(Z->dev,Z->x2,&Z->d2)
+                               : fga_dgix_build(Z->dev,Z->g2,nthreads,FGA_GIX_SOFT_MASK,&Z->d2,&Z->x2)))
+          goto fail;
+      }
+    else
+      { /* the ranks' prefix ranges from the per-prefix entry counts of both tables (file indices, or one syncmer scan per
+           genome on the device), then this rank's slice of each table: 1/N of the upload or of the build's sort */
+        uint32_t *c1 = NULL, *c2 = NULL;
+        int bad = 0;
+        int64_t pb, pe;
+        Z->cuts = malloc(sizeof(int64_t)*(nranks+1));
+        if (Z->cuts == NULL) { fga_set_error("out of memory"); goto fail; }
+        if (!have1)
+          { c1 = malloc(sizeof(uint32_t)*FGA_NPREFIX);
+            if (c1 == NULL || fga_dgix_prefix_counts(Z->dev,Z->g1,nthreads,c1)) bad = 1;
+          }
+        if (!bad && !Z->self && !have2)
+          { c2 = malloc(sizeof(uint32_t)*FGA_NPREFIX);
+            if (c2 == NULL || fga_dgix_prefix_counts(Z->dev,Z->g2,nthreads,c2)) bad = 1;
+          }
+        if (!bad && (have1 != 0) != (Z->self ? have1 != 0 : have2 != 0))
+          { fga_set_error("a sliced session wants both genome indices as files, or neither");
+            bad = 1;
+          }
+        if (bad) { free(c1); free(c2); goto fail; }
+        cuts_from_counts(have1 ? Z->x1->index : NULL,(have1 && !Z->self) ? Z->x2->index : NULL,c1,Z->self ? NULL : c2,
+                         nranks,Z->cuts);
+        free(c1); free(c2);
+        pb = Z->cuts[rank]; pe = Z->cuts[rank+1];
+        if (pe <= pb) pe = pb + 1 <= FGA_NPREFIX ? pb + 1 : pb;           /* an empty range still needs a (tiny) table */
+        if (pe <= pb) { pb = FGA_NPREFIX-1; pe = FGA_NPREFIX; }
+        if (have1 ? fga_dgix_upload_range(Z->dev,Z->x1,pb,pe,&Z->d1)
+                  : fga_dgix_build_range(Z->dev,Z->g1,nthreads,FGA_GIX_SOFT_MASK,pb,pe,&Z->d1,&Z->x1)) goto fail;
+        if (!Z->self && (have2 ? fga_dgix_upload_range(Z->dev,Z->x2,pb,pe,&Z->d2)
+                               : fga_dgix_build_range(Z->dev,Z->g2,nthreads,FGA_GIX_SOFT_MASK,pb,pe,&Z->d2,&Z->x2)))
+          goto fail;
+      }
     /* the builder's key buffers (2 x 16 B per k-mer) stay in their workspace slots: the comparison's first large
        buffers (seeds, per-part staging) take them over (fga_dev_acquire) */
   }
@@ -132,7 +218,7 @@ fail:
 
 fga_dev *fga_session_device(fga_session *Z) { return Z->dev; }
 int64_t  fga_session_table_bytes(const fga_session *Z)
-{ return Z->x1->nents*Z->x1->ebytes + (Z->self ? 0 : Z->x2->nents*Z->x2->ebytes); }
+{ return fga_dgix_nents(Z->d1)*Z->x1->ebytes + (Z->self ? 0 : fga_dgix_nents(Z->d2)*Z->x2->ebytes); }
 int      fga_session_seed_bytes(const fga_session *Z)
 { return 1 + Z->x1->postbytes + Z->x1->contbytes + (Z->self ? Z->x1->postbytes + Z->x1->contbytes
                                                             : Z->x2->postbytes + Z->x2->contbytes); }
@@ -166,6 +252,16 @@ int fga_session_merge(fga_session *Z, const fga_run_params *P, int64_t prefix_be
           return 1;
         }
   }
+  if (Z->nranks > 1)                     /* a sliced session can only merge (part of) its own prefix range */
+    { const int64_t lo = Z->cuts[Z->rank], hi = Z->cuts[Z->rank+1];
+      if (prefix_begin == 0 && prefix_end == 0 && hi > lo)
+        { prefix_begin = lo; prefix_end = hi; }
+      if (!(prefix_begin == prefix_end) && (prefix_begin < lo || prefix_end > hi))
+        { fga_set_error("the session holds the 12-mer prefixes [%lld,%lld) of the tables, the merge asks for [%lld,%lld)",
+                        (long long) lo,(long long) hi,(long long) prefix_begin,(long long) prefix_end);
+          return 1;
+        }
+    }
   memset(&mp,0,sizeof(mp));
   mp.freq = P->freq; mp.soft_mask = P->soft_mask; mp.flip = 0;
   mp.prefix_begin = prefix_begin; mp.prefix_end = prefix_end;
@@ -174,7 +270,7 @@ int fga_session_merge(fga_session *Z, const fga_run_params *P, int64_t prefix_be
      the large guess would be a fresh allocation of 77 GB instead of a take-over of the index builder's key buffer),
      never more than a quarter of the device memory still to be had */
   { int64_t guess = (P->symmetric && !self) ? 2*(x1->nents + x2->nents) + (1<<20) : 0;
-    if (prefix_begin == 0 && (prefix_end <= 0 || prefix_end >= FGA_NPREFIX))
+    if (Z->nranks <= 1 && prefix_begin == 0 && (prefix_end <= 0 || prefix_end >= FGA_NPREFIX))
       { const int64_t room = (int64_t) (fga_dev_available(dev) / 4 / sizeof(fga_seed));
         if (guess == 0)
           guess = (x1->nents > ((int64_t) 1 << 28) ? x1->nents : 2*x1->nents) + (1<<20);      /* one per entry at human scale */
@@ -448,7 +544,16 @@ done:
 int fga_session_nctg(const fga_session *Z) { return Z->x1->nctg; }
 
 int fga_session_prefix_cuts(fga_session *Z, int nshards, int64_t *cuts)
-{ return fga_merge_prefix_cuts(Z->dev,Z->d1,Z->self ? NULL : Z->d2,nshards,cuts); }
+{ if (Z->nranks > 1)                     /* a sliced session: the ranges it was opened with */
+    { if (nshards != Z->nranks)
+        { fga_set_error("the session holds rank %d's slice of %d prefix ranges, %d were asked for",Z->rank,Z->nranks,nshards);
+          return 1;
+        }
+      memcpy(cuts,Z->cuts,sizeof(int64_t)*(nshards+1));
+      return 0;
+    }
+  return fga_merge_prefix_cuts(Z->dev,Z->d1,Z->self ? NULL : Z->d2,nshards,cuts);
+}
 
 /* one pass of the hot path over the resident inputs: phases 1-3.  When the merge finds more seeds than one sort pass
    should take (P->pass_seeds, default 1.5 G: the sort's tile counters are 32-bit and three 16-byte buffers per seed are

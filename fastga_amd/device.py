@@ -321,11 +321,18 @@ def run(root1, root2=None, out_path=None, device=0, freq=10, soft_mask=False, sy
 class Session:
     """inputs resident in HBM; run() is one pass of the hot path (fga_session_*)."""
 
-    def __init__(self, root1, root2=None, device=0):
+    def __init__(self, root1, root2=None, device=0, rank=0, nranks=1, nthreads=8):
+        """nranks > 1: the session of rank `rank` of one comparison over nranks GPUs -- it holds only its own 12-mer prefix
+        range of both tables (fga_session_open_sliced)"""
         self.L = load_library()
         self.h = C.c_void_p()
-        check(self.L.fga_session_open(root1.encode(), root2.encode() if root2 else None, device, C.byref(self.h)),
-              "open session")
+        if nranks > 1:
+            check(self.L.fga_session_open_sliced(root1.encode(), root2.encode() if root2 else None, device, nthreads,
+                                                 rank, nranks, C.byref(self.h)), "open sliced session")
+        else:
+            check(self.L.fga_session_open(root1.encode(), root2.encode() if root2 else None, device, C.byref(self.h)),
+                  "open session")
+        self.rank, self.nranks = rank, nranks
         self.table_bytes = self.L.fga_session_table_bytes(self.h)
         self.seed_bytes = self.L.fga_session_seed_bytes(self.h)
         self.bases = (self.L.fga_session_bases(self.h, 0), self.L.fga_session_bases(self.h, 1))

@@ -207,6 +207,10 @@ def _declare(L):
         "fga_session_prefix_cuts": (i32, [vp, i32, P(i64)]),
         "fga_alns_concat": (i32, [P(P(Alns)), i32, P(P(Alns))]),
         "fga_dev_upload": (i32, [vp, vp, vp, C.c_size_t]),
+        "fga_session_open_sliced": (i32, [cp, cp, i32, i32, i32, i32, P(vp)]),
+        "fga_dgix_build_range": (i32, [vp, vp, i32, i32, i64, i64, P(vp), P(vp)]),
+        "fga_dgix_upload_range": (i32, [vp, vp, i64, i64, P(vp)]),
+        "fga_dgix_prefix_counts": (i32, [vp, vp, i32, vp]),
         "fga_alns_merge_filtered": (i32, [P(P(Alns)), i32, P(P(Alns))]),
         "fga_session_finish_filtered": (i32, [vp, P(RunParams), P(P(Alns)), i32, P(RunStats)]),
         "fga_shim_New_Work_Data": (vp, []),

@@ -99,6 +99,7 @@ void    fga_dev_set_host_threads(fga_dev *dev, int nthreads);   /* threads for t
 
 int   fga_dgix_upload(fga_dev *dev, const fga_gix *gix, fga_dgix **out);
 void  fga_dgix_free(fga_dgix *dgix);
+int64_t fga_dgix_nents(const fga_dgix *dgix);      /* entries resident on the device (a slice: of its prefix range) */
 /* The index built on the device straight into HBM: replaces the GIXmake run for the seed merge's input (GIXmake.c
  * sample / distribution / sort / merge threads).  `gdb` must hold its bases (fga_gdb_open); nthreads plays GIXmake's
  * -T for the layout (contig padding, table parts).  *dgix is what fga_dgix_upload of the fga_gix_build files would
@@ -110,6 +111,14 @@ int   fga_dgix_build(fga_dev *dev, const fga_gdb *gdb, int nthreads, int flags, 
 /* <root>.gix + .<root>.ktab.N from an index that holds a host copy of its table (fga_dgix_build with want_host_copy,
  * or one loaded with fga_gix_open): the files fga_gix_build / GIXmake write */
 int   fga_gix_write_files(const fga_gix *gix, const char *target);
+/* One rank's slice of a table: only the entries whose 12-mer prefix lies in [pbeg,pend) (the reference's merge
+ * threads each read one such range of both tables, FastGA.c:2291-2321) -- read from index files, or built on the device
+ * from the GDB with 1/N of the sort.  fga_dgix_prefix_counts gives the per-prefix entry counts of the table a build would
+ * make (one syncmer scan, nothing built): what the ranges are cut from (fga_session_open_sliced does all of it). */
+int   fga_dgix_upload_range(fga_dev *dev, const fga_gix *gix, int64_t pbeg, int64_t pend, fga_dgix **out);
+int   fga_dgix_build_range(fga_dev *dev, const fga_gdb *gdb, int nthreads, int flags, int64_t pbeg, int64_t pend,
+                           fga_dgix **dgix, fga_gix **gix);
+int   fga_dgix_prefix_counts(fga_dev *dev, const fga_gdb *gdb, int nthreads, uint32_t *counts /* host, 2^24 */);
 
 /* Adaptive seed merge: replaces adaptamer_merge -> new_merge_thread (FastGA.c:2281, 610) and, with
  * t2 == NULL, self_adaptamer_merge -> new_self_merge_thread (FastGA.c:2496, 1616).  Returns 0, or 2 when
@@ -369,6 +378,12 @@ typedef struct fga_session fga_session;
 int      fga_session_open(const char *root1, const char *root2, int device, fga_session **out);
 /* nthreads = the -T the reference would hand to the GIXmake it runs for a missing index (fga_session_open: 8) */
 int      fga_session_open_threads(const char *root1, const char *root2, int device, int nthreads, fga_session **out);
+/* rank `rank` of `nranks` of one comparison: the session holds only ITS 12-mer prefix range of both tables (the genomes'
+ * bases stay whole: phase 2 needs them).  The ranges are cut for equal merge cost from the tables' per-prefix counts, the
+ * same on every rank without communication; fga_session_prefix_cuts(s, nranks, ..) returns them, and fga_session_merge
+ * takes the rank's own range. */
+int      fga_session_open_sliced(const char *root1, const char *root2, int device, int nthreads, int rank, int nranks,
+                                 fga_session **out);
 int      fga_session_run(fga_session *s, const fga_run_params *prm, fga_run_stats *stats);
 void     fga_session_close(fga_session *s);
 fga_dev *fga_session_device(fga_session *s);

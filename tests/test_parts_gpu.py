@@ -107,7 +107,7 @@ def _sharded_worker(rank, world, port, ra, rb, out, q, self_mode):
     try:
         from fastga_amd import device as D
         from fastga_amd.parallel import run_sharded
-        ses = D.Session(ra, None if self_mode else rb)
+        ses = D.Session(ra, None if self_mode else rb, rank=rank, nranks=world)      # holds its own slice of the tables only
         st = run_sharded(ses, dist, dict(out_path=out, nthreads=4), "cpu")
         ses.close()
         q.put((rank, {k: st[k] for k in ("nseeds", "nalns", "nlive", "part_seeds", "exchange_seeds_out")}))
@@ -150,3 +150,80 @@ def test_run_sharded_with_two_ranks_on_one_gpu(toy_pair, tmp_path, self_mode):
     H.ref_fastga(ra, None if self_mode else rb, rd, os.path.join(rd, "ref"), threads=4)
     from fastga_amd import workload
     assert workload.digest_1aln(_view(out)) == workload.digest_1aln(_view(os.path.join(rd, "ref.1aln")))
+
+
+@pytest.mark.parametrize("mode", ["pair", "self", "files"])
+def test_sliced_sessions_hold_their_prefix_range_only(toy_pair, tmp_path, mode):
+    """every rank of an N-GPU run opens the session with ITS 12-mer prefix range of both tables (fga_session_open_sliced:
+    the ranges are cut from the per-prefix counts on every rank alike; index built on the device with 1/N of the sort, or
+    the slice of the index files uploaded): the slices' seeds are the whole table's seeds, nothing else can be merged,
+    and the comparison put together from the slices is the undivided one"""
+    import shutil
+    from fastga_amd import device as D
+    from fastga_amd.parallel import partition_contigs
+    d, ra, rb = toy_pair
+    w = str(tmp_path)
+    if mode == "files":
+        a, b = ra, rb                                              # toy_pair carries .gix files
+    else:                                                          # GDBs only: indices are built on the device
+        for r in (ra, rb):
+            for f in (os.path.basename(r) + ".gdb", "." + os.path.basename(r) + ".bps"):
+                shutil.copy(os.path.join(os.path.dirname(r), f), os.path.join(w, f))
+        a, b = os.path.join(w, os.path.basename(ra)), os.path.join(w, os.path.basename(rb))
+    if mode == "self":
+        b = None
+    whole = D.Session(a, b)
+    prm, st = whole.params(), whole.new_stats()
+    full = whole.merge(prm, st)
+    void = np.dtype((np.void, 16))
+    allseeds = np.sort(full.download().view(void))
+    full.free()
+    base_out = os.path.join(w, "whole.1aln")
+    whole.run(out_path=base_out, nthreads=4)
+    N = 3
+    sessions = [D.Session(a, b, rank=r, nranks=N) for r in range(N)]
+    cuts = [np.zeros(N + 1, dtype=np.int64) for _ in range(N)]
+    for r, s in enumerate(sessions):
+        from fastga_amd.lib import check
+        import ctypes as C
+        check(s.L.fga_session_prefix_cuts(s.h, N, cuts[r].ctypes.data_as(C.POINTER(C.c_int64))), "cuts")
+        assert s.table_bytes < whole.table_bytes                    # a slice, not the table
+    assert all(np.array_equal(cuts[0], c) for c in cuts) and cuts[0][0] == 0 and cuts[0][-1] == 1 << 24
+    assert sum(s.table_bytes for s in sessions) == whole.table_bytes
+    parts, hist = [], np.zeros(whole.nctg, dtype=np.int64)
+    for r, s in enumerate(sessions):
+        sd = s.merge(s.params(), s.new_stats(), int(cuts[0][r]), int(cuts[0][r + 1]))
+        parts.append(sd.download())
+        hist += s.contig_histogram(sd)
+        sd.free()
+        with pytest.raises(Exception):                              # another rank's range is not in this session
+            o = (r + 1) % N
+            s.merge(s.params(), s.new_stats(), int(cuts[0][o]), int(cuts[0][o + 1]))
+    got = np.sort(np.concatenate(parts).view(void))
+    if mode == "self":                                              # the halved totals of a self merge aside, the same records
+        assert np.array_equal(np.unique(got), np.unique(allseeds)) and abs(len(got) - len(allseeds)) <= N
+    else:
+        assert np.array_equal(got, allseeds)
+    # the comparison from the slices: every "rank" aligns the seeds of its A-contig part on its own session
+    select = partition_contigs(hist, N)
+    raws = []
+    for p, s in enumerate(sessions):
+        mine = np.concatenate([x[select[(x["actg"] >> 8).astype(np.int64)] == p] for x in parts])
+        buf = s.dev_malloc(16 * max(len(mine), 1))
+        if len(mine):
+            s.dev_upload(buf, mine)
+        part = s.import_seeds([(buf, len(mine))])
+        s.dev_free(buf)
+        stp = s.new_stats()
+        raw = s.align(s.params(nthreads=4), stp, part)
+        raws.append((s, s.filter(raw, nthreads=4)))
+        s.free_alns(raw)
+    out = os.path.join(w, "sliced.1aln")
+    s0 = sessions[0]
+    s0.finish_filtered(s0.params(out_path=out, nthreads=4), s0.new_stats(), [f for _, f in raws])
+    for s, f in raws:
+        s.free_alns(f)
+    assert _view(out) == _view(base_out)
+    for s in sessions:
+        s.close()
+    whole.close()
