@@ -58,7 +58,7 @@ const uint8_t *fga_gix_table(const fga_gix *gix);
 /* ==== device side (MI355X / gfx950) =================================================================== */
 
 typedef struct fga_dev    fga_dev;     /* one GPU: device id, HIP stream, timing events            */
-typedef struct fga_dgix   fga_dgix;    /* device-resident genome index (on-disk bytes, unchanged)  */
+typedef struct fga_dgix   fga_dgix;    /* device-resident genome index (one array per field + prefix index) */
 typedef struct fga_dseeds fga_dseeds;  /* device-resident adaptive seeds                            */
 
 /* One adaptive seed.  Carries exactly the fields of the reference's seed temp record

@@ -5,13 +5,13 @@
 #                                       pmc_fetch = FETCH_SIZE, pmc_write = WRITE_SIZE (KiB; gfx950: FETCH_SIZE counts
 #                                       half of a wide coalesced stream, see MI355X_MICROARCH.md), pmc_sq = SQ issue/wait
 # Copy the two files into profiles/ afterwards.
-tag=${1:-r02}
+tag=${1:-r03}
 commit=${2:-unknown}          # the commit the snapshot was taken at (gpurun ships no .git): pass `git rev-parse --short HEAD`
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out
 mkdir -p $out/prof_$tag
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $root/bench.py --steps 5 --warmup 2 --no-cpu --no-cold"
+BENCH="python $root/bench.py --steps 5 --warmup 2 --no-cpu --no-cold --no-human-scale"
 timeout 200 rocprofv3 --kernel-trace --stats -d $out/prof_$tag/kt -o kt --output-format csv -- $BENCH > $out/prof_$tag/kt.log 2>&1
 cp $out/prof_$tag/kt/kt_kernel_stats.csv $out/${tag}_kernel_stats.csv
 grep -a '"metric"' $out/prof_$tag/kt.log | tail -1 > $out/${tag}_bench_under_rocprof.json
@@ -37,7 +37,7 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_lds"):
         rows.append((name, k, c, len(d), v / max(1, len(d))))
 with open(dst, "w") as f:
     f.write("# commit: %s\n" % (sys.argv[3] if len(sys.argv) > 3 else "unknown"))
-    f.write("# command: bench.py --steps 5 --warmup 2 --no-cpu --no-cold under rocprofv3 --pmc <counters> (one pass per counter group)\n")
+    f.write("# command: bench.py --steps 5 --warmup 2 --no-cpu --no-cold --no-human-scale under rocprofv3 --pmc <counters> (one pass per counter group)\n")
     f.write("pass,kernel,counter,launches,avg_per_launch\n")
     for r in rows:
         f.write("%s,%s,%s,%d,%.6g\n" % r)
