@@ -90,7 +90,16 @@ def dense_pair(tmp_path_factory, built_library):
     unit = rng.integers(0, 2, 7, dtype=np.uint8)
     A[0][1000:41000] = synth.mutate(rng, np.tile(unit, 6000), 0.01)[:40000]
     B = [synth.mutate(rng, c, 0.03) for c in A]
-    return d, workload.build_genome(d, "A", A), workload.build_genome(d, "B", B)
+    # lower-case stretches in both genomes: the index carries mask bytes, so -M also decides inside streamed windows
+    mA = [np.zeros(len(c), dtype=bool) for c in A]
+    mB = [np.zeros(len(c), dtype=bool) for c in B]
+    for ms in (mA, mB):
+        for m in ms:
+            for _ in range(40):
+                s0 = int(rng.integers(0, max(1, len(m) - 4000)))
+                m[s0:s0 + int(rng.integers(100, 4000))] = True
+    return (d, workload.build_genome(d, "A", A, masks=mA, use_mask=True),
+            workload.build_genome(d, "B", B, masks=mB, use_mask=True))
 
 
 @pytest.fixture(scope="session")

@@ -131,6 +131,13 @@ def test_dense_panels_are_streamed_in_windows(dense_pair):
     _compare(dev, B, A, dB, dA, flip=True, freq=100)
     _compare(dev, A, None, dA, None)
     _compare(dev, A, None, dA, None, freq=100)
+    _compare(dev, A, None, dA, None, freq=255)                    # the wide-window build on panels of thousands
+    # the tables carry mask bytes: -M inside the streamed windows, all modes
+    plain = _compare(dev, A, B, dA, dB, freq=20)
+    assert 0 < _compare(dev, A, B, dA, dB, freq=20, soft_mask=True) < plain
+    _compare(dev, B, A, dB, dA, flip=True, soft_mask=True)
+    _compare(dev, A, None, dA, None, soft_mask=True)
+    _compare(dev, A, B, dA, dB, freq=200, soft_mask=True)
     dA.free(); dB.free(); dev.close()
 
 

@@ -38,3 +38,31 @@ def test_sorted_keys_match_reference_order(toy_pair):
     hi, lo = k["hi"], k["lo"]
     assert np.all((hi[1:] > hi[:-1]) | ((hi[1:] == hi[:-1]) & (lo[1:] >= lo[:-1])))
     keys.free(); seeds.free(); dA.free(); dB.free(); dev.close()
+
+
+def test_three_kernel_passes_give_the_same_keys(family_pair, monkeypatch):
+    """FGA_SORT_3N=1 selects round 2's passes (tile histogram, scan, scatter) instead of the one-sweep ones: same keys in
+    the same order (both are stable), on a seed buffer with open block tails and on the index builder's k-mer keys"""
+    from fastga_amd.gixio import Gix, Gdb
+    from fastga_amd import device as D
+    d, ra, rb = family_pair
+    A, B = Gix(ra + ".gix"), Gix(rb + ".gix")
+    ga, gb = Gdb(ra + ".gdb"), Gdb(rb + ".gdb")
+    dev = D.Device(0)
+    dA, dB = dev.upload(A), dev.upload(B)
+    got = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("FGA_SORT_3N", mode)
+        seeds = D.seed_merge(dev, dA, dB, freq=30)
+        keys = D.seed_sort(dev, seeds, int(ga.maxctg), int(gb.maxctg), A.nctg, B.nctg)
+        k = keys.download()
+        got[mode] = (np.sort(k.view(np.dtype((np.void, 16)))), k["hi"].copy(), k["lo"].copy())
+        keys.free(); seeds.free()
+        dgx, xg = D.build_gix_device(dev, ga, 8, host_copy=True)          # 13 passes over the k-mer keys
+        assert np.array_equal(xg.entries(), A.entries()) and np.array_equal(xg.index, A.index)
+        dgx.free(); xg.close()
+    assert np.array_equal(got["0"][0], got["1"][0])                       # same multiset (seed order in the buffer varies)
+    for m in ("0", "1"):
+        hi, lo = got[m][1], got[m][2]
+        assert np.all((hi[1:] > hi[:-1]) | ((hi[1:] == hi[:-1]) & (lo[1:] >= lo[:-1])))
+    dA.free(); dB.free(); dev.close()
