@@ -226,7 +226,7 @@ def test_configs_4_and_5_at_3gbp_match_the_reference_digests(tmp_path_factory, b
         for k in ("records", "header_md5", "records_sum128", "order_md5"):
             assert got[k] == exp[k], (k, got, exp, st)
         assert st["nparts"] >= 2                                   # more seeds than one sort pass takes
-        assert st["hbm_peak_bytes"] < 250 << 30
+        assert st["hbm_peak_bytes"] < 286 << 30               # everything the two passes need at once fits the device
         os.unlink(ours)
         out8 = os.path.join(d, "parts8.1aln")
         st8 = parallel.run_parts_on_one_gpu(ses, 8, out_path=out8, nthreads=T)
