@@ -167,7 +167,9 @@ __device__ __forceinline__ int64_t wave_lower_bound(const uint64_t *K, int64_t l
 }
 
 #ifdef MERGE_PROF      // per-phase cycle accounting of every wavefront (tools/merge_bench.py prints it): timing builds only
-__device__ unsigned long long merge_prof[8];
+__device__ unsigned long long merge_prof[16];
+__device__ unsigned long long merge_tl[8192*4];     // per workgroup: start, end (100 MHz clock), tiles, ranges
+static int merge_prof_grid = 0;
 #define XPROF(k)   { unsigned long long _n = clock64(); O.pa[k] += _n - O.pt; O.pt = _n; }
 #else
 #define XPROF(k)
@@ -177,7 +179,7 @@ struct walk_out                      // a wavefront's current output chunk and s
   { int64_t chunk_pos, chunk_end;
     unsigned long long tsum;
 #ifdef MERGE_PROF
-    unsigned long long pt, pa[8];
+    unsigned long long pt, pa[16], t0, ntile, nrange;
 #endif
   };
 
@@ -222,7 +224,7 @@ template <int MODE, int NR>
 __device__ __forceinline__ void match_rounds(const merge_args &A, const uint64_t *keyB, const uint8_t *lcpB, const uint8_t *mA,
                                              const uint8_t *mB, const uint8_t *cB, const uint64_t *k1, const uint32_t *ix2,
                                              uint32_t b, int plo, bool panels, int n2, int na, int t_lo,
-                                             uint32_t *res, int &total, unsigned long long &tsum, int &lb_last)
+                                             uint32_t *res, int &total, unsigned long long &tsum, int &lb_last, walk_out &O)
 { const int lane = threadIdx.x;
   const int freq = A.freq;
   uint64_t ks[NR];
@@ -266,6 +268,7 @@ __device__ __forceinline__ void match_rounds(const merge_args &A, const uint64_t
       for (int r = 0; r < NR; r++)
         base[r] += ((len[r] > 0) & (kf[r] < ks[r])) ? 1 : 0;
     }
+  XPROF(8)
   uint64_t kb[NR], kc[NR];
   int bd[NR], bu[NR], nb[NR], na_[NR];
   #pragma unroll
@@ -275,43 +278,69 @@ __device__ __forceinline__ void match_rounds(const merge_args &A, const uint64_t
       kb[r] = keyB[nb[r] >= 0 ? nb[r] : 0]; kc[r] = keyB[na_[r]];
       bd[r] = (int) lcpB[nb[r] >= 0 ? nb[r] : 0]; bu[r] = (int) lcpB[na_[r]+1];
     }
-  total = 0;
+#ifdef MERGE_PROF
+  if (__builtin_amdgcn_ballot_w64(kb[0] + kc[0] + bd[0] + bu[0] == 0x1234567) != 0) tsum += 1;     // the reads have landed
+#endif
+  XPROF(9)
+  // run growth on the table's own lcp bytes.  The first step of either direction is decided on the bytes read above; the
+  // further steps of all rounds and both directions go side by side (one LDS round trip per step, not one per round and
+  // direction).  Upwards the cutoff is measured from the lower bound, not from the run's start (which the downward growth
+  // is still looking for): a run that ends earlier on the tighter measure has reached the cutoff either way.
+  int low[NR], hgh[NR], pl[NR];
+  bool okr[NR], cd[NR], cu[NR];
+  bool grow = false;
   #pragma unroll
   for (int r = 0; r < NR; r++)
     { const int c = r*64 + lane;
       const bool act = c < na;
-      const int i = (MODE == MODE_SELF) ? base[r] : c;
-      int low, hgh, lbnd;
-      if (MODE == MODE_SELF) { low = i; hgh = i+1; lbnd = i; }
-      else                   { low = hgh = lbnd = base[r]; }
+      const int lbnd = base[r];
+      low[r] = lbnd; hgh[r] = (MODE == MODE_SELF) ? lbnd + 1 : lbnd;
       const bool hasb = nb[r] >= pb0[r], hasa = na_[r] < pb1[r];
       const int lkb = hasb ? lcp_key(ks[r],kb[r]) : 0, lka = hasa ? lcp_key(ks[r],kc[r]) : 0;
       const int plen = lkb > lka ? lkb : lka;                      // 0: no T2 entry of this panel next to the key
-      const bool ok = act && plen >= 12;
-      // run growth on the table's own lcp bytes; the first step of either direction is decided on the bytes read above
-      const bool gd = ok && lkb >= plen;
-      low -= gd ? 1 : 0;
-      if (gd && low > pb0[r] && lbnd-low <= freq && bd[r] >= plen)
-        { low -= 1;
-          while (low > pb0[r] && lbnd-low <= freq && (int) lcpB[low] >= plen)
-            low -= 1;
+      pl[r] = plen;
+      okr[r] = act && plen >= 12;
+      const bool gd = okr[r] && lkb >= plen;
+      low[r] -= gd ? 1 : 0;
+      cd[r] = gd && low[r] > pb0[r] && lbnd-low[r] <= freq && bd[r] >= plen;
+      low[r] -= cd[r] ? 1 : 0;
+      cd[r] = cd[r] && low[r] > pb0[r] && lbnd-low[r] <= freq;
+      const bool gu = okr[r] && lka >= plen && hgh[r] < pb1[r];
+      hgh[r] += gu ? 1 : 0;
+      cu[r] = gu && hgh[r] < pb1[r] && hgh[r]-lbnd <= freq && bu[r] >= plen;
+      hgh[r] += cu[r] ? 1 : 0;
+      cu[r] = cu[r] && hgh[r] < pb1[r] && hgh[r]-lbnd <= freq;
+      grow = grow || cd[r] || cu[r];
+    }
+  while (__builtin_amdgcn_ballot_w64(grow) != 0)
+    { int vd[NR], vu[NR];
+      #pragma unroll
+      for (int r = 0; r < NR; r++)
+        { vd[r] = (int) lcpB[low[r]]; vu[r] = (int) lcpB[hgh[r]]; }            // read by every lane (in range either way)
+      grow = false;
+      #pragma unroll
+      for (int r = 0; r < NR; r++)
+        { const bool d = cd[r] & (vd[r] >= pl[r]), u = cu[r] & (vu[r] >= pl[r]);
+          low[r] -= d ? 1 : 0; hgh[r] += u ? 1 : 0;
+          cd[r] = d & (low[r] > pb0[r]) & (base[r]-low[r] <= freq);
+          cu[r] = u & (hgh[r] < pb1[r]) & (hgh[r]-base[r] <= freq);
+          grow = grow || cd[r] || cu[r];
         }
-      const bool gu = ok && lka >= plen && hgh < pb1[r] && hgh-low <= freq;
-      hgh += gu ? 1 : 0;
-      if (gu && hgh < pb1[r] && hgh-low <= freq && bu[r] >= plen)
-        { hgh += 1;
-          while (hgh < pb1[r] && hgh-low <= freq && (int) lcpB[hgh] >= plen)
-            hgh += 1;
-        }
+    }
+  total = 0;
+  #pragma unroll
+  for (int r = 0; r < NR; r++)
+    { const int i = (MODE == MODE_SELF) ? base[r] : r*64 + lane;
+      const int plen = pl[r];
       const int mlen = A.soft_mask ? plen : 41;
-      bool pass = ok && hgh-low < freq;
+      bool pass = okr[r] && hgh[r]-low[r] < freq;
       if (A.soft_mask)
         pass = pass && (int) (MODE == MODE_SELF ? mB[i] : mA[i]) < mlen;
       int cnt;
       if (MODE == MODE_FLIP || A.soft_mask)
         { cnt = 0;
           if (pass)
-            for (int j = low; j < hgh; j++)
+            for (int j = low[r]; j < hgh[r]; j++)
               { if (A.soft_mask && (int) mB[j] >= mlen)
                   continue;
                 if (MODE == MODE_FLIP && (lds_c(cB,A.cw2,j) & A.sign2))
@@ -322,11 +351,12 @@ __device__ __forceinline__ void match_rounds(const merge_args &A, const uint64_t
               }
         }
       else
-        cnt = pass ? (hgh-low) - (MODE == MODE_SELF ? 1 : 0) : 0;
-      res[r] = (pass && cnt > 0) ? ((uint32_t) (MODE == MODE_SELF ? i - low : i) | ((uint32_t) low << 8) | ((uint32_t) plen << 18) | ((uint32_t) cnt << 24)) : 0u;
+        cnt = pass ? (hgh[r]-low[r]) - (MODE == MODE_SELF ? 1 : 0) : 0;
+      res[r] = (pass && cnt > 0) ? ((uint32_t) (MODE == MODE_SELF ? i - low[r] : i) | ((uint32_t) low[r] << 8) | ((uint32_t) plen << 18) | ((uint32_t) cnt << 24)) : 0u;
       total += cnt;
       tsum += (unsigned long long) cnt * plen;
     }
+  XPROF(10)
   // lower bound of the last consumed entry (entry na-1: round (na-1) >> 6, lane (na-1) & 63)
   lb_last = 0;
   if (MODE != MODE_SELF && na > 0)
@@ -386,6 +416,9 @@ __device__ __forceinline__ int walk_tile(const merge_args &A, tile_lds<T2CAP> &S
     { k1[0] = k1[1] = k1[2] = k1[3] = 0; }
   // the direct-to-LDS loads are asynchronous and nothing below depends on a VGPR they return: wait for them by hand
   XPROF(1)
+#ifdef MERGE_PROF
+  O.ntile += 1;
+#endif
   VM_WAIT();
   WSYNC();
   XPROF(2)
@@ -404,6 +437,11 @@ __device__ __forceinline__ int walk_tile(const merge_args &A, tile_lds<T2CAP> &S
     { WSYNC();
       return 0;
     }
+#ifdef MERGE_FILL_ONLY                  // timing experiment: tiles are cut and filled, nothing else
+  lb_last = n2 - margin - 1;
+  WSYNC();
+  return na;
+#endif
 
   XPROF(3)
   // 3. match: result per round packed i (8 bits; self: i - low) | low << 8 | plen << 18 | seeds << 24
@@ -413,16 +451,19 @@ __device__ __forceinline__ int walk_tile(const merge_args &A, tile_lds<T2CAP> &S
     const uint32_t b32 = (uint32_t) b0;
     const int plo = p0 & 0xff;
     const uint32_t *ixq = (MODE == MODE_SELF) ? ix1 : ix2;
-    if (nr == 1)      match_rounds<MODE,1>(A,keyB,lcpB,mA,mB,cB,k1,ixq,b32,plo,panels,n2,na,t_lo,res,total,O.tsum,lb_last);
-    else if (nr == 2) match_rounds<MODE,2>(A,keyB,lcpB,mA,mB,cB,k1,ixq,b32,plo,panels,n2,na,t_lo,res,total,O.tsum,lb_last);
-    else if (nr == 3) match_rounds<MODE,3>(A,keyB,lcpB,mA,mB,cB,k1,ixq,b32,plo,panels,n2,na,t_lo,res,total,O.tsum,lb_last);
-    else              match_rounds<MODE,4>(A,keyB,lcpB,mA,mB,cB,k1,ixq,b32,plo,panels,n2,na,t_lo,res,total,O.tsum,lb_last);
+    if (nr == 1)      match_rounds<MODE,1>(A,keyB,lcpB,mA,mB,cB,k1,ixq,b32,plo,panels,n2,na,t_lo,res,total,O.tsum,lb_last,O);
+    else if (nr == 2) match_rounds<MODE,2>(A,keyB,lcpB,mA,mB,cB,k1,ixq,b32,plo,panels,n2,na,t_lo,res,total,O.tsum,lb_last,O);
+    else if (nr == 3) match_rounds<MODE,3>(A,keyB,lcpB,mA,mB,cB,k1,ixq,b32,plo,panels,n2,na,t_lo,res,total,O.tsum,lb_last,O);
+    else              match_rounds<MODE,4>(A,keyB,lcpB,mA,mB,cB,k1,ixq,b32,plo,panels,n2,na,t_lo,res,total,O.tsum,lb_last,O);
   }
 
   XPROF(4)
   // 4. slots and emission
   int T;
   int off = wave_excl_scan_add_dpp(total,T);
+#ifdef MERGE_NO_EMIT                    // timing experiment: matched, not emitted
+  O.tsum += T; T = 0;
+#endif
   if (T > 0)
     { const int64_t rem = O.chunk_end - O.chunk_pos;
       int64_t nbase = 0, nsize = 0;
@@ -441,6 +482,7 @@ __device__ __forceinline__ int walk_tile(const merge_args &A, tile_lds<T2CAP> &S
       // partner: the k-th T2 entry of the run, or, where mask bytes / strands / the entry itself drop members of the run,
       // the k-th one that stays.
       const bool plain = (MODE != MODE_FLIP) && !A.soft_mask;
+      XPROF(11)
       WSYNC();                                                   // the match's key reads are done: the array becomes the window
       for (int wb = 0; wb < T; wb += EWIN)
         { const int wn = T - wb < EWIN ? T - wb : EWIN;          // slots of this window
@@ -459,6 +501,7 @@ __device__ __forceinline__ int walk_tile(const merge_args &A, tile_lds<T2CAP> &S
               }
           }
           WSYNC();
+          XPROF(12)
           int carry = 0;
           for (int s0 = 0; s0 < wn; s0 += 64)
             { const int slot = s0 + lane;                       // within the window
@@ -498,7 +541,11 @@ __device__ __forceinline__ int walk_tile(const merge_args &A, tile_lds<T2CAP> &S
                   const uint32_t ssign = (sc & A.sign1) != 0, csign = (cc & A.sign2) != 0;
                   const int64_t gs = (int64_t) wb + slot;
                   const int64_t at = (gs < rem) ? O.chunk_pos + gs : nbase + (gs - rem);
+#ifdef MERGE_NO_STORE                   // timing experiment: everything but the seed stores (the test keeps the operands alive)
+                  if (at < A.cap && spos + cpos + sc + cc + ssign + csign + plen == 0xfffffff7u)
+#else
                   if (at < A.cap)
+#endif
                     A.out[at] = make_seed<MODE>(plen,spos,sc & (A.sign1-1),ssign,cpos,cc & (A.sign2-1),csign);
                 }
             }
@@ -527,7 +574,8 @@ void seed_merge_walk_kernel(merge_args A)
   O.chunk_pos = O.chunk_end = 0; O.tsum = 0;
 #ifdef MERGE_PROF
   O.pt = clock64();
-  for (int k = 0; k < 8; k++) O.pa[k] = 0;
+  for (int k = 0; k < 16; k++) O.pa[k] = 0;
+  O.t0 = wall_clock64(); O.ntile = 0; O.nrange = 0;
 #endif
 
   // Ranges come off eight queues, one per XCD (workgroup b runs on XCD b mod 8; range shard + 8 k is the k-th of its
@@ -547,6 +595,9 @@ void seed_merge_walk_kernel(merge_args A)
       const int pe = (int) A.cuts[r+1];
       if (p >= pe)
         continue;
+#ifdef MERGE_PROF
+      O.nrange += 1;
+#endif
       int u = 0;                                     // index buffer in use
       // Index entries of the next XPC prefixes, two per lane (clamped at the range end).  They are fetched one tile
       // ahead and travel HBM -> LDS like the tile data, not into registers: a register result would make the compiler
@@ -566,6 +617,7 @@ void seed_merge_walk_kernel(merge_args A)
       IDX_ISSUE(p,0)
       uint32_t a = p > 0 ? idx1[p-1] : 0u, b = p > 0 ? idx2[p-1] : 0u;
       VM_WAIT();
+      XPROF(15)
       while (p < pe)
         { uint32_t ca0, ca1, cb0, cb1;
           { const uint32_t at = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint32_t *) &S.ixs[u][0][4 + lane];
@@ -580,6 +632,7 @@ void seed_merge_walk_kernel(merge_args A)
             ca0 = (uint32_t) va; ca1 = (uint32_t) (va >> 32);
             cb0 = (uint32_t) vb; cb1 = (uint32_t) (vb >> 32);
           }
+          XPROF(13)
           const int navail = pe - p < XPC ? pe - p : XPC;
           // whole panels that fit a tile
           const uint32_t cap2 = (MODE == MODE_SELF) ? T1CAP : T2CAP;
@@ -600,6 +653,7 @@ void seed_merge_walk_kernel(merge_args A)
             { S.ixs[u][0][3] = a; S.ixs[u][1][3] = b; }
           // the index entries of the tile after this one are on their way while this one is processed
           const int pn = p + adv;
+          XPROF(14)
           if (pn < pe)
             IDX_ISSUE(pn,u^1)
           XPROF(0)
@@ -665,7 +719,12 @@ void seed_merge_walk_kernel(merge_args A)
 #ifdef MERGE_PROF
   XPROF(6)
   if (lane == 0)
-    for (int k = 0; k < 8; k++) atomicAdd(merge_prof+k,O.pa[k]);
+    { for (int k = 0; k < 16; k++) atomicAdd(merge_prof+k,O.pa[k]);
+      if (blockIdx.x < 8192)
+        { merge_tl[4*blockIdx.x] = O.t0; merge_tl[4*blockIdx.x+1] = wall_clock64();
+          merge_tl[4*blockIdx.x+2] = O.ntile; merge_tl[4*blockIdx.x+3] = O.nrange;
+        }
+    }
 #endif
   unsigned long long tsum = O.tsum;
   #pragma unroll
@@ -834,6 +893,9 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
         { nranges = (int) (total/2048) + 1; nbig = nranges/4; }
       if (nbig < 1) { nbig = 1; if (nranges < 2) nranges = 2; }
       if (grid > nranges) grid = nranges;
+#ifdef MERGE_PROF
+      merge_prof_grid = grid;
+#endif
       work = fga_dev_acquire(dev,SLOT_TILES,sizeof(int64_t)*(size_t) (nranges+2) + 64);
       if (work == NULL)
         { fga_set_error("fga_seed_merge: device allocation failed");
@@ -873,13 +935,38 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
       hipEventElapsedTime(&dev->last_ms[FGA_STAGE_MERGE],dev->ev0,ev2);
     }
 #ifdef MERGE_PROF
-  { unsigned long long hp[8], z[8] = {0,0,0,0,0,0,0,0};
+  { unsigned long long hp[16], z[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};
     hipMemcpyFromSymbol(hp,HIP_SYMBOL(merge_prof),sizeof(hp));
     hipMemcpyToSymbol(HIP_SYMBOL(merge_prof),z,sizeof(z));
-    double tot = 0; for (int k = 0; k < 8; k++) tot += (double) hp[k];
+    double tot = 0; for (int k = 0; k < 16; k++) tot += (double) hp[k];
     if (tot > 0)
       fprintf(stderr,"merge phases (%% of wave cycles): tile select %.1f  load issue %.1f  load wait %.1f  window %.1f  match %.1f  emit %.1f  rest %.1f   (%.0f Mcycles)\n",
               100*hp[0]/tot,100*hp[1]/tot,100*hp[2]/tot,100*hp[3]/tot,100*hp[4]/tot,100*hp[5]/tot,100*hp[6]/tot,tot*1e-6);
+    if (tot > 0)
+      fprintf(stderr,"   match: bounds+search %.1f  neighbour reads %.1f  growth+count %.1f  (rest in match)   emission: scan+block %.1f  zero+descriptors %.1f  (slot loop in emit)\n",
+              100*hp[8]/tot,100*hp[9]/tot,100*hp[10]/tot,100*hp[11]/tot,100*hp[12]/tot);
+    if (tot > 0)
+      fprintf(stderr,"   select: loop back + index read %.1f  ballots %.1f  (index issue in tile select)  range start %.1f\n",100*hp[13]/tot,100*hp[14]/tot,100*hp[15]/tot);
+    static unsigned long long tl[8192*4];
+    hipMemcpyFromSymbol(tl,HIP_SYMBOL(merge_tl),sizeof(tl));
+    int ng = merge_prof_grid < 8192 ? merge_prof_grid : 8192;
+    unsigned long long t0 = ~0ull, t1 = 0, busy = 0, tiles = 0, late = 0, tmax = 0, rmax = 0;
+    for (int g = 0; g < ng; g++)
+      { if (tl[4*g] < t0) t0 = tl[4*g];
+        if (tl[4*g+1] > t1) t1 = tl[4*g+1];
+        if (tl[4*g] > late) late = tl[4*g];
+        busy += tl[4*g+1] - tl[4*g]; tiles += tl[4*g+2];
+        if (tl[4*g+2] > tmax) tmax = tl[4*g+2];
+        if (tl[4*g+3] > rmax) rmax = tl[4*g+3];
+      }
+    double span = (double) (t1 - t0);
+    int hist[10] = {0,0,0,0,0,0,0,0,0,0};
+    for (int g = 0; g < ng; g++)
+      { int b = (int) (10.0 * (double) (tl[4*g+1] - t0) / (span + 1)); hist[b < 10 ? b : 9] += 1; }
+    fprintf(stderr,"merge timeline: %d wavefronts, span %.1f us, last start at %.1f us, busy %.1f %% of span x wavefronts, tiles %llu (max %llu per wavefront), max ranges %llu\n   end-time deciles:",
+            ng,span/100.0,(double) (late-t0)/100.0,100.0*(double) busy/(span*ng),tiles,tmax,rmax);
+    for (int b = 0; b < 10; b++) fprintf(stderr," %d",hist[b]);
+    fprintf(stderr,"\n");
   }
 #endif
   S->phys_count = (int64_t) hc[0];
