@@ -32,25 +32,177 @@ extern "C" int fga_dev_open(int device, fga_dev **out)
   return 0;
 }
 
-// idle workspace slots go back to the device (the slots are grow-only while in use; after an index build, or between the
-// passes of a multi-pass run, tens of GB sit in slots nobody will ask for at that size again)
-extern "C" void fga_dev_trim(fga_dev *dev)
-{ for (int q = 0; q < SLOT_COUNT; q++)
-    if (dev->slot_ptr[q] != NULL && !dev->slot_busy[q])
-      { hipFree(dev->slot_ptr[q]);
-        dev->slot_ptr[q] = NULL; dev->slot_bytes[q] = 0;
+// ---------------------------------------------------------------------------------------------------
+// device memory: a pool of regions
+// ---------------------------------------------------------------------------------------------------
+// hipMalloc of tens of GB is not free: memory the process (or an earlier one) has used before is cleared by the driver when
+// it is handed out again -- 20-27 ms per GB measured (a 54 GB buffer: 1.0-1.5 s; 64 GB after the hipFree of another: 3.2 s),
+// 0.4 ms for memory that was never touched.  A 3 Gbp comparison allocates ~330 GB over its life (index staging, on-disk
+// bytes, views, seeds, sort buffers, trace-point pool) and holds at most ~250 at a time, so every byte that is REUSED
+// instead of freed and allocated again saves that time.  All device memory of a MiB and more therefore comes from regions
+// this process keeps: a request takes the smallest free piece that holds it (split, the rest stays free), a release merges
+// the piece with its free neighbours; a region goes back to the driver only when a new one cannot be had otherwise
+// (fga_dev_trim: all regions that are entirely free), or when its device context closes.  Pieces are 2 MiB aligned.
+// Like hipFree, releasing a piece waits for the device: the piece may be handed out again at once, to a copy on another
+// stream.
+#include <mutex>
+#define POOL_MIN    ((size_t) 1 << 20)
+#define POOL_ALIGN  ((size_t) 2 << 20)
+#define POOL_MAXDEV 16
+struct pool_piece { char *ptr; size_t bytes; int region; bool busy; };
+struct pool_region { char *base; size_t bytes; };
+struct pool_state
+  { std::vector<pool_piece>  pieces;          // by (region, address): the pieces of a region tile it
+    std::vector<pool_region> regions;         // slot r stays r while the region lives (base NULL: slot free)
+    std::mutex mu;
+  };
+static pool_state g_pool[POOL_MAXDEV];
+
+static pool_state *pool_here(void)
+{ int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= POOL_MAXDEV) return NULL;
+  return &g_pool[d];
+}
+
+static void pool_trim_locked(pool_state *P)
+{ for (size_t k = 0; k < P->pieces.size(); )
+    { const pool_piece &q = P->pieces[k];
+      if (!q.busy && q.ptr == P->regions[q.region].base && q.bytes == P->regions[q.region].bytes)
+        { const double t0 = fga_wall();
+          hipFree(q.ptr);
+          if (q.bytes >= ((size_t) 1 << 30)) fga_note("hipFree of an idle region",t0);
+          P->regions[q.region].base = NULL; P->regions[q.region].bytes = 0;
+          P->pieces.erase(P->pieces.begin() + (long) k);
+        }
+      else
+        k += 1;
+    }
+}
+
+hipError_t fga_pool_malloc(void **out, size_t bytes)
+{ *out = NULL;
+  if (bytes == 0) bytes = 16;
+  pool_state *P = pool_here();
+  if (bytes < POOL_MIN || P == NULL)
+    return hipMalloc(out,bytes);
+  const size_t need = (bytes + POOL_ALIGN-1) / POOL_ALIGN * POOL_ALIGN;
+  std::lock_guard<std::mutex> lock(P->mu);
+  long best = -1;
+  for (size_t k = 0; k < P->pieces.size(); k++)
+    if (!P->pieces[k].busy && P->pieces[k].bytes >= need && (best < 0 || P->pieces[k].bytes < P->pieces[(size_t) best].bytes))
+      best = (long) k;
+  if (best >= 0)
+    { pool_piece &q = P->pieces[(size_t) best];
+      const size_t rest = q.bytes - need;
+      q.busy = true; q.bytes = need;
+      *out = q.ptr;
+      if (rest > 0)
+        { pool_piece r = { q.ptr + need, rest, q.region, false };
+          P->pieces.insert(P->pieces.begin() + best + 1,r);
+        }
+      return hipSuccess;
+    }
+  void *p = NULL;
+  const double t0 = fga_wall();
+  hipError_t e = hipMalloc(&p,need);
+  if (e != hipSuccess)
+    { (void) hipGetLastError();
+      pool_trim_locked(P);                      // regions nobody uses go back, then once more
+      e = hipMalloc(&p,need);
+      if (e != hipSuccess)
+        { (void) hipGetLastError();
+          return e;
+        }
+    }
+  if (need >= ((size_t) 1 << 30))
+    { char what[64];
+      snprintf(what,sizeof(what),"hipMalloc %.1f GB",need*1e-9);
+      fga_note(what,t0);
+    }
+  int r = -1;
+  for (size_t k = 0; k < P->regions.size(); k++)
+    if (P->regions[k].base == NULL) { r = (int) k; break; }
+  if (r < 0) { r = (int) P->regions.size(); P->regions.push_back(pool_region()); }
+  P->regions[(size_t) r].base = (char *) p; P->regions[(size_t) r].bytes = need;
+  // pieces are kept by (region, address): a new region's piece goes behind the pieces of the regions before it
+  size_t at = P->pieces.size();
+  for (size_t k = 0; k < P->pieces.size(); k++)
+    if (P->pieces[k].region > r) { at = k; break; }
+  pool_piece q = { (char *) p, need, r, true };
+  P->pieces.insert(P->pieces.begin() + (long) at,q);
+  *out = p;
+  return hipSuccess;
+}
+
+hipError_t fga_pool_free(void *ptr)
+{ if (ptr == NULL) return hipSuccess;
+  pool_state *P = pool_here();
+  if (P != NULL)
+    { std::unique_lock<std::mutex> lock(P->mu);
+      for (size_t k = 0; k < P->pieces.size(); k++)
+        if (P->pieces[k].ptr == (char *) ptr && P->pieces[k].busy)
+          { lock.unlock();
+            (void) hipDeviceSynchronize();        // what hipFree does: nothing in flight refers to the piece any more
+            lock.lock();
+            for (k = 0; k < P->pieces.size(); k++)          // (the list may have changed while unlocked)
+              if (P->pieces[k].ptr == (char *) ptr && P->pieces[k].busy)
+                break;
+            if (k == P->pieces.size())
+              return hipSuccess;
+            P->pieces[k].busy = false;
+            if (k+1 < P->pieces.size() && !P->pieces[k+1].busy && P->pieces[k+1].region == P->pieces[k].region)
+              { P->pieces[k].bytes += P->pieces[k+1].bytes;
+                P->pieces.erase(P->pieces.begin() + (long) k + 1);
+              }
+            if (k > 0 && !P->pieces[k-1].busy && P->pieces[k-1].region == P->pieces[k].region)
+              { P->pieces[k-1].bytes += P->pieces[k].bytes;
+                P->pieces.erase(P->pieces.begin() + (long) k);
+              }
+            return hipSuccess;
+          }
+    }
+  return hipFree(ptr);
+}
+
+// bytes in free pieces, and the largest of them
+static void pool_idle(size_t *total, size_t *largest)
+{ *total = *largest = 0;
+  pool_state *P = pool_here();
+  if (P == NULL) return;
+  std::lock_guard<std::mutex> lock(P->mu);
+  for (const pool_piece &q : P->pieces)
+    if (!q.busy)
+      { *total += q.bytes;
+        if (q.bytes > *largest) *largest = q.bytes;
       }
 }
 
-// device memory an allocation could get right now: free memory + what the idle slots hold
+// the regions nobody uses go back to the device (another library in the process -- torch's exchange buffers -- may need them)
+extern "C" void fga_dev_trim(fga_dev *dev)
+{ if (hipSetDevice(dev->device) != hipSuccess) return;
+  pool_state *P = pool_here();
+  if (P == NULL) return;
+  std::lock_guard<std::mutex> lock(P->mu);
+  pool_trim_locked(P);
+}
+
+// device memory an allocation could get right now: free memory + what the pool's free pieces hold
 extern "C" size_t fga_dev_available(fga_dev *dev)
-{ size_t fr = 0, tot = 0;
-  if (hipMemGetInfo(&fr,&tot) != hipSuccess)
+{ size_t fr = 0, tot = 0, idle = 0, big = 0;
+  if (hipSetDevice(dev->device) != hipSuccess || hipMemGetInfo(&fr,&tot) != hipSuccess)
     return 0;
-  for (int q = 0; q < SLOT_COUNT; q++)
-    if (dev->slot_ptr[q] != NULL && !dev->slot_busy[q])
-      fr += dev->slot_bytes[q];
-  return fr;
+  pool_idle(&idle,&big);
+  return fr + idle;
+}
+
+// the largest single allocation that can succeed without giving regions back: a free piece, or fresh memory less a reserve
+size_t fga_dev_largest(fga_dev *dev, size_t reserve)
+{ size_t fr = 0, tot = 0, idle = 0, big = 0;
+  if (hipSetDevice(dev->device) != hipSuccess || hipMemGetInfo(&fr,&tot) != hipSuccess)
+    return 0;
+  pool_idle(&idle,&big);
+  fr = fr > reserve ? fr - reserve : 0;
+  return fr > big ? fr : big;
 }
 
 // FGA_TIMING=1: wall-clock notes on stderr (allocations of a GB and more, the steps of an index build): where a
@@ -62,79 +214,19 @@ extern "C" void fga_note(const char *what, double since)
     fprintf(stderr,"[fga timing] %-40s %9.1f ms\n",what,1e3*(fga_wall() - since));
 }
 
-static void *alloc_or_trim(fga_dev *dev, size_t bytes)
-{ void *p = NULL;
-  const double t0 = fga_wall();
-  if (hipMalloc(&p,bytes) == hipSuccess)
-    { if (bytes >= ((size_t) 1 << 30))
-        { char what[64];
-          snprintf(what,sizeof(what),"hipMalloc %.1f GB",bytes*1e-9);
-          fga_note(what,t0);
-        }
-      return p;
-    }
-  (void) hipGetLastError();
-  fga_dev_trim(dev);                        // give the idle slots back and try once more
-  if (hipMalloc(&p,bytes) == hipSuccess)
-    return p;
-  (void) hipGetLastError();
-  return NULL;
-}
-
+// the pipeline's work buffers: `slot` says what the buffer is for (a name in the callers, nothing more: every buffer is a
+// piece of the pool)
 void *fga_dev_acquire(fga_dev *dev, int slot, size_t bytes)
-{ if (bytes == 0) bytes = 16;
-  if (slot < 0 || slot >= SLOT_COUNT || dev->slot_busy[slot])
-    return alloc_or_trim(dev,bytes);        // slot taken (or none asked): a private allocation
-  if (dev->slot_ptr[slot] == NULL || dev->slot_bytes[slot] < bytes)
-    { // another idle slot may hold a buffer that is large enough (the index builder's key buffers, the undivided seed
-      // buffer of a multi-pass run): take it over instead of freeing / allocating tens of GB -- a hipMalloc that follows
-      // the hipFree of such a buffer has been measured at 1-3 s
-      int best = -1;
-      for (int q = 0; q < SLOT_COUNT; q++)
-        if (q != slot && !dev->slot_busy[q] && dev->slot_ptr[q] != NULL && dev->slot_bytes[q] >= bytes &&
-            (best < 0 || dev->slot_bytes[q] < dev->slot_bytes[best]))
-          best = q;
-      size_t fr = 0, tot = 0;
-      if (best >= 0 && bytes >= ((size_t) 64 << 20) && dev->slot_bytes[best] > 2*bytes + ((size_t) 1 << 30) &&
-          hipMemGetInfo(&fr,&tot) == hipSuccess && fr < ((size_t) 32 << 30))
-        { // far larger than what is asked for (a part's buffers after the undivided ones) and the device is nearly full:
-          // give it back and allocate what is needed.  With room to spare the large buffer is taken over all the same: a
-          // fresh allocation of tens of GB after such a free has been measured at 3 s (the extension's 64 GB trace-point
-          // pool at 10 % divergence)
-          const double t0 = fga_wall();
-          hipFree(dev->slot_ptr[best]);
-          fga_note("hipFree of an oversize idle slot",t0);
-          dev->slot_ptr[best] = NULL; dev->slot_bytes[best] = 0;
-          best = -1;
-        }
-      if (best >= 0 && bytes >= ((size_t) 64 << 20))
-        { void *tp = dev->slot_ptr[slot]; size_t tb = dev->slot_bytes[slot];
-          dev->slot_ptr[slot] = dev->slot_ptr[best]; dev->slot_bytes[slot] = dev->slot_bytes[best];
-          dev->slot_ptr[best] = tp; dev->slot_bytes[best] = tb;
-        }
-      else
-        { if (dev->slot_ptr[slot] != NULL)
-            hipFree(dev->slot_ptr[slot]);
-          dev->slot_ptr[slot] = NULL; dev->slot_bytes[slot] = 0;
-          size_t slack = bytes/8;               // room to grow without a new allocation, bounded: a 50 GB buffer does not get 6 GB of it
-          if (slack > ((size_t) 256 << 20)) slack = (size_t) 256 << 20;
-          size_t want = bytes + slack;
-          dev->slot_ptr[slot] = alloc_or_trim(dev,want);
-          if (dev->slot_ptr[slot] == NULL)
-            return NULL;
-          dev->slot_bytes[slot] = want;
-        }
-    }
-  dev->slot_busy[slot] = 1;
-  return dev->slot_ptr[slot];
+{ (void) dev; (void) slot;
+  void *p = NULL;
+  if (fga_pool_malloc(&p,bytes > 0 ? bytes : 16) != hipSuccess)
+    return NULL;
+  return p;
 }
 
 void fga_dev_release(fga_dev *dev, int slot, void *ptr)
-{ if (ptr == NULL) return;
-  if (slot >= 0 && slot < SLOT_COUNT && dev->slot_ptr[slot] == ptr)
-    dev->slot_busy[slot] = 0;
-  else
-    hipFree(ptr);
+{ (void) dev; (void) slot;
+  fga_pool_free(ptr);
 }
 
 void *fga_dev_pinned(fga_dev *dev, size_t bytes)
@@ -164,7 +256,8 @@ extern "C" void fga_dev_stage_release(fga_dev *dev, void *ptr)
 extern "C" int fga_dev_malloc(fga_dev *dev, size_t bytes, void **out)
 { *out = NULL;
   FGA_HIP(hipSetDevice(dev->device));
-  *out = alloc_or_trim(dev,bytes > 0 ? bytes : 16);        // idle workspace slots are given back before giving up
+  if (fga_pool_malloc(out,bytes > 0 ? bytes : 16) != hipSuccess)
+    *out = NULL;
   if (*out == NULL)
     { fga_set_error("device allocation of %zu bytes failed: out of memory",bytes);
       return 1;
@@ -175,7 +268,7 @@ extern "C" int fga_dev_malloc(fga_dev *dev, size_t bytes, void **out)
 extern "C" void fga_dev_free(fga_dev *dev, void *ptr)
 { if (ptr == NULL) return;
   hipSetDevice(dev->device);
-  hipFree(ptr);
+  fga_pool_free(ptr);
 }
 
 // free device memory right now, remembered as a low-water mark: with the grow-only workspace slots, the difference to
@@ -215,8 +308,7 @@ extern "C" void fga_dev_close(fga_dev *d)
 { if (d == NULL) return;
   hipSetDevice(d->device);
   hipStreamSynchronize(d->stream);
-  for (int q = 0; q < SLOT_COUNT; q++)
-    if (d->slot_ptr[q] != NULL) hipFree(d->slot_ptr[q]);
+  fga_dev_trim(d);
   if (d->pinned != NULL) hipHostFree(d->pinned);
   hipEventDestroy(d->ev0);
   hipEventDestroy(d->ev1);
@@ -269,23 +361,23 @@ static int dgix_upload_impl(fga_dev *dev, const fga_gix *X, int64_t pbeg, int64_
     }
   size_t tbytes = (size_t) D->nents * X->ebytes;
   hipError_t e;
-  if ((e = hipMalloc(&D->table,tbytes + 64)) != hipSuccess ||
-      (e = hipMalloc(&D->index,sizeof(int64_t)*FGA_NPREFIX)) != hipSuccess)
+  if ((e = fga_dmalloc(&D->table,tbytes + 64)) != hipSuccess ||
+      (e = fga_dmalloc(&D->index,sizeof(int64_t)*FGA_NPREFIX)) != hipSuccess)
     { fga_set_error("fga_dgix_upload: device allocation of %zu bytes failed: %s",tbytes,hipGetErrorString(e));
-      hipFree(D->table); hipFree(D->index); free(D); free(sub);
+      fga_pool_free(D->table); fga_pool_free(D->index); free(D); free(sub);
       return 1;
     }
   if ((e = hipMemcpy(D->table,X->table + (size_t) lo*X->ebytes,tbytes,hipMemcpyHostToDevice)) != hipSuccess ||
       (e = hipMemset(D->table + tbytes,0,64)) != hipSuccess ||
       (e = hipMemcpy(D->index,hidx,sizeof(int64_t)*FGA_NPREFIX,hipMemcpyHostToDevice)) != hipSuccess)
     { fga_set_error("fga_dgix_upload: copy failed: %s",hipGetErrorString(e));
-      hipFree(D->table); hipFree(D->index); free(D); free(sub);
+      fga_pool_free(D->table); fga_pool_free(D->index); free(D); free(sub);
       return 1;
     }
   free(sub);
   D->legacy_cutoff = X->legacy ? X->freq : 0;
   if (fga_dgix_make_view(dev,D,0))
-    { hipFree(D->table); hipFree(D->index); free(D);
+    { fga_pool_free(D->table); fga_pool_free(D->index); free(D);
       return 1;
     }
   *out = D;
@@ -311,8 +403,8 @@ extern "C" void fga_dgix_free(fga_dgix *D)
 { if (D == NULL) return;
   hipSetDevice(D->dev->device);
   fga_dgix_free_views(D);
-  hipFree(D->table);
-  hipFree(D->index);
+  fga_pool_free(D->table);
+  fga_pool_free(D->index);
   free(D);
 }
 
@@ -352,6 +444,6 @@ extern "C" void fga_seeds_free(fga_dseeds *S)
   hipSetDevice(S->dev->device);
   fga_dev_release(S->dev,S->slot,S->seeds);
   fga_dev_release(S->dev,SLOT_VALID,S->valid);
-  hipFree(S->dcount);
+  fga_pool_free(S->dcount);
   free(S);
 }

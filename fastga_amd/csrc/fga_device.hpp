@@ -26,11 +26,6 @@ struct fga_dev
     hipEvent_t   ev0, ev1;
     int          ncu;
     float        last_ms[8];     // per-stage kernel time of the most recent call (HIP events)
-    // grow-only workspace slots: hipMalloc/hipFree of GB-sized buffers costs ~100 ms each, so the big
-    // buffers of the pipeline stay with the device context between calls
-    void        *slot_ptr[16];
-    size_t       slot_bytes[16];
-    int          slot_busy[16];
     void        *pinned;          // pinned host staging buffer (key download)
     size_t       pinned_bytes;
     // what the last extension launch really needed (cells of the trace-point pool per hit-box base, output trace bytes
@@ -40,6 +35,13 @@ struct fga_dev
     int          host_threads;    // threads the host tails of the device stages may use (fga_dev_set_host_threads; 0 = 1)
   };
 void fga_dev_note_memory(fga_dev *dev);
+
+// Device memory of a MiB and more is a piece of a region the process keeps (fga_device.hip: the pool); smaller requests go
+// to hipMalloc.  fga_pool_free takes either kind.  Every allocation of the library goes through these two.
+hipError_t fga_pool_malloc(void **out, size_t bytes);
+hipError_t fga_pool_free(void *ptr);
+template <class T> static inline hipError_t fga_dmalloc(T **out, size_t bytes) { return fga_pool_malloc((void **) out,bytes); }
+size_t fga_dev_largest(fga_dev *dev, size_t reserve);          // largest allocation that needs no region given back
 
 // a table as the seed merge reads it: one array per field (fga_view.hip)
 struct fga_view
@@ -75,7 +77,7 @@ void fga_dgix_free_views(fga_dgix *D);
 //   bctg       : B contig | (B entry's own sign bit) << 30 | (C-stream flag) << 31
 enum { SLOT_SEEDS = 0, SLOT_SORT0, SLOT_SORT1, SLOT_HIST, SLOT_TILES, SLOT_CELLS, SLOT_TRACE, SLOT_ALNS,
        SLOT_TBYTES, SLOT_MISC, SLOT_VALID, SLOT_STAGE, SLOT_COUNT };
-void *fga_dev_acquire(fga_dev *dev, int slot, size_t bytes);   // NULL on failure; pair with fga_dev_release
+void *fga_dev_acquire(fga_dev *dev, int slot, size_t bytes);   // a work buffer (the slot names its purpose); NULL on failure
 void  fga_dev_release(fga_dev *dev, int slot, void *ptr);
 void *fga_dev_pinned(fga_dev *dev, size_t bytes);              // host pinned staging, grow-only
 int   fga_radix_sort_u128(fga_dev *dev, uint4 *buf0, uint4 *buf1, int64_t n, int lowbit, int nbits, uint4 **sorted);

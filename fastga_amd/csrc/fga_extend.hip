@@ -201,13 +201,13 @@ extern "C" int fga_dgenome_upload(fga_dev *dev, const fga_gdb *G, const int *per
   for (int c = 0; c < G->ncontig; c++)
     { boff[c] = G->contigs[c].boff; clen[c] = G->contigs[c].clen; }
   hipError_t e;
-  if ((e = hipMalloc(&D->img,bytes)) != hipSuccess ||
-      (e = hipMalloc(&D->boff,sizeof(int64_t)*G->ncontig)) != hipSuccess ||
-      (e = hipMalloc(&D->clen,sizeof(int64_t)*G->ncontig)) != hipSuccess ||
-      (e = hipMalloc(&D->perm,sizeof(int)*(nperm > 0 ? nperm : 1))) != hipSuccess ||
-      (want_revcomp && (e = hipMalloc(&D->img_rc,bytes)) != hipSuccess))
+  if ((e = fga_dmalloc(&D->img,bytes)) != hipSuccess ||
+      (e = fga_dmalloc(&D->boff,sizeof(int64_t)*G->ncontig)) != hipSuccess ||
+      (e = fga_dmalloc(&D->clen,sizeof(int64_t)*G->ncontig)) != hipSuccess ||
+      (e = fga_dmalloc(&D->perm,sizeof(int)*(nperm > 0 ? nperm : 1))) != hipSuccess ||
+      (want_revcomp && (e = fga_dmalloc(&D->img_rc,bytes)) != hipSuccess))
     { fga_set_error("fga_dgenome_upload: device allocation failed: %s",hipGetErrorString(e));
-      hipFree(D->img); hipFree(D->boff); hipFree(D->clen); hipFree(D->perm); hipFree(D->img_rc); free(D);
+      fga_pool_free(D->img); fga_pool_free(D->boff); fga_pool_free(D->clen); fga_pool_free(D->perm); fga_pool_free(D->img_rc); free(D);
       return 1;
     }
   hipMemset(D->img,0,bytes);
@@ -229,7 +229,7 @@ extern "C" int fga_dgenome_upload(fga_dev *dev, const fga_gdb *G, const int *per
   if (e == hipSuccess) e = hipGetLastError();
   if (e != hipSuccess)
     { fga_set_error("fga_dgenome_upload: %s",hipGetErrorString(e));
-      hipFree(D->img); hipFree(D->boff); hipFree(D->clen); hipFree(D->perm); hipFree(D->img_rc); free(D->hclen); free(D);
+      fga_pool_free(D->img); fga_pool_free(D->boff); fga_pool_free(D->clen); fga_pool_free(D->perm); fga_pool_free(D->img_rc); free(D->hclen); free(D);
       return 1;
     }
   *out = D;
@@ -239,7 +239,7 @@ extern "C" int fga_dgenome_upload(fga_dev *dev, const fga_gdb *G, const int *per
 extern "C" void fga_dgenome_free(fga_dgenome *D)
 { if (D == NULL) return;
   hipSetDevice(D->dev->device);
-  hipFree(D->img); hipFree(D->img_rc); hipFree(D->boff); hipFree(D->clen); hipFree(D->perm);
+  fga_pool_free(D->img); fga_pool_free(D->img_rc); fga_pool_free(D->boff); fga_pool_free(D->clen); fga_pool_free(D->perm);
   free(D->hclen);
   free(D);
 }
@@ -342,21 +342,21 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
   int64_t span = 0;
   for (int64_t h = 0; h < H->nhits; h++)
     span += (H->hits[h].ahgh - H->hits[h].alow) / 2 + 200;
-  // cells / trace bytes per hit-box base: 0.48 / 0.04 to begin with (24 diagonals x 2 / 100; 4 / 100), afterwards what the
-  // device context's last launch needed plus a quarter
-  const double cpb = dev->ext_cells_per_base > 0. ? 1.25*dev->ext_cells_per_base : 0.48;
+  // cells / trace bytes per hit-box base: 0.12 / 0.04 to begin with, afterwards what the device context's last launch needed
+  // plus a quarter.  (Measured beyond every wavefront's first level: 0.02-0.03 cells per base -- 3 Gbp at 10 %: 4.0 GB used,
+  // 150 Mbp repeat-heavy self: 1.1 GB, the 100 Mbp bench pair: 0.33 GB; the first estimate, 0.48, asked for 63.6 / 5.7 /
+  // 2.6 GB, and at 3 Gbp the allocation of those 64 GB cost 0.6-3.2 s.  A launch that does run out is repeated once with
+  // what it counted.)
+  const double cpb = dev->ext_cells_per_base > 0. ? 1.25*dev->ext_cells_per_base : 0.12;
   const double tpb = dev->ext_tbytes_per_base > 0. ? 1.25*dev->ext_tbytes_per_base : 0.04;
   int64_t pool_cells = prm->cell_cap > 0 ? prm->cell_cap
                                          : (int64_t) nwg*((1 << ARENA_L0) + 256) + (int64_t) (cpb*span)
                                            + ((int64_t) 64 << 20);
   int64_t aln_cap   = prm->aln_cap   > 0 ? prm->aln_cap   : 4*H->nhits + 1024;
   int64_t tb_cap    = prm->trace_cap > 0 ? prm->trace_cap : (int64_t) (tpb*span) + 64*aln_cap + (1 << 20);
-  { size_t fr = 0, tot = 0;                  // never ask for more than what is free (the slot's own bytes count as free)
-    if (hipMemGetInfo(&fr,&tot) == hipSuccess && fr > 0)
-      { const int64_t have = (int64_t) dev->slot_bytes[SLOT_CELLS];
-        const int64_t lim = ((int64_t) fr + have - ((int64_t) 8 << 30)) / (int64_t) sizeof(int4);
-        if (lim > 0 && pool_cells > lim) pool_cells = lim;
-      }
+  { // never ask for more than one allocation can get (a free piece of the device pool, or free memory less 8 GiB)
+    const int64_t lim = (int64_t) (fga_dev_largest(dev,(size_t) 8 << 30) / sizeof(int4)) - 256;
+    if (lim > 0 && pool_cells > lim) pool_cells = lim;
   }
 
   ext_args A;
@@ -377,14 +377,14 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
   unsigned long long *d_cnt = NULL;
   arena_lists *d_lists = NULL;
   hipError_t e;
-  if ((e = hipMalloc(&d_lists,sizeof(arena_lists))) != hipSuccess ||
-      (e = hipMalloc(&d_units,sizeof(fga_unit)*H->nunits)) != hipSuccess ||
-      (e = hipMalloc(&d_hits,sizeof(fga_hit)*(H->nhits+1))) != hipSuccess ||
-      (e = hipMalloc(&d_order,sizeof(int)*H->nunits)) != hipSuccess ||
-      (e = hipMalloc(&d_wide,sizeof(int)*H->nunits)) != hipSuccess ||
-      (e = hipMalloc(&d_next,sizeof(int))) != hipSuccess ||
-      (e = hipMalloc(&d_tab,sizeof(int16_t)*2*32768)) != hipSuccess ||
-      (e = hipMalloc(&d_cnt,sizeof(unsigned long long)*32)) != hipSuccess)
+  if ((e = fga_dmalloc(&d_lists,sizeof(arena_lists))) != hipSuccess ||
+      (e = fga_dmalloc(&d_units,sizeof(fga_unit)*H->nunits)) != hipSuccess ||
+      (e = fga_dmalloc(&d_hits,sizeof(fga_hit)*(H->nhits+1))) != hipSuccess ||
+      (e = fga_dmalloc(&d_order,sizeof(int)*H->nunits)) != hipSuccess ||
+      (e = fga_dmalloc(&d_wide,sizeof(int)*H->nunits)) != hipSuccess ||
+      (e = fga_dmalloc(&d_next,sizeof(int))) != hipSuccess ||
+      (e = fga_dmalloc(&d_tab,sizeof(int16_t)*2*32768)) != hipSuccess ||
+      (e = fga_dmalloc(&d_cnt,sizeof(unsigned long long)*32)) != hipSuccess)
     { fga_set_error("fga_extend: device allocation failed: %s",hipGetErrorString(e));
       goto fail;
     }
@@ -528,14 +528,14 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
       R->naln = o;
     }
   R->ncalls = ncalls_total;
-  hipFree(d_units); hipFree(d_hits); hipFree(d_order); hipFree(d_wide); hipFree(d_next); hipFree(d_tab); hipFree(d_cnt); hipFree(d_lists);
+  fga_pool_free(d_units); fga_pool_free(d_hits); fga_pool_free(d_order); fga_pool_free(d_wide); fga_pool_free(d_next); fga_pool_free(d_tab); fga_pool_free(d_cnt); fga_pool_free(d_lists);
   fga_dev_release(dev,SLOT_CELLS,A.pool);
   fga_dev_release(dev,SLOT_ALNS,A.alns); fga_dev_release(dev,SLOT_TBYTES,A.tbytes);
   *out = R;
   return 0;
 
 fail:
-  hipFree(d_units); hipFree(d_hits); hipFree(d_order); hipFree(d_wide); hipFree(d_next); hipFree(d_tab); hipFree(d_cnt); hipFree(d_lists);
+  fga_pool_free(d_units); fga_pool_free(d_hits); fga_pool_free(d_order); fga_pool_free(d_wide); fga_pool_free(d_next); fga_pool_free(d_tab); fga_pool_free(d_cnt); fga_pool_free(d_lists);
   fga_dev_release(dev,SLOT_CELLS,A.pool);
   fga_dev_release(dev,SLOT_ALNS,A.alns); fga_dev_release(dev,SLOT_TBYTES,A.tbytes);
   free(R->alns); free(R->tbytes); free(R);
@@ -575,10 +575,10 @@ extern "C" void *fga_shim_New_Work_Data(void)
   const char *e = getenv("FGA_DEVICE");
   if (fga_dev_open(e != NULL ? atoi(e) : 0,&W->dev))
     { delete W; return NULL; }
-  if (hipMalloc(&W->dout,sizeof(int)*8) != hipSuccess || hipMalloc(&W->dcnt,sizeof(unsigned long long)*32) != hipSuccess ||
-      hipMalloc(&W->dlists,sizeof(arena_lists)) != hipSuccess || hipMemset(W->dlists,0,sizeof(arena_lists)) != hipSuccess)
+  if (fga_dmalloc(&W->dout,sizeof(int)*8) != hipSuccess || fga_dmalloc(&W->dcnt,sizeof(unsigned long long)*32) != hipSuccess ||
+      fga_dmalloc(&W->dlists,sizeof(arena_lists)) != hipSuccess || hipMemset(W->dlists,0,sizeof(arena_lists)) != hipSuccess)
     { fga_set_error("fga_shim_New_Work_Data: device allocation failed");
-      hipFree(W->dout); fga_dev_close(W->dev); delete W;
+      fga_pool_free(W->dout); fga_dev_close(W->dev); delete W;
       return NULL;
     }
   return W;
@@ -588,7 +588,7 @@ extern "C" void fga_shim_Free_Work_Data(void *work)
 { shim_work *W = (shim_work *) work;
   if (W == NULL) return;
   hipSetDevice(W->dev->device);
-  hipFree(W->dA); hipFree(W->dB); hipFree(W->pool); hipFree(W->dtrace); hipFree(W->dout); hipFree(W->dcnt); hipFree(W->dlists);
+  fga_pool_free(W->dA); fga_pool_free(W->dB); fga_pool_free(W->pool); fga_pool_free(W->dtrace); fga_pool_free(W->dout); fga_pool_free(W->dcnt); fga_pool_free(W->dlists);
   fga_dev_close(W->dev);
   delete W;
 }
@@ -615,8 +615,8 @@ static int shim_upload(shim_work *W, const char *seq, int len, uint8_t **dbuf, s
   for (int i = 0; i < len; i++)
     p[i >> 2] |= (uint8_t) ((seq[i] & 3) << (2*(i & 3)));
   if (*cap < bytes)
-    { hipFree(*dbuf); *dbuf = NULL; *cap = 0;
-      if (hipMalloc(dbuf,bytes + bytes/4) != hipSuccess)
+    { fga_pool_free(*dbuf); *dbuf = NULL; *cap = 0;
+      if (fga_dmalloc(dbuf,bytes + bytes/4) != hipSuccess)
         { fga_set_error("fga_shim_Local_Alignment: device allocation failed");
           return 1;
         }
@@ -649,8 +649,8 @@ extern "C" int fga_shim_Local_Alignment(void *align_, void *work, void *spec_, i
   // pool: up to ~64 cells per 100 bases (wide waves) + the trace scratch
   const int64_t need = 64*((int64_t) maxlen/TS + 64) + (1 << ARENA_L0) + 4096;
   if (W->pool_cells < need)
-    { hipFree(W->pool); W->pool = NULL; W->pool_cells = 0;
-      if (hipMalloc(&W->pool,sizeof(int4)*((size_t) need + 128)) != hipSuccess)
+    { fga_pool_free(W->pool); W->pool = NULL; W->pool_cells = 0;
+      if (fga_dmalloc(&W->pool,sizeof(int4)*((size_t) need + 128)) != hipSuccess)
         { fga_set_error("fga_shim_Local_Alignment: device allocation failed");
           return 1;
         }
@@ -658,8 +658,8 @@ extern "C" int fga_shim_Local_Alignment(void *align_, void *work, void *spec_, i
     }
   const int tcap = 4*(align->alen/TS + 4) + 16;
   if (W->dtrace_cap < tcap)
-    { hipFree(W->dtrace); W->dtrace = NULL; W->dtrace_cap = 0;
-      if (hipMalloc(&W->dtrace,sizeof(uint16_t)*(size_t) tcap) != hipSuccess)
+    { fga_pool_free(W->dtrace); W->dtrace = NULL; W->dtrace_cap = 0;
+      if (fga_dmalloc(&W->dtrace,sizeof(uint16_t)*(size_t) tcap) != hipSuccess)
         { fga_set_error("fga_shim_Local_Alignment: device allocation failed");
           return 1;
         }

@@ -360,20 +360,22 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
       goto done;
     }
 
-  if ((e = hipMalloc(&dimg,(size_t) G->bpslen + 64)) != hipSuccess ||
-      (e = hipMalloc(&dboff,sizeof(int64_t)*boff.size())) != hipSuccess ||
-      (e = hipMalloc(&dclen,sizeof(int64_t)*clen.size())) != hipSuccess ||
-      (e = hipMalloc(&dinvp,sizeof(int)*(size_t) nctg)) != hipSuccess ||
-      (e = hipMalloc(&ditems,sizeof(gix_item)*items.size())) != hipSuccess ||
-      (e = hipMalloc(&dcount,sizeof(uint32_t)*FGA_NPREFIX)) != hipSuccess ||
-      (e = hipMalloc(&dctr,sizeof(unsigned long long)*(1 + 1024 + 4096 + 1))) != hipSuccess ||
-      (e = hipMalloc(&dpartid,1024)) != hipSuccess)
+  if ((e = fga_dmalloc(&dimg,(size_t) G->bpslen + 64)) != hipSuccess ||
+      (e = fga_dmalloc(&dboff,sizeof(int64_t)*boff.size())) != hipSuccess ||
+      (e = fga_dmalloc(&dclen,sizeof(int64_t)*clen.size())) != hipSuccess ||
+      (e = fga_dmalloc(&dinvp,sizeof(int)*(size_t) nctg)) != hipSuccess ||
+      (e = fga_dmalloc(&ditems,sizeof(gix_item)*items.size())) != hipSuccess ||
+      (e = fga_dmalloc(&dcount,sizeof(uint32_t)*FGA_NPREFIX)) != hipSuccess ||
+      (e = fga_dmalloc(&dctr,sizeof(unsigned long long)*(1 + 1024 + 4096 + 1))) != hipSuccess ||
+      (e = fga_dmalloc(&dpartid,1024)) != hipSuccess)
     { fga_set_error("fga_dgix_build: device allocation failed: %s",hipGetErrorString(e));
       goto done;
     }
   if (!count_only)
-    { buf0 = (uint4 *) fga_dev_acquire(dev,SLOT_SORT0,sizeof(uint4)*(size_t) cap);
-      buf1 = (uint4 *) fga_dev_acquire(dev,SLOT_SORT1,sizeof(uint4)*(size_t) cap);
+    { // both key buffers in ONE piece of the device pool: what follows an index build (seeds, sort buffers, the trace-point
+      // pool of the extension) is then cut from one free stretch, not from two halves a larger request does not fit
+      buf0 = (uint4 *) fga_dev_acquire(dev,SLOT_SORT0,2*sizeof(uint4)*(size_t) cap);
+      buf1 = buf0 != NULL ? buf0 + cap : NULL;
       if (buf0 == NULL || buf1 == NULL)
         { fga_set_error("fga_dgix_build: device allocation of the key buffers failed");
           goto done;
@@ -419,10 +421,10 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
     nkeys = (int64_t) hk[0];
     if (nkeys > cap)
       { // low-complexity sequence (up to two k-mers per base): the exact size is known now, go again
-        fga_dev_release(dev,SLOT_SORT0,buf0); fga_dev_release(dev,SLOT_SORT1,buf1);
+        fga_dev_release(dev,SLOT_SORT0,buf0);
         cap = nkeys + 4096;
-        buf0 = (uint4 *) fga_dev_acquire(dev,SLOT_SORT0,sizeof(uint4)*(size_t) cap);
-        buf1 = (uint4 *) fga_dev_acquire(dev,SLOT_SORT1,sizeof(uint4)*(size_t) cap);
+        buf0 = (uint4 *) fga_dev_acquire(dev,SLOT_SORT0,2*sizeof(uint4)*(size_t) cap);
+        buf1 = buf0 != NULL ? buf0 + cap : NULL;
         if (buf0 == NULL || buf1 == NULL)
           { fga_set_error("fga_dgix_build: device allocation of the key buffers failed");
             goto done;
@@ -476,8 +478,8 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
   D = (fga_dgix *) calloc(1,sizeof(fga_dgix));
   if (D == NULL) { fga_set_error("out of memory"); goto done; }
   D->dev = dev; D->nents = nkeys; D->ebytes = ebytes; D->postbytes = postbytes; D->contbytes = contbytes; D->nctg = nctg;
-  if ((e = hipMalloc(&D->table,(size_t) nkeys*ebytes + 64)) != hipSuccess ||
-      (e = hipMalloc(&D->index,sizeof(int64_t)*FGA_NPREFIX)) != hipSuccess)
+  if ((e = fga_dmalloc(&D->table,(size_t) nkeys*ebytes + 64)) != hipSuccess ||
+      (e = fga_dmalloc(&D->index,sizeof(int64_t)*FGA_NPREFIX)) != hipSuccess)
     { fga_set_error("fga_dgix_build: device allocation of the table failed: %s",hipGetErrorString(e));
       goto done;
     }
@@ -494,10 +496,10 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
       E.table = D->table; E.partid = dpartid;
       E.moff = NULL; E.mbeg = E.mend = NULL; E.perm = NULL;
       if (use_mask)
-        { if ((e = hipMalloc(&dmoff,sizeof(int64_t)*(size_t) (nctg+1))) != hipSuccess ||
-              (e = hipMalloc(&dmbeg,sizeof(int64_t)*(size_t) G->nmask)) != hipSuccess ||
-              (e = hipMalloc(&dmend,sizeof(int64_t)*(size_t) G->nmask)) != hipSuccess ||
-              (e = hipMalloc(&dperm,sizeof(int)*(size_t) nctg)) != hipSuccess)
+        { if ((e = fga_dmalloc(&dmoff,sizeof(int64_t)*(size_t) (nctg+1))) != hipSuccess ||
+              (e = fga_dmalloc(&dmbeg,sizeof(int64_t)*(size_t) G->nmask)) != hipSuccess ||
+              (e = fga_dmalloc(&dmend,sizeof(int64_t)*(size_t) G->nmask)) != hipSuccess ||
+              (e = fga_dmalloc(&dperm,sizeof(int)*(size_t) nctg)) != hipSuccess)
             { fga_set_error("fga_dgix_build: device allocation failed: %s",hipGetErrorString(e));
               goto done;
             }
@@ -565,13 +567,13 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
   status = 0;
 
 done:
-  hipFree(dimg); hipFree(dboff); hipFree(dclen); hipFree(dinvp); hipFree(ditems); hipFree(dcount); hipFree(dctr);
-  hipFree(dpartid);
-  hipFree(dmoff); hipFree(dmbeg); hipFree(dmend); hipFree(dperm);
-  fga_dev_release(dev,SLOT_SORT0,buf0); fga_dev_release(dev,SLOT_SORT1,buf1);
+  fga_pool_free(dimg); fga_pool_free(dboff); fga_pool_free(dclen); fga_pool_free(dinvp); fga_pool_free(ditems); fga_pool_free(dcount); fga_pool_free(dctr);
+  fga_pool_free(dpartid);
+  fga_pool_free(dmoff); fga_pool_free(dmbeg); fga_pool_free(dmend); fga_pool_free(dperm);
+  fga_dev_release(dev,SLOT_SORT0,buf0);
   free(perm); free(invp);
   if (status != 0)
-    { if (D != NULL) { fga_dgix_free_views(D); hipFree(D->table); hipFree(D->index); free(D); }
+    { if (D != NULL) { fga_dgix_free_views(D); fga_pool_free(D->table); fga_pool_free(D->index); free(D); }
       if (X != NULL) fga_gix_close(X);
       return 1;
     }

@@ -836,11 +836,11 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
     }
   else
     { const int64_t nb = (S->phys_capacity + FGA_SEED_BLOCK-1) / FGA_SEED_BLOCK + 2;
-      if ((err = hipMalloc(&counters,12*sizeof(unsigned long long))) != hipSuccess ||
+      if ((err = fga_dmalloc(&counters,12*sizeof(unsigned long long))) != hipSuccess ||
           (S->seeds = (fga_seed *) fga_dev_acquire(dev,SLOT_SEEDS,sizeof(fga_seed)*(size_t) S->phys_capacity)) == NULL ||
           (S->valid = (uint16_t *) fga_dev_acquire(dev,SLOT_VALID,sizeof(uint16_t)*(size_t) nb)) == NULL)
         { fga_set_error("fga_seed_merge: device allocation failed: %s",hipGetErrorString(err));
-          hipFree(counters); fga_dev_release(dev,SLOT_SEEDS,S->seeds); free(S);
+          fga_pool_free(counters); fga_dev_release(dev,SLOT_SEEDS,S->seeds); free(S);
           return 1;
         }
       S->slot = SLOT_SEEDS;
@@ -858,7 +858,7 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
         (err = hipStreamSynchronize(dev->stream)) != hipSuccess)        // `cold` is on this stack frame
       { fga_set_error("fga_seed_merge: upload failed: %s",hipGetErrorString(err));
         if (append == NULL)
-          { hipFree(counters); fga_dev_release(dev,SLOT_SEEDS,S->seeds); fga_dev_release(dev,SLOT_VALID,S->valid); free(S); }
+          { fga_pool_free(counters); fga_dev_release(dev,SLOT_SEEDS,S->seeds); fga_dev_release(dev,SLOT_VALID,S->valid); free(S); }
         return 1;
       }
     A.cold = (const merge_cold *) (counters+8);
@@ -979,7 +979,7 @@ done:
   fga_dev_release(dev,SLOT_TILES,work);
   if (rc != 0)
     { if (append == NULL)
-        { hipFree(counters); fga_dev_release(dev,SLOT_SEEDS,S->seeds); fga_dev_release(dev,SLOT_VALID,S->valid); free(S); }
+        { fga_pool_free(counters); fga_dev_release(dev,SLOT_SEEDS,S->seeds); fga_dev_release(dev,SLOT_VALID,S->valid); free(S); }
       return 1;
     }
   if (out != NULL) *out = S;

@@ -199,10 +199,10 @@ extern "C" int fga_seeds_import(fga_dev *dev, const void *const *src_device, con
   S->dev = dev; S->capacity = S->phys_capacity = total + 16; S->count = S->phys_count = total; S->tseed = 0;
   S->seeds = (fga_seed *) fga_dev_acquire(dev,SLOT_SEEDS,sizeof(fga_seed)*(size_t) S->phys_capacity);
   S->slot = SLOT_SEEDS;
-  hipError_t e = hipMalloc(&S->dcount,4*sizeof(unsigned long long));
+  hipError_t e = fga_dmalloc(&S->dcount,4*sizeof(unsigned long long));
   if (S->seeds == NULL || e != hipSuccess)
     { fga_set_error("fga_seeds_import: device allocation failed");
-      fga_dev_release(dev,SLOT_SEEDS,S->seeds); hipFree(S->dcount); free(S);
+      fga_dev_release(dev,SLOT_SEEDS,S->seeds); fga_pool_free(S->dcount); free(S);
       return 1;
     }
   { unsigned long long hc[4] = { (unsigned long long) total, 0ull, 0ull, 0ull };

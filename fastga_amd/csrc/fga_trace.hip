@@ -457,18 +457,18 @@ extern "C" int fga_trace_pts(fga_dev *dev, const fga_dgenome *GA, const fga_dgen
   const size_t tbbytes = (size_t) (alns->ntrace > 0 ? alns->ntrace : 1);
 
 #define TRY(call) do { if ((e = (call)) != hipSuccess) goto fail; } while (0)
-  TRY(hipMalloc(&d_alns,sizeof(fga_aln)*n));
-  TRY(hipMalloc(&d_tb,tbbytes+16));
-  TRY(hipMalloc(&d_need,sizeof(int64_t)*2*n));
-  TRY(hipMalloc(&d_pbase,sizeof(int64_t)*(n+1)));
-  TRY(hipMalloc(&d_rbase,sizeof(int64_t)*(n+1)));
-  TRY(hipMalloc(&d_sbase,sizeof(int64_t)*(n+1)));
-  TRY(hipMalloc(&d_toff,sizeof(int64_t)*(n+1)));
-  TRY(hipMalloc(&d_atlen,sizeof(int32_t)*n));
-  TRY(hipMalloc(&d_adiffs,sizeof(int32_t)*n));
-  TRY(hipMalloc(&d_astat,sizeof(int32_t)*n));
-  TRY(hipMalloc(&d_pcnt,sizeof(int32_t)*npan));
-  TRY(hipMalloc(&d_pdiff,sizeof(int32_t)*npan));
+  TRY(fga_dmalloc(&d_alns,sizeof(fga_aln)*n));
+  TRY(fga_dmalloc(&d_tb,tbbytes+16));
+  TRY(fga_dmalloc(&d_need,sizeof(int64_t)*2*n));
+  TRY(fga_dmalloc(&d_pbase,sizeof(int64_t)*(n+1)));
+  TRY(fga_dmalloc(&d_rbase,sizeof(int64_t)*(n+1)));
+  TRY(fga_dmalloc(&d_sbase,sizeof(int64_t)*(n+1)));
+  TRY(fga_dmalloc(&d_toff,sizeof(int64_t)*(n+1)));
+  TRY(fga_dmalloc(&d_atlen,sizeof(int32_t)*n));
+  TRY(fga_dmalloc(&d_adiffs,sizeof(int32_t)*n));
+  TRY(fga_dmalloc(&d_astat,sizeof(int32_t)*n));
+  TRY(fga_dmalloc(&d_pcnt,sizeof(int32_t)*npan));
+  TRY(fga_dmalloc(&d_pdiff,sizeof(int32_t)*npan));
   TRY(hipMemcpyAsync(d_alns,alns->alns,sizeof(fga_aln)*n,hipMemcpyHostToDevice,dev->stream));
   if (alns->ntrace > 0)
     TRY(hipMemcpyAsync(d_tb,alns->tbytes,alns->ntrace,hipMemcpyHostToDevice,dev->stream));
@@ -492,7 +492,7 @@ extern "C" int fga_trace_pts(fga_dev *dev, const fga_dgenome *GA, const fga_dgen
     rbase[n] = r; sbase[n] = s;
     rawtot = r;
   }
-  TRY(hipMalloc(&d_raw,sizeof(int32_t)*(rawtot+1)));
+  TRY(fga_dmalloc(&d_raw,sizeof(int32_t)*(rawtot+1)));
   TRY(hipMemcpyAsync(d_rbase,rbase.data(),sizeof(int64_t)*(n+1),hipMemcpyHostToDevice,dev->stream));
   TRY(hipMemcpyAsync(d_sbase,sbase.data(),sizeof(int64_t)*(n+1),hipMemcpyHostToDevice,dev->stream));
   T.raw = d_raw;
@@ -507,8 +507,8 @@ extern "C" int fga_trace_pts(fga_dev *dev, const fga_dgenome *GA, const fga_dgen
         if (sbase[j]-sbase[i] > maxcells) maxcells = sbase[j]-sbase[i];
         i = j;
       }
-    TRY(hipMalloc(&d_cells,sizeof(uint16_t)*(maxcells+1)));
-    TRY(hipMalloc(&d_panels,sizeof(trace_panel)*npan));
+    TRY(fga_dmalloc(&d_cells,sizeof(uint16_t)*(maxcells+1)));
+    TRY(fga_dmalloc(&d_panels,sizeof(trace_panel)*npan));
     T.cells = d_cells;
     for (size_t b = 0; b+1 < cut.size(); b++)
       { T.a0 = cut[b]; T.a1 = cut[b+1];
@@ -533,7 +533,7 @@ extern "C" int fga_trace_pts(fga_dev *dev, const fga_dgenome *GA, const fga_dgen
   TRY(hipMemcpyAsync(R->toff,d_toff,sizeof(int64_t)*(n+1),hipMemcpyDeviceToHost,dev->stream));
   TRY(hipStreamSynchronize(dev->stream));
   total = R->toff[n];
-  TRY(hipMalloc(&d_dense,sizeof(int32_t)*(total+1)));
+  TRY(fga_dmalloc(&d_dense,sizeof(int32_t)*(total+1)));
   T.dense = d_dense;
   hipLaunchKernelGGL(trace_pack_kernel,dim3((unsigned) n),dim3(64),0,dev->stream,T);
   hipEventRecord(dev->ev1,dev->stream);
@@ -566,9 +566,9 @@ extern "C" int fga_trace_pts(fga_dev *dev, const fga_dgenome *GA, const fga_dgen
 fail:
   fga_set_error("fga_trace_pts: %s",hipGetErrorString(e));
 done:
-  hipFree(d_alns); hipFree(d_tb); hipFree(d_need); hipFree(d_pbase); hipFree(d_rbase); hipFree(d_sbase);
-  hipFree(d_toff); hipFree(d_atlen); hipFree(d_adiffs); hipFree(d_astat); hipFree(d_pcnt); hipFree(d_pdiff);
-  hipFree(d_raw); hipFree(d_dense); hipFree(d_panels); hipFree(d_cells);
+  fga_pool_free(d_alns); fga_pool_free(d_tb); fga_pool_free(d_need); fga_pool_free(d_pbase); fga_pool_free(d_rbase); fga_pool_free(d_sbase);
+  fga_pool_free(d_toff); fga_pool_free(d_atlen); fga_pool_free(d_adiffs); fga_pool_free(d_astat); fga_pool_free(d_pcnt); fga_pool_free(d_pdiff);
+  fga_pool_free(d_raw); fga_pool_free(d_dense); fga_pool_free(d_panels); fga_pool_free(d_cells);
   if (rc != 0)
     { fga_traces_free(R);
       return 1;

@@ -145,7 +145,7 @@ void view_fwd_index_kernel(fga_view V, fga_view F, uint32_t signbit, const int64
 }
 
 static void view_free(fga_view *V)
-{ hipFree(V->K); hipFree(V->L); hipFree(V->M); hipFree(V->P); hipFree(V->C); hipFree(V->idx);
+{ fga_pool_free(V->K); fga_pool_free(V->L); fga_pool_free(V->M); fga_pool_free(V->P); fga_pool_free(V->C); fga_pool_free(V->idx);
   memset(V,0,sizeof(*V));
 }
 
@@ -155,10 +155,10 @@ static int view_alloc(fga_view *V, int64_t n, int cont, int want_l)
   V->cw = cont <= 1 ? 1 : (cont == 2 ? 2 : 4);
   const size_t m = (size_t) n + 256;                 // windows are loaded in 16-byte pieces from 4-entry aligned starts
   hipError_t e;
-  if ((e = hipMalloc(&V->K,8*m)) != hipSuccess || (want_l && (e = hipMalloc(&V->L,m)) != hipSuccess) ||
-      (e = hipMalloc(&V->M,m)) != hipSuccess || (e = hipMalloc(&V->P,4*m)) != hipSuccess ||
-      (e = hipMalloc(&V->C,(size_t) V->cw*m)) != hipSuccess ||
-      (e = hipMalloc(&V->idx,sizeof(uint32_t)*(size_t) FGA_NPREFIX)) != hipSuccess)
+  if ((e = fga_dmalloc(&V->K,8*m)) != hipSuccess || (want_l && (e = fga_dmalloc(&V->L,m)) != hipSuccess) ||
+      (e = fga_dmalloc(&V->M,m)) != hipSuccess || (e = fga_dmalloc(&V->P,4*m)) != hipSuccess ||
+      (e = fga_dmalloc(&V->C,(size_t) V->cw*m)) != hipSuccess ||
+      (e = fga_dmalloc(&V->idx,sizeof(uint32_t)*(size_t) FGA_NPREFIX)) != hipSuccess)
     { fga_set_error("device allocation of a table view (%lld entries) failed: %s",(long long) n,hipGetErrorString(e));
       view_free(V);
       return 1;
@@ -195,7 +195,7 @@ int fga_dgix_make_view(fga_dev *dev, fga_dgix *D, int keep_table)
     }
   fga_note("view: repack kernel",t0); t0 = fga_wall();
   if (!keep_table)
-    { hipFree(D->table);
+    { fga_pool_free(D->table);
       D->table = NULL;
       fga_note("view: on-disk bytes freed",t0);
     }
@@ -220,9 +220,9 @@ int fga_dgix_make_forward(fga_dev *dev, fga_dgix *D)
   int64_t nf = 0;
   fga_view F;
   memset(&F,0,sizeof(F));
-  if ((e = hipMalloc(&dcnt,sizeof(uint32_t)*(size_t) (nblk+1))) != hipSuccess ||
-      (e = hipMalloc(&dsub,sizeof(uint16_t)*16*(size_t) (nblk+1))) != hipSuccess ||
-      (e = hipMalloc(&doff,sizeof(int64_t)*(size_t) (nblk+1))) != hipSuccess)
+  if ((e = fga_dmalloc(&dcnt,sizeof(uint32_t)*(size_t) (nblk+1))) != hipSuccess ||
+      (e = fga_dmalloc(&dsub,sizeof(uint16_t)*16*(size_t) (nblk+1))) != hipSuccess ||
+      (e = fga_dmalloc(&doff,sizeof(int64_t)*(size_t) (nblk+1))) != hipSuccess)
     { fga_set_error("forward view: device allocation failed: %s",hipGetErrorString(e));
       goto done;
     }
@@ -256,7 +256,7 @@ int fga_dgix_make_forward(fga_dev *dev, fga_dgix *D)
   fga_note("forward view",tf0);
   rc = 0;
 done:
-  hipFree(dcnt); hipFree(dsub); hipFree(doff);
+  fga_pool_free(dcnt); fga_pool_free(dsub); fga_pool_free(doff);
   if (rc) view_free(&F);
   return rc;
 }
