@@ -106,10 +106,10 @@ int      fga_gix_write_files(const fga_gix *X, const char *target);
 
 /* device context internals the host pipeline uses (fga_device.hip) */
 struct fga_dev;
-void   fga_dev_trim(struct fga_dev *dev);          /* idle workspace slots back to the device        */
+void   fga_dev_trim(struct fga_dev *dev);          /* unused regions of the device pool back to the driver */
 void  *fga_dev_stage_acquire(struct fga_dev *dev, size_t bytes);   /* the per-part staging buffer of a multi-pass run (a workspace slot) */
 void   fga_dev_stage_release(struct fga_dev *dev, void *ptr);
-size_t fga_dev_available(struct fga_dev *dev);     /* free device memory + what the idle slots hold  */
+size_t fga_dev_available(struct fga_dev *dev);     /* free device memory + the pool's free pieces    */
 
 void   fga_note(const char *what, double since);   /* FGA_TIMING=1: elapsed wall time since `since` on stderr */
 

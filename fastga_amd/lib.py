@@ -145,6 +145,8 @@ def _declare(L):
         "fga_dev_free": (None, [vp, vp]),
         "fga_dev_download": (i32, [vp, vp, vp, C.c_size_t]),
         "fga_dev_peak_bytes": (i64, [vp]),
+        "fga_dev_trim": (None, [vp]),
+        "fga_dev_available": (C.c_size_t, [vp]),
         "fga_dev_set_host_threads": (None, [vp, i32]),
         "fga_dgix_build": (i32, [vp, vp, i32, i32, P(vp), P(vp)]),
         "fga_gix_write_files": (i32, [vp, cp]),

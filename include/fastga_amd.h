@@ -94,6 +94,12 @@ void  fga_dev_free(fga_dev *dev, void *ptr);
 int   fga_dev_download(fga_dev *dev, void *host_dst, const void *device_src, size_t bytes);
 int   fga_dev_upload(fga_dev *dev, void *device_dst, const void *host_src, size_t bytes);
 int64_t fga_dev_peak_bytes(fga_dev *dev);   /* peak device memory in use by this process so far (stage-boundary samples) */
+/* Device memory of a MiB and more is cut from regions the library keeps for reuse (allocation and release of tens of GB
+   through the driver cost seconds).  fga_dev_trim gives the regions nobody uses back to the driver -- call it before another
+   library of the process (an RCCL / torch allocator) needs the room; fga_dev_available = free device memory + what the
+   library's free pieces hold. */
+void    fga_dev_trim(fga_dev *dev);
+size_t  fga_dev_available(fga_dev *dev);
 void    fga_dev_set_host_threads(fga_dev *dev, int nthreads);   /* threads for the host tails of the device stages (unit
                                                                    order, hit re-lay, work order of the extension); default 1 */
 
