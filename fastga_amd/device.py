@@ -442,6 +442,10 @@ class Session:
         check(self.L.fga_dev_malloc(self.L.fga_session_device(self.h), max(int(nbytes), 16), C.byref(p)), "device malloc")
         return p.value
 
+    def trim(self):
+        """fga_dev_trim: regions of the device pool that nothing uses go back to the driver"""
+        self.L.fga_dev_trim(self.L.fga_session_device(self.h))
+
     def dev_free(self, ptr):
         self.L.fga_dev_free(self.L.fga_session_device(self.h), C.c_void_p(ptr))
 

@@ -148,7 +148,7 @@ def run_sharded(ses, dist, prm_kwargs, device):
             else torch.zeros((0, 4), dtype=torch.int32)
         ses.dev_free(sbuf)
     else:
-        send = torch.empty((max(n, 1), 4), dtype=torch.int32, device=device)
+        send = _torch_empty(ses, torch, (max(n, 1), 4), device)
         off = ses.split_to(seeds, select, world, send.data_ptr())
     seeds.free()
     in_splits = np.diff(off).astype(np.int64)
@@ -157,7 +157,7 @@ def run_sharded(ses, dist, prm_kwargs, device):
     dist.all_to_all_single(t_out, t_in)
     out_splits = t_out.cpu().numpy()
     total = int(out_splits.sum())
-    recv = torch.empty((max(total, 1), 4), dtype=torch.int32, device=device)
+    recv = _torch_empty(ses, torch, (max(total, 1), 4), device)
     dist.all_to_all_single(recv[:total], send[:n], output_split_sizes=out_splits.tolist(),
                            input_split_sizes=in_splits.tolist())
     if host:
@@ -188,6 +188,16 @@ def run_sharded(ses, dist, prm_kwargs, device):
     d["part_seeds"] = total
     d["out_path"] = out_path if rank == 0 else None
     return d
+
+
+def _torch_empty(ses, torch, shape, device):
+    """an int32 exchange buffer from torch's allocator; when the device is full of regions the library keeps for reuse,
+    those nobody uses go back to the driver first (fga_dev_trim) and the allocation is tried once more"""
+    try:
+        return torch.empty(shape, dtype=torch.int32, device=device)
+    except RuntimeError:
+        ses.trim()
+        return torch.empty(shape, dtype=torch.int32, device=device)
 
 
 def prefix_cuts(ses, nshards):
