@@ -136,9 +136,13 @@ hipError_t fga_pool_malloc(void **out, size_t bytes)
 
 hipError_t fga_pool_free(void *ptr)
 { if (ptr == NULL) return hipSuccess;
-  pool_state *P = pool_here();
-  if (P != NULL)
-    { std::unique_lock<std::mutex> lock(P->mu);
+  // the pool of the calling thread's device first, then the others (a pointer is a piece of at most one)
+  pool_state *here = pool_here();
+  for (int d = -1; d < POOL_MAXDEV; d++)
+    { pool_state *P = d < 0 ? here : &g_pool[d];
+      if (P == NULL || (d >= 0 && P == here))
+        continue;
+      std::unique_lock<std::mutex> lock(P->mu);
       for (size_t k = 0; k < P->pieces.size(); k++)
         if (P->pieces[k].ptr == (char *) ptr && P->pieces[k].busy)
           { lock.unlock();
