@@ -61,6 +61,13 @@ typedef struct
     int64_t sC, sG;                           /* per-S maxima                    */
   } skel_stats;
 
+/* threads the record formatters use: 8 unless the caller's thread has asked for another number (the pipeline passes its
+ * -T); the bytes written do not depend on it (contiguous record ranges, concatenated in order) */
+#define WRITER_MAXT 64
+static __thread int writer_threads = 8;
+void fga_aln_writer_threads(int n)
+{ writer_threads = n < 1 ? 1 : (n > WRITER_MAXT ? WRITER_MAXT : n); }
+
 static void skeleton_stats(const fga_gdb *G, skel_stats *st)
 { int s, c;
   int64_t nC = 0, nG = 0, tS = 0;
@@ -252,9 +259,9 @@ int fga_write_1aln(const char *path, const fga_gdb *g1, const fga_gdb *g2, const
 
   { /* the record body dominates the file: records are formatted by hand, in parallel (contiguous record ranges
        into per-thread buffers sized from the trace lengths), and written in order */
-    int nth = 8, t;
-    fmt_job  job[8];
-    pthread_t th[8];
+    int nth = writer_threads, t;
+    fmt_job  job[WRITER_MAXT];
+    pthread_t th[WRITER_MAXT];
     long nc = sysconf(_SC_NPROCESSORS_ONLN);
     if (nc > 0 && nc < nth) nth = (int) nc;
     if (totT < 200000) nth = 1;
@@ -590,9 +597,9 @@ int fga_write_1aln_binary(const char *path, const fga_gdb *g1, const fga_gdb *g2
   char date[64], *cwd;
   time_t t = time(NULL);
   bbuf H, B, F;
-  int nth = 8, q, rc = 1;
-  bin_job job[8];
-  pthread_t th[8];
+  int nth = writer_threads, q, rc = 1;
+  bin_job job[WRITER_MAXT];
+  pthread_t th[WRITER_MAXT];
   wcodec ct, cx;
 
   memset(&H,0,sizeof(H)); memset(&B,0,sizeof(B)); memset(&F,0,sizeof(F));

@@ -111,6 +111,7 @@ void  *fga_dev_stage_acquire(struct fga_dev *dev, size_t bytes);   /* the per-pa
 void   fga_dev_stage_release(struct fga_dev *dev, void *ptr);
 size_t fga_dev_available(struct fga_dev *dev);     /* free device memory + the pool's free pieces    */
 
+void   fga_aln_writer_threads(int n);              /* threads of the .1aln record formatters, for the calling thread (default 8) */
 void   fga_note(const char *what, double since);   /* FGA_TIMING=1: elapsed wall time since `since` on stderr */
 
 /* small helpers */

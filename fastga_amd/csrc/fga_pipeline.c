@@ -451,6 +451,7 @@ static int finish_output(fga_session *Z, const fga_run_params *P, const fga_alns
       int rc;
       if (asprintf(&n1,"%s",g1->path) < 0) n1 = NULL;
       if (!self && asprintf(&n2,"%s",g2->path) < 0) n2 = NULL;
+      fga_aln_writer_threads(P->nthreads > 8 ? P->nthreads : 8);
       /* the binary ONEcode container, like the reference; FGA_ALN_ASCII=1 selects the text form */
       if (getenv("FGA_ALN_ASCII") != NULL && atoi(getenv("FGA_ALN_ASCII")) != 0)
         rc = fga_write_1aln(P->out_path,g1,self ? NULL : g2,fin,100,n1 ? n1 : "genome1",n2,cmd);
