@@ -39,6 +39,16 @@ enum { MODE_PAIR = 0, MODE_FLIP = 1, MODE_SELF = 2 };
 #define XPC             128                  // prefixes per tile at most (two index entries per lane)
 #define EWIN            1024                 // slots per emission window (descriptor dwords in the key array)
 #ifndef WAVE_OCC
+// The words the wavefronts of a launch update with atomics live 256 bytes apart: atomics on ONE cache line are served one
+// after the other, ~88 per microsecond for the whole chip (MI355X_MICROARCH.md), whichever words of the line they name.
+// Until this was measured the slot counter, the statistics and the eight queue heads shared one 64-byte line: 90,000
+// atomics per launch on the 100 Mbp pair = 1.0 of its 1.25 ms.  (In 8-byte / 4-byte units:)
+#define CTR_COUNT   0                        // slots handed out
+#define CTR_STATS   32                       // sum of plen, slots left unused
+#define CTR_QUEUE   64                       // queue head k at CTR_QUEUE + 32 k
+#define CTR_COLD    320                      // the end-of-kernel arguments (read only)
+#define CTR_WORDS   384
+#define QSTRIDE     64                       // ints between two queue heads
 #define WAVE_OCC        4                    // resident wavefronts per SIMD the register budget is held to
 #endif
 #ifndef RANGES_PER_WAVE
@@ -584,13 +594,13 @@ void seed_merge_walk_kernel(merge_args A)
   const int shard = (int) (blockIdx.x & 7);
   int knext = 0;
   if (lane == 0)
-    knext = atomicAdd(A.next + shard,1);
+    knext = atomicAdd(A.next + QSTRIDE*shard,1);
   for (;;)
     { const int r = shard + 8*__builtin_amdgcn_readfirstlane(knext);
       if (r >= A.nranges)
         break;
       if (lane == 0)
-        knext = atomicAdd(A.next + shard,1);
+        knext = atomicAdd(A.next + QSTRIDE*shard,1);
       int p = (int) A.cuts[r];
       const int pe = (int) A.cuts[r+1];
       if (p >= pe)
@@ -836,7 +846,7 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
     }
   else
     { const int64_t nb = (S->phys_capacity + FGA_SEED_BLOCK-1) / FGA_SEED_BLOCK + 2;
-      if ((err = fga_dmalloc(&counters,12*sizeof(unsigned long long))) != hipSuccess ||
+      if ((err = fga_dmalloc(&counters,CTR_WORDS*sizeof(unsigned long long))) != hipSuccess ||
           (S->seeds = (fga_seed *) fga_dev_acquire(dev,SLOT_SEEDS,sizeof(fga_seed)*(size_t) S->phys_capacity)) == NULL ||
           (S->valid = (uint16_t *) fga_dev_acquire(dev,SLOT_VALID,sizeof(uint16_t)*(size_t) nb)) == NULL)
         { fga_set_error("fga_seed_merge: device allocation failed: %s",hipGetErrorString(err));
@@ -845,23 +855,23 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
         }
       S->slot = SLOT_SEEDS;
       S->dcount = (int64_t *) counters;
-      hipMemsetAsync(counters,0,8*sizeof(unsigned long long),dev->stream);
+      hipMemsetAsync(counters,0,CTR_WORDS*sizeof(unsigned long long),dev->stream);
       hipMemsetD16Async((hipDeviceptr_t) S->valid,(unsigned short) FGA_SEED_BLOCK,(size_t) nb,dev->stream);
     }
   A.out = S->seeds; A.cap = phys;
   A.count = counters;
   { merge_cold cold;                                   // what the wavefronts read once, at their end: behind the counters
-    cold.tseed = counters+1; cold.hslots = counters+2;
+    cold.tseed = counters+CTR_STATS; cold.hslots = counters+CTR_STATS+1;
     cold.valid = S->valid; cold.nblocks = (S->phys_capacity + FGA_SEED_BLOCK-1) / FGA_SEED_BLOCK + 2;
-    static_assert(sizeof(merge_cold) <= 4*sizeof(unsigned long long),"cold arguments live in counters[8..11]");
-    if ((err = hipMemcpyAsync(counters+8,&cold,sizeof(cold),hipMemcpyHostToDevice,dev->stream)) != hipSuccess ||
+    static_assert(sizeof(merge_cold) <= (CTR_WORDS-CTR_COLD)*sizeof(unsigned long long),"cold arguments live behind the counters");
+    if ((err = hipMemcpyAsync(counters+CTR_COLD,&cold,sizeof(cold),hipMemcpyHostToDevice,dev->stream)) != hipSuccess ||
         (err = hipStreamSynchronize(dev->stream)) != hipSuccess)        // `cold` is on this stack frame
       { fga_set_error("fga_seed_merge: upload failed: %s",hipGetErrorString(err));
         if (append == NULL)
           { fga_pool_free(counters); fga_dev_release(dev,SLOT_SEEDS,S->seeds); fga_dev_release(dev,SLOT_VALID,S->valid); free(S); }
         return 1;
       }
-    A.cold = (const merge_cold *) (counters+8);
+    A.cold = (const merge_cold *) (counters+CTR_COLD);
   }
 
   int rc = 1;
@@ -902,9 +912,9 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
           goto done;
         }
       int64_t *cuts = (int64_t *) work;
-      int *qhead = (int *) (counters + 4);
+      int *qhead = (int *) (counters + CTR_QUEUE);
       A.cuts = cuts; A.nranges = nranges; A.next = qhead;
-      hipMemsetAsync(qhead,0,8*sizeof(int),dev->stream);
+      hipMemsetAsync(qhead,0,8*QSTRIDE*sizeof(int),dev->stream);
       hipEventRecord(dev->ev0,dev->stream);
       hipLaunchKernelGGL(range_cut_kernel,dim3((nranges+1+255)/256),dim3(256),0,dev->stream,
                          A.idx1,A.idx2,pbeg,pend,base,total,nranges,nbig,cuts);
@@ -914,19 +924,19 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
       hipEventRecord(ev2,dev->stream);
     }
   // one round trip: the three counters
-  { unsigned long long *pin = (unsigned long long *) fga_dev_pinned(dev,sizeof(unsigned long long)*8);
+  { unsigned long long *pin = (unsigned long long *) fga_dev_pinned(dev,sizeof(unsigned long long)*(CTR_STATS+2));
     if (pin == NULL)
       { fga_set_error("fga_seed_merge: pinned staging allocation failed");
         goto done;
       }
-    err = hipMemcpyAsync(pin,counters,3*sizeof(unsigned long long),hipMemcpyDeviceToHost,dev->stream);
+    err = hipMemcpyAsync(pin,counters,(CTR_STATS+2)*sizeof(unsigned long long),hipMemcpyDeviceToHost,dev->stream);
     if (err == hipSuccess) err = hipStreamSynchronize(dev->stream);
     if (err == hipSuccess) err = hipGetLastError();
     if (err != hipSuccess)
       { fga_set_error("fga_seed_merge: kernel failed: %s",hipGetErrorString(err));
         goto done;
       }
-    hc[0] = pin[0]; hc[1] = pin[1]; hc[2] = pin[2];
+    hc[0] = pin[CTR_COUNT]; hc[1] = pin[CTR_STATS]; hc[2] = pin[CTR_STATS+1];
     hslots = (int64_t) hc[2];
   }
   if (!empty)
