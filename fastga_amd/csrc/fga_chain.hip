@@ -145,9 +145,8 @@ __device__ int scan_sequential(const chain_args &G, const unit_info &U, fga_hit 
   return nh;
 }
 
-__device__ __forceinline__ void publish_unit(const chain_args &G, const unit_info &U, int64_t first, int nh)
-{ const unsigned long long u = atomicAdd(G.ctr+1,1ull);
-  if ((int64_t) u < G.unit_cap)
+__device__ __forceinline__ void store_unit(const chain_args &G, const unit_info &U, int64_t first, int nh, unsigned long long u)
+{ if ((int64_t) u < G.unit_cap)
     { fga_unit R;
       R.actg = U.actg; R.bctg = U.bctg; R.comp = U.comp; R.nhits = nh;
       R.first_hit = first; R.bucket = U.cdiag;
@@ -156,63 +155,94 @@ __device__ __forceinline__ void publish_unit(const chain_args &G, const unit_inf
     }
 }
 
+__device__ __forceinline__ void publish_unit(const chain_args &G, const unit_info &U, int64_t first, int nh)
+{ store_unit(G,U,first,nh,atomicAdd(G.ctr+1,1ull)); }
+
+// One thread per bucket head.  The hit and unit slots of a wavefront's threads come from ONE atomic each (the threads'
+// hit counts are scanned across the wavefront): the two counters share a cache line, atomics on a line are served one
+// after the other (~88 per microsecond for the whole chip), and with one pair of atomics per unit this kernel took
+// exactly that long -- 22 ms for the 1.01 M units of the 150 Mbp self comparison, 84 ms at 3 Gbp.
 __global__ __launch_bounds__(256)
 void chain_small_kernel(chain_args G)
 { const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= G.n)
-    return;
-  const u128 ki = key_at(G,i);
-  const u128 Ui = ki >> G.s_buck;
-  const uint64_t dmask = (1ull << G.wd) - 1;
-  bool head = true, prevadj = false;
-  if (i > 0)
-    { const u128 Up = key_at(G,i-1) >> G.s_buck;
-      head = (Up != Ui);
-      prevadj = (Up + 1 == Ui) && (((uint64_t) Ui & dmask) != 0);
-    }
-  if (!head)
-    return;
-
+  const int lane = (int) (threadIdx.x & 63);
   unit_info U;
-  U.b = i; U.isnew = !prevadj;
-  const int64_t lim = G.small_limit;
-  int64_t bound = 2*key_lcp(ki);                   // sum of 2 lcp over the unit: an upper bound of any chain's cov
-  int64_t m = i+1;
-  while (m < G.n && m-i <= lim)
-    { const u128 k = key_at(G,m);
-      if ((k >> G.s_buck) != Ui) break;
-      bound += 2*key_lcp(k);
-      m += 1;
-    }
-  int64_t e = m;
-  if (m-i <= lim && ((uint64_t) Ui & dmask) != dmask)
-    { const u128 Un = Ui + 1;
-      while (e < G.n && e-i <= lim)
-        { const u128 k = key_at(G,e);
-          if ((k >> G.s_buck) != Un) break;
-          bound += 2*key_lcp(k);
-          e += 1;
+  int nh = 0;
+  bool live = i < G.n;
+  u128 ki = 0;
+  if (live)
+    { ki = key_at(G,i);
+      const u128 Ui = ki >> G.s_buck;
+      const uint64_t dmask = (1ull << G.wd) - 1;
+      bool head = true, prevadj = false;
+      if (i > 0)
+        { const u128 Up = key_at(G,i-1) >> G.s_buck;
+          head = (Up != Ui);
+          prevadj = (Up + 1 == Ui) && (((uint64_t) Ui & dmask) != 0);
+        }
+      live = head;
+      if (live)
+        { U.b = i; U.isnew = !prevadj;
+          const int64_t lim = G.small_limit;
+          int64_t bound = 2*key_lcp(ki);                   // sum of 2 lcp over the unit: an upper bound of any chain's cov
+          int64_t m = i+1;
+          while (m < G.n && m-i <= lim)
+            { const u128 k = key_at(G,m);
+              if ((k >> G.s_buck) != Ui) break;
+              bound += 2*key_lcp(k);
+              m += 1;
+            }
+          int64_t e = m;
+          if (m-i <= lim && ((uint64_t) Ui & dmask) != dmask)
+            { const u128 Un = Ui + 1;
+              while (e < G.n && e-i <= lim)
+                { const u128 k = key_at(G,e);
+                  if ((k >> G.s_buck) != Un) break;
+                  bound += 2*key_lcp(k);
+                  e += 1;
+                }
+            }
+          if (e-i > lim)                                   // a long unit: one wavefront will take it
+            { const unsigned long long q = atomicAdd(G.ctr+2,1ull);
+              if ((int64_t) q < G.big_cap)
+                G.bigq[q] = i;
+              live = false;
+            }
+          else
+            { U.m = m; U.e = e; U.aux = (e > m);
+              if ((!U.isnew && !U.aux) || bound < G.cmin)
+                live = false;
+            }
         }
     }
-  if (e-i > lim)                                   // a long unit: one wavefront will take it
-    { const unsigned long long q = atomicAdd(G.ctr+2,1ull);
-      if ((int64_t) q < G.big_cap)
-        G.bigq[q] = i;
-      return;
+  if (live)
+    { unit_coords(G,ki,U);
+      nh = scan_sequential<false>(G,U,NULL);
     }
-  U.m = m; U.e = e; U.aux = (e > m);
-  if (!U.isnew && !U.aux)
+  // slots for the wavefront's units and hits (every lane is here)
+  const uint64_t em = __ballot(nh > 0);
+  if (em == 0)
     return;
-  if (bound < G.cmin)
-    return;
-  unit_coords(G,ki,U);
-  const int nh = scan_sequential<false>(G,U,NULL);
+  int incl = nh;
+  #pragma unroll
+  for (int d = 1; d < 64; d <<= 1)
+    { const int t = __shfl_up(incl,d,64);
+      if (lane >= d) incl += t;
+    }
+  const int total = __shfl(incl,63,64);
+  unsigned long long hbase = 0, ubase = 0;
+  if (lane == 0)
+    { hbase = atomicAdd(G.ctr+0,(unsigned long long) total);
+      ubase = atomicAdd(G.ctr+1,(unsigned long long) __popcll(em));
+    }
+  hbase = ((unsigned long long) (uint32_t) __shfl((int) (uint32_t) (hbase >> 32),0,64) << 32) | (uint32_t) __shfl((int) (uint32_t) hbase,0,64);
+  ubase = ((unsigned long long) (uint32_t) __shfl((int) (uint32_t) (ubase >> 32),0,64) << 32) | (uint32_t) __shfl((int) (uint32_t) ubase,0,64);
   if (nh == 0)
     return;
-  const int64_t first = (int64_t) atomicAdd(G.ctr+0,(unsigned long long) nh);
+  const int64_t first = (int64_t) hbase + (incl - nh);
   if (first + nh <= G.hit_cap)
     scan_sequential<true>(G,U,G.hits + first);
-  publish_unit(G,U,first,nh);
+  store_unit(G,U,first,nh,ubase + (unsigned long long) __popcll(em & ((1ull << lane) - 1)));
 }
 
 // ---------------------------------------------------------------------------------------------------
