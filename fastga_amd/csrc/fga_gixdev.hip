@@ -17,7 +17,7 @@
 //   gix_entries_kernel   one thread per sorted key: lcp with its predecessor (0 at a part start), on-disk entry bytes
 #include "fga_device.hpp"
 
-#define GCH   2048            // positions per workgroup
+#define GCH   2048            // positions per chunk
 #define GNT   256
 #define GPER  (GCH/GNT)
 
@@ -53,12 +53,18 @@ void gix_scan_kernel(gix_scan_args A)
   __shared__ unsigned long long gbase;
 
   const int tid = threadIdx.x;
-  const gix_item it = A.items[blockIdx.x];
+  for (int x = tid; x < 1024; x += GNT)
+    sh[x] = 0;
+  // A workgroup takes chunks in a stride and adds its sample histogram to the global one ONCE, at its end: a chunk holds
+  // syncmers of ~600 of the 1024 sample buckets, and with one workgroup per chunk a 3 Gbp genome made 9 * 10^8 atomics on
+  // the 128 cache lines of that histogram -- atomics on one line are served one after the other (~88 per microsecond).
+  for (int item = blockIdx.x; item < A.nitems; item += gridDim.x)
+  {
+  __syncthreads();                            // the arrays of the chunk before are done with (and sh[] is cleared)
+  const gix_item it = A.items[item];
   const int c = it.ctg, j0 = it.j0;
   const int64_t len = A.clen[c];
   const uint8_t *img = A.img + A.boff[c];
-  for (int x = tid; x < 1024; x += GNT)
-    sh[x] = 0;
   for (int x = tid; x < GCH + 96; x += GNT)
     { const int64_t b = (int64_t) j0 - 28 + x;
       uint8_t v = 4;
@@ -134,11 +140,7 @@ void gix_scan_kernel(gix_scan_args A)
   __syncthreads();
   int64_t at = (int64_t) gbase + base;
   if (A.keys == NULL)                               // count only: the sample histogram is all that is left to do
-    { for (int x = tid; x < 1024; x += GNT)
-        if (sh[x] != 0)
-          atomicAdd(A.sbuck + x,(unsigned long long) sh[x]);
-      return;
-    }
+    continue;
 
   const uint64_t ctg = (uint64_t) A.invp[c];
   const uint64_t sign = 0x80ull << (8*(A.contbytes-1));
@@ -169,6 +171,7 @@ void gix_scan_kernel(gix_scan_args A)
           at += 1;
         }
     }
+  }
   __syncthreads();
   for (int x = tid; x < 1024; x += GNT)
     if (sh[x] != 0)
@@ -332,6 +335,7 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
   uint32_t *dcount = NULL;
   unsigned long long *dctr = NULL;       // [0] keys, [1..1024] sbuck, then 4096 chunk sums, then maxpre
   uint4 *buf0 = NULL, *buf1 = NULL, *sorted = NULL;
+  unsigned scan_grid = 1;                  // workgroups of the scan kernel (each takes chunks in a stride)
   std::vector<gix_item> items;
   std::vector<int64_t> boff((size_t) G->ncontig), clen((size_t) G->ncontig);
   int64_t cap = 0, nkeys = 0;
@@ -395,13 +399,15 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
 
   tn = fga_wall();
   hipEventRecord(dev->ev0,dev->stream);
+  scan_grid = (unsigned) (items.size() < (size_t) dev->ncu*8 ? items.size() : (size_t) dev->ncu*8);
+  if (scan_grid < 1) scan_grid = 1;
   { gix_scan_args A;
     A.img = dimg; A.boff = dboff; A.clen = dclen; A.invp = dinvp;
     A.items = ditems; A.nitems = (int) items.size();
     A.postbytes = postbytes; A.contbytes = contbytes;
     A.keys = buf0; A.cap = cap; A.nkeys = dctr; A.count = dcount; A.sbuck = dctr + 1;
     A.pbeg = (uint32_t) pbeg; A.pend = (uint32_t) pend;
-    hipLaunchKernelGGL(gix_scan_kernel,dim3((unsigned) items.size()),dim3(GNT),0,dev->stream,A);
+    hipLaunchKernelGGL(gix_scan_kernel,dim3(scan_grid),dim3(GNT),0,dev->stream,A);
   }
   if (count_only)
     { if ((e = hipMemcpyAsync(counts_host,dcount,sizeof(uint32_t)*FGA_NPREFIX,hipMemcpyDeviceToHost,dev->stream)) != hipSuccess ||
@@ -437,7 +443,7 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
         A2.postbytes = postbytes; A2.contbytes = contbytes;
         A2.keys = buf0; A2.cap = cap; A2.nkeys = dctr; A2.count = dcount; A2.sbuck = dctr + 1;
         A2.pbeg = (uint32_t) pbeg; A2.pend = (uint32_t) pend;
-        hipLaunchKernelGGL(gix_scan_kernel,dim3((unsigned) items.size()),dim3(GNT),0,dev->stream,A2);
+        hipLaunchKernelGGL(gix_scan_kernel,dim3(scan_grid),dim3(GNT),0,dev->stream,A2);
         if ((e = hipMemcpyAsync(hk,dctr,sizeof(hk),hipMemcpyDeviceToHost,dev->stream)) != hipSuccess ||
             (e = hipStreamSynchronize(dev->stream)) != hipSuccess)
           { fga_set_error("fga_dgix_build: scan kernel failed: %s",hipGetErrorString(e));
