@@ -35,7 +35,12 @@
 
 enum { MODE_PAIR = 0, MODE_FLIP = 1, MODE_SELF = 2 };
 
+#ifndef T1CAP
 #define T1CAP           256                  // table-1 entries per tile: four rounds of one entry per lane
+#endif
+#ifndef T2STD
+#define T2STD           512                  // table-2 entries per tile / window of the standard build
+#endif
 #define XPC             128                  // prefixes per tile at most (two index entries per lane)
 #define EWIN            1024                 // slots per emission window (descriptor dwords in the key array)
 #ifndef WAVE_OCC
@@ -292,65 +297,43 @@ __device__ __forceinline__ void match_rounds(const merge_args &A, const uint64_t
   if (__builtin_amdgcn_ballot_w64(kb[0] + kc[0] + bd[0] + bu[0] == 0x1234567) != 0) tsum += 1;     // the reads have landed
 #endif
   XPROF(9)
-  // run growth on the table's own lcp bytes.  The first step of either direction is decided on the bytes read above; the
-  // further steps of all rounds and both directions go side by side (one LDS round trip per step, not one per round and
-  // direction).  Upwards the cutoff is measured from the lower bound, not from the run's start (which the downward growth
-  // is still looking for): a run that ends earlier on the tighter measure has reached the cutoff either way.
-  int low[NR], hgh[NR], pl[NR];
-  bool okr[NR], cd[NR], cu[NR];
-  bool grow = false;
+  total = 0;
   #pragma unroll
   for (int r = 0; r < NR; r++)
     { const int c = r*64 + lane;
       const bool act = c < na;
-      const int lbnd = base[r];
-      low[r] = lbnd; hgh[r] = (MODE == MODE_SELF) ? lbnd + 1 : lbnd;
+      const int i = (MODE == MODE_SELF) ? base[r] : c;
+      int low, hgh, lbnd;
+      if (MODE == MODE_SELF) { low = i; hgh = i+1; lbnd = i; }
+      else                   { low = hgh = lbnd = base[r]; }
       const bool hasb = nb[r] >= pb0[r], hasa = na_[r] < pb1[r];
       const int lkb = hasb ? lcp_key(ks[r],kb[r]) : 0, lka = hasa ? lcp_key(ks[r],kc[r]) : 0;
       const int plen = lkb > lka ? lkb : lka;                      // 0: no T2 entry of this panel next to the key
-      pl[r] = plen;
-      okr[r] = act && plen >= 12;
-      const bool gd = okr[r] && lkb >= plen;
-      low[r] -= gd ? 1 : 0;
-      cd[r] = gd && low[r] > pb0[r] && lbnd-low[r] <= freq && bd[r] >= plen;
-      low[r] -= cd[r] ? 1 : 0;
-      cd[r] = cd[r] && low[r] > pb0[r] && lbnd-low[r] <= freq;
-      const bool gu = okr[r] && lka >= plen && hgh[r] < pb1[r];
-      hgh[r] += gu ? 1 : 0;
-      cu[r] = gu && hgh[r] < pb1[r] && hgh[r]-lbnd <= freq && bu[r] >= plen;
-      hgh[r] += cu[r] ? 1 : 0;
-      cu[r] = cu[r] && hgh[r] < pb1[r] && hgh[r]-lbnd <= freq;
-      grow = grow || cd[r] || cu[r];
-    }
-  while (__builtin_amdgcn_ballot_w64(grow) != 0)
-    { int vd[NR], vu[NR];
-      #pragma unroll
-      for (int r = 0; r < NR; r++)
-        { vd[r] = (int) lcpB[low[r]]; vu[r] = (int) lcpB[hgh[r]]; }            // read by every lane (in range either way)
-      grow = false;
-      #pragma unroll
-      for (int r = 0; r < NR; r++)
-        { const bool d = cd[r] & (vd[r] >= pl[r]), u = cu[r] & (vu[r] >= pl[r]);
-          low[r] -= d ? 1 : 0; hgh[r] += u ? 1 : 0;
-          cd[r] = d & (low[r] > pb0[r]) & (base[r]-low[r] <= freq);
-          cu[r] = u & (hgh[r] < pb1[r]) & (hgh[r]-base[r] <= freq);
-          grow = grow || cd[r] || cu[r];
+      const bool ok = act && plen >= 12;
+      // run growth on the table's own lcp bytes; the first step of either direction is decided on the bytes read above
+      const bool gd = ok && lkb >= plen;
+      low -= gd ? 1 : 0;
+      if (gd && low > pb0[r] && lbnd-low <= freq && bd[r] >= plen)
+        { low -= 1;
+          while (low > pb0[r] && lbnd-low <= freq && (int) lcpB[low] >= plen)
+            low -= 1;
         }
-    }
-  total = 0;
-  #pragma unroll
-  for (int r = 0; r < NR; r++)
-    { const int i = (MODE == MODE_SELF) ? base[r] : r*64 + lane;
-      const int plen = pl[r];
+      const bool gu = ok && lka >= plen && hgh < pb1[r] && hgh-low <= freq;
+      hgh += gu ? 1 : 0;
+      if (gu && hgh < pb1[r] && hgh-low <= freq && bu[r] >= plen)
+        { hgh += 1;
+          while (hgh < pb1[r] && hgh-low <= freq && (int) lcpB[hgh] >= plen)
+            hgh += 1;
+        }
       const int mlen = A.soft_mask ? plen : 41;
-      bool pass = okr[r] && hgh[r]-low[r] < freq;
+      bool pass = ok && hgh-low < freq;
       if (A.soft_mask)
         pass = pass && (int) (MODE == MODE_SELF ? mB[i] : mA[i]) < mlen;
       int cnt;
       if (MODE == MODE_FLIP || A.soft_mask)
         { cnt = 0;
           if (pass)
-            for (int j = low[r]; j < hgh[r]; j++)
+            for (int j = low; j < hgh; j++)
               { if (A.soft_mask && (int) mB[j] >= mlen)
                   continue;
                 if (MODE == MODE_FLIP && (lds_c(cB,A.cw2,j) & A.sign2))
@@ -361,8 +344,8 @@ __device__ __forceinline__ void match_rounds(const merge_args &A, const uint64_t
               }
         }
       else
-        cnt = pass ? (hgh[r]-low[r]) - (MODE == MODE_SELF ? 1 : 0) : 0;
-      res[r] = (pass && cnt > 0) ? ((uint32_t) (MODE == MODE_SELF ? i - low[r] : i) | ((uint32_t) low[r] << 8) | ((uint32_t) plen << 18) | ((uint32_t) cnt << 24)) : 0u;
+        cnt = pass ? (hgh-low) - (MODE == MODE_SELF ? 1 : 0) : 0;
+      res[r] = (pass && cnt > 0) ? ((uint32_t) (MODE == MODE_SELF ? i - low : i) | ((uint32_t) low << 8) | ((uint32_t) plen << 18) | ((uint32_t) cnt << 24)) : 0u;
       total += cnt;
       tsum += (unsigned long long) cnt * plen;
     }
@@ -572,7 +555,7 @@ __device__ __forceinline__ int walk_tile(const merge_args &A, tile_lds<T2CAP> &S
 }
 
 template <int MODE, int T2CAP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(T2CAP == 512 ? WAVE_OCC : 2,T2CAP == 512 ? WAVE_OCC : 2)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(T2CAP == T2STD ? WAVE_OCC : 2,T2CAP == T2STD ? WAVE_OCC : 2)))
 void seed_merge_walk_kernel(merge_args A)
 { __shared__ __attribute__((aligned(16))) tile_lds<T2CAP> S;
   extern __shared__ __attribute__((aligned(16))) uint8_t cdyn[];     // contig|sign words of both sides: (T2CAP+32) cw2 + (T1CAP+32) cw1 bytes
@@ -883,12 +866,12 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
   dev->last_ms[FGA_STAGE_MERGE] = dev->last_ms[FGA_STAGE_MERGE_PARTITION] = 0.f;
   if (!empty)
     { // the sub-tile margin FREQ+2 must leave room in a window: the wide-window build takes over for large cutoffs
-      const bool wide = 2*(prm->freq + 2) > 512 - 128;
-      const int t2cap = wide ? 1024 : 512;
+      const bool wide = 2*(prm->freq + 2) > T2STD - 128;
+      const int t2cap = wide ? 1024 : T2STD;
       const size_t dyn = (size_t) (t2cap + 32)*A.cw2 + (size_t) (T1CAP + 32)*A.cw1 + 16;
       // every wavefront of the launch is resident (they are persistent): as many as the LDS of a CU holds, at most the
       // register budget's
-      const size_t lds = ((wide ? sizeof(tile_lds<1024>) : sizeof(tile_lds<512>)) + dyn + 2047) / 2048 * 2048;
+      const size_t lds = ((wide ? sizeof(tile_lds<1024>) : sizeof(tile_lds<T2STD>)) + dyn + 2047) / 2048 * 2048;
       int per_cu = (int) ((160*1024) / lds) - 1;       // measured: 13 x 11.6 KB are not all resident
       const int fit = per_cu;
       const int occ = wide ? 8 : 12;                   // measured: 10-12 at 100 Mbp (8: -7 %), 12-13 at 3 Gbp
@@ -899,6 +882,10 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
       int grid = dev->ncu * per_cu;
       // ranges off the queues: two big ones per wavefront over the first five eighths of the cost, six small ones over the rest
       int nbig = grid*2, nranges = grid*8;
+      { const char *e1 = getenv("FGA_MERGE_NR"), *e2 = getenv("FGA_MERGE_NBIG");          // experiments: ranges per wavefront
+        if (e1 != NULL && atoi(e1) >= 2 && atoi(e1) <= 64) nranges = grid*atoi(e1);
+        if (e2 != NULL && atoi(e2) >= 1 && atoi(e2) < nranges/grid) nbig = grid*atoi(e2);
+      }
       if ((int64_t) nranges > total/2048 + 1)
         { nranges = (int) (total/2048) + 1; nbig = nranges/4; }
       if (nbig < 1) { nbig = 1; if (nranges < 2) nranges = 2; }
@@ -920,7 +907,7 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
                          A.idx1,A.idx2,pbeg,pend,base,total,nranges,nbig,cuts);
       hipEventRecord(dev->ev1,dev->stream);
       if (wide) launch_walk<1024>(mode,grid,dyn,dev->stream,A);
-      else      launch_walk<512>(mode,grid,dyn,dev->stream,A);
+      else      launch_walk<T2STD>(mode,grid,dyn,dev->stream,A);
       hipEventRecord(ev2,dev->stream);
     }
   // one round trip: the three counters
