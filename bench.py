@@ -167,9 +167,10 @@ def main():
         step()
     barrier()
     t = time.time()
-    stats = []
+    stats, cut_ms = [], []
     for _ in range(args.steps):
         stats.append(step())
+        cut_ms.append(ses.dev_wrapper().stage_ms(0))      # FGA_STAGE_MERGE_PARTITION: range_cut_kernel of the step's merge launch
     barrier()
     elapsed = time.time() - t
 
@@ -235,7 +236,11 @@ def main():
             "roofline": {"kernel": "seed merge launch (HIP events around fga_seed_merge's kernels on the library's stream)",
                          "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes": int(alg_bytes // max(1, world)), "kernel_ms": kavg},
+                         "traffic": None, "algorithmic_bytes": int(alg_bytes // max(1, world)), "kernel_ms": kavg,
+                         # the walk kernel alone (the launch less its range_cut_kernel): what the rocprofv3 per-kernel average
+                         # of seed_merge_walk_kernel corresponds to
+                         "walk_kernel_ms": kavg - sum(cut_ms) / len(cut_ms),
+                         "walk_kernel_frac": (alg_bytes / max(1, world)) / ((kavg - sum(cut_ms) / len(cut_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "extend": {"kernel": "extend_kernel", "bound": "latency (one wavefront per unit; longest unit's serial chain)",
                        "kernel_ms": kext, "algorithmic_bytes": int(b_ext),
                        "achieved_GBps": b_ext / (kext * 1e-3) / 1e9 if kext > 0 else None,
@@ -364,13 +369,16 @@ def pmc_traffic():
         return None, None
     fetch = write = None
     commit = ""
-    for r in csv.DictReader(ln for ln in open(files[-1]) if not ln.startswith("#")):
-        k = r["kernel"]
+    for row in csv.reader(ln for ln in open(files[-1]) if not ln.startswith("#")):
+        if len(row) < 5 or row[0] == "pass":
+            continue
+        # pass, kernel, counter, launches, avg_per_launch -- a template kernel's name holds commas of its own
+        k, counter, avg = ",".join(row[1:-3]), row[-3], row[-1]
         if "seed_merge" in k or "range_cut" in k:
-            if r["counter"] == "FETCH_SIZE":
-                fetch = (fetch or 0.0) + float(r["avg_per_launch"])
-            elif r["counter"] == "WRITE_SIZE":
-                write = (write or 0.0) + float(r["avg_per_launch"])
+            if counter == "FETCH_SIZE":
+                fetch = (fetch or 0.0) + float(avg)
+            elif counter == "WRITE_SIZE":
+                write = (write or 0.0) + float(avg)
     for ln in open(files[-1]):
         if ln.startswith("# commit"):
             commit = ln.split(":", 1)[1].strip()

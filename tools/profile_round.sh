@@ -39,7 +39,8 @@ with open(dst, "w") as f:
     f.write("# commit: %s\n" % (sys.argv[3] if len(sys.argv) > 3 else "unknown"))
     f.write("# command: bench.py --steps 5 --warmup 2 --no-cpu --no-cold --no-human-scale under rocprofv3 --pmc <counters> (one pass per counter group)\n")
     f.write("pass,kernel,counter,launches,avg_per_launch\n")
+    w = csv.writer(f, lineterminator="\n")               # (a template kernel's name holds commas: quoted)
     for r in rows:
-        f.write("%s,%s,%s,%d,%.6g\n" % r)
+        w.writerow([r[0], r[1], r[2], r[3], "%.6g" % r[4]])
 print(open(dst).read())
 PY
