@@ -35,9 +35,9 @@ extern "C" int fga_dev_open(int device, fga_dev **out)
 // ---------------------------------------------------------------------------------------------------
 // device memory: a pool of regions
 // ---------------------------------------------------------------------------------------------------
-// hipMalloc of tens of GB is not free: memory the process (or an earlier one) has used before is cleared by the driver when
-// it is handed out again -- 20-27 ms per GB measured (a 54 GB buffer: 1.0-1.5 s; 64 GB after the hipFree of another: 3.2 s),
-// 0.4 ms for memory that was never touched.  A 3 Gbp comparison allocates ~330 GB over its life (index staging, on-disk
+// hipMalloc of tens of GB is not free: 10-28 ms per GB on most boxes and processes (a 54 GB buffer: 1.0-1.5 s; 64 GB after
+// the hipFree of another buffer: 3.2 s; its hipFree: 1.7 s), 0.4 ms on others -- which one a process gets could not be
+// predicted.  A 3 Gbp comparison allocates ~330 GB over its life (index staging, on-disk
 // bytes, views, seeds, sort buffers, trace-point pool) and holds at most ~250 at a time, so every byte that is REUSED
 // instead of freed and allocated again saves that time.  All device memory of a MiB and more therefore comes from regions
 // this process keeps: a request takes the smallest free piece that holds it (split, the rest stays free), a release merges
@@ -46,37 +46,43 @@ extern "C" int fga_dev_open(int device, fga_dev **out)
 // Like hipFree, releasing a piece waits for the device: the piece may be handed out again at once, to a copy on another
 // stream.
 #include <mutex>
+#include "fga_pool.hpp"
 #define POOL_MIN    ((size_t) 1 << 20)
 #define POOL_ALIGN  ((size_t) 2 << 20)
 #define POOL_MAXDEV 16
-struct pool_piece { char *ptr; size_t bytes; int region; bool busy; };
-struct pool_region { char *base; size_t bytes; };
 struct pool_state
-  { std::vector<pool_piece>  pieces;          // by (region, address): the pieces of a region tile it
-    std::vector<pool_region> regions;         // slot r stays r while the region lives (base NULL: slot free)
+  { fga_pool_core core;                       // pieces and regions (fga_pool.hpp: also run on the host by the tests)
     std::mutex mu;
   };
 static pool_state g_pool[POOL_MAXDEV];
+
+static int pool_hip_alloc(void **out, size_t bytes)
+{ const double t0 = fga_wall();
+  if (hipMalloc(out,bytes) != hipSuccess)
+    { (void) hipGetLastError();
+      *out = NULL;
+      return 1;
+    }
+  if (bytes >= ((size_t) 1 << 30))
+    { char what[64];
+      snprintf(what,sizeof(what),"hipMalloc %.1f GB",bytes*1e-9);
+      fga_note(what,t0);
+    }
+  return 0;
+}
+
+static void pool_hip_release(void *ptr)
+{ const double t0 = fga_wall();
+  hipFree(ptr);
+  fga_note("hipFree of an idle region",t0);
+}
+
+static const fga_pool_backend pool_hip = { pool_hip_alloc, pool_hip_release };
 
 static pool_state *pool_here(void)
 { int d = 0;
   if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= POOL_MAXDEV) return NULL;
   return &g_pool[d];
-}
-
-static void pool_trim_locked(pool_state *P)
-{ for (size_t k = 0; k < P->pieces.size(); )
-    { const pool_piece &q = P->pieces[k];
-      if (!q.busy && q.ptr == P->regions[q.region].base && q.bytes == P->regions[q.region].bytes)
-        { const double t0 = fga_wall();
-          hipFree(q.ptr);
-          if (q.bytes >= ((size_t) 1 << 30)) fga_note("hipFree of an idle region",t0);
-          P->regions[q.region].base = NULL; P->regions[q.region].bytes = 0;
-          P->pieces.erase(P->pieces.begin() + (long) k);
-        }
-      else
-        k += 1;
-    }
 }
 
 hipError_t fga_pool_malloc(void **out, size_t bytes)
@@ -87,51 +93,9 @@ hipError_t fga_pool_malloc(void **out, size_t bytes)
     return hipMalloc(out,bytes);
   const size_t need = (bytes + POOL_ALIGN-1) / POOL_ALIGN * POOL_ALIGN;
   std::lock_guard<std::mutex> lock(P->mu);
-  long best = -1;
-  for (size_t k = 0; k < P->pieces.size(); k++)
-    if (!P->pieces[k].busy && P->pieces[k].bytes >= need && (best < 0 || P->pieces[k].bytes < P->pieces[(size_t) best].bytes))
-      best = (long) k;
-  if (best >= 0)
-    { pool_piece &q = P->pieces[(size_t) best];
-      const size_t rest = q.bytes - need;
-      q.busy = true; q.bytes = need;
-      *out = q.ptr;
-      if (rest > 0)
-        { pool_piece r = { q.ptr + need, rest, q.region, false };
-          P->pieces.insert(P->pieces.begin() + best + 1,r);
-        }
-      return hipSuccess;
-    }
-  void *p = NULL;
-  const double t0 = fga_wall();
-  hipError_t e = hipMalloc(&p,need);
-  if (e != hipSuccess)
-    { (void) hipGetLastError();
-      pool_trim_locked(P);                      // regions nobody uses go back, then once more
-      e = hipMalloc(&p,need);
-      if (e != hipSuccess)
-        { (void) hipGetLastError();
-          return e;
-        }
-    }
-  if (need >= ((size_t) 1 << 30))
-    { char what[64];
-      snprintf(what,sizeof(what),"hipMalloc %.1f GB",need*1e-9);
-      fga_note(what,t0);
-    }
-  int r = -1;
-  for (size_t k = 0; k < P->regions.size(); k++)
-    if (P->regions[k].base == NULL) { r = (int) k; break; }
-  if (r < 0) { r = (int) P->regions.size(); P->regions.push_back(pool_region()); }
-  P->regions[(size_t) r].base = (char *) p; P->regions[(size_t) r].bytes = need;
-  // pieces are kept by (region, address): a new region's piece goes behind the pieces of the regions before it
-  size_t at = P->pieces.size();
-  for (size_t k = 0; k < P->pieces.size(); k++)
-    if (P->pieces[k].region > r) { at = k; break; }
-  pool_piece q = { (char *) p, need, r, true };
-  P->pieces.insert(P->pieces.begin() + (long) at,q);
-  *out = p;
-  return hipSuccess;
+  bool fresh;
+  *out = P->core.take(need,pool_hip,&fresh);
+  return *out != NULL ? hipSuccess : hipErrorOutOfMemory;
 }
 
 hipError_t fga_pool_free(void *ptr)
@@ -143,27 +107,13 @@ hipError_t fga_pool_free(void *ptr)
       if (P == NULL || (d >= 0 && P == here))
         continue;
       std::unique_lock<std::mutex> lock(P->mu);
-      for (size_t k = 0; k < P->pieces.size(); k++)
-        if (P->pieces[k].ptr == (char *) ptr && P->pieces[k].busy)
-          { lock.unlock();
-            (void) hipDeviceSynchronize();        // what hipFree does: nothing in flight refers to the piece any more
-            lock.lock();
-            for (k = 0; k < P->pieces.size(); k++)          // (the list may have changed while unlocked)
-              if (P->pieces[k].ptr == (char *) ptr && P->pieces[k].busy)
-                break;
-            if (k == P->pieces.size())
-              return hipSuccess;
-            P->pieces[k].busy = false;
-            if (k+1 < P->pieces.size() && !P->pieces[k+1].busy && P->pieces[k+1].region == P->pieces[k].region)
-              { P->pieces[k].bytes += P->pieces[k+1].bytes;
-                P->pieces.erase(P->pieces.begin() + (long) k + 1);
-              }
-            if (k > 0 && !P->pieces[k-1].busy && P->pieces[k-1].region == P->pieces[k].region)
-              { P->pieces[k-1].bytes += P->pieces[k].bytes;
-                P->pieces.erase(P->pieces.begin() + (long) k);
-              }
-            return hipSuccess;
-          }
+      if (!P->core.holds(ptr))
+        continue;
+      lock.unlock();
+      (void) hipDeviceSynchronize();            // what hipFree does: nothing in flight refers to the piece any more
+      lock.lock();
+      P->core.give(ptr);                        // (false if another thread released it meanwhile: nothing to do)
+      return hipSuccess;
     }
   return hipFree(ptr);
 }
@@ -174,11 +124,7 @@ static void pool_idle(size_t *total, size_t *largest)
   pool_state *P = pool_here();
   if (P == NULL) return;
   std::lock_guard<std::mutex> lock(P->mu);
-  for (const pool_piece &q : P->pieces)
-    if (!q.busy)
-      { *total += q.bytes;
-        if (q.bytes > *largest) *largest = q.bytes;
-      }
+  P->core.idle(total,largest);
 }
 
 // the regions nobody uses go back to the device (another library in the process -- torch's exchange buffers -- may need them)
@@ -187,7 +133,7 @@ extern "C" void fga_dev_trim(fga_dev *dev)
   pool_state *P = pool_here();
   if (P == NULL) return;
   std::lock_guard<std::mutex> lock(P->mu);
-  pool_trim_locked(P);
+  P->core.trim(pool_hip);
 }
 
 // device memory an allocation could get right now: free memory + what the pool's free pieces hold
