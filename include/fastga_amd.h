@@ -155,6 +155,10 @@ void    fga_keys_layout(const fga_dkeys *keys, int *wa, int *wb, int *wd, int *w
 int     fga_keys_download(const fga_dkeys *keys, void *host /* 16 B per key: lo64, hi64 */, int64_t max);
 const void *fga_keys_download_pinned(const fga_dkeys *keys);  /* into the device context's pinned staging buffer */
 void    fga_keys_free(fga_dkeys *keys);
+/* rmsd_sort (RSDsort.c:292) on records that already sit in HBM: n 128-bit little-endian records in the device buffer
+ * buf0, ordered ascending on bits [lowbit, lowbit+nbits) -- stable, LSD radix --, buf1 = scratch of the same size; *sorted
+ * is whichever of the two holds the result.  Enqueued on the context's stream and synchronised before return. */
+int     fga_dev_radix_sort_u128(fga_dev *dev, void *buf0, void *buf1, int64_t n, int lowbit, int nbits, void **sorted);
 
 /* ---- chain detection: replaces the chain scan of align_contigs (FastGA.c:3016-3176, 3340-3403) ------------ */
 typedef struct
