@@ -341,7 +341,6 @@ void os_pass_kernel(const void *in, uint4 *out, int64_t n, int shift, int next_s
         { key[r] = load_key<FROM_SEEDS>(in,i,L);
           d = digit_of(key[r],shift);
         }
-#ifndef OS_NO_RANK
       uint64_t peers = __ballot(ok);
       #pragma unroll
       for (int b = 0; b < 8; b++)
@@ -355,10 +354,6 @@ void os_pass_kernel(const void *in, uint4 *out, int64_t n, int shift, int next_s
       rank[r] = (uint16_t) (basec + before);
       if (ok && (peers >> lane) >> 1 == 0)
         wcnt[wave][d] = basec + before + 1;
-#else
-      rank[r] = 0;
-      if (ok && lane == (r & 63)) wcnt[wave][d] = 1;
-#endif
     }
   __syncthreads();
   // thread d: the tile's count of digit d, published; per-wave bases; look-back over the earlier tiles
@@ -373,9 +368,6 @@ void os_pass_kernel(const void *in, uint4 *out, int64_t n, int shift, int next_s
     if (tile > 0)
       __hip_atomic_store(mine,OS_PACK(stamp,OS_LOCAL,run),__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
     unsigned long long excl = 0;
-#ifdef OS_NO_WAIT
-    excl = (unsigned long long) tile * run;
-#else
     for (int t = tile-1; t >= 0; t--)
       { const unsigned long long *p = status + (size_t) t*256 + tid;
         unsigned long long sv = __hip_atomic_load(p,__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
@@ -387,7 +379,6 @@ void os_pass_kernel(const void *in, uint4 *out, int64_t n, int shift, int next_s
         if (OS_STATE(sv) == OS_INCL)
           break;
       }
-#endif
     __hip_atomic_store(mine,OS_PACK(stamp,OS_INCL,excl + run),__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
     dbase[tid] = gbase[tid] + excl;
   }
@@ -397,22 +388,10 @@ void os_pass_kernel(const void *in, uint4 *out, int64_t n, int shift, int next_s
     { const int64_t i = wbase + r*64 + lane;
       if (i < n && r*64 + lane < vcount)
         { const uint32_t d = digit_of(key[r],shift);
-          int64_t pos = (int64_t) dbase[d] + wcnt[wave][d] + rank[r];
-#if defined(OS_NO_WAIT) || defined(OS_NO_RANK)
-          if (pos >= n) pos = n-1;
-#endif
-#ifdef OS_FAKE_RUN     // timing experiment: runs of OS_FAKE_RUN consecutive keys go to pseudo-random places (OS_FAKE_OFF: not aligned)
-          { const uint64_t g = (uint64_t) i / OS_FAKE_RUN, nr = (uint64_t) n / OS_FAKE_RUN - 2;
-            uint64_t hsh = g * 0x9e3779b97f4a7c15ull; hsh ^= hsh >> 29; hsh *= 0xbf58476d1ce4e5b9ull; hsh ^= hsh >> 32;
-            pos = (int64_t) ((hsh % nr) * OS_FAKE_RUN + (uint64_t) i % OS_FAKE_RUN) + OS_FAKE_OFF;
-          }
-#endif
+          const int64_t pos = (int64_t) dbase[d] + wcnt[wave][d] + rank[r];
           uint4 v;
           v.x = (uint32_t) key[r].lo; v.y = (uint32_t) (key[r].lo >> 32);
           v.z = (uint32_t) key[r].hi; v.w = (uint32_t) (key[r].hi >> 32);
-#ifdef OS_NO_STORE
-          if (pos == -12345)
-#endif
           out[pos] = v;
           if (next_hist != NULL)
             atomicAdd(&nh[digit_of(key[r],next_shift)],1u);
@@ -423,626 +402,6 @@ void os_pass_kernel(const void *in, uint4 *out, int64_t n, int shift, int next_s
       if (nh[tid] != 0)
         atomicAdd(next_hist + tid,(unsigned long long) nh[tid]);
     }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// One-sweep passes, round 4: the prefix over the tiles is made by ONE scanner workgroup instead of a look-back by every
-// tile.  What bounded the look-back version (1.0-2.0 TB/s per pass): a tile walked back through its predecessors one
-// dependent agent-scope load (0.7-2 us under load) at a time, the tiles that started just before it were still in their
-// own walk, so a tile lived ~130 us for ~25 us of data movement.  Here
-//   * the workgroup that draws ticket 0 is the scanner: lane d of it keeps the running count of digit d, publishes the
-//     exclusive prefix of tile t (EXCL[t][d], one 8-byte word {stamp | value}), then adds tile t's count (LOCAL[t][d], one
-//     4-byte word {stamp | count}), U tiles' counts requested at once;
-//   * a tile publishes its 2^RB digit counts and polls its OWN prefix words: two hand-offs instead of a walk;
-//   * tiles are NT/64 seed blocks (NT = 512: 8192 keys), digits RB bits wide.
-// Forward progress: tickets are drawn in start order, so the scanner and every earlier tile are resident when a tile
-// waits; a tile's counts depend on nothing.
-// ---------------------------------------------------------------------------------------------------
-#define OS2_PACKL(stamp,cnt)   (((uint32_t) (stamp) << 24) | (uint32_t) (cnt))
-#define OS2_PACKX(stamp,val)   (((unsigned long long) (stamp) << 56) | (unsigned long long) (val))
-
-__device__ __forceinline__ uint32_t digit_rb(const u128 &k, int shift, uint32_t mask)
-{ if (shift >= 64)
-    return (uint32_t) (k.hi >> (shift-64)) & mask;
-  uint64_t v = k.lo >> shift;
-  if (shift > 48)
-    v |= k.hi << (64-shift);
-  return (uint32_t) v & mask;
-}
-
-template <int NT, int RB, bool FROM_SEEDS>
-__global__ __launch_bounds__(NT)
-void os2_pass_kernel(const void *in, uint4 *out, int64_t n, int shift, int next_shift, key_layout L, int stamp,
-                     const unsigned long long *gbase, unsigned long long *status,
-                     unsigned long long *next_hist, unsigned int *ticket, const uint16_t *valid)
-{ constexpr int NW = NT/64, ND = 1 << RB, TILE = NT*OS_ITEMS;
-  constexpr uint32_t DM = ND-1;
-  __shared__ uint16_t wcnt[NW][ND];           // per-wave digit counts (<= 1024), then per-wave digit bases inside the tile
-  __shared__ unsigned long long dbase[ND];    // where the tile's keys of every digit start in `out`
-  __shared__ uint32_t nh[ND];                 // digits of the next pass among the keys written
-  __shared__ int tile_s;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0)
-#ifdef OS_NO_TICKET
-    tile_s = blockIdx.x;
-#else
-    tile_s = (int) atomicAdd(ticket,1u);
-#endif
-  static_assert(NT*OS_ITEMS <= 65536,"tile positions are 16-bit");
-  for (int x = tid; x < NW*ND/2; x += NT)
-    ((uint32_t *) &wcnt[0][0])[x] = 0;
-  for (int x = tid; x < ND; x += NT)
-    nh[x] = 0;
-  __syncthreads();
-  const int tile = tile_s;
-
-  const int64_t wbase = (int64_t) tile * TILE + (int64_t) wave * (64*OS_ITEMS);
-  const int vcount = (FROM_SEEDS && valid != NULL && wbase < n) ? (int) valid[wbase >> 10] : 64*OS_ITEMS;
-  u128     key[OS_ITEMS];
-  uint16_t rank[OS_ITEMS];
-  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64-lane));
-  #pragma unroll
-  for (int r = 0; r < OS_ITEMS; r++)
-    { const int64_t i = wbase + r*64 + lane;
-      const bool ok = i < n && r*64 + lane < vcount;
-      uint32_t d = ND;
-      if (ok)
-        { key[r] = load_key<FROM_SEEDS>(in,i,L);
-          d = digit_rb(key[r],shift,DM);
-        }
-#ifndef OS_NO_RANK
-      uint64_t peers = __ballot(ok);
-      #pragma unroll
-      for (int b = 0; b < RB; b++)
-        { const uint64_t m = __ballot((d >> b) & 1);
-          peers &= ((d >> b) & 1) ? m : ~m;
-        }
-      const uint32_t before = __popcll(peers & lt);
-      uint32_t basec = 0;
-      if (ok)
-        basec = wcnt[wave][d];
-      rank[r] = (uint16_t) (basec + before);
-      if (ok && (peers >> lane) >> 1 == 0)
-        wcnt[wave][d] = (uint16_t) (basec + before + 1);
-#else
-      rank[r] = 0;
-      if (ok && lane == (r & 63)) wcnt[wave][d] = 1;
-#endif
-    }
-  __syncthreads();
-  // thread d: the tile's count of digit d, published; per-wave bases; look-back over the earlier tiles
-  for (int d = tid; d < ND; d += NT)
-    { uint32_t run = 0;
-      #pragma unroll
-      for (int w = 0; w < NW; w++)
-        { const uint32_t c = wcnt[w][d];
-          wcnt[w][d] = (uint16_t) run;
-          run += c;
-        }
-      unsigned long long *mine = status + (size_t) tile*ND + d;
-#ifndef OS_NO_STATUS
-      if (tile > 0)
-        __hip_atomic_store(mine,OS_PACK(stamp,OS_LOCAL,run),__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
-#endif
-      unsigned long long excl = 0;
-#ifdef OS_NO_WAIT
-      excl = (unsigned long long) tile * run;
-#else
-      for (int t = tile-1; t >= 0; t--)
-        { const unsigned long long *p = status + (size_t) t*ND + d;
-          unsigned long long sv = __hip_atomic_load(p,__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
-          while (OS_STAMP(sv) != stamp || OS_STATE(sv) == 0)
-            { __builtin_amdgcn_s_sleep(1);
-              sv = __hip_atomic_load(p,__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
-            }
-          excl += OS_VALUE(sv);
-          if (OS_STATE(sv) == OS_INCL)
-            break;
-        }
-#endif
-#ifndef OS_NO_STATUS
-      __hip_atomic_store(mine,OS_PACK(stamp,OS_INCL,excl + run),__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
-#endif
-      dbase[d] = gbase[d] + excl;
-    }
-  __syncthreads();
-  #pragma unroll
-  for (int r = 0; r < OS_ITEMS; r++)
-    { const int64_t i = wbase + r*64 + lane;
-      if (i < n && r*64 + lane < vcount)
-        { const uint32_t d = digit_rb(key[r],shift,DM);
-          int64_t pos = (int64_t) dbase[d] + wcnt[wave][d] + rank[r];
-#if defined(OS_NO_WAIT) || defined(OS_NO_RANK)
-          if (pos >= n) pos = n-1;
-#endif
-          uint4 v;
-          v.x = (uint32_t) key[r].lo; v.y = (uint32_t) (key[r].lo >> 32);
-          v.z = (uint32_t) key[r].hi; v.w = (uint32_t) (key[r].hi >> 32);
-#ifndef OS_NO_STORE
-          out[pos] = v;
-#else
-          if (pos == -12345) out[0] = v;
-#endif
-#ifndef OS_NO_NHIST
-          if (next_hist != NULL)
-            atomicAdd(&nh[digit_rb(key[r],next_shift,DM)],1u);
-#endif
-        }
-    }
-#ifdef OS_NO_NHIST
-  if (next_hist == (unsigned long long *) 8)
-#else
-  if (next_hist != NULL)
-#endif
-    { __syncthreads();
-      for (int d = tid; d < ND; d += NT)
-        if (nh[d] != 0)
-          atomicAdd(next_hist + d,(unsigned long long) nh[d]);
-    }
-}
-
-template <int RB, bool FROM_SEEDS>
-__global__ __launch_bounds__(ST)
-void os2_first_hist_kernel(const void *in, int64_t n, int shift, key_layout L, unsigned long long *ghist, const uint16_t *valid)
-{ constexpr int ND = 1 << RB;
-  __shared__ uint32_t h[ND];
-  for (int d = threadIdx.x; d < ND; d += ST)
-    h[d] = 0;
-  __syncthreads();
-  for (int64_t tile = blockIdx.x; tile*STILE < n; tile += gridDim.x)
-    { const int64_t base = tile * STILE;
-      #pragma unroll 4
-      for (int r = 0; r < SITEMS; r++)
-        { const int64_t i = base + r*ST + threadIdx.x;
-          if (i < n && (!FROM_SEEDS || valid == NULL || (int) (i & 1023) < (int) valid[i >> 10]))
-            { const u128 k = load_key<FROM_SEEDS>(in,i,L);
-              atomicAdd(&h[digit_rb(k,shift,ND-1)],1u);
-            }
-        }
-    }
-  __syncthreads();
-  for (int d = threadIdx.x; d < ND; d += ST)
-    if (h[d] != 0)
-      atomicAdd(ghist + d,(unsigned long long) h[d]);
-}
-
-// ghist[ND] counts -> gbase[ND] exclusive starts; clears the counts of the pass after next and the ticket
-template <int RB>
-__global__ __launch_bounds__(256)
-void os2_scan_kernel(const unsigned long long *ghist, unsigned long long *gbase, unsigned long long *clear, unsigned int *ticket)
-{ constexpr int ND = 1 << RB, PER = ND/256;
-  __shared__ unsigned long long part[256];
-  unsigned long long v[PER], s = 0;
-  #pragma unroll
-  for (int q = 0; q < PER; q++)
-    { v[q] = ghist[threadIdx.x*PER + q];
-      s += v[q];
-    }
-  part[threadIdx.x] = s;
-  __syncthreads();
-  if (threadIdx.x == 0)
-    { unsigned long long run = 0;
-      for (int d = 0; d < 256; d++) { const unsigned long long x = part[d]; part[d] = run; run += x; }
-      *ticket = 0;
-    }
-  __syncthreads();
-  unsigned long long run = part[threadIdx.x];
-  #pragma unroll
-  for (int q = 0; q < PER; q++)
-    { gbase[threadIdx.x*PER + q] = run;
-      run += v[q];
-      if (clear != NULL)
-        clear[threadIdx.x*PER + q] = 0;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// os3: one-sweep pass whose every store is a whole, aligned 64-byte block.
-// Measured on MI355X (tools/ubench/sort_bench.hip, 550 M records): a pass that writes each 64-byte block (4 records) with 4
-// adjacent lanes of ONE store instruction runs at the speed of a copy (3.3 ms = 5.3 TB/s); the same bytes written one record
-// per instruction (a scatter straight from registers: 7.4 ms) or in runs that begin and end inside a block (6.5 ms) pay a
-// read-modify-write per piece.  So:
-//   * the keys of a tile go to LDS in the order they will have in `out` and leave it slot by slot, lane j next to lane j+1;
-//     the slot of a digit's run is congruent to its position in `out` modulo 4, so a block is 4 adjacent lanes;
-//   * a tile with >= 3 keys of a digit does NOT write the last (G+c) mod 4 of them when more keys of that digit follow: the
-//     next tile that has keys of the digit writes them in front of its own -- it finds them in the first tile's tail record
-//     (its last 3 keys of every digit, 48 bytes, published before the tile's count) through the look-back, whose status
-//     words carry the last tile that had keys of the digit and whether it had three.
-//   status word: stamp 8 | state 2 | value 54; value = prefix 33 | that tile had >= 3 keys 1 | last tile with keys + 1, 20
-// ---------------------------------------------------------------------------------------------------
-#define OS3_PREFIX(v)   ((v) & ((1ull << 33) - 1))
-#define OS3_BIG(v)      ((int) (((v) >> 33) & 1))
-#define OS3_LINK(v)     ((int) (((v) >> 34) & 0xfffff))
-#define OS3_VALUE(prefix,big,link)  ((unsigned long long) (prefix) | ((unsigned long long) (big) << 33) | ((unsigned long long) (link) << 34))
-#define OS3_MAX_TILES   ((1 << 20) - 2)
-
-template <int NT, int KPT, int PH, bool FROM_SEEDS>
-__global__ __launch_bounds__(NT)
-void os3_pass_kernel(const void *in, uint4 *out, int64_t n, int shift, int next_shift, key_layout L, int stamp,
-                     const unsigned long long *gbase, const unsigned long long *ghist, unsigned long long *status,
-                     uint4 *xtail, unsigned long long *next_hist, unsigned int *ticket, const uint16_t *valid)
-{ constexpr int NW = NT/64, ND = 256, TILE = NT*KPT;
-  static_assert(1024 % (64*KPT) == 0,"a wavefront's keys lie in one block of the seed buffer");
-  constexpr int SLOTS = TILE + 6*ND;                      // runs padded to their phase in front and to a block behind
-  constexpr int SH = (((SLOTS + PH - 1) / PH) + 3) & ~3;  // slots staged at a time
-  static_assert(SH >= 3*ND,"the tail records are staged in the same buffer");
-  static_assert(PH*SH < 65536,"slots are 16-bit");
-  __shared__ uint4    stage[SH];
-  __shared__ uint16_t wcnt[NW][ND];           // per-wave digit counts, then per-wave digit bases inside the tile
-  __shared__ long long delta[ND];             // position in `out` of slot 0 of the digit's run, minus its slot
-  __shared__ uint32_t range[ND];              // slots of the digit this tile writes: first | end << 16
-  __shared__ uint16_t cnt[ND];                // keys of the digit in the tile
-  __shared__ uint16_t sd[ND];                 // slot of the digit's first key
-  __shared__ uint16_t blockdig[PH*SH/4];      // digit whose run covers the 4-slot block (0xffff: none)
-  __shared__ uint32_t nh[ND];                 // digits of the next pass among the tile's keys
-  __shared__ uint32_t wtot[4];
-  __shared__ int tile_s;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0)
-    tile_s = (int) atomicAdd(ticket,1u);
-  for (int x = tid; x < NW*ND/2; x += NT)
-    ((uint32_t *) &wcnt[0][0])[x] = 0;
-  for (int x = tid; x < PH*SH/8; x += NT)
-    ((uint32_t *) blockdig)[x] = 0xffffffffu;
-  if (tid < ND)
-    nh[tid] = 0;
-  __syncthreads();
-  const int tile = tile_s;
-
-  const int64_t wbase = (int64_t) tile * TILE + (int64_t) wave * (64*KPT);
-  int vcount = 64*KPT;
-  if (FROM_SEEDS && valid != NULL && wbase < n)
-    { vcount = (int) valid[wbase >> 10] - (int) (wbase & 1023);
-      if (vcount > 64*KPT) vcount = 64*KPT;
-    }
-  u128     key[KPT];
-  uint32_t rk[KPT/2];                    // 16 bits per key: rank in the wavefront, then in the tile, then the slot
-#define RK_GET(r)     ((rk[(r) >> 1] >> (16*((r) & 1))) & 0xffffu)
-#define RK_SET(r,v)   (rk[(r) >> 1] = ((r) & 1) ? ((rk[(r) >> 1] & 0xffffu) | ((uint32_t) (v) << 16)) : ((rk[(r) >> 1] & 0xffff0000u) | (uint32_t) (v)))
-  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64-lane));
-  #pragma unroll
-  for (int r = 0; r < KPT/2; r++)
-    rk[r] = 0;
-  #pragma unroll
-  for (int r = 0; r < KPT; r++)
-    { const int64_t i = wbase + r*64 + lane;
-      const bool ok = i < n && r*64 + lane < vcount;
-      uint32_t d = ND;
-      if (ok)
-        { key[r] = load_key<FROM_SEEDS>(in,i,L);
-          d = digit_rb(key[r],shift,ND-1);
-        }
-      uint64_t peers = __ballot(ok);
-      #pragma unroll
-      for (int b = 0; b < 8; b++)
-        { const uint64_t m = __ballot((d >> b) & 1);
-          peers &= ((d >> b) & 1) ? m : ~m;
-        }
-      const uint32_t before = __popcll(peers & lt);
-      uint32_t basec = 0;
-      if (ok)
-        basec = wcnt[wave][d];
-      RK_SET(r,basec + before);
-      if (ok && (peers >> lane) >> 1 == 0)
-        wcnt[wave][d] = (uint16_t) (basec + before + 1);
-    }
-  __syncthreads();
-  uint32_t c = 0;                             // thread d < ND: keys of digit d in the tile
-  if (tid < ND)
-    { uint32_t run = 0;
-      #pragma unroll
-      for (int w = 0; w < NW; w++)
-        { const uint32_t x = wcnt[w][tid];
-          wcnt[w][tid] = (uint16_t) run;
-          run += x;
-        }
-      c = run;
-      cnt[tid] = (uint16_t) c;
-    }
-  __syncthreads();
-  // the tile's last three keys of every digit, published before its counts
-  #pragma unroll
-  for (int r = 0; r < KPT; r++)
-    { const int64_t i = wbase + r*64 + lane;
-      if (i < n && r*64 + lane < vcount)
-        { const uint32_t d = digit_rb(key[r],shift,ND-1);
-          const uint32_t tr = wcnt[wave][d] + RK_GET(r), cd = cnt[d];
-          RK_SET(r,tr);
-          if (tr + 3 >= cd)
-            { uint4 v;
-              v.x = (uint32_t) key[r].lo; v.y = (uint32_t) (key[r].lo >> 32);
-              v.z = (uint32_t) key[r].hi; v.w = (uint32_t) (key[r].hi >> 32);
-              stage[d*3 + (tr + 3 - cd)] = v;
-            }
-        }
-    }
-  __syncthreads();
-#ifndef OS3_NO_X
-  { uint4 *xt = xtail + (size_t) tile * (3*ND);
-    for (int x = tid; x < 3*ND; x += NT)
-      { typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-        const uint4 sv = stage[x];
-        const v4u v = { sv.x, sv.y, sv.z, sv.w };
-        uint4 *q = xt + x;
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(q), "v"(v) : "memory");
-      }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-#endif
-  __syncthreads();
-  // thread d: count published; look-back; where the run goes; what it borrows; its slots
-  uint4 bk0, bk1, bk2;
-  bk0 = bk1 = bk2 = make_uint4(0,0,0,0);
-  uint32_t rb = 0, pre = 0, padded = 0, wlen = 0;
-  long long G = 0;
-  if (tid < ND)
-    { const int d = tid;
-      unsigned long long *mine = status + (size_t) tile*ND + d;
-      if (tile > 0)
-        __hip_atomic_store(mine,OS_PACK(stamp,OS_LOCAL,c),__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
-      unsigned long long excl = 0;
-      int pred = -1, predbig = 0;
-      for (int t = tile-1; t >= 0; t--)
-        { const unsigned long long *p = status + (size_t) t*ND + d;
-          unsigned long long sv = __hip_atomic_load(p,__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
-          while (OS_STAMP(sv) != stamp || OS_STATE(sv) == 0)
-            { __builtin_amdgcn_s_sleep(1);
-              sv = __hip_atomic_load(p,__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
-            }
-          const unsigned long long v = OS_VALUE(sv);
-          if (OS_STATE(sv) == OS_INCL)
-            { excl += OS3_PREFIX(v);
-              if (pred < 0 && OS3_LINK(v) != 0)
-                { pred = OS3_LINK(v) - 1; predbig = OS3_BIG(v); }
-              break;
-            }
-          excl += v;
-          if (pred < 0 && v > 0)
-            { pred = t; predbig = v >= 3; }
-        }
-      { const int link = c > 0 ? tile+1 : pred+1, big = c > 0 ? (c >= 3) : predbig;
-        __hip_atomic_store(mine,OS_PACK(stamp,OS_INCL,OS3_VALUE(excl + c,big,link)),__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
-      }
-      G = (long long) (gbase[d] + excl);
-      if (c > 0)
-        { pre = (uint32_t) (G & 3);
-#ifdef OS3_NO_X
-          if (pre > 123456)
-#else
-          if (pre > 0 && pred >= 0 && predbig)
-#endif
-            { rb = pre;
-              const uint4 *xp = xtail + (size_t) pred * (3*ND) + d*3;
-              typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-              v4u a, b, e;
-              asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %3, off offset:16 sc1\n\t"
-                           "global_load_dwordx4 %2, %3, off offset:32 sc1\n\ts_waitcnt vmcnt(0)"
-                           : "=&v"(a), "=&v"(b), "=&v"(e) : "v"(xp) : "memory");
-              bk0 = make_uint4(a.x,a.y,a.z,a.w); bk1 = make_uint4(b.x,b.y,b.z,b.w); bk2 = make_uint4(e.x,e.y,e.z,e.w);
-            }
-          padded = (pre + c + 3) & ~3u;
-          const bool last = (unsigned long long) G + c == gbase[d] + ghist[d];
-          wlen = (c >= 3 && !last) ? (uint32_t) ((((unsigned long long) G + c) & ~3ull) - (unsigned long long) G) : c;
-        }
-    }
-  // exclusive scan of the padded run lengths over the digits
-  { uint32_t inc = padded;
-    #pragma unroll
-    for (int o = 1; o < 64; o <<= 1)
-      { const uint32_t y = __shfl_up(inc,o,64);
-        if (lane >= o) inc += y;
-      }
-    if (tid < ND && lane == 63)
-      wtot[wave] = inc;
-    __syncthreads();
-    if (tid < ND)
-      { uint32_t off = 0;
-        for (int w = 0; w < wave; w++)
-          off += wtot[w];
-        const uint32_t s0 = off + inc - padded + pre;         // slot of the first own key
-        sd[tid] = (uint16_t) s0;
-        range[tid] = (s0 - rb) | ((s0 + wlen) << 16);
-        delta[tid] = G - (long long) s0;
-      }
-  }
-  __syncthreads();
-  #pragma unroll
-  for (int r = 0; r < KPT; r++)
-    { const int64_t i = wbase + r*64 + lane;
-      if (i < n && r*64 + lane < vcount)
-        RK_SET(r,RK_GET(r) + sd[digit_rb(key[r],shift,ND-1)]);
-    }
-  #pragma unroll 1
-#ifdef OS3_NO_PHASES
-  for (int h = 0; h < (int) (n == -7); h++)
-#else
-  for (int h = 0; h < PH; h++)
-#endif
-    { const int lo = h*SH;
-      #pragma unroll
-      for (int r = 0; r < KPT; r++)
-        { const int64_t i = wbase + r*64 + lane;
-          const int sl = (int) RK_GET(r) - lo;
-          if (i < n && r*64 + lane < vcount && sl >= 0 && sl < SH)
-            { uint4 v;
-              v.x = (uint32_t) key[r].lo; v.y = (uint32_t) (key[r].lo >> 32);
-              v.z = (uint32_t) key[r].hi; v.w = (uint32_t) (key[r].hi >> 32);
-              stage[sl] = v;
-              blockdig[RK_GET(r) >> 2] = (uint16_t) digit_rb(key[r],shift,ND-1);
-            }
-        }
-      if (rb > 0)
-        { const int s0 = (int) sd[tid] - (int) rb - lo;       // borrowed keys: the block in front of the run
-          if (s0 >= 0 && s0 < SH)
-            { if (rb == 3) { stage[s0] = bk0; stage[s0+1] = bk1; stage[s0+2] = bk2; }
-              else if (rb == 2) { stage[s0] = bk1; stage[s0+1] = bk2; }
-              else stage[s0] = bk2;
-              blockdig[(s0 + lo) >> 2] = (uint16_t) tid;
-            }
-        }
-      __syncthreads();
-      for (int s = lo + tid; s < lo + SH; s += NT)
-        { const uint32_t q = blockdig[s >> 2];
-          if (q != 0xffffu)
-            { const uint32_t rg = range[q];
-#ifdef OS3_NO_OUT
-              if ((uint32_t) s >= (rg & 0xffffu) && (uint32_t) s < (rg >> 16) && delta[q] == -77)
-#else
-              if ((uint32_t) s >= (rg & 0xffffu) && (uint32_t) s < (rg >> 16))
-#endif
-                out[delta[q] + s] = stage[s - lo];
-            }
-        }
-      __syncthreads();
-    }
-  if (next_hist != NULL)
-    { 
-      #pragma unroll
-      for (int r = 0; r < KPT; r++)
-        { const int64_t i = wbase + r*64 + lane;
-          if (i < n && r*64 + lane < vcount)
-            atomicAdd(&nh[digit_rb(key[r],next_shift,ND-1)],1u);
-        }
-      __syncthreads();
-      if (tid < ND && nh[tid] != 0)
-        atomicAdd(next_hist + tid,(unsigned long long) nh[tid]);
-    }
-}
-
-#undef RK_GET
-#undef RK_SET
-
-static size_t os3_work_bytes(int64_t ntiles)
-{ return sizeof(unsigned long long)*(3*256 + 8 + (size_t) ntiles*256) + (size_t) ntiles*768*sizeof(uint4); }
-
-template <int NT, int KPT, int PH>
-static void os3_sort_t(fga_dev *dev, const void *first, bool from_seeds, int64_t next, const uint16_t *valid, key_layout L,
-                       uint4 *buf0, uint4 *buf1, int64_t n, int lowbit, int nbits, void *work, int64_t ntiles_max, uint4 **sorted)
-{ constexpr int ND = 256, RB = 8, TILE = NT*KPT;
-  const int npass = (nbits + RB - 1) / RB;
-  unsigned long long *hist[2] = { (unsigned long long *) work, (unsigned long long *) work + ND };
-  unsigned long long *gbase = (unsigned long long *) work + 2*ND;
-  unsigned int *ticket = (unsigned int *) ((unsigned long long *) work + 3*ND);
-  unsigned long long *status = (unsigned long long *) work + 3*ND + 8;
-  uint4 *xtail = (uint4 *) (status + (size_t) ntiles_max*ND);
-  hipMemsetAsync(work,0,sizeof(unsigned long long)*(3*ND + 8 + (size_t) ntiles_max*ND),dev->stream);
-  const void *src = first;
-  uint4 *dst = buf0;
-  const int64_t cnt = from_seeds ? next : n;
-  { int grid = (int) ((cnt + STILE - 1) / STILE);
-    if (grid > dev->ncu*8) grid = dev->ncu*8;
-    if (grid < 1) grid = 1;
-    if (from_seeds)
-      hipLaunchKernelGGL((os2_first_hist_kernel<RB,true>),dim3(grid),dim3(ST),0,dev->stream,src,cnt,lowbit,L,hist[0],valid);
-    else
-      hipLaunchKernelGGL((os2_first_hist_kernel<RB,false>),dim3(grid),dim3(ST),0,dev->stream,src,cnt,lowbit,L,hist[0],(const uint16_t *) NULL);
-  }
-  for (int p = 0; p < npass; p++)
-    { const int shift = lowbit + RB*p;
-      const int64_t m = (p == 0) ? cnt : n;
-      const int nt = (int) ((m + TILE - 1) / TILE);
-      unsigned long long *hc = hist[p & 1], *hn = (p+1 < npass) ? hist[(p+1) & 1] : NULL;
-      hipLaunchKernelGGL((os2_scan_kernel<RB>),dim3(1),dim3(256),0,dev->stream,hc,gbase,hn,ticket);
-      if (p == 0 && from_seeds)
-        hipLaunchKernelGGL((os3_pass_kernel<NT,KPT,PH,true>),dim3(nt),dim3(NT),0,dev->stream,src,dst,m,shift,shift+RB,L,p+1,gbase,hc,status,xtail,
-                           hn,ticket,valid);
-      else
-        hipLaunchKernelGGL((os3_pass_kernel<NT,KPT,PH,false>),dim3(nt),dim3(NT),0,dev->stream,src,dst,m,shift,shift+RB,L,p+1,gbase,hc,status,xtail,
-                           hn,ticket,(const uint16_t *) NULL);
-      src = dst;
-      dst = (dst == buf0) ? buf1 : buf0;
-    }
-  *sorted = (uint4 *) src;
-}
-
-// work: 3 x ND + 8 unsigned long long (two digit histograms, the digit bases, the ticket), then per tile ND prefix words
-// (8 bytes) and ND count words (4 bytes)
-static size_t os2_work_bytes(int64_t ntiles, int rb)
-{ const size_t nd = (size_t) 1 << rb;
-  return sizeof(unsigned long long)*(3*nd + 8 + (size_t) ntiles*nd); }
-
-struct os2_config { int nt, rb, v1, impl, ph, kpt; };
-static os2_config os2_cfg()
-{ static os2_config c = { 0, 0, 0, 0, 0, 0 };
-  if (c.nt == 0)
-    { const char *e;
-      c.rb = ((e = getenv("FGA_SORT_RB")) != NULL) ? atoi(e) : 8;
-      c.v1 = ((e = getenv("FGA_SORT_V1")) != NULL) ? atoi(e) : 0;
-      c.impl = ((e = getenv("FGA_SORT_IMPL")) != NULL) ? atoi(e) : 3;
-      c.ph = ((e = getenv("FGA_SORT_PH")) != NULL) ? atoi(e) : 3;
-      c.kpt = ((e = getenv("FGA_SORT_KPT")) != NULL) ? atoi(e) : 16;
-      if (c.kpt != 8 || c.impl != 3) c.kpt = 16;
-      c.nt = ((e = getenv("FGA_SORT_NT")) != NULL) ? atoi(e) : (c.impl == 3 ? 256 : 512);
-      if (c.rb != 8 && c.rb != 9 && c.rb != 10 && c.rb != 11) c.rb = 8;
-      if (c.nt != 256 && c.nt != 512 && c.nt != 1024) c.nt = 512;
-      if (c.rb != 8 && c.nt == 256) c.nt = 512;
-      if (c.impl == 3) c.rb = 8;
-    }
-  return c;
-}
-
-template <int NT, int RB>
-static void os2_sort_t(fga_dev *dev, const void *first, bool from_seeds, int64_t next, const uint16_t *valid, key_layout L,
-                       uint4 *buf0, uint4 *buf1, int64_t n, int lowbit, int nbits, void *work, int64_t ntiles_max, uint4 **sorted)
-{ constexpr int ND = 1 << RB, TILE = NT*OS_ITEMS;
-  const int npass = (nbits + RB - 1) / RB;
-  unsigned long long *hist[2] = { (unsigned long long *) work, (unsigned long long *) work + ND };
-  unsigned long long *gbase = (unsigned long long *) work + 2*ND;
-  unsigned int *ticket = (unsigned int *) ((unsigned long long *) work + 3*ND);
-  unsigned long long *status = (unsigned long long *) work + 3*ND + 8;
-  hipMemsetAsync(work,0,os2_work_bytes(ntiles_max,RB),dev->stream);
-  const void *src = first;
-  uint4 *dst = buf0;
-  const int64_t cnt = from_seeds ? next : n;                     // slots the first pass looks at
-  { int grid = (int) ((cnt + STILE - 1) / STILE);
-    if (grid > dev->ncu*8) grid = dev->ncu*8;
-    if (grid < 1) grid = 1;
-    if (from_seeds)
-      hipLaunchKernelGGL((os2_first_hist_kernel<RB,true>),dim3(grid),dim3(ST),0,dev->stream,src,cnt,lowbit,L,hist[0],valid);
-    else
-      hipLaunchKernelGGL((os2_first_hist_kernel<RB,false>),dim3(grid),dim3(ST),0,dev->stream,src,cnt,lowbit,L,hist[0],(const uint16_t *) NULL);
-  }
-  for (int p = 0; p < npass; p++)
-    { const int shift = lowbit + RB*p;
-      const int64_t m = (p == 0) ? cnt : n;
-      const int nt = (int) ((m + TILE - 1) / TILE);
-      unsigned long long *hc = hist[p & 1], *hn = (p+1 < npass) ? hist[(p+1) & 1] : NULL;
-      hipLaunchKernelGGL((os2_scan_kernel<RB>),dim3(1),dim3(256),0,dev->stream,hc,gbase,hn,ticket);
-      if (p == 0 && from_seeds)
-        hipLaunchKernelGGL((os2_pass_kernel<NT,RB,true>),dim3(nt),dim3(NT),0,dev->stream,src,dst,m,shift,shift+RB,L,p+1,gbase,status,
-                           hn,ticket,valid);
-      else
-        hipLaunchKernelGGL((os2_pass_kernel<NT,RB,false>),dim3(nt),dim3(NT),0,dev->stream,src,dst,m,shift,shift+RB,L,p+1,gbase,status,
-                           hn,ticket,(const uint16_t *) NULL);
-      src = dst;
-      dst = (dst == buf0) ? buf1 : buf0;
-    }
-  *sorted = (uint4 *) src;
-}
-
-static int64_t os2_tiles(int64_t slots) { const os2_config c = os2_cfg(); return (slots + c.nt*c.kpt - 1) / (c.nt*c.kpt); }
-
-static bool os3_on(int64_t ntiles) { return os2_cfg().impl == 3 && ntiles <= OS3_MAX_TILES; }
-static size_t os23_work_bytes(int64_t ntiles) { return os3_on(ntiles) ? os3_work_bytes(ntiles) : os2_work_bytes(ntiles,os2_cfg().rb); }
-
-static void os2_sort(fga_dev *dev, const void *first, bool from_seeds, int64_t next, const uint16_t *valid, key_layout L,
-                     uint4 *buf0, uint4 *buf1, int64_t n, int lowbit, int nbits, void *work, int64_t ntiles_max, uint4 **sorted)
-{ const os2_config c = os2_cfg();
-  if (os3_on(ntiles_max))
-    {
-#define OS3_CASE(NT_,KPT_,PH_) if (c.nt == NT_ && c.kpt == KPT_ && c.ph == PH_) { os3_sort_t<NT_,KPT_,PH_>(dev,first,from_seeds,next,valid,L,buf0,buf1,n,lowbit,nbits,work,ntiles_max,sorted); return; }
-      OS3_CASE(256,16,3) OS3_CASE(256,16,4) OS3_CASE(512,16,4) OS3_CASE(512,16,5)
-      OS3_CASE(512,8,3) OS3_CASE(512,8,4) OS3_CASE(1024,8,4) OS3_CASE(1024,8,5)
-#undef OS3_CASE
-      fprintf(stderr,"fga_sort: no such kernel configuration (NT %d, KPT %d, PH %d)\n",c.nt,c.kpt,c.ph);
-      exit(1);
-      return;
-    }
-#define OS2_CASE(NT_,RB_) if (c.nt == NT_ && c.rb == RB_) { os2_sort_t<NT_,RB_>(dev,first,from_seeds,next,valid,L,buf0,buf1,n,lowbit,nbits,work,ntiles_max,sorted); return; }
-  OS2_CASE(256,8) OS2_CASE(512,8) OS2_CASE(1024,8)
-  OS2_CASE(512,9) OS2_CASE(1024,9) OS2_CASE(512,10) OS2_CASE(1024,10) OS2_CASE(512,11) OS2_CASE(1024,11)
-#undef OS2_CASE
-  os2_sort_t<512,8>(dev,first,from_seeds,next,valid,L,buf0,buf1,n,lowbit,nbits,work,ntiles_max,sorted);
 }
 
 // the passes of one sort, one-sweep; `first` reads seeds (FROM_SEEDS) or keys; buffers alternate.  Enqueued on the stream.
@@ -1085,6 +444,16 @@ static void os_sort(fga_dev *dev, const void *first, bool from_seeds, int64_t ne
   *sorted = (uint4 *) src;
 }
 
+// FGA_SORT_3N=1: the three-kernel passes (tile histogram, scan, scatter: 3 n traffic per pass) instead of the one-sweep ones
+static bool sort_three_kernel_passes()
+{ static int v = -1;
+  if (v < 0)
+    { const char *e = getenv("FGA_SORT_3N");
+      v = (e != NULL && atoi(e) != 0) ? 1 : 0;
+    }
+  return v != 0;
+}
+
 static int bits_for(int64_t maxval)      // bits needed to hold values 0..maxval
 { int b = 1;
   while ((maxval >> b) != 0) b++;
@@ -1121,7 +490,6 @@ extern "C" int fga_seed_sort(fga_dev *dev, const fga_dseeds *S, const fga_sort_p
   K->amxpos = prm->amxpos; K->bmxpos = prm->bmxpos;
   const int lowbit = prm->anti_order_only ? 12 : 0;       // diag&63 and lcp: the chain scan does not need them ordered
   const int npass = (tbits - lowbit + 7) / 8;
-  const int nbits = tbits - lowbit;
   // the first pass walks the seed buffer (holes included), the others the keys
   const int ntiles0 = (int) ((next + STILE - 1) / STILE), ntilesk = (int) ((n + STILE - 1) / STILE);
   const int ntiles = ntiles0 > ntilesk ? ntiles0 : ntilesk;
@@ -1135,12 +503,9 @@ extern "C" int fga_seed_sort(fga_dev *dev, const fga_dseeds *S, const fga_sort_p
   const int64_t hm = (int64_t) 256*ntiles;
   const int nch = (int) ((hm + SCAN_CH - 1) / SCAN_CH);
   hipError_t e;
-  // FGA_SORT_3N=1: the three-kernel passes (tile histogram, scan, scatter: 3 n traffic per pass) instead of the one-sweep ones
-  const bool three = getenv("FGA_SORT_3N") != NULL && atoi(getenv("FGA_SORT_3N")) != 0;
+  const bool three = sort_three_kernel_passes();
   const int64_t ostiles = ((next > n ? next : n) + OS_TILE - 1) / OS_TILE;
-  const bool v2 = !three && !os2_cfg().v1;
-  const int64_t os2tiles = os2_tiles(next > n ? next : n);
-  const size_t wbytes = three ? sizeof(uint32_t)*(256*(size_t) ntiles + nch + 1) : v2 ? os23_work_bytes(os2tiles) : os_work_bytes(ostiles);
+  const size_t wbytes = three ? sizeof(uint32_t)*(256*(size_t) ntiles + nch + 1) : os_work_bytes(ostiles);
   K->alloc_bytes = sizeof(uint4)*(size_t) n;
   e = hipSuccess;
   buf[0] = (uint4 *) fga_dev_acquire(dev,SLOT_SORT0,K->alloc_bytes);
@@ -1157,10 +522,7 @@ extern "C" int fga_seed_sort(fga_dev *dev, const fga_dseeds *S, const fga_sort_p
   const void *src = S->seeds;
   if (!three)
     { uint4 *sorted = NULL;
-      if (v2)
-        os2_sort(dev,S->seeds,true,next,S->valid,L,buf[0],buf[1],n,lowbit,nbits,hist,os2tiles,&sorted);
-      else
-        os_sort(dev,S->seeds,true,next,S->valid,L,buf[0],buf[1],n,lowbit,npass,hist,ostiles,&sorted);
+      os_sort(dev,S->seeds,true,next,S->valid,L,buf[0],buf[1],n,lowbit,npass,hist,ostiles,&sorted);
       src = sorted;
     }
   else
@@ -1219,11 +581,9 @@ int fga_radix_sort_u128(fga_dev *dev, uint4 *buf0, uint4 *buf1, int64_t n, int l
   const int ntiles = (int) ((n + STILE - 1) / STILE);
   const int64_t hm = (int64_t) 256*ntiles;
   const int nch = (int) ((hm + SCAN_CH - 1) / SCAN_CH);
-  const bool three = getenv("FGA_SORT_3N") != NULL && atoi(getenv("FGA_SORT_3N")) != 0;
-  const bool v2 = !three && !os2_cfg().v1;
+  const bool three = sort_three_kernel_passes();
   uint32_t *hist = (uint32_t *) fga_dev_acquire(dev,SLOT_HIST,three ? sizeof(uint32_t)*(256*(size_t) ntiles + nch + 1)
-                                                                    : v2 ? os23_work_bytes(os2_tiles(n))
-                                                                         : os_work_bytes((n + OS_TILE - 1) / OS_TILE));
+                                                                    : os_work_bytes((n + OS_TILE - 1) / OS_TILE));
   if (hist == NULL)
     { fga_set_error("radix sort: device allocation failed");
       return 1;
@@ -1232,9 +592,7 @@ int fga_radix_sort_u128(fga_dev *dev, uint4 *buf0, uint4 *buf1, int64_t n, int l
   key_layout L;
   memset(&L,0,sizeof(L));
   uint4 *src = buf0, *dst = buf1;
-  if (v2)
-    os2_sort(dev,buf0,false,n,(const uint16_t *) NULL,L,buf1,buf0,n,lowbit,nbits,hist,os2_tiles(n),&src);
-  else if (!three)
+  if (!three)
     os_sort(dev,buf0,false,n,(const uint16_t *) NULL,L,buf1,buf0,n,lowbit,npass,hist,(n + OS_TILE - 1) / OS_TILE,&src);
   else
   for (int p = 0; p < npass; p++)
@@ -1254,6 +612,7 @@ int fga_radix_sort_u128(fga_dev *dev, uint4 *buf0, uint4 *buf1, int64_t n, int l
   return 0;
 }
 
+// rmsd_sort on records that already sit in HBM (include/fastga_amd.h); what tools/ubench/sort_bench.hip times
 extern "C" int fga_dev_radix_sort_u128(fga_dev *dev, void *buf0, void *buf1, int64_t n, int lowbit, int nbits, void **sorted)
 { if (dev == NULL || buf0 == NULL || buf1 == NULL || sorted == NULL || n < 0 || lowbit < 0 || nbits < 0 || lowbit + nbits > 128)
     { fga_set_error("fga_dev_radix_sort_u128: bad argument");
