@@ -68,6 +68,7 @@ struct fga_dgix
     fga_view  fview;      // forward-strand entries only (made on first use as table 1 of a pair comparison)
   };
 int  fga_dgix_make_view(fga_dev *dev, fga_dgix *D, int keep_table);
+int  fga_view_alloc(fga_view *V, int64_t n, int cont, int want_l);       // the field arrays of n entries (+ read slack), defined
 int  fga_dgix_make_forward(fga_dev *dev, fga_dgix *D);
 void fga_dgix_free_views(fga_dgix *D);
 

@@ -241,13 +241,15 @@ void gix_index_write_kernel(const uint32_t *count, const unsigned long long *sum
 struct gix_entries_args
   { const uint4 *keys; int64_t n;
     int postbytes, contbytes, ebytes;
-    uint8_t *table;
+    uint8_t *table;                 // TO_VIEW == false: the on-disk entry bytes
+    fga_view view;                  // TO_VIEW == true: the merge kernel's field arrays, written directly (fga_view.hip)
     const uint8_t *partid;          // [1024] number of part boundaries at or below this 5-base bucket
     // soft mask (optional): lower-case intervals per original contig, and the sorted -> original contig map
     const int64_t *moff, *mbeg, *mend;
     const int     *perm;
   };
 
+template <bool TO_VIEW>
 __global__ __launch_bounds__(256)
 void gix_entries_kernel(gix_entries_args A)
 { const int64_t i = (int64_t) blockIdx.x*blockDim.x + threadIdx.x;
@@ -272,10 +274,13 @@ void gix_entries_kernel(gix_entries_args A)
     }
   const uint64_t suf = ((hi & 0xffffffffffull) << 16) | lo16;           // bases 12..39
   const uint64_t pay = (lo & 0xffffffffffffull) >> (48 - 8*(A.postbytes+A.contbytes));
-  uint8_t *o = A.table + (size_t) i*A.ebytes;
-  #pragma unroll
-  for (int q = 0; q < 7; q++)
-    o[q] = (uint8_t) (suf >> (8*(6-q)));
+  uint8_t *o = TO_VIEW ? NULL : A.table + (size_t) i*A.ebytes;
+  if (!TO_VIEW)
+    { 
+      #pragma unroll
+      for (int q = 0; q < 7; q++)
+        o[q] = (uint8_t) (suf >> (8*(6-q)));
+    }
   // soft-mask byte of the k-mers whose syncmer starts at j: bases from j to the end of the lower-case interval that
   // holds j, capped at 40; 0 outside intervals (setup_thread_with_masks, GIXmake.c:1100-1108)
   uint32_t pbg = 0;
@@ -295,10 +300,33 @@ void gix_entries_kernel(gix_entries_args A)
           pbg = (uint32_t) (dd > FGA_KMER ? FGA_KMER : dd);
         }
     }
+  if (TO_VIEW)
+    { // what view_repack_kernel makes of the entry bytes: the key carries the low byte of the 12-mer prefix; the first entry
+      // of a panel has an lcp below 12 by construction (its 12-mer differs from the one before)
+      const fga_view &V = A.view;
+      const uint32_t pm = A.postbytes >= 4 ? 0xffffffffu : ((1u << (8*A.postbytes)) - 1);
+      V.K[i] = (((hi >> 40) & 0xff) << 56) | suf;
+      V.L[i] = (uint8_t) lcp;
+      V.M[i] = (uint8_t) pbg;
+      V.P[i] = (uint32_t) pay & pm;
+      const uint32_t c = (uint32_t) (pay >> (8*A.postbytes)) & (A.contbytes >= 4 ? 0xffffffffu : ((1u << (8*A.contbytes)) - 1));
+      if (V.cw == 1)      ((uint8_t  *) V.C)[i] = (uint8_t) c;
+      else if (V.cw == 2) ((uint16_t *) V.C)[i] = (uint16_t) c;
+      else                ((uint32_t *) V.C)[i] = c;
+      return;
+    }
   o[7] = (uint8_t) pbg;
   o[8] = (uint8_t) lcp;
   for (int q = 0; q < A.postbytes + A.contbytes; q++)
     o[9+q] = (uint8_t) (pay >> (8*q));
+}
+
+// the view's 32-bit prefix index from the 64-bit one
+__global__ __launch_bounds__(256)
+void gix_view_index_kernel(const int64_t *idx64, uint32_t *idx32)
+{ const int64_t p = (int64_t) blockIdx.x*256 + threadIdx.x;
+  if (p < FGA_NPREFIX)
+    idx32[p] = (uint32_t) idx64[p];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -314,6 +342,7 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
   if (pbeg < 0) pbeg = 0;
   if (pend > FGA_NPREFIX || pend <= 0) pend = FGA_NPREFIX;
   const int want_host_copy = (flags & FGA_GIX_HOST_COPY) != 0;
+  bool direct_view = false;
   const int use_mask = (flags & FGA_GIX_SOFT_MASK) != 0 && G->nmask > 0;
   int64_t *dmoff = NULL, *dmbeg = NULL, *dmend = NULL;
   int *dperm = NULL;
@@ -352,9 +381,11 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
     { boff[(size_t) c] = G->contigs[c].boff; clen[(size_t) c] = G->contigs[c].clen;
       for (int64_t j = 0; j + 12 <= G->contigs[c].clen; j += GCH)
         { gix_item it; it.ctg = c; it.j0 = (int) j; items.push_back(it); }
-      cap += G->contigs[c].clen;                      // < 1 k-mer per base and strand pair on average (2/5 per strand)
+      cap += G->contigs[c].clen;                      // 0.79 k-mers per base on sequence without structure (2/5 per strand)
     }
-  cap = cap + (cap >> 3) + 4096;
+  // the first guess for the two key buffers: 0.84 per base (what the scan finds beyond it -- low-complexity sequence: up to
+  // two per base -- is scanned again into buffers of the exact size, below); every GB less is a GB the driver need not hand out
+  cap = cap - (cap >> 3) - (cap >> 5) + 65536;
   if (pend - pbeg < FGA_NPREFIX)                          // a slice: its share of the prefix space and half as much again
     cap = (int64_t) ((double) cap * (double) (pend - pbeg) / FGA_NPREFIX * 1.5) + 65536;
   if (count_only)
@@ -484,12 +515,23 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
   D = (fga_dgix *) calloc(1,sizeof(fga_dgix));
   if (D == NULL) { fga_set_error("out of memory"); goto done; }
   D->dev = dev; D->nents = nkeys; D->ebytes = ebytes; D->postbytes = postbytes; D->contbytes = contbytes; D->nctg = nctg;
-  if ((e = fga_dmalloc(&D->table,(size_t) nkeys*ebytes + 64)) != hipSuccess ||
+  // with a host copy wanted the on-disk entry bytes are made (and turned into the view afterwards, as for an uploaded table);
+  // otherwise the entries go straight into the view's field arrays: 14 bytes per entry that are never allocated or written
+  direct_view = !want_host_copy;
+  if (direct_view && (nkeys >= ((int64_t) 1 << 32) - 1024 || postbytes > 4))
+    { fga_set_error("genome index of %lld entries, %d position bytes: beyond what a table view holds (2^32 entries, 4 Gbp contigs)",
+                    (long long) nkeys,postbytes);
+      goto done;
+    }
+  if ((!direct_view && (e = fga_dmalloc(&D->table,(size_t) nkeys*ebytes + 64)) != hipSuccess) ||
       (e = fga_dmalloc(&D->index,sizeof(int64_t)*FGA_NPREFIX)) != hipSuccess)
     { fga_set_error("fga_dgix_build: device allocation of the table failed: %s",hipGetErrorString(e));
       goto done;
     }
-  hipMemsetAsync(D->table + (size_t) nkeys*ebytes,0,64,dev->stream);
+  if (direct_view && fga_view_alloc(&D->view,nkeys,contbytes,1))
+    goto done;
+  if (!direct_view)
+    hipMemsetAsync(D->table + (size_t) nkeys*ebytes,0,64,dev->stream);
   { unsigned long long *sums = dctr + 1025;
     hipLaunchKernelGGL(gix_index_sums_kernel,dim3(FGA_NPREFIX/ICH),dim3(256),0,dev->stream,dcount,sums);
     hipLaunchKernelGGL(gix_index_scan_kernel,dim3(1),dim3(1024),0,dev->stream,sums,FGA_NPREFIX/ICH,sums);
@@ -500,6 +542,7 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
     { gix_entries_args E;
       E.keys = sorted; E.n = nkeys; E.postbytes = postbytes; E.contbytes = contbytes; E.ebytes = ebytes;
       E.table = D->table; E.partid = dpartid;
+      E.view = D->view;
       E.moff = NULL; E.mbeg = E.mend = NULL; E.perm = NULL;
       if (use_mask)
         { if ((e = fga_dmalloc(&dmoff,sizeof(int64_t)*(size_t) (nctg+1))) != hipSuccess ||
@@ -519,8 +562,13 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
           hipStreamSynchronize(dev->stream);
           E.moff = dmoff; E.mbeg = dmbeg; E.mend = dmend; E.perm = dperm;
         }
-      hipLaunchKernelGGL(gix_entries_kernel,dim3((unsigned) ((nkeys + 255)/256)),dim3(256),0,dev->stream,E);
+      if (direct_view)
+        hipLaunchKernelGGL(gix_entries_kernel<true>,dim3((unsigned) ((nkeys + 255)/256)),dim3(256),0,dev->stream,E);
+      else
+        hipLaunchKernelGGL(gix_entries_kernel<false>,dim3((unsigned) ((nkeys + 255)/256)),dim3(256),0,dev->stream,E);
     }
+  if (direct_view)
+    hipLaunchKernelGGL(gix_view_index_kernel,dim3(FGA_NPREFIX/256),dim3(256),0,dev->stream,D->index,D->view.idx);
   hipEventRecord(dev->ev1,dev->stream);
   { unsigned long long hm = 0;
     if ((e = hipMemcpyAsync(&hm,dctr + 1025 + 4096,sizeof(hm),hipMemcpyDeviceToHost,dev->stream)) != hipSuccess ||
@@ -566,7 +614,7 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
           }
       }
     // the merge kernel's view of the table; the on-disk bytes leave the device
-    if (fga_dgix_make_view(dev,D,0))
+    if (!direct_view && fga_dgix_make_view(dev,D,0))
       goto done;
     fga_note("index build: view",tn);
   }

@@ -149,7 +149,7 @@ static void view_free(fga_view *V)
   memset(V,0,sizeof(*V));
 }
 
-static int view_alloc(fga_view *V, int64_t n, int cont, int want_l)
+int fga_view_alloc(fga_view *V, int64_t n, int cont, int want_l)
 { memset(V,0,sizeof(*V));
   V->n = n;
   V->cw = cont <= 1 ? 1 : (cont == 2 ? 2 : 4);
@@ -180,8 +180,14 @@ int fga_dgix_make_view(fga_dev *dev, fga_dgix *D, int keep_table)
     { fga_set_error("genome index with %d position bytes: contigs beyond 4 Gbp are not supported",D->postbytes);
       return 1;
     }
+  if (D->postbytes + D->contbytes > 7)
+    { // view_repack_kernel reads the payload from entry bytes 9..15: an eighth byte (the one with the strand bit) would be cut
+      fga_set_error("genome index with %d position and %d contig bytes: payloads beyond 7 bytes are not supported",
+                    D->postbytes,D->contbytes);
+      return 1;
+    }
   double t0 = fga_wall();
-  if (view_alloc(&D->view,D->nents,D->contbytes,1))
+  if (fga_view_alloc(&D->view,D->nents,D->contbytes,1))
     return 1;
   fga_note("view: allocation",t0); t0 = fga_wall();
   hipLaunchKernelGGL(view_repack_kernel,dim3(FGA_NPREFIX/256),dim3(VW_T),0,dev->stream,
@@ -236,7 +242,7 @@ int fga_dgix_make_forward(fga_dev *dev, fga_dgix *D)
   for (int64_t b = 0; b < nblk; b++)
     { off[(size_t) b] = nf; nf += cnt[(size_t) b]; }
   off[(size_t) nblk] = nf;
-  if (view_alloc(&F,nf,D->contbytes,0))
+  if (fga_view_alloc(&F,nf,D->contbytes,0))
     goto done;
   if ((e = hipMemcpyAsync(doff,off.data(),sizeof(int64_t)*(size_t) (nblk+1),hipMemcpyHostToDevice,dev->stream)) != hipSuccess)
     { fga_set_error("forward view: upload failed: %s",hipGetErrorString(e));
