@@ -474,6 +474,11 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
 #ifdef EXT_WIDTH_HIST
       fprintf(stderr,"extend widths: calls by widest wave <=60 / <=120 / <=248 / wider: %llu %llu %llu %llu; wave steps in them: %llu %llu %llu %llu\n",
               hc[20],hc[21],hc[22],hc[23],hc[24],hc[25],hc[26],hc[27]);
+      { const double all = (double) (hc[24] + hc[25] + hc[26] + hc[27]);
+        fprintf(stderr,"extend widths, step-weighted: wave steps <=12 / <=30 / <=60 / <=120 diagonals wide: %llu %llu %llu %llu of %.0f "
+                       "(%.1f %% / %.1f %% / %.1f %% / %.1f %%)\n",hc[28],hc[29],hc[30],hc[31],all,100.*hc[28]/(all > 0 ? all : 1),
+                100.*hc[29]/(all > 0 ? all : 1),100.*hc[30]/(all > 0 ? all : 1),100.*hc[31]/(all > 0 ? all : 1));
+      }
 #endif
 
       R->naln = (int64_t) hc[0]; R->ntrace = (int64_t) hc[1]; ncalls_total = (int64_t) hc[2]; R->nwaves = (int64_t) hc[3];

@@ -50,6 +50,7 @@ struct fga_session
     double load_s, upload_s;
     int nranks, rank;          /* > 1: the session holds the rank's 12-mer prefix range of both tables only */
     int64_t *cuts;             /* [nranks+1] the prefix ranges of all ranks */
+    int64_t *scount;           /* [2*nctg] seeds per (strand, A contig) of the merges so far (reference order only) */
   };
 
 void fga_session_close(fga_session *Z)
@@ -60,7 +61,7 @@ void fga_session_close(fga_session *Z)
   fga_dev_close(Z->dev);
   fga_gix_close(Z->x2); fga_gix_close(Z->x1);
   fga_gdb_close(Z->g2); fga_gdb_close(Z->g1);
-  free(Z->cuts);
+  free(Z->cuts); free(Z->scount);
   free(Z);
 }
 
@@ -254,8 +255,12 @@ int fga_session_merge(fga_session *Z, const fga_run_params *P, int64_t prefix_be
   }
   if (Z->nranks > 1)                     /* a sliced session can only merge (part of) its own prefix range */
     { const int64_t lo = Z->cuts[Z->rank], hi = Z->cuts[Z->rank+1];
-      if (prefix_begin == 0 && prefix_end == 0 && hi > lo)
-        { prefix_begin = lo; prefix_end = hi; }
+      if (prefix_begin == 0 && prefix_end == 0)
+        { if (hi > lo)
+            { prefix_begin = lo; prefix_end = hi; }
+          else                                  /* an empty range of its own: the table is a placeholder slice of another */
+            prefix_begin = prefix_end = lo >= 1 ? lo : 1;      /* rank's prefixes; (0,0) would read as "everything" */
+        }
       if (!(prefix_begin == prefix_end) && (prefix_begin < lo || prefix_end > hi))
         { fga_set_error("the session holds the 12-mer prefixes [%lld,%lld) of the tables, the merge asks for [%lld,%lld)",
                         (long long) lo,(long long) hi,(long long) prefix_begin,(long long) prefix_end);
@@ -292,6 +297,16 @@ int fga_session_merge(fga_session *Z, const fga_run_params *P, int64_t prefix_be
       rc = fga_seed_merge_append(dev,Z->d2,Z->d1,&mp,seeds);
       if (rc) goto fail;
       if (S != NULL) S->merge_kernel_ms += fga_dev_stage_ms(dev,FGA_STAGE_MERGE);
+    }
+  if (P->reference_threads > 0)          /* the reference's buck[] per stream: what its search threads' ranges are cut from */
+    { const int nctg = x1->nctg;
+      int64_t *c = malloc(sizeof(int64_t)*2*nctg);
+      int j;
+      if (c == NULL || (Z->scount == NULL && (Z->scount = calloc(2*(size_t) nctg,sizeof(int64_t))) == NULL))
+        { free(c); fga_set_error("out of memory"); goto fail; }
+      if (fga_seeds_strand_histogram(dev,seeds,nctg,c)) { free(c); goto fail; }
+      for (j = 0; j < 2*nctg; j++) Z->scount[j] += c[j];
+      free(c);
     }
   if (S != NULL)
     { int64_t n = fga_seeds_count(seeds), l = fga_seeds_plen_sum(seeds);
@@ -434,13 +449,55 @@ oom:
 }
 
 /* phase 3 for a set in final order: .1aln, PAF / PSL */
-static int finish_output(fga_session *Z, const fga_run_params *P, const fga_alns *fin, fga_run_stats *st)
+/* records that tie on (aread, abpos) in the order FastGA -T<reference_threads> writes them (fga_order.c) */
+static int reference_order(fga_session *Z, const fga_run_params *P, fga_alns *fin)
+{ const fga_gdb *g1 = Z->g1, *g2 = Z->self ? Z->g1 : Z->g2;
+  const fga_gix *x1 = Z->x1, *x2 = Z->self ? Z->x1 : Z->x2;
+  const int T = P->reference_threads;
+  int nc = x1->nctg, j, rc = 1, swide, dbyte = 0;
+  int64_t *clen = NULL, *cnt = NULL, amx = 0, bmx = 0, cum = 1;
+  int *slot = NULL, *invp = NULL;
+  if (Z->scount == NULL)
+    { fga_set_error("reference order wanted, but no merge of this session counted its seeds per strand (reference_threads "
+                    "must be set for fga_session_merge too, or fga_session_set_strand_counts called)");
+      return 1;
+    }
+  if (nc < T) nc = T;                                  /* short_GDB_fix: at least one contig per thread */
+  if (nc < g1->ncontig) nc = g1->ncontig;
+  clen = malloc(sizeof(int64_t)*nc); cnt = calloc(2*(size_t) nc,sizeof(int64_t));
+  slot = malloc(sizeof(int)*2*nc); invp = malloc(sizeof(int)*nc);
+  if (clen == NULL || cnt == NULL || slot == NULL || invp == NULL)
+    { fga_set_error("out of memory"); goto done; }
+  for (j = 0; j < nc; j++)
+    { clen[j] = (j < x1->nctg && x1->perm[j] < g1->ncontig) ? g1->contigs[x1->perm[j]].clen : FGA_KMER;
+      invp[j] = 0;
+      if (clen[j] > amx) amx = clen[j];
+    }
+  for (j = 0; j < x1->nctg; j++)
+    { if (x1->perm[j] < g1->ncontig) invp[x1->perm[j]] = j;
+      cnt[j] = Z->scount[j]; cnt[nc + j] = Z->scount[x1->nctg + j];
+    }
+  bmx = g2->maxctg;
+  if (x2->nctg > g2->ncontig && bmx < FGA_KMER) bmx = FGA_KMER;
+  if (Z->self) bmx = amx;
+  while (cum < amx + bmx) { cum *= 256; dbyte += 1; }              /* DBYTE (FastGA.c:5040-5046) */
+  swide = 2*dbyte + x2->contbytes + 2;                             /* FastGA.c:4190 */
+  if (fga_reference_slots(cnt,clen,nc,T,swide,slot)) goto done;
+  rc = fga_alns_reference_order(fin,slot,invp,nc);
+done:
+  free(clen); free(cnt); free(slot); free(invp);
+  return rc;
+}
+
+static int finish_output(fga_session *Z, const fga_run_params *P, fga_alns *fin, fga_run_stats *st)
 { fga_gdb *g1 = Z->g1, *g2 = Z->g2;
   fga_dev *dev = Z->dev;
   const int self = Z->self;
   int64_t i;
   double t1;
 
+  if (P->reference_threads > 0 && reference_order(Z,P,fin))
+    return 1;
   st->nlive = fin->naln;
   for (i = 0; i < fin->naln; i++)
     st->cover += fin->alns[i].aepos - fin->alns[i].abpos;
@@ -544,6 +601,36 @@ done:
    are several): see fga_partition_contigs */
 int fga_session_nctg(const fga_session *Z) { return Z->x1->nctg; }
 
+int fga_session_strand_counts(const fga_session *Z, int64_t *counts)
+{ if (Z == NULL || counts == NULL)
+    { fga_set_error("fga_session_strand_counts: null argument");
+      return 1;
+    }
+  if (Z->scount == NULL)
+    memset(counts,0,sizeof(int64_t)*2*Z->x1->nctg);
+  else
+    memcpy(counts,Z->scount,sizeof(int64_t)*2*Z->x1->nctg);
+  return 0;
+}
+
+int fga_session_set_strand_counts(fga_session *Z, const int64_t *counts)
+{ if (Z == NULL || counts == NULL)
+    { fga_set_error("fga_session_set_strand_counts: null argument");
+      return 1;
+    }
+  if (Z->scount == NULL && (Z->scount = malloc(sizeof(int64_t)*2*Z->x1->nctg)) == NULL)
+    { fga_set_error("out of memory");
+      return 1;
+    }
+  memcpy(Z->scount,counts,sizeof(int64_t)*2*Z->x1->nctg);
+  return 0;
+}
+
+void fga_session_clear_strand_counts(fga_session *Z)       /* before the merges of a new comparison on the same session */
+{ if (Z != NULL && Z->scount != NULL)
+    memset(Z->scount,0,sizeof(int64_t)*2*Z->x1->nctg);
+}
+
 int fga_session_prefix_cuts(fga_session *Z, int nshards, int64_t *cuts)
 { if (Z->nranks > 1)                     /* a sliced session: the ranges it was opened with */
     { if (nshards != Z->nranks)
@@ -574,6 +661,7 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
 
   memset(&st,0,sizeof(st));
   st.load_s = Z->load_s; st.upload_s = Z->upload_s;
+  fga_session_clear_strand_counts(Z);
   if (fga_session_merge(Z,P,0,0,&seeds,&st)) goto done;
   fga_note("run: seed merge (incl. buffers)",tstart);
   { int64_t n = fga_seeds_count(seeds);

@@ -18,26 +18,29 @@
 #define SH_MAXP  64                  // parts
 
 __global__ __launch_bounds__(SH_T)
-void seed_contig_hist_kernel(const fga_seed *seeds, int64_t n, int nctg, unsigned long long *counts, const uint16_t *valid)
+void seed_contig_hist_kernel(const fga_seed *seeds, int64_t n, int nctg, int strands, unsigned long long *counts, const uint16_t *valid)
 { __shared__ unsigned int h[SH_LDSH];
-  const bool lds = nctg <= SH_LDSH;
+  const int nh = strands ? 2*nctg : nctg;       // strands: the C-stream seeds are counted in a second row of nctg counters
+  const bool lds = nh <= SH_LDSH;
   if (lds)
-    { for (int c = threadIdx.x; c < nctg; c += SH_T) h[c] = 0;
+    { for (int c = threadIdx.x; c < nh; c += SH_T) h[c] = 0;
       __syncthreads();
     }
   // a workgroup takes consecutive 16 KB stretches; its LDS counters cannot overflow (< 2^32 seeds per workgroup)
   for (int64_t i = (int64_t) blockIdx.x*SH_T + threadIdx.x; i < n; i += (int64_t) gridDim.x*SH_T)
     { if (valid != NULL && (int) (i & 1023) >= (int) valid[i >> 10])       // a hole of the merge kernel's block allocation
         continue;
-      const uint32_t c = seeds[i].actg >> 8;
+      const fga_seed s = seeds[i];
+      uint32_t c = s.actg >> 8;
       if (c < (uint32_t) nctg)
-        { if (lds) atomicAdd(h+c,1u);
+        { if (strands && (s.bctg >> 31)) c += (uint32_t) nctg;
+          if (lds) atomicAdd(h+c,1u);
           else     atomicAdd(counts+c,1ull);
         }
     }
   if (lds)
     { __syncthreads();
-      for (int c = threadIdx.x; c < nctg; c += SH_T)
+      for (int c = threadIdx.x; c < nh; c += SH_T)
         if (h[c] != 0) atomicAdd(counts+c,(unsigned long long) h[c]);
     }
 }
@@ -89,13 +92,24 @@ void seed_part_scatter_kernel(const fga_seed *seeds, int64_t n, const int *selec
 
 extern "C" const void *fga_seeds_device_ptr(const fga_dseeds *S) { return S == NULL ? NULL : S->seeds; }
 
+static int seeds_histogram(fga_dev *dev, const fga_dseeds *S, int nctg, int strands, int64_t *counts);
+
 extern "C" int fga_seeds_contig_histogram(fga_dev *dev, const fga_dseeds *S, int nctg, int64_t *counts)
-{ if (dev == NULL || S == NULL || counts == NULL || nctg <= 0)
+{ return seeds_histogram(dev,S,nctg,0,counts); }
+
+// the same per strand: counts[u*nctg + j] = seeds of stream u (0: N, 1: C) whose A contig is j -- the reference's buck[]
+// of its N_Units / C_Units (FastGA.c:933-984), what rmsd_sort cuts the search threads' ranges from (fga_order.c)
+extern "C" int fga_seeds_strand_histogram(fga_dev *dev, const fga_dseeds *S, int nctg, int64_t *counts)
+{ return seeds_histogram(dev,S,nctg,1,counts); }
+
+static int seeds_histogram(fga_dev *dev, const fga_dseeds *S, int nctg_, int strands, int64_t *counts)
+{ if (dev == NULL || S == NULL || counts == NULL || nctg_ <= 0)
     { fga_set_error("fga_seeds_contig_histogram: bad argument");
       return 1;
     }
   FGA_HIP(hipSetDevice(dev->device));
   const int64_t n = fga_seeds_extent(S);
+  const int nctg = strands ? 2*nctg_ : nctg_;          // counters
   unsigned long long *d = (unsigned long long *) fga_dev_acquire(dev,SLOT_MISC,sizeof(unsigned long long)*(size_t) nctg);
   if (d == NULL)
     { fga_set_error("fga_seeds_contig_histogram: device allocation failed");
@@ -105,7 +119,7 @@ extern "C" int fga_seeds_contig_histogram(fga_dev *dev, const fga_dseeds *S, int
   if (n > 0)
     { int64_t wg = (n + SH_TILE - 1) / SH_TILE;
       if (wg > (int64_t) dev->ncu*8) wg = (int64_t) dev->ncu*8;
-      hipLaunchKernelGGL(seed_contig_hist_kernel,dim3((unsigned) wg),dim3(SH_T),0,dev->stream,S->seeds,n,nctg,d,S->valid);
+      hipLaunchKernelGGL(seed_contig_hist_kernel,dim3((unsigned) wg),dim3(SH_T),0,dev->stream,S->seeds,n,nctg_,strands,d,S->valid);
     }
   hipError_t e = hipMemcpyAsync(counts,d,sizeof(int64_t)*(size_t) nctg,hipMemcpyDeviceToHost,dev->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);

@@ -367,6 +367,8 @@ void os_pass_kernel(const void *in, uint4 *out, int64_t n, int shift, int next_s
     unsigned long long *mine = status + (size_t) tile*256 + tid;
     if (tile > 0)
       __hip_atomic_store(mine,OS_PACK(stamp,OS_LOCAL,run),__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
+    // (Requesting the status entries of 4 / 8 / 16 predecessors together instead of one per step -- a step is a dependent
+    //  agent-scope load -- changes nothing at 48.6 M keys and costs 2-20 % at 0.55 G: the walk is not what bounds a pass.)
     unsigned long long excl = 0;
     for (int t = tile-1; t >= 0; t--)
       { const unsigned long long *p = status + (size_t) t*256 + tid;
@@ -433,7 +435,7 @@ static void os_sort(fga_dev *dev, const void *first, bool from_seeds, int64_t ne
       const int nt = (int) ((m + OS_TILE - 1) / OS_TILE);
       unsigned long long *hc = hist[p & 1], *hn = (p+1 < npass) ? hist[(p+1) & 1] : NULL;
       hipLaunchKernelGGL(os_scan256_kernel,dim3(1),dim3(256),0,dev->stream,hc,gbase,hn,ticket);
-      if (p == 0 && from_seeds)
+if (p == 0 && from_seeds)
         hipLaunchKernelGGL(os_pass_kernel<true>,dim3(nt),dim3(ST),0,dev->stream,src,dst,m,shift,shift+8,L,p+1,gbase,status,hn,ticket,valid);
       else
         hipLaunchKernelGGL(os_pass_kernel<false>,dim3(nt),dim3(ST),0,dev->stream,src,dst,m,shift,shift+8,L,p+1,gbase,status,hn,ticket,
@@ -696,25 +698,13 @@ extern "C" int fga_shim_rmsd_sort(uint8_t *array, int64_t nelem, int rsize, int 
       return -1;
     }
   const int64_t asize = nelem*rsize;
-  // the reference's thread ranges: consecutive panels of about asize/nthreads bytes each (RSDsort.c:318-343)
+  // the reference's thread ranges: consecutive panels of about asize/nthreads bytes each (RSDsort.c:318-343; fga_order.c)
   int n = 0;
-  { int64_t thr = asize / nthreads, sum = 0, off = 0;
-    int x = 0, beg;
-    while (x < nparts && part[x] <= 0) x += 1;
-    beg = x;
-    for (; x < nparts; x++)
-      if (part[x] > 0)
-        { sum += part[x];
-          if (sum >= thr && n < nthreads)
-            { range[n].beg = beg; range[n].end = x+1; range[n].off = off;
-              n += 1;
-              thr = (asize * (n+1)) / nthreads;
-              beg = x+1;
-              off = sum;
-            }
-        }
-    for (x = n; x < nthreads; x++)
-      { range[x].beg = range[x].end = (n > 0 ? range[n-1].end : 0); range[x].off = asize; }
+  { std::vector<int> rb((size_t) nthreads), re((size_t) nthreads);
+    std::vector<int64_t> ro((size_t) nthreads);
+    n = fga_rmsd_ranges(part,nparts,asize,nthreads,rb.data(),re.data(),ro.data());
+    for (int x = 0; x < nthreads; x++)
+      { range[x].beg = rb[(size_t) x]; range[x].end = re[(size_t) x]; range[x].off = ro[(size_t) x]; }
   }
   if (nelem == 0)
     return n;

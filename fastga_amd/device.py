@@ -306,13 +306,14 @@ def trace_pts(dev, ga, gb, alns, tb, tspace=100, self_cmp=False):
 
 def run(root1, root2=None, out_path=None, device=0, freq=10, soft_mask=False, symmetric=False, chain_break=1000,
         chain_min=85, align_min=100, identity=0.7, nthreads=8, command_line="FastGA", paf_path=None, paf_flags=0,
-        pass_seeds=0):
-    """The whole hot path (fga_run): prebuilt GDB/GIX roots in, .1aln (and PAF) out.  Returns the stats as a dict."""
+        pass_seeds=0, reference_threads=0):
+    """The whole hot path (fga_run): prebuilt GDB/GIX roots in, .1aln (and PAF) out.  Returns the stats as a dict.
+    reference_threads = n > 0: records that tie on (aread, abpos) in the order `FastGA -T<n>` writes them."""
     from .lib import RunParams, RunStats
     L = load_library()
     prm = RunParams(device, freq, int(soft_mask), int(symmetric), 2 * chain_break, 2 * chain_min, align_min,
                     1.0 - identity, nthreads, out_path.encode() if out_path else None, command_line.encode(),
-                    paf_path.encode() if paf_path else None, paf_flags, pass_seeds)
+                    paf_path.encode() if paf_path else None, paf_flags, pass_seeds, reference_threads)
     st = RunStats()
     check(L.fga_run(root1.encode(), root2.encode() if root2 else None, C.byref(prm), C.byref(st)), "fga_run")
     return {n: getattr(st, n) for n, _ in RunStats._fields_}
@@ -339,11 +340,11 @@ class Session:
 
     def run(self, out_path=None, freq=10, soft_mask=False, symmetric=False, chain_break=1000, chain_min=85,
             align_min=100, identity=0.7, nthreads=8, command_line="FastGA", paf_path=None, paf_flags=0,
-            pass_seeds=0):
+            pass_seeds=0, reference_threads=0):
         from .lib import RunParams, RunStats
         prm = RunParams(0, freq, int(soft_mask), int(symmetric), 2 * chain_break, 2 * chain_min, align_min,
                         1.0 - identity, nthreads, out_path.encode() if out_path else None, command_line.encode(),
-                        paf_path.encode() if paf_path else None, paf_flags, pass_seeds)
+                        paf_path.encode() if paf_path else None, paf_flags, pass_seeds, reference_threads)
         st = RunStats()
         check(self.L.fga_session_run(self.h, C.byref(prm), C.byref(st)), "session run")
         return {n: getattr(st, n) for n, _ in RunStats._fields_}
@@ -351,11 +352,11 @@ class Session:
     # ---- the three stages of run(), for one comparison cut into A-contig parts (fastga_amd/parallel.py) ----
     def params(self, out_path=None, freq=10, soft_mask=False, symmetric=False, chain_break=1000, chain_min=85,
                align_min=100, identity=0.7, nthreads=8, command_line="FastGA", paf_path=None, paf_flags=0,
-               pass_seeds=0):
+               pass_seeds=0, reference_threads=0):
         from .lib import RunParams
         return RunParams(0, freq, int(soft_mask), int(symmetric), 2 * chain_break, 2 * chain_min, align_min,
                          1.0 - identity, nthreads, out_path.encode() if out_path else None, command_line.encode(),
-                         paf_path.encode() if paf_path else None, paf_flags, pass_seeds)
+                         paf_path.encode() if paf_path else None, paf_flags, pass_seeds, reference_threads)
 
     def new_stats(self):
         from .lib import RunStats
@@ -376,6 +377,20 @@ class Session:
         check(self.L.fga_session_merge(self.h, C.byref(prm), prefix_begin, prefix_end, C.byref(h), C.byref(stats)),
               "session merge")
         return Seeds(self.dev_wrapper(), h)
+
+    def strand_counts(self):
+        """seeds per (strand, A contig) the merges of this session have counted (reference order only)"""
+        cnt = np.zeros(2 * self.nctg, dtype=np.int64)
+        check(self.L.fga_session_strand_counts(self.h, cnt.ctypes.data_as(C.POINTER(C.c_int64))), "strand counts")
+        return cnt
+
+    def set_strand_counts(self, cnt):
+        cnt = np.ascontiguousarray(cnt, dtype=np.int64)
+        assert len(cnt) == 2 * self.nctg
+        check(self.L.fga_session_set_strand_counts(self.h, cnt.ctypes.data_as(C.POINTER(C.c_int64))), "strand counts")
+
+    def clear_strand_counts(self):
+        self.L.fga_session_clear_strand_counts(self.h)
 
     def contig_histogram(self, seeds):
         cnt = np.zeros(self.nctg, dtype=np.int64)

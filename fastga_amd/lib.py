@@ -83,7 +83,7 @@ class RunParams(C.Structure):
                 ("chain_break", C.c_int), ("chain_min", C.c_int), ("align_min", C.c_int),
                 ("align_rate", C.c_double), ("nthreads", C.c_int), ("out_path", C.c_char_p),
                 ("command_line", C.c_char_p), ("paf_path", C.c_char_p), ("paf_flags", C.c_int),
-                ("pass_seeds", C.c_int64)]
+                ("pass_seeds", C.c_int64), ("reference_threads", C.c_int)]
 
 
 class RunStats(C.Structure):
@@ -207,6 +207,12 @@ def _declare(L):
         "fga_seeds_device_ptr": (vp, [vp]),
         "fga_merge_prefix_cuts": (i32, [vp, vp, vp, i32, P(i64)]),
         "fga_session_prefix_cuts": (i32, [vp, i32, P(i64)]),
+        "fga_session_strand_counts": (i32, [vp, P(i64)]),
+        "fga_session_set_strand_counts": (i32, [vp, P(i64)]),
+        "fga_session_clear_strand_counts": (None, [vp]),
+        "fga_seeds_strand_histogram": (i32, [vp, vp, i32, P(i64)]),
+        "fga_rmsd_ranges": (i32, [P(i64), i32, i64, i32, P(i32), P(i32), P(i64)]),
+        "fga_reference_slots": (i32, [P(i64), P(i64), i32, i32, i32, P(i32)]),
         "fga_alns_concat": (i32, [P(P(Alns)), i32, P(P(Alns))]),
         "fga_dev_upload": (i32, [vp, vp, vp, C.c_size_t]),
         "fga_session_open_sliced": (i32, [cp, cp, i32, i32, i32, i32, P(vp)]),

@@ -122,7 +122,8 @@ def gather_records(dist, recs, tb, counts, device, dst=0):
 
 def run_sharded(ses, dist, prm_kwargs, device):
     """One pass of the hot path over the session's resident inputs, cut over dist's ranks.  Every rank holds both
-    tables and genomes (replicated: 2 x 33 GB at 3 Gbp fits each GPU's 288 GB several times over).  Returns the stats
+    genomes' bases (phase 2 needs them) and, with a sliced session (Session(rank=, nranks=)), only its own 12-mer prefix
+    range of the two tables; an unsliced session holds the whole tables and merges its range of them.  Returns the stats
     dict on every rank; rank 0's has the totals of the finished run (nlive, cover) and wrote the output.
     device = "cuda:<n>" with backend nccl (RCCL: the exchange buffers are device tensors), or "cpu" with backend gloo
     (records staged through the host; how tests/test_parts_gpu.py runs this very function with two ranks on one GPU)."""
@@ -136,9 +137,15 @@ def run_sharded(ses, dist, prm_kwargs, device):
     prm = ses.params(**kw)
     st = ses.new_stats()
     cuts = prefix_cuts(ses, world)
+    ses.clear_strand_counts()
     seeds = ses.merge(prm, st, int(cuts[rank]), int(cuts[rank + 1]))
     n = seeds.count
+    # the library keeps the device memory it is done with for reuse; what RCCL and torch allocate on their first
+    # collective comes from the driver, so idle regions go back first (only regions that are entirely free are returned)
+    ses.trim()
     hist = all_reduce_counts(dist, ses.contig_histogram(seeds), device)
+    if kw.get("reference_threads", 0) > 0:        # the reference's tie order needs the per-strand counts of ALL ranges
+        ses.set_strand_counts(all_reduce_counts(dist, ses.strand_counts(), device))
     select = partition_contigs(hist, world)
     host = str(device) == "cpu"          # gloo: the collectives move host tensors, the records are staged through the host
     if host:
@@ -214,6 +221,7 @@ def run_parts_on_one_gpu(ses, nparts, **prm_kwargs):
     prm = ses.params(**prm_kwargs)
     st = ses.new_stats()
     cuts = prefix_cuts(ses, nparts)
+    ses.clear_strand_counts()                                 # the "ranks" share the session: their counts add up in it
     sends, offs, hist = [], [], np.zeros(ses.nctg, dtype=np.int64)
     merged = []
     for r in range(nparts):                                   # "rank r": phase 1 on its prefix range

@@ -337,6 +337,9 @@ typedef struct
     int     paf_flags;       /* FGA_PAF_* (-pafm / -pafx / -pafs / -pafS)                 */
     int64_t pass_seeds;      /* most seeds one sort / search pass takes (0: 1.5 G); more -> phase 2 runs over A-contig
                                 parts, the reference's NPARTS loop (FastGA.c:5186-5204)  */
+    int     reference_threads; /* n > 0: records that tie on (aread, abpos) in the order `FastGA -T<n>` writes them -- by the
+                                slot of the search thread that held the A contig's panel of that strand (la_merge,
+                                FastGA.c:3906-3918; fga_reference_slots); 0: by (bread, strand, survival)           */
   } fga_run_params;
 
 typedef struct
@@ -362,6 +365,18 @@ int  fga_run(const char *root1, const char *root2 /* NULL: self */, const fga_ru
  *      needs all records of a contig pair together, and those all come from the part that owns the A contig.          */
 /* seeds per A contig (length-sorted index) of a seed buffer: the reference's buck[] counts */
 int  fga_seeds_contig_histogram(fga_dev *dev, const fga_dseeds *seeds, int nctg, int64_t *counts /* host, nctg */);
+/* the same per strand: counts[u*nctg + j], u = 0 (N stream) / 1 (C stream): the buck[] of the reference's N_Units / C_Units */
+int  fga_seeds_strand_histogram(fga_dev *dev, const fga_dseeds *seeds, int nctg, int64_t *counts /* host, 2*nctg */);
+/* ---- the reference's order of records that tie on (aread, abpos): replaces what la_sort + la_merge (FastGA.c:3800-3835,
+ *      3906-3918) make of the search threads' Range[] (rmsd_sort, RSDsort.c:318-343; FastGA.c:4336-4345) -- fga_order.c.
+ *      fga_rmsd_ranges     the panel ranges rmsd_sort cuts for `nthreads` threads (part[x] = bytes of panel x)
+ *      fga_reference_slots slot[u*nctg + j] = search thread of (strand u, A contig j) in `FastGA -T<nthreads>`, from the
+ *                          per-strand seed counts, the A contig lengths in index order and the sort record width
+ *      fga_alns_reference_order  a filtered set (aread, abpos, bread, comp, survival) -> (aread, abpos, slot, bread, ..) */
+int  fga_rmsd_ranges(const int64_t *part, int nparts, int64_t asize, int nthreads, int *beg, int *end, int64_t *off);
+int  fga_reference_slots(const int64_t *counts /* 2*nctg */, const int64_t *clen /* nctg */, int nctg, int nthreads, int swide,
+                         int *slot /* 2*nctg */);
+int  fga_alns_reference_order(fga_alns *alns, const int *slot, const int *invp /* original contig -> index order */, int nctg);
 /* select[c] = part of A contig c: heaviest contig first, each to the lightest part so far.  A pure function of its
    arguments (every rank computes the same map from the all-reduced counts) */
 int  fga_partition_contigs(const int64_t *weight, int nctg, int nparts, int *select);
@@ -402,6 +417,11 @@ int      fga_session_seed_bytes(const fga_session *s);    /* 1 + IBYTE + JBYTE o
 int64_t  fga_session_bases(const fga_session *s, int which);
 int      fga_session_nctg(const fga_session *s);          /* A contigs of the index (the partition's domain) */
 int      fga_session_prefix_cuts(fga_session *s, int nshards, int64_t *cuts /* nshards+1 */);
+/* per-strand seed counts of the A contigs (2 * fga_session_nctg values) that fga_session_merge has accumulated when
+   prm->reference_threads > 0; ranks of a sharded run add theirs up (all-reduce) and hand the sums to the rank that finishes */
+int      fga_session_strand_counts(const fga_session *s, int64_t *counts);
+int      fga_session_set_strand_counts(fga_session *s, const int64_t *counts);
+void     fga_session_clear_strand_counts(fga_session *s);     /* before the merges of a new comparison (fga_session_run does) */
 /* fga_session_run in its three stages (stats are accumulated into *stats, which the caller zeroes once):
  *   merge  : phase 1 over a 12-mer prefix range (0,0 = all)                      -> seeds in HBM
  *   align  : phase 2 on a set of seeds (consumed): sort, chain scan, extension   -> accepted alignments, unfiltered

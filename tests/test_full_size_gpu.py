@@ -4,9 +4,10 @@ self comparison, which the reference needs minutes for -- against a digest produ
 tests/golden/make_golden_config3.py.  Covers what the toy-size tests cannot: contig-long alignments (tens of thousands
 of wave steps), sequence windows falling back to HBM, arena growth, seed-buffer re-runs, the self + soft-mask mode.
 
-Identity is judged on ONEview's text: strict line equality where the reference's own order is deterministic, and
-fastga_amd.workload.digest_1aln (header, records as a multiset, (aread, abpos) order) where records of different
-reference threads tie on (aread, abpos) (la_merge orders those by thread slot, FastGA.c:3906-3918)."""
+Identity is judged on ONEview's text, line for line: the runs ask for the reference's own tie order (reference_threads =
+the reference's -T: records that tie on (aread, abpos) go by the slot of the search thread that held them, la_merge,
+FastGA.c:3906-3918; fga_order.c).  The 1 Gbp / 3 Gbp runs compare with digests made by the reference (header, records as a
+multiset, (aread, abpos) order; `lines_md5` = the record lines in sequence where the golden file has it)."""
 import ctypes as C
 import json
 import os
@@ -73,7 +74,7 @@ def _compare_with_reference(ra, rb, d, flags=(), strict=True, pafx=False, ref_th
         pytest.skip("oracle/_ref did not travel")
     ours = os.path.join(d, "ours.1aln")
     paf = os.path.join(d, "ours.paf") if pafx else None
-    st = D.run(ra, rb, ours, nthreads=T, paf_path=paf, paf_flags=2 if pafx else 0, **kw)
+    st = D.run(ra, rb, ours, nthreads=T, paf_path=paf, paf_flags=2 if pafx else 0, reference_threads=ref_threads, **kw)
     H.ref_fastga(ra, rb, d, os.path.join(d, "ref"), threads=ref_threads, flags=flags)
     a, b = H.oneview(ours), H.oneview(os.path.join(d, "ref.1aln"))
     da, db = workload.digest_1aln(a), workload.digest_1aln(b)
@@ -112,7 +113,7 @@ def test_config1_substitute_s1_86mbp_is_identical_to_the_reference(tmp_path_fact
     d = str(tmp_path_factory.mktemp("s1"))
     ra, rb = workload.build_config1_s1(d, threads=T, gix=False)
     _write_index_files((ra, rb), nthreads=8)
-    st, dg = _compare_with_reference(ra, rb, d, strict=False, ref_threads=8)
+    st, dg = _compare_with_reference(ra, rb, d, strict=True, ref_threads=8)
     assert dg["records"] > 5000 and st["nhits"] > 5000
 
 
@@ -135,7 +136,7 @@ def test_config3_150mbp_self_soft_masked_is_identical_to_the_reference(tmp_path_
     d = str(tmp_path_factory.mktemp("c3"))
     root = workload.build_config3(d, mbp=150.0, threads=T)
     _write_index_files((root,), use_mask=True)
-    st, dg = _compare_with_reference(root, None, d, flags=("-M",), strict=False, soft_mask=True)
+    st, dg = _compare_with_reference(root, None, d, flags=("-M",), strict=True, soft_mask=True)
     assert dg["records"] > 5000
 
 
@@ -151,7 +152,7 @@ def test_human_scale_contigs_3x94mbp_pair_is_identical_to_the_reference(tmp_path
     _write_index_files((ra, rb), nthreads=3)            # the reference wants -T <= the number of contigs
     os.environ["FGA_EXTEND_PROFILE"] = "1"
     try:
-        st, dg = _compare_with_reference(ra, rb, d, strict=False, ref_threads=3)
+        st, dg = _compare_with_reference(ra, rb, d, strict=True, ref_threads=3)
     finally:
         os.environ.pop("FGA_EXTEND_PROFILE", None)
     assert dg["records"] > 1000 and st["nwaves"] > 3_000_000
@@ -168,7 +169,7 @@ def test_human_scale_contigs_3x94mbp_at_10_percent_is_identical_to_the_reference
                                  inv_frac=0.02, swap_frac=0.02, threads=T, gix=False)
     _write_index_files((ra, rb), nthreads=3)
     t = time.time()
-    st, dg = _compare_with_reference(ra, rb, d, strict=False, ref_threads=3)
+    st, dg = _compare_with_reference(ra, rb, d, strict=True, ref_threads=3)
     print(f"human-scale 10 %: ours {1000*sum(st[k] for k in ('merge_s','sort_s','chain_s','extend_s','filter_s','write_s')):.0f} ms (extension kernel {st['extend_kernel_ms']:.0f} ms), "
           f"peak HBM {st['hbm_peak_bytes']/2**30:.1f} GiB, reference + ours {time.time()-t:.0f} s, {dg['records']} records")
     assert dg["records"] > 1000 and st["hbm_peak_bytes"] < 64 << 30

@@ -313,6 +313,11 @@ int main(int argc, char *argv[])
   if (ident < .55 || ident >= 1.)
     { fprintf(stderr,"FastGA: '-i' minimum alignment similarity must be in [0.55,1.0)\n"); return 1; }
   if (P.nthreads < 1) P.nthreads = 1;
+  /* records that tie on (aread, abpos) in the order the reference's FastGA -T<n> writes them (FGA_TIE_ORDER=own: by
+     (bread, strand, survival), which does not depend on -T) */
+  P.reference_threads = P.nthreads;
+  if (getenv("FGA_TIE_ORDER") != NULL && strcmp(getenv("FGA_TIE_ORDER"),"own") == 0)
+    P.reference_threads = 0;
   if (access(tmpdir,W_OK|X_OK) != 0)
     { fprintf(stderr,"FastGA: Cannot create temporary files in directory %s\n",tmpdir); return 1; }
   if (logpath != NULL && (Log = fopen(logpath,"a")) == NULL)
