@@ -110,7 +110,17 @@ hipError_t fga_pool_free(void *ptr)
       if (!P->core.holds(ptr))
         continue;
       lock.unlock();
-      (void) hipDeviceSynchronize();            // what hipFree does: nothing in flight refers to the piece any more
+      // what hipFree does: nothing in flight refers to the piece any more -- on the device that OWNS the piece, which need
+      // not be the calling thread's current one
+      { const int owner = d < 0 ? -1 : d;
+        int cur = -1;
+        if (owner >= 0 && hipGetDevice(&cur) == hipSuccess && cur != owner && hipSetDevice(owner) == hipSuccess)
+          { (void) hipDeviceSynchronize();
+            (void) hipSetDevice(cur);
+          }
+        else
+          (void) hipDeviceSynchronize();
+      }
       lock.lock();
       P->core.give(ptr);                        // (false if another thread released it meanwhile: nothing to do)
       return hipSuccess;

@@ -9,11 +9,17 @@
 //
 //   gix_scan_kernel      one workgroup per 2048 positions of a contig: unpacks the bases into LDS, canonical 8-mer codes,
 //                        sliding minimum over five codes -> syncmer starts; every (syncmer, strand) whose 40-mer fits the
-//                        contig becomes one 128-bit sort key  [80-bit k-mer | payload]  appended through one atomic per
-//                        workgroup; per-prefix counts and GIXmake's 5-base sample histogram (which decides the table
-//                        parts, hence where the lcp byte restarts at 0) by atomics
-//   fga_radix_sort_u128  the seed sort's LSD radix kernels on the significant key bits
-//   gix_index_*_kernel   inclusive scan of the 2^24 prefix counts -> the index
+//                        contig is one 128-bit key  [80-bit k-mer | payload].  Run twice: the first pass COUNTS -- per 12-mer
+//                        prefix, and GIXmake's 5-base sample histogram (which decides the table parts, hence where the lcp
+//                        byte restarts at 0) --, the second PLACES every key inside its prefix's panel of the final table
+//                        (slot = end of the panel - what an atomic counter of the panel hands out): the reference's own
+//                        MSD step (GIXmake.c distribution threads), the panels being known from the counts
+//   gix_index_*_kernel   inclusive scan of the 2^24 prefix counts -> the index (between the two scans)
+//   gix_tiles_kernel / gix_tile_sort_kernel   the panels are put in order in LDS: a workgroup takes the panels that start in
+//                        one 1024-key stretch of the table (<= 2048 keys), spreads them over 256 buckets by the leading 8 bits
+//                        in which the stretch's keys differ (an LDS counting pass) and ranks every key inside its bucket by
+//                        comparison; panels beyond 2048 keys (low-complexity sequence) go to a list and through the seed sort's
+//                        LSD radix passes.  13 global radix passes over all keys (0.45 s per 3 Gbp genome) are gone.
 //   gix_entries_kernel   one thread per sorted key: lcp with its predecessor (0 at a part start), on-disk entry bytes
 #include "fga_device.hpp"
 
@@ -32,7 +38,8 @@ struct gix_scan_args
     const int     *invp;            // original contig -> length-sorted index
     const gix_item *items; int nitems;
     int postbytes, contbytes;
-    uint4 *keys; int64_t cap;          // keys == NULL: count only (per-prefix counts and the sample histogram)
+    uint4 *keys;                       // NULL: the counting pass (per-prefix counts, the sample histogram, the number of keys);
+    const int64_t *index;              // else the placing pass: key -> keys[index[prefix] - (what is left of count[prefix])]
     uint32_t pbeg, pend;               // only k-mers whose 12-mer prefix lies in [pbeg,pend) are kept (a rank's slice)
     unsigned long long *nkeys;
     uint32_t *count;                // [2^24]
@@ -50,7 +57,6 @@ void gix_scan_kernel(gix_scan_args A)
   __shared__ uint16_t v8[GCH + 8];            // canonical 8-mer code at j0 + x
   __shared__ uint32_t sh[1024];
   __shared__ int      wtot[GNT/64];
-  __shared__ unsigned long long gbase;
 
   const int tid = threadIdx.x;
   for (int x = tid; x < 1024; x += GNT)
@@ -109,8 +115,10 @@ void gix_scan_kernel(gix_scan_args A)
         { f12 = (f12 << 2) | s[x+k];
           c12 = (c12 << 2) | (3u - s[x+11-k]);
         }
-      atomicAdd(&sh[f12 >> 14],1u);
-      atomicAdd(&sh[c12 >> 14],1u);
+      if (A.keys == NULL)
+        { atomicAdd(&sh[f12 >> 14],1u);
+          atomicAdd(&sh[c12 >> 14],1u);
+        }
       if (j <= len - FGA_KMER && f12 >= A.pbeg && f12 < A.pend)
         { fmask |= 1u << r; cnt += 1;
           if (A.keys == NULL) atomicAdd(A.count + f12,1u);
@@ -121,26 +129,20 @@ void gix_scan_kernel(gix_scan_args A)
         }
     }
 
-  // slots: block exclusive scan, one global atomic per workgroup
-  int inc = cnt;
-  for (int d = 1; d < 64; d <<= 1)
-    { const int y = __shfl_up(inc,d,64);
-      if ((tid & 63) >= d) inc += y;
+  if (A.keys == NULL)                               // counting pass: the number of keys, one global atomic per workgroup
+    { int inc = cnt;
+      for (int d = 1; d < 64; d <<= 1)
+        inc += __shfl_xor(inc,d,64);
+      if ((tid & 63) == 0)
+        wtot[tid >> 6] = inc;
+      __syncthreads();
+      if (tid == 0)
+        { int total = 0;
+          for (int w = 0; w < GNT/64; w++) total += wtot[w];
+          if (total > 0) atomicAdd(A.nkeys,(unsigned long long) total);
+        }
+      continue;
     }
-  if ((tid & 63) == 63)
-    wtot[tid >> 6] = inc;
-  __syncthreads();
-  int base = inc - cnt, total = 0;
-  for (int w = 0; w < GNT/64; w++)
-    { if (w < (tid >> 6)) base += wtot[w];
-      total += wtot[w];
-    }
-  if (tid == 0)
-    gbase = total > 0 ? atomicAdd(A.nkeys,(unsigned long long) total) : 0ull;
-  __syncthreads();
-  int64_t at = (int64_t) gbase + base;
-  if (A.keys == NULL)                               // count only: the sample histogram is all that is left to do
-    continue;
 
   const uint64_t ctg = (uint64_t) A.invp[c];
   const uint64_t sign = 0x80ull << (8*(A.contbytes-1));
@@ -165,17 +167,18 @@ void gix_scan_kernel(gix_scan_args A)
           const uint64_t pay = strand ? ((uint64_t) (j+12) | ((ctg | sign) << (8*A.postbytes)))
                                       : ((uint64_t) j | (ctg << (8*A.postbytes)));
           const uint64_t lo = ((uint64_t) lo16 << 48) | (pay << (48 - 8*(A.postbytes+A.contbytes)));    // payload left-aligned under the k-mer: the significant key bits are contiguous
-          atomicAdd(A.count + (uint32_t) (hi >> 40),1u);
-          if (at < A.cap)
-            A.keys[at] = make_uint4((uint32_t) lo,(uint32_t) (lo >> 32),(uint32_t) hi,(uint32_t) (hi >> 32));
-          at += 1;
+          // into its panel: the panel [index[p] - count[p], index[p]) fills from the end (the order inside it is made below)
+          const uint32_t p = (uint32_t) (hi >> 40);
+          const uint32_t left = atomicSub(A.count + p,1u);
+          A.keys[A.index[p] - (int64_t) left] = make_uint4((uint32_t) lo,(uint32_t) (lo >> 32),(uint32_t) hi,(uint32_t) (hi >> 32));
         }
     }
   }
   __syncthreads();
-  for (int x = tid; x < 1024; x += GNT)
-    if (sh[x] != 0)
-      atomicAdd(A.sbuck + x,(unsigned long long) sh[x]);
+  if (A.keys == NULL)
+    for (int x = tid; x < 1024; x += GNT)
+      if (sh[x] != 0)
+        atomicAdd(A.sbuck + x,(unsigned long long) sh[x]);
 }
 
 // ---- prefix counts -> inclusive int64 index (three small kernels over 2^24 counters) ----
@@ -235,6 +238,156 @@ void gix_index_write_kernel(const uint32_t *count, const unsigned long long *sum
     { run += c[q]; o[threadIdx.x*16 + q] = (int64_t) run; }
   if (mx > 0)
     atomicMax(maxpre,mx);
+}
+
+// ---- the panels put in order: LDS sort of the panels that start in one stretch of the table ----
+#define GT_T    1024          // a tile: the panels that START in [b*GT_T, (b+1)*GT_T) of the table
+#define GT_CAP  2048          // keys one workgroup orders in LDS at a time (every panel of a tile but the last ends inside the stretch)
+#define GT_NT   256
+
+struct gix_tile { int64_t lo, last; uint32_t pfirst, plast; };    // first key of the tile; first key and prefix of its last panel; prefix of its first
+struct gix_over { int64_t start, count; };                        // a panel beyond GT_CAP keys
+
+__device__ __forceinline__ int64_t gix_excl(const int64_t *index, int64_t p) { return p <= 0 ? 0 : index[p-1]; }
+
+// tile b = the panels that start in [b*GT_T, (b+1)*GT_T): tiles[b].lo = start of the first of them (tiles[b+1].lo is where the
+// tile ends; tiles[ntiles].lo = n), the last non-empty one and the prefixes the tile spans
+__global__ __launch_bounds__(256)
+void gix_tiles_kernel(const int64_t *index, int64_t n, int64_t ntiles, gix_tile *tiles)
+{ const int64_t b = (int64_t) blockIdx.x*256 + threadIdx.x;
+  if (b > ntiles)
+    return;
+  int64_t lo[2];
+  for (int k = 0; k < 2; k++)                        // smallest p in [0, 2^24] with excl(p) >= (b+k)*GT_T
+    { const int64_t v = (b+k)*GT_T;
+      int64_t a = 0, e = FGA_NPREFIX;
+      while (a < e)
+        { const int64_t m = (a+e) >> 1;
+          if (gix_excl(index,m) >= v) e = m; else a = m+1;
+        }
+      lo[k] = gix_excl(index,a);
+    }
+  gix_tile t;
+  t.lo = lo[0]; t.last = lo[0]; t.pfirst = t.plast = 0;
+  if (lo[1] > lo[0])
+    { int64_t a = 0, e = FGA_NPREFIX-1;               // the last panel: smallest p with index[p] >= lo[1]
+      while (a < e)
+        { const int64_t m = (a+e) >> 1;
+          if (index[m] >= lo[1]) e = m; else a = m+1;
+        }
+      t.plast = (uint32_t) a; t.last = gix_excl(index,a);
+      a = 0; e = FGA_NPREFIX-1;                       // the first one: smallest p with index[p] > lo[0]
+      while (a < e)
+        { const int64_t m = (a+e) >> 1;
+          if (index[m] > lo[0]) e = m; else a = m+1;
+        }
+      t.pfirst = (uint32_t) a;
+    }
+  tiles[b] = t;
+}
+
+__device__ __forceinline__ bool gix_key_less(const uint4 &a, const uint4 &b)
+{ const uint64_t ah = ((uint64_t) a.w << 32) | a.z, bh = ((uint64_t) b.w << 32) | b.z;
+  const uint64_t al = ((uint64_t) a.y << 32) | a.x, bl = ((uint64_t) b.y << 32) | b.x;
+  return ah < bh || (ah == bh && al < bl);
+}
+
+// keys[0..m) (m <= GT_CAP) of the prefixes [pfirst, plast] into ascending order.  One counting pass in LDS on the leading 8
+// bits in which keys of these prefixes can differ (the prefix bits that vary, then the first bases of the suffix), then every
+// key's rank inside its bucket by comparison with the bucket's other keys (a handful; the lanes of a wavefront sit in the
+// same or neighbouring buckets and read the same LDS words).  Keys are distinct (the payload is a position).
+__device__ void gix_lds_sort(uint4 *keys, int m, uint32_t pfirst, uint32_t plast, uint4 *bufA, uint4 *bufB,
+                             uint32_t *cnt, uint32_t *bs, uint32_t *fill, uint32_t *wsum)
+{ const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t span = plast - pfirst;
+  const int sh = 32 + (span == 0 ? 0 : 32 - __clz((int) span));       // (hi - (pfirst << 40)) >> sh < 256
+  const uint64_t base = (uint64_t) pfirst << 40;
+  cnt[tid] = 0;
+  __syncthreads();
+  for (int x = tid; x < m; x += GT_NT)
+    { const uint4 k = keys[x];
+      bufA[x] = k;
+      const uint64_t hi = ((uint64_t) k.w << 32) | k.z;
+      atomicAdd(&cnt[(uint32_t) ((hi - base) >> sh) & 255u],1u);
+    }
+  __syncthreads();
+  { const uint32_t c = cnt[tid];
+    uint32_t inc = c;
+    #pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+      { const uint32_t y = __shfl_up(inc,d,64);
+        if (lane >= d) inc += y;
+      }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t off = 0;
+    for (int w = 0; w < wave; w++) off += wsum[w];
+    bs[tid] = off + inc - c; fill[tid] = off + inc - c;
+    if (tid == GT_NT-1) bs[GT_NT] = off + inc;
+  }
+  __syncthreads();
+  for (int x = tid; x < m; x += GT_NT)
+    { const uint4 k = bufA[x];
+      const uint64_t hi = ((uint64_t) k.w << 32) | k.z;
+      const uint32_t at = atomicAdd(&fill[(uint32_t) ((hi - base) >> sh) & 255u],1u);
+      bufB[at] = k;
+    }
+  __syncthreads();
+  for (int x = tid; x < m; x += GT_NT)
+    { const uint4 k = bufB[x];
+      const uint64_t hi = ((uint64_t) k.w << 32) | k.z;
+      const uint32_t d = (uint32_t) ((hi - base) >> sh) & 255u;
+      const int s = (int) bs[d], e = (int) bs[d+1];
+      int r = 0;
+      for (int j = s; j < e; j++)
+        { const uint4 q = bufB[j];
+          r += (gix_key_less(q,k) || (j < x && !gix_key_less(k,q))) ? 1 : 0;
+        }
+      bufA[s + r] = k;
+    }
+  __syncthreads();
+  for (int x = tid; x < m; x += GT_NT)
+    keys[x] = bufA[x];
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(GT_NT)
+void gix_tile_sort_kernel(uint4 *keys, const gix_tile *tiles, gix_over *over, unsigned int *nover)
+{ __shared__ uint4 bufA[GT_CAP], bufB[GT_CAP];
+  __shared__ uint32_t cnt[GT_NT], bs[GT_NT+1], fill[GT_NT], wsum[GT_NT/64];
+  const gix_tile t = tiles[blockIdx.x];
+  const int64_t hi = tiles[blockIdx.x+1].lo, m = hi - t.lo;
+  if (m <= 1)
+    return;
+  if (m <= GT_CAP)
+    { gix_lds_sort(keys + t.lo,(int) m,t.pfirst,t.plast,bufA,bufB,cnt,bs,fill,wsum);
+      return;
+    }
+  // the last panel reaches beyond the stretch: the panels before it (they end inside it: < GT_T keys), then the last one
+  if (t.last - t.lo > 1)
+    gix_lds_sort(keys + t.lo,(int) (t.last - t.lo),t.pfirst,t.plast > t.pfirst ? t.plast-1 : t.pfirst,bufA,bufB,cnt,bs,fill,wsum);
+  const int64_t s = hi - t.last;
+  if (s <= GT_CAP)
+    gix_lds_sort(keys + t.last,(int) s,t.plast,t.plast,bufA,bufB,cnt,bs,fill,wsum);
+  else if (threadIdx.x == 0)
+    { const unsigned int k = atomicAdd(nover,1u);
+      over[k].start = t.last; over[k].count = s;
+    }
+}
+
+// the panels beyond GT_CAP keys, gathered into one stretch (dir 0) / put back (dir 1): off[k] = first slot of panel k
+__global__ __launch_bounds__(256)
+void gix_over_copy_kernel(uint4 *keys, uint4 *scratch, const gix_over *over, const int64_t *off, int nover, int64_t total, int dir)
+{ for (int64_t i = (int64_t) blockIdx.x*256 + threadIdx.x; i < total; i += (int64_t) gridDim.x*256)
+    { int a = 0, e = nover-1;                          // largest k with off[k] <= i
+      while (a < e)
+        { const int m = (a+e+1) >> 1;
+          if (off[m] <= i) a = m; else e = m-1;
+        }
+      const int64_t src = over[a].start + (i - off[a]);
+      if (dir == 0) scratch[i] = keys[src];
+      else          keys[src] = scratch[i];
+    }
 }
 
 // ---- sorted keys -> on-disk entries ----
@@ -363,11 +516,14 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
   gix_item *ditems = NULL;
   uint32_t *dcount = NULL;
   unsigned long long *dctr = NULL;       // [0] keys, [1..1024] sbuck, then 4096 chunk sums, then maxpre
-  uint4 *buf0 = NULL, *buf1 = NULL, *sorted = NULL;
+  uint4 *buf0 = NULL, *sorted = NULL, *oscr = NULL;
+  gix_tile *dtiles = NULL;
+  gix_over *dover = NULL;
+  int64_t *dooff = NULL;
   unsigned scan_grid = 1;                  // workgroups of the scan kernel (each takes chunks in a stride)
   std::vector<gix_item> items;
   std::vector<int64_t> boff((size_t) G->ncontig), clen((size_t) G->ncontig);
-  int64_t cap = 0, nkeys = 0;
+  int64_t nkeys = 0, ntiles = 0;
   hipError_t e = hipSuccess;
   float ms = 0.f;
   double tn = 0.;
@@ -381,15 +537,7 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
     { boff[(size_t) c] = G->contigs[c].boff; clen[(size_t) c] = G->contigs[c].clen;
       for (int64_t j = 0; j + 12 <= G->contigs[c].clen; j += GCH)
         { gix_item it; it.ctg = c; it.j0 = (int) j; items.push_back(it); }
-      cap += G->contigs[c].clen;                      // 0.79 k-mers per base on sequence without structure (2/5 per strand)
     }
-  // the first guess for the two key buffers: 0.84 per base (what the scan finds beyond it -- low-complexity sequence: up to
-  // two per base -- is scanned again into buffers of the exact size, below); every GB less is a GB the driver need not hand out
-  cap = cap - (cap >> 3) - (cap >> 5) + 65536;
-  if (pend - pbeg < FGA_NPREFIX)                          // a slice: its share of the prefix space and half as much again
-    cap = (int64_t) ((double) cap * (double) (pend - pbeg) / FGA_NPREFIX * 1.5) + 65536;
-  if (count_only)
-    cap = 0;
   if (items.empty())
     { fga_set_error("fga_dgix_build: no contig is long enough to hold a syncmer");
       goto done;
@@ -405,16 +553,6 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
       (e = fga_dmalloc(&dpartid,1024)) != hipSuccess)
     { fga_set_error("fga_dgix_build: device allocation failed: %s",hipGetErrorString(e));
       goto done;
-    }
-  if (!count_only)
-    { // both key buffers in ONE piece of the device pool: what follows an index build (seeds, sort buffers, the trace-point
-      // pool of the extension) is then cut from one free stretch, not from two halves a larger request does not fit
-      buf0 = (uint4 *) fga_dev_acquire(dev,SLOT_SORT0,2*sizeof(uint4)*(size_t) cap);
-      buf1 = buf0 != NULL ? buf0 + cap : NULL;
-      if (buf0 == NULL || buf1 == NULL)
-        { fga_set_error("fga_dgix_build: device allocation of the key buffers failed");
-          goto done;
-        }
     }
   if ((e = hipMemcpyToSymbol(HIP_SYMBOL(gix_tmap),fga_gix_tmap(),256)) != hipSuccess ||
       (e = hipMemcpyAsync(dimg,G->bps,(size_t) G->bpslen,hipMemcpyHostToDevice,dev->stream)) != hipSuccess ||
@@ -436,7 +574,7 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
     A.img = dimg; A.boff = dboff; A.clen = dclen; A.invp = dinvp;
     A.items = ditems; A.nitems = (int) items.size();
     A.postbytes = postbytes; A.contbytes = contbytes;
-    A.keys = buf0; A.cap = cap; A.nkeys = dctr; A.count = dcount; A.sbuck = dctr + 1;
+    A.keys = NULL; A.index = NULL; A.nkeys = dctr; A.count = dcount; A.sbuck = dctr + 1;        // the counting pass
     A.pbeg = (uint32_t) pbeg; A.pend = (uint32_t) pend;
     hipLaunchKernelGGL(gix_scan_kernel,dim3(scan_grid),dim3(GNT),0,dev->stream,A);
   }
@@ -456,36 +594,6 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
         goto done;
       }
     nkeys = (int64_t) hk[0];
-    if (nkeys > cap)
-      { // low-complexity sequence (up to two k-mers per base): the exact size is known now, go again
-        fga_dev_release(dev,SLOT_SORT0,buf0);
-        cap = nkeys + 4096;
-        buf0 = (uint4 *) fga_dev_acquire(dev,SLOT_SORT0,2*sizeof(uint4)*(size_t) cap);
-        buf1 = buf0 != NULL ? buf0 + cap : NULL;
-        if (buf0 == NULL || buf1 == NULL)
-          { fga_set_error("fga_dgix_build: device allocation of the key buffers failed");
-            goto done;
-          }
-        hipMemsetAsync(dcount,0,sizeof(uint32_t)*FGA_NPREFIX,dev->stream);
-        hipMemsetAsync(dctr,0,sizeof(unsigned long long)*(1 + 1024 + 4096 + 1),dev->stream);
-        gix_scan_args A2;
-        A2.img = dimg; A2.boff = dboff; A2.clen = dclen; A2.invp = dinvp;
-        A2.items = ditems; A2.nitems = (int) items.size();
-        A2.postbytes = postbytes; A2.contbytes = contbytes;
-        A2.keys = buf0; A2.cap = cap; A2.nkeys = dctr; A2.count = dcount; A2.sbuck = dctr + 1;
-        A2.pbeg = (uint32_t) pbeg; A2.pend = (uint32_t) pend;
-        hipLaunchKernelGGL(gix_scan_kernel,dim3(scan_grid),dim3(GNT),0,dev->stream,A2);
-        if ((e = hipMemcpyAsync(hk,dctr,sizeof(hk),hipMemcpyDeviceToHost,dev->stream)) != hipSuccess ||
-            (e = hipStreamSynchronize(dev->stream)) != hipSuccess)
-          { fga_set_error("fga_dgix_build: scan kernel failed: %s",hipGetErrorString(e));
-            goto done;
-          }
-        nkeys = (int64_t) hk[0];
-        if (nkeys > cap)
-          { fga_set_error("fga_dgix_build: internal error, %lld k-mers exceed the buffer of %lld",(long long) nkeys,(long long) cap);
-            goto done;
-          }
-      }
     // table parts from the sample histogram, as a bucket -> part id map
     int64_t sb[1024];
     int ksplit[65];
@@ -505,13 +613,7 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
     hipStreamSynchronize(dev->stream);
   }
 
-  fga_note("index build: uploads + syncmer scan",tn); tn = fga_wall();
-  { const int bits = 80 + 8*(postbytes+contbytes);
-    const int npass = (bits + 7) / 8;
-    if (fga_radix_sort_u128(dev,buf0,buf1,nkeys,128 - 8*npass,8*npass,&sorted))
-      goto done;
-  }
-
+  fga_note("index build: uploads + syncmer scan (counting pass)",tn); tn = fga_wall();
   D = (fga_dgix *) calloc(1,sizeof(fga_dgix));
   if (D == NULL) { fga_set_error("out of memory"); goto done; }
   D->dev = dev; D->nents = nkeys; D->ebytes = ebytes; D->postbytes = postbytes; D->contbytes = contbytes; D->nctg = nctg;
@@ -538,6 +640,67 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
     hipLaunchKernelGGL(gix_index_write_kernel,dim3(FGA_NPREFIX/ICH),dim3(256),0,dev->stream,dcount,sums,D->index,
                        (unsigned int *) (dctr + 1025 + 4096));
   }
+  // the keys, each inside its prefix's panel: the second scan (the counts are what is left of every panel), then the panels
+  // put in order tile by tile in LDS; panels beyond a tile's capacity through the LSD radix passes
+  if (nkeys > 0)
+    { // (a little more than the keys need: the piece is what the comparison's seed buffer -- one seed per entry + 2^20 + a
+      //  block per wavefront at human scale, fga_merge.hip -- takes over afterwards, instead of asking the driver for a region)
+      buf0 = (uint4 *) fga_dev_acquire(dev,SLOT_SORT0,sizeof(uint4)*(size_t) (nkeys + (1 << 20) + 2*(int64_t) dev->ncu*32*1024 + 4096));
+      ntiles = (nkeys + GT_T - 1) / GT_T;
+      dtiles = (gix_tile *) fga_dev_acquire(dev,SLOT_TILES,sizeof(gix_tile)*(size_t) (ntiles + 1));
+      dover = (gix_over *) fga_dev_acquire(dev,SLOT_MISC,sizeof(gix_over)*(size_t) (nkeys / GT_CAP + 2) + 64);
+      if (buf0 == NULL || dtiles == NULL || dover == NULL)
+        { fga_set_error("fga_dgix_build: device allocation of the key buffer failed");
+          goto done;
+        }
+      unsigned int *dnover = (unsigned int *) (dover + (nkeys / GT_CAP + 2));
+      hipMemsetAsync(dnover,0,sizeof(unsigned int),dev->stream);
+      gix_scan_args A;
+      A.img = dimg; A.boff = dboff; A.clen = dclen; A.invp = dinvp;
+      A.items = ditems; A.nitems = (int) items.size();
+      A.postbytes = postbytes; A.contbytes = contbytes;
+      A.keys = buf0; A.index = D->index; A.nkeys = dctr; A.count = dcount; A.sbuck = dctr + 1;         // the placing pass
+      A.pbeg = (uint32_t) pbeg; A.pend = (uint32_t) pend;
+      hipLaunchKernelGGL(gix_scan_kernel,dim3(scan_grid),dim3(GNT),0,dev->stream,A);
+      hipLaunchKernelGGL(gix_tiles_kernel,dim3((unsigned) ((ntiles + 1 + 255)/256)),dim3(256),0,dev->stream,D->index,nkeys,ntiles,dtiles);
+      hipLaunchKernelGGL(gix_tile_sort_kernel,dim3((unsigned) ntiles),dim3(GT_NT),0,dev->stream,buf0,dtiles,dover,dnover);
+      unsigned int nover = 0;
+      if ((e = hipMemcpyAsync(&nover,dnover,sizeof(nover),hipMemcpyDeviceToHost,dev->stream)) != hipSuccess ||
+          (e = hipStreamSynchronize(dev->stream)) != hipSuccess || (e = hipGetLastError()) != hipSuccess)
+        { fga_set_error("fga_dgix_build: placing / panel sort kernels failed: %s",hipGetErrorString(e));
+          goto done;
+        }
+      if (nover > 0)
+        { std::vector<gix_over> ov((size_t) nover);
+          std::vector<int64_t> ooff((size_t) nover);
+          int64_t total = 0;
+          if ((e = hipMemcpy(ov.data(),dover,sizeof(gix_over)*(size_t) nover,hipMemcpyDeviceToHost)) != hipSuccess)
+            { fga_set_error("fga_dgix_build: download failed: %s",hipGetErrorString(e)); goto done; }
+          std::sort(ov.begin(),ov.end(),[](const gix_over &a, const gix_over &b) { return a.start < b.start; });
+          for (unsigned int k = 0; k < nover; k++) { ooff[(size_t) k] = total; total += ov[(size_t) k].count; }
+          oscr = (uint4 *) fga_dev_acquire(dev,SLOT_SORT1,2*sizeof(uint4)*(size_t) total);
+          if (oscr == NULL || (e = fga_dmalloc(&dooff,sizeof(int64_t)*(size_t) nover)) != hipSuccess)
+            { fga_set_error("fga_dgix_build: device allocation for %lld keys of %u large panels failed",(long long) total,nover);
+              goto done;
+            }
+          hipMemcpyAsync(dover,ov.data(),sizeof(gix_over)*(size_t) nover,hipMemcpyHostToDevice,dev->stream);
+          hipMemcpyAsync(dooff,ooff.data(),sizeof(int64_t)*(size_t) nover,hipMemcpyHostToDevice,dev->stream);
+          unsigned cg = (unsigned) ((total + 255)/256 < (int64_t) dev->ncu*16 ? (total + 255)/256 : (int64_t) dev->ncu*16);
+          hipLaunchKernelGGL(gix_over_copy_kernel,dim3(cg),dim3(256),0,dev->stream,buf0,oscr,dover,dooff,(int) nover,total,0);
+          const int npass = (80 + 8*(postbytes+contbytes) + 7) / 8;
+          uint4 *osorted = NULL;
+          if (fga_radix_sort_u128(dev,oscr,oscr + total,total,128 - 8*npass,8*npass,&osorted))
+            goto done;
+          hipLaunchKernelGGL(gix_over_copy_kernel,dim3(cg),dim3(256),0,dev->stream,buf0,osorted,dover,dooff,(int) nover,total,1);
+          if ((e = hipStreamSynchronize(dev->stream)) != hipSuccess || (e = hipGetLastError()) != hipSuccess)
+            { fga_set_error("fga_dgix_build: sort of the large panels failed: %s",hipGetErrorString(e));
+              goto done;
+            }
+          fga_dev_release(dev,SLOT_SORT1,oscr); oscr = NULL;
+        }
+      sorted = buf0;
+    }
+  fga_note("index build: placing pass + panel order",tn); tn = fga_wall();
   if (nkeys > 0)
     { gix_entries_args E;
       E.keys = sorted; E.n = nkeys; E.postbytes = postbytes; E.contbytes = contbytes; E.ebytes = ebytes;
@@ -623,7 +786,8 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
 done:
   fga_pool_free(dimg); fga_pool_free(dboff); fga_pool_free(dclen); fga_pool_free(dinvp); fga_pool_free(ditems); fga_pool_free(dcount); fga_pool_free(dctr);
   fga_pool_free(dpartid);
-  fga_pool_free(dmoff); fga_pool_free(dmbeg); fga_pool_free(dmend); fga_pool_free(dperm);
+  fga_pool_free(dmoff); fga_pool_free(dmbeg); fga_pool_free(dmend); fga_pool_free(dperm); fga_pool_free(dooff);
+  fga_dev_release(dev,SLOT_SORT1,oscr); fga_dev_release(dev,SLOT_TILES,dtiles); fga_dev_release(dev,SLOT_MISC,dover);
   fga_dev_release(dev,SLOT_SORT0,buf0);
   free(perm); free(invp);
   if (status != 0)

@@ -69,8 +69,6 @@ static int gix_exists(const char *root)
 { char *p = NULL;
   size_t n = strlen(root);
   int ok;
-  if (getenv("FGA_IGNORE_GIX_FILES") != NULL && atoi(getenv("FGA_IGNORE_GIX_FILES")) != 0)
-    return 0;                      /* tests: index files made by another program sit beside the GDB; build ours on the device */
   if (n > 4 && (strcmp(root+n-4,".gix") == 0 || strcmp(root+n-4,".gdb") == 0)) n -= 4;
   else if (n > 5 && strcmp(root+n-5,".1gdb") == 0) n -= 5;
   if (asprintf(&p,"%.*s.gix",(int) n,root) < 0) return 0;
@@ -85,11 +83,16 @@ int fga_session_open(const char *root1, const char *root2, int device, fga_sessi
 
 /* nthreads: GIXmake's -T for an index the session has to build itself -- it decides the contig padding of a short GDB
    and the table parts (SURVEY.md hard part 9), i.e. the layout FastGA -T<n> would have got from its GIXmake call */
-static int session_open_impl(const char *root1, const char *root2, int device, int nthreads, int rank, int nranks,
+static int session_open_impl(const char *root1, const char *root2, int device, int nthreads, int rank, int nranks, int flags,
                              fga_session **out);
 
 int fga_session_open_threads(const char *root1, const char *root2, int device, int nthreads, fga_session **out)
-{ return session_open_impl(root1,root2,device,nthreads,0,1,out); }
+{ return session_open_impl(root1,root2,device,nthreads,0,1,0,out); }
+
+/* flags: FGA_SESSION_BUILD_INDEX -- the genome indices are built on the device even when <root>.gix files exist (they may
+   be another program's: a parity run against the reference's own GIXmake output) */
+int fga_session_open_flags(const char *root1, const char *root2, int device, int nthreads, int flags, fga_session **out)
+{ return session_open_impl(root1,root2,device,nthreads,0,1,flags,out); }
 
 int fga_session_open_sliced(const char *root1, const char *root2, int device, int nthreads, int rank, int nranks,
                             fga_session **out)
@@ -98,7 +101,7 @@ int fga_session_open_sliced(const char *root1, const char *root2, int device, in
       *out = NULL;
       return 1;
     }
-  return session_open_impl(root1,root2,device,nthreads,rank,nranks,out);
+  return session_open_impl(root1,root2,device,nthreads,rank,nranks,0,out);
 }
 
 /* prefix ranges of equal merge cost (entries of both tables + 2 per prefix) from the tables' per-prefix entry counts:
@@ -131,7 +134,7 @@ static void cuts_from_counts(const int64_t *idx1, const int64_t *idx2, const uin
     if (cuts[w] < cuts[w-1]) cuts[w] = cuts[w-1];
 }
 
-static int session_open_impl(const char *root1, const char *root2, int device, int nthreads, int rank, int nranks,
+static int session_open_impl(const char *root1, const char *root2, int device, int nthreads, int rank, int nranks, int flags,
                              fga_session **out)
 { fga_session *Z = calloc(1,sizeof(fga_session));
   double t0;
@@ -144,7 +147,8 @@ static int session_open_impl(const char *root1, const char *root2, int device, i
   t0 = fga_wall();
   /* an index file is loaded when it is there; otherwise the index is built on the device from the GDB, straight
      into HBM (no .gix/.ktab files appear, like the reference without -k) */
-  { int have1 = gix_exists(root1), have2 = Z->self ? 1 : gix_exists(root2);
+  { const int build = (flags & FGA_SESSION_BUILD_INDEX) != 0;
+    int have1 = !build && gix_exists(root1), have2 = Z->self ? 1 : (!build && gix_exists(root2));
     if (fga_gdb_open(root1,&Z->g1) || (have1 && fga_gix_open(root1,&Z->x1))) goto fail;
     if (!Z->self)
       { if (fga_gdb_open(root2,&Z->g2) || (have2 && fga_gix_open(root2,&Z->x2))) goto fail; }
@@ -349,6 +353,11 @@ int fga_session_align(fga_session *Z, const fga_run_params *P, fga_dseeds *seeds
     fga_dev_peak_bytes(dev);                 /* seeds + both key buffers are live here: the footprint's peak */
     fga_seeds_free(seeds); seeds = NULL;
     st.sort_kernel_ms = fga_dev_stage_ms(dev,FGA_STAGE_SORT);
+    { int wa, wb, wd, wt;
+      fga_keys_layout(keys,&wa,&wb,&wd,&wt);
+      st.sort_keys = fga_keys_count(keys);
+      st.sort_passes = (1 + wa + wb + wd + wt + 7) / 8;        /* the bits above diag&63 | lcp (anti_order_only) */
+    }
   }
   t1 = fga_wall();
   st.sort_s = t1 - t0;
@@ -398,6 +407,8 @@ done:
       S->sort_kernel_ms += st.sort_kernel_ms; S->extend_kernel_ms += st.extend_kernel_ms;
       S->nhits += st.nhits; S->nunits += st.nunits; S->nalns += st.nalns; S->ncalls += st.ncalls; S->nwaves += st.nwaves;
       S->ext_cells += st.ext_cells; S->ext_bases += st.ext_bases; S->ext_trace += st.ext_trace;
+      S->sort_keys += st.sort_keys;
+      if (st.sort_passes > S->sort_passes) S->sort_passes = st.sort_passes;
       if (st.ext_busy_waves > 0.) S->ext_busy_waves = st.ext_busy_waves;
     }
   free(alen); free(table);
@@ -761,7 +772,8 @@ done:
 int fga_run(const char *root1, const char *root2, const fga_run_params *P, fga_run_stats *S)
 { fga_session *Z;
   int rc;
-  if (fga_session_open_threads(root1,root2,P->device,P->nthreads > 0 ? P->nthreads : 8,&Z))
+  if (fga_session_open_flags(root1,root2,P->device,P->nthreads > 0 ? P->nthreads : 8,
+                             P->build_index ? FGA_SESSION_BUILD_INDEX : 0,&Z))
     return 1;
   rc = fga_session_run(Z,P,S);
   fga_session_close(Z);

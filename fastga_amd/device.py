@@ -306,14 +306,14 @@ def trace_pts(dev, ga, gb, alns, tb, tspace=100, self_cmp=False):
 
 def run(root1, root2=None, out_path=None, device=0, freq=10, soft_mask=False, symmetric=False, chain_break=1000,
         chain_min=85, align_min=100, identity=0.7, nthreads=8, command_line="FastGA", paf_path=None, paf_flags=0,
-        pass_seeds=0, reference_threads=0):
+        pass_seeds=0, reference_threads=0, build_index=False):
     """The whole hot path (fga_run): prebuilt GDB/GIX roots in, .1aln (and PAF) out.  Returns the stats as a dict.
     reference_threads = n > 0: records that tie on (aread, abpos) in the order `FastGA -T<n>` writes them."""
     from .lib import RunParams, RunStats
     L = load_library()
     prm = RunParams(device, freq, int(soft_mask), int(symmetric), 2 * chain_break, 2 * chain_min, align_min,
                     1.0 - identity, nthreads, out_path.encode() if out_path else None, command_line.encode(),
-                    paf_path.encode() if paf_path else None, paf_flags, pass_seeds, reference_threads)
+                    paf_path.encode() if paf_path else None, paf_flags, pass_seeds, int(build_index), reference_threads)
     st = RunStats()
     check(L.fga_run(root1.encode(), root2.encode() if root2 else None, C.byref(prm), C.byref(st)), "fga_run")
     return {n: getattr(st, n) for n, _ in RunStats._fields_}
@@ -322,7 +322,7 @@ def run(root1, root2=None, out_path=None, device=0, freq=10, soft_mask=False, sy
 class Session:
     """inputs resident in HBM; run() is one pass of the hot path (fga_session_*)."""
 
-    def __init__(self, root1, root2=None, device=0, rank=0, nranks=1, nthreads=8):
+    def __init__(self, root1, root2=None, device=0, rank=0, nranks=1, nthreads=8, build_index=False):
         """nranks > 1: the session of rank `rank` of one comparison over nranks GPUs -- it holds only its own 12-mer prefix
         range of both tables (fga_session_open_sliced)"""
         self.L = load_library()
@@ -331,8 +331,8 @@ class Session:
             check(self.L.fga_session_open_sliced(root1.encode(), root2.encode() if root2 else None, device, nthreads,
                                                  rank, nranks, C.byref(self.h)), "open sliced session")
         else:
-            check(self.L.fga_session_open(root1.encode(), root2.encode() if root2 else None, device, C.byref(self.h)),
-                  "open session")
+            check(self.L.fga_session_open_flags(root1.encode(), root2.encode() if root2 else None, device, nthreads,
+                                                1 if build_index else 0, C.byref(self.h)), "open session")
         self.rank, self.nranks = rank, nranks
         self.table_bytes = self.L.fga_session_table_bytes(self.h)
         self.seed_bytes = self.L.fga_session_seed_bytes(self.h)
@@ -340,11 +340,11 @@ class Session:
 
     def run(self, out_path=None, freq=10, soft_mask=False, symmetric=False, chain_break=1000, chain_min=85,
             align_min=100, identity=0.7, nthreads=8, command_line="FastGA", paf_path=None, paf_flags=0,
-            pass_seeds=0, reference_threads=0):
+            pass_seeds=0, reference_threads=0, build_index=False):
         from .lib import RunParams, RunStats
         prm = RunParams(0, freq, int(soft_mask), int(symmetric), 2 * chain_break, 2 * chain_min, align_min,
                         1.0 - identity, nthreads, out_path.encode() if out_path else None, command_line.encode(),
-                        paf_path.encode() if paf_path else None, paf_flags, pass_seeds, reference_threads)
+                        paf_path.encode() if paf_path else None, paf_flags, pass_seeds, int(build_index), reference_threads)
         st = RunStats()
         check(self.L.fga_session_run(self.h, C.byref(prm), C.byref(st)), "session run")
         return {n: getattr(st, n) for n, _ in RunStats._fields_}
@@ -352,11 +352,11 @@ class Session:
     # ---- the three stages of run(), for one comparison cut into A-contig parts (fastga_amd/parallel.py) ----
     def params(self, out_path=None, freq=10, soft_mask=False, symmetric=False, chain_break=1000, chain_min=85,
                align_min=100, identity=0.7, nthreads=8, command_line="FastGA", paf_path=None, paf_flags=0,
-               pass_seeds=0, reference_threads=0):
+               pass_seeds=0, reference_threads=0, build_index=False):
         from .lib import RunParams
         return RunParams(0, freq, int(soft_mask), int(symmetric), 2 * chain_break, 2 * chain_min, align_min,
                          1.0 - identity, nthreads, out_path.encode() if out_path else None, command_line.encode(),
-                         paf_path.encode() if paf_path else None, paf_flags, pass_seeds, reference_threads)
+                         paf_path.encode() if paf_path else None, paf_flags, pass_seeds, int(build_index), reference_threads)
 
     def new_stats(self):
         from .lib import RunStats

@@ -83,7 +83,7 @@ class RunParams(C.Structure):
                 ("chain_break", C.c_int), ("chain_min", C.c_int), ("align_min", C.c_int),
                 ("align_rate", C.c_double), ("nthreads", C.c_int), ("out_path", C.c_char_p),
                 ("command_line", C.c_char_p), ("paf_path", C.c_char_p), ("paf_flags", C.c_int),
-                ("pass_seeds", C.c_int64), ("reference_threads", C.c_int)]
+                ("pass_seeds", C.c_int64), ("build_index", C.c_int), ("reference_threads", C.c_int)]
 
 
 class RunStats(C.Structure):
@@ -94,7 +94,8 @@ class RunStats(C.Structure):
                [(n, C.c_float) for n in ("merge_kernel_ms", "sort_kernel_ms", "extend_kernel_ms",
                                          "trace_kernel_ms")] + [("nparts", C.c_int), ("bases1", C.c_int64), ("bases2", C.c_int64), ("ext_cells", C.c_int64),
                                                      ("ext_bases", C.c_int64), ("ext_trace", C.c_int64),
-                                                     ("ext_busy_waves", C.c_double), ("hbm_peak_bytes", C.c_int64)]
+                                                     ("ext_busy_waves", C.c_double), ("hbm_peak_bytes", C.c_int64),
+                                                     ("sort_keys", C.c_int64), ("sort_passes", C.c_int)]
 
 
 class SortParams(C.Structure):
@@ -190,6 +191,7 @@ def _declare(L):
         "fga_run": (i32, [cp, cp, P(RunParams), P(RunStats)]),
         "fga_session_open": (i32, [cp, cp, i32, P(vp)]),
         "fga_session_open_threads": (i32, [cp, cp, i32, i32, P(vp)]),
+        "fga_session_open_flags": (i32, [cp, cp, i32, i32, i32, P(vp)]),
         "fga_session_run": (i32, [vp, P(RunParams), P(RunStats)]),
         "fga_session_close": (None, [vp]),
         "fga_session_device": (vp, [vp]),

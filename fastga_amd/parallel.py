@@ -218,33 +218,58 @@ def run_parts_on_one_gpu(ses, nparts, **prm_kwargs):
     """The sharded run's C-ABI calls on ONE GPU, rank by rank in sequence (merge of each prefix range, histogram,
     partition, split, import of each part's pieces, align, finish over all parts): the parity check of the multi-GPU
     path for any number of parts.  The staging buffers come from fga_dev_malloc (no torch in this process)."""
+    import time
     prm = ses.params(**prm_kwargs)
     st = ses.new_stats()
     cuts = prefix_cuts(ses, nparts)
     ses.clear_strand_counts()                                 # the "ranks" share the session: their counts add up in it
     sends, offs, hist = [], [], np.zeros(ses.nctg, dtype=np.int64)
     merged = []
+    per_rank = {"merge_s": [], "split_s": [], "align_s": [], "sort_s": [], "chain_s": [], "extend_s": [], "filter_s": [],
+                "extend_kernel_ms": [], "wave_steps": [], "records": []}
     for r in range(nparts):                                   # "rank r": phase 1 on its prefix range
+        t = time.time()
         seeds = ses.merge(prm, st, int(cuts[r]), int(cuts[r + 1]))
         hist += ses.contig_histogram(seeds)
+        per_rank["merge_s"].append(time.time() - t)
         merged.append((seeds, ses.dev_malloc(16 * seeds.count)))
     select = partition_contigs(hist, nparts)
     for seeds, buf in merged:
+        t = time.time()
         offs.append(ses.split_to(seeds, select, nparts, buf))
+        per_rank["split_s"].append(time.time() - t)
         seeds.free()
         sends.append(buf)
     raws = []
     for p in range(nparts):                                   # "rank p": its part's pieces from every rank, phase 2
         pieces = [(sends[r] + 16 * int(offs[r][p]), int(offs[r][p + 1] - offs[r][p])) for r in range(nparts)]
+        before = ses.stats_dict(st)
+        t = time.time()
         part = ses.import_seeds(pieces)
         raw = ses.align(prm, st, part)
+        per_rank["align_s"].append(time.time() - t)
+        after = ses.stats_dict(st)
+        for k in ("sort_s", "chain_s", "extend_s", "extend_kernel_ms"):
+            per_rank[k].append(after[k] - before[k])
+        per_rank["wave_steps"].append(int(after["nwaves"] - before["nwaves"]))
+        t = time.time()
         raws.append(ses.filter(raw, nthreads=prm_kwargs.get("nthreads", 8)))      # "rank p" filters its own records
+        per_rank["filter_s"].append(time.time() - t)
+        per_rank["records"].append(int(raws[-1].contents.naln))
         ses.free_alns(raw)
     for buf in sends:
         ses.dev_free(buf)
+    t = time.time()
     ses.finish_filtered(prm, st, raws)
+    finish_s = time.time() - t
+    gather_bytes = [int(r.contents.naln) * 56 + int(r.contents.ntrace) for r in raws]
     for r in raws:
         ses.free_alns(r)
     d = ses.stats_dict(st)
     d["part_seed_counts"] = [int(sum(offs[r][p + 1] - offs[r][p] for r in range(nparts))) for p in range(nparts)]
+    # what an N-GPU run moves and waits for, rank by rank (bench.py projects the N-GPU wall time from these)
+    d["per_rank"] = per_rank
+    d["sent_bytes"] = [[16 * int(offs[r][p + 1] - offs[r][p]) for p in range(nparts)] for r in range(nparts)]   # [from][to]
+    d["gather_bytes"] = gather_bytes
+    d["finish_s"] = finish_s
     return d

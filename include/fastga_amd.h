@@ -337,6 +337,7 @@ typedef struct
     int     paf_flags;       /* FGA_PAF_* (-pafm / -pafx / -pafs / -pafS)                 */
     int64_t pass_seeds;      /* most seeds one sort / search pass takes (0: 1.5 G); more -> phase 2 runs over A-contig
                                 parts, the reference's NPARTS loop (FastGA.c:5186-5204)  */
+    int     build_index;     /* fga_run: build the genome indices on the device even when <root>.gix files exist */
     int     reference_threads; /* n > 0: records that tie on (aread, abpos) in the order `FastGA -T<n>` writes them -- by the
                                 slot of the search thread that held the A contig's panel of that strand (la_merge,
                                 FastGA.c:3906-3918; fga_reference_slots); 0: by (bread, strand, survival)           */
@@ -352,6 +353,8 @@ typedef struct
     int64_t ext_cells, ext_bases, ext_trace;   /* extension accounting summed over the parts (fga_alns)         */
     double  ext_busy_waves;                    /* wavefronts busy on average (last part)                        */
     int64_t hbm_peak_bytes;                    /* peak device memory in use by this process, sampled at the stage boundaries */
+    int64_t sort_keys;                         /* records sorted, summed over the parts; sort_passes radix passes each:      */
+    int     sort_passes;                       /*   algorithmic traffic of the sort = 2 x 16 B x sort_keys x sort_passes     */
   } fga_run_stats;
 
 int  fga_run(const char *root1, const char *root2 /* NULL: self */, const fga_run_params *prm, fga_run_stats *stats);
@@ -403,6 +406,8 @@ typedef struct fga_session fga_session;
 int      fga_session_open(const char *root1, const char *root2, int device, fga_session **out);
 /* nthreads = the -T the reference would hand to the GIXmake it runs for a missing index (fga_session_open: 8) */
 int      fga_session_open_threads(const char *root1, const char *root2, int device, int nthreads, fga_session **out);
+enum { FGA_SESSION_BUILD_INDEX = 1 };   /* indices built on the device even when <root>.gix files exist */
+int      fga_session_open_flags(const char *root1, const char *root2, int device, int nthreads, int flags, fga_session **out);
 /* rank `rank` of `nranks` of one comparison: the session holds only ITS 12-mer prefix range of both tables (the genomes'
  * bases stay whole: phase 2 needs them).  The ranges are cut for equal merge cost from the tables' per-prefix counts, the
  * same on every rank without communication; fga_session_prefix_cuts(s, nranks, ..) returns them, and fga_session_merge

@@ -94,11 +94,7 @@ def test_config2_100mbp_pair_is_identical_to_the_reference(tmp_path_factory, bui
     d = str(tmp_path_factory.mktemp("c2"))
     ra, rb = workload.build_config2(d, mbp=100.0, threads=T)
     _reference_index_files_equal_device_builds((ra, rb), d)      # the reference reads its own GIXmake's files ...
-    os.environ["FGA_IGNORE_GIX_FILES"] = "1"                     # ... and ours builds its index on the device
-    try:
-        st, dg = _compare_with_reference(ra, rb, d, strict=True, pafx=True)
-    finally:
-        os.environ.pop("FGA_IGNORE_GIX_FILES", None)
+    st, dg = _compare_with_reference(ra, rb, d, strict=True, pafx=True, build_index=True)   # ... and ours builds its index on the device
     assert dg["records"] > 1500 and st["nwaves"] > 5_000_000        # contig-long alignments were really extended
     # the work itself is pinned too, not only its outcome: the number of wave steps of the whole comparison.  (A wrong
     # root cell for the trim point of a wave that never sets one changed it by 14 in 7.9 M while every record stayed
