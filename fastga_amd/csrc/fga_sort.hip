@@ -406,10 +406,174 @@ void os_pass_kernel(const void *in, uint4 *out, int64_t n, int shift, int next_s
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// One-sweep pass with wide tiles whose keys leave in tile order (round 4).  What bounds os_pass_kernel is not its look-back
+// and not its instruction count but the stores (tools/ubench/sort_bench.hip, profiles/r04_sort_*): a 64-byte block written
+// whole by 4 adjacent lanes of ONE store instruction goes at the speed of a copy (5.3 TB/s read + write); the same bytes written
+// record by record, or in runs that begin and end inside a block, pay a read-modify-write per piece (2.4 / 2.7 TB/s).  A
+// 4096-key tile holds 16 keys per digit and scatters them from registers: every store instruction touches 64 blocks.  Here
+//   * a tile is NW x 1024 keys (NW wavefronts: 8192 / 16384 keys, runs of 32 / 64 keys per digit),
+//   * the keys go through LDS in the order they have in the output, 2048 slots at a time, and leave it slot by slot:
+//     consecutive lanes write consecutive records of a digit's run, so only the two ends of a run share their block.
+// Ranking, status words and look-back are os_pass_kernel's (4 / 2 times fewer tiles to walk over).
+// ---------------------------------------------------------------------------------------------------
+#define OSW_STAGE   2048
+
+template <bool FROM_SEEDS, int NW>
+__global__ __launch_bounds__(NW*64)
+void osw_pass_kernel(const void *in, uint4 *out, int64_t n, int shift, int next_shift, key_layout L, int stamp,
+                     const unsigned long long *gbase, unsigned long long *status, unsigned long long *next_hist,
+                     unsigned int *ticket, const uint16_t *valid)
+{ constexpr int NT = NW*64, TILE = NW*1024, ROUNDS = TILE/OSW_STAGE, SPT = OSW_STAGE/NT;
+  __shared__ uint32_t wcnt[NW][256];          // per-wave digit counts, then per-wave digit bases inside the tile
+  __shared__ long long off[256];              // position in `out` of the digit's first key of this tile, minus its tile position
+  __shared__ uint32_t dstart[256];            // tile position of the digit's first key
+  __shared__ uint32_t nh[256];                // digits of the next pass among the keys written
+  __shared__ uint4 stage[OSW_STAGE];
+  __shared__ uint32_t wsum[4];
+  __shared__ int tile_s, total_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0)
+    tile_s = (int) atomicAdd(ticket,1u);
+  for (int x = tid; x < NW*256; x += NT)
+    (&wcnt[0][0])[x] = 0;
+  if (tid < 256) nh[tid] = 0;
+  __syncthreads();
+  const int tile = tile_s;
+
+  const int64_t wbase = (int64_t) tile * TILE + (int64_t) wave * 1024;       // a wavefront's 1024 items: one block of the seed buffer
+  const int vcount = (FROM_SEEDS && valid != NULL && wbase < n) ? (int) valid[wbase >> 10] : 1024;
+  u128     key[16];
+  uint16_t rank[16];
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64-lane));
+  #pragma unroll
+  for (int r = 0; r < 16; r++)
+    { const int64_t i = wbase + r*64 + lane;
+      const bool ok = i < n && r*64 + lane < vcount;
+      uint32_t d = 256;
+      if (ok)
+        { key[r] = load_key<FROM_SEEDS>(in,i,L);
+          d = digit_of(key[r],shift);
+        }
+      uint64_t peers = __ballot(ok);
+      #pragma unroll
+      for (int b = 0; b < 8; b++)
+        { const uint64_t m = __ballot((d >> b) & 1);
+          peers &= ((d >> b) & 1) ? m : ~m;
+        }
+      const uint32_t before = __popcll(peers & lt);
+      uint32_t basec = 0;
+      if (ok)
+        basec = wcnt[wave][d];
+      rank[r] = (uint16_t) (basec + before);
+      if (ok && (peers >> lane) >> 1 == 0)
+        wcnt[wave][d] = basec + before + 1;
+    }
+  __syncthreads();
+  // thread d < 256: the tile's count of digit d, published; per-wave bases; look-back; where the digit's run begins in the tile
+  if (tid < 256)
+    { uint32_t run = 0;
+      #pragma unroll
+      for (int w = 0; w < NW; w++)
+        { const uint32_t c = wcnt[w][tid];
+          wcnt[w][tid] = run;
+          run += c;
+        }
+      unsigned long long *mine = status + (size_t) tile*256 + tid;
+      if (tile > 0)
+        __hip_atomic_store(mine,OS_PACK(stamp,OS_LOCAL,run),__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
+      uint32_t inc = run;                       // exclusive scan of the counts over the digits (waves 0..3)
+      #pragma unroll
+      for (int d = 1; d < 64; d <<= 1)
+        { const uint32_t y = __shfl_up(inc,d,64);
+          if (lane >= d) inc += y;
+        }
+      if (lane == 63) wsum[wave] = inc;
+      unsigned long long excl = 0;
+      for (int t = tile-1; t >= 0; t--)
+        { const unsigned long long *p = status + (size_t) t*256 + tid;
+          unsigned long long sv = __hip_atomic_load(p,__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
+          while (OS_STAMP(sv) != stamp || OS_STATE(sv) == 0)
+            { __builtin_amdgcn_s_sleep(1);
+              sv = __hip_atomic_load(p,__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
+            }
+          excl += OS_VALUE(sv);
+          if (OS_STATE(sv) == OS_INCL)
+            break;
+        }
+      __hip_atomic_store(mine,OS_PACK(stamp,OS_INCL,excl + run),__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
+      dstart[tid] = inc - run;                  // completed below with the earlier waves' totals
+      off[tid] = (long long) (gbase[tid] + excl);
+    }
+  __syncthreads();
+  if (tid < 256)
+    { uint32_t o = 0;
+      for (int w = 0; w < wave; w++) o += wsum[w];
+      const uint32_t ds = dstart[tid] + o;
+      dstart[tid] = ds;
+      off[tid] -= (long long) ds;
+      if (tid == 255)
+        total_s = (int) (wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+    }
+  __syncthreads();
+  // every key's position in the tile (over the rank: 16 bits each)
+  #pragma unroll
+  for (int r = 0; r < 16; r++)
+    { const int64_t i = wbase + r*64 + lane;
+      if (i < n && r*64 + lane < vcount)
+        { const uint32_t d = digit_of(key[r],shift);
+          rank[r] = (uint16_t) (dstart[d] + wcnt[wave][d] + rank[r]);
+        }
+      else
+        rank[r] = 0xffff;
+    }
+  const int total = total_s;
+  for (int q = 0; q < ROUNDS; q++)
+    { if (q*OSW_STAGE >= total)
+        break;
+      #pragma unroll
+      for (int r = 0; r < 16; r++)
+        if ((rank[r] >> 11) == q && rank[r] != 0xffff)
+          { uint4 v;
+            v.x = (uint32_t) key[r].lo; v.y = (uint32_t) (key[r].lo >> 32);
+            v.z = (uint32_t) key[r].hi; v.w = (uint32_t) (key[r].hi >> 32);
+            stage[rank[r] & (OSW_STAGE-1)] = v;
+          }
+      __syncthreads();
+      #pragma unroll
+      for (int j = 0; j < SPT; j++)
+        { const int sl = j*NT + tid, p = q*OSW_STAGE + sl;
+          if (p < total)
+            { const uint4 v = stage[sl];
+              u128 k;
+              k.lo = ((uint64_t) v.y << 32) | v.x; k.hi = ((uint64_t) v.w << 32) | v.z;
+              out[off[digit_of(k,shift)] + p] = v;
+              if (next_hist != NULL)
+                atomicAdd(&nh[digit_of(k,next_shift)],1u);
+            }
+        }
+      __syncthreads();
+    }
+  if (next_hist != NULL && tid < 256 && nh[tid] != 0)
+    atomicAdd(next_hist + tid,(unsigned long long) nh[tid]);
+}
+
 // the passes of one sort, one-sweep; `first` reads seeds (FROM_SEEDS) or keys; buffers alternate.  Enqueued on the stream.
 // work: 3 x 256 + 8 unsigned long long (two digit histograms, the digit bases, the ticket) + status (256 per tile)
 static size_t os_work_bytes(int64_t ntiles)
 { return sizeof(unsigned long long)*(3*256 + 8 + 256*(size_t) ntiles); }
+
+// FGA_SORT_WIDE = 0 | 8 | 16: wavefronts per tile of the one-sweep passes (0: the 4096-key tiles of os_pass_kernel); read once
+static int os_wide()
+{ static int v = -1;
+  if (v < 0)
+    { const char *e = getenv("FGA_SORT_WIDE");
+      v = e != NULL ? atoi(e) : 8;
+      if (v != 0 && v != 8 && v != 16) v = 8;
+    }
+  return v;
+}
+static int64_t os_tile_keys() { return os_wide() == 0 ? OS_TILE : (int64_t) os_wide()*1024; }
 
 static void os_sort(fga_dev *dev, const void *first, bool from_seeds, int64_t next, const uint16_t *valid, key_layout L,
                     uint4 *buf0, uint4 *buf1, int64_t n, int lowbit, int npass, void *work, int64_t ntiles_max, uint4 **sorted)
@@ -432,10 +596,23 @@ static void os_sort(fga_dev *dev, const void *first, bool from_seeds, int64_t ne
   for (int p = 0; p < npass; p++)
     { const int shift = lowbit + 8*p;
       const int64_t m = (p == 0) ? cnt : n;
-      const int nt = (int) ((m + OS_TILE - 1) / OS_TILE);
+      const int nt = (int) ((m + os_tile_keys() - 1) / os_tile_keys());
       unsigned long long *hc = hist[p & 1], *hn = (p+1 < npass) ? hist[(p+1) & 1] : NULL;
       hipLaunchKernelGGL(os_scan256_kernel,dim3(1),dim3(256),0,dev->stream,hc,gbase,hn,ticket);
-if (p == 0 && from_seeds)
+      const uint16_t *nov = NULL;
+      if (os_wide() == 8)
+        { if (p == 0 && from_seeds)
+            hipLaunchKernelGGL((osw_pass_kernel<true,8>),dim3(nt),dim3(512),0,dev->stream,src,dst,m,shift,shift+8,L,p+1,gbase,status,hn,ticket,valid);
+          else
+            hipLaunchKernelGGL((osw_pass_kernel<false,8>),dim3(nt),dim3(512),0,dev->stream,src,dst,m,shift,shift+8,L,p+1,gbase,status,hn,ticket,nov);
+        }
+      else if (os_wide() == 16)
+        { if (p == 0 && from_seeds)
+            hipLaunchKernelGGL((osw_pass_kernel<true,16>),dim3(nt),dim3(1024),0,dev->stream,src,dst,m,shift,shift+8,L,p+1,gbase,status,hn,ticket,valid);
+          else
+            hipLaunchKernelGGL((osw_pass_kernel<false,16>),dim3(nt),dim3(1024),0,dev->stream,src,dst,m,shift,shift+8,L,p+1,gbase,status,hn,ticket,nov);
+        }
+      else if (p == 0 && from_seeds)
         hipLaunchKernelGGL(os_pass_kernel<true>,dim3(nt),dim3(ST),0,dev->stream,src,dst,m,shift,shift+8,L,p+1,gbase,status,hn,ticket,valid);
       else
         hipLaunchKernelGGL(os_pass_kernel<false>,dim3(nt),dim3(ST),0,dev->stream,src,dst,m,shift,shift+8,L,p+1,gbase,status,hn,ticket,
