@@ -416,6 +416,12 @@ void os_pass_kernel(const void *in, uint4 *out, int64_t n, int shift, int next_s
 //   * the keys go through LDS in the order they have in the output, 2048 slots at a time, and leave it slot by slot:
 //     consecutive lanes write consecutive records of a digit's run, so only the two ends of a run share their block.
 // Ranking, status words and look-back are os_pass_kernel's (4 / 2 times fewer tiles to walk over).
+// Measured (tools/ubench/sort_bench, profiles/r04_sort_wide_tiles.txt): 8 wavefronts 3.1 TB/s per pass (48.6 M keys 4.4 -> 3.5
+// ms, 0.55 G keys 56 -> 39.8 ms); 16 wavefronts (one workgroup per CU) no better.  Tried on top and dropped: every run staged
+// at its own phase modulo 4 (padding slots between the runs), so that a block of `out` is an ALIGNED group of 4 lanes --
+// 3.7 / 38.8 ms: it is the partial blocks at the two ends of every run (2 of 9 at 32 keys per run) that still cost, not how
+// the lanes of a full block are grouped.  What would remove them is carrying a run's last (position mod 4) keys over to the
+// next tile that has keys of the digit (the block-aligned pass of this round's history, c447788): not rebuilt.
 // ---------------------------------------------------------------------------------------------------
 #define OSW_STAGE   2048
 
