@@ -305,6 +305,21 @@ def main():
                     out[key] = human_scale_run(D, workload, shared, threads, div, project=(div == 0.01))
                 except Exception as e:            # never takes the bench line down
                     out[key] = {"error": str(e)}
+    # N > 1: the comparison north_star names -- ONE 3 Gbp x 3 Gbp pair cut over the N GPUs (strong scaling), beside the
+    # weak-scaled `value` above.  Every rank opens a sliced session (its 12-mer prefix range of both tables, built on the
+    # device) and runs run_sharded once warm; the cold span is the open + that run.  FGA_BENCH_SHARDED_3G=0 skips it.
+    sharded3g = None
+    want3g = os.environ.get("FGA_BENCH_SHARDED_3G", "1")          # "force": also with one rank under --force-sharded (a code-path check)
+    if dist is not None and (world > 1 or want3g == "force") and not args.no_human_scale and args.strong_mbp <= 0 and want3g != "0":
+        try:
+            ses.close()
+            ses = None
+            sharded3g = sharded_human_scale(D, workload, dist, shared, threads, rank, world, local)
+        except Exception as e:                    # never takes the bench line down
+            sharded3g = {"error": str(e)}
+    if rank == 0:
+        if sharded3g is not None:
+            out["human_scale_sharded"] = sharded3g
         print(json.dumps(out), flush=True)
 
     if ses is not None:
@@ -312,6 +327,70 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def sharded_human_scale(D, workload, dist, workdir, threads, rank, world, local):
+    """BASELINE configs[3] over the N GPUs of the node: 3 Gbp x 3 Gbp, 1 %, one comparison (fastga_amd.parallel.run_sharded
+    with sliced sessions).  Rank 0 makes the genomes (C generator, ~12 s) in the shared work directory."""
+    import shutil
+    import torch
+    from fastga_amd.parallel import run_sharded
+    d = os.path.join(workdir, "human_scale_sharded")
+    ra, rb = os.path.join(d, "A"), os.path.join(d, "B")
+    t = time.time()
+    if rank == 0:
+        os.makedirs(d, exist_ok=True)
+        ra, rb = workload.build_config4(d, mbp=float(os.environ.get("FGA_BENCH_SHARDED_MBP", "3000")), divergence=0.01,
+                                        threads=threads)
+    names = [ra, rb]
+    dist.broadcast_object_list(names, src=0)
+    ra, rb = names
+    dist.barrier()
+    prep = time.time() - t
+    try:
+        torch.cuda.synchronize()
+        dist.barrier()
+        t = time.time()
+        ses = D.Session(ra, rb, device=local, rank=rank, nranks=world, nthreads=threads)
+        ses.sync()
+        dist.barrier()
+        opened = time.time() - t
+        out = os.path.join(d, "sharded.1aln")
+        kw = dict(out_path=out, nthreads=threads, command_line="bench.py FastGA 3 Gbp sharded", reference_threads=32)
+        times = []
+        last = None
+        for _ in range(2):                         # the first run also pays RCCL's buffers for these message sizes
+            dist.barrier(); torch.cuda.synchronize()
+            t = time.time()
+            last = run_sharded(ses, dist, kw, f"cuda:{local}")
+            ses.sync(); dist.barrier(); torch.cuda.synchronize()
+            tt = torch.tensor([time.time() - t], device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            times.append(float(tt.item()))
+        ses.close()
+        res = None
+        if rank == 0:
+            dt = min(times)
+            res = {"workload": f"synthetic 3 Gbp vs 3 Gbp, 1% divergence, 32 contigs, 45% repeats (BASELINE configs[3]): ONE "
+                               f"comparison over {world} GPUs (prefix ranges -> all-to-all-v by A-contig part -> gather)",
+                   "n_gpus": world, "scaling": "strong", "value": 3.0 / dt, "unit": "Gbp-pair/s", "seconds": round(dt, 3),
+                   "seconds_runs": [round(x, 3) for x in times], "records": int(last["nlive"]),
+                   "open_sliced_sessions_s": round(opened, 2), "genomes_s": round(prep, 1),
+                   "cold": {"seconds": round(opened + dt, 2), "span": "GDBs on disk -> every rank's slice of both indices built "
+                                                                       "on its GPU -> the comparison -> .1aln closed on rank 0"}}
+            gold = os.path.join(ROOT, "tests", "golden", "config4_3000m_digest.json")
+            if os.path.exists(gold):
+                g = json.load(open(gold))
+                res["records_equal_reference"] = bool(last["nlive"] == g["records"])
+                if g.get("reference_seconds"):
+                    res["reference_seconds"] = g["reference_seconds"]
+                    res["vs_reference_warm"] = g["reference_seconds"] / dt
+                    res["cold"]["vs_reference"] = g["reference_seconds"] / (opened + dt)
+        return res
+    finally:
+        dist.barrier()
+        if rank == 0:
+            shutil.rmtree(d, ignore_errors=True)
 
 
 # VALU wave-instructions per wave step of the extension (rocprofv3 PMC pass of the bench pair, profiles/r03_pmc_summary.csv)

@@ -459,7 +459,23 @@ typedef struct
   { fga_gdb *G;
     int      sctop, cttop;
     int64_t  hdrcap, boff, spos;
+    /* a .1ano file only: its M lines (scaffold, beg, end) */
+    int      want_m;
+    int64_t *mrec, nm, mcap;
   } skel_ctx;
+
+static int skel_mline(skel_ctx *X, int64_t scf, int64_t beg, int64_t end)
+{ if (X->nm >= X->mcap)
+    { int64_t *nr;
+      X->mcap = X->mcap ? 2*X->mcap : 4096;
+      nr = realloc(X->mrec,sizeof(int64_t)*3*X->mcap);
+      if (nr == NULL) { fga_set_error("out of memory"); return 1; }
+      X->mrec = nr;
+    }
+  X->mrec[3*X->nm] = scf; X->mrec[3*X->nm+1] = beg; X->mrec[3*X->nm+2] = end;
+  X->nm += 1;
+  return 0;
+}
 
 /* one skeleton line: 'f' (r4), 'S' (str,len), 'G' / 'C' (ival), '<' (str,len); everything else is ignored
  * (provenance, schema, counts, deprecated u and M lines) */
@@ -606,7 +622,8 @@ static int read_binary_skeleton(skel_ctx *X, const uint8_t *buf, size_t size, co
       const char *str = NULL;
       int64_t slen = 0, ival = 0;
       double r4[4] = {0,0,0,0};
-      int nr = 0, first_int = 1;
+      int64_t iv[3] = {0,0,0};
+      int nr = 0, first_int = 1, ni = 0;
       if (!(x & 0x80) || k >= 52)
         { fga_set_error("%s: unexpected byte 0x%02x in the binary data section",spath,x);
           goto done;
@@ -624,6 +641,7 @@ static int read_binary_skeleton(skel_ctx *X, const uint8_t *buf, size_t size, co
               if ((u = fga_one_int(p,end,&v)) == 0) goto trunc;
               p += u;
               if (first_int) { ival = v; first_int = 0; }
+              if (ni < 3) iv[ni++] = v;
               break;
             case F_REAL:
               if (p+8 > end) goto trunc;
@@ -702,6 +720,13 @@ static int read_binary_skeleton(skel_ctx *X, const uint8_t *buf, size_t size, co
                 }
               break;
           }
+        }
+      if (t == 'M' && X->want_m)
+        { if (ni < 3 || skel_mline(X,iv[0],iv[1],iv[2]))
+            { if (ni < 3) fga_set_error("%s: M line with fewer than three integers",spath);
+              goto done;
+            }
+          continue;
         }
       if (skel_line(X,(char) t,str,slen,ival,r4))
         goto done;
@@ -910,6 +935,243 @@ fail:
   free(G->bps);
   free(G);
   return 1;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ *  Mask files: `#<mask>[.1ano]` arguments (FastGA.c:4568-4573 -> GIXmake.c:1821-1842)
+ *
+ *  A .1ano / .ano file (ONEcode, binary or ASCII; Read_ANO, ANO.c:105-512) holds a GDB skeleton and M lines
+ *  (scaffold index, beg, end) in scaffold coordinates.  Its scaffolds are matched to the GDB's by name, length and
+ *  contig structure (Are_Skeletons_Equal, GDB.c:2094-2132), every interval goes to the contig its start lies in
+ *  (ANO.c:445-486), and the masks named on the command line are united per contig: intervals in order of their start,
+ *  one that starts AFTER the end so far begins a new interval (ANO_Union, ANO.c:747-757) -- the soft mask the index
+ *  build reads (setup_thread_with_masks, GIXmake.c:1100-1108; fga_gix.c / fga_gixdev.hip).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct { int64_t ctg, beg, end; } mask_iv;
+
+static int mask_iv_cmp(const void *l, const void *r)
+{ const mask_iv *a = l, *b = r;
+  if (a->ctg != b->ctg) return a->ctg < b->ctg ? -1 : 1;
+  if (a->beg != b->beg) return a->beg < b->beg ? -1 : 1;
+  return 0;
+}
+
+/* the intervals of one mask file, in contig coordinates of G, appended to *iv */
+static int ano_read(const fga_gdb *G, const char *path, mask_iv **iv, int64_t *niv, int64_t *cap)
+{ char *root = NULL, *fname = NULL;
+  size_t n = strlen(path);
+  uint8_t *buf = NULL;
+  size_t size = 0;
+  FILE *f = NULL;
+  fga_gdb *A = NULL;
+  skel_ctx X;
+  int *map = NULL;
+  int rc = 1, binary = 0, s, t, c;
+  int64_t i;
+
+  memset(&X,0,sizeof(X));
+  if (n > 5 && strcmp(path+n-5,".1ano") == 0) n -= 5;
+  else if (n > 4 && strcmp(path+n-4,".ano") == 0) n -= 4;
+  if (asprintf(&root,"%.*s",(int) n,path) < 0) { root = NULL; goto oom; }
+  if (asprintf(&fname,"%s.1ano",root) < 0) { fname = NULL; goto oom; }
+  f = fopen(fname,"r");
+  if (f == NULL)
+    { free(fname);
+      if (asprintf(&fname,"%s.ano",root) < 0) { fname = NULL; goto oom; }
+      f = fopen(fname,"r");
+    }
+  if (f == NULL)
+    { fga_set_error("Cannot find/open ANO file %s",path);
+      goto done;
+    }
+  if (fseek(f,0,SEEK_END) == 0)
+    { long sz = ftell(f);
+      rewind(f);
+      if (sz > 0 && (buf = malloc((size_t) sz + 1)) != NULL)
+        { size = fread(buf,1,(size_t) sz,f);
+          buf[size] = '\0';
+        }
+    }
+  fclose(f); f = NULL;
+  if (buf == NULL || size < 8 || memcmp(buf,"1 ",2) != 0 || strstr((char *) buf," ano ") == NULL)
+    { fga_set_error("%s is not a ONEcode ano file",fname);
+      goto done;
+    }
+  { const uint8_t *q = buf;                         /* binary?  The header of a binary file ends with a "$ <endian>" line */
+    while (q < buf+size)
+      { const uint8_t *e = memchr(q,'\n',(size_t) (buf+size-q));
+        if (q[0] == '$') { binary = 1; break; }
+        if (e == NULL || (q[0] & 0x80) || (q[0] >= 'A' && q[0] <= 'z' && q[0] != '~'))
+          break;
+        q = e+1;
+      }
+  }
+  A = calloc(1,sizeof(fga_gdb));
+  if (A == NULL) goto oom;
+  X.G = A; X.want_m = 1;
+  if (binary)
+    { if (read_binary_skeleton(&X,buf,size,fname)) goto done; }
+  else
+    { char *ln = (char *) buf;
+      while (ln != NULL && *ln != '\0')
+        { char *e = strchr(ln,'\n');
+          if (e != NULL) *e = '\0';
+          if (ln[0] != '\0' && (ln[1] == ' ' || ln[1] == '\0'))
+            switch (ln[0])
+            { case 'S':
+                { const char *str; int64_t len;
+                  if (ascii_string(ln+1,&str,&len))
+                    { fga_set_error("%s: malformed S line",fname); goto done; }
+                  if (skel_line(&X,'S',str,len,0,NULL)) goto done;
+                }
+                break;
+              case 'G': case 'C':
+                if (skel_line(&X,ln[0],NULL,0,atoll(ln+1),NULL)) goto done;
+                break;
+              case 'M':
+                { long long a, b, cc;
+                  if (sscanf(ln+1," %lld %lld %lld",&a,&b,&cc) != 3)
+                    { fga_set_error("%s: malformed M line",fname); goto done; }
+                  if (skel_mline(&X,a,b,cc)) goto done;
+                }
+                break;
+              default:
+                break;
+            }
+          ln = e != NULL ? e+1 : NULL;
+        }
+    }
+  if (A->nscaff == 0)
+    { fga_set_error(".1ano does not contain prefacing GDB skeleton");
+      goto done;
+    }
+  A->scaffolds[A->nscaff-1].ectg = A->ncontig;
+  A->scaffolds[A->nscaff-1].slen = X.spos;
+
+  /* its scaffolds in terms of the GDB's */
+  if (A->nscaff != G->nscaff)
+    { fga_set_error("%s: GDB structures not equivalent",fname);
+      goto done;
+    }
+  map = malloc(sizeof(int)*(A->nscaff > 0 ? A->nscaff : 1));
+  if (map == NULL) goto oom;
+  { char *used = calloc(G->nscaff > 0 ? G->nscaff : 1,1);
+    if (used == NULL) goto oom;
+    for (s = 0; s < A->nscaff; s++)
+      { const fga_scaffold *sa = A->scaffolds + s;
+        map[s] = -1;
+        for (t = 0; t < G->nscaff; t++)
+          { const fga_scaffold *ta = G->scaffolds + t;
+            if (used[t] || ta->slen != sa->slen || strcmp(G->headers+ta->hoff,A->headers+sa->hoff) != 0 ||
+                ta->ectg - ta->fctg != sa->ectg - sa->fctg)
+              continue;
+            for (c = ta->fctg; c < ta->ectg; c++)
+              if (G->contigs[c].clen != A->contigs[sa->fctg+(c-ta->fctg)].clen ||
+                  G->contigs[c].sbeg != A->contigs[sa->fctg+(c-ta->fctg)].sbeg)
+                break;
+            if (c < ta->ectg)
+              continue;
+            map[s] = t; used[t] = 1;
+            break;
+          }
+        if (map[s] < 0)
+          { free(used);
+            fga_set_error("%s: GDB structures not equivalent",fname);
+            goto done;
+          }
+      }
+    free(used);
+  }
+  for (i = 0; i < X.nm; i++)
+    { int64_t scf = X.mrec[3*i], beg = X.mrec[3*i+1], end = X.mrec[3*i+2];
+      const fga_scaffold *ts;
+      if (scf < 0 || scf >= A->nscaff)
+        { fga_set_error("%s: %lld'th scaffold not declared in prolog",fname,(long long) scf+1);
+          goto done;
+        }
+      if (beg > end) { const int64_t x = beg; beg = end; end = x; }
+      ts = G->scaffolds + map[scf];
+      c = ts->fctg;
+      while (c+1 < ts->ectg && beg >= G->contigs[c+1].sbeg)
+        c += 1;
+      if (*niv >= *cap)
+        { mask_iv *nv;
+          *cap = *cap ? 2*(*cap) : 4096;
+          nv = realloc(*iv,sizeof(mask_iv)*(*cap));
+          if (nv == NULL) goto oom;
+          *iv = nv;
+        }
+      (*iv)[*niv].ctg = c; (*iv)[*niv].beg = beg - G->contigs[c].sbeg; (*iv)[*niv].end = end - G->contigs[c].sbeg;
+      *niv += 1;
+    }
+  rc = 0;
+  goto done;
+oom:
+  fga_set_error("out of memory");
+done:
+  if (f != NULL) fclose(f);
+  if (A != NULL) { free(A->scaffolds); free(A->contigs); free(A->headers); free(A->srcpath); free(A); }
+  free(X.mrec); free(map); free(buf); free(root); free(fname);
+  return rc;
+}
+
+/* the soft mask of G becomes the union of the masks named: paths[k] = a .1ano / .ano file, or "" for the GDB's own mask
+   (the lower-case runs of its FASTA: what a bare `#` names, GIXmake.c:1829-1832) */
+int fga_gdb_apply_masks(fga_gdb *G, const char *const *paths, int npaths)
+{ mask_iv *iv = NULL;
+  int64_t niv = 0, cap = 0, i, k, out = 0, *moff = NULL, *mbeg = NULL, *mend = NULL;
+  int p;
+  if (G == NULL || (npaths > 0 && paths == NULL))
+    { fga_set_error("fga_gdb_apply_masks: null argument");
+      return 1;
+    }
+  for (p = 0; p < npaths; p++)
+    if (paths[p] == NULL || paths[p][0] == '\0')
+      { int c;
+        for (c = 0; c < G->ncontig && G->nmask > 0; c++)
+          for (i = G->moff[c]; i < G->moff[c+1]; i++)
+            { if (niv >= cap)
+                { mask_iv *nv;
+                  cap = cap ? 2*cap : 4096;
+                  nv = realloc(iv,sizeof(mask_iv)*cap);
+                  if (nv == NULL) { free(iv); fga_set_error("out of memory"); return 1; }
+                  iv = nv;
+                }
+              iv[niv].ctg = c; iv[niv].beg = G->mbeg[i]; iv[niv].end = G->mend[i];
+              niv += 1;
+            }
+      }
+    else if (ano_read(G,paths[p],&iv,&niv,&cap))
+      { free(iv);
+        return 1;
+      }
+  if (niv > 1)
+    qsort(iv,niv,sizeof(mask_iv),mask_iv_cmp);
+  moff = calloc(G->ncontig+1,sizeof(int64_t));
+  mbeg = malloc(sizeof(int64_t)*(niv > 0 ? niv : 1));
+  mend = malloc(sizeof(int64_t)*(niv > 0 ? niv : 1));
+  if (moff == NULL || mbeg == NULL || mend == NULL)
+    { free(iv); free(moff); free(mbeg); free(mend);
+      fga_set_error("out of memory");
+      return 1;
+    }
+  for (i = 0; i < niv; i = k)
+    { int64_t end = -1;
+      for (k = i; k < niv && iv[k].ctg == iv[i].ctg; k++)
+        if (iv[k].beg > end)
+          { mbeg[out] = iv[k].beg; mend[out] = end = iv[k].end;
+            out += 1;
+            moff[iv[i].ctg+1] += 1;
+          }
+        else if (iv[k].end > end)
+          mend[out-1] = end = iv[k].end;
+    }
+  for (p = 0; p < G->ncontig; p++)
+    moff[p+1] += moff[p];
+  free(G->moff); free(G->mbeg); free(G->mend);
+  G->moff = moff; G->mbeg = mbeg; G->mend = mend; G->nmask = out;
+  free(iv);
+  return 0;
 }
 
 void fga_gdb_close(fga_gdb *G)

@@ -81,6 +81,7 @@ int      fga_gdb_open(const char *path, fga_gdb **out);
 void     fga_gdb_close(fga_gdb *G);
 uint8_t *fga_gdb_get_contig(const fga_gdb *G, int c, uint8_t *buf);
 int      fga_gdb_write_skeleton(const fga_gdb *G, const char *path, const char *prog, const char *command);
+int      fga_gdb_apply_masks(fga_gdb *G, const char *const *paths, int npaths);   /* "#<mask>" arguments: the union becomes G's soft mask */
 
 /* binary ONEcode pieces shared by the GDB and the .1aln readers (fga_one.c) */
 typedef struct

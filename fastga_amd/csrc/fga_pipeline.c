@@ -721,7 +721,9 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
           if (fga_session_align(Z,P,part,&raw[p],&st)) goto done;
           /* this part's records through the redundancy filter in the background (every contig pair's records are in the
              part that owns the A contig) while the next part's kernels run */
-          pf[p].in = raw[p]; pf[p].nthreads = P->nthreads > 2 ? P->nthreads/2 : 1;
+          /* half of the run's threads beside the next part's kernels (whose host tails want the rest); all of them for the
+             last part, which nothing runs beside */
+          pf[p].in = raw[p]; pf[p].nthreads = p == nparts-1 ? P->nthreads : (P->nthreads > 2 ? P->nthreads/2 : 1);
           if (pthread_create(&pf[p].th,NULL,part_filter_main,&pf[p]) == 0)
             pf[p].started = 1;
           else

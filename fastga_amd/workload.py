@@ -112,7 +112,8 @@ def digest_1aln(lines):
     order = " ".join(" ".join(r.split("\n", 1)[0].split()[1:3]) for r in recs)
     md5 = lambda t: hashlib.md5(t.encode()).hexdigest()      # noqa: E731
     return {"records": len(recs), "header_md5": md5("\n".join(lines[:first])),
-            "records_md5": md5("\n".join(sorted(recs))), "order_md5": md5(order)}
+            "records_md5": md5("\n".join(sorted(recs))), "order_md5": md5(order),
+            "lines_md5": md5("".join(ln + "\n" for ln in lines[first:]))}      # the record lines in sequence: ties included
 
 
 def digest_1aln_stream(path, oneview_bin):
@@ -123,7 +124,7 @@ def digest_1aln_stream(path, oneview_bin):
     import hashlib
     import subprocess
     p = subprocess.Popen([oneview_bin, path], stdout=subprocess.PIPE, text=True, bufsize=1 << 20)
-    head, order = hashlib.md5(), hashlib.md5()
+    head, order, seq = hashlib.md5(), hashlib.md5(), hashlib.md5()
     total, nrec, cur, in_head, first = 0, 0, [], True, True
     mask = (1 << 128) - 1
 
@@ -148,8 +149,9 @@ def digest_1aln_stream(path, oneview_bin):
             head.update((ln + "\n").encode())
         else:
             cur.append(ln)
+            seq.update((ln + "\n").encode())
     close_record()
     if p.wait() != 0:
         raise RuntimeError(f"{oneview_bin} {path} failed")
     return {"records": nrec, "header_md5": head.hexdigest(), "records_sum128": f"{total:032x}",
-            "order_md5": order.hexdigest()}
+            "order_md5": order.hexdigest(), "lines_md5": seq.hexdigest()}      # lines_md5: the record lines in sequence

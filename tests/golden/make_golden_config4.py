@@ -21,13 +21,14 @@ ap.add_argument("--mbp", type=float, default=3000.0)
 ap.add_argument("--threads", type=int, default=32)
 ap.add_argument("--workdir", default="/dev/shm/fga_golden")
 ap.add_argument("--no-gpu", action="store_true")
+ap.add_argument("--outdir", default=HERE, help="where the digests go (default: beside this script)")
 a = ap.parse_args()
 for name, div in (("config4", 0.01), ("config5", 0.10)):
     wd = os.path.join(a.workdir, name)
     os.makedirs(wd, exist_ok=True)
     cmd = [sys.executable, os.path.join(ROOT, "tools", "config4_check.py"), "--mbp", f"{a.mbp:g}", "--div", f"{div:g}",
            "--reference", "--ref-threads", str(a.threads), "--workdir", wd,
-           "--golden", os.path.join(HERE, f"{name}_{a.mbp:g}m_digest.json")] + (["--no-gpu"] if a.no_gpu else [])
+           "--golden", os.path.join(a.outdir, f"{name}_{a.mbp:g}m_digest.json")] + (["--no-gpu"] if a.no_gpu else [])
     print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     subprocess.run(["rm", "-rf", wd])

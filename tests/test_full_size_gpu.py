@@ -186,11 +186,11 @@ def test_config3_1gbp_self_soft_masked_matches_the_reference_digest(tmp_path_fac
     d = str(tmp_path_factory.mktemp("c3g"))
     root = workload.build_config3(d, mbp=1000.0, threads=T)
     ours = os.path.join(d, "ours.1aln")
-    st = D.run(root, None, ours, nthreads=T, soft_mask=True)
+    st = D.run(root, None, ours, nthreads=T, soft_mask=True, reference_threads=exp.get("reference_threads", 8))
     got = workload.digest_1aln(H.oneview(ours))
     # the reference halves the seed count of a self comparison per merge thread (FastGA.c:1906): sum of floors
     assert 0 <= st["nseeds"] - exp["total_seeds"] <= 64
-    for k in ("records", "header_md5", "records_md5", "order_md5"):
+    for k in ("records", "header_md5", "records_md5", "order_md5", "lines_md5"):      # lines_md5: the record lines in sequence
         assert got[k] == exp[k], (k, got, exp, st)
 
 
@@ -217,16 +217,17 @@ def test_configs_4_and_5_at_3gbp_match_the_reference_digests(tmp_path_factory, b
         ra, rb = workload.build_config4(d, mbp=3000.0, divergence=div, threads=T)
         ses = D.Session(ra, rb)
         ours = os.path.join(d, "ours.1aln")
-        st = ses.run(out_path=ours, nthreads=T)
+        RT = exp.get("reference_threads", 32)                     # ties on (aread, abpos) as FastGA -T32 wrote them
+        st = ses.run(out_path=ours, nthreads=T, reference_threads=RT)
         got = workload.digest_1aln_stream(ours, oneview)
         assert st["nseeds"] == exp["total_seeds"] and st["nhits"] == exp["hits"] and st["nalns"] == exp["alignments"]
-        for k in ("records", "header_md5", "records_sum128", "order_md5"):
+        for k in ("records", "header_md5", "records_sum128", "order_md5", "lines_md5"):   # lines_md5: the record lines in sequence
             assert got[k] == exp[k], (k, got, exp, st)
         assert st["nparts"] >= 2                                   # more seeds than one sort pass takes
         assert st["hbm_peak_bytes"] < 286 << 30               # everything the two passes need at once fits the device
         os.unlink(ours)
         out8 = os.path.join(d, "parts8.1aln")
-        st8 = parallel.run_parts_on_one_gpu(ses, 8, out_path=out8, nthreads=T)
+        st8 = parallel.run_parts_on_one_gpu(ses, 8, out_path=out8, nthreads=T, reference_threads=RT)
         assert st8["nseeds"] == exp["total_seeds"] and len(st8["part_seed_counts"]) == 8
         assert max(st8["part_seed_counts"]) < 1.1 * min(st8["part_seed_counts"])       # balanced on seed counts
         got8 = workload.digest_1aln_stream(out8, oneview)

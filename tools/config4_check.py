@@ -47,7 +47,7 @@ if not a.no_gpu:
     ses = D.Session(ra, rb)
     print(f"upload + 2 device index builds: {time.time()-t:.2f} s, tables {ses.table_bytes/1e9:.1f} GB", flush=True)
     t = time.time()
-    st = ses.run(out_path=ours, nthreads=a.threads, pass_seeds=a.pass_seeds)
+    st = ses.run(out_path=ours, nthreads=a.threads, pass_seeds=a.pass_seeds, reference_threads=a.ref_threads or a.threads)
     dt = time.time() - t
     print(f"fga_session_run: {dt:.2f} s = {a.mbp*1e-3/dt:.2f} Gbp-pair/s | seeds {st['nseeds']} hits {st['nhits']} units {st['nunits']} "
           f"alns {st['nalns']} records {st['nlive']} waves {st['nwaves']} parts {st['nparts']} peak HBM {st['hbm_peak_bytes']/2**30:.1f} GiB", flush=True)
@@ -65,7 +65,8 @@ if not a.no_gpu:
     if a.parts > 1:
         out2 = os.path.join(d, "parts.1aln")
         t = time.time()
-        st2 = parallel.run_parts_on_one_gpu(ses, a.parts, out_path=out2, nthreads=a.threads)
+        st2 = parallel.run_parts_on_one_gpu(ses, a.parts, out_path=out2, nthreads=a.threads,
+                                            reference_threads=a.ref_threads or a.threads)
         print(f"{a.parts} ranges x {a.parts} parts: {time.time()-t:.2f} s | seeds {st2['nseeds']} records {st2['nlive']} "
               f"part seeds {st2['part_seed_counts']}", flush=True)
         if os.path.exists(oneview):
@@ -100,7 +101,7 @@ if a.reference:
     res["reference_digest"] = dg
     print("   reference digest:", dg, flush=True)
     if "ours_digest" in res:
-        same = all(res["ours_digest"][k] == dg[k] for k in ("records", "header_md5", "records_sum128", "order_md5"))
+        same = all(res["ours_digest"][k] == dg[k] for k in ("records", "header_md5", "records_sum128", "order_md5", "lines_md5"))
         print("   ours == reference:", same, flush=True)
         res["identical"] = same
     if a.golden:
