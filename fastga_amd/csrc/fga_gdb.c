@@ -1126,7 +1126,21 @@ int fga_gdb_apply_masks(fga_gdb *G, const char *const *paths, int npaths)
       return 1;
     }
   for (p = 0; p < npaths; p++)
-    if (paths[p] == NULL || paths[p][0] == '\0')
+    if ((paths[p] == NULL || paths[p][0] == '\0') && G->nmask == 0 && G->path != NULL)
+      { /* the GDB's own mask, of a GDB the reference's FAtoGDB made: <root>.1ano beside the skeleton (GIXmake.c:1829-1832) */
+        char *ap = NULL;
+        size_t n = strlen(G->path);
+        FILE *tf;
+        if (n > 5 && strcmp(G->path+n-5,".1gdb") == 0) n -= 5;
+        else if (n > 4 && strcmp(G->path+n-4,".gdb") == 0) n -= 4;
+        if (asprintf(&ap,"%.*s.1ano",(int) n,G->path) < 0) { free(iv); fga_set_error("out of memory"); return 1; }
+        if ((tf = fopen(ap,"r")) != NULL)
+          { fclose(tf);
+            if (ano_read(G,ap,&iv,&niv,&cap)) { free(ap); free(iv); return 1; }
+          }
+        free(ap);
+      }
+    else if (paths[p] == NULL || paths[p][0] == '\0')
       { int c;
         for (c = 0; c < G->ncontig && G->nmask > 0; c++)
           for (i = G->moff[c]; i < G->moff[c+1]; i++)

@@ -83,16 +83,24 @@ int fga_session_open(const char *root1, const char *root2, int device, fga_sessi
 
 /* nthreads: GIXmake's -T for an index the session has to build itself -- it decides the contig padding of a short GDB
    and the table parts (SURVEY.md hard part 9), i.e. the layout FastGA -T<n> would have got from its GIXmake call */
+typedef struct { const char *const *m1; int n1; const char *const *m2; int n2; } mask_args;
 static int session_open_impl(const char *root1, const char *root2, int device, int nthreads, int rank, int nranks, int flags,
-                             fga_session **out);
+                             const mask_args *masks, fga_session **out);
 
 int fga_session_open_threads(const char *root1, const char *root2, int device, int nthreads, fga_session **out)
-{ return session_open_impl(root1,root2,device,nthreads,0,1,0,out); }
+{ return session_open_impl(root1,root2,device,nthreads,0,1,0,NULL,out); }
 
 /* flags: FGA_SESSION_BUILD_INDEX -- the genome indices are built on the device even when <root>.gix files exist (they may
    be another program's: a parity run against the reference's own GIXmake output) */
 int fga_session_open_flags(const char *root1, const char *root2, int device, int nthreads, int flags, fga_session **out)
-{ return session_open_impl(root1,root2,device,nthreads,0,1,flags,out); }
+{ return session_open_impl(root1,root2,device,nthreads,0,1,flags,NULL,out); }
+
+int fga_session_open_masked(const char *root1, const char *root2, int device, int nthreads, int flags,
+                            const char *const *masks1, int nmasks1, const char *const *masks2, int nmasks2, fga_session **out)
+{ mask_args M;
+  M.m1 = masks1; M.n1 = nmasks1; M.m2 = masks2; M.n2 = nmasks2;
+  return session_open_impl(root1,root2,device,nthreads,0,1,flags,&M,out);
+}
 
 int fga_session_open_sliced(const char *root1, const char *root2, int device, int nthreads, int rank, int nranks,
                             fga_session **out)
@@ -101,7 +109,7 @@ int fga_session_open_sliced(const char *root1, const char *root2, int device, in
       *out = NULL;
       return 1;
     }
-  return session_open_impl(root1,root2,device,nthreads,rank,nranks,0,out);
+  return session_open_impl(root1,root2,device,nthreads,rank,nranks,0,NULL,out);
 }
 
 /* prefix ranges of equal merge cost (entries of both tables + 2 per prefix) from the tables' per-prefix entry counts:
@@ -135,7 +143,7 @@ static void cuts_from_counts(const int64_t *idx1, const int64_t *idx2, const uin
 }
 
 static int session_open_impl(const char *root1, const char *root2, int device, int nthreads, int rank, int nranks, int flags,
-                             fga_session **out)
+                             const mask_args *masks, fga_session **out)
 { fga_session *Z = calloc(1,sizeof(fga_session));
   double t0;
   *out = NULL;
@@ -149,9 +157,16 @@ static int session_open_impl(const char *root1, const char *root2, int device, i
      into HBM (no .gix/.ktab files appear, like the reference without -k) */
   { const int build = (flags & FGA_SESSION_BUILD_INDEX) != 0;
     int have1 = !build && gix_exists(root1), have2 = Z->self ? 1 : (!build && gix_exists(root2));
-    if (fga_gdb_open(root1,&Z->g1) || (have1 && fga_gix_open(root1,&Z->x1))) goto fail;
+    /* a genome with masks named gets its index built anew with their union as its soft mask (the reference runs GIXmake
+       with the masks, FastGA.c:4739-4776) */
+    if (masks != NULL && masks->n1 > 0) have1 = 0;
+    if (masks != NULL && masks->n2 > 0 && !Z->self) have2 = 0;
+    if (fga_gdb_open(root1,&Z->g1) || (masks != NULL && masks->n1 > 0 && fga_gdb_apply_masks(Z->g1,masks->m1,masks->n1)) ||
+        (have1 && fga_gix_open(root1,&Z->x1))) goto fail;
     if (!Z->self)
-      { if (fga_gdb_open(root2,&Z->g2) || (have2 && fga_gix_open(root2,&Z->x2))) goto fail; }
+      { if (fga_gdb_open(root2,&Z->g2) || (masks != NULL && masks->n2 > 0 && fga_gdb_apply_masks(Z->g2,masks->m2,masks->n2)) ||
+            (have2 && fga_gix_open(root2,&Z->x2))) goto fail;
+      }
     Z->load_s = fga_wall() - t0;
     if (fga_dev_open(device,&Z->dev)) goto fail;
     t0 = fga_wall();
@@ -774,8 +789,8 @@ done:
 int fga_run(const char *root1, const char *root2, const fga_run_params *P, fga_run_stats *S)
 { fga_session *Z;
   int rc;
-  if (fga_session_open_flags(root1,root2,P->device,P->nthreads > 0 ? P->nthreads : 8,
-                             P->build_index ? FGA_SESSION_BUILD_INDEX : 0,&Z))
+  if (fga_session_open_masked(root1,root2,P->device,P->nthreads > 0 ? P->nthreads : 8,
+                              P->build_index ? FGA_SESSION_BUILD_INDEX : 0,P->masks1,P->nmasks1,P->masks2,P->nmasks2,&Z))
     return 1;
   rc = fga_session_run(Z,P,S);
   fga_session_close(Z);

@@ -306,14 +306,21 @@ def trace_pts(dev, ga, gb, alns, tb, tspace=100, self_cmp=False):
 
 def run(root1, root2=None, out_path=None, device=0, freq=10, soft_mask=False, symmetric=False, chain_break=1000,
         chain_min=85, align_min=100, identity=0.7, nthreads=8, command_line="FastGA", paf_path=None, paf_flags=0,
-        pass_seeds=0, reference_threads=0, build_index=False):
+        pass_seeds=0, reference_threads=0, build_index=False, masks1=None, masks2=None):
     """The whole hot path (fga_run): prebuilt GDB/GIX roots in, .1aln (and PAF) out.  Returns the stats as a dict.
     reference_threads = n > 0: records that tie on (aread, abpos) in the order `FastGA -T<n>` writes them."""
     from .lib import RunParams, RunStats
     L = load_library()
+    def cstrs(paths):
+        if not paths:
+            return None, 0
+        return (C.c_char_p * len(paths))(*[p.encode() for p in paths]), len(paths)
+    m1, n1 = cstrs(masks1)
+    m2, n2 = cstrs(masks2)
     prm = RunParams(device, freq, int(soft_mask), int(symmetric), 2 * chain_break, 2 * chain_min, align_min,
                     1.0 - identity, nthreads, out_path.encode() if out_path else None, command_line.encode(),
-                    paf_path.encode() if paf_path else None, paf_flags, pass_seeds, int(build_index), reference_threads)
+                    paf_path.encode() if paf_path else None, paf_flags, pass_seeds, int(build_index), m1, n1, m2, n2,
+                    reference_threads)
     st = RunStats()
     check(L.fga_run(root1.encode(), root2.encode() if root2 else None, C.byref(prm), C.byref(st)), "fga_run")
     return {n: getattr(st, n) for n, _ in RunStats._fields_}
@@ -344,7 +351,8 @@ class Session:
         from .lib import RunParams, RunStats
         prm = RunParams(0, freq, int(soft_mask), int(symmetric), 2 * chain_break, 2 * chain_min, align_min,
                         1.0 - identity, nthreads, out_path.encode() if out_path else None, command_line.encode(),
-                        paf_path.encode() if paf_path else None, paf_flags, pass_seeds, int(build_index), reference_threads)
+                        paf_path.encode() if paf_path else None, paf_flags, pass_seeds, int(build_index), None, 0, None, 0,
+                    reference_threads)
         st = RunStats()
         check(self.L.fga_session_run(self.h, C.byref(prm), C.byref(st)), "session run")
         return {n: getattr(st, n) for n, _ in RunStats._fields_}
@@ -356,7 +364,8 @@ class Session:
         from .lib import RunParams
         return RunParams(0, freq, int(soft_mask), int(symmetric), 2 * chain_break, 2 * chain_min, align_min,
                          1.0 - identity, nthreads, out_path.encode() if out_path else None, command_line.encode(),
-                         paf_path.encode() if paf_path else None, paf_flags, pass_seeds, int(build_index), reference_threads)
+                         paf_path.encode() if paf_path else None, paf_flags, pass_seeds, int(build_index), None, 0, None, 0,
+                    reference_threads)
 
     def new_stats(self):
         from .lib import RunStats

@@ -83,7 +83,9 @@ class RunParams(C.Structure):
                 ("chain_break", C.c_int), ("chain_min", C.c_int), ("align_min", C.c_int),
                 ("align_rate", C.c_double), ("nthreads", C.c_int), ("out_path", C.c_char_p),
                 ("command_line", C.c_char_p), ("paf_path", C.c_char_p), ("paf_flags", C.c_int),
-                ("pass_seeds", C.c_int64), ("build_index", C.c_int), ("reference_threads", C.c_int)]
+                ("pass_seeds", C.c_int64), ("build_index", C.c_int),
+                ("masks1", C.POINTER(C.c_char_p)), ("nmasks1", C.c_int), ("masks2", C.POINTER(C.c_char_p)), ("nmasks2", C.c_int),
+                ("reference_threads", C.c_int)]
 
 
 class RunStats(C.Structure):
@@ -192,6 +194,7 @@ def _declare(L):
         "fga_session_open": (i32, [cp, cp, i32, P(vp)]),
         "fga_session_open_threads": (i32, [cp, cp, i32, i32, P(vp)]),
         "fga_session_open_flags": (i32, [cp, cp, i32, i32, i32, P(vp)]),
+        "fga_gdb_apply_masks": (i32, [vp, P(cp), i32]),
         "fga_session_run": (i32, [vp, P(RunParams), P(RunStats)]),
         "fga_session_close": (None, [vp]),
         "fga_session_device": (vp, [vp]),

@@ -338,6 +338,11 @@ typedef struct
     int64_t pass_seeds;      /* most seeds one sort / search pass takes (0: 1.5 G); more -> phase 2 runs over A-contig
                                 parts, the reference's NPARTS loop (FastGA.c:5186-5204)  */
     int     build_index;     /* fga_run: build the genome indices on the device even when <root>.gix files exist */
+    /* `#<mask>` arguments (FastGA.c:4568-4573): .1ano / .ano files whose union is the genome's soft mask ("" = the GDB's own
+       lower-case mask); a genome with masks named gets its index built anew, like the reference's GIXmake call, and the
+       comparison runs with soft masking on.  fga_run only. */
+    const char *const *masks1; int nmasks1;
+    const char *const *masks2; int nmasks2;
     int     reference_threads; /* n > 0: records that tie on (aread, abpos) in the order `FastGA -T<n>` writes them -- by the
                                 slot of the search thread that held the A contig's panel of that strand (la_merge,
                                 FastGA.c:3906-3918; fga_reference_slots); 0: by (bread, strand, survival)           */
@@ -408,6 +413,12 @@ int      fga_session_open(const char *root1, const char *root2, int device, fga_
 int      fga_session_open_threads(const char *root1, const char *root2, int device, int nthreads, fga_session **out);
 enum { FGA_SESSION_BUILD_INDEX = 1 };   /* indices built on the device even when <root>.gix files exist */
 int      fga_session_open_flags(const char *root1, const char *root2, int device, int nthreads, int flags, fga_session **out);
+/* the same with mask files named for the genomes (see fga_run_params.masks1): their indices are built on the device */
+int      fga_session_open_masked(const char *root1, const char *root2, int device, int nthreads, int flags,
+                                 const char *const *masks1, int nmasks1, const char *const *masks2, int nmasks2,
+                                 fga_session **out);
+/* the soft mask of an opened GDB becomes the union of the masks named (Read_ANO + ANO_Union, ANO.c:105-512, 678-830) */
+int      fga_gdb_apply_masks(fga_gdb *gdb, const char *const *paths, int npaths);
 /* rank `rank` of `nranks` of one comparison: the session holds only ITS 12-mer prefix range of both tables (the genomes'
  * bases stay whole: phase 2 needs them).  The ranges are cut for equal merge cost from the tables' per-prefix counts, the
  * same on every rank without communication; fga_session_prefix_cuts(s, nranks, ..) returns them, and fga_session_merge

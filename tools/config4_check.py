@@ -23,6 +23,7 @@ ap.add_argument("--golden", default=None)
 ap.add_argument("--workdir", default=None)
 ap.add_argument("--no-gpu", action="store_true", help="reference only (golden made on a box without a GPU)")
 ap.add_argument("--keep", action="store_true")
+ap.add_argument("--no-digest", action="store_true", help="skip the ONEview digest of our .1aln (profiling runs)")
 a = ap.parse_args()
 
 def sh(cmd):
@@ -58,7 +59,7 @@ if not a.no_gpu:
           f"= {alg/st['merge_kernel_ms']/1e6/8000:.3f} of 8 TB/s", flush=True)
     res["ours"] = {k: st[k] for k in ("nseeds", "nhits", "nunits", "nalns", "nlive", "nwaves", "nparts", "hbm_peak_bytes")}
     res["ours"]["seconds"] = dt
-    if os.path.exists(oneview):
+    if os.path.exists(oneview) and not a.no_digest:
         t = time.time()
         res["ours_digest"] = workload.digest_1aln_stream(ours, oneview)
         print(f"   digest ({time.time()-t:.0f} s): {res['ours_digest']}", flush=True)

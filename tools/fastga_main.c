@@ -11,8 +11,14 @@
  * HBM; a GDB created from a FASTA source is removed again unless -k (Clean_Exit, FastGA.c:152-196).
  * What differs: the sub-process glue is in-process -- a missing GDB / GIX is built with this library's own producers
  * (fga_fasta_to_gdb; the index on the device, or as files with -k) instead of system("FAtoGDB"/"GIXmake"), PAF / PSL are
- * written natively instead of through ALNtoPAF / ALNtoPSL, and "#<mask>" arguments (external .1bed / .1ano mask files
- * for GIXmake) are refused with a message: soft masks come from lower-case FASTA (-M).
+ * written natively instead of through ALNtoPAF / ALNtoPSL.  "#[<mask>[.1ano]]" arguments name the masks of the genome
+ * before them ("#" alone: the GDB's own lower-case mask); the union of a genome's masks becomes its soft mask
+ * (fga_gdb_apply_masks: Read_ANO + ANO_Union), its index is built with it and soft masking is on -- what the reference's
+ * usage text promises.  (The reference itself hands the masks to `GIXmake ... #<mask>` through system(), where the shell
+ * reads " #<mask>" as a comment, and files a mask behind the FIRST genome under the second, FastGA.c:4568-4573: its own
+ * FastGA never applies them.  The pin for this build is therefore the two-step form, `GIXmake <genome> #<mask>` followed by
+ * `FastGA -M`: tests/test_mask_files.py, tests/test_mask_files_gpu.py.)  Records that tie on (aread, abpos) come in the
+ * order `FastGA -T<n>` writes them (fga_order.c; FGA_TIE_ORDER=own: an order that does not depend on -T).
  */
 #define _GNU_SOURCE
 #include <stdio.h>
@@ -144,7 +150,7 @@ static void clean_exit(int status)
   exit(status);
 }
 
-static int prepare(const char *src, source *S, int nthreads, int want_gix_files)
+static int prepare(const char *src, source *S, int nthreads, int want_gix_files, const char *const *masks, int nmasks)
 { int isfa;
   char *r = root_of(src,&isfa);
   S->root = r;
@@ -172,11 +178,14 @@ static int prepare(const char *src, source *S, int nthreads, int want_gix_files)
         }
       free(fa);
     }
-  if (!exists("%s.gix",r) && want_gix_files)        /* otherwise the index is built on the device, in HBM only */
+  /* index files only with -k (otherwise the index is built on the device, in HBM only); a genome with masks named gets
+     them made anew with the union of the masks, as the reference's GIXmake call would (FastGA.c:4739-4776) */
+  if ((!exists("%s.gix",r) || nmasks > 0) && want_gix_files)
     { fga_gdb *g;
       say("\n  Creating genome index (GIX) %s.gix\n",r);
       S->made_gix = 1;
-      if (fga_gdb_open(r,&g) || fga_gix_build_masked(g,r,nthreads,fga_gdb_nmask(g) > 0))
+      if (fga_gdb_open(r,&g) || (nmasks > 0 && fga_gdb_apply_masks(g,masks,nmasks)) ||
+          fga_gix_build_masked(g,r,nthreads,fga_gdb_nmask(g) > 0))
         { fprintf(stderr,"FastGA: %s\n",fga_last_error());
           return 1;
         }
@@ -206,6 +215,8 @@ int main(int argc, char *argv[])
   char *src[2] = { NULL, NULL }, *out = NULL, *outpath = NULL;
   const char *tmpdir, *logpath = NULL;
   int nsrc = 0, paf = 0, i;
+  const char *mask1[64], *mask2[64];
+  int nmask1 = 0, nmask2 = 0;
   int cmin = 85, cbreak = 1000;
   double ident = .7;
   char cmd[4096];
@@ -283,14 +294,11 @@ int main(int argc, char *argv[])
           }
       }
     else if (argv[i][0] == '#')
-      { /* "#" alone = the implicit mask of the preceding genome (the lower-case intervals its GDB carries, GIXmake.c:1829-
-           1832): that is the mask this build's index always carries, so the argument only switches soft masking on
-           (FastGA.c:4580).  A named .1ano / .1bed file would need GIXmake's ANO reader: refused. */
-        if (argv[i][1] != '\0')
-          { fprintf(stderr,"FastGA: mask file arguments (%s) are not supported by this build: the index is made from the GDB's\n"
-                           "        own lower-case intervals; soft-mask the FASTA and use -M or a bare #\n",argv[i]);
-            return 1;
-          }
+      { /* a mask of the preceding genome (FastGA.c:4568-4573): "#" alone = its implicit mask (the lower-case intervals the
+           GDB carries, GIXmake.c:1829-1832), "#<mask>[.1ano]" = a ONEcode annotation file; the union of a genome's masks is
+           its soft mask, its index is built anew with it, and soft masking is on (FastGA.c:4580) */
+        if (nsrc >= 2) { if (nmask2 < 64) mask2[nmask2++] = argv[i]+1; }
+        else           { if (nmask1 < 64) mask1[nmask1++] = argv[i]+1; }
         P.soft_mask = 1;
       }
     else if (nsrc < 2)
@@ -338,9 +346,13 @@ int main(int argc, char *argv[])
         clean_exit(1);
       P.out_path = outpath;
     }
+  if (nsrc == 1 && nmask2 > 0)                    /* (cannot happen: masks after the only genome are its own) */
+    nmask2 = 0;
   for (i = 0; i < nsrc; i++)
-    if (prepare(src[i],Src+i,P.nthreads,Keep))
+    if (prepare(src[i],Src+i,P.nthreads,Keep,i == 0 ? mask1 : mask2,i == 0 ? nmask1 : nmask2))
       clean_exit(1);
+  P.masks1 = mask1; P.nmasks1 = nmask1;
+  P.masks2 = mask2; P.nmasks2 = nmask2;
   if (nsrc == 2 && strcmp(Src[0].root,Src[1].root) == 0)
     nsrc = 1;
 

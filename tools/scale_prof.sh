@@ -14,5 +14,37 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $out/prof_$tag/c3 -o kt --output
 cp $out/prof_$tag/c3/kt_kernel_stats.csv $out/${tag}_config3_kernel_stats.csv
 timeout 300 rocprofv3 --kernel-trace --stats -d $out/prof_$tag/thr -o kt --output-format csv -- python $root/tools/scale_check.py --mbp 150 --self --repeats 0.30 > $out/prof_$tag/thr.log 2>&1
 cp $out/prof_$tag/thr/kt_kernel_stats.csv $out/${tag}_throughput_kernel_stats.csv
+# PMC passes over the same shapes (each counter group in its own run, no trace domains): the kernels that dominate them --
+# the sort passes, ext_mid, the seed merge at 3 Gbp and in self mode, the index build -- with their counters per launch
+pmc_shape() { shape=$1; shift
+  for grp in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES" \
+             "sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" "lds SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
+    set -- $grp; name=$1; shift
+    timeout 400 rocprofv3 --pmc "$@" -d $out/prof_$tag/pmc_${shape}_$name -o pmc --output-format csv -- $CMD > $out/prof_$tag/pmc_${shape}_$name.log 2>&1
+  done
+  python - "$out/prof_$tag" "$shape" "$out/${tag}_${shape}_pmc_summary.csv" "$CMD" <<'PY'
+import csv, glob, sys, collections
+src, shape, dst, cmd = sys.argv[1:5]
+rows = []
+for name in ("fetch", "write", "sq", "sq2", "lds"):
+    agg = collections.defaultdict(lambda: [0.0, set()])
+    for f in glob.glob(f"{src}/pmc_{shape}_{name}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = (r["Kernel_Name"].split("(")[0], r["Counter_Name"])
+            agg[k][0] += float(r["Counter_Value"]); agg[k][1].add(r["Dispatch_Id"])
+    for (k, c), (v, d) in sorted(agg.items()):
+        if any(x in k for x in ("pass_kernel", "extend_kernel", "seed_merge", "gix_", "chain_small", "chain_segment")):
+            rows.append(("pmc_" + name, k, c, len(d), v / max(1, len(d))))
+with open(dst, "w") as f:
+    f.write("# command: %s under rocprofv3 --pmc <counters> (one pass per counter group); FETCH_SIZE / WRITE_SIZE in KiB\n" % cmd)
+    f.write("pass,kernel,counter,launches,avg_per_launch\n")
+    w = csv.writer(f, lineterminator="\n")
+    for r in rows:
+        w.writerow([r[0], r[1], r[2], r[3], "%.6g" % r[4]])
+PY
+}
+CMD="python $root/tools/config4_check.py --mbp 3000 --div 0.01 --no-digest"; pmc_shape config4
+CMD="python $root/tools/scale_check.py --mbp 150 --self --repeats 0.30"; pmc_shape throughput
+CMD="python $root/tools/config3_check.py --mbp 1000"; pmc_shape config3
 grep -h "fga_session_run\|stages\|run 1" $out/prof_$tag/c4.log $out/prof_$tag/c3.log $out/prof_$tag/thr.log
 for f in config4 config3 throughput; do echo "== $f"; head -14 $out/${tag}_${f}_kernel_stats.csv | cut -c1-150; done
