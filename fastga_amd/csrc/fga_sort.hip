@@ -294,8 +294,9 @@ void os_scan256_kernel(const unsigned long long *ghist, unsigned long long *gbas
   if (threadIdx.x == 0)
     { unsigned long long run = 0;
       for (int d = 0; d < 256; d++) { const unsigned long long v = t[d]; t[d] = run; run += v; }
-      *ticket = 0;
     }
+  if (threadIdx.x < 8)
+    ticket[threadIdx.x*32] = 0;                 // the eight ticket queues of a pass (OS_TICKET_STRIDE), queue 0 = the only one of os_pass_kernel
   __syncthreads();
   gbase[threadIdx.x] = t[threadIdx.x];
   if (clear != NULL)
@@ -429,7 +430,7 @@ template <bool FROM_SEEDS, int NW>
 __global__ __launch_bounds__(NW*64)
 void osw_pass_kernel(const void *in, uint4 *out, int64_t n, int shift, int next_shift, key_layout L, int stamp,
                      const unsigned long long *gbase, unsigned long long *status, unsigned long long *next_hist,
-                     unsigned int *ticket, const uint16_t *valid)
+                     unsigned int *ticket, const uint16_t *valid, unsigned chunk)
 { constexpr int NT = NW*64, TILE = NW*1024, ROUNDS = TILE/OSW_STAGE, SPT = OSW_STAGE/NT;
   __shared__ uint32_t wcnt[NW][256];          // per-wave digit counts, then per-wave digit bases inside the tile
   __shared__ long long off[256];              // position in `out` of the digit's first key of this tile, minus its tile position
@@ -439,13 +440,33 @@ void osw_pass_kernel(const void *in, uint4 *out, int64_t n, int shift, int next_
   __shared__ uint32_t wsum[4];
   __shared__ int tile_s, total_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // Tiles are taken from eight queues, one per XCD (workgroup b runs on XCD b mod 8): queue x hands out the tiles of the
+  // chunks x, x+8, x+16, .. of `chunk` consecutive tiles, in order.  Neighbouring tiles then share an XCD's L2, where the
+  // two partial blocks at the ends of their runs of a digit meet and leave as one whole block (32-key runs: 3.3 -> 4.2 TB/s
+  // in tools/ubench/sort_bench's store patterns).  Forward progress does not depend on where or in which order workgroups
+  // start, only on this: a queue's tickets map to increasing tiles, so the tiles handed out AHEAD of the smallest tile not
+  // yet handed out are at most 7 x chunk (one chunk per other queue); they wait in their look-back, everything else that
+  // is resident works on smaller tiles, finishes and makes room for the workgroup that takes that tile.  The host keeps
+  // 7 x chunk well below the workgroups the device holds at once.  A queue that has run out sends the workgroup to the
+  // next one (as many workgroups as tiles are launched).
   if (tid == 0)
-    tile_s = (int) atomicAdd(ticket,1u);
+    { int t = -1;
+      for (int k = 0; k < 8 && t < 0; k++)
+        { const unsigned q = (blockIdx.x + (unsigned) k) & 7u;
+          const unsigned tk = atomicAdd(ticket + q*32,1u);
+          const long long cand = ((long long) (tk / chunk)*8 + q)*chunk + tk % chunk;
+          if (cand*TILE < n)
+            t = (int) cand;
+        }
+      tile_s = t;
+    }
   for (int x = tid; x < NW*256; x += NT)
     (&wcnt[0][0])[x] = 0;
   if (tid < 256) nh[tid] = 0;
   __syncthreads();
   const int tile = tile_s;
+  if (tile < 0)                               // (cannot happen: tiles and workgroups are as many)
+    return;
 
   const int64_t wbase = (int64_t) tile * TILE + (int64_t) wave * 1024;       // a wavefront's 1024 items: one block of the seed buffer
   const int vcount = (FROM_SEEDS && valid != NULL && wbase < n) ? (int) valid[wbase >> 10] : 1024;
@@ -565,9 +586,12 @@ void osw_pass_kernel(const void *in, uint4 *out, int64_t n, int shift, int next_
 }
 
 // the passes of one sort, one-sweep; `first` reads seeds (FROM_SEEDS) or keys; buffers alternate.  Enqueued on the stream.
-// work: 3 x 256 + 8 unsigned long long (two digit histograms, the digit bases, the ticket) + status (256 per tile)
+// work: 3 x 256 unsigned long long (two digit histograms, the digit bases), the tickets (eight queues, 128 bytes apart: the
+// atomics of one cache line are served one after the other), then status (256 words per tile)
+#define OS_TICKET_WORDS 128         // unsigned long long words reserved for the tickets
+#define OS_TICKET_STRIDE 32         // unsigned int words between two queues' tickets
 static size_t os_work_bytes(int64_t ntiles)
-{ return sizeof(unsigned long long)*(3*256 + 8 + 256*(size_t) ntiles); }
+{ return sizeof(unsigned long long)*(3*256 + OS_TICKET_WORDS + 256*(size_t) ntiles); }
 
 // FGA_SORT_WIDE = 0 | 8 | 16: wavefronts per tile of the one-sweep passes (0: the 4096-key tiles of os_pass_kernel); read once
 static int os_wide()
@@ -586,7 +610,7 @@ static void os_sort(fga_dev *dev, const void *first, bool from_seeds, int64_t ne
 { unsigned long long *hist[2] = { (unsigned long long *) work, (unsigned long long *) work + 256 };
   unsigned long long *gbase = (unsigned long long *) work + 512;
   unsigned int *ticket = (unsigned int *) ((unsigned long long *) work + 768);
-  unsigned long long *status = (unsigned long long *) work + 776;
+  unsigned long long *status = (unsigned long long *) work + 768 + OS_TICKET_WORDS;
   hipMemsetAsync(work,0,os_work_bytes(ntiles_max),dev->stream);
   const void *src = first;
   uint4 *dst = buf0;
@@ -606,17 +630,26 @@ static void os_sort(fga_dev *dev, const void *first, bool from_seeds, int64_t ne
       unsigned long long *hc = hist[p & 1], *hn = (p+1 < npass) ? hist[(p+1) & 1] : NULL;
       hipLaunchKernelGGL(os_scan256_kernel,dim3(1),dim3(256),0,dev->stream,hc,gbase,hn,ticket);
       const uint16_t *nov = NULL;
+      // consecutive tiles one queue hands out: 7 x chunk tiles can be ahead of the smallest tile not yet taken and wait for
+      // it, so chunk stays below 1/32 of the workgroups the device certainly holds at once (one per CU)
+      unsigned chunk = (unsigned) (dev->ncu / 32);
+      { static int forced = -1;
+        if (forced < 0) { const char *e = getenv("FGA_SORT_CHUNK"); forced = e != NULL ? atoi(e) : 0; }
+        if (forced > 0) chunk = (unsigned) forced;
+      }
+      if (chunk < 1) chunk = 1;
+      if (chunk > 64) chunk = 64;
       if (os_wide() == 8)
         { if (p == 0 && from_seeds)
-            hipLaunchKernelGGL((osw_pass_kernel<true,8>),dim3(nt),dim3(512),0,dev->stream,src,dst,m,shift,shift+8,L,p+1,gbase,status,hn,ticket,valid);
+            hipLaunchKernelGGL((osw_pass_kernel<true,8>),dim3(nt),dim3(512),0,dev->stream,src,dst,m,shift,shift+8,L,p+1,gbase,status,hn,ticket,valid,chunk);
           else
-            hipLaunchKernelGGL((osw_pass_kernel<false,8>),dim3(nt),dim3(512),0,dev->stream,src,dst,m,shift,shift+8,L,p+1,gbase,status,hn,ticket,nov);
+            hipLaunchKernelGGL((osw_pass_kernel<false,8>),dim3(nt),dim3(512),0,dev->stream,src,dst,m,shift,shift+8,L,p+1,gbase,status,hn,ticket,nov,chunk);
         }
       else if (os_wide() == 16)
         { if (p == 0 && from_seeds)
-            hipLaunchKernelGGL((osw_pass_kernel<true,16>),dim3(nt),dim3(1024),0,dev->stream,src,dst,m,shift,shift+8,L,p+1,gbase,status,hn,ticket,valid);
+            hipLaunchKernelGGL((osw_pass_kernel<true,16>),dim3(nt),dim3(1024),0,dev->stream,src,dst,m,shift,shift+8,L,p+1,gbase,status,hn,ticket,valid,chunk);
           else
-            hipLaunchKernelGGL((osw_pass_kernel<false,16>),dim3(nt),dim3(1024),0,dev->stream,src,dst,m,shift,shift+8,L,p+1,gbase,status,hn,ticket,nov);
+            hipLaunchKernelGGL((osw_pass_kernel<false,16>),dim3(nt),dim3(1024),0,dev->stream,src,dst,m,shift,shift+8,L,p+1,gbase,status,hn,ticket,nov,chunk);
         }
       else if (p == 0 && from_seeds)
         hipLaunchKernelGGL(os_pass_kernel<true>,dim3(nt),dim3(ST),0,dev->stream,src,dst,m,shift,shift+8,L,p+1,gbase,status,hn,ticket,valid);

@@ -121,18 +121,20 @@ static void front_bench(const uint4 *in, uint4 *out, int64_t n)
 { hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int ntiles = (int) ((n / 4096 - 1) & ~7ll);
+  for (int xl = 0; xl < 2; xl++)
   for (int tr = 0; tr < 2; tr++)
     for (int off = 0; off < 4; off += 3)
       { float best = 1e30f;
         for (int r = 0; r < 3; r++)
           { CK(hipEventRecord(e0,0));
-            hipLaunchKernelGGL((front_kernel<RUN,ST>),dim3(ntiles),dim3(256),0,0,(const v4u *) in,(v4u *) out,ntiles,0,off,tr);
+            hipLaunchKernelGGL((front_kernel<RUN,ST>),dim3(ntiles),dim3(256),0,0,(const v4u *) in,(v4u *) out,ntiles,xl,off,tr);
             CK(hipEventRecord(e1,0));
             CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms,e0,e1));
             if (ms < best) best = ms;
           }
-        printf("fronts: runs of %d records, store %s, %s, offset %d records: %.3f ms = %.2f TB/s (read + write)\n",RUN,
+        printf("fronts%s: runs of %d records, store %s, %s, offset %d records: %.3f ms = %.2f TB/s (read + write)\n",
+               xl ? " (neighbouring tiles on one XCD)" : "",RUN,
                ST == 0 ? "plain" : ST == 1 ? "nontemporal" : "sc0 sc1",
                tr ? "a block's 4 records from 4 instructions" : "a block from 4 lanes of one instruction",off,best,2.0*16.0*ntiles*4096/best*1e-9);
       }
@@ -169,7 +171,7 @@ int main(int argc, char **argv)
   if (getenv("SORT_BENCH_COPY") != NULL)
     { copy_bench<16,0>(orig,b0,n); copy_bench<8,0>(orig,b0,n); copy_bench<4,0>(orig,b0,n);
       copy_bench<16,1>(orig,b0,n); copy_bench<8,1>(orig,b0,n);
-      front_bench<16,0>(orig,b0,n); front_bench<16,1>(orig,b0,n);
+      front_bench<16,0>(orig,b0,n); front_bench<32,0>(orig,b0,n); front_bench<64,0>(orig,b0,n);
       return 0;
     }
   float best = 1e30f, sum = 0;
