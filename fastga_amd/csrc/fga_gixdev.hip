@@ -21,6 +21,9 @@
 //                        comparison; panels beyond 2048 keys (low-complexity sequence) go to a list and through the seed sort's
 //                        LSD radix passes.  13 global radix passes over all keys (0.45 s per 3 Gbp genome) are gone.
 //   gix_entries_kernel   one thread per sorted key: lcp with its predecessor (0 at a part start), on-disk entry bytes
+// What bounds the two scans (1 Gbp genome, 0.79 G keys: 33 + 43 ms): their atomics -- one per key on the 64 MB of panel counters,
+// 25 G per second whatever else the kernel does (without the placing pass's returning atomic it takes 32 ms, without its
+// 16-byte stores 33 ms; cutting every k-mer out of packed words instead of 40 byte reads changed 4 %).
 #include "fga_device.hpp"
 
 #define GCH   2048            // positions per chunk
@@ -46,21 +49,45 @@ struct gix_scan_args
     unsigned long long *sbuck;      // [1024]
   };
 
-__device__ __forceinline__ uint32_t comp4(uint32_t x)     // reverse complement of a packed 4-mer
-{ x = ~x & 0xff;
-  return ((x & 0x03) << 6) | ((x & 0x0c) << 2) | ((x & 0x30) >> 2) | ((x & 0xc0) >> 6);
+// The chunk's bases stay PACKED in LDS (2 bits each, base t of the chunk in bits 2*(t & 15) of dword t >> 4: the order of the
+// .bps image) and every quantity is cut out of 64-bit windows of it with v_alignbit -- round 3 unpacked them into a byte per
+// base and built every k-mer with 40 LDS byte reads, which was three quarters of the kernel's LDS instructions.
+//   the forward 40-mer of position x, most significant base first   = the window of bases x .. x+39 with its 2-bit groups
+//                                                                       reversed (v_bfrev + a swap of neighbouring bits)
+//   the complement-strand 40-mer that ends at x+11                    = the bitwise NOT of the window of bases x-28 .. x+11
+//                                                                       (its last base is the k-mer's first, complemented)
+//   the 12-mer prefixes of both                                       = the 24 bits of bases x .. x+11, reversed / complemented
+//   the canonical 8-mer code (TMap order)                             = two table lookups per strand on the window's bytes
+__device__ __forceinline__ uint32_t rev2_32(uint32_t v)       // the sixteen 2-bit groups of v in reverse order
+{ const uint32_t r = __builtin_bitreverse32(v);
+  return ((r & 0xaaaaaaaau) >> 1) | ((r & 0x55555555u) << 1);
 }
+
+__device__ __forceinline__ uint64_t pw_window(const uint32_t *pw, int t)       // bases t .. t+31 of the chunk, base t in bits 0-1
+{ const int w = t >> 4;
+  const uint32_t sh = (uint32_t) (t & 15) * 2;
+  const uint32_t d0 = pw[w], d1 = pw[w+1], d2 = pw[w+2];
+  return ((uint64_t) __builtin_amdgcn_alignbit(d2,d1,sh) << 32) | __builtin_amdgcn_alignbit(d1,d0,sh);
+}
+
+#define GPRE  32              // bases in front of the chunk that are kept (a complement k-mer reaches 28 back)
+#define GPW   ((GCH + 96)/16 + 3)
 
 __global__ __launch_bounds__(GNT)
 void gix_scan_kernel(gix_scan_args A)
-{ __shared__ uint8_t  sb[GCH + 96];           // bases of [j0-28, j0+GCH+44), 4 = outside the contig
+{ __shared__ uint32_t pw[GPW];                // packed bases of [j0-GPRE, j0+GCH+64), zero outside the contig's bytes
   __shared__ uint16_t v8[GCH + 8];            // canonical 8-mer code at j0 + x
+  __shared__ uint8_t  tf[256], tc[256];       // TMap code of a window byte (4 bases, first base in bits 0-1) read forward / as its reverse complement
   __shared__ uint32_t sh[1024];
   __shared__ int      wtot[GNT/64];
 
   const int tid = threadIdx.x;
   for (int x = tid; x < 1024; x += GNT)
     sh[x] = 0;
+  { const uint32_t y = (uint32_t) tid;                                   // GNT == 256: one table entry per thread
+    tf[y] = gix_tmap[rev2_32(y) >> 24];                                  // the 4-mer with its first base most significant
+    tc[y] = gix_tmap[~y & 0xffu];                                        // complemented, last base first: the same bits, inverted
+  }
   // A workgroup takes chunks in a stride and adds its sample histogram to the global one ONCE, at its end: a chunk holds
   // syncmers of ~600 of the 1024 sample buckets, and with one workgroup per chunk a 3 Gbp genome made 9 * 10^8 atomics on
   // the 128 cache lines of that histogram -- atomics on one line are served one after the other (~88 per microsecond).
@@ -71,22 +98,21 @@ void gix_scan_kernel(gix_scan_args A)
   const int c = it.ctg, j0 = it.j0;
   const int64_t len = A.clen[c];
   const uint8_t *img = A.img + A.boff[c];
-  for (int x = tid; x < GCH + 96; x += GNT)
-    { const int64_t b = (int64_t) j0 - 28 + x;
-      uint8_t v = 4;
-      if (b >= 0 && b < len)
-        v = (img[b >> 2] >> (2*(b & 3))) & 3;
-      sb[x] = v;
-    }
+  { const int64_t nbytes = (len + 3) >> 2, b0 = ((int64_t) j0 - GPRE) >> 2;        // j0 is a multiple of GCH: whole bytes
+    uint8_t *pb = (uint8_t *) pw;
+    for (int y = tid; y < 4*GPW; y += GNT)
+      { const int64_t cb = b0 + y;
+        pb[y] = (cb >= 0 && cb < nbytes) ? img[cb] : (uint8_t) 0;
+      }
+  }
   __syncthreads();
-  const uint8_t *s = sb + 28;                 // s[x] = base at j0 + x
   for (int x = tid; x < GCH + 8; x += GNT)
     { uint16_t v = 0xffff;
       if ((int64_t) j0 + x + 8 <= len)
-        { const uint32_t a = (s[x] << 6) | (s[x+1] << 4) | (s[x+2] << 2) | s[x+3];
-          const uint32_t b = (s[x+4] << 6) | (s[x+5] << 4) | (s[x+6] << 2) | s[x+7];
-          const uint32_t mn = ((uint32_t) gix_tmap[a] << 8) | gix_tmap[b];
-          const uint32_t mc = ((uint32_t) gix_tmap[comp4(b)] << 8) | gix_tmap[comp4(a)];
+        { const uint32_t y = (uint32_t) pw_window(pw,x + GPRE) & 0xffffu;          // bases x .. x+7
+          const uint32_t ya = y & 0xffu, yb = y >> 8;
+          const uint32_t mn = ((uint32_t) tf[ya] << 8) | tf[yb];
+          const uint32_t mc = ((uint32_t) tc[yb] << 8) | tc[ya];
           v = (uint16_t) (mn < mc ? mn : mc);
         }
       v8[x] = v;
@@ -109,12 +135,9 @@ void gix_scan_kernel(gix_scan_args A)
       if (v8[x] != m && v8[x+4] != m)
         continue;
       // GIXmake's sample: every syncmer, both strands, whether or not the 40-mer fits
-      uint32_t f12 = 0, c12 = 0;                   // 12-mer prefix of the forward / complement k-mer of this syncmer
-      #pragma unroll
-      for (int k = 0; k < 12; k++)
-        { f12 = (f12 << 2) | s[x+k];
-          c12 = (c12 << 2) | (3u - s[x+11-k]);
-        }
+      // 12-mer prefix of the forward / complement k-mer of this syncmer: bases x .. x+11, first / last base most significant
+      const uint32_t w24 = (uint32_t) pw_window(pw,x + GPRE) & 0xffffffu;
+      const uint32_t f12 = rev2_32(w24) >> 8, c12 = ~w24 & 0xffffffu;
       if (A.keys == NULL)
         { atomicAdd(&sh[f12 >> 14],1u);
           atomicAdd(&sh[c12 >> 14],1u);
@@ -154,15 +177,19 @@ void gix_scan_kernel(gix_scan_args A)
       for (int strand = 0; strand < 2; strand++)
         { if (!(((strand ? cmask : fmask) >> r) & 1))
             continue;
-          uint64_t hi = 0;
-          uint32_t lo16 = 0;
+          uint64_t hi;
+          uint32_t lo16;
           if (strand == 0)
-            { for (int k = 0; k < 32; k++) hi = (hi << 2) | s[x+k];
-              for (int k = 32; k < 40; k++) lo16 = (lo16 << 2) | s[x+k];
+            { const uint64_t v0 = pw_window(pw,x + GPRE);                               // bases x .. x+31
+              const uint32_t v1 = (uint32_t) pw_window(pw,x + GPRE + 32) & 0xffffu;     //       x+32 .. x+39
+              hi = ((uint64_t) rev2_32((uint32_t) v0) << 32) | rev2_32((uint32_t) (v0 >> 32));
+              lo16 = rev2_32(v1) >> 16;
             }
           else
-            { for (int k = 0; k < 32; k++) hi = (hi << 2) | (uint64_t) (3 - s[x+11-k]);
-              for (int k = 32; k < 40; k++) lo16 = (lo16 << 2) | (uint32_t) (3 - s[x+11-k]);
+            { const uint64_t w0 = pw_window(pw,x + GPRE - 28);                          // bases x-28 .. x+3
+              const uint64_t w1 = pw_window(pw,x + GPRE - 20);                          //       x-20 .. x+11: the k-mer's first 32 bases, last first
+              hi = ~w1;
+              lo16 = ~(uint32_t) w0 & 0xffffu;                                          // bases x-28 .. x-21: its last 8
             }
           const uint64_t pay = strand ? ((uint64_t) (j+12) | ((ctg | sign) << (8*A.postbytes)))
                                       : ((uint64_t) j | (ctg << (8*A.postbytes)));
