@@ -38,6 +38,7 @@ enum { MODE_PAIR = 0, MODE_FLIP = 1, MODE_SELF = 2 };
 #ifndef T1CAP
 #define T1CAP           256                  // table-1 entries per tile: four rounds of one entry per lane
 #endif
+#define FGA_MERGE_MAX_FREQ 1982               // 2 x (cutoff + 2) entries of margin and 128 to work on must fit the largest window (4096)
 #ifndef T2STD
 #define T2STD           512                  // table-2 entries per tile / window of the standard build
 #endif
@@ -233,13 +234,33 @@ __device__ __forceinline__ void lds_fill(const void *g, void *l, int nbytes, int
     G2L(gc + x0 + (size_t) (uint32_t) lane16,lc + x0,16);
 }
 
+// How the match's result for one table-1 entry (and the emission's descriptor made from it) is packed: entry i of the tile
+// (self: i - low), first run member `low`, plen, number of seeds.  32 bits in the windows of up to 1024 entries (8 + 10 + 6 +
+// 8 bits: run counts below 256, i.e. -f <= 255); 64 bits in the 4096-entry windows of the build for larger cutoffs.
+template <int T2CAP>
+struct res_fmt
+  { static constexpr bool BIG = (T2CAP > 1024);
+    typedef typename std::conditional<BIG,uint64_t,uint32_t>::type word;
+    // i: the entry's index in the tile (< T1CAP = 256), or in a self comparison its distance from the run's start (<= -f)
+    static constexpr int I_BITS = BIG ? 16 : 8, LOW_SH = I_BITS, LOW_BITS = BIG ? 16 : 10, PLEN_SH = LOW_SH + LOW_BITS,
+                         CNT_SH = BIG ? 40 : 24;
+    static __device__ __forceinline__ word pack(int i, int low, int plen, int cnt)
+    { return (word) (uint32_t) i | ((word) (uint32_t) low << LOW_SH) | ((word) (uint32_t) plen << PLEN_SH) | ((word) (uint32_t) cnt << CNT_SH); }
+    static __device__ __forceinline__ int  cnt(word r)   { return (int) (r >> CNT_SH); }
+    static __device__ __forceinline__ word body(word r)  { return r & (((word) 1 << CNT_SH) - 1); }          // all but the count
+    static __device__ __forceinline__ int  i(word d)     { return (int) (d & (((word) 1 << I_BITS) - 1)); }
+    static __device__ __forceinline__ int  low(word d)   { return (int) ((d >> LOW_SH) & (((word) 1 << LOW_BITS) - 1)); }
+    static __device__ __forceinline__ int  plen(word d)  { return (int) ((d >> PLEN_SH) & 0x3f); }
+  };
+
 // The match of up to NR rounds of T1 entries (entry c = r*64 + lane of the tile) side by side.  qe: the entry's panel
 // among the tile's (index into ix2, whose slot -1 holds the entries before the tile), or < 0: one panel = the window.
-template <int MODE, int NR>
+template <int MODE, int NR, int T2CAP>
 __device__ __forceinline__ void match_rounds(const merge_args &A, const uint64_t *keyB, const uint8_t *lcpB, const uint8_t *mA,
                                              const uint8_t *mB, const uint8_t *cB, const uint64_t *k1, const uint32_t *ix2,
                                              uint32_t b, int plo, bool panels, int n2, int na, int t_lo,
-                                             uint32_t *res, int &total, unsigned long long &tsum, int &lb_last, walk_out &O)
+                                             typename res_fmt<T2CAP>::word *res, int &total, unsigned long long &tsum, int &lb_last,
+                                             walk_out &O)
 { const int lane = threadIdx.x;
   const int freq = A.freq;
   uint64_t ks[NR];
@@ -345,7 +366,7 @@ __device__ __forceinline__ void match_rounds(const merge_args &A, const uint64_t
         }
       else
         cnt = pass ? (hgh-low) - (MODE == MODE_SELF ? 1 : 0) : 0;
-      res[r] = (pass && cnt > 0) ? ((uint32_t) (MODE == MODE_SELF ? i - low : i) | ((uint32_t) low << 8) | ((uint32_t) plen << 18) | ((uint32_t) cnt << 24)) : 0u;
+      res[r] = (pass && cnt > 0) ? res_fmt<T2CAP>::pack(MODE == MODE_SELF ? i - low : i,low,plen,cnt) : 0;
       total += cnt;
       tsum += (unsigned long long) cnt * plen;
     }
@@ -383,7 +404,7 @@ __device__ __forceinline__ int walk_tile(const merge_args &A, tile_lds<T2CAP> &S
   uint8_t  *lcpB = S.lcpB0 + obc, *mB = S.mB0 + obc, *mA = S.mA0 + oac;
   uint8_t  *cB0 = cdyn, *cA0 = cdyn + (size_t) (T2CAP + 32)*cw2;
   uint8_t  *cB = cB0 + (size_t) obc*cw2, *cA = cA0 + (size_t) oac*cw1;
-  uint32_t *own32 = (uint32_t *) S.keyB0;          // the emission reuses the key array (keys are done with by then)
+  typename res_fmt<T2CAP>::word *ownd = (typename res_fmt<T2CAP>::word *) S.keyB0;      // the emission's descriptors reuse the key array (keys are done with by then)
 
   // 1. HBM -> LDS (global_load_lds): T2 keys, lcp bytes, payloads; T1 payloads.  T1 keys -> registers.
   lds_fill(A.K2 + (b0 - obk),S.keyB0,(n2 + obk)*8,lane16);
@@ -437,17 +458,18 @@ __device__ __forceinline__ int walk_tile(const merge_args &A, tile_lds<T2CAP> &S
 #endif
 
   XPROF(3)
-  // 3. match: result per round packed i (8 bits; self: i - low) | low << 8 | plen << 18 | seeds << 24
-  uint32_t res[4];
+  // 3. match: result per round packed i (8 bits; self: i - low) | low | plen | seeds (res_fmt)
+  typedef res_fmt<T2CAP> RF;
+  typename RF::word res[4];
   int total = 0;
   { const int nr = (na + 63) >> 6;
     const uint32_t b32 = (uint32_t) b0;
     const int plo = p0 & 0xff;
     const uint32_t *ixq = (MODE == MODE_SELF) ? ix1 : ix2;
-    if (nr == 1)      match_rounds<MODE,1>(A,keyB,lcpB,mA,mB,cB,k1,ixq,b32,plo,panels,n2,na,t_lo,res,total,O.tsum,lb_last,O);
-    else if (nr == 2) match_rounds<MODE,2>(A,keyB,lcpB,mA,mB,cB,k1,ixq,b32,plo,panels,n2,na,t_lo,res,total,O.tsum,lb_last,O);
-    else if (nr == 3) match_rounds<MODE,3>(A,keyB,lcpB,mA,mB,cB,k1,ixq,b32,plo,panels,n2,na,t_lo,res,total,O.tsum,lb_last,O);
-    else              match_rounds<MODE,4>(A,keyB,lcpB,mA,mB,cB,k1,ixq,b32,plo,panels,n2,na,t_lo,res,total,O.tsum,lb_last,O);
+    if (nr == 1)      match_rounds<MODE,1,T2CAP>(A,keyB,lcpB,mA,mB,cB,k1,ixq,b32,plo,panels,n2,na,t_lo,res,total,O.tsum,lb_last,O);
+    else if (nr == 2) match_rounds<MODE,2,T2CAP>(A,keyB,lcpB,mA,mB,cB,k1,ixq,b32,plo,panels,n2,na,t_lo,res,total,O.tsum,lb_last,O);
+    else if (nr == 3) match_rounds<MODE,3,T2CAP>(A,keyB,lcpB,mA,mB,cB,k1,ixq,b32,plo,panels,n2,na,t_lo,res,total,O.tsum,lb_last,O);
+    else              match_rounds<MODE,4,T2CAP>(A,keyB,lcpB,mA,mB,cB,k1,ixq,b32,plo,panels,n2,na,t_lo,res,total,O.tsum,lb_last,O);
   }
 
   XPROF(4)
@@ -479,16 +501,16 @@ __device__ __forceinline__ int walk_tile(const merge_args &A, tile_lds<T2CAP> &S
       WSYNC();                                                   // the match's key reads are done: the array becomes the window
       for (int wb = 0; wb < T; wb += EWIN)
         { const int wn = T - wb < EWIN ? T - wb : EWIN;          // slots of this window
-          for (int x = lane; 4*x < wn; x += 64)
-            ((uint4 *) own32)[x] = make_uint4(0,0,0,0);
+          for (int x = lane; (int) (16/sizeof(typename RF::word))*x < wn; x += 64)
+            ((uint4 *) ownd)[x] = make_uint4(0,0,0,0);
           WSYNC();
           { int o = off;
             #pragma unroll
             for (int r = 0; r < 4; r++)
-              { const int cnt = (int) (res[r] >> 24);
+              { const int cnt = RF::cnt(res[r]);
                 if (cnt > 0 && o + cnt > wb && o < wb + EWIN)
                   { const int before = o < wb ? wb - o : 0;
-                    own32[o + before - wb] = (res[r] & 0xffffffu) | ((uint32_t) before << 24);
+                    ownd[o + before - wb] = RF::body(res[r]) | ((typename RF::word) (uint32_t) before << RF::CNT_SH);
                   }
                 o += cnt;
               }
@@ -498,17 +520,17 @@ __device__ __forceinline__ int walk_tile(const merge_args &A, tile_lds<T2CAP> &S
           int carry = 0;
           for (int s0 = 0; s0 < wn; s0 += 64)
             { const int slot = s0 + lane;                       // within the window
-              int v = (slot < wn && own32[slot] != 0) ? slot+1 : 0;        // a descriptor is never 0: plen >= 12
+              int v = (slot < wn && ownd[slot] != 0) ? slot+1 : 0;         // a descriptor is never 0: plen >= 12
               v = wave_incl_scan_max_dpp(v);
               v = v > carry ? v : carry;
               carry = __builtin_amdgcn_readlane(v,63);
               if (slot < wn)
                 { const int start = v-1;
-                  const uint32_t d = own32[start];
-                  const int plen = (int) ((d >> 18) & 0x3f);
-                  int k = (slot - start) + (int) (d >> 24);
-                  int j = (int) ((d >> 8) & 0x3ff);
-                  const int i = (int) (d & 0xff) + (MODE == MODE_SELF ? j : 0);      // self: stored relative to the run's start
+                  const typename RF::word d = ownd[start];
+                  const int plen = RF::plen(d);
+                  int k = (slot - start) + RF::cnt(d);
+                  int j = RF::low(d);
+                  const int i = RF::i(d) + (MODE == MODE_SELF ? j : 0);               // self: stored relative to the run's start
                   if (plain)
                     { j += k;
                       if (MODE == MODE_SELF && j >= i)
@@ -555,7 +577,7 @@ __device__ __forceinline__ int walk_tile(const merge_args &A, tile_lds<T2CAP> &S
 }
 
 template <int MODE, int T2CAP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(T2CAP == T2STD ? WAVE_OCC : 2,T2CAP == T2STD ? WAVE_OCC : 2)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(T2CAP == T2STD ? WAVE_OCC : (T2CAP > 1024 ? 1 : 2),T2CAP == T2STD ? WAVE_OCC : (T2CAP > 1024 ? 1 : 2))))
 void seed_merge_walk_kernel(merge_args A)
 { __shared__ __attribute__((aligned(16))) tile_lds<T2CAP> S;
   extern __shared__ __attribute__((aligned(16))) uint8_t cdyn[];     // contig|sign words of both sides: (T2CAP+32) cw2 + (T1CAP+32) cw1 bytes
@@ -754,8 +776,8 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
     { fga_set_error("fga_seed_merge: the index has no device view");
       return 1;
     }
-  if (prm->freq < 1 || prm->freq > 255)
-    { fga_set_error("fga_seed_merge: frequency cutoff must be in [1,255]");
+  if (prm->freq < 1 || prm->freq > FGA_MERGE_MAX_FREQ)
+    { fga_set_error("fga_seed_merge: frequency cutoff must be in [1,%d]",FGA_MERGE_MAX_FREQ);
       return 1;
     }
   // an index read from the pre-v1.3 layout holds no k-mer above the cutoff it was built with (FastGA.c:4959-4974)
@@ -866,15 +888,17 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
   dev->last_ms[FGA_STAGE_MERGE] = dev->last_ms[FGA_STAGE_MERGE_PARTITION] = 0.f;
   if (!empty)
     { // the sub-tile margin FREQ+2 must leave room in a window: the wide-window build takes over for large cutoffs
-      const bool wide = 2*(prm->freq + 2) > T2STD - 128;
-      const int t2cap = wide ? 1024 : T2STD;
+      // (cutoffs above 255 need the 64-bit result words: they take the 4096-entry windows whatever their margin)
+      const bool wide = 2*(prm->freq + 2) > T2STD - 128, huge = prm->freq > 255;
+      const int t2cap = huge ? 4096 : (wide ? 1024 : T2STD);
       const size_t dyn = (size_t) (t2cap + 32)*A.cw2 + (size_t) (T1CAP + 32)*A.cw1 + 16;
       // every wavefront of the launch is resident (they are persistent): as many as the LDS of a CU holds, at most the
       // register budget's
-      const size_t lds = ((wide ? sizeof(tile_lds<1024>) : sizeof(tile_lds<T2STD>)) + dyn + 2047) / 2048 * 2048;
+      const size_t lds = ((huge ? sizeof(tile_lds<4096>) : wide ? sizeof(tile_lds<1024>) : sizeof(tile_lds<T2STD>)) + dyn + 2047) / 2048 * 2048;
       int per_cu = (int) ((160*1024) / lds) - 1;       // measured: 13 x 11.6 KB are not all resident
+      if (per_cu < 1) per_cu = 1;
       const int fit = per_cu;
-      const int occ = wide ? 8 : 12;                   // measured: 10-12 at 100 Mbp (8: -7 %), 12-13 at 3 Gbp
+      const int occ = huge ? 2 : (wide ? 8 : 12);      // measured: 10-12 at 100 Mbp (8: -7 %), 12-13 at 3 Gbp
       if (per_cu > occ) per_cu = occ;
       { const char *ev = getenv("FGA_MERGE_WAVES");
         if (ev != NULL && atoi(ev) > 0 && atoi(ev) <= fit && atoi(ev) <= 28) per_cu = atoi(ev);     // phys_capacity's slack covers 32 per CU
@@ -906,8 +930,9 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
       hipLaunchKernelGGL(range_cut_kernel,dim3((nranges+1+255)/256),dim3(256),0,dev->stream,
                          A.idx1,A.idx2,pbeg,pend,base,total,nranges,nbig,cuts);
       hipEventRecord(dev->ev1,dev->stream);
-      if (wide) launch_walk<1024>(mode,grid,dyn,dev->stream,A);
-      else      launch_walk<T2STD>(mode,grid,dyn,dev->stream,A);
+      if (huge)      launch_walk<4096>(mode,grid,dyn,dev->stream,A);
+      else if (wide) launch_walk<1024>(mode,grid,dyn,dev->stream,A);
+      else           launch_walk<T2STD>(mode,grid,dyn,dev->stream,A);
       hipEventRecord(ev2,dev->stream);
     }
   // one round trip: the three counters

@@ -77,6 +77,28 @@ def big_family_pair(tmp_path_factory, built_library):
 
 
 @pytest.fixture(scope="session")
+def huge_family_pair(tmp_path_factory, built_library):
+    """0.8 Mbp pair with a 1 kbp family planted 450 times at 0.1 % divergence (a third on the other strand), the second
+    genome 0.5 % away: its k-mers have 250-400 partners -- cutoffs between -f256 and -f450 decide their fate (the reference
+    takes any -f; here they run on the merge kernel's 4096-entry windows with 64-bit result words)"""
+    from fastga_amd import workload, synth
+    d = str(tmp_path_factory.mktemp("hugefam"))
+    rng = np.random.default_rng(80)
+    lens = synth.contig_lengths(24, 6, 800_000)
+    A = [rng.integers(0, 4, int(L), dtype=np.uint8) for L in lens]
+    fam = rng.integers(0, 4, 1000, dtype=np.uint8)
+    for k in range(450):
+        c = A[k % len(A)]
+        cp = synth.mutate(rng, fam, 0.001)
+        if k % 3 == 0:
+            cp = synth.revcomp(cp)
+        p0 = int(rng.integers(0, len(c) - len(cp) - 1))
+        c[p0:p0 + len(cp)] = cp
+    B = [synth.mutate(rng, c, 0.005) for c in A]
+    return d, workload.build_genome(d, "A", A), workload.build_genome(d, "B", B)
+
+
+@pytest.fixture(scope="session")
 def dense_pair(tmp_path_factory, built_library):
     """3 Mbp of A/C-only sequence against its 3 % diverged copy: the forward-strand k-mers crowd into 4096 of the 2^24
     12-mer panels (and the complement ones into another 4096), ~150 entries each and many beyond a tile -- the panel

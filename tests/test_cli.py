@@ -30,7 +30,7 @@ def test_argument_errors(fasta_dir):
     r = _run([], d)
     assert r.returncode == 1 and "Usage: FastGA" in r.stderr
     r = _run(["toy_A", "#repeats.1bed", "toy_B"], d)
-    assert r.returncode == 1 and "mask file arguments" in r.stderr and "-M" in r.stderr
+    assert r.returncode == 1 and "Cannot find/open ANO file" in r.stderr          # the reference's own message (ANO.c:146)
     r = _run(["-P/nonexistent/dir", "toy_A", "toy_B"], d)
     assert r.returncode == 1 and "/nonexistent/dir" in r.stderr
     r = _run(["-L:/nonexistent/dir/log", "toy_A", "toy_B"], d)
@@ -39,8 +39,8 @@ def test_argument_errors(fasta_dir):
     assert r.returncode == 1 and "Only one of" in r.stderr
     r = _run(["-i.3", "toy_A", "toy_B"], d)
     assert r.returncode == 1 and "[0.55,1.0)" in r.stderr
-    r = _run(["-f300", "toy_A", "toy_B"], d)
-    assert r.returncode == 1 and "[1,255]" in r.stderr
+    r = _run(["-f2000", "toy_A", "toy_B"], d)
+    assert r.returncode == 1 and "[1,1982]" in r.stderr
     r = _run(["-Tx", "toy_A", "toy_B"], d)
     assert r.returncode == 1 and "not an integer" in r.stderr
     r = _run(["-1", "toy_A", "toy_B"], d)

@@ -14,7 +14,7 @@ def _compare(ra, rb, workdir, strict_order=True, allow_empty=False, **kw):
     if not H.have_reference():
         pytest.skip("oracle/_ref did not travel")
     ours = os.path.join(workdir, "ours.1aln")
-    st = D.run(ra, rb, ours, nthreads=8, **kw)
+    st = D.run(ra, rb, ours, nthreads=8, reference_threads=8, **kw)       # ties on (aread, abpos) as FastGA -T8 orders them
     flags = []
     if kw.get("symmetric"):
         flags.append("-S")
@@ -70,6 +70,14 @@ def test_pair_symmetric_and_options(toy_pair, tmp_path):
     _compare(ra, rb, str(tmp_path), symmetric=True, freq=6, identity=0.8, chain_min=60)
 
 
+def test_cutoff_above_255_matches_reference(huge_family_pair, tmp_path):
+    """-f330 on a 450-copy family whose k-mers have 250-400 partners: some stay below the cutoff, some do not (at the
+    default -f10 they are all dropped); the reference takes any -f (FastGA.c:4497-4499)"""
+    d, ra, rb = huge_family_pair
+    st = _compare(ra, rb, str(tmp_path), freq=330)
+    assert st["nseeds"] > 2_000_000 and st["nlive"] > 1000
+
+
 def test_divergent_pair_matches_reference(tmp_path, built_library):
     from fastga_amd import workload
     d = str(tmp_path)
@@ -99,7 +107,7 @@ def test_self_comparison_matches_reference(tmp_path, built_library):
             cp = synth.revcomp(cp)
         A[c2][t:t + len(cp)] = cp
     ra = workload.build_genome(d, "S", A)
-    _compare(ra, None, d, strict_order=False)
+    _compare(ra, None, d)
 
 
 def test_soft_masked_pair_matches_reference(tmp_path, built_library):

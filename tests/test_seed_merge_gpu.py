@@ -106,11 +106,29 @@ def test_large_cutoffs_on_a_300_copy_family(big_family_pair):
     dA, dB = dev.upload(A), dev.upload(B)
     n10, n64, n200 = (_compare(dev, A, B, dA, dB, freq=f) for f in (10, 64, 200))
     assert n10 < n64 < n200
+    _compare(dev, A, B, dA, dB, freq=400)                     # (above 255: the 4096-entry windows, see the next test)
     _compare(dev, B, A, dB, dA, flip=True, freq=64)
     _compare(dev, B, A, dB, dA, flip=True, freq=200)
     _compare(dev, A, None, dA, None, freq=64)
     _compare(dev, A, None, dA, None, freq=255)
     _compare(dev, A, B, dA, dB, freq=120, soft_mask=True)
+    dA.free(); dB.free(); dev.close()
+
+
+def test_cutoffs_above_255_on_a_450_copy_family(huge_family_pair):
+    """-f256 .. -f450 where they matter: k-mers with 250-400 partners (the reference takes any -f, FastGA.c:4497-4499; the
+    kernel runs them on 4096-entry windows with 64-bit result words), pair / flipped / self / soft-masked, against the oracle"""
+    from fastga_amd.gixio import Gix
+    from fastga_amd import device as D
+    d, ra, rb = huge_family_pair
+    A, B = Gix(ra + ".gix"), Gix(rb + ".gix")
+    dev = D.Device(0)
+    dA, dB = dev.upload(A), dev.upload(B)
+    n255, n300, n450 = (_compare(dev, A, B, dA, dB, freq=f) for f in (255, 300, 450))
+    assert n255 < n300 < n450, (n255, n300, n450)
+    _compare(dev, B, A, dB, dA, flip=True, freq=330)
+    _compare(dev, A, None, dA, None, freq=330)
+    _compare(dev, A, B, dA, dB, freq=340, soft_mask=True)
     dA.free(); dB.free(); dev.close()
 
 
@@ -132,6 +150,11 @@ def test_dense_panels_are_streamed_in_windows(dense_pair):
     _compare(dev, A, None, dA, None)
     _compare(dev, A, None, dA, None, freq=100)
     _compare(dev, A, None, dA, None, freq=255)                    # the wide-window build on panels of thousands
+    for f in (256, 1000, 1982):                                   # the 4096-entry windows, up to the largest cutoff they hold
+        _compare(dev, A, B, dA, dB, freq=f)
+    _compare(dev, B, A, dB, dA, flip=True, freq=700)
+    _compare(dev, A, None, dA, None, freq=1982)
+    _compare(dev, A, B, dA, dB, freq=600, soft_mask=True)
     # the tables carry mask bytes: -M inside the streamed windows, all modes
     plain = _compare(dev, A, B, dA, dB, freq=20)
     assert 0 < _compare(dev, A, B, dA, dB, freq=20, soft_mask=True) < plain
