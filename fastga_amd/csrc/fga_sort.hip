@@ -426,12 +426,12 @@ void os_pass_kernel(const void *in, uint4 *out, int64_t n, int shift, int next_s
 // ---------------------------------------------------------------------------------------------------
 #define OSW_STAGE   2048
 
-template <bool FROM_SEEDS, int NW>
-__global__ __launch_bounds__(NW*64)
+template <bool FROM_SEEDS, int NW, int KPT>
+__global__ __launch_bounds__(NW*64) __attribute__((amdgpu_waves_per_eu(KPT <= 8 ? 8 : 4,KPT <= 8 ? 8 : 4)))
 void osw_pass_kernel(const void *in, uint4 *out, int64_t n, int shift, int next_shift, key_layout L, int stamp,
                      const unsigned long long *gbase, unsigned long long *status, unsigned long long *next_hist,
                      unsigned int *ticket, const uint16_t *valid, unsigned chunk)
-{ constexpr int NT = NW*64, TILE = NW*1024, ROUNDS = TILE/OSW_STAGE, SPT = OSW_STAGE/NT;
+{ constexpr int NT = NW*64, WK = 64*KPT, TILE = NW*WK, SPT = OSW_STAGE/NT;      // KPT keys per thread, WK per wavefront
   __shared__ uint32_t wcnt[NW][256];          // per-wave digit counts, then per-wave digit bases inside the tile
   __shared__ long long off[256];              // position in `out` of the digit's first key of this tile, minus its tile position
   __shared__ uint32_t dstart[256];            // tile position of the digit's first key
@@ -468,13 +468,15 @@ void osw_pass_kernel(const void *in, uint4 *out, int64_t n, int shift, int next_
   if (tile < 0)                               // (cannot happen: tiles and workgroups are as many)
     return;
 
-  const int64_t wbase = (int64_t) tile * TILE + (int64_t) wave * 1024;       // a wavefront's 1024 items: one block of the seed buffer
-  const int vcount = (FROM_SEEDS && valid != NULL && wbase < n) ? (int) valid[wbase >> 10] : 1024;
-  u128     key[16];
-  uint16_t rank[16];
+  // a wavefront's WK items lie inside one 1024-slot block of the seed buffer; boff = where in it
+  const int64_t wbase = (int64_t) tile * TILE + (int64_t) wave * WK;
+  const int boff = (int) (wbase & 1023);
+  const int vcount = (FROM_SEEDS && valid != NULL && wbase < n) ? (int) valid[wbase >> 10] - boff : WK;
+  u128     key[KPT];
+  uint16_t rank[KPT];
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64-lane));
   #pragma unroll
-  for (int r = 0; r < 16; r++)
+  for (int r = 0; r < KPT; r++)
     { const int64_t i = wbase + r*64 + lane;
       const bool ok = i < n && r*64 + lane < vcount;
       uint32_t d = 256;
@@ -545,7 +547,7 @@ void osw_pass_kernel(const void *in, uint4 *out, int64_t n, int shift, int next_
   __syncthreads();
   // every key's position in the tile (over the rank: 16 bits each)
   #pragma unroll
-  for (int r = 0; r < 16; r++)
+  for (int r = 0; r < KPT; r++)
     { const int64_t i = wbase + r*64 + lane;
       if (i < n && r*64 + lane < vcount)
         { const uint32_t d = digit_of(key[r],shift);
@@ -555,11 +557,11 @@ void osw_pass_kernel(const void *in, uint4 *out, int64_t n, int shift, int next_
         rank[r] = 0xffff;
     }
   const int total = total_s;
-  for (int q = 0; q < ROUNDS; q++)
+  for (int q = 0; q*OSW_STAGE < TILE; q++)
     { if (q*OSW_STAGE >= total)
         break;
       #pragma unroll
-      for (int r = 0; r < 16; r++)
+      for (int r = 0; r < KPT; r++)
         if ((rank[r] >> 11) == q && rank[r] != 0xffff)
           { uint4 v;
             v.x = (uint32_t) key[r].lo; v.y = (uint32_t) (key[r].lo >> 32);
@@ -603,7 +605,8 @@ static int os_wide()
     }
   return v;
 }
-static int64_t os_tile_keys() { return os_wide() == 0 ? OS_TILE : (int64_t) os_wide()*1024; }
+#define KPT16 8          // keys per thread of the 16-wavefront tiles: 8192-key tiles like the 8-wavefront ones, twice the wavefronts per CU
+static int64_t os_tile_keys() { return os_wide() == 0 ? OS_TILE : (os_wide() == 16 ? (int64_t) 16*64*KPT16 : (int64_t) os_wide()*1024); }
 
 static void os_sort(fga_dev *dev, const void *first, bool from_seeds, int64_t next, const uint16_t *valid, key_layout L,
                     uint4 *buf0, uint4 *buf1, int64_t n, int lowbit, int npass, void *work, int64_t ntiles_max, uint4 **sorted)
@@ -641,15 +644,15 @@ static void os_sort(fga_dev *dev, const void *first, bool from_seeds, int64_t ne
       if (chunk > 64) chunk = 64;
       if (os_wide() == 8)
         { if (p == 0 && from_seeds)
-            hipLaunchKernelGGL((osw_pass_kernel<true,8>),dim3(nt),dim3(512),0,dev->stream,src,dst,m,shift,shift+8,L,p+1,gbase,status,hn,ticket,valid,chunk);
+            hipLaunchKernelGGL((osw_pass_kernel<true,8,16>),dim3(nt),dim3(512),0,dev->stream,src,dst,m,shift,shift+8,L,p+1,gbase,status,hn,ticket,valid,chunk);
           else
-            hipLaunchKernelGGL((osw_pass_kernel<false,8>),dim3(nt),dim3(512),0,dev->stream,src,dst,m,shift,shift+8,L,p+1,gbase,status,hn,ticket,nov,chunk);
+            hipLaunchKernelGGL((osw_pass_kernel<false,8,16>),dim3(nt),dim3(512),0,dev->stream,src,dst,m,shift,shift+8,L,p+1,gbase,status,hn,ticket,nov,chunk);
         }
       else if (os_wide() == 16)
         { if (p == 0 && from_seeds)
-            hipLaunchKernelGGL((osw_pass_kernel<true,16>),dim3(nt),dim3(1024),0,dev->stream,src,dst,m,shift,shift+8,L,p+1,gbase,status,hn,ticket,valid,chunk);
+            hipLaunchKernelGGL((osw_pass_kernel<true,16,KPT16>),dim3(nt),dim3(1024),0,dev->stream,src,dst,m,shift,shift+8,L,p+1,gbase,status,hn,ticket,valid,chunk);
           else
-            hipLaunchKernelGGL((osw_pass_kernel<false,16>),dim3(nt),dim3(1024),0,dev->stream,src,dst,m,shift,shift+8,L,p+1,gbase,status,hn,ticket,nov,chunk);
+            hipLaunchKernelGGL((osw_pass_kernel<false,16,KPT16>),dim3(nt),dim3(1024),0,dev->stream,src,dst,m,shift,shift+8,L,p+1,gbase,status,hn,ticket,nov,chunk);
         }
       else if (p == 0 && from_seeds)
         hipLaunchKernelGGL(os_pass_kernel<true>,dim3(nt),dim3(ST),0,dev->stream,src,dst,m,shift,shift+8,L,p+1,gbase,status,hn,ticket,valid);
