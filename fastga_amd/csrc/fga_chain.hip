@@ -783,8 +783,8 @@ extern "C" int fga_chain_scan_device(fga_dev *dev, const fga_dkeys *K, const fga
       if ((int64_t) hc[0] <= hit_cap && (int64_t) hc[1] <= unit_cap && (int64_t) hc[5] <= stage_cap)
         { const int64_t nh = (int64_t) hc[0], nu = (int64_t) hc[1];
           const double tq0 = fga_wall();
-          hh = (fga_hit *)  fga_big_malloc(sizeof(fga_hit)*(size_t) (nh+1));
-          hu = (fga_unit *) fga_big_malloc(sizeof(fga_unit)*(size_t) (nu+1));
+          hh = (fga_hit *)  malloc(sizeof(fga_hit)*(size_t) (nh+1));
+          hu = (fga_unit *) malloc(sizeof(fga_unit)*(size_t) (nu+1));
           hd = (int64_t *)  malloc(sizeof(int64_t)*(size_t) (nu+1));
           if (hh == NULL || hu == NULL || hd == NULL)
             { fga_set_error("out of memory");
@@ -806,7 +806,7 @@ extern "C" int fga_chain_scan_device(fga_dev *dev, const fga_dkeys *K, const fga
             R = (fga_hits *) calloc(1,sizeof(fga_hits));
             if (R != NULL)
               { R->nhits = nh; R->nunits = nu;
-                R->hits  = (fga_hit *)  fga_big_malloc(sizeof(fga_hit)*(size_t) (nh+1));
+                R->hits  = (fga_hit *)  malloc(sizeof(fga_hit)*(size_t) (nh+1));
                 R->units = (fga_unit *) malloc(sizeof(fga_unit)*(size_t) (nu+1));
               }
             int bits = 1;

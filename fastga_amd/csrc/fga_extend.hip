@@ -511,8 +511,8 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
       if (R->naln > aln_cap)  aln_cap = R->naln + R->naln/8 + 1024;
       if (R->ntrace > tb_cap) tb_cap = R->ntrace + R->ntrace/8 + (1 << 20);
     }
-  R->alns = (fga_aln *) fga_big_malloc(sizeof(fga_aln)*(R->naln+1));
-  R->tbytes = (uint8_t *) fga_big_malloc(R->ntrace+16);
+  R->alns = (fga_aln *) malloc(sizeof(fga_aln)*(R->naln+1));
+  R->tbytes = (uint8_t *) malloc(R->ntrace+16);
   if (R->alns == NULL || R->tbytes == NULL)
     { fga_set_error("out of memory");
       goto fail;

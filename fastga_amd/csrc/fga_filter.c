@@ -267,8 +267,7 @@ typedef struct
     int        sb;                       /* bits of the seq field in the discovery key */
     fga_alns  *R;
     int64_t   *off;                      /* trace offset of every surviving record */
-    int        final_minor;              /* final order: keys of the minor part (bread, comp) / the major part / 2: the whole key */
-    int        kb_b, kb_p;               /* bits of bread / abpos in the whole key */
+    int        final_minor;              /* final order: keys of the minor part (bread, comp) / the major part */
   } pass_ctx;
 
 static void pass_discovery_keys(void *arg, int id, int64_t b, int64_t e)
@@ -300,10 +299,7 @@ static void pass_final_keys(void *arg, int id, int64_t b, int64_t e)
   int64_t i;
   (void) id;
   for (i = b; i < e; i++)
-    { if (C->final_minor == 2)
-        C->skey[i] = ((((uint64_t) (uint32_t) C->live[i]->aread << C->kb_p | (uint32_t) C->live[i]->abpos) << C->kb_b
-                       | (uint32_t) C->live[i]->bread) << 1) | (C->live[i]->flags & 1);
-      else if (C->final_minor)
+    { if (C->final_minor)
         C->skey[i] = ((uint64_t) (uint32_t) C->live[i]->bread << 1) | (C->live[i]->flags & 1);
       else
         C->skey[i] = ((uint64_t) (uint32_t) C->live[i]->aread << 32) | (uint32_t) C->live[i]->abpos;
@@ -357,11 +353,11 @@ int fga_filter_alignments_mt(const fga_alns *in, int nthreads, fga_alns **out)
       return 0;
     }
   team   = fga_team_open(n < 50000 ? 1 : nthreads);         /* starting threads costs ~1 ms */
-  recs   = fga_big_malloc(sizeof(rec)*n);
-  perm   = fga_big_malloc(sizeof(rec *)*n);
-  live   = fga_big_malloc(sizeof(rec *)*n);
-  skey   = fga_big_malloc(sizeof(uint64_t)*n);
-  sval   = fga_big_malloc(sizeof(int64_t)*(n+1));
+  recs   = malloc(sizeof(rec)*n);
+  perm   = malloc(sizeof(rec *)*n);
+  live   = malloc(sizeof(rec *)*n);
+  skey   = malloc(sizeof(uint64_t)*n);
+  sval   = malloc(sizeof(int64_t)*(n+1));
   segbeg = malloc(sizeof(int64_t)*(n+1));
   if (team == NULL || recs == NULL || perm == NULL || live == NULL || skey == NULL || sval == NULL || segbeg == NULL)
     goto oom;
@@ -384,7 +380,7 @@ int fga_filter_alignments_mt(const fga_alns *in, int nthreads, fga_alns **out)
         if (fga_team_sort_pairs(team,skey,sval,n,ub+sb)) goto oom;
       }
     else
-      { sorted = fga_big_malloc(sizeof(fga_aln)*n);
+      { sorted = malloc(sizeof(fga_aln)*n);
         if (sorted == NULL) goto oom;
         memcpy(sorted,in->alns,sizeof(fga_aln)*n);
         qsort(sorted,n,sizeof(fga_aln),by_discovery);
@@ -415,37 +411,24 @@ int fga_filter_alignments_mt(const fga_alns *in, int nthreads, fga_alns **out)
    * comp) over the records in survival order, then (aread, abpos).  Repeats give many records the same (aread, abpos),
    * so no comparison sort of tie runs */
   if (nlive > 1)
-    { int32_t maxa = 0, maxb = 0, maxp = 0;
-      int ab = 1, bb = 1, pb = 1;
+    { int32_t maxa = 0, maxb = 0;
+      int ab = 1, bb = 1;
       for (i = 0; i < nlive; i++)
         { if (live[i]->aread > maxa) maxa = live[i]->aread;
           if (live[i]->bread > maxb) maxb = live[i]->bread;
-          if (live[i]->abpos > maxp) maxp = live[i]->abpos;
         }
       while (ab < 32 && ((int64_t) 1 << ab) <= maxa) ab += 1;
       while (bb < 32 && ((int64_t) 1 << bb) <= maxb) bb += 1;
-      while (pb < 32 && ((int64_t) 1 << pb) <= maxp) pb += 1;
-      if (ab + pb + bb + 1 <= 64)
-        { /* the whole key in one word -- aread | abpos | bread | comp --: one key pass, one stable sort over the records in
-             survival order, one gather (at 10^6 records the passes through the record pointers are what the order costs) */
-          C.final_minor = 2; C.kb_b = bb; C.kb_p = pb;
-          fga_team_run(team,nlive,pass_final_keys,&C);
-          if (fga_team_sort_pairs(team,skey,sval,nlive,ab+pb+bb+1)) goto oom;
-          fga_team_run(team,nlive,pass_final_gather,&C);
-          memcpy(live,perm,sizeof(rec *)*nlive);
-        }
-      else
-        { C.final_minor = 1;
-          fga_team_run(team,nlive,pass_final_keys,&C);
-          if (fga_team_sort_pairs(team,skey,sval,nlive,bb+1)) goto oom;
-          fga_team_run(team,nlive,pass_final_gather,&C);            /* perm = live in (bread, comp, survival) order */
-          memcpy(live,perm,sizeof(rec *)*nlive);
-          C.final_minor = 0;
-          fga_team_run(team,nlive,pass_final_keys,&C);
-          if (fga_team_sort_pairs(team,skey,sval,nlive,32+ab)) goto oom;
-          fga_team_run(team,nlive,pass_final_gather,&C);
-          memcpy(live,perm,sizeof(rec *)*nlive);
-        }
+      C.final_minor = 1;
+      fga_team_run(team,nlive,pass_final_keys,&C);
+      if (fga_team_sort_pairs(team,skey,sval,nlive,bb+1)) goto oom;
+      fga_team_run(team,nlive,pass_final_gather,&C);            /* perm = live in (bread, comp, survival) order */
+      memcpy(live,perm,sizeof(rec *)*nlive);
+      C.final_minor = 0;
+      fga_team_run(team,nlive,pass_final_keys,&C);
+      if (fga_team_sort_pairs(team,skey,sval,nlive,32+ab)) goto oom;
+      fga_team_run(team,nlive,pass_final_gather,&C);
+      memcpy(live,perm,sizeof(rec *)*nlive);
     }
 
   tw[4] = fga_wall();
@@ -454,8 +437,8 @@ int fga_filter_alignments_mt(const fga_alns *in, int nthreads, fga_alns **out)
       tbytes += live[i]->tlen;
     }
   R->naln = nlive; R->ntrace = tbytes;
-  R->alns = fga_big_malloc(sizeof(fga_aln)*(nlive+1));
-  R->tbytes = fga_big_malloc(tbytes+16);
+  R->alns = malloc(sizeof(fga_aln)*(nlive+1));
+  R->tbytes = malloc(tbytes+16);
   if (R->alns == NULL || R->tbytes == NULL) goto oom;
   C.off = sval;
   fga_team_run(team,nlive,pass_copy_out,&C);
@@ -523,8 +506,8 @@ int fga_alns_merge_filtered(const fga_alns *const *fin, int nfin, fga_alns **out
             i = j;
           }
       }
-  R->alns = fga_big_malloc(sizeof(fga_aln)*(R->naln+1));
-  R->tbytes = fga_big_malloc(R->ntrace+16);
+  R->alns = malloc(sizeof(fga_aln)*(R->naln+1));
+  R->tbytes = malloc(R->ntrace+16);
   if (R->alns == NULL || R->tbytes == NULL) goto oom;
   if (nrun > 1)
     qsort(runs,nrun,sizeof(arun),arun_cmp);

@@ -116,7 +116,6 @@ void   fga_aln_writer_threads(int n);              /* threads of the .1aln recor
 void   fga_note(const char *what, double since);   /* FGA_TIMING=1: elapsed wall time since `since` on stderr */
 
 /* small helpers */
-void *fga_big_malloc(size_t bytes);                         /* malloc, huge-page backed from 8 MB on (fga_par.c) */
 char *fga_path_dir(const char *path);                       /* malloc'd directory part ("." if none) */
 char *fga_path_root(const char *path, const char *suffix);  /* malloc'd basename without suffix      */
 double fga_wall(void);

@@ -11,25 +11,7 @@
 #include <string.h>
 #include <pthread.h>
 
-#include <sys/mman.h>
-
 #include "fga_host.h"
-
-/* malloc for the stage's large arrays (records, trace bytes, sort buffers: tens to hundreds of MB that are written once,
-   by all threads at once): 2 MB aligned and marked for transparent huge pages, so that the first touch costs a page fault
-   per 2 MB instead of per 4 KB -- at 10^6 records the faults of fresh arrays were a third of the filter's time.  free()
-   releases it like any other block. */
-void *fga_big_malloc(size_t bytes)
-{ void *p = NULL;
-  if (bytes < ((size_t) 8 << 20))
-    return malloc(bytes > 0 ? bytes : 1);
-  if (posix_memalign(&p,(size_t) 2 << 20,(bytes + ((size_t) 2 << 20) - 1) & ~(((size_t) 2 << 20) - 1)) != 0)
-    return malloc(bytes);
-#ifdef MADV_HUGEPAGE
-  (void) madvise(p,bytes,MADV_HUGEPAGE);
-#endif
-  return p;
-}
 
 struct fga_team
   { int              nthreads;
@@ -178,8 +160,8 @@ static void sort_scatter(void *arg, int id, int64_t b, int64_t e)
 
 int fga_team_sort_pairs(fga_team *T, uint64_t *key, int64_t *val, int64_t n, int bits)
 { const int nt = T->nthreads;
-  uint64_t *k2 = fga_big_malloc(sizeof(uint64_t)*(n > 0 ? n : 1));
-  int64_t  *v2 = fga_big_malloc(sizeof(int64_t)*(n > 0 ? n : 1));
+  uint64_t *k2 = malloc(sizeof(uint64_t)*(n > 0 ? n : 1));
+  int64_t  *v2 = malloc(sizeof(int64_t)*(n > 0 ? n : 1));
   int64_t  *cnt = malloc(sizeof(int64_t)*RDIG*nt);
   uint64_t *ka = key, *kb = k2;
   int64_t  *va = val, *vb = v2;

@@ -447,8 +447,8 @@ int fga_alns_concat(const fga_alns *const *raw, int nraw, fga_alns **out)
         R->ncells += raw[k]->ncells; R->nbases += raw[k]->nbases;        /* the launches' accounting adds up; busy wavefronts: the largest */
         if (raw[k]->busy_waves > R->busy_waves) R->busy_waves = raw[k]->busy_waves;
       }
-  R->alns = fga_big_malloc(sizeof(fga_aln)*(R->naln+1));
-  R->tbytes = fga_big_malloc(R->ntrace+16);
+  R->alns = malloc(sizeof(fga_aln)*(R->naln+1));
+  R->tbytes = malloc(R->ntrace+16);
   if (R->alns == NULL || R->tbytes == NULL) goto oom;
   for (k = 0; k < nraw; k++)
     if (raw[k] != NULL)
