@@ -57,11 +57,21 @@ typedef struct
     long  cap;
   } scratch;
 
+/* where the regrouping of alignment i has to start: 0 for scripts as Compute_Trace_PTS leaves them, the entry the
+ * device stopped at for scripts of fga_trace_pts_regrouped, -1 when the device finished the alignment */
+static inline int todo_from(const fga_traces *tr, int64_t i)
+{ return tr->resume == NULL ? 0 : tr->resume[i]; }
+
 /* t[0..T): the indel list (-p: gap in A before its p-th base, +q: gap in B before its q-th base; 1-based).
- * A1/B1 are 1-based (A1[1] = first base).  Returns 0, or 1 when out of memory. */
+ * A1/B1 are 1-based (A1[1] = first base).  `start` > 0: the entries before it have been regrouped already (on the
+ * device, fga_trace_pts_regrouped: a box too large for a lane's scratch is handed back) and `start` is the first entry
+ * of the next box.  Returns 0, or 1 when out of memory. */
 static int gap_regroup(const uint8_t *A1, int alen, const uint8_t *B1, int blen, int abpos, int bbpos,
-                       int32_t *t, int T, int *diffs, scratch *S)
-{ int x = 0, diag = abpos-bbpos, gained = 0;
+                       int32_t *t, int T, int start, int *diffs, scratch *S)
+{ int x, diag = abpos-bbpos, gained = 0;
+
+  for (x = 0; x < start; x++)
+    diag += t[x] < 0 ? -1 : 1;
 
   while (x < T)
     { boxview v;
@@ -306,6 +316,12 @@ static void tx_name(text *X, const char *s)
 static void tx_int(text *X, int64_t v)
 { char b[24];
   int  k = 0;
+  if ((uint64_t) v < 100)                            /* run lengths: one or two digits almost always */
+    { if (v >= 10)
+        X->s[X->n++] = (char) ('0' + v/10);
+      X->s[X->n++] = (char) ('0' + v%10);
+      return;
+    }
   if (v < 0)
     { tx_char(X,'-'); v = -v; }
   do { b[k++] = (char) ('0' + v%10); v /= 10; } while (v > 0);
@@ -467,7 +483,8 @@ static void *paf_thread(void *arg)
             if (tcopy == NULL) goto oom;
           }
         memcpy(tcopy,J->tr->trace+J->tr->toff[i],sizeof(int32_t)*T);
-        if (gap_regroup(A1,(int) ca->clen,B1,blen,a->abpos,a->bbpos,tcopy,T,&diffs,&S)) goto oom;
+        if (todo_from(J->tr,i) >= 0 &&
+            gap_regroup(A1,(int) ca->clen,B1,blen,a->abpos,a->bbpos,tcopy,T,todo_from(J->tr,i),&diffs,&S)) goto oom;
         if (build_ops(&L,a,tcopy,T,A1,B1,!(cigar_m && !cs),&del)) goto oom;
 
         block = (a->aepos-a->abpos) + del;
@@ -614,7 +631,8 @@ static void *psl_thread(void *arg)
           if (tcopy == NULL) goto oom;
         }
       memcpy(tcopy,J->tr->trace+J->tr->toff[i],sizeof(int32_t)*T);
-      if (gap_regroup(A1,(int) ca->clen,B1,(int) cb->clen,a.abpos,a.bbpos,tcopy,T,&diffs,&S)) goto oom;
+      if (todo_from(J->tr,i) >= 0 &&
+          gap_regroup(A1,(int) ca->clen,B1,(int) cb->clen,a.abpos,a.bbpos,tcopy,T,todo_from(J->tr,i),&diffs,&S)) goto oom;
 
       for (cut = 0; T > 0 && tcopy[T-1] == -a.aepos-1; T--)       /* gaps after the last base of A */
         cut += 1;
@@ -724,6 +742,7 @@ static int write_lines(const char *path, const fga_gdb *g1, const fga_gdb *g2, c
   FILE     *f;
   int       t, rc = 0;
   int64_t   total = 0, acc = 0, i, nxt;
+  double    t0, t1;
 
   if (g2 == NULL) g2 = g1;
   if ((flags & FGA_PAF_CIGAR_M) && (flags & FGA_PAF_CIGAR_X))
@@ -763,6 +782,7 @@ static int write_lines(const char *path, const fga_gdb *g1, const fga_gdb *g2, c
         { acc += alns->alns[i].aepos-alns->alns[i].abpos + 200; i++; }
       job[t].end = i;
     }
+  t0 = fga_wall();
   for (t = 1; t < nthreads; t++)
     if (pthread_create(th+t,NULL,psl ? psl_thread : paf_thread,job+t) != 0)
       { (psl ? psl_thread : paf_thread)(job+t); th[t] = 0; }
@@ -771,6 +791,7 @@ static int write_lines(const char *path, const fga_gdb *g1, const fga_gdb *g2, c
     if (th[t]) pthread_join(th[t],NULL);
   for (t = 0; t < nthreads; t++)
     rc |= job[t].status;
+  t1 = fga_wall();
   if (rc == 0)
     { const int to_stdout = (path == NULL || strcmp(path,"-") == 0);
       f = to_stdout ? stdout : fopen(path,"w");
@@ -790,6 +811,8 @@ static int write_lines(const char *path, const fga_gdb *g1, const fga_gdb *g2, c
             }
         }
     }
+  if (getenv("FGA_PAF_TIMING") != NULL)
+    fprintf(stderr,"  write_lines: %d threads format %.1f ms, file %.1f ms\n",nthreads,1e3*(t1-t0),1e3*(fga_wall()-t1));
   for (t = 0; t < nthreads; t++)
     free(job[t].out.s);
   free(job); free(th);
@@ -838,10 +861,14 @@ int fga_gap_improve(const fga_gdb *g1, const fga_gdb *g2, const fga_alns *alns, 
           if (bbuf == NULL) goto oom;
         }
       B1 = load_piece(g2,a->bread,a->bbpos,a->bepos,comp,bbuf);
+      if (todo_from(traces,i) < 0)
+        continue;
       if (gap_regroup(A1,(int) g1->contigs[a->aread].clen,B1,(int) g2->contigs[a->bread].clen,a->abpos,a->bbpos,
-                      traces->trace+traces->toff[i],traces->tlen[i],&diffs,&S))
+                      traces->trace+traces->toff[i],traces->tlen[i],todo_from(traces,i),&diffs,&S))
         goto oom;
       traces->diffs[i] = diffs;
+      if (traces->resume != NULL)
+        traces->resume[i] = -1;
     }
   rc = 0;
   goto done;

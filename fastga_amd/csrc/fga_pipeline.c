@@ -553,8 +553,8 @@ static int finish_output(fga_session *Z, const fga_run_params *P, fga_alns *fin,
       int rc = 0;
       t1 = fga_wall();
       if (bases)
-        { rc = fga_trace_pts(dev,Z->dg1,Z->dg2,fin,100,0,&tr);
-          st->trace_kernel_ms = fga_dev_stage_ms(dev,FGA_STAGE_TRACE);
+        { rc = fga_trace_pts_regrouped(dev,Z->dg1,Z->dg2,fin,100,0,&tr);   /* Compute_Trace_PTS + Gap_Improver */
+          st->trace_kernel_ms = fga_dev_stage_ms(dev,FGA_STAGE_TRACE) + fga_dev_stage_ms(dev,FGA_STAGE_REGROUP);
         }
       st->trace_s = fga_wall() - t1;
       t1 = fga_wall();

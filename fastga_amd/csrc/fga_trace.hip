@@ -20,6 +20,7 @@
 // read the row being written.  A panel's row budget is its own difference count minus |M-N| (the reference allows
 // the largest count of the whole alignment; on a consistent trace the optimum never needs more than its own).
 #include "fga_device.hpp"
+#include "fga_gapcore.inc"
 
 namespace {
 
@@ -385,16 +386,76 @@ __global__ void __launch_bounds__(64) trace_pack_kernel(trace_args T)
     }
 }
 
+// Gap_Improver, one lane per alignment (fga_gapcore.inc): persistent wavefronts take 64 alignments at a time from a list
+// ordered by script length (longest first, so that the lanes of a wavefront have similar work and the long ones start
+// early); a lane's F / H scratch is lane-interleaved in the wavefront's slot.  Alignments with more than `tmax` indels
+// are left to the host's formatter threads (resume 0): a lane is a chain of dependent loads, ~100 us per indel against
+// the 0.3 us of a host thread -- 131 k of them beat 32 threads tenfold on 10^6 short alignments (57 ms), but one lane
+// would hold the launch for a long one (512 indels: 50 ms).
+struct regroup_args
+  { const fga_aln  *alns;
+    const int64_t  *toff;
+    int32_t        *dense, *adiffs, *resume;
+    const int32_t  *order;
+    int64_t         n;
+    const uint32_t *imgA, *imgB, *imgBr;
+    const int64_t  *boffA, *boffB, *clenA, *clenB;
+    int64_t         padA, padB;
+    int32_t        *F;
+    uint16_t       *H;
+    int             fcap, tmax;
+    int64_t         hcap;
+    unsigned int   *ticket;
+  };
+
+__global__ void __launch_bounds__(64) trace_regroup_kernel(regroup_args R)
+{ const int lane = threadIdx.x;
+  int32_t  *F = R.F + (int64_t) blockIdx.x*R.fcap*64 + lane;
+  uint16_t *H = R.H + (int64_t) blockIdx.x*R.hcap*64 + lane;
+  for (;;)
+    { unsigned int c = 0;
+      if (lane == 0) c = atomicAdd(R.ticket,1u);
+      c = __shfl(c,0);
+      const int64_t k = (int64_t) c*64 + lane;
+      if ((int64_t) c*64 >= R.n)
+        break;
+      if (k >= R.n)
+        continue;
+      const int64_t i = R.order[k];
+      const fga_aln a = R.alns[i];
+      const int64_t o = R.toff[i];
+      const int T = (int) (R.toff[i+1]-o);
+      if (T < 2)
+        { R.resume[i] = -1;
+          continue;
+        }
+      if (T > R.tmax)
+        { R.resume[i] = 0;
+          continue;
+        }
+      const bool comp = (a.flags & 0x1) != 0;
+      gap_seq SA, SB;
+      SA.img = R.imgA; SA.z = (R.padA + R.boffA[a.aread])*4 - 1; SA.lo = 1; SA.hi = (int) R.clenA[a.aread];
+      SB.img = comp ? R.imgBr : R.imgB; SB.z = (R.padB + R.boffB[a.bread])*4 - 1; SB.lo = a.bbpos+1; SB.hi = a.bepos;
+      int gained = 0;
+      const int r = gap_regroup_packed<64>(SA,SB,SA.hi,(int) R.clenB[a.bread],a.abpos,a.bbpos,R.dense+o,T,
+                                           F,R.fcap,H,R.hcap,&gained);
+      R.resume[i] = r;
+      if (gained != 0)
+        R.adiffs[i] += gained;
+    }
+}
+
 }  // namespace
 
 extern "C" void fga_traces_free(fga_traces *t)
 { if (t == NULL) return;
-  free(t->toff); free(t->tlen); free(t->diffs); free(t->trace);
+  free(t->toff); free(t->tlen); free(t->diffs); free(t->trace); free(t->resume);
   free(t);
 }
 
-extern "C" int fga_trace_pts(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome *GB, const fga_alns *alns,
-                             int tspace, int self, fga_traces **out)
+static int trace_pts_impl(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome *GB, const fga_alns *alns,
+                          int tspace, int self, int regroup, fga_traces **out)
 { *out = NULL;
   FGA_HIP(hipSetDevice(dev->device));
   fga_traces *R = (fga_traces *) calloc(1,sizeof(fga_traces));
@@ -404,7 +465,7 @@ extern "C" int fga_trace_pts(fga_dev *dev, const fga_dgenome *GA, const fga_dgen
     }
   const int64_t n = alns->naln;
   R->naln = n;
-  dev->last_ms[FGA_STAGE_TRACE] = 0.f;
+  dev->last_ms[FGA_STAGE_TRACE] = dev->last_ms[FGA_STAGE_REGROUP] = 0.f;
   if (n == 0)
     { *out = R;
       return 0;
@@ -446,6 +507,8 @@ extern "C" int fga_trace_pts(fga_dev *dev, const fga_dgenome *GA, const fga_dgen
   int32_t *d_atlen = NULL, *d_adiffs = NULL, *d_astat = NULL, *d_pcnt = NULL, *d_pdiff = NULL;
   int32_t *d_raw = NULL, *d_dense = NULL;
   trace_panel *d_panels = NULL; uint16_t *d_cells = NULL;
+  int32_t *d_order = NULL, *d_resume = NULL, *d_F = NULL; uint16_t *d_H = NULL; unsigned int *d_ticket = NULL;
+  hipEvent_t evr0 = NULL, evr1 = NULL;
   std::vector<int64_t> need(2*n), rbase(n+1), sbase(n+1);
   trace_args T;
   memset(&T,0,sizeof(T));
@@ -537,6 +600,53 @@ extern "C" int fga_trace_pts(fga_dev *dev, const fga_dgenome *GA, const fga_dgen
   T.dense = d_dense;
   hipLaunchKernelGGL(trace_pack_kernel,dim3((unsigned) n),dim3(64),0,dev->stream,T);
   hipEventRecord(dev->ev1,dev->stream);
+  if (regroup)
+    { regroup_args G;
+      memset(&G,0,sizeof(G));
+      G.fcap = 520; G.hcap = 16384; G.tmax = 512;
+      { const char *ev = getenv("FGA_REGROUP_CAPS");        // test hook / tuning: "<fcap>,<hcap>,<tmax>"
+        long long f, h, m;
+        if (ev != NULL && sscanf(ev,"%lld,%lld,%lld",&f,&h,&m) == 3 && f > 0 && h > 0 && m > 0)
+          { G.fcap = (int) f; G.hcap = h; G.tmax = (int) m; }
+      }
+      // longest scripts first (counting sort on the length, everything beyond tmax in the first bucket)
+      std::vector<int32_t> order((size_t) n);
+      { std::vector<int64_t> cnt((size_t) G.tmax+3,0);
+        for (int64_t i = 0; i < n; i++)
+          { const int64_t l = R->toff[i+1]-R->toff[i];
+            cnt[(size_t) (l > G.tmax ? 0 : G.tmax+1-l) + 1] += 1;
+          }
+        for (int b = 0; b <= G.tmax+1; b++)
+          cnt[(size_t) b+1] += cnt[(size_t) b];
+        for (int64_t i = 0; i < n; i++)
+          { const int64_t l = R->toff[i+1]-R->toff[i];
+            order[(size_t) cnt[(size_t) (l > G.tmax ? 0 : G.tmax+1-l)]++] = (int32_t) i;
+          }
+      }
+      int64_t slots = (n+63)/64;
+      if (slots > (int64_t) dev->ncu*8) slots = (int64_t) dev->ncu*8;
+      TRY(fga_dmalloc(&d_order,sizeof(int32_t)*n));
+      TRY(fga_dmalloc(&d_resume,sizeof(int32_t)*n));
+      TRY(fga_dmalloc(&d_F,sizeof(int32_t)*64*(size_t) G.fcap*slots));
+      TRY(fga_dmalloc(&d_H,sizeof(uint16_t)*64*(size_t) G.hcap*slots));
+      TRY(fga_dmalloc(&d_ticket,sizeof(unsigned int)));
+      TRY(hipMemcpyAsync(d_order,order.data(),sizeof(int32_t)*n,hipMemcpyHostToDevice,dev->stream));
+      TRY(hipMemsetAsync(d_ticket,0,sizeof(unsigned int),dev->stream));
+      G.alns = d_alns; G.toff = d_toff; G.dense = d_dense; G.adiffs = d_adiffs; G.resume = d_resume; G.order = d_order;
+      G.n = n; G.imgA = T.imgA; G.imgB = T.imgB; G.imgBr = T.imgBr;
+      G.boffA = GA->boff; G.boffB = GB->boff; G.clenA = GA->clen; G.clenB = GB->clen; G.padA = GA->pad; G.padB = GB->pad;
+      G.F = d_F; G.H = d_H; G.ticket = d_ticket;
+      TRY(hipEventCreate(&evr0)); TRY(hipEventCreate(&evr1));
+      hipEventRecord(evr0,dev->stream);
+      hipLaunchKernelGGL(trace_regroup_kernel,dim3((unsigned) slots),dim3(64),0,dev->stream,G);
+      hipEventRecord(evr1,dev->stream);
+      R->resume = (int32_t *) malloc(sizeof(int32_t)*n);
+      if (R->resume == NULL)
+        { fga_set_error("out of memory");
+          goto done;
+        }
+      TRY(hipMemcpyAsync(R->resume,d_resume,sizeof(int32_t)*n,hipMemcpyDeviceToHost,dev->stream));
+    }
   R->trace = (int32_t *) malloc(sizeof(int32_t)*(total+1));
   if (R->trace == NULL)
     { fga_set_error("out of memory");
@@ -550,6 +660,17 @@ extern "C" int fga_trace_pts(fga_dev *dev, const fga_dgenome *GA, const fga_dgen
     TRY(hipStreamSynchronize(dev->stream));
     TRY(hipGetLastError());
     hipEventElapsedTime(&dev->last_ms[FGA_STAGE_TRACE],dev->ev0,dev->ev1);
+    if (regroup)
+      { hipEventElapsedTime(&dev->last_ms[FGA_STAGE_REGROUP],evr0,evr1);
+        if (getenv("FGA_TRACE_TIMING") != NULL)
+          { int64_t back = 0;
+            for (int64_t i = 0; i < n; i++)
+              back += R->resume[i] >= 0;
+            fprintf(stderr,"  fga_trace_pts_regrouped: scripts %.1f ms, regrouping %.1f ms (%lld of %lld alignments handed "
+                           "back to the host)\n",dev->last_ms[FGA_STAGE_TRACE],dev->last_ms[FGA_STAGE_REGROUP],
+                    (long long) back,(long long) n);
+          }
+      }
     for (int64_t i = 0; i < n; i++)
       if (stat[i] != 0)
         { fga_set_error("fga_trace_pts: alignment %lld: trace points are inconsistent with the sequences "
@@ -569,10 +690,91 @@ done:
   fga_pool_free(d_alns); fga_pool_free(d_tb); fga_pool_free(d_need); fga_pool_free(d_pbase); fga_pool_free(d_rbase); fga_pool_free(d_sbase);
   fga_pool_free(d_toff); fga_pool_free(d_atlen); fga_pool_free(d_adiffs); fga_pool_free(d_astat); fga_pool_free(d_pcnt); fga_pool_free(d_pdiff);
   fga_pool_free(d_raw); fga_pool_free(d_dense); fga_pool_free(d_panels); fga_pool_free(d_cells);
+  fga_pool_free(d_order); fga_pool_free(d_resume); fga_pool_free(d_F); fga_pool_free(d_H); fga_pool_free(d_ticket);
+  if (evr0 != NULL) hipEventDestroy(evr0);
+  if (evr1 != NULL) hipEventDestroy(evr1);
   if (rc != 0)
     { fga_traces_free(R);
       return 1;
     }
   *out = R;
   return 0;
+}
+
+extern "C" int fga_trace_pts(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome *GB, const fga_alns *alns,
+                             int tspace, int self, fga_traces **out)
+{ return trace_pts_impl(dev,GA,GB,alns,tspace,self,0,out); }
+
+extern "C" int fga_trace_pts_regrouped(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome *GB, const fga_alns *alns,
+                                       int tspace, int self, fga_traces **out)
+{ return trace_pts_impl(dev,GA,GB,alns,tspace,self,1,out); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The host instantiation of fga_gapcore.inc: the check of the device kernel's source where there is no GPU.  The images
+// are laid out as fga_dgenome_upload / revcomp_kernel lay them out on the device (fga_extend.hip).
+// ---------------------------------------------------------------------------------------------------------------------
+#define CHECK_PAD 4096
+
+static uint8_t *host_image(const fga_gdb *G, int rc)
+{ const size_t bytes = (size_t) G->bpslen + 2*CHECK_PAD + 16;
+  uint8_t *img = (uint8_t *) calloc(bytes,1);
+  if (img == NULL)
+    return NULL;
+  if (!rc)
+    { memcpy(img+CHECK_PAD,G->bps,G->bpslen);
+      return img;
+    }
+  for (int c = 0; c < G->ncontig; c++)
+    { const int64_t len = G->contigs[c].clen;
+      const uint8_t *src = G->bps + G->contigs[c].boff;
+      uint8_t *dst = img + CHECK_PAD + G->contigs[c].boff;
+      for (int64_t x = 0; x < len; x++)
+        { const int64_t y = len-1-x;
+          const int b = (src[y >> 2] >> (2*(y & 3))) & 3;
+          dst[x >> 2] |= (uint8_t) ((3-b) << (2*(x & 3)));
+        }
+    }
+  return img;
+}
+
+extern "C" int fga_gap_core_check(const fga_gdb *g1, const fga_gdb *g2, const fga_alns *alns, fga_traces *traces,
+                                  int fcap, int64_t hcap)
+{ if (g2 == NULL) g2 = g1;
+  if (traces == NULL || traces->naln != alns->naln || fcap < 2 || hcap < 2)
+    { fga_set_error("fga_gap_core_check: the edit scripts do not belong to this alignment set");
+      return 1;
+    }
+  uint8_t *ia = host_image(g1,0), *ib = host_image(g2,0), *ir = host_image(g2,1);
+  int32_t *F = (int32_t *) malloc(sizeof(int32_t)*(size_t) fcap);
+  uint16_t *H = (uint16_t *) malloc(sizeof(uint16_t)*(size_t) hcap);
+  int rc = 1;
+  free(traces->resume);
+  traces->resume = (int32_t *) malloc(sizeof(int32_t)*(size_t) (alns->naln > 0 ? alns->naln : 1));
+  if (ia == NULL || ib == NULL || ir == NULL || F == NULL || H == NULL || traces->resume == NULL)
+    { fga_set_error("fga_gap_core_check: out of memory");
+      goto done;
+    }
+  for (int64_t i = 0; i < alns->naln; i++)
+    { const fga_aln &a = alns->alns[i];
+      if (a.aread < 0 || a.aread >= g1->ncontig || a.bread < 0 || a.bread >= g2->ncontig || a.abpos < 0 || a.bbpos < 0 ||
+          a.aepos > g1->contigs[a.aread].clen || a.bepos > g2->contigs[a.bread].clen)
+        { fga_set_error("fga_gap_core_check: alignment %lld lies outside the contigs",(long long) i);
+          goto done;
+        }
+      const bool comp = (a.flags & 0x1) != 0;
+      gap_seq SA, SB;
+      SA.img = (const uint32_t *) ia; SA.z = (CHECK_PAD + g1->contigs[a.aread].boff)*4 - 1;
+      SA.lo = 1; SA.hi = (int) g1->contigs[a.aread].clen;
+      SB.img = (const uint32_t *) (comp ? ir : ib); SB.z = (CHECK_PAD + g2->contigs[a.bread].boff)*4 - 1;
+      SB.lo = a.bbpos+1; SB.hi = a.bepos;
+      int gained = 0;
+      traces->resume[i] = traces->tlen[i] < 2 ? -1 :
+          gap_regroup_packed<1>(SA,SB,SA.hi,(int) g2->contigs[a.bread].clen,a.abpos,a.bbpos,
+                                traces->trace+traces->toff[i],traces->tlen[i],F,fcap,H,hcap,&gained);
+      traces->diffs[i] += gained;
+    }
+  rc = 0;
+done:
+  free(ia); free(ib); free(ir); free(F); free(H);
+  return rc;
 }

@@ -282,15 +282,18 @@ def extend(dev, ga, gb, hitlist, path_ave, table, score, tspace=100, self_cmp=Fa
     return alns, tb, stats
 
 
-def trace_pts(dev, ga, gb, alns, tb, tspace=100, self_cmp=False):
+def trace_pts(dev, ga, gb, alns, tb, tspace=100, self_cmp=False, regrouped=False):
     """fga_trace_pts: Compute_Trace_PTS (align.c:6171, GREEDIEST) of every alignment of a set on the device.
-    alns: ALN_DTYPE records, tb: their trace bytes.  Returns (toff[n+1], tlen[n], diffs[n], ints)."""
+    alns: ALN_DTYPE records, tb: their trace bytes.  Returns (toff[n+1], tlen[n], diffs[n], ints, info).
+    regrouped: fga_trace_pts_regrouped (Gap_Improver applied on the device), info["resume"] = where the host has to go on
+    per alignment (-1: nowhere)."""
     from .lib import Traces
     alns = np.ascontiguousarray(alns)
     tb = np.ascontiguousarray(tb, dtype=np.uint8)
     a = Alns(len(alns), len(tb), 0, 0, alns.ctypes.data, tb.ctypes.data)
     out = C.POINTER(Traces)()
-    check(dev.L.fga_trace_pts(dev.h, ga.h, gb.h, C.byref(a), tspace, int(self_cmp), C.byref(out)), "trace_pts")
+    fn = dev.L.fga_trace_pts_regrouped if regrouped else dev.L.fga_trace_pts
+    check(fn(dev.h, ga.h, gb.h, C.byref(a), tspace, int(self_cmp), C.byref(out)), "trace_pts")
     t = out.contents
     n, nt = t.naln, t.ntrace
 
@@ -300,6 +303,8 @@ def trace_pts(dev, ga, gb, alns, tb, tspace=100, self_cmp=False):
         return np.frombuffer((C.c_char * (count * np.dtype(dt).itemsize)).from_address(ptr), dtype=dt).copy()
     res = (take(t.toff, n + 1 if n else 0, np.int64), take(t.tlen, n, np.int32), take(t.diffs, n, np.int32),
            take(t.trace, nt, np.int32), {"panels": t.npanels})
+    if regrouped:
+        res[4]["resume"] = take(t.resume, n, np.int32)
     dev.L.fga_traces_free(out)
     return res
 

@@ -75,7 +75,7 @@ class Alns(C.Structure):
 
 class Traces(C.Structure):
     _fields_ = [("naln", C.c_int64), ("ntrace", C.c_int64), ("npanels", C.c_int64), ("toff", C.c_void_p),
-                ("tlen", C.c_void_p), ("diffs", C.c_void_p), ("trace", C.c_void_p)]
+                ("tlen", C.c_void_p), ("diffs", C.c_void_p), ("trace", C.c_void_p), ("resume", C.c_void_p)]
 
 
 class RunParams(C.Structure):
@@ -185,6 +185,8 @@ def _declare(L):
         "fga_write_1aln": (i32, [cp, vp, vp, P(Alns), i32, cp, cp, cp]),
         "fga_write_1aln_binary": (i32, [cp, vp, vp, P(Alns), i32, cp, cp, cp]),
         "fga_trace_pts": (i32, [vp, vp, vp, P(Alns), i32, i32, P(P(Traces))]),
+        "fga_trace_pts_regrouped": (i32, [vp, vp, vp, P(Alns), i32, i32, P(P(Traces))]),
+        "fga_gap_core_check": (i32, [vp, vp, P(Alns), P(Traces), i32, C.c_int64]),
         "fga_traces_free": (None, [P(Traces)]),
         "fga_write_paf": (i32, [cp, vp, vp, P(Alns), P(Traces), i32, i32]),
         "fga_write_psl": (i32, [cp, vp, vp, P(Alns), P(Traces), i32]),

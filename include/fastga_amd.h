@@ -79,7 +79,7 @@ typedef struct
   } fga_merge_params;
 
 enum { FGA_STAGE_MERGE_PARTITION = 0, FGA_STAGE_MERGE = 1, FGA_STAGE_SORT = 2, FGA_STAGE_CHAIN = 3,
-       FGA_STAGE_EXTEND = 4, FGA_STAGE_GIX = 5, FGA_STAGE_TRACE = 6, FGA_NSTAGES = 8 };
+       FGA_STAGE_EXTEND = 4, FGA_STAGE_GIX = 5, FGA_STAGE_TRACE = 6, FGA_STAGE_REGROUP = 7, FGA_NSTAGES = 8 };
 
 int   fga_dev_open(int device, fga_dev **out);
 void  fga_dev_close(fga_dev *dev);
@@ -271,11 +271,28 @@ typedef struct
     int32_t *tlen;             /* [naln]   Path.tlen after Compute_Trace_PTS        */
     int32_t *diffs;            /* [naln]   Path.diffs after Compute_Trace_PTS       */
     int32_t *trace;            /* [ntrace]                                          */
+    int32_t *resume;           /* NULL: the scripts are Compute_Trace_PTS's.  Else [naln], scripts of
+                                  fga_trace_pts_regrouped: -1 = Gap_Improver has been applied to the alignment, x >= 0 =
+                                  applied to the entries before x, the box starting at x did not fit a lane's scratch
+                                  (or the alignment is too long for one lane): the host regrouping continues from x  */
   } fga_traces;
 
 int  fga_trace_pts(fga_dev *dev, const fga_dgenome *ga, const fga_dgenome *gb, const fga_alns *alns,
                    int tspace, int self, fga_traces **out);
+/* Compute_Trace_PTS followed by Gap_Improver (align.h:393-399, align.c:6714-7133) on the device, as every reader of a
+ * .1aln calls the two back to back (ALNtoPAF.c:278-283, ALNtoPSL.c:193-197): one lane regroups one alignment's script in
+ * place, reading the sequences from the packed genome images (A: the whole contig, B: the aligned piece, ALNtoPAF.c:
+ * 258-277); trace / diffs are Path.trace / Path.diffs after Gap_Improver wherever resume[i] < 0.  fga_write_paf /
+ * fga_write_psl / fga_gap_improve accept the result and finish the alignments the device handed back. */
+int  fga_trace_pts_regrouped(fga_dev *dev, const fga_dgenome *ga, const fga_dgenome *gb, const fga_alns *alns,
+                             int tspace, int self, fga_traces **out);
 void fga_traces_free(fga_traces *t);
+/* fga_trace_pts_regrouped's per-alignment routine (fga_gapcore.inc, the source the device kernel is compiled from)
+ * instantiated for the HOST over packed images made from the two GDBs: the check of that source against the oracle
+ * where there is no GPU (tests/test_gap_core.py); not called by the product.  traces: scripts of Compute_Trace_PTS,
+ * rewritten in place, traces->resume allocated and filled; fcap / hcap: the scratch of one "lane" in cells. */
+int  fga_gap_core_check(const fga_gdb *g1, const fga_gdb *g2 /* NULL: self */, const fga_alns *alns, fga_traces *traces,
+                        int fcap, int64_t hcap);
 
 /* ---- PAF output: replaces the ALNtoPAF process behind `FastGA -paf[m|x|s|S]` (ALNtoPAF.c:103-636; options 662-680).
  *      One line per alignment in set order.  With a CIGAR or cs tag the edit scripts of fga_trace_pts are needed; they

@@ -171,3 +171,80 @@ def test_trace_pts_replays_at_bench_scale(tmp_path, built_library):
     for q, i in enumerate(pick):
         assert np.array_equal(res2[3][int(res2[0][q]):int(res2[0][q + 1])], res[3][int(res[0][i]):int(res[0][i + 1])])
     dga.free(); dgb.free(); dev.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+#  Gap_Improver on the device (fga_trace_pts_regrouped): against the host regrouping, which the CPU suite pins against
+#  the oracle and the reference's ALNtoPAF (tests/test_paf_writer.py, tests/test_gap_core.py)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _host_improved(L, ga, gb, alns, tb, res, self_cmp, resume=None):
+    from fastga_amd.lib import Alns, Traces
+    cp = [np.ascontiguousarray(x).copy() for x in res[:4]]
+    rs = None if resume is None else np.ascontiguousarray(resume, dtype=np.int32).copy()
+    A = Alns(len(alns), len(tb), 0, 0, alns.ctypes.data, tb.ctypes.data)
+    T = Traces(len(alns), len(cp[3]), 0, *(x.ctypes.data for x in cp), None if rs is None else rs.ctypes.data)
+    assert L.fga_gap_improve(ga.h, None if self_cmp else gb.h, C.byref(A), C.byref(T)) == 0, L.fga_last_error()
+    assert rs is None or (rs == -1).all()
+    return cp
+
+
+def _regroup_checks(L, dev, ga, gb, dga, dgb, alns, tb, self_cmp=False):
+    import os
+    from fastga_amd import device as D
+    alns, tb = np.ascontiguousarray(alns), np.ascontiguousarray(tb, dtype=np.uint8)
+    plain = D.trace_pts(dev, dga, dgb, alns, tb)
+    want = _host_improved(L, ga, gb, alns, tb, plain, self_cmp)
+    changed = int((want[3] != plain[3]).sum())
+    got = D.trace_pts(dev, dga, dgb, alns, tb, regrouped=True)
+    rs = got[4]["resume"]
+    long_ = plain[1] > 512                                 # scripts one lane would hold the launch for: the host's
+    assert (rs[~long_] == -1).all() and (rs[long_] == 0).all() and not long_.all()
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    for i in np.nonzero(~long_)[0]:
+        o, e = int(want[0][i]), int(want[0][i + 1])
+        assert np.array_equal(got[3][o:e], want[3][o:e]) and got[2][i] == want[2][i], i
+    fin = _host_improved(L, ga, gb, alns, tb, got, self_cmp, resume=rs)
+    assert np.array_equal(fin[3], want[3]) and np.array_equal(fin[2], want[2])
+    # a lane scratch most boxes do not fit, then scripts "too long for one lane": handed back, finished by the host
+    back = 0
+    for caps in ("3,12,100000", "1024,16384,8"):
+        os.environ["FGA_REGROUP_CAPS"] = caps
+        try:
+            part = D.trace_pts(dev, dga, dgb, alns, tb, regrouped=True)
+        finally:
+            del os.environ["FGA_REGROUP_CAPS"]
+        rs = part[4]["resume"]
+        back += int((rs >= 0).sum())
+        if caps.endswith(",8"):
+            long_ = plain[1] > 8
+            assert (rs[long_] == 0).all() and (rs[~long_ & (plain[1] >= 2)] == -1).all()
+        fin = _host_improved(L, ga, gb, alns, tb, part, self_cmp, resume=rs)
+        assert np.array_equal(fin[3], want[3]) and np.array_equal(fin[2], want[2])
+    return changed, back
+
+
+def test_regrouped_scripts_equal_the_host_gap_improver(toy_pair, tmp_path, built_library):
+    from fastga_amd import device as D, workload
+    L = built_library
+    dev = D.Device(0)
+    d, ra, rb = toy_pair
+    ga, gb, dga, dgb, alns, tb = _alignments(dev, ra, rb)
+    changed, back = _regroup_checks(L, dev, ga, gb, dga, dgb, alns, tb)
+    assert changed > 0 and back > 0
+    dga.free(); dgb.free()
+    # 15 % divergence: crowded boxes, both strands
+    ra, rb = workload.build_pair(str(tmp_path), seed=5, ncontig=5, total=600_000, divergence=0.15, inv_frac=0.1)
+    ga, gb, dga, dgb, alns, tb = _alignments(dev, ra, rb, aln_rate=0.45)
+    changed, back = _regroup_checks(L, dev, ga, gb, dga, dgb, alns, tb)
+    assert changed > 500 and back > 0
+    dga.free(); dgb.free()
+    # self comparison (the readers load A and B separately: self flag off)
+    sd = str(tmp_path / "self")
+    import os
+    os.makedirs(sd)
+    ra, _ = workload.build_pair(sd, seed=9, ncontig=4, total=400_000, divergence=0.05, repeat_frac=0.15)
+    ga, gb, dga, dgb, alns, tb = _alignments(dev, ra, ra, self_cmp=True)
+    changed, back = _regroup_checks(L, dev, ga, gb, dga, dgb, alns, tb, self_cmp=True)
+    assert changed > 0
+    dga.free(); dgb.free(); dev.close()
