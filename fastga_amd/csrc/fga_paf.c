@@ -16,6 +16,9 @@
 #include <string.h>
 #include <stdint.h>
 #include <pthread.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include "fga_host.h"
 #include "fastga_amd.h"
@@ -266,7 +269,7 @@ typedef struct
     size_t n, cap;
   } text;
 
-static int op_add(oplist *L, char op, int len)
+static inline int op_add(oplist *L, char op, int len)
 { if (len <= 0)
     return 0;
   if (L->n > 0 && L->op[L->n-1] == op)
@@ -329,23 +332,43 @@ static void tx_int(text *X, int64_t v)
     tx_char(X,b[--k]);
 }
 
-/* columns k..k+len of A against h..h+len of B as one M, or as =/X runs */
+/* columns k..k+len of A against h..h+len of B as one M, or as =/X runs.  With SSE2 the columns are compared sixteen at a
+ * time into a bit mask of up to 64 columns and the runs are read off the mask (the loads may run up to 15 bytes past the
+ * block: the sequence buffers carry that slack); the per-column loop of the other build is the same thing one at a time. */
 static int op_block(oplist *L, const uint8_t *A1, const uint8_t *B1, int k, int h, int len, int eqx)
-{ int i;
+{ const uint8_t *a = A1+k, *b = B1+h;
+  int i;
   if (!eqx)
     return op_add(L,'M',len);
+#if defined(__SSE2__)
   for (i = 0; i < len; )
-    { const uint8_t *a = A1+k, *b = B1+h;
-      int j = i;
-      while (j+8 <= len)                          /* equal columns eight at a time */
-        { uint64_t x, y;
-          memcpy(&x,a+j,8); memcpy(&y,b+j,8);
-          if ((x ^= y) != 0)
-            { j += __builtin_ctzll(x) >> 3;
-              break;
-            }
-          j += 8;
+    { const int n = len-i < 64 ? len-i : 64;
+      uint64_t eq = 0;
+      int w, pos;
+      for (w = 0; w < n; w += 16)
+        { const __m128i x = _mm_loadu_si128((const __m128i *) (a+i+w)), y = _mm_loadu_si128((const __m128i *) (b+i+w));
+          eq |= (uint64_t) (unsigned) _mm_movemask_epi8(_mm_cmpeq_epi8(x,y)) << w;
         }
+      if (n < 64)
+        eq &= (1ull << n) - 1;
+      for (pos = 0; pos < n; )
+        { const uint64_t rest = eq >> pos;
+          int r;
+          if (rest & 1)
+            { r = ~rest == 0 ? 64 : __builtin_ctzll(~rest);
+              if (op_add(L,'=',r)) return 1;
+            }
+          else
+            { r = rest == 0 ? n-pos : __builtin_ctzll(rest);
+              if (op_add(L,'X',r)) return 1;
+            }
+          pos += r;
+        }
+      i += n;
+    }
+#else
+  for (i = 0; i < len; )
+    { int j = i;
       while (j < len && a[j] == b[j])
         j += 1;
       if (op_add(L,'=',j-i)) return 1;
@@ -355,6 +378,7 @@ static int op_block(oplist *L, const uint8_t *A1, const uint8_t *B1, int k, int 
       if (op_add(L,'X',j-i)) return 1;
       i = j;
     }
+#endif
   return 0;
 }
 
@@ -383,6 +407,8 @@ static int build_ops(oplist *L, const fga_aln *a, const int32_t *t, int T, const
   return 0;
 }
 
+/* one chunk of consecutive alignments: formatted by whichever worker takes it, written by the caller's thread as soon
+ * as every chunk before it has been written */
 typedef struct
   { const fga_gdb *g1, *g2;
     const fga_alns *alns;
@@ -392,7 +418,43 @@ typedef struct
     int64_t  beg, end;
     text     out;
     int      status;
+    int      done;
   } paf_job;
+
+/* what a worker keeps from chunk to chunk */
+typedef struct
+  { oplist   L;
+    scratch  S;
+    uint8_t *abuf, *bbuf, *arev;
+    int32_t *tcopy, *blk;
+    int64_t  acap, bcap, tcap, kcap;
+  } fmt_scratch;
+
+static void fmt_free(fmt_scratch *W)
+{ free(W->L.op); free(W->L.ln); free(W->S.buf); free(W->abuf); free(W->bbuf); free(W->arev); free(W->tcopy); free(W->blk);
+  memset(W,0,sizeof(*W));
+}
+
+/* The bases of A an alignment with T indels can look at: Gap_Improver reads A and B column by column and stops at the
+ * sentinels around the aligned piece of B (ALNtoPAF.c:258-277), so on A it stays within T+2 bases of [abpos,aepos] --
+ * the diagonal moves by one per indel.  The window gets the sentinel where it ends at a contig end, like the reference's
+ * whole-contig buffer; elsewhere its border is never consulted.  ptr[q] = q-th base (1-based), NULL when out of memory. */
+static const uint8_t *load_a_window(const fga_gdb *G, int c, int abpos, int aepos, int T, fmt_scratch *W)
+{ const int64_t len = G->contigs[c].clen;
+  int64_t wb = (int64_t) abpos - T - 8, we = (int64_t) aepos + T + 8;
+  if (wb < 0) wb = 0;
+  if (we > len) we = len;
+  if (we-wb+64 > W->acap)
+    { W->acap = 2*(we-wb) + 4096;
+      free(W->abuf);
+      W->abuf = malloc(W->acap);
+      if (W->abuf == NULL)
+        { W->acap = 0;
+          return NULL;
+        }
+    }
+  return load_piece(G,c,(int) wb,(int) we,0,W->abuf);
+}
 
 static void put_divergence(text *X, const fga_aln *a, int64_t iid)
 { const int64_t len = a->aepos-a->abpos;
@@ -404,27 +466,18 @@ static void put_divergence(text *X, const fga_aln *a, int64_t iid)
   tx_char(X,(char) ('0'+v%10));
 }
 
-static void *paf_thread(void *arg)
-{ paf_job *J = arg;
-  const fga_gdb *g1 = J->g1, *g2 = J->g2;
+static int format_paf(paf_job *J, fmt_scratch *W)
+{ const fga_gdb *g1 = J->g1, *g2 = J->g2;
   const int cigar_m = (J->flags & FGA_PAF_CIGAR_M) != 0, cigar_x = (J->flags & FGA_PAF_CIGAR_X) != 0;
   const int cs_s = (J->flags & FGA_PAF_CS_SHORT) != 0, cs_l = (J->flags & FGA_PAF_CS_LONG) != 0;
   const int swap = (J->flags & FGA_PAF_SWAP) != 0;
   const int cigar = cigar_m || cigar_x, cs = cs_s || cs_l, bases = cigar || cs;
+  const int eqx = !(cigar_m && !cs);                       /* =/X runs wanted: the columns have to be compared */
   static const char lower[4] = { 'a','c','g','t' }, upper[4] = { 'A','C','G','T' };
-  oplist   L = { NULL, NULL, 0, 0 };
-  scratch  S = { NULL, 0 };
   text    *X = &J->out;
-  uint8_t *abuf = NULL, *bbuf = NULL, *arev = NULL;
-  int32_t *tcopy = NULL;
-  int64_t  tcap = 0, bcap = 0, i;
-  int      alast = -1;
-  const uint8_t *A1 = NULL;
+  oplist  *L = &W->L;
+  int64_t  i;
 
-  if (bases)
-    { abuf = malloc(g1->maxctg+4);
-      if (abuf == NULL) goto oom;
-    }
   for (i = J->beg; i < J->end; i++)
     { const fga_aln *a = J->alns->alns+i;
       const int comp = (a->flags & 0x1) != 0;
@@ -461,31 +514,35 @@ static void *paf_thread(void *arg)
         }
 
       { const int T = J->tr->tlen[i], blen = (int) cb->clen, n = a->bepos-a->bbpos;
+        const int todo = todo_from(J->tr,i);
         int diffs = J->tr->diffs[i], del = 0, q, j, from, to, step;
-        const uint8_t *B1, *Aw, *Bw;
+        const uint8_t *A1 = NULL, *B1 = NULL, *Aw, *Bw;
+        const int32_t *t = J->tr->trace+J->tr->toff[i];
         int64_t block, iid;
 
-        if (a->aread != alast)
-          { A1 = fga_gdb_get_contig(g1,a->aread,abuf) - 1;
-            alast = a->aread;
+        if (todo >= 0 || eqx)                              /* the bases are needed to regroup and to tell = from X */
+          { A1 = load_a_window(g1,a->aread,a->abpos,a->aepos,T,W);
+            if (A1 == NULL) goto oom;
+            if (n+64 > W->bcap)
+              { W->bcap = 2*(int64_t) n + 4096;
+                free(W->bbuf);
+                W->bbuf = malloc(W->bcap);
+                if (W->bbuf == NULL) { W->bcap = 0; goto oom; }
+              }
+            B1 = load_piece(g2,a->bread,a->bbpos,a->bepos,comp,W->bbuf);
           }
-        if (n+4 > bcap)
-          { bcap = 2*(int64_t) n + 4096;
-            free(bbuf);
-            bbuf = malloc(bcap);
-            if (bbuf == NULL) goto oom;
+        if (todo >= 0)
+          { if (T+1 > W->tcap)
+              { W->tcap = 2*(int64_t) T + 1024;
+                free(W->tcopy);
+                W->tcopy = malloc(sizeof(int32_t)*W->tcap);
+                if (W->tcopy == NULL) { W->tcap = 0; goto oom; }
+              }
+            memcpy(W->tcopy,t,sizeof(int32_t)*T);
+            if (gap_regroup(A1,(int) ca->clen,B1,blen,a->abpos,a->bbpos,W->tcopy,T,todo,&diffs,&W->S)) goto oom;
+            t = W->tcopy;
           }
-        B1 = load_piece(g2,a->bread,a->bbpos,a->bepos,comp,bbuf);
-        if (T+1 > tcap)
-          { tcap = 2*(int64_t) T + 1024;
-            free(tcopy);
-            tcopy = malloc(sizeof(int32_t)*tcap);
-            if (tcopy == NULL) goto oom;
-          }
-        memcpy(tcopy,J->tr->trace+J->tr->toff[i],sizeof(int32_t)*T);
-        if (todo_from(J->tr,i) >= 0 &&
-            gap_regroup(A1,(int) ca->clen,B1,blen,a->abpos,a->bbpos,tcopy,T,todo_from(J->tr,i),&diffs,&S)) goto oom;
-        if (build_ops(&L,a,tcopy,T,A1,B1,!(cigar_m && !cs),&del)) goto oom;
+        if (build_ops(L,a,t,T,A1,B1,eqx,&del)) goto oom;
 
         block = (a->aepos-a->abpos) + del;
         iid = block-diffs;
@@ -494,29 +551,29 @@ static void *paf_thread(void *arg)
         tx_str(X,"\tdf:i:"); tx_int(X,diffs);
 
         if (swap)
-          for (q = 0; q < L.n; q++)
-            L.op[q] = L.op[q] == 'I' ? 'D' : (L.op[q] == 'D' ? 'I' : L.op[q]);
-        from = 0; to = L.n; step = 1;
+          for (q = 0; q < L->n; q++)
+            L->op[q] = L->op[q] == 'I' ? 'D' : (L->op[q] == 'D' ? 'I' : L->op[q]);
+        from = 0; to = L->n; step = 1;
         if (comp && !swap)
-          { from = L.n-1; to = -1; step = -1; }
+          { from = L->n-1; to = -1; step = -1; }
 
         if (cigar)
-          { if (tx_room(X,(size_t) L.n*12+64)) goto oom;
+          { if (tx_room(X,(size_t) L->n*12+64)) goto oom;
             tx_str(X,"\tcg:Z:");
             if (cigar_m && cs)                         /* =/X runs were built for the cs tag: print them merged */
               { int run = 0;
                 for (q = from; q != to; q += step)
-                  if (L.op[q] == 'I' || L.op[q] == 'D')
+                  if (L->op[q] == 'I' || L->op[q] == 'D')
                     { if (run > 0) { tx_int(X,run); tx_char(X,'M'); run = 0; }
-                      tx_int(X,L.ln[q]); tx_char(X,L.op[q]);
+                      tx_int(X,L->ln[q]); tx_char(X,L->op[q]);
                     }
                   else
-                    run += L.ln[q];
+                    run += L->ln[q];
                 if (run > 0) { tx_int(X,run); tx_char(X,'M'); }
               }
             else
               for (q = from; q != to; q += step)
-                { tx_int(X,L.ln[q]); tx_char(X,L.op[q]); }
+                { tx_int(X,L->ln[q]); tx_char(X,L->op[q]); }
           }
 
         if (cs)
@@ -525,21 +582,21 @@ static void *paf_thread(void *arg)
             Bw = B1+a->bbpos+1;
             if (comp && !swap)                         /* read both segments on the other strand, operations reversed */
               { uint8_t *r;
-                free(arev);
-                arev = malloc((size_t) alen_seg + n + 8);
-                if (arev == NULL) goto oom;
-                r = arev;
+                free(W->arev);
+                W->arev = malloc((size_t) alen_seg + n + 8);
+                if (W->arev == NULL) goto oom;
+                r = W->arev;
                 for (j = 0; j < alen_seg; j++) r[j] = (uint8_t) (3-Aw[alen_seg-1-j]);
                 for (j = 0; j < n; j++) r[alen_seg+j] = (uint8_t) (3-Bw[n-1-j]);
                 Aw = r; Bw = r+alen_seg;
               }
             if (swap)
               { const uint8_t *c = Aw; Aw = Bw; Bw = c; }
-            if (tx_room(X,(size_t) 3*(alen_seg+n) + (size_t) L.n*12 + 64)) goto oom;
+            if (tx_room(X,(size_t) 3*(alen_seg+n) + (size_t) L->n*12 + 64)) goto oom;
             tx_str(X,"\tcs:Z:");
             for (q = from; q != to; q += step)
-              { const int l = L.ln[q];
-                switch (L.op[q])
+              { const int l = L->ln[q];
+                switch (L->op[q])
                   { case '=':
                       if (cs_s)
                         { tx_char(X,':'); tx_int(X,l); }
@@ -573,33 +630,21 @@ static void *paf_thread(void *arg)
         tx_char(X,'\n');
       }
     }
-  J->status = 0;
-  goto done;
+  return 0;
 
 oom:
   fga_set_error("fga_write_paf: out of memory");
-  J->status = 1;
-done:
-  free(L.op); free(L.ln); free(S.buf); free(abuf); free(bbuf); free(arev); free(tcopy);
-  return NULL;
+  return 1;
 }
 
 
 /* One PSL line per alignment (gen_psl, ALNtoPSL.c:77-405): counts, strand, names and ranges, then the ungapped blocks.
  * Always base-level: the edit script is regrouped first, trailing indels at the very end are trimmed off. */
-static void *psl_thread(void *arg)
-{ paf_job *J = arg;
-  const fga_gdb *g1 = J->g1, *g2 = J->g2;
-  scratch  S = { NULL, 0 };
+static int format_psl(paf_job *J, fmt_scratch *W)
+{ const fga_gdb *g1 = J->g1, *g2 = J->g2;
   text    *X = &J->out;
-  uint8_t *abuf = NULL, *bbuf = NULL;
-  int32_t *tcopy = NULL, *blk = NULL;
-  int64_t  tcap = 0, bcap = 0, kcap = 0, i;
-  int      alast = -1;
-  const uint8_t *A1 = NULL;
+  int64_t  i;
 
-  abuf = malloc(g1->maxctg+4);
-  if (abuf == NULL) goto oom;
   for (i = J->beg; i < J->end; i++)
     { fga_aln a = J->alns->alns[i];                  /* a copy: the trim moves aepos / bepos */
       const int comp = (a.flags & 0x1) != 0;
@@ -610,29 +655,31 @@ static void *psl_thread(void *arg)
       int T = J->tr->tlen[i], diffs = J->tr->diffs[i];
       int x, k, h, cut, nblk, prev;
       int ngapA = 0, ngapB = 0, runA = 0, runB = 0, subs, same;
-      const uint8_t *B1;
+      const int todo = todo_from(J->tr,i);
+      const int32_t *tcopy = J->tr->trace+J->tr->toff[i];
+      int32_t *blk;
       int64_t boff;
 
-      if (a.aread != alast)
-        { A1 = fga_gdb_get_contig(g1,a.aread,abuf) - 1;
-          alast = a.aread;
+      if (todo >= 0)                                 /* the blocks need no bases, only an unfinished regrouping does */
+        { const uint8_t *A1 = load_a_window(g1,a.aread,a.abpos,a.aepos,T,W), *B1;
+          if (A1 == NULL) goto oom;
+          if (n+64 > W->bcap)
+            { W->bcap = 2*(int64_t) n + 4096;
+              free(W->bbuf);
+              W->bbuf = malloc(W->bcap);
+              if (W->bbuf == NULL) { W->bcap = 0; goto oom; }
+            }
+          B1 = load_piece(g2,a.bread,a.bbpos,a.bepos,comp,W->bbuf);
+          if (T+1 > W->tcap)
+            { W->tcap = 2*(int64_t) T + 1024;
+              free(W->tcopy);
+              W->tcopy = malloc(sizeof(int32_t)*W->tcap);
+              if (W->tcopy == NULL) { W->tcap = 0; goto oom; }
+            }
+          memcpy(W->tcopy,tcopy,sizeof(int32_t)*T);
+          if (gap_regroup(A1,(int) ca->clen,B1,(int) cb->clen,a.abpos,a.bbpos,W->tcopy,T,todo,&diffs,&W->S)) goto oom;
+          tcopy = W->tcopy;
         }
-      if (n+16 > bcap)
-        { bcap = 2*(int64_t) n + 4096;
-          free(bbuf);
-          bbuf = malloc(bcap);
-          if (bbuf == NULL) goto oom;
-        }
-      B1 = load_piece(g2,a.bread,a.bbpos,a.bepos,comp,bbuf);
-      if (T+1 > tcap)
-        { tcap = 2*(int64_t) T + 1024;
-          free(tcopy);
-          tcopy = malloc(sizeof(int32_t)*tcap);
-          if (tcopy == NULL) goto oom;
-        }
-      memcpy(tcopy,J->tr->trace+J->tr->toff[i],sizeof(int32_t)*T);
-      if (todo_from(J->tr,i) >= 0 &&
-          gap_regroup(A1,(int) ca->clen,B1,(int) cb->clen,a.abpos,a.bbpos,tcopy,T,todo_from(J->tr,i),&diffs,&S)) goto oom;
 
       for (cut = 0; T > 0 && tcopy[T-1] == -a.aepos-1; T--)       /* gaps after the last base of A */
         cut += 1;
@@ -649,12 +696,13 @@ static void *psl_thread(void *arg)
       subs = diffs-(ngapA+ngapB);
       same = (a.aepos-a.abpos)-ngapB-subs;
 
-      if (T+2 > kcap)
-        { kcap = 2*(int64_t) T + 1024;
-          free(blk);
-          blk = malloc(sizeof(int32_t)*3*kcap);
-          if (blk == NULL) goto oom;
+      if (T+2 > W->kcap)
+        { W->kcap = 2*(int64_t) T + 1024;
+          free(W->blk);
+          W->blk = malloc(sizeof(int32_t)*3*W->kcap);
+          if (W->blk == NULL) { W->kcap = 0; goto oom; }
         }
+      blk = W->blk;
       nblk = 0;                                      /* blocks as (length, A start, B start), 0-based */
       k = a.abpos+1; h = a.bbpos+1;
       for (x = 0; x <= T; x++)
@@ -708,15 +756,11 @@ static void *psl_thread(void *arg)
         }
       tx_char(X,'\n');
     }
-  J->status = 0;
-  goto done;
+  return 0;
 
 oom:
   fga_set_error("fga_write_psl: out of memory");
-  J->status = 1;
-done:
-  free(S.buf); free(abuf); free(bbuf); free(tcopy); free(blk);
-  return NULL;
+  return 1;
 }
 
 /* every record must lie inside the contigs it names (the sets come from arbitrary .1aln files through bin/ALNtoPAF) */
@@ -734,15 +778,50 @@ static int check_records(const char *who, const fga_gdb *g1, const fga_gdb *g2, 
   return 0;
 }
 
+/* the formatting of a set: workers take chunks of consecutive alignments from a counter, the caller's thread writes
+ * every finished chunk as soon as all chunks before it are out -- the file is written while the rest is formatted, and
+ * a written chunk's text is given back */
+typedef struct
+  { paf_job        *chunk;
+    int             nchunk, next, failed;
+    pthread_mutex_t mu;
+    pthread_cond_t  cv;
+  } paf_run;
+
+static void *paf_worker(void *arg)
+{ paf_run    *R = arg;
+  fmt_scratch W;
+  memset(&W,0,sizeof(W));
+  while (1)
+    { const int c = __sync_fetch_and_add(&R->next,1);
+      paf_job *J;
+      int st;
+      if (c >= R->nchunk || R->failed)
+        break;
+      J = R->chunk+c;
+      st = J->psl ? format_psl(J,&W) : format_paf(J,&W);
+      pthread_mutex_lock(&R->mu);
+      J->status = st;
+      J->done = 1;
+      if (st) R->failed = 1;
+      pthread_cond_broadcast(&R->cv);
+      pthread_mutex_unlock(&R->mu);
+    }
+  fmt_free(&W);
+  return NULL;
+}
+
 static int write_lines(const char *path, const fga_gdb *g1, const fga_gdb *g2, const fga_alns *alns,
                        const fga_traces *traces, int flags, int nthreads, int psl)
 { const int bases = psl || (flags & (FGA_PAF_CIGAR_M|FGA_PAF_CIGAR_X|FGA_PAF_CS_SHORT|FGA_PAF_CS_LONG)) != 0;
-  paf_job  *job;
+  const int to_stdout = (path == NULL || strcmp(path,"-") == 0);
+  const char *who = psl ? "fga_write_psl" : "fga_write_paf";
+  paf_run    R;
   pthread_t *th;
-  FILE     *f;
-  int       t, rc = 0;
-  int64_t   total = 0, acc = 0, i, nxt;
-  double    t0, t1;
+  FILE      *f;
+  int        t, c, nchunk, rc = 0, started = 0;
+  int64_t    total = 0, acc = 0, i, nxt;
+  double     t0, twait = 0., tfile = 0.;
 
   if (g2 == NULL) g2 = g1;
   if ((flags & FGA_PAF_CIGAR_M) && (flags & FGA_PAF_CIGAR_X))
@@ -754,68 +833,97 @@ static int write_lines(const char *path, const fga_gdb *g1, const fga_gdb *g2, c
       return 1;
     }
   if (bases && (traces == NULL || traces->naln != alns->naln))
-    { fga_set_error("%s: base-level output needs the edit scripts of fga_trace_pts for the same alignments",
-                    psl ? "fga_write_psl" : "fga_write_paf");
+    { fga_set_error("%s: base-level output needs the edit scripts of fga_trace_pts for the same alignments",who);
       return 1;
     }
-  if (check_records(psl ? "fga_write_psl" : "fga_write_paf",g1,g2,alns))
+  if (check_records(who,g1,g2,alns))
     return 1;
   unpack_tables();
   if (nthreads < 1) nthreads = 1;
   if (nthreads > 64) nthreads = 64;
   if (alns->naln < nthreads) nthreads = alns->naln > 0 ? (int) alns->naln : 1;
-  job = calloc(nthreads,sizeof(paf_job));
+  nchunk = 8*nthreads;
+  if (alns->naln < nchunk) nchunk = alns->naln > 0 ? (int) alns->naln : 1;
+  memset(&R,0,sizeof(R));
+  R.chunk = calloc(nchunk,sizeof(paf_job));
   th = calloc(nthreads,sizeof(pthread_t));
-  if (job == NULL || th == NULL)
-    { free(job); free(th);
+  if (R.chunk == NULL || th == NULL)
+    { free(R.chunk); free(th);
       fga_set_error("out of memory");
       return 1;
     }
+  R.nchunk = nchunk;
   for (i = 0; i < alns->naln; i++)                   /* equal shares of aligned bases, contiguous in file order */
     total += alns->alns[i].aepos-alns->alns[i].abpos + 200;
   nxt = 0;
-  for (t = 0, i = 0; t < nthreads; t++)
-    { job[t].g1 = g1; job[t].g2 = g2; job[t].alns = alns; job[t].tr = traces; job[t].flags = flags; job[t].psl = psl;
-      job[t].beg = i;
-      nxt += total/nthreads + 1;
-      while (i < alns->naln && (acc < nxt || t == nthreads-1))
+  for (c = 0, i = 0; c < nchunk; c++)
+    { paf_job *J = R.chunk+c;
+      J->g1 = g1; J->g2 = g2; J->alns = alns; J->tr = traces; J->flags = flags; J->psl = psl;
+      J->beg = i;
+      nxt += total/nchunk + 1;
+      while (i < alns->naln && (acc < nxt || c == nchunk-1))
         { acc += alns->alns[i].aepos-alns->alns[i].abpos + 200; i++; }
-      job[t].end = i;
+      J->end = i;
     }
+  f = to_stdout ? stdout : fopen(path,"w");
+  if (f == NULL)
+    { fga_set_error("cannot create %s",path);
+      free(R.chunk); free(th);
+      return 1;
+    }
+  pthread_mutex_init(&R.mu,NULL);
+  pthread_cond_init(&R.cv,NULL);
   t0 = fga_wall();
-  for (t = 1; t < nthreads; t++)
-    if (pthread_create(th+t,NULL,psl ? psl_thread : paf_thread,job+t) != 0)
-      { (psl ? psl_thread : paf_thread)(job+t); th[t] = 0; }
-  (psl ? psl_thread : paf_thread)(job);
-  for (t = 1; t < nthreads; t++)
-    if (th[t]) pthread_join(th[t],NULL);
   for (t = 0; t < nthreads; t++)
-    rc |= job[t].status;
-  t1 = fga_wall();
-  if (rc == 0)
-    { const int to_stdout = (path == NULL || strcmp(path,"-") == 0);
-      f = to_stdout ? stdout : fopen(path,"w");
-      if (f == NULL)
-        { fga_set_error("cannot create %s",path);
+    if (pthread_create(th+t,NULL,paf_worker,&R) == 0)
+      started = 1;
+    else
+      th[t] = 0;
+  if (!started)                                      /* no thread could be made: format here */
+    paf_worker(&R);
+  for (c = 0; c < nchunk && rc == 0; c++)
+    { paf_job *J = R.chunk+c;
+      const double w0 = fga_wall();
+      double w1;
+      pthread_mutex_lock(&R.mu);
+      while (!J->done && !R.failed)
+        pthread_cond_wait(&R.cv,&R.mu);
+      if (!J->done || J->status)
+        rc = 1;
+      pthread_mutex_unlock(&R.mu);
+      w1 = fga_wall();
+      twait += w1-w0;
+      if (rc == 0 && J->out.n > 0 && fwrite(J->out.s,1,J->out.n,f) != J->out.n)
+        { fga_set_error("write error on %s",to_stdout ? "stdout" : path);
+          pthread_mutex_lock(&R.mu);
+          R.failed = 1;
+          pthread_mutex_unlock(&R.mu);
           rc = 1;
         }
-      else
-        { for (t = 0; t < nthreads && rc == 0; t++)
-            if (job[t].out.n > 0 && fwrite(job[t].out.s,1,job[t].out.n,f) != job[t].out.n)
-              { fga_set_error("write error on %s",to_stdout ? "stdout" : path);
-                rc = 1;
-              }
-          if (to_stdout) fflush(f); else if (fclose(f) != 0 && rc == 0)
-            { fga_set_error("write error on %s",path);
-              rc = 1;
-            }
+      tfile += fga_wall()-w1;
+      free(J->out.s);
+      J->out.s = NULL;
+    }
+  for (t = 0; t < nthreads; t++)
+    if (th[t]) pthread_join(th[t],NULL);
+  if (to_stdout)
+    fflush(f);
+  else
+    { if (fclose(f) != 0 && rc == 0)
+        { fga_set_error("write error on %s",path);
+          rc = 1;
         }
+      if (rc != 0)
+        remove(path);
     }
   if (getenv("FGA_PAF_TIMING") != NULL)
-    fprintf(stderr,"  write_lines: %d threads format %.1f ms, file %.1f ms\n",nthreads,1e3*(t1-t0),1e3*(fga_wall()-t1));
-  for (t = 0; t < nthreads; t++)
-    free(job[t].out.s);
-  free(job); free(th);
+    fprintf(stderr,"  write_lines: %d threads, %d chunks: %.1f ms (writer waited %.1f ms for chunks, wrote for %.1f ms)\n",
+            nthreads,nchunk,1e3*(fga_wall()-t0),1e3*twait,1e3*tfile);
+  for (c = 0; c < nchunk; c++)
+    free(R.chunk[c].out.s);
+  pthread_mutex_destroy(&R.mu);
+  pthread_cond_destroy(&R.cv);
+  free(R.chunk); free(th);
   return rc;
 }
 
@@ -829,11 +937,9 @@ int fga_write_psl(const char *path, const fga_gdb *g1, const fga_gdb *g2, const 
 
 /* the regrouping alone, applied in place to a whole set: Path.trace / Path.diffs after Gap_Improver */
 int fga_gap_improve(const fga_gdb *g1, const fga_gdb *g2, const fga_alns *alns, fga_traces *traces)
-{ scratch  S = { NULL, 0 };
-  uint8_t *abuf, *bbuf = NULL;
-  int64_t  bcap = 0, i;
-  int      alast = -1, rc = 1;
-  const uint8_t *A1 = NULL;
+{ fmt_scratch W;
+  int64_t  i;
+  int      rc = 1;
 
   if (g2 == NULL) g2 = g1;
   if (traces == NULL || traces->naln != alns->naln)
@@ -843,28 +949,25 @@ int fga_gap_improve(const fga_gdb *g1, const fga_gdb *g2, const fga_alns *alns, 
   if (check_records("fga_gap_improve",g1,g2,alns))
     return 1;
   unpack_tables();
-  abuf = malloc(g1->maxctg+4);
-  if (abuf == NULL) goto oom;
+  memset(&W,0,sizeof(W));
   for (i = 0; i < alns->naln; i++)
     { const fga_aln *a = alns->alns+i;
       const int comp = (a->flags & 0x1) != 0, n = a->bepos-a->bbpos;
-      const uint8_t *B1;
+      const uint8_t *A1, *B1;
       int diffs = traces->diffs[i];
-      if (a->aread != alast)
-        { A1 = fga_gdb_get_contig(g1,a->aread,abuf) - 1;
-          alast = a->aread;
-        }
-      if (n+16 > bcap)
-        { bcap = 2*(int64_t) n + 4096;
-          free(bbuf);
-          bbuf = malloc(bcap);
-          if (bbuf == NULL) goto oom;
-        }
-      B1 = load_piece(g2,a->bread,a->bbpos,a->bepos,comp,bbuf);
       if (todo_from(traces,i) < 0)
         continue;
+      A1 = load_a_window(g1,a->aread,a->abpos,a->aepos,traces->tlen[i],&W);
+      if (A1 == NULL) goto oom;
+      if (n+64 > W.bcap)
+        { W.bcap = 2*(int64_t) n + 4096;
+          free(W.bbuf);
+          W.bbuf = malloc(W.bcap);
+          if (W.bbuf == NULL) { W.bcap = 0; goto oom; }
+        }
+      B1 = load_piece(g2,a->bread,a->bbpos,a->bepos,comp,W.bbuf);
       if (gap_regroup(A1,(int) g1->contigs[a->aread].clen,B1,(int) g2->contigs[a->bread].clen,a->abpos,a->bbpos,
-                      traces->trace+traces->toff[i],traces->tlen[i],todo_from(traces,i),&diffs,&S))
+                      traces->trace+traces->toff[i],traces->tlen[i],todo_from(traces,i),&diffs,&W.S))
         goto oom;
       traces->diffs[i] = diffs;
       if (traces->resume != NULL)
@@ -875,6 +978,6 @@ int fga_gap_improve(const fga_gdb *g1, const fga_gdb *g2, const fga_alns *alns, 
 oom:
   fga_set_error("fga_gap_improve: out of memory");
 done:
-  free(S.buf); free(abuf); free(bbuf);
+  fmt_free(&W);
   return rc;
 }

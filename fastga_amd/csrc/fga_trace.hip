@@ -604,11 +604,24 @@ static int trace_pts_impl(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
     { regroup_args G;
       memset(&G,0,sizeof(G));
       G.fcap = 520; G.hcap = 16384; G.tmax = 512;
+      { // What the host's formatter threads would need for all of it (0.3 us per indel and thread) decides what the device
+        // takes: a lane needs 35-100 us per indel, so the launch lasts as long as its longest script -- it may cost a
+        // quarter of the host's estimate, and is not made at all when that leaves it only scripts of a few indels (the 2 k
+        // contig-long alignments of the bench pair: 3 M indels, 9 ms on 32 threads, against 17 ms for 512-indel lanes).
+        const int nthr = dev->host_threads > 0 ? dev->host_threads : 8;
+        const double host_ms = 0.3e-3 * (double) total / nthr;
+        if (host_ms*5. < G.tmax)
+          G.tmax = (int) (host_ms*5.);
+      }
+      if (G.tmax < 64)
+        { G.tmax = 1; G.fcap = 2; G.hcap = 2; }             // everything to the host (T < 2 needs no regrouping)
       { const char *ev = getenv("FGA_REGROUP_CAPS");        // test hook / tuning: "<fcap>,<hcap>,<tmax>"
         long long f, h, m;
         if (ev != NULL && sscanf(ev,"%lld,%lld,%lld",&f,&h,&m) == 3 && f > 0 && h > 0 && m > 0)
           { G.fcap = (int) f; G.hcap = h; G.tmax = (int) m; }
       }
+      if (G.fcap > G.tmax+8)
+        G.fcap = G.tmax+8;
       // longest scripts first (counting sort on the length, everything beyond tmax in the first bucket)
       std::vector<int32_t> order((size_t) n);
       { std::vector<int64_t> cnt((size_t) G.tmax+3,0);

@@ -61,3 +61,12 @@ for rep in range(3):
     t = time.time()
     assert L.fga_write_paf(out.encode(), g.h, None, C.byref(A_), C.byref(T), 2, a.threads) == 0
     print(f"fga_write_paf -x, {a.threads} threads: {1000*(time.time()-t):.1f} ms, {os.path.getsize(out)/1e6:.0f} MB", flush=True)
+# the formatter alone: scripts regrouped beforehand (what fga_trace_pts_regrouped hands over; here by the host instantiation
+# of the device routine), resume = -1 everywhere
+cp = [x.copy() for x in arrs]
+T = Traces(len(recs), int(toff[-1]), 0, *(x.ctypes.data for x in cp), None)
+assert L.fga_gap_core_check(g.h, None, C.byref(A_), C.byref(T), 1024, 1 << 20) == 0
+for rep in range(3):
+    t = time.time()
+    assert L.fga_write_paf(out.encode(), g.h, None, C.byref(A_), C.byref(T), 2, a.threads) == 0
+    print(f"fga_write_paf -x on regrouped scripts, {a.threads} threads: {1000*(time.time()-t):.1f} ms", flush=True)
