@@ -96,6 +96,7 @@ int main(int argc, char *argv[])
   if (db2 != NULL && fga_gdb_open(db2,&g2)) goto fail;
   if (bases)
     { if (fga_dev_open(0,&dev)) goto fail;
+      fga_dev_set_host_threads(dev,nthreads);
       if (fga_dgenome_upload(dev,g1,NULL,0,g2 == NULL,&d1)) goto fail;
       if (g2 != NULL && fga_dgenome_upload(dev,g2,NULL,0,1,&d2)) goto fail;
       if (fga_trace_pts_regrouped(dev,d1,g2 != NULL ? d2 : d1,alns,tspace,0,&tr)) goto fail;
