@@ -56,6 +56,20 @@ __device__ __forceinline__ int64_t key_anti(const chain_args &G, u128 k)
 __device__ __forceinline__ int key_lcp(u128 k)  { return (int) ((uint32_t) k & 63); }
 __device__ __forceinline__ int key_drem(u128 k) { return (int) (((uint32_t) k >> 6) & 63); }
 
+// chain_small_kernel's view of the key stream: the workgroup's 256 records, the one before them and the SMALL_LOOK after
+// them sit in LDS (one coalesced pass); a unit of at most SMALL_LIMIT records that starts in the workgroup's range lies
+// inside, so the walks of the bucket heads -- chains of dependent reads, one record at a time -- never wait for HBM.
+#define SMALL_LOOK  64          // > SMALL_LIMIT + 1
+struct key_tile
+  { const uint4 *lds;           // record lo + t at lds[t]
+    int64_t      lo, hi;        // records [lo,hi) are in the tile
+  };
+
+__device__ __forceinline__ u128 key_at(const chain_args &G, const key_tile &K, int64_t i)
+{ const uint4 k = (i >= K.lo && i < K.hi) ? K.lds[i-K.lo] : G.keys[i];
+  return ((u128) (((uint64_t) k.w << 32) | k.z) << 64) | (((uint64_t) k.y << 32) | k.x);
+}
+
 struct unit_info
   { int64_t b, m, e;            // run d = [b,m), run d+1 = [m,e)
     int     isnew, aux, comp, actg, bctg;
@@ -89,15 +103,16 @@ __device__ __forceinline__ fga_hit make_hit(const chain_args &G, const unit_info
 }
 
 // The reference's sequential scan of one unit (FastGA.c:3060-3176 as restated in fga_chain.c); WRITE = false only
-// counts the hits.
+// counts the hits.  (Keeping the first two hits of the counting pass in registers, so that almost no unit is scanned
+// twice, made the kernel slower: 10.1 -> 12.2 ms.)
 template <bool WRITE>
-__device__ int scan_sequential(const chain_args &G, const unit_info &U, fga_hit *out)
+__device__ int scan_sequential(const chain_args &G, const key_tile &K, const unit_info &U, fga_hit *out)
 { const int64_t CB = G.cbreak, CMIN = G.cmin;
   int64_t s = U.b, t = U.m;
-  u128 ks = key_at(G,s), kt = 0;
+  u128 ks = key_at(G,K,s), kt = 0;
   int64_t ipost = key_anti(G,ks), apost = INT64_MAX;
   if (U.aux)
-    { kt = key_at(G,t); apost = key_anti(G,kt); }
+    { kt = key_at(G,K,t); apost = key_anti(G,kt); }
   int64_t ahgh = -CB, alow = (apost < ipost) ? apost : ipost, anti, cov = 0;
   int dgmin = 2*BUCK_WIDTH, dgmax = 0, dg, lcp, wch, mix = 0, go = 1, nh = 0;
   while (go)
@@ -105,7 +120,7 @@ __device__ int scan_sequential(const chain_args &G, const unit_info &U, fga_hit 
         { lcp = key_lcp(kt); dg = key_drem(kt) + BUCK_WIDTH; anti = apost;
           t += 1;
           if (t >= U.e) apost = INT64_MAX;
-          else { kt = key_at(G,t); apost = key_anti(G,kt); }
+          else { kt = key_at(G,K,t); apost = key_anti(G,kt); }
           wch = 0x2;
         }
       else
@@ -118,7 +133,7 @@ __device__ int scan_sequential(const chain_args &G, const unit_info &U, fga_hit 
               else         ipost = INT64_MAX;
             }
           else
-            { ks = key_at(G,s); ipost = key_anti(G,ks); }
+            { ks = key_at(G,K,s); ipost = key_anti(G,ks); }
           wch = 0x1;
         }
       lcp <<= 1;
@@ -158,13 +173,202 @@ __device__ __forceinline__ void store_unit(const chain_args &G, const unit_info 
 __device__ __forceinline__ void publish_unit(const chain_args &G, const unit_info &U, int64_t first, int nh)
 { store_unit(G,U,first,nh,atomicAdd(G.ctr+1,1ull)); }
 
-// One thread per bucket head.  The hit and unit slots of a wavefront's threads come from ONE atomic each (the threads'
-// hit counts are scanned across the wavefront): the two counters share a cache line, atomics on a line are served one
-// after the other (~88 per microsecond for the whole chip), and with one pair of atomics per unit this kernel took
-// exactly that long -- 22 ms for the 1.01 M units of the 150 Mbp self comparison, 84 ms at 3 Gbp.
-__global__ __launch_bounds__(256)
+// One thread per record.  What the kernel is made of was found by taking it apart (round 4): the hit and unit slots of a
+// WORKGROUP come from one atomic each (per unit, and again per wavefront, the kernel took as long as its atomics: the two
+// counters share a cache line and a line serves ~88 atomics per microsecond); a bucket head does not WALK its unit -- the
+// walk is a loop of 128-bit shifts and compares whose longest instance in a wavefront (49 steps, twice) every lane waits
+// for -- but reads the unit's end off a bit mask of the bucket heads of the workgroup's records and the bound of its
+// coverage off a prefix sum of their lcp values; and the sequential scans of the units that can reach the threshold run
+// compacted, one unit per lane of full wavefronts.  22 ms -> 9 ms for the 1.01 M units of the 150 Mbp self comparison
+// (workgroups of 256 / 512 / 1024 records: 14 / 9 / 12.5 ms -- fewer atomics against fewer workgroups per CU to overlap the
+// phases between the barriers); on the bench pair, where almost no bucket can reach the threshold, 0.4 -> 0.7 ms.
+
+// first bucket head after offset o of the workgroup's range (> o), as far as two mask words reach; else a large number
+template <int SMALL_WORDS>
+__device__ __forceinline__ int next_head(const uint64_t *mask, int o)
+{ const int w = (o+1) >> 6, b = (o+1) & 63;
+  uint64_t x = mask[w] >> b;
+  if (x != 0)
+    return o + 1 + (__ffsll((long long) x) - 1);
+  if (w+1 < SMALL_WORDS && (x = mask[w+1]) != 0)
+    return (w+1)*64 + (__ffsll((long long) x) - 1);
+  return 1 << 20;
+}
+
+template <int SMALL_BLOCK>
+__global__ __launch_bounds__(SMALL_BLOCK)
 void chain_small_kernel(chain_args G)
-{ const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+{ constexpr int SMALL_WORDS = SMALL_BLOCK/64 + 1;   // head-mask words: the block's records and SMALL_LOOK (= 64) beyond
+  __shared__ uint4 tile[SMALL_BLOCK + 1 + SMALL_LOOK];
+  __shared__ int wave_hits[SMALL_BLOCK/64 + 1], wave_units[SMALL_BLOCK/64];
+  __shared__ unsigned long long block_base[2];
+  __shared__ uint32_t list[SMALL_BLOCK];
+  __shared__ uint64_t heads[SMALL_WORDS];
+  __shared__ int      lsum[SMALL_BLOCK + SMALL_LOOK + 1];       // lsum[o] = sum of the lcp values of offsets < o
+  const int64_t base = (int64_t) blockIdx.x * blockDim.x;
+  const int64_t i = base + threadIdx.x;
+  const int lane = (int) (threadIdx.x & 63);
+  const int wave = (int) (threadIdx.x >> 6);
+  key_tile K;
+  K.lds = tile;
+  K.lo = base - 1;
+  K.hi = K.lo + SMALL_BLOCK + 1 + SMALL_LOOK;
+  if (K.hi > G.n) K.hi = G.n;
+  for (int64_t t = K.lo + threadIdx.x; t < K.hi; t += SMALL_BLOCK)
+    if (t >= 0)
+      tile[t-K.lo] = G.keys[t];
+  if (K.lo < 0) K.lo = 0, K.lds = tile + 1;
+  __syncthreads();
+
+  // bucket heads and lcp values of the offsets 0 .. SMALL_BLOCK+SMALL_LOOK-1 (position n counts as a head: the end)
+  const uint64_t dmask = (1ull << G.wd) - 1;
+  u128 Ui = 0;
+  bool head = false, prevadj = false;
+  for (int r = 0; r < 2; r++)
+    { const int o = r*SMALL_BLOCK + (int) threadIdx.x;
+      if (r == 1 && o >= SMALL_BLOCK + SMALL_LOOK)
+        break;                                               // whole wavefronts leave: offsets come in 64s
+      const int64_t p = base + o;
+      bool h = (p == G.n);
+      int  l = 0;
+      if (p < G.n)
+        { const u128 k = key_at(G,K,p);
+          const u128 Uk = k >> G.s_buck;
+          bool adj = false;
+          h = true;
+          l = key_lcp(k);
+          if (p > 0)
+            { const u128 Up = key_at(G,K,p-1) >> G.s_buck;
+              h = (Up != Uk);
+              adj = (Up + 1 == Uk) && (((uint64_t) Uk & dmask) != 0);
+            }
+          if (r == 0)
+            { Ui = Uk; head = h; prevadj = adj; }
+        }
+      const uint64_t hm = __ballot(h);
+      int incl = l;
+      #pragma unroll
+      for (int d = 1; d < 64; d <<= 1)
+        { const int t = __shfl_up(incl,d,64);
+          if (lane >= d) incl += t;
+        }
+      const int wo = o >> 6;
+      if (lane == 0)
+        heads[wo] = hm;
+      if (lane == 63)
+        wave_hits[wo] = incl;                               // the wavefront's lcp total (the array is free until the slots)
+      lsum[o+1] = incl;                                       // completed below with the wavefronts before
+    }
+  __syncthreads();
+  { int before = 0;                                           // lcp total of the wavefronts before this thread's offsets
+    for (int w = 0; w < wave; w++)
+      before += wave_hits[w];
+    int all = before;
+    for (int w = wave; w < SMALL_BLOCK/64; w++)
+      all += wave_hits[w];
+    __syncthreads();
+    lsum[threadIdx.x+1] += before;
+    if (threadIdx.x < SMALL_LOOK)
+      lsum[SMALL_BLOCK+threadIdx.x+1] += all;
+    if (threadIdx.x == 0)
+      lsum[0] = 0;
+  }
+  __syncthreads();
+
+  unit_info U;
+  int nh = 0;
+  bool live = (i < G.n) && head;
+  if (live)
+    { const int o = (int) threadIdx.x, lim = G.small_limit;
+      int m = next_head<SMALL_WORDS>(heads,o), e;
+      U.b = i; U.isnew = !prevadj;
+      if (m-o > lim)
+        e = m;                                                // a long unit
+      else
+        { e = m;
+          if (((uint64_t) Ui & dmask) != dmask && base+m < G.n && (key_at(G,K,base+m) >> G.s_buck) == Ui + 1)
+            e = next_head<SMALL_WORDS>(heads,m);
+        }
+      if (e-o > lim)                                          // a long unit: one wavefront will take it
+        { const unsigned long long q = atomicAdd(G.ctr+2,1ull);
+          if ((int64_t) q < G.big_cap)
+            G.bigq[q] = i;
+          live = false;
+        }
+      else
+        { const int bound = 2*(lsum[e]-lsum[o]);              // sum of 2 lcp over the unit: an upper bound of any chain's cov
+          U.m = base+m; U.e = base+e; U.aux = (e > m);
+          if ((!U.isnew && !U.aux) || bound < G.cmin)
+            live = false;
+        }
+    }
+  // the units that can reach the threshold, compacted over the workgroup
+  { const uint64_t lm = __ballot(live);
+    if (lane == 0)
+      wave_units[wave] = __popcll(lm);
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int w = 0; w < SMALL_BLOCK/64; w++)
+      { const int c = wave_units[w];
+        if (w < wave) base += c;
+        total += c;
+      }
+    if (live)
+      list[base + __popcll(lm & ((1ull << lane) - 1))] = (uint32_t) threadIdx.x | ((uint32_t) (U.m-U.b) << 10) |
+                                                         ((uint32_t) (U.e-U.b) << 16) | ((uint32_t) U.isnew << 22);
+    __syncthreads();
+    live = (int) threadIdx.x < total;
+  }
+  if (live)
+    { const uint32_t d = list[threadIdx.x];
+      U.b = base + (d & 1023);
+      U.m = U.b + ((d >> 10) & 63); U.e = U.b + ((d >> 16) & 63);
+      U.aux = (U.e > U.m); U.isnew = (int) ((d >> 22) & 1);
+      unit_coords(G,key_at(G,K,U.b),U);
+      nh = scan_sequential<false>(G,K,U,NULL);
+    }
+  // slots for the workgroup's units and hits (every thread is here)
+  const uint64_t em = __ballot(nh > 0);
+  int incl = nh;
+  #pragma unroll
+  for (int d = 1; d < 64; d <<= 1)
+    { const int t = __shfl_up(incl,d,64);
+      if (lane >= d) incl += t;
+    }
+  if (lane == 63)
+    { wave_hits[wave] = incl; wave_units[wave] = __popcll(em); }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    { int h = 0, u = 0;
+      for (int w = 0; w < SMALL_BLOCK/64; w++)
+        { const int hw = wave_hits[w], uw = wave_units[w];
+          wave_hits[w] = h; wave_units[w] = u;
+          h += hw; u += uw;
+        }
+      if (u > 0)
+        { block_base[0] = atomicAdd(G.ctr+0,(unsigned long long) h);
+          block_base[1] = atomicAdd(G.ctr+1,(unsigned long long) u);
+        }
+    }
+  __syncthreads();
+  if (nh == 0)
+    return;
+  const int64_t first = (int64_t) block_base[0] + wave_hits[wave] + (incl - nh);
+  if (first + nh <= G.hit_cap)
+    scan_sequential<true>(G,K,U,G.hits + first);
+  store_unit(G,U,first,nh,block_base[1] + (unsigned long long) (wave_units[wave] + __popcll(em & ((1ull << lane) - 1))));
+}
+
+// The same result for key streams whose buckets are noise -- one unit in 10^4 records can reach the threshold (the bench
+// pair: 2,087 units in 48.6 M records): one thread per record straight from HBM, a bucket head walks the one or two
+// records of its unit, slots by one pair of atomics per wavefront that has a unit at all.  0.38 ms on the bench pair
+// against the 0.7 ms of the workgroup-tiled kernel above, 22 against 9 ms where units are dense: fga_chain_scan_device
+// picks by the unit density of the device's previous launch.
+__global__ __launch_bounds__(256)
+void chain_sparse_kernel(chain_args G)
+{ key_tile K;
+  K.lds = NULL; K.lo = K.hi = 0;                     // nothing staged: every key from HBM
+ const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = (int) (threadIdx.x & 63);
   unit_info U;
   int nh = 0;
@@ -217,7 +421,7 @@ void chain_small_kernel(chain_args G)
     }
   if (live)
     { unit_coords(G,ki,U);
-      nh = scan_sequential<false>(G,U,NULL);
+      nh = scan_sequential<false>(G,K,U,NULL);
     }
   // slots for the wavefront's units and hits (every lane is here)
   const uint64_t em = __ballot(nh > 0);
@@ -241,7 +445,7 @@ void chain_small_kernel(chain_args G)
     return;
   const int64_t first = (int64_t) hbase + (incl - nh);
   if (first + nh <= G.hit_cap)
-    scan_sequential<true>(G,U,G.hits + first);
+    scan_sequential<true>(G,K,U,G.hits + first);
   store_unit(G,U,first,nh,ubase + (unsigned long long) __popcll(em & ((1ull << lane) - 1)));
 }
 
@@ -680,7 +884,7 @@ extern "C" int fga_chain_scan_device(fga_dev *dev, const fga_dkeys *K, const fga
   int nctg = 1 << K->wa;
   int small_limit = SMALL_LIMIT;
   { const char *e = getenv("FGA_CHAIN_SMALL_LIMIT");      // test hook: force units through the wave-parallel kernel
-    if (e != NULL && atoi(e) >= 0)
+    if (e != NULL && atoi(e) >= 0 && atoi(e) <= SMALL_LIMIT)
       small_limit = atoi(e);
   }
   int64_t hit_cap  = n/8 + 65536;
@@ -727,14 +931,21 @@ extern "C" int fga_chain_scan_device(fga_dev *dev, const fga_dkeys *K, const fga
           }
       }
       hipEventRecord(dev->ev0,dev->stream);
-      { const int64_t nblk = (n + 255) / 256;
-        hipLaunchKernelGGL(chain_small_kernel,dim3((unsigned) nblk),dim3(256),0,dev->stream,A);
+      { int blk = dev->chain_density > 0. && dev->chain_density < 5e-4 ? 0 : 512;
+        const char *ev = getenv("FGA_CHAIN_BLOCK");          // experiments: 256 / 512 / 1024 records per workgroup, 0: sparse kernel
+        if (ev != NULL) blk = atoi(ev);
+        const int64_t nblk = (n + blk - 1) / (blk > 0 ? blk : 1);
+        if (blk == 0)        hipLaunchKernelGGL(chain_sparse_kernel,dim3((unsigned) ((n + 255) / 256)),dim3(256),0,dev->stream,A);
+        else if (blk == 256) hipLaunchKernelGGL(chain_small_kernel<256>,dim3((unsigned) nblk),dim3(256),0,dev->stream,A);
+        else if (blk == 1024) hipLaunchKernelGGL(chain_small_kernel<1024>,dim3((unsigned) nblk),dim3(1024),0,dev->stream,A);
+        else                 hipLaunchKernelGGL(chain_small_kernel<512>,dim3((unsigned) ((n + 511) / 512)),dim3(512),0,dev->stream,A);
       }
       if (hipMemcpyAsync(hc,A.ctr,sizeof(hc),hipMemcpyDeviceToHost,dev->stream) != hipSuccess ||
           hipStreamSynchronize(dev->stream) != hipSuccess)
         { fga_set_error("fga_chain_scan_device: small-unit kernel failed: %s",hipGetErrorString(hipGetLastError()));
           goto fail;
         }
+      dev->chain_density = (double) hc[1] / (double) n;
       if ((int64_t) hc[2] > big_cap)
         { fga_set_error("fga_chain_scan_device: internal error, long-unit queue overflow");
           goto fail;

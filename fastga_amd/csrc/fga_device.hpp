@@ -31,6 +31,7 @@ struct fga_dev
     // what the last extension launch really needed (cells of the trace-point pool per hit-box base, output trace bytes
     // per base): the next launch over similar inputs starts from there instead of finding out by a repeated launch
     double       ext_cells_per_base, ext_tbytes_per_base;
+    double       chain_density;   // small units with hits per key of the last chain scan (0: none yet): picks its kernel
     size_t       hbm_low_water;   // smallest free device memory seen at the stage boundaries (fga_dev_note_memory)
     int          host_threads;    // threads the host tails of the device stages may use (fga_dev_set_host_threads; 0 = 1)
   };

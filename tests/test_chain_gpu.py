@@ -1,4 +1,5 @@
-"""GPU parity: the device chain scan (thread-per-bucket + wave-parallel kernels) against oracle/chain_oracle.c -- the
+"""GPU parity: the device chain scan (thread-per-record kernels -- workgroup-tiled for dense, straight from HBM for sparse
+key streams, every workgroup size -- + wave-parallel kernels) against oracle/chain_oracle.c -- the
 sequential restatement of the reference's scan (align_contigs, FastGA.c:3016-3176) that tests/test_chain_oracle.py pins
 to the hit boxes a DEBUG_HIT build of the reference prints -- on the same sorted records: bit-exact hits and units (the
 product's host scan, fga_chain_scan, is compared too).  The small/long unit threshold is varied so that every unit also
@@ -29,14 +30,20 @@ def _scan_both(ra, rb, limits, chain_min=170, chain_break=2000):
     _equals_oracle(keys, ru, rh, chain_break, chain_min, amx, bmx, alen_sorted)
     out = []
     for lim in limits:
+        blk = None                                   # (limit, workgroup size): 0 = the kernel for sparse key streams
+        if isinstance(lim, tuple):
+            lim, blk = lim
         if lim is None:
             os.environ.pop("FGA_CHAIN_SMALL_LIMIT", None)
         else:
             os.environ["FGA_CHAIN_SMALL_LIMIT"] = str(lim)
+        if blk is not None:
+            os.environ["FGA_CHAIN_BLOCK"] = str(blk)
         try:
             got = D.chain_scan_device(dev, keys, chain_break, chain_min, amx, bmx, alen_sorted)
         finally:
             os.environ.pop("FGA_CHAIN_SMALL_LIMIT", None)
+            os.environ.pop("FGA_CHAIN_BLOCK", None)
         out.append((lim, got.units, got.hits))
         got.free()
     ref.free(); keys.free(); dA.free(); dB.free(); dev.close()
@@ -62,7 +69,7 @@ def _equals_oracle(keys, units, hits, chain_break, chain_min, amx, bmx, alen_sor
 @pytest.mark.parametrize("chain_min", [170, 100])
 def test_device_chain_scan_matches_host(toy_pair, chain_min):
     d, ra, rb = toy_pair
-    ru, rh, out = _scan_both(ra, rb, [None, 3, 0], chain_min=chain_min)
+    ru, rh, out = _scan_both(ra, rb, [None, 3, 0, (None, 0), (None, 256), (None, 1024), (5, 0), (5, 1024)], chain_min=chain_min)
     assert len(rh) > 20
     for lim, u, h in out:
         assert len(u) == len(ru) and len(h) == len(rh), (lim, len(u), len(ru), len(h), len(rh))
@@ -73,7 +80,7 @@ def test_device_chain_scan_matches_host(toy_pair, chain_min):
 def test_device_chain_scan_self(toy_pair):
     """self comparison: every contig pairs with itself, which gives the longest buckets"""
     d, ra, rb = toy_pair
-    ru, rh, out = _scan_both(ra, ra, [None, 0])
+    ru, rh, out = _scan_both(ra, ra, [None, 0, (None, 0), (None, 256), (7, 1024)])
     assert len(rh) > 0
     for lim, u, h in out:
         assert np.array_equal(u, ru) and np.array_equal(h, rh), lim
