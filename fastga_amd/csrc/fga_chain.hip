@@ -34,6 +34,8 @@ typedef unsigned __int128 u128;
 #define SMALL_LIMIT 48          // units with more records go to the wave-parallel kernel
 #define HIT_STAGE   128         // hits staged in LDS per big unit before the contiguous block is reserved
 
+#define CTR_UNITS   32
+#define CTR_WORDS   40
 struct chain_args
   { const uint4 *keys; int64_t n;
     int s_buck, s_b, s_a, s_strand, wd, wt, wb, wa;
@@ -42,7 +44,8 @@ struct chain_args
     fga_hit  *hits;   int64_t hit_cap;
     fga_unit *units;  int64_t *unit_head; int64_t unit_cap;
     int64_t  *bigq;   int64_t big_cap;
-    unsigned long long *ctr;        // [0] hits, [1] units, [2] queued long units, [3] segment cursor, [4] segments,
+    unsigned long long *ctr;        // [0] hits, [CTR_UNITS] units (a cache line of its own: the two are the hot ones),
+                                    // [2] queued long units, [3] segment cursor, [4] segments,
                                     // [5] staged inner hits
     int small_limit;
   };
@@ -171,7 +174,7 @@ __device__ __forceinline__ void store_unit(const chain_args &G, const unit_info 
 }
 
 __device__ __forceinline__ void publish_unit(const chain_args &G, const unit_info &U, int64_t first, int nh)
-{ store_unit(G,U,first,nh,atomicAdd(G.ctr+1,1ull)); }
+{ store_unit(G,U,first,nh,atomicAdd(G.ctr+CTR_UNITS,1ull)); }
 
 // One thread per record.  What the kernel is made of was found by taking it apart (round 4): the hit and unit slots of a
 // WORKGROUP come from one atomic each (per unit, and again per wavefront, the kernel took as long as its atomics: the two
@@ -347,7 +350,7 @@ void chain_small_kernel(chain_args G)
         }
       if (u > 0)
         { block_base[0] = atomicAdd(G.ctr+0,(unsigned long long) h);
-          block_base[1] = atomicAdd(G.ctr+1,(unsigned long long) u);
+          block_base[1] = atomicAdd(G.ctr+CTR_UNITS,(unsigned long long) u);
         }
     }
   __syncthreads();
@@ -437,7 +440,7 @@ void chain_sparse_kernel(chain_args G)
   unsigned long long hbase = 0, ubase = 0;
   if (lane == 0)
     { hbase = atomicAdd(G.ctr+0,(unsigned long long) total);
-      ubase = atomicAdd(G.ctr+1,(unsigned long long) __popcll(em));
+      ubase = atomicAdd(G.ctr+CTR_UNITS,(unsigned long long) __popcll(em));
     }
   hbase = ((unsigned long long) (uint32_t) __shfl((int) (uint32_t) (hbase >> 32),0,64) << 32) | (uint32_t) __shfl((int) (uint32_t) hbase,0,64);
   ubase = ((unsigned long long) (uint32_t) __shfl((int) (uint32_t) (ubase >> 32),0,64) << 32) | (uint32_t) __shfl((int) (uint32_t) ubase,0,64);
@@ -895,12 +898,12 @@ extern "C" int fga_chain_scan_device(fga_dev *dev, const fga_dkeys *K, const fga
   void *hbuf = NULL, *ubuf = NULL, *bbuf = NULL, *sbuf = NULL;
   const int stage_slot = (K->slot == SLOT_SORT0) ? SLOT_SORT1 : SLOT_SORT0;     // the sort's idle ping-pong buffer
   int64_t *dalen = NULL;
-  unsigned long long hc[8];
+  unsigned long long hc[CTR_WORDS];
   fga_hit *hh = NULL; fga_unit *hu = NULL; int64_t *hd = NULL;
 
   for (int attempt = 0; attempt < 2; attempt++)
     { const size_t ubytes = sizeof(fga_unit)*(size_t) unit_cap + sizeof(int64_t)*(size_t) unit_cap
-                          + sizeof(int64_t)*(size_t) big_cap + sizeof(int64_t)*(size_t) nctg + 128;
+                          + sizeof(int64_t)*(size_t) big_cap + sizeof(int64_t)*(size_t) nctg + sizeof(unsigned long long)*CTR_WORDS + 128;
       hbuf = fga_dev_acquire(dev,SLOT_HIST,sizeof(fga_hit)*(size_t) hit_cap);
       ubuf = fga_dev_acquire(dev,SLOT_TILES,ubytes);
       if (hbuf == NULL || ubuf == NULL)
@@ -924,7 +927,7 @@ extern "C" int fga_chain_scan_device(fga_dev *dev, const fga_dkeys *K, const fga
       { std::vector<int64_t> al((size_t) nctg,0);
         for (int64_t i = 0; i < nctg && i < prm->nalen; i++) al[(size_t) i] = prm->alen[i];
         if (hipMemcpyAsync(dalen,al.data(),sizeof(int64_t)*(size_t) nctg,hipMemcpyHostToDevice,dev->stream) != hipSuccess ||
-            hipMemsetAsync(A.ctr,0,sizeof(unsigned long long)*8,dev->stream) != hipSuccess ||
+            hipMemsetAsync(A.ctr,0,sizeof(unsigned long long)*CTR_WORDS,dev->stream) != hipSuccess ||
             hipStreamSynchronize(dev->stream) != hipSuccess)
           { fga_set_error("fga_chain_scan_device: upload failed");
             goto fail;
@@ -945,7 +948,7 @@ extern "C" int fga_chain_scan_device(fga_dev *dev, const fga_dkeys *K, const fga
         { fga_set_error("fga_chain_scan_device: small-unit kernel failed: %s",hipGetErrorString(hipGetLastError()));
           goto fail;
         }
-      dev->chain_density = (double) hc[1] / (double) n;
+      dev->chain_density = (double) hc[CTR_UNITS] / (double) n;
       if ((int64_t) hc[2] > big_cap)
         { fga_set_error("fga_chain_scan_device: internal error, long-unit queue overflow");
           goto fail;
@@ -991,8 +994,8 @@ extern "C" int fga_chain_scan_device(fga_dev *dev, const fga_dkeys *K, const fga
           goto fail;
         }
       hipEventElapsedTime(&dev->last_ms[FGA_STAGE_CHAIN],dev->ev0,dev->ev1);
-      if ((int64_t) hc[0] <= hit_cap && (int64_t) hc[1] <= unit_cap && (int64_t) hc[5] <= stage_cap)
-        { const int64_t nh = (int64_t) hc[0], nu = (int64_t) hc[1];
+      if ((int64_t) hc[0] <= hit_cap && (int64_t) hc[CTR_UNITS] <= unit_cap && (int64_t) hc[5] <= stage_cap)
+        { const int64_t nh = (int64_t) hc[0], nu = (int64_t) hc[CTR_UNITS];
           const double tq0 = fga_wall();
           hh = (fga_hit *)  malloc(sizeof(fga_hit)*(size_t) (nh+1));
           hu = (fga_unit *) malloc(sizeof(fga_unit)*(size_t) (nu+1));
@@ -1049,7 +1052,7 @@ extern "C" int fga_chain_scan_device(fga_dev *dev, const fga_dkeys *K, const fga
       if ((int64_t) hc[5] > stage_cap)
         hit_cap = unit_cap = stage_cap = n + 16;
       else
-        { hit_cap = (int64_t) hc[0] + 16; unit_cap = (int64_t) hc[1] + 16; }
+        { hit_cap = (int64_t) hc[0] + 16; unit_cap = (int64_t) hc[CTR_UNITS] + 16; }
       fga_dev_release(dev,SLOT_HIST,hbuf); fga_dev_release(dev,SLOT_TILES,ubuf);
       fga_dev_release(dev,SLOT_MISC,bbuf); fga_dev_release(dev,stage_slot,sbuf);
       hbuf = ubuf = bbuf = sbuf = NULL;
