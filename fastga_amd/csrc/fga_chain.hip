@@ -861,21 +861,64 @@ void chain_stitch_kernel(chain_args G, big_args B, int64_t nbig)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// host side
+// canonical order on the device: units by the index of their first record (the reference's order), hits re-laid in
+// unit order -- a key per unit, the LSD sort of fga_sort.hip on the index bits, a scan of the hit counts, a gather.
+// (Round 3 downloaded units and hits as the kernels left them and ordered them on the host team: 19 + 20 ms per part
+// for the 1.9 M units of a 3 Gbp part, 6 + 7 ms for the 1.0 M of the 150 Mbp self comparison.)
 // ---------------------------------------------------------------------------------------------------
-struct relay_ctx { const fga_unit *hu; const fga_hit *hh; const int64_t *ord, *pos; fga_hits *R; };
+__global__ void unit_key_kernel(const int64_t *head, int64_t nu, uint4 *rec)
+{ const int64_t i = (int64_t) blockIdx.x*blockDim.x + threadIdx.x;
+  if (i >= nu) return;
+  const uint64_t h = (uint64_t) head[i];
+  rec[i] = make_uint4((uint32_t) i,(uint32_t) h,(uint32_t) (h >> 32),0u);          // sorted on bits 32.. : the head index
+}
 
-static void relay_slice(void *arg, int id, int64_t b, int64_t e)
-{ relay_ctx *C = (relay_ctx *) arg;
-  (void) id;
-  for (int64_t i = b; i < e; i++)
-    { fga_unit u = C->hu[C->ord[i]];
-      memcpy(C->R->hits + C->pos[i],C->hh + u.first_hit,sizeof(fga_hit)*(size_t) u.nhits);
-      u.first_hit = C->pos[i];
-      C->R->units[i] = u;
+__global__ void unit_count_kernel(const uint4 *rec, const fga_unit *units, int64_t nu, int32_t *cnt)
+{ const int64_t j = (int64_t) blockIdx.x*blockDim.x + threadIdx.x;
+  if (j < nu)
+    cnt[j] = units[rec[j].x].nhits;
+}
+
+// exclusive prefix of n 32-bit counts into 64-bit offsets.  One workgroup of 1024.
+__global__ void __launch_bounds__(1024) unit_scan_kernel(const int32_t *cnt, int64_t *out, int64_t n)
+{ __shared__ int64_t part[1024];
+  const int t = threadIdx.x;
+  const int64_t per = (n + 1023) / 1024;
+  const int64_t lo = t*per < n ? t*per : n, hi = lo+per < n ? lo+per : n;
+  int64_t s = 0;
+  for (int64_t i = lo; i < hi; i++)
+    s += cnt[i];
+  part[t] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1)
+    { const int64_t v = t >= o ? part[t-o] : 0;
+      __syncthreads();
+      part[t] += v;
+      __syncthreads();
+    }
+  s = t > 0 ? part[t-1] : 0;
+  for (int64_t i = lo; i < hi; i++)
+    { out[i] = s;
+      s += cnt[i];
     }
 }
 
+__global__ void unit_relay_kernel(const uint4 *rec, const fga_unit *units, const fga_hit *hits, const int64_t *pos,
+                                  int64_t nu, fga_unit *ounits, fga_hit *ohits)
+{ const int64_t j = (int64_t) blockIdx.x*blockDim.x + threadIdx.x;
+  if (j >= nu) return;
+  fga_unit u = units[rec[j].x];
+  const fga_hit *src = hits + u.first_hit;
+  fga_hit *dst = ohits + pos[j];
+  for (int q = 0; q < u.nhits; q++)
+    dst[q] = src[q];
+  u.first_hit = pos[j];
+  ounits[j] = u;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
 extern "C" int fga_chain_scan_device(fga_dev *dev, const fga_dkeys *K, const fga_chain_params *prm, fga_hits **out)
 { *out = NULL;
   FGA_HIP(hipSetDevice(dev->device));
@@ -899,12 +942,11 @@ extern "C" int fga_chain_scan_device(fga_dev *dev, const fga_dkeys *K, const fga
   const int stage_slot = (K->slot == SLOT_SORT0) ? SLOT_SORT1 : SLOT_SORT0;     // the sort's idle ping-pong buffer
   int64_t *dalen = NULL;
   unsigned long long hc[CTR_WORDS];
-  fga_hit *hh = NULL; fga_unit *hu = NULL; int64_t *hd = NULL;
 
   for (int attempt = 0; attempt < 2; attempt++)
     { const size_t ubytes = sizeof(fga_unit)*(size_t) unit_cap + sizeof(int64_t)*(size_t) unit_cap
                           + sizeof(int64_t)*(size_t) big_cap + sizeof(int64_t)*(size_t) nctg + sizeof(unsigned long long)*CTR_WORDS + 128;
-      hbuf = fga_dev_acquire(dev,SLOT_HIST,sizeof(fga_hit)*(size_t) hit_cap);
+      hbuf = fga_dev_acquire(dev,SLOT_ALNS,sizeof(fga_hit)*(size_t) hit_cap);     // (SLOT_HIST: the unit sort's histograms)
       ubuf = fga_dev_acquire(dev,SLOT_TILES,ubytes);
       if (hbuf == NULL || ubuf == NULL)
         { fga_set_error("fga_chain_scan_device: out of device memory");
@@ -997,53 +1039,53 @@ extern "C" int fga_chain_scan_device(fga_dev *dev, const fga_dkeys *K, const fga
       if ((int64_t) hc[0] <= hit_cap && (int64_t) hc[CTR_UNITS] <= unit_cap && (int64_t) hc[5] <= stage_cap)
         { const int64_t nh = (int64_t) hc[0], nu = (int64_t) hc[CTR_UNITS];
           const double tq0 = fga_wall();
-          hh = (fga_hit *)  malloc(sizeof(fga_hit)*(size_t) (nh+1));
-          hu = (fga_unit *) malloc(sizeof(fga_unit)*(size_t) (nu+1));
-          hd = (int64_t *)  malloc(sizeof(int64_t)*(size_t) (nu+1));
-          if (hh == NULL || hu == NULL || hd == NULL)
-            { fga_set_error("out of memory");
-              goto fail;
+          double tq1;
+          uint4 *r0 = NULL, *r1 = NULL, *rs = NULL;
+          int32_t *dcnt = NULL; int64_t *dpos = NULL;
+          fga_unit *ou = NULL; fga_hit *oh = NULL;
+          bool bad = false;
+          R = (fga_hits *) calloc(1,sizeof(fga_hits));
+          if (R != NULL)
+            { R->nhits = nh; R->nunits = nu;
+              R->hits  = (fga_hit *)  malloc(sizeof(fga_hit)*(size_t) (nh+1));
+              R->units = (fga_unit *) malloc(sizeof(fga_unit)*(size_t) (nu+1));
             }
-          if ((nh > 0 && hipMemcpy(hh,A.hits,sizeof(fga_hit)*(size_t) nh,hipMemcpyDeviceToHost) != hipSuccess) ||
-              (nu > 0 && (hipMemcpy(hu,A.units,sizeof(fga_unit)*(size_t) nu,hipMemcpyDeviceToHost) != hipSuccess ||
-                          hipMemcpy(hd,A.unit_head,sizeof(int64_t)*(size_t) nu,hipMemcpyDeviceToHost) != hipSuccess)))
-            { fga_set_error("fga_chain_scan_device: download failed");
-              goto fail;
+          if (R == NULL || R->hits == NULL || R->units == NULL)
+            { fga_hits_free(R); R = NULL; fga_set_error("out of memory"); goto fail; }
+          if (nu > 0)
+            { int bits = 1;
+              while (bits < 63 && ((int64_t) 1 << bits) <= n) bits += 1;      // first-record indices are distinct, in [0,n)
+              const unsigned gb = (unsigned) ((nu + 255) / 256);
+              if (fga_dmalloc(&r0,sizeof(uint4)*(size_t) nu) != hipSuccess || fga_dmalloc(&r1,sizeof(uint4)*(size_t) nu) != hipSuccess ||
+                  fga_dmalloc(&dcnt,sizeof(int32_t)*(size_t) nu) != hipSuccess || fga_dmalloc(&dpos,sizeof(int64_t)*(size_t) nu) != hipSuccess ||
+                  fga_dmalloc(&ou,sizeof(fga_unit)*(size_t) nu) != hipSuccess || fga_dmalloc(&oh,sizeof(fga_hit)*(size_t) (nh+1)) != hipSuccess)
+                bad = true;
+              if (!bad)
+                { hipLaunchKernelGGL(unit_key_kernel,dim3(gb),dim3(256),0,dev->stream,(const int64_t *) A.unit_head,nu,r0);
+                  if (fga_radix_sort_u128(dev,r0,r1,nu,32,bits,&rs))
+                    bad = true;
+                }
+              if (!bad)
+                { hipLaunchKernelGGL(unit_count_kernel,dim3(gb),dim3(256),0,dev->stream,(const uint4 *) rs,(const fga_unit *) A.units,nu,dcnt);
+                  hipLaunchKernelGGL(unit_scan_kernel,dim3(1),dim3(1024),0,dev->stream,(const int32_t *) dcnt,dpos,nu);
+                  hipLaunchKernelGGL(unit_relay_kernel,dim3(gb),dim3(256),0,dev->stream,(const uint4 *) rs,(const fga_unit *) A.units,
+                                     (const fga_hit *) A.hits,(const int64_t *) dpos,nu,ou,oh);
+                  if ((nh > 0 && hipMemcpyAsync(R->hits,oh,sizeof(fga_hit)*(size_t) nh,hipMemcpyDeviceToHost,dev->stream) != hipSuccess) ||
+                      hipMemcpyAsync(R->units,ou,sizeof(fga_unit)*(size_t) nu,hipMemcpyDeviceToHost,dev->stream) != hipSuccess ||
+                      hipStreamSynchronize(dev->stream) != hipSuccess || hipGetLastError() != hipSuccess)
+                    bad = true;
+                }
+              fga_pool_free(r0); fga_pool_free(r1); fga_pool_free(dcnt); fga_pool_free(dpos); fga_pool_free(ou); fga_pool_free(oh);
+              if (bad)
+                { fga_hits_free(R); R = NULL;
+                  fga_set_error("fga_chain_scan_device: ordering the units on the device failed");
+                  goto fail;
+                }
             }
-          const double tq1 = fga_wall();
-          double tq2 = 0.;
-          // canonical order: units by the index of their first record, hits re-laid in unit order (on the host team:
-          // 10^6 units in the repeat-heavy shapes)
-          { fga_team *team = fga_team_open(nu < 50000 ? 1 : (dev->host_threads > 0 ? dev->host_threads : 1));
-            int64_t *ord = (int64_t *) malloc(sizeof(int64_t)*(size_t) (nu+1));
-            int64_t *pos = (int64_t *) malloc(sizeof(int64_t)*(size_t) (nu+1));
-            R = (fga_hits *) calloc(1,sizeof(fga_hits));
-            if (R != NULL)
-              { R->nhits = nh; R->nunits = nu;
-                R->hits  = (fga_hit *)  malloc(sizeof(fga_hit)*(size_t) (nh+1));
-                R->units = (fga_unit *) malloc(sizeof(fga_unit)*(size_t) (nu+1));
-              }
-            int bits = 1;
-            while (bits < 63 && ((int64_t) 1 << bits) <= n) bits += 1;      // first-record indices are distinct, in [0,n)
-            for (int64_t i = 0; i < nu; i++) ord[i] = i;
-            if (team == NULL || ord == NULL || pos == NULL || R == NULL || R->hits == NULL || R->units == NULL ||
-                fga_team_sort_pairs(team,(uint64_t *) hd,ord,nu,bits))
-              { fga_team_close(team); free(ord); free(pos);
-                fga_hits_free(R); R = NULL; fga_set_error("out of memory"); goto fail;
-              }
-            tq2 = fga_wall();
-            int64_t at = 0;
-            for (int64_t i = 0; i < nu; i++)
-              { pos[i] = at; at += hu[ord[i]].nhits; }
-            relay_ctx RC;
-            RC.hu = hu; RC.hh = hh; RC.ord = ord; RC.pos = pos; RC.R = R;
-            fga_team_run(team,nu,relay_slice,&RC);
-            fga_team_close(team); free(ord); free(pos);
-          }
+          tq1 = fga_wall();
           if (getenv("FGA_HOST_TIMING") != NULL)
-            fprintf(stderr,"chain timing: kernels %.1f ms; host: download of %lld hits / %lld units %.1f ms, unit order %.1f ms, "
-                           "re-lay %.1f ms\n",dev->last_ms[FGA_STAGE_CHAIN],(long long) nh,(long long) nu,1e3*(tq1-tq0),
-                    1e3*(tq2-tq1),1e3*(fga_wall()-tq2));
+            fprintf(stderr,"chain timing: kernels %.1f ms; %lld hits / %lld units ordered on the device and downloaded in %.1f ms\n",
+                    dev->last_ms[FGA_STAGE_CHAIN],(long long) nh,(long long) nu,1e3*(tq1-tq0));
           status = 0;
           break;
         }
@@ -1053,7 +1095,7 @@ extern "C" int fga_chain_scan_device(fga_dev *dev, const fga_dkeys *K, const fga
         hit_cap = unit_cap = stage_cap = n + 16;
       else
         { hit_cap = (int64_t) hc[0] + 16; unit_cap = (int64_t) hc[CTR_UNITS] + 16; }
-      fga_dev_release(dev,SLOT_HIST,hbuf); fga_dev_release(dev,SLOT_TILES,ubuf);
+      fga_dev_release(dev,SLOT_ALNS,hbuf); fga_dev_release(dev,SLOT_TILES,ubuf);
       fga_dev_release(dev,SLOT_MISC,bbuf); fga_dev_release(dev,stage_slot,sbuf);
       hbuf = ubuf = bbuf = sbuf = NULL;
     }
@@ -1061,9 +1103,8 @@ extern "C" int fga_chain_scan_device(fga_dev *dev, const fga_dkeys *K, const fga
     fga_set_error("fga_chain_scan_device: output capacity could not be settled");
 
 fail:
-  fga_dev_release(dev,SLOT_HIST,hbuf); fga_dev_release(dev,SLOT_TILES,ubuf);
+  fga_dev_release(dev,SLOT_ALNS,hbuf); fga_dev_release(dev,SLOT_TILES,ubuf);
   fga_dev_release(dev,SLOT_MISC,bbuf); fga_dev_release(dev,stage_slot,sbuf);
-  free(hh); free(hu); free(hd);
   if (status == 0)
     *out = R;
   return status;

@@ -1,18 +1,8 @@
 #!/bin/bash
-# chain scan with the two hot counters on separate cache lines: parity, the throughput shape, and 3 Gbp per workgroup size
+# chain scan with units ordered and hits re-laid on the device: parity, the throughput shape, the bench pair, 3 Gbp
 root=${GRAFT_REPO_ROOT:-/root/repo}
 cd $root
-timeout 600 python -m pytest tests/test_chain_gpu.py -x -q 2>&1 | tail -2
-for b in 512 1024; do
-  FGA_CHAIN_BLOCK=$b FGA_HOST_TIMING=1 timeout 300 python tools/scale_check.py --mbp 150 --self 2>&1 | grep "chain timing" | tail -1 | cut -c1-60
-done
-python -c "
-import sys; sys.path.insert(0,'.')
-from fastga_amd import workload
-import tempfile,os
-d='/tmp/c4'; os.makedirs(d,exist_ok=True)
-" 
-for b in 512 1024; do
-  echo "3 Gbp, block $b"
-  FGA_CHAIN_BLOCK=$b FGA_HOST_TIMING=1 timeout 400 python tools/config4_check.py --mbp 3000 --div 0.01 --no-digest --workdir /tmp/c4 --keep 2>&1 | grep "chain timing\|session_run\|stages" | cut -c1-200
-done
+timeout 900 python -m pytest tests/test_chain_gpu.py tests/test_end_to_end_gpu.py tests/test_edge_cases_gpu.py tests/test_parts_gpu.py -x -q 2>&1 | tail -2
+FGA_HOST_TIMING=1 timeout 300 python tools/scale_check.py --mbp 150 --self 2>&1 | grep "chain timing\|run 1\|stages" | tail -3 | cut -c1-230
+FGA_HOST_TIMING=1 timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu --no-cold --no-human-scale 2>&1 | grep "chain timing" | tail -1 | cut -c1-200
+FGA_HOST_TIMING=1 timeout 400 python tools/config4_check.py --mbp 3000 --div 0.01 --no-digest 2>&1 | grep "chain timing\|session_run\|stages" | cut -c1-230
