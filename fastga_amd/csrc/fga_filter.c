@@ -260,14 +260,16 @@ int fga_filter_alignments(const fga_alns *in, fga_alns **out)
 /* the O(n) passes of the driver, one slice per thread */
 typedef struct
   { const fga_alns *in;
-    fga_aln   *sorted;
+    const fga_aln *sorted;
     rec       *recs, **perm, **live;
     uint64_t  *skey;
     int64_t   *sval;
     int        sb;                       /* bits of the seq field in the discovery key */
     fga_alns  *R;
     int64_t   *off;                      /* trace offset of every surviving record */
-    int        final_minor;              /* final order: keys of the minor part (bread, comp) / the major part */
+    int64_t   *segbeg, *segout;          /* segments of perm; first survivor slot of every segment (nseg+1) */
+    int32_t   *abp;                      /* abpos of the survivors, beside live */
+    int64_t    tsum[65];                 /* trace bytes of the slices before a thread's slice of the survivors */
   } pass_ctx;
 
 static void pass_discovery_keys(void *arg, int id, int64_t b, int64_t e)
@@ -294,40 +296,231 @@ static void pass_records(void *arg, int id, int64_t b, int64_t e)
     }
 }
 
-static void pass_final_keys(void *arg, int id, int64_t b, int64_t e)
+/* survivors of every segment: counted, then laid out segment by segment (slices of SEGMENTS) */
+static void pass_count_live(void *arg, int id, int64_t b, int64_t e)
 { pass_ctx *C = arg;
-  int64_t i;
+  int64_t s, i;
   (void) id;
-  for (i = b; i < e; i++)
-    { if (C->final_minor)
-        C->skey[i] = ((uint64_t) (uint32_t) C->live[i]->bread << 1) | (C->live[i]->flags & 1);
-      else
-        C->skey[i] = ((uint64_t) (uint32_t) C->live[i]->aread << 32) | (uint32_t) C->live[i]->abpos;
-      C->sval[i] = i;
+  for (s = b; s < e; s++)
+    { int64_t c = 0;
+      for (i = C->segbeg[s]; i < C->segbeg[s+1]; i++)
+        c += !(C->perm[i]->flags & ELIMINATED);
+      C->segout[s] = c;
     }
 }
 
-static void pass_final_gather(void *arg, int id, int64_t b, int64_t e)
+static void pass_fill_live(void *arg, int id, int64_t b, int64_t e)
 { pass_ctx *C = arg;
-  int64_t i;
+  int64_t s, i;
   (void) id;
+  for (s = b; s < e; s++)
+    { int64_t o = C->segout[s];
+      for (i = C->segbeg[s]; i < C->segbeg[s+1]; i++)
+        if (!(C->perm[i]->flags & ELIMINATED))
+          { C->perm[i]->ord = o;                 /* order of survival = the reference's file order */
+            C->abp[o] = C->perm[i]->abpos;
+            C->live[o++] = C->perm[i];
+          }
+    }
+}
+
+static void pass_trace_sums(void *arg, int id, int64_t b, int64_t e)
+{ pass_ctx *C = arg;
+  int64_t i, t = 0;
   for (i = b; i < e; i++)
-    C->perm[i] = C->live[C->sval[i]];
+    t += C->live[i]->tlen;
+  C->tsum[id+1] = t;
 }
 
 static void pass_copy_out(void *arg, int id, int64_t b, int64_t e)
 { pass_ctx *C = arg;
-  int64_t i;
-  (void) id;
+  int64_t i, off = C->tsum[id];
   for (i = b; i < e; i++)
     { rec *r = C->live[i];
       fga_aln *a = C->R->alns+i;
       memset(a,0,sizeof(*a));
       a->tlen = r->tlen; a->diffs = r->diffs; a->abpos = r->abpos; a->bbpos = r->bbpos;
       a->aepos = r->aepos; a->bepos = r->bepos; a->flags = r->flags & 0x3; a->aread = r->aread; a->bread = r->bread;
-      a->unit = -1; a->seq = (int32_t) i; a->toff = C->off[i];
-      memcpy(C->R->tbytes + C->off[i],r->trace,r->tlen);
+      a->unit = -1; a->seq = (int32_t) i; a->toff = off;
+      memcpy(C->R->tbytes + off,r->trace,r->tlen);
+      off += r->tlen;
     }
+}
+
+
+/* ---- final order by merging --------------------------------------------------------------------------------------
+ * The survivors of a segment -- one (aread, bread, comp) -- leave the filter in (abpos, survival) order, so the final
+ * order (aread, abpos, bread, comp, survival) of an A contig is the MERGE of its segments' lists by (abpos, bread, comp):
+ * O(n log k) comparisons on 8-byte pointers instead of two radix sorts over 16-byte pairs with their key builds and
+ * gathers (at 2 M records of a 3 Gbp part: 2 x 70 ms of the 260 the last part's filter adds to the run).  A contig's
+ * merge is cut by abpos splitters (sampled from its lists) into tasks of similar size; threads take tasks from a counter. */
+typedef struct
+  { int64_t beg, end;        /* the segment's survivors: live[beg,end) */
+    int32_t aread, key2;     /* key2 = bread << 1 | comp */
+  } seg_list;
+
+typedef struct
+  { int64_t l0, l1;          /* lists [l0,l1) of `lists` (one A contig) */
+    int32_t lo, hi;          /* abpos range [lo,hi) */
+    int64_t out;             /* first output position */
+  } merge_task;
+
+typedef struct
+  { rec        **live, **out;
+    const int32_t *abp;      /* abpos of live[i] */
+    seg_list    *lists;
+    merge_task  *task;
+    int64_t      ntask, next;
+    int          failed;
+  } merge_ctx;
+
+static int by_aread_key2(const void *l, const void *r)
+{ const seg_list *a = l, *b = r;
+  if (a->aread != b->aread) return a->aread < b->aread ? -1 : 1;
+  if (a->key2 != b->key2) return a->key2 < b->key2 ? -1 : 1;
+  return a->beg < b->beg ? -1 : (a->beg > b->beg);
+}
+
+static int by_int32(const void *l, const void *r)
+{ const int32_t a = *(const int32_t *) l, b = *(const int32_t *) r;
+  return a < b ? -1 : (a > b);
+}
+
+static inline int64_t first_at_or_after(const int32_t *abp, int64_t b, int64_t e, int32_t x)     /* first i in [b,e) with abpos >= x */
+{ while (b < e)
+    { const int64_t m = b + ((e-b) >> 1);
+      if (abp[m] < x) b = m+1; else e = m;
+    }
+  return b;
+}
+
+typedef struct { int32_t abpos, key2; int64_t at, end; } heap_item;       /* `at` also orders lists of one key (there is one) */
+
+static inline int heap_less(const heap_item *a, const heap_item *b)
+{ if (a->abpos != b->abpos) return a->abpos < b->abpos;
+  if (a->key2 != b->key2) return a->key2 < b->key2;
+  return a->at < b->at;
+}
+
+static void heap_down(heap_item *h, int n, int i)
+{ const heap_item x = h[i];
+  for (;;)
+    { int c = 2*i+1;
+      if (c >= n) break;
+      if (c+1 < n && heap_less(h+c+1,h+c)) c += 1;
+      if (!heap_less(h+c,&x)) break;
+      h[i] = h[c];
+      i = c;
+    }
+  h[i] = x;
+}
+
+static void merge_tasks(void *arg, int id, int64_t b0, int64_t e0)
+{ merge_ctx *M = arg;
+  heap_item *h = NULL;
+  int64_t hcap = 0;
+  (void) id; (void) b0; (void) e0;
+  for (;;)
+    { const int64_t t = __sync_fetch_and_add(&M->next,1);
+      const merge_task *T;
+      int64_t l, o;
+      int n = 0, i;
+      if (t >= M->ntask)
+        break;
+      T = M->task+t;
+      if (T->l1-T->l0 > hcap)
+        { hcap = 2*(T->l1-T->l0) + 64;
+          free(h);
+          h = malloc(sizeof(heap_item)*hcap);
+          if (h == NULL) { M->failed = 1; break; }
+        }
+      for (l = T->l0; l < T->l1; l++)
+        { const seg_list *S = M->lists+l;
+          const int64_t b = first_at_or_after(M->abp,S->beg,S->end,T->lo);
+          const int64_t e = T->hi == 0x7fffffff ? S->end : first_at_or_after(M->abp,b,S->end,T->hi);
+          if (b < e)
+            { h[n].abpos = M->abp[b]; h[n].key2 = S->key2; h[n].at = b; h[n].end = e; n += 1; }
+        }
+      o = T->out;
+      if (n == 1)
+        { memcpy(M->out+o,M->live+h[0].at,sizeof(rec *)*(h[0].end-h[0].at));
+          continue;
+        }
+      for (i = n/2-1; i >= 0; i--)
+        heap_down(h,n,i);
+      while (n > 0)
+        { M->out[o++] = M->live[h[0].at];
+          if (++h[0].at < h[0].end)
+            h[0].abpos = M->abp[h[0].at];
+          else
+            h[0] = h[--n];
+          if (n > 1)
+            heap_down(h,n,0);
+        }
+    }
+  free(h);
+}
+
+/* live[0,nlive) segment by segment (lists[0,nlist): every list in (abpos, survival) order) -> out in the final order.
+ * Returns 0, or 1 when out of memory. */
+static int final_order_by_merge(fga_team *team, rec **live, const int32_t *abp, rec **out, int64_t nlive, seg_list *lists,
+                                int64_t nlist)
+{ merge_ctx   M;
+  merge_task *task = NULL;
+  int32_t    *sample = NULL;
+  int64_t     ntask = 0, tcap, g0, g1, base = 0, chunk, l;
+  const int   nthr = fga_team_size(team);
+
+  qsort(lists,nlist,sizeof(seg_list),by_aread_key2);
+  chunk = nlive/(8*(int64_t) nthr);
+  if (chunk < 8192) chunk = 8192;
+  { const char *ev = getenv("FGA_FILTER_CHUNK");       /* test hook: records per merge task */
+    if (ev != NULL && atoll(ev) > 0) chunk = atoll(ev);
+  }
+  tcap = 2*nlist + nlive/chunk + 16;
+  task = malloc(sizeof(merge_task)*tcap);
+  if (task == NULL) return 1;
+  for (g0 = 0; g0 < nlist; g0 = g1)
+    { int64_t m = 0, parts, k;
+      for (g1 = g0; g1 < nlist && lists[g1].aread == lists[g0].aread; g1++)
+        m += lists[g1].end-lists[g1].beg;
+      parts = (m + chunk - 1)/chunk;
+      if (parts <= 1)
+        { task[ntask].l0 = g0; task[ntask].l1 = g1; task[ntask].lo = -0x7fffffff-1; task[ntask].hi = 0x7fffffff;
+          task[ntask].out = base; ntask += 1;
+        }
+      else
+        { /* splitters: every step-th abpos of every list, sorted, at equal ranks */
+          const int64_t step = m/(parts*64) > 0 ? m/(parts*64) : 1;
+          int64_t ns = 0, scap = m/step + (g1-g0) + 16;
+          int32_t lo = -0x7fffffff-1;
+          int32_t *sm = realloc(sample,sizeof(int32_t)*scap);
+          if (sm == NULL) { free(sample); free(task); return 1; }
+          sample = sm;
+          for (l = g0; l < g1; l++)
+            for (k = lists[l].beg + step/2; k < lists[l].end; k += step)
+              sample[ns++] = abp[k];
+          qsort(sample,ns,sizeof(int32_t),by_int32);
+          for (k = 1; k <= parts; k++)
+            { const int32_t hi = (k == parts || ns == 0) ? 0x7fffffff : sample[(ns*k)/parts < ns ? (ns*k)/parts : ns-1];
+              int64_t off = 0;
+              if (hi <= lo && k < parts)
+                continue;                                   /* equal splitters: the range is empty */
+              for (l = g0; l < g1; l++)
+                off += first_at_or_after(abp,lists[l].beg,lists[l].end,lo) - lists[l].beg;
+              task[ntask].l0 = g0; task[ntask].l1 = g1; task[ntask].lo = lo; task[ntask].hi = hi;
+              task[ntask].out = base + off; ntask += 1;
+              lo = hi;
+              if (hi == 0x7fffffff)
+                break;
+            }
+        }
+      base += m;
+    }
+  M.live = live; M.abp = abp; M.out = out; M.lists = lists; M.task = task; M.ntask = ntask; M.next = 0; M.failed = 0;
+  fga_team_run(team,nthr,merge_tasks,&M);
+  free(task); free(sample);
+  return M.failed;
 }
 
 int fga_filter_alignments_mt(const fga_alns *in, int nthreads, fga_alns **out)
@@ -336,7 +529,10 @@ int fga_filter_alignments_mt(const fga_alns *in, int nthreads, fga_alns **out)
   rec      *recs = NULL, **perm = NULL, **live = NULL;
   uint64_t *skey = NULL;
   int64_t  *sval = NULL, *segbeg = NULL;
-  int64_t   n = in->naln, i, j, nlive = 0, tbytes = 0, nseg = 0;
+  seg_list *lists = NULL;
+  int64_t  *segout = NULL;
+  int32_t  *abp = NULL;
+  int64_t   n = in->naln, i, j, nlive = 0, tbytes = 0, nseg = 0, nlist = 0;
   fga_team *team = NULL;
   pass_ctx  C;
 
@@ -366,15 +562,20 @@ int fga_filter_alignments_mt(const fga_alns *in, int nthreads, fga_alns **out)
 
   /* discovery order = (unit, seq): radix sort when the two fit a 64-bit key, else the comparison sort */
   { int64_t maxu = 0, maxs = 0;
-    int ub = 1, sb = 1, ok = 1;
+    int ub = 1, sb = 1, ok = 1, inorder = 1;
     for (i = 0; i < n; i++)
       { if (in->alns[i].unit < 0 || in->alns[i].seq < 0) { ok = 0; break; }
         if (in->alns[i].unit > maxu) maxu = in->alns[i].unit;
         if (in->alns[i].seq > maxs) maxs = in->alns[i].seq;
+        if (i > 0 && (in->alns[i].unit < in->alns[i-1].unit ||
+                      (in->alns[i].unit == in->alns[i-1].unit && in->alns[i].seq < in->alns[i-1].seq)))
+          inorder = 0;
       }
     while (((int64_t) 1 << ub) <= maxu) ub += 1;
     while (((int64_t) 1 << sb) <= maxs) sb += 1;
-    if (ok && ub + sb <= 64)
+    if (ok && inorder)                      /* fga_extend hands its records over in discovery order (sorted on the device) */
+      C.sorted = in->alns;
+    else if (ok && ub + sb <= 64)
       { C.sb = sb;
         fga_team_run(team,n,pass_discovery_keys,&C);
         if (fga_team_sort_pairs(team,skey,sval,n,ub+sb)) goto oom;
@@ -401,50 +602,49 @@ int fga_filter_alignments_mt(const fga_alns *in, int nthreads, fga_alns **out)
   tw[2] = fga_wall();
   if (run_segments(perm,segbeg,nseg,fga_team_size(team) > 1 ? nthreads : 1)) goto oom;
   tw[3] = fga_wall();
-  for (i = 0; i < n; i++)
-    if (!(perm[i]->flags & ELIMINATED))
-      { perm[i]->ord = nlive;                 /* order of survival = the reference's file order */
-        live[nlive++] = perm[i];
-      }
-
-  /* final order (aread, abpos, bread, comp, survival): two stable radix sorts, least significant part first -- (bread,
-   * comp) over the records in survival order, then (aread, abpos).  Repeats give many records the same (aread, abpos),
-   * so no comparison sort of tie runs */
-  if (nlive > 1)
-    { int32_t maxa = 0, maxb = 0;
-      int ab = 1, bb = 1;
-      for (i = 0; i < nlive; i++)
-        { if (live[i]->aread > maxa) maxa = live[i]->aread;
-          if (live[i]->bread > maxb) maxb = live[i]->bread;
+  lists  = malloc(sizeof(seg_list)*(nseg > 0 ? nseg : 1));
+  segout = malloc(sizeof(int64_t)*(nseg+1));
+  abp    = malloc(sizeof(int32_t)*(n > 0 ? n : 1));
+  if (lists == NULL || segout == NULL || abp == NULL) goto oom;
+  C.segbeg = segbeg; C.segout = segout; C.abp = abp;
+  fga_team_run(team,nseg,pass_count_live,&C);
+  for (j = 0; j < nseg; j++)
+    { const int64_t c = segout[j];
+      segout[j] = nlive;
+      if (c > 0)
+        { lists[nlist].beg = nlive; lists[nlist].end = nlive+c;
+          nlist += 1;
         }
-      while (ab < 32 && ((int64_t) 1 << ab) <= maxa) ab += 1;
-      while (bb < 32 && ((int64_t) 1 << bb) <= maxb) bb += 1;
-      C.final_minor = 1;
-      fga_team_run(team,nlive,pass_final_keys,&C);
-      if (fga_team_sort_pairs(team,skey,sval,nlive,bb+1)) goto oom;
-      fga_team_run(team,nlive,pass_final_gather,&C);            /* perm = live in (bread, comp, survival) order */
-      memcpy(live,perm,sizeof(rec *)*nlive);
-      C.final_minor = 0;
-      fga_team_run(team,nlive,pass_final_keys,&C);
-      if (fga_team_sort_pairs(team,skey,sval,nlive,32+ab)) goto oom;
-      fga_team_run(team,nlive,pass_final_gather,&C);
+      nlive += c;
+    }
+  segout[nseg] = nlive;
+  fga_team_run(team,nseg,pass_fill_live,&C);
+  for (j = 0; j < nlist; j++)
+    { const rec *r = live[lists[j].beg];
+      lists[j].aread = r->aread;
+      lists[j].key2 = (int32_t) (((uint32_t) r->bread << 1) | (r->flags & 1));
+    }
+
+  /* final order (aread, abpos, bread, comp, survival): the merge of every A contig's segment lists */
+  if (nlive > 1)
+    { if (final_order_by_merge(team,live,abp,perm,nlive,lists,nlist)) goto oom;
       memcpy(live,perm,sizeof(rec *)*nlive);
     }
 
   tw[4] = fga_wall();
-  for (i = 0; i < nlive; i++)                 /* sval is free again: the trace offsets */
-    { sval[i] = tbytes;
-      tbytes += live[i]->tlen;
-    }
+  C.tsum[0] = 0;
+  fga_team_run(team,nlive,pass_trace_sums,&C);
+  for (j = 0; j < fga_team_size(team); j++)
+    C.tsum[j+1] += C.tsum[j];
+  tbytes = C.tsum[fga_team_size(team)];
   R->naln = nlive; R->ntrace = tbytes;
   R->alns = malloc(sizeof(fga_aln)*(nlive+1));
   R->tbytes = malloc(tbytes+16);
   if (R->alns == NULL || R->tbytes == NULL) goto oom;
-  C.off = sval;
   fga_team_run(team,nlive,pass_copy_out,&C);
   for (i = 0; i < n; i++)
     if (recs[i].owns) free(recs[i].trace);
-  free(sorted); free(recs); free(perm); free(live); free(skey); free(sval); free(segbeg);
+  free(sorted); free(recs); free(perm); free(live); free(skey); free(sval); free(segbeg); free(lists); free(segout); free(abp);
   if (timing)
     fprintf(stderr,"filter timing: %lld records, %lld segments: discovery order %.1f ms, records %.1f ms, segments %.1f ms (%d threads), "
                    "final order %.1f ms, copy out %.1f ms\n",(long long) n,(long long) nseg,1e3*(tw[1]-tw[0]),1e3*(tw[2]-tw[1]),
@@ -455,7 +655,7 @@ int fga_filter_alignments_mt(const fga_alns *in, int nthreads, fga_alns **out)
 
 oom:
   fga_set_error("out of memory in alignment filter");
-  free(sorted); free(recs); free(perm); free(live); free(skey); free(sval); free(segbeg);
+  free(sorted); free(recs); free(perm); free(live); free(skey); free(sval); free(segbeg); free(lists); free(segout); free(abp);
   fga_team_close(team);
   if (R != NULL) { free(R->alns); free(R->tbytes); free(R); }
   return 1;

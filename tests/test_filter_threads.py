@@ -5,11 +5,11 @@ import ctypes as C
 import numpy as np
 
 
-def _random_set(rng, npairs, per_pair):
+def _random_set(rng, npairs, per_pair, nctg=40):
     from fastga_amd.device import ALN_DTYPE
     recs, tb, off, unit = [], [], 0, 0
     for pair in range(npairs):
-        a, b, comp = int(rng.integers(0, 40)), int(rng.integers(0, 40)), int(rng.integers(0, 2))
+        a, b, comp = int(rng.integers(0, nctg)), int(rng.integers(0, 40)), int(rng.integers(0, 2))
         seq = 0
         for _ in range(int(rng.integers(1, per_pair + 1))):
             ab = int(rng.integers(0, 200_000))
@@ -70,3 +70,34 @@ def test_filter_is_thread_and_arrival_order_independent(built_library):
     s1 = _run(L, small, tbs, 1)
     s8 = _run(L, small, tbs, 8)
     assert np.array_equal(s1[0], s8[0]) and np.array_equal(s1[1], s8[1])
+
+
+def test_final_order_merge_does_not_depend_on_its_task_cuts(built_library):
+    """the final order is a merge of every A contig's segment lists, cut by abpos splitters into tasks: two A contigs
+    with ~30 k survivors each, many records on the same (aread, abpos) in different segments -- one task per contig,
+    tasks of 64 records, the default cut and several thread counts must give the same bytes, in sorted order"""
+    import os
+    L = built_library
+    rng = np.random.default_rng(5)
+    alns, tb = _random_set(rng, 12000, 8, nctg=2)
+    alns["abpos"] -= alns["abpos"] % 100                         # ties on abpos across segments
+    alns["aepos"] = np.maximum(alns["aepos"], alns["abpos"] + 100)
+    assert len(alns) > 50000
+    res = []
+    for chunk, nt in ((None, 8), (10**9, 1), (64, 8), (64, 3), (1000, 32)):
+        if chunk is None:
+            os.environ.pop("FGA_FILTER_CHUNK", None)
+        else:
+            os.environ["FGA_FILTER_CHUNK"] = str(chunk)
+        try:
+            res.append(_run(L, alns, tb, nt))
+        finally:
+            os.environ.pop("FGA_FILTER_CHUNK", None)
+    a1, t1 = res[0]
+    assert len(a1) > 20000
+    for a, t in res[1:]:
+        assert np.array_equal(a, a1) and np.array_equal(t, t1)
+    key = list(zip(a1["aread"].tolist(), a1["abpos"].tolist(), a1["bread"].tolist(), (a1["flags"] & 1).tolist()))
+    assert key == sorted(key)
+    ties = sum(1 for x, y in zip(key, key[1:]) if x[:2] == y[:2] and x[2:] != y[2:])
+    assert ties > 1000
