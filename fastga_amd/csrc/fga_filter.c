@@ -681,10 +681,41 @@ static int aln_minor_cmp(const fga_aln *a, const fga_aln *b)
   return 0;
 }
 
+/* a piece of a run that comes from one input: records [x0,x1) of the run to position `at`, trace bytes to `tat` */
+typedef struct { const fga_alns *S; int64_t beg, x0, x1, at, tat; } copy_task;
+typedef struct { copy_task *task; int64_t ntask, next; fga_alns *R; } copy_ctx;
+
+static void copy_tasks(void *arg, int id, int64_t b0, int64_t e0)
+{ copy_ctx *C = arg;
+  (void) id; (void) b0; (void) e0;
+  for (;;)
+    { const int64_t t = __sync_fetch_and_add(&C->next,1);
+      const copy_task *T;
+      const fga_aln *src;
+      int64_t t0, t1, x, at;
+      if (t >= C->ntask)
+        break;
+      T = C->task+t;
+      src = T->S->alns + T->beg;
+      t0 = src[T->x0].toff; t1 = src[T->x1-1].toff + src[T->x1-1].tlen;
+      memcpy(C->R->tbytes + T->tat,T->S->tbytes + t0,(size_t) (t1 - t0));   /* a filtered set's trace bytes are laid out in record order */
+      at = T->at;
+      for (x = T->x0; x < T->x1; x++)
+        { fga_aln a = src[x];
+          a.toff = T->tat + (a.toff - t0); a.seq = (int32_t) at; a.unit = -1;
+          C->R->alns[at++] = a;
+        }
+    }
+}
+
 int fga_alns_merge_filtered(const fga_alns *const *fin, int nfin, fga_alns **out)
+{ return fga_alns_merge_filtered_mt(fin,nfin,1,out); }
+
+int fga_alns_merge_filtered_mt(const fga_alns *const *fin, int nfin, int nthreads, fga_alns **out)
 { fga_alns *R = calloc(1,sizeof(fga_alns));
   arun *runs = NULL;
-  int64_t nrun = 0, caprun = 0, at = 0, tat = 0, i;
+  copy_task *task = NULL;
+  int64_t nrun = 0, caprun = 0, at = 0, tat = 0, i, ntask = 0, captask = 0;
   int k;
   *out = NULL;
   if (R == NULL) goto oom;
@@ -714,18 +745,25 @@ int fga_alns_merge_filtered(const fga_alns *const *fin, int nfin, fga_alns **out
   for (i = 0; i < nrun; )
     { int64_t j = i+1;
       while (j < nrun && runs[j].aread == runs[i].aread) j += 1;
-      if (j == i+1)                                   /* the usual case: the contig's records come from one part */
-        { const fga_alns *S = fin[runs[i].set];
+      if (j == i+1)                                   /* the usual case: the contig's records come from one part: copied */
+        { const fga_alns *S = fin[runs[i].set];        /* in pieces of 64 k records by all threads, below             */
           const fga_aln *src = S->alns + runs[i].beg;
-          const int64_t t0 = src[0].toff, t1 = src[runs[i].cnt-1].toff + src[runs[i].cnt-1].tlen;
-          int64_t x;
-          memcpy(R->tbytes + tat,S->tbytes + t0,(size_t) (t1 - t0));     /* a filtered set's trace bytes are laid out in record order */
-          for (x = 0; x < runs[i].cnt; x++)
-            { fga_aln a = src[x];
-              a.toff = tat + (a.toff - t0); a.seq = (int32_t) at; a.unit = -1;
-              R->alns[at++] = a;
+          int64_t x0;
+          for (x0 = 0; x0 < runs[i].cnt; x0 += 65536)
+            { const int64_t x1 = x0 + 65536 < runs[i].cnt ? x0 + 65536 : runs[i].cnt;
+              if (ntask >= captask)
+                { copy_task *nt;
+                  captask = captask ? 2*captask : 1024;
+                  nt = realloc(task,sizeof(copy_task)*captask);
+                  if (nt == NULL) goto oom;
+                  task = nt;
+                }
+              task[ntask].S = S; task[ntask].beg = runs[i].beg; task[ntask].x0 = x0; task[ntask].x1 = x1;
+              task[ntask].at = at; task[ntask].tat = tat;
+              ntask += 1;
+              at += x1-x0;
+              tat += (src[x1-1].toff + src[x1-1].tlen) - src[x0].toff;
             }
-          tat += t1 - t0;
         }
       else                                            /* several inputs hold records of this contig: merge their runs */
         { int64_t *pos = calloc(j-i,sizeof(int64_t));
@@ -751,13 +789,22 @@ int fga_alns_merge_filtered(const fga_alns *const *fin, int nfin, fga_alns **out
         }
       i = j;
     }
+  if (ntask > 0)
+    { copy_ctx C;
+      fga_team *team = fga_team_open(at < 50000 ? 1 : nthreads);
+      if (team == NULL) goto oom;
+      C.task = task; C.ntask = ntask; C.next = 0; C.R = R;
+      fga_team_run(team,fga_team_size(team),copy_tasks,&C);
+      fga_team_close(team);
+    }
+  free(task); task = NULL;
   R->naln = at; R->ntrace = tat;
   free(runs);
   *out = R;
   return 0;
 oom:
   fga_set_error("out of memory merging filtered alignment sets");
-  free(runs);
+  free(runs); free(task);
   if (R != NULL) { free(R->alns); free(R->tbytes); free(R); }
   return 1;
 }

@@ -109,10 +109,11 @@ int fga_reference_slots(const int64_t *counts, const int64_t *clen, int nctg, in
    inside every run of equal (aread, abpos) the records of the strand with the smaller slot first (stable).
    invp[aread] = length-sorted index of original contig aread.  The trace bytes are laid out in record order again. */
 int fga_alns_reference_order(fga_alns *A, const int *slot, const int *invp, int nctg)
-{ int64_t i, j, k, moved = 0;
+{ int64_t i, j, k, tbcap = 0;
   fga_aln *tmp = NULL;
   uint8_t *tb = NULL;
   int64_t tmpcap = 0;
+  int relay = 0;
   if (A == NULL || slot == NULL || invp == NULL)
     { fga_set_error("fga_alns_reference_order: null argument");
       return 1;
@@ -148,27 +149,53 @@ int fga_alns_reference_order(fga_alns *A, const int *slot, const int *invp, int 
       at = 0;
       for (k = i; k < j; k++) if ((int) (A->alns[k].flags & 1) == first) tmp[at++] = A->alns[k];
       for (k = i; k < j; k++) if ((int) (A->alns[k].flags & 1) != first) tmp[at++] = A->alns[k];
+      /* the run's trace bytes: when they lie in record order (what the filter and fga_alns_merge_filtered produce) they
+         are permuted inside their own byte range; any other layout is re-laid as a whole at the end */
+      { int64_t t0 = A->alns[i].toff, t1 = t0, tat;
+        int packed = 1;
+        for (k = i; k < j; k++)
+          { if (A->alns[k].toff != t1) { packed = 0; break; }
+            t1 += A->alns[k].tlen;
+          }
+        if (packed && !relay)
+          { if (t1-t0 > tbcap)
+              { uint8_t *nb;
+                tbcap = 2*(t1-t0) + 4096;
+                nb = realloc(tb,tbcap);
+                if (nb == NULL) goto oom;
+                tb = nb;
+              }
+            tat = 0;
+            for (k = 0; k < j-i; k++)
+              { memcpy(tb + tat,A->tbytes + tmp[k].toff,(size_t) tmp[k].tlen);
+                tmp[k].toff = t0 + tat;
+                tat += tmp[k].tlen;
+              }
+            memcpy(A->tbytes + t0,tb,(size_t) (t1-t0));
+          }
+        else
+          relay = 1;
+      }
       memcpy(A->alns + i,tmp,sizeof(fga_aln)*(j-i));
-      moved += j-i;
     }
-  if (moved > 0)
+  if (relay)
     { /* trace bytes in record order again (fga_alns_merge_filtered and the writers take runs of them) */
       int64_t tat = 0;
-      tb = malloc(A->ntrace + 16);
-      if (tb == NULL) goto oom;
+      uint8_t *all = malloc(A->ntrace + 16);
+      if (all == NULL) goto oom;
       for (i = 0; i < A->naln; i++)
         { fga_aln *a = A->alns + i;
-          memcpy(tb + tat,A->tbytes + a->toff,(size_t) a->tlen);
+          memcpy(all + tat,A->tbytes + a->toff,(size_t) a->tlen);
           a->toff = tat;
           tat += a->tlen;
         }
       free(A->tbytes);
-      A->tbytes = tb;
+      A->tbytes = all;
       A->ntrace = tat;
     }
   for (i = 0; i < A->naln; i++)
     A->alns[i].seq = (int32_t) i;
-  free(tmp);
+  free(tmp); free(tb);
   return 0;
 oom:
   free(tmp); free(tb);

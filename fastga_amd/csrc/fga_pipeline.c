@@ -612,7 +612,7 @@ int fga_session_finish_filtered(fga_session *Z, const fga_run_params *P, const f
 
   memset(&st,0,sizeof(st));
   t1 = fga_wall();
-  if (fga_alns_merge_filtered(filtered,nsets,&fin)) goto done;
+  if (fga_alns_merge_filtered_mt(filtered,nsets,P->nthreads,&fin)) goto done;
   st.filter_s = fga_wall() - t1;
   if (finish_output(Z,P,fin,&st)) goto done;
   status = 0;

@@ -227,6 +227,7 @@ def _declare(L):
         "fga_dgix_upload_range": (i32, [vp, vp, i64, i64, P(vp)]),
         "fga_dgix_prefix_counts": (i32, [vp, vp, i32, vp]),
         "fga_alns_merge_filtered": (i32, [P(P(Alns)), i32, P(P(Alns))]),
+        "fga_alns_merge_filtered_mt": (i32, [P(P(Alns)), i32, i32, P(P(Alns))]),
         "fga_session_finish_filtered": (i32, [vp, P(RunParams), P(P(Alns)), i32, P(RunStats)]),
         "fga_shim_New_Work_Data": (vp, []),
         "fga_shim_Free_Work_Data": (None, [vp]),

@@ -422,6 +422,7 @@ int  fga_alns_concat(const fga_alns *const *raw, int nraw, fga_alns **out);
 /* filtered sets (outputs of fga_filter_alignments[_mt], one per A-contig part) as one set in final order: their runs per
    A contig laid out by contig -- the reference's la_merge over its per-thread files (FastGA.c:3991-4133); host only */
 int  fga_alns_merge_filtered(const fga_alns *const *filtered, int nsets, fga_alns **out);
+int     fga_alns_merge_filtered_mt(const fga_alns *const *filtered, int nsets, int nthreads, fga_alns **out);   /* the copies on all threads */
 
 /* the same with the inputs kept resident in HBM between passes (what bench.py times) */
 typedef struct fga_session fga_session;

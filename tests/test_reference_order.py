@@ -190,6 +190,16 @@ def test_tie_order_of_the_real_reference(tmp_path_factory, built_library, thread
     for f in fields:
         assert np.array_equal(got[f], recs[f]), (f, threads)
     assert _traces(got, gtb) == _traces(recs, tb)
+    # the same with the trace bytes in record order, as the filter hands them over: permuted inside every moved run's bytes
+    packed = mixed.copy()
+    pieces = _traces(mixed, tb)
+    packed["toff"] = np.concatenate([[0], np.cumsum([len(x) for x in pieces])[:-1]])
+    ptb = np.frombuffer(b"".join(pieces), dtype=np.uint8)
+    got2, gtb2 = _order_with(L, packed, ptb, slot, invp, nctg)
+    for f in fields:
+        assert np.array_equal(got2[f], recs[f]), (f, threads)
+    assert _traces(got2, gtb2) == _traces(recs, tb)
+    assert np.array_equal(got2["toff"], np.concatenate([[0], np.cumsum(got2["tlen"])[:-1]]))
     if threads > 3:
         assert not all(np.array_equal(mixed[f], recs[f]) for f in fields), "every tie was in the filter's order already"
     # idempotent, and a no-op with equal slots

@@ -219,8 +219,8 @@ def test_gathered_parts_filter_like_the_whole_world2(built_library):
 
 # ------------------------------------------------------------------------------------------------ filter per part, merge
 
-def _merge_filtered(L, sets):
-    """fga_alns_merge_filtered over [(records, trace bytes)]"""
+def _merge_filtered(L, sets, nthreads=None):
+    """fga_alns_merge_filtered[_mt] over [(records, trace bytes)]"""
     from fastga_amd.lib import Alns
     from fastga_amd.device import ALN_DTYPE
     keep, ptrs = [], (C.POINTER(Alns) * max(len(sets), 1))()
@@ -230,7 +230,10 @@ def _merge_filtered(L, sets):
         keep.append((a, r, t))
         ptrs[k] = C.pointer(a)
     out = C.POINTER(Alns)()
-    assert L.fga_alns_merge_filtered(ptrs, len(sets), C.byref(out)) == 0
+    if nthreads is None:
+        assert L.fga_alns_merge_filtered(ptrs, len(sets), C.byref(out)) == 0
+    else:
+        assert L.fga_alns_merge_filtered_mt(ptrs, len(sets), nthreads, C.byref(out)) == 0
     o = out.contents
     got = np.frombuffer((C.c_char * (o.naln * ALN_DTYPE.itemsize)).from_address(o.alns), dtype=ALN_DTYPE).copy()
     gt = np.frombuffer((C.c_char * max(o.ntrace, 1)).from_address(o.tbytes), dtype=np.uint8)[:o.ntrace].copy()
@@ -264,6 +267,23 @@ def test_parts_filtered_on_their_own_merge_to_the_filter_of_the_whole(built_libr
         assert np.array_equal(np.sort(m[0][f]), np.sort(exp[0][f]))
     key = m[0]["aread"].astype(np.int64) << 32 | m[0]["abpos"]
     assert np.all(np.diff(key) >= 0)
+
+
+def test_merge_of_filtered_parts_on_all_threads(built_library):
+    """fga_alns_merge_filtered_mt: > 50 k records so that the copies are made by a team, runs longer than a copy task
+    (64 k records), same bytes as on one thread"""
+    from tests.test_filter_threads import _random_set, _run
+    L = built_library
+    rng = np.random.default_rng(3)
+    alns, tb = _random_set(rng, 40000, 8, nctg=3)
+    fa, ft = _run(L, alns, tb, 8)
+    assert len(fa) > 130000
+    sets = [_subset(fa, ft, fa["aread"] == c) for c in (2, 0, 1)]
+    one = _merge_filtered(L, sets)
+    assert one[0].tobytes() == fa.tobytes() and one[1].tobytes() == ft.tobytes()
+    for nt in (2, 8, 32):
+        got = _merge_filtered(L, sets, nthreads=nt)
+        assert got[0].tobytes() == one[0].tobytes() and got[1].tobytes() == one[1].tobytes()
 
 
 def _filtered_gather_worker(rank, world, port, q):
