@@ -522,8 +522,10 @@ static int finish_output(fga_session *Z, const fga_run_params *P, fga_alns *fin,
   int64_t i;
   double t1;
 
+  t1 = fga_wall();
   if (P->reference_threads > 0 && reference_order(Z,P,fin))
     return 1;
+  fga_note("finish: the reference's tie order",t1);
   st->nlive = fin->naln;
   for (i = 0; i < fin->naln; i++)
     st->cover += fin->alns[i].aepos - fin->alns[i].abpos;
@@ -544,6 +546,7 @@ static int finish_output(fga_session *Z, const fga_run_params *P, fga_alns *fin,
       if (rc) return 1;
     }
   st->write_s = fga_wall() - t1;
+  fga_note("finish: .1aln written",t1);
 
   /* ---- PAF (what the reference leaves to a second process, ALNtoPAF): outside the .1aln clock ---- */
   if (P->paf_path != NULL)
@@ -723,6 +726,7 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
       if ((stage = fga_dev_stage_acquire(dev,(size_t) n*sizeof(fga_seed) + 64)) == NULL) goto done;
       if (fga_seeds_split_to(dev,seeds,select,nctg,nparts,stage,poff)) goto done;
       fga_seeds_free(seeds); seeds = NULL;   /* its slot is taken over by the parts' buffers */
+      fga_note("run: seeds regrouped by A-contig part",tstart);
       pf = calloc(nparts,sizeof(part_filter));
       if (pf == NULL)
         { fga_set_error("out of memory");
@@ -733,7 +737,9 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
           const int64_t c = poff[p+1] - poff[p];
           fga_dseeds *part = NULL;
           if (fga_seeds_import(dev,&src,&c,1,&part)) goto done;
+          fga_note("run: part imported",tstart);
           if (fga_session_align(Z,P,part,&raw[p],&st)) goto done;
+          fga_note("run: part aligned",tstart);
           /* this part's records through the redundancy filter in the background (every contig pair's records are in the
              part that owns the A contig) while the next part's kernels run */
           /* half of the run's threads beside the next part's kernels (whose host tails want the rest); all of them for the
@@ -757,6 +763,7 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
             if (fsets != NULL) fsets[p] = pf[p].out;
           }
         st.filter_s += fga_wall() - tj;                 /* what the filter added to the critical path */
+        fga_note("run: filters joined",tstart);
         if (!bad && fga_session_finish_filtered(Z,P,fsets,nparts,&st)) bad = 1;
         free(fsets);
         if (bad) goto done;
