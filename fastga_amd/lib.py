@@ -187,6 +187,7 @@ def _declare(L):
         "fga_trace_pts": (i32, [vp, vp, vp, P(Alns), i32, i32, P(P(Traces))]),
         "fga_trace_pts_regrouped": (i32, [vp, vp, vp, P(Alns), i32, i32, P(P(Traces))]),
         "fga_gap_core_check": (i32, [vp, vp, P(Alns), P(Traces), i32, C.c_int64]),
+        "fga_dev_driver_seconds": (C.c_double, []),
         "fga_traces_free": (None, [P(Traces)]),
         "fga_write_paf": (i32, [cp, vp, vp, P(Alns), P(Traces), i32, i32]),
         "fga_write_psl": (i32, [cp, vp, vp, P(Alns), P(Traces), i32]),

@@ -93,6 +93,8 @@ int   fga_dev_malloc(fga_dev *dev, size_t bytes, void **out);
 void  fga_dev_free(fga_dev *dev, void *ptr);
 int   fga_dev_download(fga_dev *dev, void *host_dst, const void *device_src, size_t bytes);
 int   fga_dev_upload(fga_dev *dev, void *device_dst, const void *host_src, size_t bytes);
+double  fga_dev_driver_seconds(void);       /* seconds this process has waited in hipMalloc / hipFree for the pool's regions: 0.3 ms
+                                               a call, unless the driver first has to clear memory another process released (seconds) */
 int64_t fga_dev_peak_bytes(fga_dev *dev);   /* peak device memory in use by this process so far (stage-boundary samples) */
 /* Device memory of a MiB and more is cut from regions the library keeps for reuse (allocation and release of tens of GB
    through the driver cost seconds).  fga_dev_trim gives the regions nobody uses back to the driver -- call it before another
