@@ -566,7 +566,9 @@ def pmc_traffic():
     -> x2; WRITE_SIZE in KiB.  All kernels of the merge launch are added up."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv")))
+    import re
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv"))
+                   if re.fullmatch(r"r\d+_pmc_summary\.csv", os.path.basename(f)))     # the bench pair's, not another shape's
     if not files:
         return None, None
     fetch = write = None

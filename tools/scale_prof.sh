@@ -8,7 +8,7 @@ root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out
 mkdir -p $out/prof_$tag
 cd /tmp && export TMPDIR=/tmp
-timeout 500 rocprofv3 --kernel-trace --stats -d $out/prof_$tag/c4 -o kt --output-format csv -- python $root/tools/config4_check.py --mbp 3000 --div 0.01 > $out/prof_$tag/c4.log 2>&1
+timeout 500 rocprofv3 --kernel-trace --stats -d $out/prof_$tag/c4 -o kt --output-format csv -- python $root/tools/config4_check.py --mbp 3000 --div 0.01 --no-digest > $out/prof_$tag/c4.log 2>&1
 cp $out/prof_$tag/c4/kt_kernel_stats.csv $out/${tag}_config4_kernel_stats.csv
 timeout 300 rocprofv3 --kernel-trace --stats -d $out/prof_$tag/c3 -o kt --output-format csv -- python $root/tools/config3_check.py --mbp 1000 > $out/prof_$tag/c3.log 2>&1
 cp $out/prof_$tag/c3/kt_kernel_stats.csv $out/${tag}_config3_kernel_stats.csv
@@ -16,10 +16,13 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $out/prof_$tag/thr -o kt --outpu
 cp $out/prof_$tag/thr/kt_kernel_stats.csv $out/${tag}_throughput_kernel_stats.csv
 # PMC passes over the same shapes (each counter group in its own run, no trace domains): the kernels that dominate them --
 # the sort passes, ext_mid, the seed merge at 3 Gbp and in self mode, the index build -- with their counters per launch
+# PMC_GROUPS="fetch write sq" limits the counter groups of a shape (GPU minutes: a 3 Gbp pass is a minute);
+# SCALE_PROF_FULL=1 also takes the 1 Gbp self comparison's passes
 pmc_shape() { shape=$1; shift
   for grp in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES" \
              "sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" "lds SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
     set -- $grp; name=$1; shift
+    case " ${PMC_GROUPS:-fetch write sq sq2 lds} " in *" $name "*) ;; *) continue ;; esac
     timeout 400 rocprofv3 --pmc "$@" -d $out/prof_$tag/pmc_${shape}_$name -o pmc --output-format csv -- $CMD > $out/prof_$tag/pmc_${shape}_$name.log 2>&1
   done
   python - "$out/prof_$tag" "$shape" "$out/${tag}_${shape}_pmc_summary.csv" "$CMD" <<'PY'
@@ -43,8 +46,8 @@ with open(dst, "w") as f:
         w.writerow([r[0], r[1], r[2], r[3], "%.6g" % r[4]])
 PY
 }
-CMD="python $root/tools/config4_check.py --mbp 3000 --div 0.01 --no-digest"; pmc_shape config4
+CMD="python $root/tools/config4_check.py --mbp 3000 --div 0.01 --no-digest"; PMC_GROUPS="${PMC_GROUPS_3G:-fetch write sq}" pmc_shape config4
 CMD="python $root/tools/scale_check.py --mbp 150 --self --repeats 0.30"; pmc_shape throughput
-CMD="python $root/tools/config3_check.py --mbp 1000"; pmc_shape config3
+if [ "${SCALE_PROF_FULL:-0}" = 1 ]; then CMD="python $root/tools/config3_check.py --mbp 1000"; pmc_shape config3; fi
 grep -h "fga_session_run\|stages\|run 1" $out/prof_$tag/c4.log $out/prof_$tag/c3.log $out/prof_$tag/thr.log
 for f in config4 config3 throughput; do echo "== $f"; head -14 $out/${tag}_${f}_kernel_stats.csv | cut -c1-150; done
