@@ -879,28 +879,79 @@ __global__ void unit_count_kernel(const uint4 *rec, const fga_unit *units, int64
     cnt[j] = units[rec[j].x].nhits;
 }
 
-// exclusive prefix of n 32-bit counts into 64-bit offsets.  One workgroup of 1024.
-__global__ void __launch_bounds__(1024) unit_scan_kernel(const int32_t *cnt, int64_t *out, int64_t n)
-{ __shared__ int64_t part[1024];
-  const int t = threadIdx.x;
-  const int64_t per = (n + 1023) / 1024;
-  const int64_t lo = t*per < n ? t*per : n, hi = lo+per < n ? lo+per : n;
+// exclusive prefix of n 32-bit counts into 64-bit offsets, three launches: sums of 4096-count tiles, the scan of the sums
+// by one workgroup (coalesced, a tile of 1024 sums at a time), the tiles again with their bases.  (One workgroup over
+// everything, a contiguous piece per thread, took 2.7 ms for 10^6 counts: every lane of a load on a cache line of its own.)
+#define USCAN_TILE 4096
+__global__ void __launch_bounds__(256) unit_tile_sum_kernel(const int32_t *cnt, int64_t n, int64_t *tsum)
+{ __shared__ int64_t part[4];
+  const int64_t base = (int64_t) blockIdx.x*USCAN_TILE;
   int64_t s = 0;
-  for (int64_t i = lo; i < hi; i++)
-    s += cnt[i];
-  part[t] = s;
+  for (int k = threadIdx.x; k < USCAN_TILE; k += 256)
+    if (base+k < n) s += cnt[base+k];
+  for (int o = 32; o > 0; o >>= 1)
+    s += __shfl_xor(s,o,64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
   __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1)
-    { const int64_t v = t >= o ? part[t-o] : 0;
+  if (threadIdx.x == 0)
+    tsum[blockIdx.x] = part[0]+part[1]+part[2]+part[3];
+}
+
+__global__ void __launch_bounds__(1024) unit_sum_scan_kernel(int64_t *tsum, int64_t nt)        // in place, exclusive
+{ __shared__ int64_t buf[1024];
+  __shared__ int64_t carry;
+  const int t = threadIdx.x;
+  if (t == 0) carry = 0;
+  __syncthreads();
+  for (int64_t b = 0; b < nt; b += 1024)
+    { const int64_t v = b+t < nt ? tsum[b+t] : 0;
+      buf[t] = v;
       __syncthreads();
-      part[t] += v;
+      for (int o = 1; o < 1024; o <<= 1)
+        { const int64_t u = t >= o ? buf[t-o] : 0;
+          __syncthreads();
+          buf[t] += u;
+          __syncthreads();
+        }
+      if (b+t < nt) tsum[b+t] = carry + buf[t] - v;
+      __syncthreads();
+      if (t == 1023) carry += buf[1023];
       __syncthreads();
     }
-  s = t > 0 ? part[t-1] : 0;
-  for (int64_t i = lo; i < hi; i++)
-    { out[i] = s;
-      s += cnt[i];
+}
+
+__global__ void __launch_bounds__(256) unit_tile_scan_kernel(const int32_t *cnt, int64_t n, const int64_t *tsum, int64_t *out)
+{ __shared__ int64_t wsum[4];
+  const int64_t base = (int64_t) blockIdx.x*USCAN_TILE + (int64_t) threadIdx.x*16;      // sixteen consecutive counts per thread
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int32_t c[16];
+  int64_t s = 0;
+  for (int k = 0; k < 16; k++)
+    { c[k] = base+k < n ? cnt[base+k] : 0;
+      s += c[k];
     }
+  int64_t incl = s;
+  for (int o = 1; o < 64; o <<= 1)
+    { const int64_t u = __shfl_up(incl,o,64);
+      if (lane >= o) incl += u;
+    }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int64_t at = tsum[blockIdx.x] + (incl - s);
+  for (int w = 0; w < wave; w++)
+    at += wsum[w];
+  for (int k = 0; k < 16; k++)
+    { if (base+k < n) out[base+k] = at;
+      at += c[k];
+    }
+}
+
+void fga_scan_counts(fga_dev *dev, const int32_t *cnt, int64_t n, int64_t *tsum, int64_t *out)
+{ const int64_t ntile = (n + USCAN_TILE - 1) / USCAN_TILE;
+  if (n <= 0) return;
+  hipLaunchKernelGGL(unit_tile_sum_kernel,dim3((unsigned) ntile),dim3(256),0,dev->stream,cnt,n,tsum);
+  hipLaunchKernelGGL(unit_sum_scan_kernel,dim3(1),dim3(1024),0,dev->stream,tsum,ntile);
+  hipLaunchKernelGGL(unit_tile_scan_kernel,dim3((unsigned) ntile),dim3(256),0,dev->stream,cnt,n,(const int64_t *) tsum,out);
 }
 
 __global__ void unit_relay_kernel(const uint4 *rec, const fga_unit *units, const fga_hit *hits, const int64_t *pos,
@@ -1041,7 +1092,8 @@ extern "C" int fga_chain_scan_device(fga_dev *dev, const fga_dkeys *K, const fga
           const double tq0 = fga_wall();
           double tq1;
           uint4 *r0 = NULL, *r1 = NULL, *rs = NULL;
-          int32_t *dcnt = NULL; int64_t *dpos = NULL;
+          int32_t *dcnt = NULL; int64_t *dpos = NULL, *dtsum = NULL;
+          const int64_t ntile = (nu + USCAN_TILE - 1) / USCAN_TILE;
           fga_unit *ou = NULL; fga_hit *oh = NULL;
           bool bad = false;
           R = (fga_hits *) calloc(1,sizeof(fga_hits));
@@ -1058,6 +1110,7 @@ extern "C" int fga_chain_scan_device(fga_dev *dev, const fga_dkeys *K, const fga
               const unsigned gb = (unsigned) ((nu + 255) / 256);
               if (fga_dmalloc(&r0,sizeof(uint4)*(size_t) nu) != hipSuccess || fga_dmalloc(&r1,sizeof(uint4)*(size_t) nu) != hipSuccess ||
                   fga_dmalloc(&dcnt,sizeof(int32_t)*(size_t) nu) != hipSuccess || fga_dmalloc(&dpos,sizeof(int64_t)*(size_t) nu) != hipSuccess ||
+                  fga_dmalloc(&dtsum,sizeof(int64_t)*(size_t) (ntile+1)) != hipSuccess ||
                   fga_dmalloc(&ou,sizeof(fga_unit)*(size_t) nu) != hipSuccess || fga_dmalloc(&oh,sizeof(fga_hit)*(size_t) (nh+1)) != hipSuccess)
                 bad = true;
               if (!bad)
@@ -1067,7 +1120,7 @@ extern "C" int fga_chain_scan_device(fga_dev *dev, const fga_dkeys *K, const fga
                 }
               if (!bad)
                 { hipLaunchKernelGGL(unit_count_kernel,dim3(gb),dim3(256),0,dev->stream,(const uint4 *) rs,(const fga_unit *) A.units,nu,dcnt);
-                  hipLaunchKernelGGL(unit_scan_kernel,dim3(1),dim3(1024),0,dev->stream,(const int32_t *) dcnt,dpos,nu);
+                  fga_scan_counts(dev,dcnt,nu,dtsum,dpos);
                   hipLaunchKernelGGL(unit_relay_kernel,dim3(gb),dim3(256),0,dev->stream,(const uint4 *) rs,(const fga_unit *) A.units,
                                      (const fga_hit *) A.hits,(const int64_t *) dpos,nu,ou,oh);
                   if ((nh > 0 && hipMemcpyAsync(R->hits,oh,sizeof(fga_hit)*(size_t) nh,hipMemcpyDeviceToHost,dev->stream) != hipSuccess) ||
@@ -1075,7 +1128,7 @@ extern "C" int fga_chain_scan_device(fga_dev *dev, const fga_dkeys *K, const fga
                       hipStreamSynchronize(dev->stream) != hipSuccess || hipGetLastError() != hipSuccess)
                     bad = true;
                 }
-              fga_pool_free(r0); fga_pool_free(r1); fga_pool_free(dcnt); fga_pool_free(dpos); fga_pool_free(ou); fga_pool_free(oh);
+              fga_pool_free(r0); fga_pool_free(r1); fga_pool_free(dcnt); fga_pool_free(dpos); fga_pool_free(dtsum); fga_pool_free(ou); fga_pool_free(oh);
               if (bad)
                 { fga_hits_free(R); R = NULL;
                   fga_set_error("fga_chain_scan_device: ordering the units on the device failed");

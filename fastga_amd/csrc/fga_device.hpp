@@ -83,6 +83,9 @@ void *fga_dev_acquire(fga_dev *dev, int slot, size_t bytes);   // a work buffer 
 void  fga_dev_release(fga_dev *dev, int slot, void *ptr);
 void *fga_dev_pinned(fga_dev *dev, size_t bytes);              // host pinned staging, grow-only
 int   fga_radix_sort_u128(fga_dev *dev, uint4 *buf0, uint4 *buf1, int64_t n, int lowbit, int nbits, uint4 **sorted);
+// exclusive prefix of n 32-bit counts into 64-bit offsets on dev->stream (fga_chain.hip: tile sums, their scan, the tiles
+// again); tsum: scratch of (n + 4095) / 4096 + 1 words.  out[n] is not written.
+void  fga_scan_counts(fga_dev *dev, const int32_t *cnt, int64_t n, int64_t *tsum, int64_t *out);
 
 struct fga_dseeds
   { fga_dev  *dev;

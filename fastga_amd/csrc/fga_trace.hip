@@ -11,7 +11,7 @@
 //   trace_panel_kernel  lane per panel:     the furthest-reaching wave rows (16-bit cells: reach + move code), pointer
 //                                           reversal, forward walk emitting the indels into the panel's raw slots
 //   trace_count_kernel  wave per alignment: indels and differences of the alignment
-//   trace_scan_kernel   one workgroup:      exclusive prefix of the per-alignment counts
+//   fga_scan_counts     (fga_chain.hip)     exclusive prefix of the per-alignment counts
 //   trace_pack_kernel   wave per alignment: raw slots -> the dense int stream
 //
 // Cells: cost row d = -2..D, diagonal k (A index = B index + k); a cell holds reach+2 in its low 12 bits and the
@@ -335,32 +335,6 @@ __global__ void __launch_bounds__(64) trace_count_kernel(trace_args T)
     { T.atlen[i] = cnt; T.adiffs[i] = dif; T.astat[i] = bad; }
 }
 
-// exclusive prefix of n 32-bit counts into 64-bit offsets; out[n] = total.  One workgroup of 1024.
-__global__ void __launch_bounds__(1024) trace_scan_kernel(const int32_t *cnt, int64_t *out, int64_t n)
-{ __shared__ int64_t part[1024];
-  const int t = threadIdx.x;
-  const int64_t per = (n + 1023) / 1024;
-  const int64_t lo = t*per < n ? t*per : n, hi = lo+per < n ? lo+per : n;
-  int64_t s = 0;
-  for (int64_t i = lo; i < hi; i++)
-    s += cnt[i];
-  part[t] = s;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1)
-    { const int64_t v = t >= o ? part[t-o] : 0;
-      __syncthreads();
-      part[t] += v;
-      __syncthreads();
-    }
-  s = t > 0 ? part[t-1] : 0;
-  for (int64_t i = lo; i < hi; i++)
-    { out[i] = s;
-      s += cnt[i];
-    }
-  if (t == 1023)
-    out[n] = part[1023];
-}
-
 __global__ void __launch_bounds__(64) trace_pack_kernel(trace_args T)
 { const int64_t i = blockIdx.x;
   const int lane = threadIdx.x;
@@ -503,7 +477,7 @@ static int trace_pts_impl(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
   int rc = 1;
   hipError_t e = hipSuccess;
   fga_aln *d_alns = NULL; uint8_t *d_tb = NULL;
-  int64_t *d_need = NULL, *d_pbase = NULL, *d_rbase = NULL, *d_sbase = NULL, *d_toff = NULL;
+  int64_t *d_need = NULL, *d_pbase = NULL, *d_rbase = NULL, *d_sbase = NULL, *d_toff = NULL, *d_tsum = NULL;
   int32_t *d_atlen = NULL, *d_adiffs = NULL, *d_astat = NULL, *d_pcnt = NULL, *d_pdiff = NULL;
   int32_t *d_raw = NULL, *d_dense = NULL;
   trace_panel *d_panels = NULL; uint16_t *d_cells = NULL;
@@ -527,7 +501,8 @@ static int trace_pts_impl(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
   TRY(fga_dmalloc(&d_rbase,sizeof(int64_t)*(n+1)));
   TRY(fga_dmalloc(&d_sbase,sizeof(int64_t)*(n+1)));
   TRY(fga_dmalloc(&d_toff,sizeof(int64_t)*(n+1)));
-  TRY(fga_dmalloc(&d_atlen,sizeof(int32_t)*n));
+  TRY(fga_dmalloc(&d_atlen,sizeof(int32_t)*(n+1)));                    // one more, zero: the scan's last offset is the total
+  TRY(fga_dmalloc(&d_tsum,sizeof(int64_t)*((n+1+4095)/4096 + 1)));
   TRY(fga_dmalloc(&d_adiffs,sizeof(int32_t)*n));
   TRY(fga_dmalloc(&d_astat,sizeof(int32_t)*n));
   TRY(fga_dmalloc(&d_pcnt,sizeof(int32_t)*npan));
@@ -585,7 +560,8 @@ static int trace_pts_impl(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
     T.panels = d_panels; T.p0 = 0;
   }
   hipLaunchKernelGGL(trace_count_kernel,dim3((unsigned) n),dim3(64),0,dev->stream,T);
-  hipLaunchKernelGGL(trace_scan_kernel,dim3(1),dim3(1024),0,dev->stream,d_atlen,d_toff,n);
+  TRY(hipMemsetAsync(d_atlen+n,0,sizeof(int32_t),dev->stream));
+  fga_scan_counts(dev,d_atlen,n+1,d_tsum,d_toff);
   R->toff = (int64_t *) malloc(sizeof(int64_t)*(n+1));
   R->tlen = (int32_t *) malloc(sizeof(int32_t)*n);
   R->diffs = (int32_t *) malloc(sizeof(int32_t)*n);
@@ -701,7 +677,7 @@ fail:
   fga_set_error("fga_trace_pts: %s",hipGetErrorString(e));
 done:
   fga_pool_free(d_alns); fga_pool_free(d_tb); fga_pool_free(d_need); fga_pool_free(d_pbase); fga_pool_free(d_rbase); fga_pool_free(d_sbase);
-  fga_pool_free(d_toff); fga_pool_free(d_atlen); fga_pool_free(d_adiffs); fga_pool_free(d_astat); fga_pool_free(d_pcnt); fga_pool_free(d_pdiff);
+  fga_pool_free(d_toff); fga_pool_free(d_tsum); fga_pool_free(d_atlen); fga_pool_free(d_adiffs); fga_pool_free(d_astat); fga_pool_free(d_pcnt); fga_pool_free(d_pdiff);
   fga_pool_free(d_raw); fga_pool_free(d_dense); fga_pool_free(d_panels); fga_pool_free(d_cells);
   fga_pool_free(d_order); fga_pool_free(d_resume); fga_pool_free(d_F); fga_pool_free(d_H); fga_pool_free(d_ticket);
   if (evr0 != NULL) hipEventDestroy(evr0);
