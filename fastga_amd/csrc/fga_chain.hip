@@ -1074,7 +1074,11 @@ extern "C" int fga_chain_scan_device(fga_dev *dev, const fga_dkeys *K, const fga
               goto fail;
             }
           if (nsegs > 0)
-            { int nwg = dev->ncu * 8;
+            { int per_cu = 16;                                     // bench pair: 8 / 16 / 24 / 32 per CU -> 2.0 / 1.6 / 1.7 / 1.6 ms of chain kernels
+              { const char *ev = getenv("FGA_CHAIN_SEG_WAVES");     // experiments: persistent wavefronts per CU
+                if (ev != NULL && atoi(ev) > 0 && atoi(ev) <= 32) per_cu = atoi(ev);
+              }
+              int nwg = dev->ncu * per_cu;
               if ((int64_t) nwg > nsegs) nwg = (int) nsegs;
               hipLaunchKernelGGL(chain_segment_kernel,dim3(nwg),dim3(64),0,dev->stream,A,B,nsegs);
               hipLaunchKernelGGL(chain_stitch_kernel,dim3((unsigned) ((nbig + 63)/64)),dim3(64),0,dev->stream,A,B,nbig);
