@@ -194,6 +194,29 @@ __global__ void aln_gather_kernel(const uint4 *rec, const fga_aln *alns, int64_t
     out[j] = alns[rec[j].x];
 }
 
+// units by decreasing estimated work (sum of their hit boxes' lengths), ties by unit index: the order the persistent
+// wavefronts take them in.  A key per unit, the LSD sort of fga_sort.hip, the indices out.  (The host team needed 15-20 ms
+// for the 2 M units of a 3 Gbp part.)
+#define WORK_BITS 40
+__global__ void unit_work_kernel(const fga_unit *units, const fga_hit *hits, int64_t nu, uint4 *rec)
+{ const int64_t u = (int64_t) blockIdx.x*blockDim.x + threadIdx.x;
+  if (u >= nu) return;
+  int64_t s = 0;
+  const fga_hit *h = hits + units[u].first_hit;
+  for (int q = 0; q < units[u].nhits; q++)
+    s += (h[q].ahgh - h[q].alow) + 1000;
+  if (s < 0) s = 0;
+  if (s > ((int64_t) 1 << WORK_BITS) - 1) s = ((int64_t) 1 << WORK_BITS) - 1;
+  const uint64_t k = (uint64_t) (((int64_t) 1 << WORK_BITS) - 1 - s);         // ascending key = decreasing work
+  rec[u] = make_uint4((uint32_t) u,(uint32_t) k,(uint32_t) (k >> 32),0u);
+}
+
+__global__ void unit_order_kernel(const uint4 *rec, int64_t nu, int *order)
+{ const int64_t j = (int64_t) blockIdx.x*blockDim.x + threadIdx.x;
+  if (j < nu)
+    order[j] = (int) rec[j].x;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
@@ -261,30 +284,6 @@ extern "C" void fga_dgenome_free(fga_dgenome *D)
   free(D);
 }
 
-struct work_ctx { const fga_hits *H; uint64_t *w; int64_t *ord; int64_t smax; };
-
-static void work_slice(void *arg, int id, int64_t b, int64_t e)
-{ work_ctx *C = (work_ctx *) arg;
-  (void) id;
-  for (int64_t u = b; u < e; u++)
-    { int64_t s = 0;
-      for (int q = 0; q < C->H->units[u].nhits; q++)
-        { const fga_hit &h = C->H->hits[C->H->units[u].first_hit + q];
-          s += (h.ahgh - h.alow) + 1000;
-        }
-      if (s < 0) s = 0;
-      C->w[u] = (uint64_t) s;
-      C->ord[u] = u;
-    }
-}
-
-static void work_flip_slice(void *arg, int id, int64_t b, int64_t e)
-{ work_ctx *C = (work_ctx *) arg;
-  (void) id;
-  for (int64_t u = b; u < e; u++)
-    C->w[u] = (uint64_t) C->smax - C->w[u];
-}
-
 extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome *GB, const fga_hits *H,
                           const fga_extend_params *prm, fga_alns **out)
 { *out = NULL;
@@ -304,37 +303,6 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
       free(R);
       return 1;
     }
-
-  // units by decreasing estimated work (sum of hit box lengths): longest first (on the host team: 10^6 units in the
-  // repeat-heavy shapes)
-  std::vector<int> order(H->nunits);
-  { fga_team *team = fga_team_open(H->nunits < 50000 ? 1 : (dev->host_threads > 0 ? dev->host_threads : 1));
-    std::vector<uint64_t> w((size_t) H->nunits);
-    std::vector<int64_t> ord((size_t) H->nunits);
-    work_ctx WC;
-    WC.H = H; WC.w = w.data(); WC.ord = ord.data(); WC.smax = 0;
-    if (team == NULL)
-      { fga_set_error("out of memory");
-        free(R);
-        return 1;
-      }
-    fga_team_run(team,H->nunits,work_slice,&WC);
-    int64_t smax = 0;
-    for (int64_t u = 0; u < H->nunits; u++)
-      if ((int64_t) w[(size_t) u] > smax) smax = (int64_t) w[(size_t) u];
-    WC.smax = smax;                                     // decreasing work, ties by unit index (the radix order is stable)
-    fga_team_run(team,H->nunits,work_flip_slice,&WC);
-    int bits = 1;
-    while (bits < 63 && ((int64_t) 1 << bits) <= smax) bits += 1;
-    const int bad = fga_team_sort_pairs(team,w.data(),ord.data(),H->nunits,bits);
-    fga_team_close(team);
-    if (bad)
-      { fga_set_error("out of memory");
-        free(R);
-        return 1;
-      }
-    for (int64_t u = 0; u < H->nunits; u++) order[u] = (int) ord[(size_t) u];
-  }
 
   // resident single-wavefront workgroups: the LDS block of a wavefront (26.5 KB) allows six per CU.  With few units the
   // run time is the longest unit's serial chain, which is fastest with four (it shares its CU's issue slots, LDS and L1
@@ -407,7 +375,23 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
     }
   hipMemcpy(d_units,H->units,sizeof(fga_unit)*H->nunits,hipMemcpyHostToDevice);
   hipMemcpy(d_hits,H->hits,sizeof(fga_hit)*H->nhits,hipMemcpyHostToDevice);
-  hipMemcpy(d_order,order.data(),sizeof(int)*H->nunits,hipMemcpyHostToDevice);
+  { uint4 *r0 = NULL, *r1 = NULL, *rs = NULL;
+    const unsigned gb = (unsigned) ((H->nunits + 255) / 256);
+    bool ok = fga_dmalloc(&r0,sizeof(uint4)*(size_t) H->nunits) == hipSuccess && fga_dmalloc(&r1,sizeof(uint4)*(size_t) H->nunits) == hipSuccess;
+    if (ok)
+      { hipLaunchKernelGGL(unit_work_kernel,dim3(gb),dim3(256),0,dev->stream,(const fga_unit *) d_units,(const fga_hit *) d_hits,(int64_t) H->nunits,r0);
+        ok = fga_radix_sort_u128(dev,r0,r1,H->nunits,32,WORK_BITS,&rs) == 0;
+      }
+    if (ok)
+      { hipLaunchKernelGGL(unit_order_kernel,dim3(gb),dim3(256),0,dev->stream,(const uint4 *) rs,(int64_t) H->nunits,d_order);
+        ok = hipStreamSynchronize(dev->stream) == hipSuccess && hipGetLastError() == hipSuccess;
+      }
+    fga_pool_free(r0); fga_pool_free(r1);
+    if (!ok)
+      { fga_set_error("fga_extend: ordering the units on the device failed");
+        goto fail;
+      }
+  }
   hipMemcpy(d_tab,prm->table,sizeof(int16_t)*32768,hipMemcpyHostToDevice);
   hipMemcpy(d_tab+32768,prm->score,sizeof(int16_t)*32768,hipMemcpyHostToDevice);
   A.units = d_units; A.hits = d_hits; A.order = d_order; A.next = d_next; A.wide_q = d_wide;
