@@ -266,3 +266,32 @@ def test_cli_process_contract_log_threads_cleanup(tmp_path, built_library):
         assert keep(os.path.join(w, "out.1aln")) == keep(os.path.join(w, "out2.1aln"))
         golden = [ln.rstrip("\n") for ln in open(os.path.join(root, "tests", "golden", "toy_AvB.1aln.txt"))]
         assert keep(os.path.join(w, "out.1aln")) == [ln for ln in golden if ln[0] not in "!<"]
+
+
+def test_native_paf_at_a_scale_where_the_device_regroups(tmp_path, built_library, capfd):
+    """25 Mbp repeat-heavy genome against itself (> 10^5 short alignments, millions of indels): the set is large enough for
+    fga_trace_pts_regrouped to keep the scripts on the device (Gap_Improver one lane per alignment, long ones handed back
+    to the formatter threads) -- the PAF with =/X CIGARs and the PSL must still be ALNtoPAF's / ALNtoPSL's, byte for byte"""
+    from fastga_amd import device as D, synth, workload
+    from oracle import harness as H
+    if not H.have_reference():
+        pytest.skip("oracle/_ref did not travel")
+    w = str(tmp_path)
+    lens = synth.contig_lengths(2, 20, 25_000_000)
+    A, _, _, _ = synth.make_pair(2, lens, 0.02, repeat_frac=0.30, inv_frac=0.02, swap_frac=0.02, self_only=True)
+    ra = workload.build_genome(w, "A", A, threads=16, gix=False)
+    ours, paf, psl = os.path.join(w, "s.1aln"), os.path.join(w, "s.paf"), os.path.join(w, "s.psl")
+    os.environ["FGA_TRACE_TIMING"] = "1"                    # (its stderr line says how many alignments were handed back)
+    try:
+        st = D.run(ra, None, ours, nthreads=16, paf_path=paf, paf_flags=2, build_index=True)
+        D.run(ra, None, ours, nthreads=16, paf_path=psl, paf_flags=32, build_index=True)
+    finally:
+        del os.environ["FGA_TRACE_TIMING"]
+    import re
+    said = re.findall(r"regrouping [0-9.]+ ms \((\d+) of (\d+) alignments handed back", capfd.readouterr().err)
+    assert len(said) == 2 and all(int(n) == st["nlive"] and int(back) < 0.1 * int(n) for back, n in said), said
+    assert st["nlive"] > 50_000 and st["trace_kernel_ms"] > 0
+    exp = H.run([H.ref_bin("ALNtoPAF"), "-T16", "-x", ours], cwd=w).stdout
+    assert open(paf).read() == exp
+    exp = H.run([H.ref_bin("ALNtoPSL"), "-T16", ours], cwd=w).stdout
+    assert open(psl).read() == exp
