@@ -19,6 +19,7 @@
 #include <time.h>
 #include <unistd.h>
 #include <sys/time.h>
+#include <pthread.h>
 #include <zlib.h>
 
 #include "fga_host.h"
@@ -449,6 +450,41 @@ done:
   free(G.srcpath);
   free(noext); free(dir); free(root); free(bpath); free(gpath);
   return status;
+}
+
+/* the bases of a genome (0.75 GB for 3 Gbp) from the page cache into a fresh buffer: the copy and the first touch of the
+ * buffer's pages by eight threads with pread (one fread: 0.44 s; this: 0.1 s -- it is a third of what opening a 3 Gbp
+ * session costs beside the two index builds) */
+typedef struct { int fd; uint8_t *dst; int64_t beg, end; int bad; } image_job;
+
+static void *image_thread(void *arg)
+{ image_job *J = arg;
+  int64_t at = J->beg;
+  while (at < J->end)
+    { const ssize_t r = pread(J->fd,J->dst+at,(size_t) (J->end-at),(off_t) at);
+      if (r <= 0) { J->bad = 1; break; }
+      at += r;
+    }
+  return NULL;
+}
+
+static int read_image(FILE *f, uint8_t *dst, int64_t len)
+{ image_job job[8];
+  pthread_t th[8];
+  int nt = len >= ((int64_t) 64 << 20) ? 8 : 1, t, bad = 0;
+  if (nt == 1)
+    return fread(dst,1,(size_t) len,f) != (size_t) len;
+  for (t = 0; t < nt; t++)
+    { job[t].fd = fileno(f); job[t].dst = dst; job[t].beg = len*t/nt; job[t].end = len*(t+1)/nt; job[t].bad = 0; }
+  for (t = 1; t < nt; t++)
+    if (pthread_create(th+t,NULL,image_thread,job+t) != 0)
+      { image_thread(job+t); th[t] = 0; }
+  image_thread(job);
+  for (t = 1; t < nt; t++)
+    if (th[t]) pthread_join(th[t],NULL);
+  for (t = 0; t < nt; t++)
+    bad |= job[t].bad;
+  return bad;
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -886,7 +922,7 @@ parsed:
         fclose(b);
         goto fail;
       }
-    if (boff > 0 && fread(G->bps,1,boff,b) != (size_t) boff)
+    if (boff > 0 && read_image(b,G->bps,boff))
       { fga_set_error("%s is shorter than its skeleton says (%lld bytes)",bpath,(long long) boff);
         fclose(b);
         goto fail;
