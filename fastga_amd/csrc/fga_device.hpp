@@ -121,6 +121,8 @@ struct fga_dkeys
   };
 
 // device-resident genome: the .bps image (padded) and, for genome 1, its per-contig reverse complement
+#define FGA_IMG_PAD 4096    // bytes of zero padding before and after a genome image (>= one LDS window)
+
 struct fga_dgenome
   { fga_dev  *dev;
     uint8_t  *img, *img_rc;

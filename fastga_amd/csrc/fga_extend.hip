@@ -220,10 +220,12 @@ __global__ void unit_order_kernel(const uint4 *rec, int64_t nu, int *order)
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
-#define IMG_PAD 4096    // bytes of zero padding before and after a genome image (>= one LDS window)
+#define IMG_PAD FGA_IMG_PAD
 
-extern "C" int fga_dgenome_upload(fga_dev *dev, const fga_gdb *G, const int *perm, int nperm, int want_revcomp,
-                                  fga_dgenome **out)
+// adopt != NULL: a padded image of G's bases that is on the device already (the index build's, fga_dgix_build_keep) is
+// taken over instead of uploading the bases a second time
+static int dgenome_make(fga_dev *dev, const fga_gdb *G, const int *perm, int nperm, int want_revcomp, uint8_t *adopt,
+                        fga_dgenome **out)
 { *out = NULL;
   FGA_HIP(hipSetDevice(dev->device));
   fga_dgenome *D = (fga_dgenome *) calloc(1,sizeof(fga_dgenome));
@@ -241,7 +243,9 @@ extern "C" int fga_dgenome_upload(fga_dev *dev, const fga_gdb *G, const int *per
   for (int c = 0; c < G->ncontig; c++)
     { boff[c] = G->contigs[c].boff; clen[c] = G->contigs[c].clen; }
   hipError_t e;
-  if ((e = fga_dmalloc(&D->img,bytes)) != hipSuccess ||
+  if (adopt != NULL)
+    D->img = adopt;
+  if ((adopt == NULL && (e = fga_dmalloc(&D->img,bytes)) != hipSuccess) ||
       (e = fga_dmalloc(&D->boff,sizeof(int64_t)*G->ncontig)) != hipSuccess ||
       (e = fga_dmalloc(&D->clen,sizeof(int64_t)*G->ncontig)) != hipSuccess ||
       (e = fga_dmalloc(&D->perm,sizeof(int)*(nperm > 0 ? nperm : 1))) != hipSuccess ||
@@ -250,8 +254,10 @@ extern "C" int fga_dgenome_upload(fga_dev *dev, const fga_gdb *G, const int *per
       fga_pool_free(D->img); fga_pool_free(D->boff); fga_pool_free(D->clen); fga_pool_free(D->perm); fga_pool_free(D->img_rc); free(D);
       return 1;
     }
-  hipMemset(D->img,0,bytes);
-  hipMemcpy(D->img + IMG_PAD,G->bps,G->bpslen,hipMemcpyHostToDevice);
+  if (adopt == NULL)
+    { hipMemset(D->img,0,bytes);
+      hipMemcpy(D->img + IMG_PAD,G->bps,G->bpslen,hipMemcpyHostToDevice);
+    }
   hipMemcpy(D->boff,boff.data(),sizeof(int64_t)*G->ncontig,hipMemcpyHostToDevice);
   hipMemcpy(D->clen,clen.data(),sizeof(int64_t)*G->ncontig,hipMemcpyHostToDevice);
   D->hclen = (int64_t *) malloc(sizeof(int64_t)*(G->ncontig > 0 ? G->ncontig : 1));
@@ -274,6 +280,20 @@ extern "C" int fga_dgenome_upload(fga_dev *dev, const fga_gdb *G, const int *per
     }
   *out = D;
   return 0;
+}
+
+extern "C" int fga_dgenome_upload(fga_dev *dev, const fga_gdb *G, const int *perm, int nperm, int want_revcomp,
+                                  fga_dgenome **out)
+{ return dgenome_make(dev,G,perm,nperm,want_revcomp,NULL,out); }
+
+extern "C" int fga_dgenome_adopt(fga_dev *dev, const fga_gdb *G, const int *perm, int nperm, int want_revcomp,
+                                 void *image, fga_dgenome **out)
+{ if (image == NULL)
+    { *out = NULL;
+      fga_set_error("fga_dgenome_adopt: no image");
+      return 1;
+    }
+  return dgenome_make(dev,G,perm,nperm,want_revcomp,(uint8_t *) image,out);
 }
 
 extern "C" void fga_dgenome_free(fga_dgenome *D)

@@ -514,9 +514,13 @@ void gix_view_index_kernel(const int64_t *idx64, uint32_t *idx32)
 // ---------------------------------------------------------------------------------------------------
 // the build proper.  [pbeg,pend): the 12-mer prefixes kept (a rank's slice of the table; the whole space for the whole
 // table).  counts_host != NULL: count only -- the per-prefix entry counts of the whole table come back, nothing is built.
+// keep_img != NULL: the genome's bases stay on the device after the build -- the image is laid out as fga_dgenome wants it
+// (FGA_IMG_PAD zero bytes either side) and handed to the caller, who gives it to fga_dgenome_adopt: the bases cross PCIe
+// once per session, not twice (0.75 GB per 3 Gbp genome from pageable memory: ~0.1 s of the 0.45 s a genome costs to open)
 static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int flags, int64_t pbeg, int64_t pend,
-                           uint32_t *counts_host, fga_dgix **dout, fga_gix **xout)
+                           uint32_t *counts_host, fga_dgix **dout, fga_gix **xout, uint8_t **keep_img)
 { if (dout != NULL) *dout = NULL;
+  if (keep_img != NULL) *keep_img = NULL;
   if (xout != NULL) *xout = NULL;
   const bool count_only = counts_host != NULL;
   if (pbeg < 0) pbeg = 0;
@@ -537,7 +541,7 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
   int status = 1;
   fga_dgix *D = NULL;
   fga_gix  *X = NULL;
-  uint8_t *dimg = NULL, *dpartid = NULL;
+  uint8_t *dimg = NULL, *dpartid = NULL, *dimg0 = NULL;      // dimg0: the padded allocation, dimg = dimg0 + FGA_IMG_PAD
   int64_t *dboff = NULL, *dclen = NULL;
   int *dinvp = NULL;
   gix_item *ditems = NULL;
@@ -570,7 +574,7 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
       goto done;
     }
 
-  if ((e = fga_dmalloc(&dimg,(size_t) G->bpslen + 64)) != hipSuccess ||
+  if ((e = fga_dmalloc(&dimg0,(size_t) G->bpslen + 2*FGA_IMG_PAD + 64)) != hipSuccess ||
       (e = fga_dmalloc(&dboff,sizeof(int64_t)*boff.size())) != hipSuccess ||
       (e = fga_dmalloc(&dclen,sizeof(int64_t)*clen.size())) != hipSuccess ||
       (e = fga_dmalloc(&dinvp,sizeof(int)*(size_t) nctg)) != hipSuccess ||
@@ -581,7 +585,10 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
     { fga_set_error("fga_dgix_build: device allocation failed: %s",hipGetErrorString(e));
       goto done;
     }
+  dimg = dimg0 + FGA_IMG_PAD;
   if ((e = hipMemcpyToSymbol(HIP_SYMBOL(gix_tmap),fga_gix_tmap(),256)) != hipSuccess ||
+      (e = hipMemsetAsync(dimg0,0,FGA_IMG_PAD,dev->stream)) != hipSuccess ||
+      (e = hipMemsetAsync(dimg + G->bpslen,0,FGA_IMG_PAD + 64,dev->stream)) != hipSuccess ||
       (e = hipMemcpyAsync(dimg,G->bps,(size_t) G->bpslen,hipMemcpyHostToDevice,dev->stream)) != hipSuccess ||
       (e = hipMemcpyAsync(dboff,boff.data(),sizeof(int64_t)*boff.size(),hipMemcpyHostToDevice,dev->stream)) != hipSuccess ||
       (e = hipMemcpyAsync(dclen,clen.data(),sizeof(int64_t)*clen.size(),hipMemcpyHostToDevice,dev->stream)) != hipSuccess ||
@@ -811,7 +818,11 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
   status = 0;
 
 done:
-  fga_pool_free(dimg); fga_pool_free(dboff); fga_pool_free(dclen); fga_pool_free(dinvp); fga_pool_free(ditems); fga_pool_free(dcount); fga_pool_free(dctr);
+  if (status == 0 && keep_img != NULL && !count_only)
+    *keep_img = dimg0;
+  else
+    fga_pool_free(dimg0);
+  fga_pool_free(dboff); fga_pool_free(dclen); fga_pool_free(dinvp); fga_pool_free(ditems); fga_pool_free(dcount); fga_pool_free(dctr);
   fga_pool_free(dpartid);
   fga_pool_free(dmoff); fga_pool_free(dmbeg); fga_pool_free(dmend); fga_pool_free(dperm); fga_pool_free(dooff);
   fga_dev_release(dev,SLOT_SORT1,oscr); fga_dev_release(dev,SLOT_TILES,dtiles); fga_dev_release(dev,SLOT_MISC,dover);
@@ -830,7 +841,7 @@ done:
 
 extern "C" int fga_dgix_build(fga_dev *dev, const fga_gdb *G, int nthreads, int flags,
                               fga_dgix **dout, fga_gix **xout)
-{ return dgix_build_impl(dev,G,nthreads,flags,0,FGA_NPREFIX,NULL,dout,xout); }
+{ return dgix_build_impl(dev,G,nthreads,flags,0,FGA_NPREFIX,NULL,dout,xout,NULL); }
 
 // one rank's slice of the table: only the k-mers whose 12-mer prefix lies in [pbeg,pend) ("GPU g uploads only
 // its slice of both tables"; the reference's merge threads each read one such range, FastGA.c:2291-2321).  Layout, contig
@@ -845,7 +856,22 @@ extern "C" int fga_dgix_build_range(fga_dev *dev, const fga_gdb *G, int nthreads
     { fga_set_error("fga_dgix_build_range: a slice has no host copy");
       return 1;
     }
-  return dgix_build_impl(dev,G,nthreads,flags,pbeg,pend,NULL,dout,xout);
+  return dgix_build_impl(dev,G,nthreads,flags,pbeg,pend,NULL,dout,xout,NULL);
+}
+
+// the same two, leaving the genome's padded image on the device for fga_dgenome_adopt (pbeg = 0, pend = 2^24: the whole table)
+extern "C" int fga_dgix_build_keep(fga_dev *dev, const fga_gdb *G, int nthreads, int flags, int64_t pbeg, int64_t pend,
+                                   fga_dgix **dout, fga_gix **xout, void **image)
+{ uint8_t *img = NULL;
+  if (image == NULL || pbeg < 0 || pend > FGA_NPREFIX || pbeg >= pend || (flags & FGA_GIX_HOST_COPY))
+    { fga_set_error("fga_dgix_build_keep: bad arguments");
+      return 1;
+    }
+  *image = NULL;
+  if (dgix_build_impl(dev,G,nthreads,flags,pbeg,pend,NULL,dout,xout,&img))
+    return 1;
+  *image = img;
+  return 0;
 }
 
 // entries per 12-mer prefix of the table fga_dgix_build would make (one syncmer scan on the device, nothing is built):
@@ -855,5 +881,5 @@ extern "C" int fga_dgix_prefix_counts(fga_dev *dev, const fga_gdb *G, int nthrea
     { fga_set_error("fga_dgix_prefix_counts: null argument");
       return 1;
     }
-  return dgix_build_impl(dev,G,nthreads,0,0,FGA_NPREFIX,counts,NULL,NULL);
+  return dgix_build_impl(dev,G,nthreads,0,0,FGA_NPREFIX,counts,NULL,NULL,NULL);
 }

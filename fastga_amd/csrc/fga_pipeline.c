@@ -145,6 +145,7 @@ static void cuts_from_counts(const int64_t *idx1, const int64_t *idx2, const uin
 static int session_open_impl(const char *root1, const char *root2, int device, int nthreads, int rank, int nranks, int flags,
                              const mask_args *masks, fga_session **out)
 { fga_session *Z = calloc(1,sizeof(fga_session));
+  void *img1 = NULL, *img2 = NULL;         /* the genomes' bases an index build left on the device */
   double t0;
   *out = NULL;
   if (Z == NULL)
@@ -175,9 +176,9 @@ static int session_open_impl(const char *root1, const char *root2, int device, i
     Z->nranks = nranks; Z->rank = rank;
     if (nranks <= 1)
       { if (have1 ? fga_dgix_upload(Z->dev,Z->x1,&Z->d1)
-                  : fga_dgix_build(Z->dev,Z->g1,nthreads,FGA_GIX_SOFT_MASK,&Z->d1,&Z->x1)) goto fail;
+                  : fga_dgix_build_keep(Z->dev,Z->g1,nthreads,FGA_GIX_SOFT_MASK,0,FGA_NPREFIX,&Z->d1,&Z->x1,&img1)) goto fail;
         if (!Z->self && (have2 ? fga_dgix_upload(Z->dev,Z->x2,&Z->d2)
-                               : fga_dgix_build(Z->dev,Z->g2,nthreads,FGA_GIX_SOFT_MASK,&Z->d2,&Z->x2)))
+                               : fga_dgix_build_keep(Z->dev,Z->g2,nthreads,FGA_GIX_SOFT_MASK,0,FGA_NPREFIX,&Z->d2,&Z->x2,&img2)))
           goto fail;
       }
     else
@@ -208,9 +209,9 @@ static int session_open_impl(const char *root1, const char *root2, int device, i
         if (pe <= pb) pe = pb + 1 <= FGA_NPREFIX ? pb + 1 : pb;           /* an empty range still needs a (tiny) table */
         if (pe <= pb) { pb = FGA_NPREFIX-1; pe = FGA_NPREFIX; }
         if (have1 ? fga_dgix_upload_range(Z->dev,Z->x1,pb,pe,&Z->d1)
-                  : fga_dgix_build_range(Z->dev,Z->g1,nthreads,FGA_GIX_SOFT_MASK,pb,pe,&Z->d1,&Z->x1)) goto fail;
+                  : fga_dgix_build_keep(Z->dev,Z->g1,nthreads,FGA_GIX_SOFT_MASK,pb,pe,&Z->d1,&Z->x1,&img1)) goto fail;
         if (!Z->self && (have2 ? fga_dgix_upload_range(Z->dev,Z->x2,pb,pe,&Z->d2)
-                               : fga_dgix_build_range(Z->dev,Z->g2,nthreads,FGA_GIX_SOFT_MASK,pb,pe,&Z->d2,&Z->x2)))
+                               : fga_dgix_build_keep(Z->dev,Z->g2,nthreads,FGA_GIX_SOFT_MASK,pb,pe,&Z->d2,&Z->x2,&img2)))
           goto fail;
       }
     /* the builder's key buffers (2 x 16 B per k-mer) stay in their workspace slots: the comparison's first large
@@ -224,14 +225,26 @@ static int session_open_impl(const char *root1, const char *root2, int device, i
     { fga_set_error("genome index and genome database disagree on the number of contigs");
       goto fail;
     }
-  if (fga_dgenome_upload(Z->dev,Z->g1,Z->x1->perm,Z->x1->nctg,1,&Z->dg1)) goto fail;
+  /* the bases an index build left on the device are taken over (the call owns the image from here on, also when it fails) */
+  { void *im = img1;
+    img1 = NULL;
+    if (im != NULL ? fga_dgenome_adopt(Z->dev,Z->g1,Z->x1->perm,Z->x1->nctg,1,im,&Z->dg1)
+                   : fga_dgenome_upload(Z->dev,Z->g1,Z->x1->perm,Z->x1->nctg,1,&Z->dg1)) goto fail;
+  }
   if (Z->self)
     Z->dg2 = Z->dg1;
-  else if (fga_dgenome_upload(Z->dev,Z->g2,Z->x2->perm,Z->x2->nctg,1,&Z->dg2)) goto fail;
+  else
+    { void *im = img2;
+      img2 = NULL;
+      if (im != NULL ? fga_dgenome_adopt(Z->dev,Z->g2,Z->x2->perm,Z->x2->nctg,1,im,&Z->dg2)
+                     : fga_dgenome_upload(Z->dev,Z->g2,Z->x2->perm,Z->x2->nctg,1,&Z->dg2)) goto fail;
+    }
   Z->upload_s = fga_wall() - t0;
   *out = Z;
   return 0;
 fail:
+  if (img1 != NULL && Z != NULL && Z->dev != NULL) fga_dev_free(Z->dev,img1);
+  if (img2 != NULL && Z != NULL && Z->dev != NULL) fga_dev_free(Z->dev,img2);
   fga_session_close(Z);
   return 1;
 }

@@ -126,6 +126,10 @@ int   fga_gix_write_files(const fga_gix *gix, const char *target);
 int   fga_dgix_upload_range(fga_dev *dev, const fga_gix *gix, int64_t pbeg, int64_t pend, fga_dgix **out);
 int   fga_dgix_build_range(fga_dev *dev, const fga_gdb *gdb, int nthreads, int flags, int64_t pbeg, int64_t pend,
                            fga_dgix **dgix, fga_gix **gix);
+/* fga_dgix_build (pbeg = 0, pend = 2^24) / fga_dgix_build_range that leaves the genome's bases on the device, laid out for
+ * fga_dgenome_adopt: they cross PCIe once per session */
+int     fga_dgix_build_keep(fga_dev *dev, const fga_gdb *gdb, int nthreads, int flags, int64_t pbeg, int64_t pend,
+                            fga_dgix **out, fga_gix **host_meta, void **image);
 int   fga_dgix_prefix_counts(fga_dev *dev, const fga_gdb *gdb, int nthreads, uint32_t *counts /* host, 2^24 */);
 
 /* Adaptive seed merge: replaces adaptamer_merge -> new_merge_thread (FastGA.c:2281, 610) and, with
@@ -241,6 +245,10 @@ typedef struct
 int  fga_align_spec(double ave_corr, int tspace, const float *freq4, int *path_ave, int16_t *table, int16_t *score);
 int  fga_dgenome_upload(fga_dev *dev, const fga_gdb *gdb, const int *perm, int nperm, int want_revcomp,
                         fga_dgenome **out);
+/* the same over bases that are on the device already: `image` is what fga_dgix_build_keep returned for the same GDB (bpslen
+ * bytes between two zero pads); the genome owns it from the call on, also when the call fails */
+int     fga_dgenome_adopt(fga_dev *dev, const fga_gdb *gdb, const int *perm, int nperm, int want_revcomp, void *image,
+                          fga_dgenome **out);
 void fga_dgenome_free(fga_dgenome *g);
 int  fga_extend(fga_dev *dev, const fga_dgenome *ga, const fga_dgenome *gb, const fga_hits *hits,
                 const fga_extend_params *prm, fga_alns **out);
