@@ -101,3 +101,27 @@ def test_reads_codec_compressed_1gdb(tmp_path, built_library):
     ref = [ln for ln in H.oneview(os.path.join(w, "many.1gdb")) if ln[:1] in "SGCf"]
     assert ours == ref and len(ours) == 12001
     g.close()
+
+
+def test_gdb_open_reads_a_large_image_with_several_threads(tmp_path, built_library):
+    """fga_gdb_open reads a .bps of 64 MB and more in eight slices with pread: a 300 Mbp genome (75 MB of packed bases)
+    comes back exactly as the bytes of the file say, contig by contig, first / middle / last contig and the slice seams"""
+    import numpy as np
+    from fastga_amd import workload
+    from fastga_amd.gixio import Gdb
+    d = str(tmp_path)
+    ra, _ = workload.build_config4(d, mbp=300.0, divergence=0.01, ncontig=12, threads=8, names=("A", "A2"))
+    raw = np.fromfile(os.path.join(d, ".A.bps"), dtype=np.uint8)
+    assert len(raw) >= 64 << 20
+    g = Gdb(ra + ".gdb")
+    off = 0
+    for c in range(g.ncontig):
+        n = int(g.clen[c])
+        nb = (n + 3) // 4
+        if c in (0, g.ncontig // 2, g.ncontig - 1) or any(off <= len(raw) * k // 8 < off + nb for k in range(1, 8)):
+            packed = raw[off:off + nb]
+            want = ((packed[:, None] >> (2 * np.arange(4, dtype=np.uint8))) & 3).reshape(-1)[:n]
+            assert np.array_equal(g.contig(c), want), c
+        off += nb
+    assert off == len(raw)
+    g.close()
