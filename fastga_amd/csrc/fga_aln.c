@@ -788,7 +788,7 @@ int fga_write_1aln_binary(const char *path, const fga_gdb *g1, const fga_gdb *g2
 oom:
   fga_set_error("out of memory");
 done:
-  for (q = 0; q < 8; q++) { free(job[q].B.p); free(job[q].rel); free(job[q].tmp); }
+  for (q = 0; q < WRITER_MAXT; q++) { free(job[q].B.p); free(job[q].rel); free(job[q].tmp); }
   free(H.p); free(B.p); free(F.p);
   free(goff); free(soff); free(aoff);
   return rc;
