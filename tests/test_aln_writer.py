@@ -80,3 +80,66 @@ def test_writers_round_trip_through_reference_tools(toy_pair, tmp_path, built_li
     g1.close()
     if g2 is not None:
         g2.close()
+
+
+@needs_ref
+def test_binary_writer_on_many_threads_writes_the_same_file(toy_pair, tmp_path, built_library):
+    """the binary container's records are formatted by 1 / 8 / 32 / 64 threads (sets beyond 200 k trace points): the same
+    bytes apart from the provenance line's time stamp, and the reference's ONEview reads all of it back -- 60 k synthetic
+    records with traces of 2-40 panels inside the toy pair's contigs"""
+    from fastga_amd.lib import Alns
+    from fastga_amd.device import ALN_DTYPE
+    from fastga_amd.gixio import Gdb
+    from tests.test_aln_reader import read_1aln
+    L = built_library
+    d, ra, rb = toy_pair
+    g1, g2 = Gdb(ra + ".gdb"), Gdb(rb + ".gdb")
+    rng = np.random.default_rng(12)
+    n = 60_000
+    recs = np.zeros(n, dtype=ALN_DTYPE)
+    recs["aread"] = np.sort(rng.integers(0, g1.ncontig, n))
+    recs["bread"] = rng.integers(0, g2.ncontig, n)
+    recs["flags"] = rng.integers(0, 2, n)
+    npan = rng.integers(1, 21, n)
+    recs["tlen"] = 2 * npan
+    pieces, off = [], 0
+    for i in range(n):
+        la, lb = int(g1.clen[recs["aread"][i]]), int(g2.clen[recs["bread"][i]])
+        k = int(min(npan[i], la // 100 - 2, lb // 110 - 2))
+        k = max(k, 1)
+        recs["tlen"][i] = 2 * k
+        ab = 100 * int(rng.integers(0, la // 100 - k))
+        bb = int(rng.integers(0, lb - 110 * k))
+        t = np.empty(2 * k, dtype=np.uint8)
+        t[0::2] = rng.integers(0, 12, k)
+        t[1::2] = rng.integers(95, 106, k)
+        recs["abpos"][i], recs["aepos"][i] = ab, ab + 100 * k
+        recs["bbpos"][i], recs["bepos"][i] = bb, bb + int(t[1::2].sum())
+        recs["diffs"][i] = int(t[0::2].sum())
+        recs["toff"][i] = off
+        pieces.append(t)
+        off += 2 * k
+    recs["unit"], recs["seq"] = -1, np.arange(n)
+    tb = np.concatenate(pieces)
+    assert len(tb) // 2 > 200_000
+    A = Alns(n, len(tb), 0, 0, recs.ctypes.data, tb.ctypes.data)
+    files = []
+    try:
+        for nt in (1, 8, 32, 64):
+            L.fga_aln_writer_threads(nt)
+            p = str(tmp_path / f"w{nt}.1aln")
+            assert L.fga_write_1aln_binary(p.encode(), g1.h, g2.h, C.byref(A), 100, ra.encode(), rb.encode(), b"test") == 0
+            files.append(open(p, "rb").read())
+    finally:
+        L.fga_aln_writer_threads(8)
+    import re
+    strip = lambda b: re.sub(rb"\n! [^\n]*\n", b"\n!\n", b, count=1)        # noqa: E731  (the time stamp)
+    assert all(strip(f) == strip(files[0]) for f in files[1:])
+    a, t, ts, _, _ = read_1aln(L, str(tmp_path / "w32.1aln"))
+    assert ts == 100 and np.array_equal(t, tb)
+    for f in ("tlen", "diffs", "abpos", "bbpos", "aepos", "bepos", "aread", "bread"):
+        assert np.array_equal(a[f], recs[f]), f
+    assert np.array_equal(a["flags"] & 1, recs["flags"] & 1)
+    txt = H.oneview(str(tmp_path / "w64.1aln"))
+    assert sum(1 for ln in txt if ln[0] == "A") == n
+    g1.close(); g2.close()
