@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the FastGA seed-and-extend hot path on MI355X.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under
-torch.distributed.run, one rank per GPU.  A *step* is one pass of the hot path -- seed merge -> sort -> chain scan ->
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches it under
+torch.distributed.run, one rank per GPU -- and when it is started WITHOUT a launcher it starts its N ranks itself the same
+way (WORLD_SIZE must equal --gpus, anything else is refused).  A *step* is one pass of the hot path -- seed merge -> sort -> chain scan ->
 wave extension -> redundancy filter -> .1aln written -- over ONE synthetic genome pair whose 2-bit genomes and GIX
 tables are already resident in HBM (uploaded / built on the device before the timed region; no index files).
 
@@ -119,11 +120,33 @@ def cpu_baseline(args, mbp, ra, rb, workdir, ours_1aln):
             "sample": f"oracle seed-merge restatement only, 1/16 of the k-mer prefix space, {dt:.1f} s"}
 
 
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, exactly the way the
+    driver does (one process per GPU under torch.distributed.run on 127.0.0.1), and hand its exit code back."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s): one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     dist = None
     if world > 1 or args.force_sharded:
         # torch FIRST: one HIP runtime per process (fastga_amd/lib.py::load_library)
@@ -305,6 +328,22 @@ def main():
                     out[key] = human_scale_run(D, workload, shared, threads, div, project=(div == 0.01))
                 except Exception as e:            # never takes the bench line down
                     out[key] = {"error": str(e)}
+    # N > 1: parity of the step that was timed (the sharded .1aln against the same comparison on one GPU, record lines in
+    # sequence), and the same comparison through fga_run_multi -- the C-ABI's own multi-GPU entry, what FastGA -G<N> runs
+    if dist is not None and os.environ.get("FGA_BENCH_VERIFY", "1") != "0":
+        try:
+            if ses is not None:
+                ses.close()
+                ses = None
+            got = file_digest(workload, out1aln) if rank == 0 else None
+            par = verify_sharded_step(D, workload, dist, kw, ra, rb, got, shared, threads, rank, world, local)
+            mul = c_abi_multi_leg(D, workload, dist, ra, rb, shared, threads, rank, world, mbp * 1e-3, threads, compare_with=got)
+            if rank == 0:
+                out["parity"] = par
+                out["c_abi_multi"] = mul
+        except Exception as e:                    # never takes the bench line down
+            if rank == 0:
+                out["parity"] = {"error": str(e)}
     # N > 1: the comparison north_star names -- ONE 3 Gbp x 3 Gbp pair cut over the N GPUs (strong scaling), beside the
     # weak-scaled `value` above.  Every rank opens a sliced session (its 12-mer prefix range of both tables, built on the
     # device) and runs run_sharded once warm; the cold span is the open + that run.  FGA_BENCH_SHARDED_3G=0 skips it.
@@ -328,6 +367,77 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def file_digest(workload, path, golden_keys=False):
+    """digest of a .1aln for the parity checks of the N > 1 legs: ONEview's text (comparable with tests/golden/*_digest.json,
+    `lines_md5` = the record lines in sequence) when the reference's viewer travelled, this library's own reader otherwise"""
+    from oracle import harness as H
+    if os.path.exists(H.ref_bin("ONEview")):
+        return workload.digest_1aln_stream(path, H.ref_bin("ONEview"))
+    if golden_keys:
+        return None
+    return workload.digest_1aln_records(path)
+
+
+def verify_sharded_step(D, workload, dist, ses_kw, ra, rb, got, workdir, threads, rank, world, local):
+    """Parity of the N-rank step: the SAME comparison once more on rank 0's GPU alone (whole tables, fga_session_run) must
+    give the file the sharded step wrote, record line for record line.  (The one-GPU path is what the test suite pins to the
+    reference; at N x 100 Mbp no golden digest exists.)  The other ranks wait."""
+    import torch
+    res = None
+    if rank == 0:
+        try:
+            one = os.path.join(workdir, "one_gpu.1aln")
+            ses = D.Session(ra, rb, device=local, nthreads=threads)
+            kw = dict(ses_kw); kw["out_path"] = one
+            t = time.time()
+            st = ses.run(**kw)
+            dt = time.time() - t
+            ses.close()
+            exp = file_digest(workload, one)
+            res = {"sharded_equals_one_gpu_run": bool(got == exp), "records": int(st["nlive"]),
+                   "one_gpu_seconds_first_run": round(dt, 3),
+                   "digest": {k: got[k] for k in got if k in ("records", "lines_md5", "order_md5", "fields_md5", "trace_md5")},
+                   "how": "the step's .1aln vs fga_session_run of the same pair on one GPU: record lines in sequence"}
+        except Exception as e:
+            res = {"error": str(e)}
+    dist.barrier()
+    torch.cuda.synchronize()
+    return res
+
+
+def c_abi_multi_leg(D, workload, dist, ra, rb, workdir, threads, rank, world, gbp, ref_threads, compare_with=None, golden=None):
+    """The same comparison through the C-ABI's own multi-GPU entry, fga_run_multi -- what `FastGA -G<world>` runs: ONE
+    process (rank 0's; the other ranks have released their sessions and wait), one host thread + HIP stream per device,
+    seeds exchanged with hipMemcpyPeerAsync, no torch, no RCCL.  Cold by construction (it opens and closes its sessions)."""
+    import torch
+    res = None
+    torch.cuda.empty_cache()
+    dist.barrier()
+    if rank == 0:
+        try:
+            out = os.path.join(workdir, "c_abi_multi.1aln")
+            t = time.time()
+            devs = tuple(int(x) for x in os.environ["FGA_BENCH_MULTI_DEVICES"].split(",")) \
+                if os.environ.get("FGA_BENCH_MULTI_DEVICES") else tuple(range(world))      # "0,0": ranks sharing a GPU (a code-path check)
+            st = D.run_multi(ra, rb, out, devices=devs, nthreads=threads, reference_threads=ref_threads,
+                             command_line="bench.py FastGA -G%d" % world)
+            dt = time.time() - t
+            res = {"entry": "fga_run_multi (one process, devices %s, hipMemcpyPeerAsync exchange)" % (list(devs),),
+                   "seconds_cold": round(dt, 3), "value_cold": gbp / dt, "unit": "Gbp-pair/s", "records": int(st["nlive"]),
+                   "stage_s_max_over_ranks": {k: round(st[k], 3) for k in ("merge_s", "sort_s", "chain_s", "extend_s", "filter_s", "write_s")},
+                   "open_s": round(st["upload_s"], 3)}
+            got = file_digest(workload, out, golden_keys=golden is not None)
+            if golden is not None and got is not None:
+                res["digest_equals_reference"] = all(got[k] == golden[k] for k in ("records", "header_md5", "records_sum128", "order_md5", "lines_md5"))
+            elif compare_with is not None:
+                res["equals_sharded_step"] = bool(got == compare_with)
+            os.unlink(out)
+        except Exception as e:
+            res = {"error": str(e)}
+    dist.barrier()
+    return res
 
 
 def sharded_human_scale(D, workload, dist, workdir, threads, rank, world, local):
@@ -370,6 +480,7 @@ def sharded_human_scale(D, workload, dist, workdir, threads, rank, world, local)
             times.append(float(tt.item()))
         ses.close()
         res = None
+        golden = None
         if rank == 0:
             dt = min(times)
             res = {"workload": f"synthetic {gbp:g} Gbp vs {gbp:g} Gbp, 1% divergence, 32 contigs, 45% repeats (BASELINE configs[3]): "
@@ -382,11 +493,27 @@ def sharded_human_scale(D, workload, dist, workdir, threads, rank, world, local)
             gold = os.path.join(ROOT, "tests", "golden", "config4_3000m_digest.json")
             if os.path.exists(gold) and abs(gbp - 3.0) < 1e-9:
                 g = json.load(open(gold))
+                golden = g
                 res["records_equal_reference"] = bool(last["nlive"] == g["records"])
+                # the parity gate of the leg: header, records as a multiset, (aread, abpos) order and the record LINES in
+                # sequence against the digest the real reference's file gave (tests/golden/make_golden_config4.py)
+                try:
+                    got = file_digest(workload, out, golden_keys=True)
+                    if got is not None:
+                        res["digest_equals_reference"] = all(got[k] == g[k] for k in
+                                                              ("records", "header_md5", "records_sum128", "order_md5", "lines_md5"))
+                        res["lines_md5"] = got["lines_md5"]
+                    else:
+                        res["digest_equals_reference"] = None      # oracle/_ref/ONEview did not travel
+                except Exception as e:
+                    res["digest_error"] = str(e)
                 if g.get("reference_seconds"):
                     res["reference_seconds"] = g["reference_seconds"]
                     res["vs_reference_warm"] = g["reference_seconds"] / dt
                     res["cold"]["vs_reference"] = g["reference_seconds"] / (opened + dt)
+        multi = c_abi_multi_leg(D, workload, dist, ra, rb, d, threads, rank, world, gbp, 32, golden=golden)
+        if rank == 0 and res is not None:
+            res["c_abi_multi"] = multi
         return res
     finally:
         dist.barrier()
@@ -428,7 +555,10 @@ def project_8gpu(st8, nparts):
     GPU (parallel.run_parts_on_one_gpu): slowest phase 1 + the all-to-all-v at one xGMI link per directed pair + slowest
     phase 2 (+ its filter) + the gather of the surviving records + the merge by A contig and the write on rank 0"""
     pr = st8["per_rank"]
-    phase1 = [m + s for m, s in zip(pr["merge_s"], pr["split_s"])]
+    # (what a rank of the emulation waited for the driver is not part of a real rank's phase 1: the emulation holds all
+    # ranks' buffers on one device)
+    drv = pr.get("merge_driver_alloc_s", [0.0] * nparts)
+    phase1 = [m - w + s for m, w, s in zip(pr["merge_s"], drv, pr["split_s"])]
     sent = st8["sent_bytes"]
     link = max(max(sent[r][p] for p in range(nparts) if p != r) for r in range(nparts)) if nparts > 1 else 0
     phase2 = [a + f for a, f in zip(pr["align_s"], pr["filter_s"])]
@@ -438,6 +568,7 @@ def project_8gpu(st8, nparts):
             "is": "a PROJECTION from 8 prefix ranges x 8 parts run one after the other on this GPU (index builds excluded: "
                   "each rank builds 1/8 of both tables); not a measurement on 8 GPUs",
             "phase1_s_max": round(max(phase1), 3), "phase1_s": [round(x, 3) for x in phase1],
+            "phase1_driver_alloc_s_excluded": [round(x, 3) for x in drv],
             "exchange_s": round(link / (XGMI_LINK_GBS * 1e9), 4), "largest_directed_pair_bytes": int(link),
             "phase2_s_max": round(max(phase2), 3), "phase2_s": [round(x, 3) for x in phase2],
             "gather_s": round(gather, 4), "finish_s": round(st8["finish_s"], 3),

@@ -293,6 +293,35 @@ extern "C" void fga_dev_close(fga_dev *d)
   free(d);
 }
 
+// direct loads / copies between this device and `peer` over xGMI (hipMemcpyPeerAsync works without, through the host); an
+// access that is enabled already, or a peer that is this very device, is fine
+extern "C" int fga_dev_enable_peer(fga_dev *d, int peer)
+{ FGA_HIP(hipSetDevice(d->device));
+  if (peer == d->device)
+    return 0;
+  int can = 0;
+  if (hipDeviceCanAccessPeer(&can,d->device,peer) != hipSuccess || !can)
+    { (void) hipGetLastError();
+      return 0;                       // no direct path: the copies are staged by the runtime
+    }
+  const hipError_t e = hipDeviceEnablePeerAccess(peer,0);
+  if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+    { fga_set_error("hipDeviceEnablePeerAccess(%d -> %d): %s",d->device,peer,hipGetErrorString(e));
+      return 1;
+    }
+  (void) hipGetLastError();
+  return 0;
+}
+
+extern "C" int fga_dev_device_count(void)
+{ int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess)
+    { (void) hipGetLastError();
+      return 0;
+    }
+  return n;
+}
+
 extern "C" int fga_dev_sync(fga_dev *d)
 { FGA_HIP(hipSetDevice(d->device));
   FGA_HIP(hipStreamSynchronize(d->stream));

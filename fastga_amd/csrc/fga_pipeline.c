@@ -18,6 +18,7 @@
 
 #include "fga_host.h"
 #include "fastga_amd.h"
+#include "fga_session.h"
 
 /* the redundancy filter of one part's records on a thread of its own, while the next part's kernels run */
 typedef struct
@@ -39,33 +40,19 @@ static void *part_filter_main(void *arg)
   return NULL;
 }
 
-struct fga_session
-  { fga_gdb *g1, *g2;
-    fga_gix *x1, *x2;
-    fga_dev *dev;
-    fga_dgix *d1, *d2;
-    fga_dgenome *dg1, *dg2;
-    int self;
-    int devbuilt;              /* an index was built on the device (no soft-mask bytes in it) */
-    double load_s, upload_s;
-    int nranks, rank;          /* > 1: the session holds the rank's 12-mer prefix range of both tables only */
-    int64_t *cuts;             /* [nranks+1] the prefix ranges of all ranks */
-    int64_t *scount;           /* [2*nctg] seeds per (strand, A contig) of the merges so far (reference order only) */
-  };
-
 void fga_session_close(fga_session *Z)
 { if (Z == NULL) return;
   if (Z->dg2 != Z->dg1) fga_dgenome_free(Z->dg2);
   fga_dgenome_free(Z->dg1);
   fga_dgix_free(Z->d2); fga_dgix_free(Z->d1);
   fga_dev_close(Z->dev);
-  fga_gix_close(Z->x2); fga_gix_close(Z->x1);
-  fga_gdb_close(Z->g2); fga_gdb_close(Z->g1);
+  if (!Z->borrowed_gix) { fga_gix_close(Z->x2); fga_gix_close(Z->x1); }
+  if (!Z->borrowed_gdb) { fga_gdb_close(Z->g2); fga_gdb_close(Z->g1); }
   free(Z->cuts); free(Z->scount);
   free(Z);
 }
 
-static int gix_exists(const char *root)
+int fga_gix_files_exist(const char *root)
 { char *p = NULL;
   size_t n = strlen(root);
   int ok;
@@ -83,23 +70,20 @@ int fga_session_open(const char *root1, const char *root2, int device, fga_sessi
 
 /* nthreads: GIXmake's -T for an index the session has to build itself -- it decides the contig padding of a short GDB
    and the table parts (SURVEY.md hard part 9), i.e. the layout FastGA -T<n> would have got from its GIXmake call */
-typedef struct { const char *const *m1; int n1; const char *const *m2; int n2; } mask_args;
-static int session_open_impl(const char *root1, const char *root2, int device, int nthreads, int rank, int nranks, int flags,
-                             const mask_args *masks, fga_session **out);
 
 int fga_session_open_threads(const char *root1, const char *root2, int device, int nthreads, fga_session **out)
-{ return session_open_impl(root1,root2,device,nthreads,0,1,0,NULL,out); }
+{ return fga_session_open_impl(root1,root2,device,nthreads,0,1,0,NULL,NULL,out); }
 
 /* flags: FGA_SESSION_BUILD_INDEX -- the genome indices are built on the device even when <root>.gix files exist (they may
    be another program's: a parity run against the reference's own GIXmake output) */
 int fga_session_open_flags(const char *root1, const char *root2, int device, int nthreads, int flags, fga_session **out)
-{ return session_open_impl(root1,root2,device,nthreads,0,1,flags,NULL,out); }
+{ return fga_session_open_impl(root1,root2,device,nthreads,0,1,flags,NULL,NULL,out); }
 
 int fga_session_open_masked(const char *root1, const char *root2, int device, int nthreads, int flags,
                             const char *const *masks1, int nmasks1, const char *const *masks2, int nmasks2, fga_session **out)
-{ mask_args M;
+{ fga_mask_args M;
   M.m1 = masks1; M.n1 = nmasks1; M.m2 = masks2; M.n2 = nmasks2;
-  return session_open_impl(root1,root2,device,nthreads,0,1,flags,&M,out);
+  return fga_session_open_impl(root1,root2,device,nthreads,0,1,flags,&M,NULL,out);
 }
 
 int fga_session_open_sliced(const char *root1, const char *root2, int device, int nthreads, int rank, int nranks,
@@ -109,7 +93,7 @@ int fga_session_open_sliced(const char *root1, const char *root2, int device, in
       *out = NULL;
       return 1;
     }
-  return session_open_impl(root1,root2,device,nthreads,rank,nranks,0,NULL,out);
+  return fga_session_open_impl(root1,root2,device,nthreads,rank,nranks,0,NULL,NULL,out);
 }
 
 /* prefix ranges of equal merge cost (entries of both tables + 2 per prefix) from the tables' per-prefix entry counts:
@@ -142,8 +126,8 @@ static void cuts_from_counts(const int64_t *idx1, const int64_t *idx2, const uin
     if (cuts[w] < cuts[w-1]) cuts[w] = cuts[w-1];
 }
 
-static int session_open_impl(const char *root1, const char *root2, int device, int nthreads, int rank, int nranks, int flags,
-                             const mask_args *masks, fga_session **out)
+int fga_session_open_impl(const char *root1, const char *root2, int device, int nthreads, int rank, int nranks, int flags,
+                          const fga_mask_args *masks, const fga_shared_inputs *shared, fga_session **out)
 { fga_session *Z = calloc(1,sizeof(fga_session));
   void *img1 = NULL, *img2 = NULL;         /* the genomes' bases an index build left on the device */
   double t0;
@@ -157,16 +141,28 @@ static int session_open_impl(const char *root1, const char *root2, int device, i
   /* an index file is loaded when it is there; otherwise the index is built on the device from the GDB, straight
      into HBM (no .gix/.ktab files appear, like the reference without -k) */
   { const int build = (flags & FGA_SESSION_BUILD_INDEX) != 0;
-    int have1 = !build && gix_exists(root1), have2 = Z->self ? 1 : (!build && gix_exists(root2));
+    int have1 = !build && fga_gix_files_exist(root1), have2 = Z->self ? 1 : (!build && fga_gix_files_exist(root2));
     /* a genome with masks named gets its index built anew with their union as its soft mask (the reference runs GIXmake
        with the masks, FastGA.c:4739-4776) */
     if (masks != NULL && masks->n1 > 0) have1 = 0;
     if (masks != NULL && masks->n2 > 0 && !Z->self) have2 = 0;
-    if (fga_gdb_open(root1,&Z->g1) || (masks != NULL && masks->n1 > 0 && fga_gdb_apply_masks(Z->g1,masks->m1,masks->n1)) ||
-        (have1 && fga_gix_open(root1,&Z->x1))) goto fail;
-    if (!Z->self)
-      { if (fga_gdb_open(root2,&Z->g2) || (masks != NULL && masks->n2 > 0 && fga_gdb_apply_masks(Z->g2,masks->m2,masks->n2)) ||
-            (have2 && fga_gix_open(root2,&Z->x2))) goto fail;
+    if (shared != NULL && shared->g1 != NULL)           /* opened (and masked) once by the caller for all of its ranks */
+      { Z->borrowed_gdb = 1;
+        Z->g1 = shared->g1; Z->g2 = Z->self ? NULL : shared->g2;
+        if (have1 && (Z->self || have2) && shared->x1 != NULL && (Z->self || shared->x2 != NULL))
+          { Z->borrowed_gix = 1;
+            Z->x1 = shared->x1; Z->x2 = Z->self ? NULL : shared->x2;
+          }
+        else if ((have1 && fga_gix_open(root1,&Z->x1)) || (!Z->self && have2 && fga_gix_open(root2,&Z->x2)))
+          goto fail;
+      }
+    else
+      { if (fga_gdb_open(root1,&Z->g1) || (masks != NULL && masks->n1 > 0 && fga_gdb_apply_masks(Z->g1,masks->m1,masks->n1)) ||
+            (have1 && fga_gix_open(root1,&Z->x1))) goto fail;
+        if (!Z->self)
+          { if (fga_gdb_open(root2,&Z->g2) || (masks != NULL && masks->n2 > 0 && fga_gdb_apply_masks(Z->g2,masks->m2,masks->n2)) ||
+                (have2 && fga_gix_open(root2,&Z->x2))) goto fail;
+          }
       }
     Z->load_s = fga_wall() - t0;
     if (fga_dev_open(device,&Z->dev)) goto fail;
@@ -812,7 +808,13 @@ int fga_run(const char *root1, const char *root2, const fga_run_params *P, fga_r
   if (fga_session_open_masked(root1,root2,P->device,P->nthreads > 0 ? P->nthreads : 8,
                               P->build_index ? FGA_SESSION_BUILD_INDEX : 0,P->masks1,P->nmasks1,P->masks2,P->nmasks2,&Z))
     return 1;
-  rc = fga_session_run(Z,P,S);
+  if ((P->nmasks1 > 0 || P->nmasks2 > 0) && !P->soft_mask)
+    { fga_run_params Q = *P;            /* masks named: the comparison runs with soft masking on (FastGA.c:4580) */
+      Q.soft_mask = 1;
+      rc = fga_session_run(Z,&Q,S);
+    }
+  else
+    rc = fga_session_run(Z,P,S);
   fga_session_close(Z);
   return rc;
 }

@@ -189,8 +189,27 @@ extern "C" int fga_seeds_split_to(fga_dev *dev, const fga_dseeds *S, const int *
   return 0;
 }
 
+static int seeds_import(fga_dev *dev, const void *const *src_device, const int *src_ids, const int64_t *counts, int npieces,
+                        fga_dseeds **out);
+
 extern "C" int fga_seeds_import(fga_dev *dev, const void *const *src_device, const int64_t *counts, int npieces,
                                 fga_dseeds **out)
+{ return seeds_import(dev,src_device,NULL,counts,npieces,out); }
+
+// the same for pieces that lie in the memory of OTHER devices of the node (src_device_id[k] = HIP device of piece k): the
+// receiving side of the seed exchange of fga_run_multi, hipMemcpyPeerAsync over xGMI
+extern "C" int fga_seeds_import_peer(fga_dev *dev, const void *const *src_device, const int *src_device_id,
+                                     const int64_t *counts, int npieces, fga_dseeds **out)
+{ if (npieces > 0 && src_device_id == NULL)
+    { fga_set_error("fga_seeds_import_peer: bad argument");
+      *out = NULL;
+      return 1;
+    }
+  return seeds_import(dev,src_device,src_device_id,counts,npieces,out);
+}
+
+static int seeds_import(fga_dev *dev, const void *const *src_device, const int *src_ids, const int64_t *counts, int npieces,
+                        fga_dseeds **out)
 { *out = NULL;
   if (dev == NULL || npieces < 0 || (npieces > 0 && (src_device == NULL || counts == NULL)))
     { fga_set_error("fga_seeds_import: bad argument");
@@ -225,7 +244,9 @@ extern "C" int fga_seeds_import(fga_dev *dev, const void *const *src_device, con
   int64_t at = 0;
   for (int k = 0; k < npieces && e == hipSuccess; k++)
     { if (counts[k] > 0)
-        e = hipMemcpyAsync(S->seeds + at,src_device[k],sizeof(fga_seed)*(size_t) counts[k],hipMemcpyDeviceToDevice,dev->stream);
+        e = (src_ids != NULL && src_ids[k] != dev->device)
+              ? hipMemcpyPeerAsync(S->seeds + at,dev->device,src_device[k],src_ids[k],sizeof(fga_seed)*(size_t) counts[k],dev->stream)
+              : hipMemcpyAsync(S->seeds + at,src_device[k],sizeof(fga_seed)*(size_t) counts[k],hipMemcpyDeviceToDevice,dev->stream);
       at += counts[k];
     }
   if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);

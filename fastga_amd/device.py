@@ -331,6 +331,31 @@ def run(root1, root2=None, out_path=None, device=0, freq=10, soft_mask=False, sy
     return {n: getattr(st, n) for n, _ in RunStats._fields_}
 
 
+def run_multi(root1, root2=None, out_path=None, devices=(0,), freq=10, soft_mask=False, symmetric=False,
+              chain_break=1000, chain_min=85, align_min=100, identity=0.7, nthreads=8, command_line="FastGA",
+              paf_path=None, paf_flags=0, reference_threads=0, build_index=False, masks1=None, masks2=None):
+    """fga_run_multi: ONE comparison cut over `devices` (HIP device numbers; they may repeat -- ranks sharing a GPU) from this
+    one process: one host thread + stream per device, seeds exchanged by A-contig part with hipMemcpyPeerAsync, one .1aln.
+    The result does not depend on the number of devices.  Returns the stats as a dict."""
+    from .lib import RunParams, RunStats
+    L = load_library()
+    def cstrs(paths):
+        if not paths:
+            return None, 0
+        return (C.c_char_p * len(paths))(*[p.encode() for p in paths]), len(paths)
+    m1, n1 = cstrs(masks1)
+    m2, n2 = cstrs(masks2)
+    prm = RunParams(0, freq, int(soft_mask), int(symmetric), 2 * chain_break, 2 * chain_min, align_min,
+                    1.0 - identity, nthreads, out_path.encode() if out_path else None, command_line.encode(),
+                    paf_path.encode() if paf_path else None, paf_flags, 0, int(build_index), m1, n1, m2, n2,
+                    reference_threads)
+    devs = (C.c_int * max(len(devices), 1))(*[int(d) for d in devices])
+    st = RunStats()
+    check(L.fga_run_multi(root1.encode(), root2.encode() if root2 else None, C.byref(prm), len(devices), devs,
+                          C.byref(st)), "fga_run_multi")
+    return {n: getattr(st, n) for n, _ in RunStats._fields_}
+
+
 class Session:
     """inputs resident in HBM; run() is one pass of the hot path (fga_session_*)."""
 

@@ -194,6 +194,10 @@ def _declare(L):
         "fga_read_1aln": (i32, [cp, P(P(Alns)), P(i32), P(cp), P(cp)]),
         "fga_gap_improve": (i32, [vp, vp, P(Alns), P(Traces)]),
         "fga_run": (i32, [cp, cp, P(RunParams), P(RunStats)]),
+        "fga_run_multi": (i32, [cp, cp, P(RunParams), i32, P(i32), P(RunStats)]),
+        "fga_seeds_import_peer": (i32, [vp, P(vp), P(i32), P(i64), i32, P(vp)]),
+        "fga_dev_enable_peer": (i32, [vp, i32]),
+        "fga_dev_device_count": (i32, []),
         "fga_session_open": (i32, [cp, cp, i32, P(vp)]),
         "fga_session_open_threads": (i32, [cp, cp, i32, i32, P(vp)]),
         "fga_session_open_flags": (i32, [cp, cp, i32, i32, i32, P(vp)]),

@@ -226,12 +226,16 @@ def run_parts_on_one_gpu(ses, nparts, **prm_kwargs):
     sends, offs, hist = [], [], np.zeros(ses.nctg, dtype=np.int64)
     merged = []
     per_rank = {"merge_s": [], "split_s": [], "align_s": [], "sort_s": [], "chain_s": [], "extend_s": [], "filter_s": [],
-                "extend_kernel_ms": [], "wave_steps": [], "records": []}
+                "extend_kernel_ms": [], "wave_steps": [], "records": [], "merge_driver_alloc_s": []}
     for r in range(nparts):                                   # "rank r": phase 1 on its prefix range
         t = time.time()
+        w = ses.L.fga_dev_driver_seconds()
         seeds = ses.merge(prm, st, int(cuts[r]), int(cuts[r + 1]))
         hist += ses.contig_histogram(seeds)
         per_rank["merge_s"].append(time.time() - t)
+        # seconds of this rank's phase 1 spent inside hipMalloc: on ONE GPU the emulation keeps every rank's seed and send
+        # buffers alive side by side, so late ranks may have to ask the driver for a fresh region (a real rank never does)
+        per_rank["merge_driver_alloc_s"].append(ses.L.fga_dev_driver_seconds() - w)
         merged.append((seeds, ses.dev_malloc(16 * seeds.count)))
     select = partition_contigs(hist, nparts)
     for seeds, buf in merged:

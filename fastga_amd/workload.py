@@ -155,3 +155,29 @@ def digest_1aln_stream(path, oneview_bin):
         raise RuntimeError(f"{oneview_bin} {path} failed")
     return {"records": nrec, "header_md5": head.hexdigest(), "records_sum128": f"{total:032x}",
             "order_md5": order.hexdigest(), "lines_md5": seq.hexdigest()}      # lines_md5: the record lines in sequence
+
+
+def digest_1aln_records(path):
+    """A digest of a .1aln through this library's own reader (fga_read_1aln; no reference tool needed): record count, md5 of
+    the records' nine fields in file order, md5 of all trace bytes in file order.  Two files with the same digest hold the
+    same records in the same sequence; it is not comparable with digest_1aln's ONEview-text digests."""
+    import ctypes as C
+    import hashlib
+    import numpy as np
+    from .lib import load_library, Alns, check
+    from .device import ALN_DTYPE
+    L = load_library()
+    out = C.POINTER(Alns)()
+    check(L.fga_read_1aln(path.encode(), C.byref(out), None, None, None), "fga_read_1aln")
+    o = out.contents
+    a = np.frombuffer((C.c_char * (o.naln * ALN_DTYPE.itemsize)).from_address(o.alns), dtype=ALN_DTYPE) \
+        if o.naln else np.zeros(0, ALN_DTYPE)
+    h = hashlib.md5()
+    for f in ("aread", "bread", "abpos", "bbpos", "aepos", "bepos", "flags", "diffs", "tlen"):
+        h.update(np.ascontiguousarray(a[f]).tobytes())
+    t = hashlib.md5()
+    if o.ntrace:
+        t.update((C.c_char * o.ntrace).from_address(o.tbytes))
+    res = {"records": int(o.naln), "fields_md5": h.hexdigest(), "trace_md5": t.hexdigest()}
+    L.fga_alns_free(out)
+    return res

@@ -434,6 +434,23 @@ int  fga_alns_concat(const fga_alns *const *raw, int nraw, fga_alns **out);
 int  fga_alns_merge_filtered(const fga_alns *const *filtered, int nsets, fga_alns **out);
 int     fga_alns_merge_filtered_mt(const fga_alns *const *filtered, int nsets, int nthreads, fga_alns **out);   /* the copies on all threads */
 
+/* pieces that lie in the memory of OTHER devices of the node (src_device_id[k] = HIP device of piece k): hipMemcpyPeerAsync
+   over xGMI instead of the reference's re-read of the seed files of one part (FastGA.c:5160-5184, 4160-4187) */
+int  fga_seeds_import_peer(fga_dev *dev, const void *const *src_device, const int *src_device_id, const int64_t *counts,
+                           int npieces, fga_dseeds **out);
+int  fga_dev_enable_peer(fga_dev *dev, int peer_device);   /* direct xGMI access dev -> peer (no-op when there is no path) */
+int  fga_dev_device_count(void);                           /* HIP devices this process sees (0: none)                    */
+
+/* ---- ONE comparison over `ndev` GPUs of one node from ONE process: the reference's parts machinery -- Select[] / IDBsplit[]
+ *      and the unit matrix (FastGA.c:5057-5134), the transpose + NPARTS loop (FastGA.c:5160-5204), la_merge
+ *      (FastGA.c:3991-4133) -- laid over the devices: one host thread + HIP stream per device, rank r merges its 12-mer
+ *      prefix range on devices[r], the seeds move by A-contig part with hipMemcpyPeerAsync, rank p runs phase 2 and the
+ *      redundancy filter on its part, the calling thread writes ONE .1aln (PAF / PSL) in the reference's order.  The
+ *      result does not depend on ndev; devices may repeat ({0,0}: two ranks on GPU 0).  ndev = 1 is fga_run on devices[0].
+ *      prm->device is ignored; prm->nthreads is shared out among the ranks.  fastga_amd/bin/FastGA: -G<n> / FGA_DEVICES. */
+int  fga_run_multi(const char *root1, const char *root2 /* NULL: self */, const fga_run_params *prm,
+                   int ndev, const int *devices, fga_run_stats *stats);
+
 /* the same with the inputs kept resident in HBM between passes (what bench.py times) */
 typedef struct fga_session fga_session;
 int      fga_session_open(const char *root1, const char *root2, int device, fga_session **out);

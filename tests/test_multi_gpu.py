@@ -1,0 +1,153 @@
+"""fga_run_multi / `FastGA -G<n>`: ONE comparison cut over several GPUs from one process, behind the C-ABI (the reference's
+parts machinery inside one process: Select[] / unit matrix FastGA.c:5057-5134, transpose + NPARTS loop 5160-5204, la_merge
+3991-4133).  On the GPU box the device list names GPU 0 several times -- virtual ranks on one GPU: every rank has its own
+host thread, HIP stream and sliced session, the seeds move between the ranks' buffers exactly as between devices -- and
+the result must be the reference's .1aln line for line whatever the number of ranks.  The argument handling is tested
+on the CPU."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "fastga_amd", "bin", "FastGA")
+
+
+def _view(path):
+    from oracle import harness as H
+    return H.oneview(path)
+
+
+def _keep(lines):
+    return [ln for ln in lines if ln[0] not in "!<"]
+
+
+# ------------------------------------------------------------------------------------------------ CPU: arguments
+
+def test_run_multi_argument_checks(built_library, toy_pair):
+    from fastga_amd.lib import RunParams, RunStats
+    L = built_library
+    d, ra, rb = toy_pair
+    prm, st = RunParams(), RunStats()
+    prm.freq, prm.nthreads, prm.align_min, prm.align_rate = 10, 4, 100, 0.3
+    prm.chain_break, prm.chain_min = 2000, 170
+    dev2 = (C.c_int * 2)(0, 0)
+    for ndev, devs in ((0, dev2), (65, dev2), (2, None), (-1, dev2)):
+        rc = L.fga_run_multi(ra.encode(), rb.encode(), C.byref(prm), ndev, devs, C.byref(st))
+        assert rc == 1 and b"fga_run_multi: bad argument" in L.fga_last_error(), (ndev, L.fga_last_error())
+    rc = L.fga_run_multi(None, rb.encode(), C.byref(prm), 2, dev2, C.byref(st))
+    assert rc == 1 and b"bad argument" in L.fga_last_error()
+    import torch
+    if not torch.cuda.is_available():                     # the product path has no CPU fallback, with any number of devices
+        rc = L.fga_run_multi(ra.encode(), rb.encode(), C.byref(prm), 2, dev2, C.byref(st))
+        assert rc == 1 and b"no CPU fallback" in L.fga_last_error()
+        assert L.fga_dev_device_count() == 0
+    else:
+        n = L.fga_dev_device_count()
+        assert n >= 1
+        bad = (C.c_int * 2)(0, n)                         # a device the node does not have
+        rc = L.fga_run_multi(ra.encode(), rb.encode(), C.byref(prm), 2, bad, C.byref(st))
+        assert rc == 1 and b"out of range" in L.fga_last_error()
+
+
+def test_cli_gpu_option_grammar(built_library, toy_pair, tmp_path):
+    d, ra, rb = toy_pair
+    def run(args, env=None):
+        e = dict(os.environ)
+        e.pop("FGA_DEVICES", None)
+        if env:
+            e.update(env)
+        return subprocess.run([EXE, *args], cwd=str(tmp_path), capture_output=True, text=True, env=e)
+    r = run(["-G0", "-1:x", ra, rb])
+    assert r.returncode == 1 and "-G number of GPUs must be in [1,64]" in r.stderr
+    r = run(["-G65", "-1:x", ra, rb])
+    assert r.returncode == 1 and "[1,64]" in r.stderr
+    r = run(["-Gx", "-1:x", ra, rb])
+    assert r.returncode == 1 and "not an integer" in r.stderr
+    r = run(["-1:x", ra, rb], env={"FGA_DEVICES": "0,a"})
+    assert r.returncode == 1 and "FGA_DEVICES must be a comma-separated list" in r.stderr
+    r = run(["-1:x", ra, rb], env={"FGA_DEVICES": "0;1"})
+    assert r.returncode == 1 and "FGA_DEVICES" in r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        r = run(["-v", "-G2", "-1:x", ra, rb])
+        assert r.returncode == 1 and "no CPU fallback" in r.stderr and "Using 2 GPUs (0,1)" in r.stderr
+        r = run(["-v", "-1:x", ra, rb], env={"FGA_DEVICES": "0,0,0"})
+        assert r.returncode == 1 and "no CPU fallback" in r.stderr and "Using 3 GPUs (0,0,0)" in r.stderr
+        assert not os.path.exists(os.path.join(str(tmp_path), "x.1aln"))
+    assert "-G<int>" in run([]).stderr                     # the usage text names the option
+
+
+# ------------------------------------------------------------------------------------------------ GPU: parity
+
+def _reference(ra, rb, w, flags=(), threads=8):
+    from oracle import harness as H
+    if not H.have_reference():
+        pytest.skip("oracle/_ref did not travel")
+    H.ref_fastga(ra, rb, w, os.path.join(w, "ref"), threads=threads, flags=flags)
+    return _keep(H.oneview(os.path.join(w, "ref.1aln")))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["pair", "symmetric", "self"])
+def test_run_multi_with_virtual_ranks_is_the_reference_line_for_line(toy_pair, tmp_path, mode):
+    from fastga_amd import device as D
+    d, ra, rb = toy_pair
+    w = str(tmp_path)
+    b = None if mode == "self" else rb
+    kw = dict(symmetric=True, freq=6) if mode == "symmetric" else {}
+    ref = _reference(ra, b, w, flags=("-S", "-f6") if mode == "symmetric" else ())
+    one = D.run(ra, b, os.path.join(w, "one.1aln"), nthreads=8, reference_threads=8, **kw)
+    assert _keep(_view(os.path.join(w, "one.1aln"))) == ref
+    for devices in ((0,), (0, 0), (0, 0, 0, 0), (0, 0, 0)):
+        out = os.path.join(w, "multi%d.1aln" % len(devices))
+        st = D.run_multi(ra, b, out, devices=devices, nthreads=8, reference_threads=8, **kw)
+        assert _keep(_view(out)) == ref, devices
+        assert st["nalns"] == one["nalns"] and st["nlive"] == one["nlive"] and st["nhits"] == one["nhits"]
+        assert st["nparts"] == len(devices)
+        if mode == "self":       # self totals are halved per merge launch (FastGA.c:1906): the floors add up differently
+            assert 0 <= one["nseeds"] - st["nseeds"] <= len(devices)
+        else:
+            assert st["nseeds"] == one["nseeds"]
+
+
+@pytest.mark.gpu
+def test_run_multi_builds_its_index_slices_on_the_devices(toy_pair, tmp_path):
+    """no index files: every rank counts the 12-mer prefixes of both genomes on its device, cuts the same ranges and builds
+    only its slice (fga_dgix_build_range); PAF with CIGARs comes from rank 0's device"""
+    from fastga_amd import device as D
+    from oracle import harness as H
+    d, ra, rb = toy_pair
+    w = str(tmp_path)
+    for root in (ra, rb):                                  # the GDBs alone
+        base = os.path.basename(root)
+        for f in (base + ".gdb", "." + base + ".bps"):
+            shutil.copy(os.path.join(os.path.dirname(root), f), os.path.join(w, f))
+    a, b = os.path.join(w, os.path.basename(ra)), os.path.join(w, os.path.basename(rb))
+    ref = _reference(ra, rb, w)
+    paf = os.path.join(w, "m.paf")
+    st = D.run_multi(a, b, os.path.join(w, "m.1aln"), devices=(0, 0, 0), nthreads=8, reference_threads=8,
+                     paf_path=paf, paf_flags=2)
+    assert _keep(_view(os.path.join(w, "m.1aln"))) == ref
+    assert not [f for f in os.listdir(w) if f.endswith(".gix") or ".ktab." in f]
+    exp = H.run([H.ref_bin("ALNtoPAF"), "-T4", "-x", os.path.join(w, "ref.1aln")], cwd=w).stdout
+    assert open(paf).read() == exp and st["trace_kernel_ms"] > 0
+
+
+@pytest.mark.gpu
+def test_cli_with_gpu_list_is_the_reference(toy_pair, tmp_path):
+    d, ra, rb = toy_pair
+    w = str(tmp_path)
+    ref = _reference(ra, rb, w, threads=4)
+    for args, env in ((["-G1"], {}), ([], {"FGA_DEVICES": "0,0"}), ([], {"FGA_DEVICES": "0,0,0,0"})):
+        e = dict(os.environ)
+        e.pop("FGA_DEVICES", None)
+        e.update(env)
+        out = os.path.join(w, "cli%d" % len(env.get("FGA_DEVICES", "0")))
+        r = subprocess.run([EXE, "-v", "-T4", *args, "-1:" + out, ra, rb], cwd=w, capture_output=True, text=True, env=e)
+        assert r.returncode == 0, r.stderr
+        assert _keep(_view(out + ".1aln")) == ref, (args, env)
+        if env:
+            assert "Using %d GPUs" % len(env["FGA_DEVICES"].split(",")) in r.stderr

@@ -4,6 +4,8 @@
  *   FastGA [-vkMS] [-L:<log>] [-T<int(8)>] [-P<dir>] [<format(-paf)>] [-f<int(10)>] [-c<int(85)>] [-s<int(1000)>]
  *          [-l<int(100)>] [-i<float(.7)>]  <source1>[.gdb|.1gdb|.gix|.fa...]  [<source2>]
  *          <format> = -paf[mxsS]* | -psl | -1:<align:path>[.1aln]
+ * plus one option of its own: -G<n> (or FGA_DEVICES=<id>,...) cuts the comparison over n GPUs of the node (fga_run_multi:
+ * the reference's parts machinery, FastGA.c:5057-5204, laid over devices); the output does not depend on it
  * and honours its process-level contract: -v statistics on stderr and -L:<log> the same lines appended to a log file,
  * both with the reference's "Resources for phase" / "Total Resources" lines (gene_core.c:514-593); -T threads (also the
  * layout of an index that has to be built: the -T the reference hands to GIXmake, FastGA.c:4757-4760); -P / $TMPDIR must
@@ -215,6 +217,7 @@ int main(int argc, char *argv[])
   char *src[2] = { NULL, NULL }, *out = NULL, *outpath = NULL;
   const char *tmpdir, *logpath = NULL;
   int nsrc = 0, paf = 0, i;
+  int ngpu = 0, ndev = 0, devices[64];
   const char *mask1[64], *mask2[64];
   int nmask1 = 0, nmask2 = 0;
   int cmin = 85, cbreak = 1000;
@@ -243,6 +246,11 @@ int main(int argc, char *argv[])
         case 's': if (arg_int(argv[i],"seed chain break threshold",&cbreak)) return 1; break;
         case 'l': if (arg_int(argv[i],"minimum alignment length",&P.align_min)) return 1; break;
         case 'T': if (arg_int(argv[i],"number of threads to use",&P.nthreads)) return 1; break;
+        case 'G':                         /* not in the reference: the comparison is cut over GPUs 0 .. n-1 of the node */
+          if (arg_int(argv[i],"number of GPUs to use",&ngpu)) return 1;
+          if (ngpu < 1 || ngpu > 64)
+            { fprintf(stderr,"FastGA: -G number of GPUs must be in [1,64]\n"); return 1; }
+          break;
         case 'i':
           { char *e;
             ident = strtod(argv[i]+2,&e);
@@ -297,8 +305,10 @@ int main(int argc, char *argv[])
       { /* a mask of the preceding genome (FastGA.c:4568-4573): "#" alone = its implicit mask (the lower-case intervals the
            GDB carries, GIXmake.c:1829-1832), "#<mask>[.1ano]" = a ONEcode annotation file; the union of a genome's masks is
            its soft mask, its index is built anew with it, and soft masking is on (FastGA.c:4580) */
-        if (nsrc >= 2) { if (nmask2 < 64) mask2[nmask2++] = argv[i]+1; }
-        else           { if (nmask1 < 64) mask1[nmask1++] = argv[i]+1; }
+        if ((nsrc >= 2 ? nmask2 : nmask1) >= 64)
+          { fprintf(stderr,"FastGA: more than 64 masks named for one genome\n"); return 1; }
+        if (nsrc >= 2) mask2[nmask2++] = argv[i]+1;
+        else           mask1[nmask1++] = argv[i]+1;
         P.soft_mask = 1;
       }
     else if (nsrc < 2)
@@ -309,7 +319,8 @@ int main(int argc, char *argv[])
     { fprintf(stderr,"\nUsage: FastGA [-vkMS] [-L:<log:path>] [-T<int(8)>] [-P<dir($TMPDIR)>] [<format(-paf)>]\n"
                      "              [-f<int(10)>] [-c<int(85)>] [-s<int(1000)>] [-l<int(100)>] [-i<float(.7)>]\n"
                      "              <source1:path>[<precursor>] [<source2:path>[<precursor>]]\n\n"
-                     "         <format> = -paf[mxsS]* | -psl | -1:<align:path>[.1aln]\n\n");
+                     "         <format> = -paf[mxsS]* | -psl | -1:<align:path>[.1aln]\n\n"
+                     "         -G<int>: cut the comparison over that many GPUs of the node (or FGA_DEVICES=<id>,<id>,...)\n\n");
       return 1;
     }
   if ((P.paf_flags & FGA_PAF_CIGAR_M) && (P.paf_flags & FGA_PAF_CIGAR_X))
@@ -359,8 +370,35 @@ int main(int argc, char *argv[])
   stamp_now(&Start);
   Phase = Start;
   if (Log != NULL) fprintf(Log,"\n%s\n",cmd);
-  say("\n  Using GPU %d and %d host threads\n",P.device,P.nthreads);
-  if (fga_run(Src[0].root,nsrc == 2 ? Src[1].root : NULL,&P,&S))
+  /* the devices of the run: -G<n> = GPUs 0 .. n-1, else FGA_DEVICES=<id>,<id>,... (ids may repeat: ranks sharing a GPU),
+     else GPU 0.  More than one: fga_run_multi, one host thread + stream per device, seeds exchanged by A-contig part */
+  if (ngpu > 0)
+    for (ndev = 0; ndev < ngpu; ndev++)
+      devices[ndev] = ndev;
+  else if (getenv("FGA_DEVICES") != NULL && getenv("FGA_DEVICES")[0] != '\0')
+    { const char *e = getenv("FGA_DEVICES");
+      while (*e != '\0')
+        { char *end;
+          long v = strtol(e,&end,10);
+          if (end == e || v < 0 || v > 1023 || (*end != ',' && *end != '\0') || ndev >= 64)
+            { fprintf(stderr,"FastGA: FGA_DEVICES must be a comma-separated list of at most 64 GPU numbers\n");
+              clean_exit(1);
+            }
+          devices[ndev++] = (int) v;
+          e = (*end == ',') ? end+1 : end;
+        }
+    }
+  if (ndev == 0)
+    devices[ndev++] = P.device;
+  P.device = devices[0];
+  if (ndev == 1)
+    say("\n  Using GPU %d and %d host threads\n",P.device,P.nthreads);
+  else
+    { say("\n  Using %d GPUs (",ndev);
+      for (i = 0; i < ndev; i++) say("%s%d",i ? "," : "",devices[i]);
+      say(") and %d host threads\n",P.nthreads);
+    }
+  if (fga_run_multi(Src[0].root,nsrc == 2 ? Src[1].root : NULL,&P,ndev,devices,&S))
     { fprintf(stderr,"FastGA: %s\n",fga_last_error());
       clean_exit(1);
     }
