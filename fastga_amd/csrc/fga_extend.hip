@@ -492,6 +492,15 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
                 100*sp[0]/t,100*sp[1]/t,100*sp[2]/t,100*sp[3]/t,100*sp[4]/t,100*sp[5]/t,t/(double) (hc[10] ? hc[10] : 1));
       }
 #endif
+#ifdef EXT_MODE_PROF
+      { static const char *nm[6] = { "register <= 12", "register <= 30", "register <= 60", "ring <= 60", "ring <= 120", "ring wider" };
+        double tc = 0, tn = 0;
+        for (int k = 0; k < 6; k++) { tc += (double) hc[20+k]; tn += (double) hc[26+k]; }
+        for (int k = 0; k < 6; k++)
+          fprintf(stderr,"extend modes: %-15s %5.1f %% of the steps, %5.1f %% of the step cycles, %7.0f cycles per step\n",nm[k],
+                  100.*hc[26+k]/(tn > 0 ? tn : 1),100.*hc[20+k]/(tc > 0 ? tc : 1),hc[26+k] ? (double) hc[20+k]/(double) hc[26+k] : 0.);
+      }
+#endif
 #ifdef EXT_WIDTH_HIST
       fprintf(stderr,"extend widths: calls by widest wave <=60 / <=120 / <=248 / wider: %llu %llu %llu %llu; wave steps in them: %llu %llu %llu %llu\n",
               hc[20],hc[21],hc[22],hc[23],hc[24],hc[25],hc[26],hc[27]);
