@@ -972,7 +972,7 @@ __global__ void unit_relay_kernel(const uint4 *rec, const fga_unit *units, const
 // ---------------------------------------------------------------------------------------------------
 extern "C" int fga_chain_scan_device(fga_dev *dev, const fga_dkeys *K, const fga_chain_params *prm, fga_hits **out)
 { *out = NULL;
-  FGA_HIP(hipSetDevice(dev->device));
+  FGA_HIP(fga_dev_enter(dev));
   const int64_t n = K->count;
   fga_hits *R = NULL;
   if (n == 0)

@@ -28,6 +28,7 @@ extern "C" int fga_dev_open(int device, fga_dev **out)
   FGA_HIP(hipStreamCreateWithFlags(&d->stream,hipStreamNonBlocking));
   FGA_HIP(hipEventCreate(&d->ev0));
   FGA_HIP(hipEventCreate(&d->ev1));
+  (void) fga_dev_enter(d);
   *out = d;
   return 0;
 }
@@ -97,47 +98,123 @@ static pool_state *pool_here(void)
   return &g_pool[d];
 }
 
+// Who waits for what at a release.  hipFree waits for the whole device, and so did this pool's release -- which made
+// sessions on different host threads take turns: every buffer one of them gave back waited for the kernels of all the others
+// (eight comparisons in flight on one GPU ran 1.5 x faster than one after the other, not 6 x).  The library's rule is one HIP
+// stream per device context, and a buffer is used by the stream of the context it was allocated under (where two contexts
+// share one -- the seed exchange of fga_run_multi -- the reader synchronises its own stream before the owner is told to
+// release).  So an allocation remembers the calling thread's current stream (fga_dev_enter), and its release waits for THAT
+// stream (and the legacy default stream, which the few hipMemset calls at allocation time use).  Small requests (< 1 MiB) do
+// not go back to hipFree either: they are kept in per-device lists by size class and handed out again.
+static thread_local hipStream_t g_tls_stream = NULL;
+static thread_local bool        g_tls_have = false;
+
+hipError_t fga_dev_enter(const fga_dev *dev)
+{ g_tls_stream = dev->stream; g_tls_have = true;
+  return hipSetDevice(dev->device);
+}
+
+#include <unordered_map>
+struct pool_owner { hipStream_t stream; bool have; int klass; };       // klass >= 0: a small buffer of 256 << klass bytes
+#define SMALL_CLASSES 13                                                // 256 B .. 1 MiB
+struct small_state
+  { std::unordered_map<void *,pool_owner> owner;                        // every live allocation of the device
+    std::vector<void *> idle[SMALL_CLASSES];
+  };
+static small_state g_small[POOL_MAXDEV];
+
+static void wait_for_owner(const pool_owner &o, int owner_dev)
+{ int cur = -1;
+  const bool hop = owner_dev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != owner_dev && hipSetDevice(owner_dev) == hipSuccess;
+  static const int whole = getenv("FGA_POOL_DEVICE_SYNC") != NULL && atoi(getenv("FGA_POOL_DEVICE_SYNC")) != 0;
+  if (o.have && !whole)
+    { (void) hipStreamSynchronize(o.stream);
+      (void) hipStreamSynchronize(NULL);
+    }
+  else
+    (void) hipDeviceSynchronize();
+  if (hop)
+    (void) hipSetDevice(cur);
+}
+
 hipError_t fga_pool_malloc(void **out, size_t bytes)
 { *out = NULL;
   if (bytes == 0) bytes = 16;
-  pool_state *P = pool_here();
-  if (bytes < POOL_MIN || P == NULL)
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= POOL_MAXDEV)
     return hipMalloc(out,bytes);
+  pool_state *P = &g_pool[d];
+  small_state *Q = &g_small[d];
+  pool_owner o; o.stream = g_tls_stream; o.have = g_tls_have; o.klass = -1;
+  if (bytes < POOL_MIN)
+    { int k = 0;
+      while (((size_t) 256 << k) < bytes) k += 1;
+      o.klass = k;
+      { std::lock_guard<std::mutex> lock(P->mu);
+        if (!Q->idle[k].empty())
+          { *out = Q->idle[k].back();
+            Q->idle[k].pop_back();
+            Q->owner[*out] = o;
+            return hipSuccess;
+          }
+      }
+      const hipError_t e = hipMalloc(out,(size_t) 256 << k);
+      if (e != hipSuccess) { *out = NULL; return e; }
+      std::lock_guard<std::mutex> lock(P->mu);
+      Q->owner[*out] = o;
+      return hipSuccess;
+    }
   const size_t need = (bytes + POOL_ALIGN-1) / POOL_ALIGN * POOL_ALIGN;
   std::lock_guard<std::mutex> lock(P->mu);
   bool fresh;
   *out = P->core.take(need,pool_hip,&fresh);
+  if (*out != NULL)
+    Q->owner[*out] = o;
   return *out != NULL ? hipSuccess : hipErrorOutOfMemory;
 }
 
 hipError_t fga_pool_free(void *ptr)
 { if (ptr == NULL) return hipSuccess;
-  // the pool of the calling thread's device first, then the others (a pointer is a piece of at most one)
-  pool_state *here = pool_here();
-  for (int d = -1; d < POOL_MAXDEV; d++)
-    { pool_state *P = d < 0 ? here : &g_pool[d];
-      if (P == NULL || (d >= 0 && P == here))
+  // the pool of the calling thread's device first, then the others (a pointer belongs to at most one)
+  int here = -1;
+  if (hipGetDevice(&here) != hipSuccess || here < 0 || here >= POOL_MAXDEV) here = -1;
+  for (int t = -1; t < POOL_MAXDEV; t++)
+    { const int d = t < 0 ? here : t;
+      if (d < 0 || (t >= 0 && d == here))
         continue;
+      pool_state *P = &g_pool[d];
+      small_state *Q = &g_small[d];
       std::unique_lock<std::mutex> lock(P->mu);
-      if (!P->core.holds(ptr))
+      auto it = Q->owner.find(ptr);
+      if (it == Q->owner.end())
         continue;
+      const pool_owner o = it->second;
+      Q->owner.erase(it);                       // (a second release of the same pointer finds nothing and falls through)
       lock.unlock();
-      // what hipFree does: nothing in flight refers to the piece any more -- on the device that OWNS the piece, which need
-      // not be the calling thread's current one
-      { const int owner = d < 0 ? -1 : d;
-        int cur = -1;
-        if (owner >= 0 && hipGetDevice(&cur) == hipSuccess && cur != owner && hipSetDevice(owner) == hipSuccess)
-          { (void) hipDeviceSynchronize();
-            (void) hipSetDevice(cur);
-          }
-        else
-          (void) hipDeviceSynchronize();
-      }
+      // nothing in flight refers to the buffer any more: what hipFree guarantees, for the stream that used it
+      wait_for_owner(o,d == here ? -1 : d);
       lock.lock();
-      P->core.give(ptr);                        // (false if another thread released it meanwhile: nothing to do)
+      if (o.klass >= 0)
+        Q->idle[o.klass].push_back(ptr);
+      else
+        P->core.give(ptr);
       return hipSuccess;
     }
   return hipFree(ptr);
+}
+
+// the small buffers nobody uses go back to the driver (the calling thread's device)
+static void small_trim(int d)
+{ if (d < 0 || d >= POOL_MAXDEV) return;
+  std::vector<void *> gone;
+  { std::lock_guard<std::mutex> lock(g_pool[d].mu);
+    for (int k = 0; k < SMALL_CLASSES; k++)
+      { gone.insert(gone.end(),g_small[d].idle[k].begin(),g_small[d].idle[k].end());
+        g_small[d].idle[k].clear();
+      }
+  }
+  for (void *p : gone)
+    hipFree(p);
 }
 
 // bytes in free pieces, and the largest of them
@@ -151,9 +228,10 @@ static void pool_idle(size_t *total, size_t *largest)
 
 // the regions nobody uses go back to the device (another library in the process -- torch's exchange buffers -- may need them)
 extern "C" void fga_dev_trim(fga_dev *dev)
-{ if (hipSetDevice(dev->device) != hipSuccess) return;
+{ if (fga_dev_enter(dev) != hipSuccess) return;
   pool_state *P = pool_here();
   if (P == NULL) return;
+  small_trim(dev->device);
   std::lock_guard<std::mutex> lock(P->mu);
   P->core.trim(pool_hip);
 }
@@ -161,7 +239,7 @@ extern "C" void fga_dev_trim(fga_dev *dev)
 // device memory an allocation could get right now: free memory + what the pool's free pieces hold
 extern "C" size_t fga_dev_available(fga_dev *dev)
 { size_t fr = 0, tot = 0, idle = 0, big = 0;
-  if (hipSetDevice(dev->device) != hipSuccess || hipMemGetInfo(&fr,&tot) != hipSuccess)
+  if (fga_dev_enter(dev) != hipSuccess || hipMemGetInfo(&fr,&tot) != hipSuccess)
     return 0;
   pool_idle(&idle,&big);
   return fr + idle;
@@ -170,7 +248,7 @@ extern "C" size_t fga_dev_available(fga_dev *dev)
 // the largest single allocation that can succeed without giving regions back: a free piece, or fresh memory less a reserve
 size_t fga_dev_largest(fga_dev *dev, size_t reserve)
 { size_t fr = 0, tot = 0, idle = 0, big = 0;
-  if (hipSetDevice(dev->device) != hipSuccess || hipMemGetInfo(&fr,&tot) != hipSuccess)
+  if (fga_dev_enter(dev) != hipSuccess || hipMemGetInfo(&fr,&tot) != hipSuccess)
     return 0;
   pool_idle(&idle,&big);
   fr = fr > reserve ? fr - reserve : 0;
@@ -215,7 +293,7 @@ void *fga_dev_pinned(fga_dev *dev, size_t bytes)
 }
 
 extern "C" void *fga_dev_stage_acquire(fga_dev *dev, size_t bytes)
-{ if (hipSetDevice(dev->device) != hipSuccess) return NULL;
+{ if (fga_dev_enter(dev) != hipSuccess) return NULL;
   void *p = fga_dev_acquire(dev,SLOT_STAGE,bytes);
   if (p == NULL)
     fga_set_error("device allocation of %zu bytes (seed staging) failed",bytes);
@@ -227,7 +305,7 @@ extern "C" void fga_dev_stage_release(fga_dev *dev, void *ptr)
 
 extern "C" int fga_dev_malloc(fga_dev *dev, size_t bytes, void **out)
 { *out = NULL;
-  FGA_HIP(hipSetDevice(dev->device));
+  FGA_HIP(fga_dev_enter(dev));
   if (fga_pool_malloc(out,bytes > 0 ? bytes : 16) != hipSuccess)
     *out = NULL;
   if (*out == NULL)
@@ -239,7 +317,7 @@ extern "C" int fga_dev_malloc(fga_dev *dev, size_t bytes, void **out)
 
 extern "C" void fga_dev_free(fga_dev *dev, void *ptr)
 { if (ptr == NULL) return;
-  hipSetDevice(dev->device);
+  fga_dev_enter(dev);
   fga_pool_free(ptr);
 }
 
@@ -261,21 +339,21 @@ extern "C" double fga_dev_driver_seconds(void)
 
 extern "C" int64_t fga_dev_peak_bytes(fga_dev *dev)
 { size_t fr = 0, tot = 0;
-  if (hipSetDevice(dev->device) != hipSuccess || hipMemGetInfo(&fr,&tot) != hipSuccess)
+  if (fga_dev_enter(dev) != hipSuccess || hipMemGetInfo(&fr,&tot) != hipSuccess)
     return -1;
   fga_dev_note_memory(dev);
   return (int64_t) (tot - dev->hbm_low_water);
 }
 
 extern "C" int fga_dev_download(fga_dev *dev, void *host_dst, const void *device_src, size_t bytes)
-{ FGA_HIP(hipSetDevice(dev->device));
+{ FGA_HIP(fga_dev_enter(dev));
   if (bytes > 0)
     FGA_HIP(hipMemcpy(host_dst,device_src,bytes,hipMemcpyDeviceToHost));
   return 0;
 }
 
 extern "C" int fga_dev_upload(fga_dev *dev, void *device_dst, const void *host_src, size_t bytes)
-{ FGA_HIP(hipSetDevice(dev->device));
+{ FGA_HIP(fga_dev_enter(dev));
   if (bytes > 0)
     FGA_HIP(hipMemcpy(device_dst,host_src,bytes,hipMemcpyHostToDevice));
   return 0;
@@ -283,12 +361,21 @@ extern "C" int fga_dev_upload(fga_dev *dev, void *device_dst, const void *host_s
 
 extern "C" void fga_dev_close(fga_dev *d)
 { if (d == NULL) return;
-  hipSetDevice(d->device);
+  fga_dev_enter(d);
   hipStreamSynchronize(d->stream);
   fga_dev_trim(d);
   if (d->pinned != NULL) hipHostFree(d->pinned);
   hipEventDestroy(d->ev0);
   hipEventDestroy(d->ev1);
+  // buffers that outlive their context no longer have a stream to wait for: their release waits for the device
+  if (d->device >= 0 && d->device < POOL_MAXDEV)
+    { std::lock_guard<std::mutex> lock(g_pool[d->device].mu);
+      for (auto &kv : g_small[d->device].owner)
+        if (kv.second.have && kv.second.stream == d->stream)
+          kv.second.have = false;
+    }
+  if (g_tls_have && g_tls_stream == d->stream)
+    { g_tls_have = false; g_tls_stream = NULL; }
   hipStreamDestroy(d->stream);
   free(d);
 }
@@ -296,7 +383,7 @@ extern "C" void fga_dev_close(fga_dev *d)
 // direct loads / copies between this device and `peer` over xGMI (hipMemcpyPeerAsync works without, through the host); an
 // access that is enabled already, or a peer that is this very device, is fine
 extern "C" int fga_dev_enable_peer(fga_dev *d, int peer)
-{ FGA_HIP(hipSetDevice(d->device));
+{ FGA_HIP(fga_dev_enter(d));
   if (peer == d->device)
     return 0;
   int can = 0;
@@ -323,7 +410,7 @@ extern "C" int fga_dev_device_count(void)
 }
 
 extern "C" int fga_dev_sync(fga_dev *d)
-{ FGA_HIP(hipSetDevice(d->device));
+{ FGA_HIP(fga_dev_enter(d));
   FGA_HIP(hipStreamSynchronize(d->stream));
   return 0;
 }
@@ -336,7 +423,7 @@ extern "C" float fga_dev_stage_ms(const fga_dev *d, int stage)
 // the entries of the 12-mer prefixes [pbeg,pend) of a host-resident table (the whole table: 0, 2^24) on the device
 static int dgix_upload_impl(fga_dev *dev, const fga_gix *X, int64_t pbeg, int64_t pend, fga_dgix **out)
 { *out = NULL;
-  FGA_HIP(hipSetDevice(dev->device));
+  FGA_HIP(fga_dev_enter(dev));
   if (X->table == NULL || X->index == NULL)
     { fga_set_error("fga_dgix_upload: the index holds no host copy of its table");
       return 1;
@@ -407,7 +494,7 @@ extern "C" int64_t fga_dgix_nents(const fga_dgix *D) { return D == NULL ? 0 : D-
 
 extern "C" void fga_dgix_free(fga_dgix *D)
 { if (D == NULL) return;
-  hipSetDevice(D->dev->device);
+  fga_dev_enter(D->dev);
   fga_dgix_free_views(D);
   fga_pool_free(D->table);
   fga_pool_free(D->index);
@@ -418,7 +505,7 @@ extern "C" int64_t fga_seeds_count(const fga_dseeds *S)    { return S->count; }
 extern "C" int64_t fga_seeds_plen_sum(const fga_dseeds *S) { return S->tseed; }
 
 extern "C" int fga_seeds_download(const fga_dseeds *S, fga_seed *host, int64_t max)
-{ FGA_HIP(hipSetDevice(S->dev->device));
+{ FGA_HIP(fga_dev_enter(S->dev));
   if (S->valid == NULL)
     { int64_t n = S->count < S->capacity ? S->count : S->capacity;
       if (n > max) n = max;
@@ -447,7 +534,7 @@ extern "C" int fga_seeds_download(const fga_dseeds *S, fga_seed *host, int64_t m
 
 extern "C" void fga_seeds_free(fga_dseeds *S)
 { if (S == NULL) return;
-  hipSetDevice(S->dev->device);
+  fga_dev_enter(S->dev);
   fga_dev_release(S->dev,S->slot,S->seeds);
   fga_dev_release(S->dev,SLOT_VALID,S->valid);
   fga_pool_free(S->dcount);

@@ -36,6 +36,10 @@ struct fga_dev
     int          host_threads;    // threads the host tails of the device stages may use (fga_dev_set_host_threads; 0 = 1)
   };
 void fga_dev_note_memory(fga_dev *dev);
+// every entry point of the C-ABI that takes a device context starts here: the device becomes the calling thread's current one
+// and the context's stream the thread's "current stream" -- the stream an allocation made by this thread belongs to, which is
+// what a release of the allocation waits for (fga_device.hip)
+hipError_t fga_dev_enter(const fga_dev *dev);
 
 // Device memory of a MiB and more is a piece of a region the process keeps (fga_device.hip: the pool); smaller requests go
 // to hipMalloc.  fga_pool_free takes either kind.  Every allocation of the library goes through these two.
@@ -67,6 +71,9 @@ struct fga_dgix
     int       legacy_cutoff;   // > 0: read from the pre-v1.3 layout, no k-mer with more positions than this is in it
     fga_view  view;       // all entries
     fga_view  fview;      // forward-strand entries only (made on first use as table 1 of a pair comparison)
+    // the range cuts of the last merge launch with this table as table 1 (fga_merge.hip): a session repeats the same
+    // comparison, and the cuts depend on the two prefix indices, the prefix range and the launch geometry only
+    struct { const void *idx1, *idx2; int pbeg, pend, nranges, nbig; int64_t base, total; int64_t *cuts; } cutc;
   };
 int  fga_dgix_make_view(fga_dev *dev, fga_dgix *D, int keep_table);
 int  fga_view_alloc(fga_view *V, int64_t n, int cont, int want_l);       // the field arrays of n entries (+ read slack), defined

@@ -227,7 +227,7 @@ __global__ void unit_order_kernel(const uint4 *rec, int64_t nu, int *order)
 static int dgenome_make(fga_dev *dev, const fga_gdb *G, const int *perm, int nperm, int want_revcomp, uint8_t *adopt,
                         fga_dgenome **out)
 { *out = NULL;
-  FGA_HIP(hipSetDevice(dev->device));
+  FGA_HIP(fga_dev_enter(dev));
   fga_dgenome *D = (fga_dgenome *) calloc(1,sizeof(fga_dgenome));
   if (D == NULL)
     { fga_set_error("out of memory");
@@ -298,7 +298,7 @@ extern "C" int fga_dgenome_adopt(fga_dev *dev, const fga_gdb *G, const int *perm
 
 extern "C" void fga_dgenome_free(fga_dgenome *D)
 { if (D == NULL) return;
-  hipSetDevice(D->dev->device);
+  fga_dev_enter(D->dev);
   fga_pool_free(D->img); fga_pool_free(D->img_rc); fga_pool_free(D->boff); fga_pool_free(D->clen); fga_pool_free(D->perm);
   free(D->hclen);
   free(D);
@@ -307,7 +307,7 @@ extern "C" void fga_dgenome_free(fga_dgenome *D)
 extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome *GB, const fga_hits *H,
                           const fga_extend_params *prm, fga_alns **out)
 { *out = NULL;
-  FGA_HIP(hipSetDevice(dev->device));
+  FGA_HIP(fga_dev_enter(dev));
   fga_alns *R = (fga_alns *) calloc(1,sizeof(fga_alns));
   if (R == NULL)
     { fga_set_error("out of memory");
@@ -614,6 +614,7 @@ struct shim_work
     arena_lists *dlists;
     std::vector<uint8_t>  pack;
     std::vector<uint16_t> trace;                  // result trace (the reference's work->points)
+    std::vector<int32_t>  itrace;                 // Compute_Trace_PTS's result (the reference's work->trace): ints, one per indel
   };
 
 struct shim_spec
@@ -641,7 +642,7 @@ extern "C" void *fga_shim_New_Work_Data(void)
 extern "C" void fga_shim_Free_Work_Data(void *work)
 { shim_work *W = (shim_work *) work;
   if (W == NULL) return;
-  hipSetDevice(W->dev->device);
+  fga_dev_enter(W->dev);
   fga_pool_free(W->dA); fga_pool_free(W->dB); fga_pool_free(W->pool); fga_pool_free(W->dtrace); fga_pool_free(W->dout); fga_pool_free(W->dcnt); fga_pool_free(W->dlists);
   fga_dev_close(W->dev);
   delete W;
@@ -695,7 +696,7 @@ extern "C" int fga_shim_Local_Alignment(void *align_, void *work, void *spec_, i
     { fga_set_error("fga_shim_Local_Alignment: only trace spacing 100 and reach 0 (what FastGA uses, FastGA.c:46, 3757)");
       return 1;
     }
-  FGA_HIP(hipSetDevice(W->dev->device));
+  FGA_HIP(fga_dev_enter(W->dev));
   const int selfie = (align->aseq == align->bseq);
   if (shim_upload(W,align->aseq,align->alen,&W->dA,&W->capA)) return 1;
   if (!selfie && shim_upload(W,align->bseq,align->blen,&W->dB,&W->capB)) return 1;
@@ -756,5 +757,144 @@ extern "C" int fga_shim_Local_Alignment(void *align_, void *work, void *spec_, i
   if (P->tlen > 0)
     FGA_HIP(hipMemcpy(W->trace.data(),W->dtrace,sizeof(uint16_t)*(size_t) P->tlen,hipMemcpyDeviceToHost));
   P->trace = W->trace.data();
+  return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Compute_Trace_PTS (align.h:266-267, align.c:6171-6308) and Gap_Improver (align.h:393-399, align.c:6714-7133) with the
+// reference's prototypes, so that the one pair of calls every reader of a .1aln makes per record (ALNtoPAF.c:278-280,
+// ALNtoPSL.c:193-197, ALNshow.c:524) can be pointed at this library with a #define.  align->path holds the trace points
+// (uint16 pairs after Decompress_TraceTo16), align->aseq / bseq the NUMERIC sequences as the readers lay them out: aseq the
+// whole A contig, bseq such that bseq[bbpos .. bepos) is the aligned piece of B, complemented by the caller for a
+// complement alignment (ALNtoPAF.c:258-277).  On return path->trace points at the edit script (ints in the Work_Data,
+// valid until the next call on it), path->tlen is its length and path->diffs its differences.  Only what the reference's
+// own callers ask for is supported: trace spacing 100, mode GREEDIEST, no band (dlow > dhgh).
+// One record per call: the aligned pieces are packed, uploaded and run through the batch stage fga_trace_pts (the record's
+// A coordinates shifted by a multiple of the trace spacing so that only the piece travels): a parity device, not the
+// fast path (fga_trace_pts[_regrouped] over a whole set).
+// ---------------------------------------------------------------------------------------------------
+static void shim_piece_gdb(fga_gdb *G, fga_contig *ctg, std::vector<uint8_t> &bps, const char *seq, int from, int len)
+{ memset(G,0,sizeof(*G));
+  memset(ctg,0,sizeof(*ctg));
+  bps.assign((size_t) ((len+3) >> 2) + 16,0);
+  for (int i = 0; i < len; i++)
+    bps[(size_t) (i >> 2)] |= (uint8_t) ((seq[from+i] & 3) << (2*(i & 3)));
+  ctg->clen = len; ctg->boff = 0; ctg->sbeg = 0; ctg->scaf = 0;
+  G->ncontig = 1; G->contigs = ctg; G->maxctg = len; G->seqtot = len;
+  G->bps = bps.data(); G->bpslen = (len+3) >> 2;
+}
+
+extern "C" int fga_shim_Compute_Trace_PTS(void *align_, void *work, int trace_spacing, int mode, int dlow, int dhgh)
+{ shim_alignment *align = (shim_alignment *) align_;
+  shim_work *W = (shim_work *) work;
+  if (align == NULL || W == NULL || align->path == NULL || align->aseq == NULL || align->bseq == NULL)
+    { fga_set_error("fga_shim_Compute_Trace_PTS: null argument");
+      return 1;
+    }
+  if (trace_spacing != TS || mode != 0 || dlow <= dhgh)
+    { fga_set_error("fga_shim_Compute_Trace_PTS: only trace spacing 100, mode GREEDIEST and no band (dlow > dhgh): what the "
+                    "reference's readers ask for (ALNtoPAF.c:278)");
+      return 1;
+    }
+  shim_path *P = align->path;
+  if (P->abpos < 0 || P->aepos < P->abpos || P->aepos > align->alen || P->bbpos < 0 || P->bepos < P->bbpos ||
+      P->bepos > align->blen || P->tlen < 0 || (P->tlen & 1) != 0 || (P->tlen > 0 && P->trace == NULL))
+    { fga_set_error("fga_shim_Compute_Trace_PTS: inconsistent path");
+      return 1;
+    }
+  FGA_HIP(fga_dev_enter(W->dev));
+  const int a0 = (P->abpos / TS) * TS, b0 = P->bbpos;            // the trace points stay on multiples of 100 in A
+  fga_gdb GA, GB;
+  fga_contig ca, cb;
+  std::vector<uint8_t> pa, pb;
+  shim_piece_gdb(&GA,&ca,pa,align->aseq,a0,P->aepos - a0);
+  shim_piece_gdb(&GB,&cb,pb,align->bseq,b0,P->bepos - b0);
+  const int perm0 = 0;
+  fga_dgenome *dga = NULL, *dgb = NULL;
+  fga_traces *T = NULL;
+  int rc = 1;
+  std::vector<uint8_t> tb((size_t) (P->tlen > 0 ? P->tlen : 1));
+  { const uint16_t *pt = (const uint16_t *) P->trace;
+    for (int i = 0; i < P->tlen; i++)
+      { if (pt[i] > 255)
+          { fga_set_error("fga_shim_Compute_Trace_PTS: a trace point value beyond 255 (the .1aln keeps bytes)");
+            return 1;
+          }
+        tb[(size_t) i] = (uint8_t) pt[i];
+      }
+  }
+  fga_aln rec;
+  memset(&rec,0,sizeof(rec));
+  rec.tlen = P->tlen; rec.diffs = P->diffs;
+  rec.abpos = P->abpos - a0; rec.aepos = P->aepos - a0; rec.bbpos = 0; rec.bepos = P->bepos - b0;
+  rec.flags = 0; rec.aread = 0; rec.bread = 0; rec.toff = 0;
+  fga_alns set;
+  memset(&set,0,sizeof(set));
+  set.naln = 1; set.ntrace = P->tlen; set.alns = &rec; set.tbytes = tb.data();
+  if (fga_dgenome_upload(W->dev,&GA,&perm0,1,0,&dga) || fga_dgenome_upload(W->dev,&GB,&perm0,1,0,&dgb) ||
+      fga_trace_pts(W->dev,dga,dgb,&set,TS,0,&T))
+    goto done;
+  { const int n = T->tlen[0];
+    const int32_t *t = T->trace + T->toff[0];
+    W->itrace.resize((size_t) (n > 0 ? n : 1));
+    for (int i = 0; i < n; i++)                       // back to the contigs' own coordinates
+      W->itrace[(size_t) i] = t[i] < 0 ? t[i] - a0 : t[i] + b0;
+    P->trace = W->itrace.data();
+    P->tlen = n;
+    P->diffs = T->diffs[0];
+  }
+  rc = 0;
+done:
+  fga_traces_free(T);
+  fga_dgenome_free(dga); fga_dgenome_free(dgb);
+  return rc;
+}
+
+extern "C" int fga_shim_Gap_Improver(void *align_, void *work)
+{ shim_alignment *align = (shim_alignment *) align_;
+  shim_work *W = (shim_work *) work;
+  if (align == NULL || W == NULL || align->path == NULL || align->aseq == NULL || align->bseq == NULL)
+    { fga_set_error("fga_shim_Gap_Improver: null argument");
+      return 1;
+    }
+  shim_path *P = align->path;
+  if (P->tlen < 0 || (P->tlen > 0 && P->trace == NULL))
+    { fga_set_error("fga_shim_Gap_Improver: no edit script in the path (call Compute_Trace_PTS first)");
+      return 1;
+    }
+  // Gap_Improver looks at the whole A contig and at B between the sentinels the readers put around the aligned piece
+  // (ALNtoPAF.c:258-277): the host regrouping (fga_gap_improve) reads the same through two one-contig GDBs -- A whole, B the
+  // piece at its own coordinates
+  fga_gdb GA, GB;
+  fga_contig ca, cb;
+  std::vector<uint8_t> pa, pb;
+  shim_piece_gdb(&GA,&ca,pa,align->aseq,0,align->alen);
+  pb.assign((size_t) ((align->blen+3) >> 2) + 16,0);
+  for (int i = P->bbpos; i < P->bepos; i++)
+    pb[(size_t) (i >> 2)] |= (uint8_t) ((align->bseq[i] & 3) << (2*(i & 3)));
+  memset(&GB,0,sizeof(GB)); memset(&cb,0,sizeof(cb));
+  cb.clen = align->blen; GB.ncontig = 1; GB.contigs = &cb; GB.maxctg = align->blen; GB.seqtot = align->blen;
+  GB.bps = pb.data(); GB.bpslen = (align->blen+3) >> 2;
+  fga_aln rec;
+  memset(&rec,0,sizeof(rec));
+  rec.diffs = P->diffs; rec.abpos = P->abpos; rec.aepos = P->aepos; rec.bbpos = P->bbpos; rec.bepos = P->bepos;
+  fga_alns set;
+  memset(&set,0,sizeof(set));
+  set.naln = 1; set.alns = &rec;
+  int64_t toff[2] = { 0, P->tlen };
+  int32_t tlen = P->tlen, diffs = P->diffs;
+  if ((int32_t *) P->trace != W->itrace.data())            // a script that is not ours: regrouped in our storage, like the
+    { const int32_t *src = (const int32_t *) P->trace;     // reference rewrites it in the Work_Data's
+      W->itrace.assign(src,src + (P->tlen > 0 ? P->tlen : 0));
+      if (W->itrace.empty()) W->itrace.resize(1);
+      P->trace = W->itrace.data();
+    }
+  fga_traces T;
+  memset(&T,0,sizeof(T));
+  T.naln = 1; T.ntrace = P->tlen; T.toff = toff; T.tlen = &tlen; T.diffs = &diffs; T.trace = W->itrace.data();
+  if (fga_gap_improve(&GA,&GB,&set,&T))
+    return 1;
+  P->diffs = diffs;
   return 0;
 }

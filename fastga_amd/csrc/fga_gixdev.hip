@@ -530,7 +530,7 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
   const int use_mask = (flags & FGA_GIX_SOFT_MASK) != 0 && G->nmask > 0;
   int64_t *dmoff = NULL, *dmbeg = NULL, *dmend = NULL;
   int *dperm = NULL;
-  FGA_HIP(hipSetDevice(dev->device));
+  FGA_HIP(fga_dev_enter(dev));
   int nctg = 0, postbytes = 0, contbytes = 0, nparts = 0;
   int *perm = NULL, *invp = NULL;
   if (nthreads < 1) nthreads = 1;

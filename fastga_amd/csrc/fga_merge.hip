@@ -791,7 +791,7 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
           return 1;
         }
   }
-  FGA_HIP(hipSetDevice(dev->device));
+  FGA_HIP(fga_dev_enter(dev));
   const int mode = self ? MODE_SELF : (prm->flip ? MODE_FLIP : MODE_PAIR);
   if (mode == MODE_PAIR && fga_dgix_make_forward(dev,(fga_dgix *) t1))      // first use as table 1 of a pair comparison
     return 1;
@@ -919,18 +919,33 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
 #ifdef MERGE_PROF
       merge_prof_grid = grid;
 #endif
-      work = fga_dev_acquire(dev,SLOT_TILES,sizeof(int64_t)*(size_t) (nranges+2) + 64);
-      if (work == NULL)
-        { fga_set_error("fga_seed_merge: device allocation failed");
-          goto done;
+      // the cuts of the previous launch over the same two indices, prefix range and geometry are still good (a session
+      // repeats its comparison): they stay with table 1 until its views go (FGA_MERGE_CUT_CACHE=0: cut anew every time)
+      fga_dgix *own = (fga_dgix *) t1;
+      static const int cache_on = getenv("FGA_MERGE_CUT_CACHE") == NULL || atoi(getenv("FGA_MERGE_CUT_CACHE")) != 0;
+      const bool hit = cache_on && own->cutc.cuts != NULL && own->cutc.idx1 == (const void *) A.idx1 &&
+                       own->cutc.idx2 == (const void *) A.idx2 && own->cutc.pbeg == pbeg && own->cutc.pend == pend &&
+                       own->cutc.nranges == nranges && own->cutc.nbig == nbig && own->cutc.base == base && own->cutc.total == total;
+      if (!hit)
+        { fga_pool_free(own->cutc.cuts);
+          memset(&own->cutc,0,sizeof(own->cutc));
+          if (fga_dmalloc(&own->cutc.cuts,sizeof(int64_t)*(size_t) (nranges+2) + 64) != hipSuccess)
+            { own->cutc.cuts = NULL;
+              fga_set_error("fga_seed_merge: device allocation failed");
+              goto done;
+            }
         }
-      int64_t *cuts = (int64_t *) work;
+      int64_t *cuts = own->cutc.cuts;
       int *qhead = (int *) (counters + CTR_QUEUE);
       A.cuts = cuts; A.nranges = nranges; A.next = qhead;
       hipMemsetAsync(qhead,0,8*QSTRIDE*sizeof(int),dev->stream);
       hipEventRecord(dev->ev0,dev->stream);
-      hipLaunchKernelGGL(range_cut_kernel,dim3((nranges+1+255)/256),dim3(256),0,dev->stream,
-                         A.idx1,A.idx2,pbeg,pend,base,total,nranges,nbig,cuts);
+      if (!hit)
+        { hipLaunchKernelGGL(range_cut_kernel,dim3((nranges+1+255)/256),dim3(256),0,dev->stream,
+                             A.idx1,A.idx2,pbeg,pend,base,total,nranges,nbig,cuts);
+          own->cutc.idx1 = A.idx1; own->cutc.idx2 = A.idx2; own->cutc.pbeg = pbeg; own->cutc.pend = pend;
+          own->cutc.nranges = nranges; own->cutc.nbig = nbig; own->cutc.base = base; own->cutc.total = total;
+        }
       hipEventRecord(dev->ev1,dev->stream);
       if (huge)      launch_walk<4096>(mode,grid,dyn,dev->stream,A);
       else if (wide) launch_walk<1024>(mode,grid,dyn,dev->stream,A);
@@ -1049,7 +1064,7 @@ extern "C" int fga_merge_prefix_cuts(fga_dev *dev, const fga_dgix *t1, const fga
     { fga_set_error("fga_merge_prefix_cuts: the index has no device view");
       return 1;
     }
-  FGA_HIP(hipSetDevice(dev->device));
+  FGA_HIP(fga_dev_enter(dev));
   const int64_t total = t1->nents + t2->nents + 2*(int64_t) FGA_NPREFIX;
   int64_t *d = (int64_t *) fga_dev_acquire(dev,SLOT_MISC,sizeof(int64_t)*(size_t) (nshards+1));
   if (d == NULL)

@@ -107,7 +107,7 @@ static int seeds_histogram(fga_dev *dev, const fga_dseeds *S, int nctg_, int str
     { fga_set_error("fga_seeds_contig_histogram: bad argument");
       return 1;
     }
-  FGA_HIP(hipSetDevice(dev->device));
+  FGA_HIP(fga_dev_enter(dev));
   const int64_t n = fga_seeds_extent(S);
   const int nctg = strands ? 2*nctg_ : nctg_;          // counters
   unsigned long long *d = (unsigned long long *) fga_dev_acquire(dev,SLOT_MISC,sizeof(unsigned long long)*(size_t) nctg);
@@ -138,7 +138,7 @@ extern "C" int fga_seeds_split_to(fga_dev *dev, const fga_dseeds *S, const int *
     { fga_set_error("fga_seeds_split_to: bad argument (1 <= nparts <= %d)",SH_MAXP);
       return 1;
     }
-  FGA_HIP(hipSetDevice(dev->device));
+  FGA_HIP(fga_dev_enter(dev));
   const int64_t n = fga_seeds_extent(S);
   for (int p = 0; p <= nparts; p++) part_off[p] = 0;
   if (n == 0)
@@ -215,7 +215,7 @@ static int seeds_import(fga_dev *dev, const void *const *src_device, const int *
     { fga_set_error("fga_seeds_import: bad argument");
       return 1;
     }
-  FGA_HIP(hipSetDevice(dev->device));
+  FGA_HIP(fga_dev_enter(dev));
   int64_t total = 0;
   for (int k = 0; k < npieces; k++)
     { if (counts[k] < 0)

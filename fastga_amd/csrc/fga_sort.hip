@@ -687,7 +687,7 @@ extern "C" int fga_seed_sort(fga_dev *dev, const fga_dseeds *S, const fga_sort_p
     { fga_set_error("fga_seed_sort: null argument");
       return 1;
     }
-  FGA_HIP(hipSetDevice(dev->device));
+  FGA_HIP(fga_dev_enter(dev));
   const int64_t next = fga_seeds_extent(S);                                   // slots of the seed buffer to look at
   const int64_t n = S->valid != NULL ? S->count : next;                        // keys that come out
   key_layout L;
@@ -839,7 +839,7 @@ extern "C" int fga_dev_radix_sort_u128(fga_dev *dev, void *buf0, void *buf1, int
     { fga_set_error("fga_dev_radix_sort_u128: bad argument");
       return 1;
     }
-  FGA_HIP(hipSetDevice(dev->device));
+  FGA_HIP(fga_dev_enter(dev));
   uint4 *res = NULL;
   hipEventRecord(dev->ev0,dev->stream);
   if (fga_radix_sort_u128(dev,(uint4 *) buf0,(uint4 *) buf1,n,lowbit,nbits,&res))
@@ -856,7 +856,7 @@ extern "C" int64_t fga_keys_count(const fga_dkeys *K) { return K->count; }
 
 extern "C" int fga_keys_download(const fga_dkeys *K, void *host, int64_t max)
 { int64_t n = K->count < max ? K->count : max;
-  FGA_HIP(hipSetDevice(K->dev->device));
+  FGA_HIP(fga_dev_enter(K->dev));
   if (n > 0)
     FGA_HIP(hipMemcpy(host,K->keys,sizeof(uint4)*(size_t) n,hipMemcpyDeviceToHost));
   return 0;
@@ -867,14 +867,14 @@ extern "C" void fga_keys_layout(const fga_dkeys *K, int *wa, int *wb, int *wd, i
 
 extern "C" void fga_keys_free(fga_dkeys *K)
 { if (K == NULL) return;
-  hipSetDevice(K->dev->device);
+  fga_dev_enter(K->dev);
   fga_dev_release(K->dev,K->slot,K->keys);
   free(K);
 }
 
 // zero-copy variant for the pipeline: keys land in the device context's pinned staging buffer
 extern "C" const void *fga_keys_download_pinned(const fga_dkeys *K)
-{ if (hipSetDevice(K->dev->device) != hipSuccess) return NULL;
+{ if (fga_dev_enter(K->dev) != hipSuccess) return NULL;
   void *h = fga_dev_pinned(K->dev,sizeof(uint4)*(size_t) (K->count+1));
   if (h == NULL)
     { fga_set_error("fga_keys_download_pinned: cannot allocate %lld bytes of pinned memory",
@@ -933,7 +933,7 @@ extern "C" int fga_shim_rmsd_sort(uint8_t *array, int64_t nelem, int rsize, int 
         return -1;
     }
   fga_dev *dev = shim_sort_dev;
-  if (hipSetDevice(dev->device) != hipSuccess)
+  if (fga_dev_enter(dev) != hipSuccess)
     { fga_set_error("fga_shim_rmsd_sort: cannot select the device");
       return -1;
     }

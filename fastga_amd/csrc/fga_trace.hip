@@ -431,7 +431,7 @@ extern "C" void fga_traces_free(fga_traces *t)
 static int trace_pts_impl(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome *GB, const fga_alns *alns,
                           int tspace, int self, int regroup, fga_traces **out)
 { *out = NULL;
-  FGA_HIP(hipSetDevice(dev->device));
+  FGA_HIP(fga_dev_enter(dev));
   fga_traces *R = (fga_traces *) calloc(1,sizeof(fga_traces));
   if (R == NULL)
     { fga_set_error("out of memory");

@@ -270,4 +270,6 @@ done:
 void fga_dgix_free_views(fga_dgix *D)
 { view_free(&D->view);
   view_free(&D->fview);
+  fga_pool_free(D->cutc.cuts);          // the cached range cuts name the views' prefix indices
+  memset(&D->cutc,0,sizeof(D->cutc));
 }

@@ -240,6 +240,8 @@ def _declare(L):
         "fga_shim_Free_Align_Spec": (None, [vp]),
         "fga_shim_Local_Alignment": (i32, [vp, vp, vp, i32, i32, i32, i32, i32]),
         "fga_shim_rmsd_sort": (i32, [vp, i64, i32, i32, i32, P(i64), i32, vp]),
+        "fga_shim_Compute_Trace_PTS": (i32, [vp, vp, i32, i32, i32, i32]),
+        "fga_shim_Gap_Improver": (i32, [vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

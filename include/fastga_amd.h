@@ -346,6 +346,13 @@ int   fga_shim_Local_Alignment(void *align, void *work, void *spec,             
                                int low, int hgh, int anti, int lbord, int hbord);
 int   fga_shim_rmsd_sort(uint8_t *array, int64_t nelem, int rsize, int ksize,         /* FastGA.c:149-150, RSDsort.c:292 */
                          int nparts, int64_t *part, int nthreads, void *range);
+/*      The pair of calls every reader of a .1aln makes per record (ALNtoPAF.c:278-280, ALNtoPSL.c:193-197): the trace
+ *      points of align->path become the edit script (ints in the Work_Data, path->trace / tlen / diffs as the reference
+ *      leaves them), then the script is regrouped in place.  Trace spacing 100, mode GREEDIEST (0), dlow > dhgh -- what the
+ *      reference's own callers pass; `work` is a fga_shim_New_Work_Data packet.                                            */
+int   fga_shim_Compute_Trace_PTS(void *align, void *work, int trace_spacing,              /* align.h:266-267, align.c:6171 */
+                                 int mode, int dlow, int dhgh);
+int   fga_shim_Gap_Improver(void *align, void *work);                                     /* align.h:399, align.c:6714     */
 
 /* ---- the whole hot path: what `FastGA -1:<out> <root1> [<root2>]` does between "GIX present" and ".1aln closed" */
 typedef struct

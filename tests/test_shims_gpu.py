@@ -116,3 +116,66 @@ def test_rmsd_sort_shim_equals_reference(built_library, rsize, ksize):
         keys = [int.from_bytes(bytes(r[rsize - ksize:]), "little") for r in blk]
         assert keys == sorted(keys)
         off += int(cnt[p])
+
+
+@needs_ref
+def test_compute_trace_pts_and_gap_improver_shims_equal_the_reference_call_by_call(built_library):
+    """fga_shim_Compute_Trace_PTS / fga_shim_Gap_Improver (align.h:266-267, 399) beside the real functions of
+    libalign_ref.so on the alignments the real Local_Alignment finds: the int edit script, its length and the difference
+    count after each of the two calls, as the readers of a .1aln make them (ALNtoPAF.c:278-280)."""
+    from fastga_amd import synth
+    from tests.test_oracle_vs_reference import _random_case
+    L = built_library
+    rng = np.random.default_rng(20260927)
+    ref = H.RefAligner()
+    work = L.fga_shim_New_Work_Data()
+    assert work, L.fga_last_error()
+
+    def ours(abuf, bbuf, path):
+        abpos, bbpos, aepos, bepos, diffs, tr = path
+        pts = np.ascontiguousarray(tr, dtype=np.uint16).copy()
+        rp = H._RPath()
+        rp.trace = pts.ctypes.data
+        rp.tlen, rp.diffs = len(pts), diffs
+        rp.abpos, rp.bbpos, rp.aepos, rp.bepos = abpos, bbpos, aepos, bepos
+        al = H._RAlign()
+        al.path = C.pointer(rp)
+        al.flags = 0
+        al.aseq, al.bseq = abuf.ctypes.data + 1, bbuf.ctypes.data + 1
+        al.alen, al.blen = len(abuf) - 2, len(bbuf) - 2
+        assert L.fga_shim_Compute_Trace_PTS(C.byref(al), work, 100, 0, 1, -1) == 0, L.fga_last_error()
+        n = rp.tlen
+        t1 = np.ctypeslib.as_array(C.cast(rp.trace, C.POINTER(C.c_int32)), shape=(max(n, 1),))[:n].copy()
+        d1 = rp.diffs
+        assert L.fga_shim_Gap_Improver(C.byref(al), work) == 0, L.fga_last_error()
+        assert rp.tlen == n
+        t2 = np.ctypeslib.as_array(C.cast(rp.trace, C.POINTER(C.c_int32)), shape=(max(n, 1),))[:n].copy()
+        return (d1, t1), (rp.diffs, t2)
+
+    done = 0
+    cases = [_random_case(rng) for _ in range(120)]
+    A = rng.integers(0, 4, 60_000, dtype=np.uint8)                 # a long one: hundreds of trace panels, many indels
+    cases.append((A, synth.mutate(rng, A, 0.06), False, -30, 30, 2 * 30_000, -1, -1))
+    for A, B, acomp, low, hgh, anti, lb, hb in cases:
+        if acomp:
+            continue                                               # the readers complement B themselves; A is never complemented
+        abuf, bbuf = H.pad_seq(A), H.pad_seq(B)
+        path = ref.align(abuf, bbuf, low, hgh, anti, lb, hb, False)
+        if path[2] - path[0] < 50 or len(path[5]) == 0 or int(path[5].max()) > 255:
+            continue
+        r1 = ref.trace_pts(abuf, bbuf, path)
+        r2 = ref.trace_pts(abuf, bbuf, path, improve=True)
+        o1, o2 = ours(abuf, bbuf, path)
+        assert r1[0] == o1[0] and np.array_equal(r1[1], o1[1]), (path[:5], r1[0], o1[0])
+        assert r2[0] == o2[0] and np.array_equal(r2[1], o2[1]), (path[:5], r2[0], o2[0])
+        done += 1
+    assert done > 40
+    # what the shim refuses, it refuses loudly: another spacing, another mode, a band
+    rp = H._RPath(); al = H._RAlign(); al.path = C.pointer(rp)
+    buf = H.pad_seq(rng.integers(0, 4, 500, dtype=np.uint8))
+    al.aseq = al.bseq = buf.ctypes.data + 1
+    al.alen = al.blen = 500
+    for args in ((50, 0, 1, -1), (100, 1, 1, -1), (100, 0, -5, 5)):
+        assert L.fga_shim_Compute_Trace_PTS(C.byref(al), work, *args) == 1 and b"only trace spacing 100" in L.fga_last_error()
+    L.fga_shim_Free_Work_Data(work)
+    ref.close()
