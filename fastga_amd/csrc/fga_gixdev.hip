@@ -44,6 +44,9 @@ struct gix_scan_args
     uint4 *keys;                       // NULL: the counting pass (per-prefix counts, the sample histogram, the number of keys);
     const int64_t *index;              // else the placing pass: key -> keys[index[prefix] - (what is left of count[prefix])]
     uint32_t pbeg, pend;               // only k-mers whose 12-mer prefix lies in [pbeg,pend) are kept (a rank's slice)
+    const int64_t *goff;               // payloads beyond 6 bytes (do not fit under the k-mer in a 128-bit key): [ncontig+1] start of
+                                       //   each ORIGINAL contig in a concatenation with gaps; the key then carries (global position
+                                       //   << 1 | strand) in its 48 payload bits and gix_entries_kernel turns it back; else NULL
     unsigned long long *nkeys;
     uint32_t *count;                // [2^24]
     unsigned long long *sbuck;      // [1024]
@@ -191,9 +194,14 @@ void gix_scan_kernel(gix_scan_args A)
               hi = ~w1;
               lo16 = ~(uint32_t) w0 & 0xffffu;                                          // bases x-28 .. x-21: its last 8
             }
-          const uint64_t pay = strand ? ((uint64_t) (j+12) | ((ctg | sign) << (8*A.postbytes)))
-                                      : ((uint64_t) j | (ctg << (8*A.postbytes)));
-          const uint64_t lo = ((uint64_t) lo16 << 48) | (pay << (48 - 8*(A.postbytes+A.contbytes)));    // payload left-aligned under the k-mer: the significant key bits are contiguous
+          uint64_t lo;
+          if (A.goff != NULL)
+            lo = ((uint64_t) lo16 << 48) | ((((uint64_t) A.goff[c] + (uint64_t) (strand ? j+12 : j)) << 1) | (uint64_t) strand);
+          else
+            { const uint64_t pay = strand ? ((uint64_t) (j+12) | ((ctg | sign) << (8*A.postbytes)))
+                                          : ((uint64_t) j | (ctg << (8*A.postbytes)));
+              lo = ((uint64_t) lo16 << 48) | (pay << (48 - 8*(A.postbytes+A.contbytes)));    // payload left-aligned under the k-mer: the significant key bits are contiguous
+            }
           // into its panel: the panel [index[p] - count[p], index[p]) fills from the end (the order inside it is made below)
           const uint32_t p = (uint32_t) (hi >> 40);
           const uint32_t left = atomicSub(A.count + p,1u);
@@ -427,6 +435,8 @@ struct gix_entries_args
     // soft mask (optional): lower-case intervals per original contig, and the sorted -> original contig map
     const int64_t *moff, *mbeg, *mend;
     const int     *perm;
+    const int64_t *goff; int ngoff;  // wide payloads: the keys carry global positions (gix_scan_args.goff); ngoff = contigs
+    const int     *invp;             //   original contig -> length-sorted index
   };
 
 template <bool TO_VIEW>
@@ -453,7 +463,20 @@ void gix_entries_kernel(gix_entries_args A)
         lcp = FGA_KMER;
     }
   const uint64_t suf = ((hi & 0xffffffffffull) << 16) | lo16;           // bases 12..39
-  const uint64_t pay = (lo & 0xffffffffffffull) >> (48 - 8*(A.postbytes+A.contbytes));
+  uint64_t pay;
+  if (A.goff != NULL)
+    { const uint64_t code = lo & 0xffffffffffffull;
+      const int64_t g = (int64_t) (code >> 1);
+      int a = 0, b = A.ngoff;                          // the contig whose stretch holds g: largest c with goff[c] <= g
+      while (b - a > 1)
+        { const int m = (a + b) >> 1;
+          if (A.goff[m] <= g) a = m; else b = m;
+        }
+      const uint64_t cw = (uint64_t) A.invp[a] | ((code & 1) ? (0x80ull << (8*(A.contbytes-1))) : 0ull);
+      pay = (uint64_t) (g - A.goff[a]) | (cw << (8*A.postbytes));
+    }
+  else
+    pay = (lo & 0xffffffffffffull) >> (48 - 8*(A.postbytes+A.contbytes));
   uint8_t *o = TO_VIEW ? NULL : A.table + (size_t) i*A.ebytes;
   if (!TO_VIEW)
     { 
@@ -550,7 +573,7 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
   uint4 *buf0 = NULL, *sorted = NULL, *oscr = NULL;
   gix_tile *dtiles = NULL;
   gix_over *dover = NULL;
-  int64_t *dooff = NULL;
+  int64_t *dooff = NULL, *dgoff = NULL;
   unsigned scan_grid = 1;                  // workgroups of the scan kernel (each takes chunks in a stride)
   std::vector<gix_item> items;
   std::vector<int64_t> boff((size_t) G->ncontig), clen((size_t) G->ncontig);
@@ -559,10 +582,25 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
   float ms = 0.f;
   double tn = 0.;
 
-  if (postbytes + contbytes > 6)
-    { fga_set_error("fga_dgix_build: payload of %d bytes does not fit the 128-bit sort key (use fga_gix_build)",
-                    postbytes+contbytes);
+  // payloads of 7 and 8 bytes (more than 32,768 contigs with one beyond 16.7 Mbp: GIXmake.c:1888-1901 sizes them freely) do
+  // not fit under the k-mer in the 128-bit key: the key then carries the k-mer's position in a concatenation of the contigs
+  const bool wide_pay = postbytes + contbytes > 6;
+  std::vector<int64_t> goff;
+  if (postbytes + contbytes > 8 || postbytes > 4)
+    { fga_set_error("fga_dgix_build: %d position and %d contig bytes: payloads beyond 8 bytes / contigs beyond 4 Gbp are not supported",
+                    postbytes,contbytes);
       goto done;
+    }
+  if (wide_pay)
+    { goff.resize((size_t) G->ncontig + 1);
+      int64_t run = 0;
+      for (int c = 0; c < G->ncontig; c++)
+        { goff[(size_t) c] = run; run += G->contigs[c].clen + 64; }
+      goff[(size_t) G->ncontig] = run;
+      if (run >= ((int64_t) 1 << 46))
+        { fga_set_error("fga_dgix_build: genome too large for the position code of wide payloads");
+          goto done;
+        }
     }
   for (int c = 0; c < G->ncontig; c++)
     { boff[(size_t) c] = G->contigs[c].boff; clen[(size_t) c] = G->contigs[c].clen;
@@ -610,6 +648,7 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
     A.postbytes = postbytes; A.contbytes = contbytes;
     A.keys = NULL; A.index = NULL; A.nkeys = dctr; A.count = dcount; A.sbuck = dctr + 1;        // the counting pass
     A.pbeg = (uint32_t) pbeg; A.pend = (uint32_t) pend;
+    A.goff = NULL;
     hipLaunchKernelGGL(gix_scan_kernel,dim3(scan_grid),dim3(GNT),0,dev->stream,A);
   }
   if (count_only)
@@ -695,6 +734,15 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
       A.postbytes = postbytes; A.contbytes = contbytes;
       A.keys = buf0; A.index = D->index; A.nkeys = dctr; A.count = dcount; A.sbuck = dctr + 1;         // the placing pass
       A.pbeg = (uint32_t) pbeg; A.pend = (uint32_t) pend;
+      A.goff = NULL;
+      if (wide_pay)
+        { if ((e = fga_dmalloc(&dgoff,sizeof(int64_t)*goff.size())) != hipSuccess ||
+              (e = hipMemcpyAsync(dgoff,goff.data(),sizeof(int64_t)*goff.size(),hipMemcpyHostToDevice,dev->stream)) != hipSuccess)
+            { fga_set_error("fga_dgix_build: device allocation failed: %s",hipGetErrorString(e));
+              goto done;
+            }
+          A.goff = dgoff;
+        }
       hipLaunchKernelGGL(gix_scan_kernel,dim3(scan_grid),dim3(GNT),0,dev->stream,A);
       hipLaunchKernelGGL(gix_tiles_kernel,dim3((unsigned) ((ntiles + 1 + 255)/256)),dim3(256),0,dev->stream,D->index,nkeys,ntiles,dtiles);
       hipLaunchKernelGGL(gix_tile_sort_kernel,dim3((unsigned) ntiles),dim3(GT_NT),0,dev->stream,buf0,dtiles,dover,dnover);
@@ -721,7 +769,7 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
           hipMemcpyAsync(dooff,ooff.data(),sizeof(int64_t)*(size_t) nover,hipMemcpyHostToDevice,dev->stream);
           unsigned cg = (unsigned) ((total + 255)/256 < (int64_t) dev->ncu*16 ? (total + 255)/256 : (int64_t) dev->ncu*16);
           hipLaunchKernelGGL(gix_over_copy_kernel,dim3(cg),dim3(256),0,dev->stream,buf0,oscr,dover,dooff,(int) nover,total,0);
-          const int npass = (80 + 8*(postbytes+contbytes) + 7) / 8;
+          const int npass = wide_pay ? 16 : (80 + 8*(postbytes+contbytes) + 7) / 8;
           uint4 *osorted = NULL;
           if (fga_radix_sort_u128(dev,oscr,oscr + total,total,128 - 8*npass,8*npass,&osorted))
             goto done;
@@ -741,6 +789,7 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
       E.table = D->table; E.partid = dpartid;
       E.view = D->view;
       E.moff = NULL; E.mbeg = E.mend = NULL; E.perm = NULL;
+      E.goff = wide_pay ? dgoff : NULL; E.ngoff = G->ncontig; E.invp = dinvp;
       if (use_mask)
         { if ((e = fga_dmalloc(&dmoff,sizeof(int64_t)*(size_t) (nctg+1))) != hipSuccess ||
               (e = fga_dmalloc(&dmbeg,sizeof(int64_t)*(size_t) G->nmask)) != hipSuccess ||
@@ -824,7 +873,7 @@ done:
     fga_pool_free(dimg0);
   fga_pool_free(dboff); fga_pool_free(dclen); fga_pool_free(dinvp); fga_pool_free(ditems); fga_pool_free(dcount); fga_pool_free(dctr);
   fga_pool_free(dpartid);
-  fga_pool_free(dmoff); fga_pool_free(dmbeg); fga_pool_free(dmend); fga_pool_free(dperm); fga_pool_free(dooff);
+  fga_pool_free(dmoff); fga_pool_free(dmbeg); fga_pool_free(dmend); fga_pool_free(dperm); fga_pool_free(dooff); fga_pool_free(dgoff);
   fga_dev_release(dev,SLOT_SORT1,oscr); fga_dev_release(dev,SLOT_TILES,dtiles); fga_dev_release(dev,SLOT_MISC,dover);
   fga_dev_release(dev,SLOT_SORT0,buf0);
   free(perm); free(invp);

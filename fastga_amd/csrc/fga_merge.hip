@@ -751,6 +751,118 @@ void seed_merge_walk_kernel(merge_args A)
     atomicAdd(cold.tseed,tsum);
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Cutoffs beyond what the largest LDS window holds (-f > 1982; the reference takes any positive cutoff, FastGA.c:4497-4499):
+// the same function of SURVEY App. B.1, evaluated straight from the field arrays in HBM.  A wavefront takes 12-mer prefixes
+// in a stride; a lane owns one table-1 entry of the panel: lower bound of its key in the table-2 panel by bisection (global
+// loads), plen from the two neighbours' keys, the run grown on table 2's own lcp bytes exactly as the window kernel grows it
+// (first step either way decided on the keys, the following ones on the bytes, given up once more than `freq` members are
+// certain), the same mask / strand / self rules, and the seeds written to a dense stretch of the buffer taken with one atomic
+// per 64 entries.  No LDS, no tiles: a run of thousands of members is walked by its lane.  Two orders of magnitude slower per
+// entry than the window kernel and meant for what it is -- a rarely used option on repeat-rich inputs; bit-identical seeds.
+// ---------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(64)
+void seed_merge_any_kernel(merge_args A, int pbeg, int pend)
+{ const int lane = threadIdx.x;
+  const uint32_t *idx1 = A.idx1, *idx2 = (MODE == MODE_SELF) ? A.idx1 : A.idx2;
+  const int freq = A.freq, cw1 = A.cw1, cw2 = A.cw2;
+  unsigned long long tsum = 0;
+  for (int64_t p = (int64_t) pbeg + blockIdx.x; p < pend; p += gridDim.x)
+    { const int64_t a0 = p > 0 ? idx1[p-1] : 0, a1 = idx1[p];
+      const int64_t b0 = p > 0 ? idx2[p-1] : 0, b1 = idx2[p];
+      if (a1 <= a0 || b1 <= b0)
+        continue;
+      for (int64_t ab = a0; ab < a1; ab += 64)
+        { const int64_t i = ab + lane;
+          const bool act = i < a1;
+          int64_t low = 0, hgh = 0;
+          int plen = 0, cnt = 0;
+          bool pass = false;
+          if (act)
+            { const uint64_t ks = A.K1[i];
+              int64_t lbnd, nb, na;
+              if (MODE == MODE_SELF)
+                { lbnd = i; low = i; hgh = i+1; nb = i-1; na = i+1; }
+              else
+                { int64_t lo = b0, hi = b1;                       // lower bound of ks among the panel's keys (same prefix byte)
+                  while (lo < hi)
+                    { const int64_t m = (lo + hi) >> 1;
+                      if (A.K2[m] < ks) lo = m+1; else hi = m;
+                    }
+                  lbnd = low = hgh = lo; nb = lo-1; na = lo;
+                }
+              const int lkb = nb >= b0 ? lcp_key(ks,A.K2[nb]) : 0, lka = na < b1 ? lcp_key(ks,A.K2[na]) : 0;
+              plen = lkb > lka ? lkb : lka;
+              const bool ok = plen >= 12;
+              if (ok && lkb >= plen)
+                { low -= 1;
+                  while (low > b0 && lbnd-low <= freq && (int) A.L2[low] >= plen)
+                    low -= 1;
+                }
+              if (ok && lka >= plen && hgh < b1 && hgh-low <= freq)
+                { hgh += 1;
+                  while (hgh < b1 && hgh-low <= freq && (int) A.L2[hgh] >= plen)
+                    hgh += 1;
+                }
+              const int mlen = A.soft_mask ? plen : 41;
+              pass = ok && hgh-low < freq;
+              if (A.soft_mask)
+                pass = pass && (int) A.M1[i] < mlen;
+              if (pass)
+                { if (MODE == MODE_FLIP || A.soft_mask)
+                    { for (int64_t j = low; j < hgh; j++)
+                        { if (A.soft_mask && (int) A.M2[j] >= mlen)
+                            continue;
+                          if (MODE == MODE_FLIP && (lds_c(A.C2 + (size_t) j*cw2,cw2,0) & A.sign2))
+                            continue;
+                          if (MODE == MODE_SELF && j == i)
+                            continue;
+                          cnt += 1;
+                        }
+                    }
+                  else
+                    cnt = (int) (hgh-low) - (MODE == MODE_SELF ? 1 : 0);
+                }
+            }
+          int T;
+          const int off = wave_excl_scan_add_dpp(cnt,T);
+          if (T == 0)
+            continue;
+          unsigned long long bb = 0;
+          if (lane == 0)
+            bb = atomicAdd(A.count,(unsigned long long) T);
+          const uint32_t blo = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) bb);
+          const uint32_t bhi = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (bb >> 32));
+          int64_t at = (int64_t) (((uint64_t) bhi << 32) | blo) + off;
+          if (cnt > 0)
+            { const int mlen = A.soft_mask ? plen : 41;
+              const uint32_t spos = A.P1[i], sc = lds_c(A.C1 + (size_t) i*cw1,cw1,0);
+              const uint32_t ssign = (sc & A.sign1) != 0;
+              for (int64_t j = low; j < hgh; j++)
+                { const uint32_t cc = lds_c(A.C2 + (size_t) j*cw2,cw2,0);
+                  if (A.soft_mask && (int) A.M2[j] >= mlen)
+                    continue;
+                  if (MODE == MODE_FLIP && (cc & A.sign2))
+                    continue;
+                  if (MODE == MODE_SELF && j == i)
+                    continue;
+                  if (at < A.cap)
+                    A.out[at] = make_seed<MODE>(plen,spos,sc & (A.sign1-1),ssign,A.P2[j],cc & (A.sign2-1),(cc & A.sign2) != 0);
+                  at += 1;
+                }
+              tsum += (unsigned long long) cnt * plen;
+            }
+        }
+    }
+  #pragma unroll
+  for (int d = 32; d >= 1; d >>= 1)
+    tsum += __shfl_xor(tsum,d,64);
+  if (lane == 0 && tsum != 0)
+    atomicAdd(A.cold->tseed,tsum);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
@@ -759,6 +871,12 @@ static void launch_walk(int mode, int grid, size_t dyn, hipStream_t st, const me
 { if (mode == MODE_SELF)      hipLaunchKernelGGL((seed_merge_walk_kernel<MODE_SELF,T2CAP>),dim3(grid),dim3(64),dyn,st,A);
   else if (mode == MODE_FLIP) hipLaunchKernelGGL((seed_merge_walk_kernel<MODE_FLIP,T2CAP>),dim3(grid),dim3(64),dyn,st,A);
   else                        hipLaunchKernelGGL((seed_merge_walk_kernel<MODE_PAIR,T2CAP>),dim3(grid),dim3(64),dyn,st,A);
+}
+
+// contigs on the A (which = 0) / B side of the seeds: with flip, table 1 is genome 2 and its entries become the B side
+static inline int64_t mode_flip_contigs(int flip, const fga_dgix *t1, const fga_dgix *t2, int which)
+{ const fga_dgix *a = flip ? t2 : t1, *b = flip ? t1 : t2;
+  return which == 0 ? (int64_t) a->nctg : (int64_t) b->nctg;
 }
 
 static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
@@ -778,8 +896,13 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
     { fga_set_error("fga_seed_merge: the index has no device view");
       return 1;
     }
-  if (prm->freq < 1 || prm->freq > FGA_MERGE_MAX_FREQ)
-    { fga_set_error("fga_seed_merge: frequency cutoff must be in [1,%d]",FGA_MERGE_MAX_FREQ);
+  if (prm->freq < 1)
+    { fga_set_error("fga_seed_merge: the frequency cutoff must be positive");
+      return 1;
+    }
+  // a seed record keeps the A contig in 24 bits (beside plen) and the B contig in 30 (beside the two strand bits)
+  if ((mode_flip_contigs(prm->flip,t1,t2,0) >> 24) != 0 || (mode_flip_contigs(prm->flip,t1,t2,1) >> 30) != 0)
+    { fga_set_error("fga_seed_merge: more than 2^24 contigs in genome 1 (or 2^30 in genome 2) are not supported");
       return 1;
     }
   // an index read from the pre-v1.3 layout holds no k-mer above the cutoff it was built with (FastGA.c:4959-4974)
@@ -888,7 +1011,17 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
   void *work = NULL;
   hipEventCreate(&ev2);
   dev->last_ms[FGA_STAGE_MERGE] = dev->last_ms[FGA_STAGE_MERGE_PARTITION] = 0.f;
-  if (!empty)
+  if (!empty && prm->freq > FGA_MERGE_MAX_FREQ)
+    { // a cutoff no LDS window holds: the kernel that reads the field arrays directly (one lane per table-1 entry)
+      const int grid = dev->ncu * 16;
+      hipEventRecord(dev->ev0,dev->stream);
+      hipEventRecord(dev->ev1,dev->stream);
+      if (mode == MODE_SELF)      hipLaunchKernelGGL(seed_merge_any_kernel<MODE_SELF>,dim3(grid),dim3(64),0,dev->stream,A,pbeg,pend);
+      else if (mode == MODE_FLIP) hipLaunchKernelGGL(seed_merge_any_kernel<MODE_FLIP>,dim3(grid),dim3(64),0,dev->stream,A,pbeg,pend);
+      else                        hipLaunchKernelGGL(seed_merge_any_kernel<MODE_PAIR>,dim3(grid),dim3(64),0,dev->stream,A,pbeg,pend);
+      hipEventRecord(ev2,dev->stream);
+    }
+  else if (!empty)
     { // the sub-tile margin FREQ+2 must leave room in a window: the wide-window build takes over for large cutoffs
       // (cutoffs above 255 need the 64-bit result words: they take the 4096-entry windows whatever their margin)
       const bool wide = 2*(prm->freq + 2) > T2STD - 128, huge = prm->freq > 255;

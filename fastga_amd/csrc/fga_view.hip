@@ -46,9 +46,9 @@ void view_repack_kernel(const uint8_t *tab, const int64_t *idx64, int E, int pos
       const uint64_t addr = (uint64_t) (tab + i*E);
       const uint32_t *w = (const uint32_t *) (addr & ~(uint64_t) 3);
       const uint32_t sh = (uint32_t) (addr & 3);
-      const uint32_t d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3], d4 = w[4];
+      const uint32_t d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3], d4 = w[4], d5 = w[5];
       const uint32_t b0 = vw_alignbyte(d1,d0,sh), b1 = vw_alignbyte(d2,d1,sh), b2 = vw_alignbyte(d3,d2,sh),
-                     b3 = vw_alignbyte(d4,d3,sh);
+                     b3 = vw_alignbyte(d4,d3,sh), b4 = vw_alignbyte(d5,d4,sh);
       // bytes 0..6: suffix, first base in the high bits
       const uint64_t be = ((uint64_t) __builtin_bswap32(b0) << 32) | __builtin_bswap32(b1);      // bytes 0..7 big endian
       const uint64_t suf = be >> 8;
@@ -57,7 +57,7 @@ void view_repack_kernel(const uint8_t *tab, const int64_t *idx64, int E, int pos
       uint32_t lcp = b2 & 0xff;
       if (i == e[k] && lcp > 11) lcp = 11;
       V.L[i] = (uint8_t) lcp;
-      const uint64_t pay = ((((uint64_t) b3 << 32) | b2) >> 8);                                 // bytes 9..15
+      const uint64_t pay = ((((uint64_t) b3 << 32) | b2) >> 8) | ((uint64_t) (b4 & 0xffu) << 56);   // bytes 9..16 (an entry of 17 bytes at most)
       V.P[i] = (uint32_t) pay & pm;
       const uint32_t c = (uint32_t) (pay >> (8*post)) & (cont >= 4 ? 0xffffffffu : ((1u << (8*cont)) - 1));
       if (V.cw == 1)      ((uint8_t  *) V.C)[i] = (uint8_t) c;
@@ -180,9 +180,8 @@ int fga_dgix_make_view(fga_dev *dev, fga_dgix *D, int keep_table)
     { fga_set_error("genome index with %d position bytes: contigs beyond 4 Gbp are not supported",D->postbytes);
       return 1;
     }
-  if (D->postbytes + D->contbytes > 7)
-    { // view_repack_kernel reads the payload from entry bytes 9..15: an eighth byte (the one with the strand bit) would be cut
-      fga_set_error("genome index with %d position and %d contig bytes: payloads beyond 7 bytes are not supported",
+  if (D->postbytes + D->contbytes > 8)
+    { fga_set_error("genome index with %d position and %d contig bytes: payloads beyond 8 bytes are not supported",
                     D->postbytes,D->contbytes);
       return 1;
     }

@@ -39,8 +39,8 @@ def test_argument_errors(fasta_dir):
     assert r.returncode == 1 and "Only one of" in r.stderr
     r = _run(["-i.3", "toy_A", "toy_B"], d)
     assert r.returncode == 1 and "[0.55,1.0)" in r.stderr
-    r = _run(["-f2000", "toy_A", "toy_B"], d)
-    assert r.returncode == 1 and "[1,1982]" in r.stderr
+    r = _run(["-f0", "toy_A", "toy_B"], d)
+    assert r.returncode == 1 and "must be positive" in r.stderr
     r = _run(["-Tx", "toy_A", "toy_B"], d)
     assert r.returncode == 1 and "not an integer" in r.stderr
     r = _run(["-1", "toy_A", "toy_B"], d)

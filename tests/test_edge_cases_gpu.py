@@ -62,3 +62,32 @@ def test_self_comparison_of_the_edge_genome(tmp_path, built_library):
     d = str(tmp_path)
     ra = _build(d, "A", make_edge_scaffolds(3), 1)
     _compare(ra, None, d, strict_order=False, allow_empty=True)
+
+
+def test_seven_byte_payloads_many_small_contigs_and_a_long_one(tmp_path, built_library):
+    """More than 32,768 contigs (3 contig bytes) with one beyond 16.7 Mbp (4 position bytes): a 7-byte payload, which
+    GIXmake sizes freely (GIXmake.c:1888-1901).  It does not fit under the k-mer in the device builder's 128-bit key (the
+    key then carries the k-mer's position in a concatenation of the contigs) and needs all seven payload bytes of the
+    uploaded entries.  Index files from the host producer, then the same comparison with both indices built on the
+    device: both must be the reference's .1aln (its own FastGA on the host producer's files)."""
+    from fastga_amd import workload, synth, device as D
+    from fastga_amd.gixio import Gix
+    from oracle import harness as H
+    d = str(tmp_path)
+    rng = np.random.default_rng(707)
+    big = rng.integers(0, 4, 17_200_000, dtype=np.uint8)
+    small = [rng.integers(0, 4, int(n), dtype=np.uint8) for n in rng.integers(60, 140, 33_000)]
+    A = [big] + small
+    B = [synth.mutate(rng, big, 0.02)] + [synth.mutate(rng, c, 0.03) for c in small[:20_000]] + \
+        [rng.integers(0, 4, int(n), dtype=np.uint8) for n in rng.integers(60, 140, 13_500)]
+    ra = workload.build_genome(d, "A", A, threads=8)
+    rb = workload.build_genome(d, "B", B, threads=8)
+    xa = Gix(ra + ".gix")
+    assert xa.postbytes == 4 and xa.contbytes == 3
+    st = _compare(ra, rb, d)                                         # index files uploaded: every payload byte of the entries
+    assert st["nlive"] > 100
+    ref = H.oneview(os.path.join(d, "ref.1aln"))
+    dev = os.path.join(d, "dev.1aln")
+    st2 = D.run(ra, rb, dev, nthreads=8, reference_threads=8, build_index=True)      # both indices built on the device
+    assert st2["nseeds"] == st["nseeds"] and st2["nlive"] == st["nlive"]
+    assert H.oneview(dev) == H.oneview(os.path.join(d, "ours.1aln")) == ref

@@ -154,6 +154,14 @@ def test_dense_panels_are_streamed_in_windows(dense_pair):
         _compare(dev, A, B, dA, dB, freq=f)
     _compare(dev, B, A, dB, dA, flip=True, freq=700)
     _compare(dev, A, None, dA, None, freq=1982)
+    # beyond the largest window: the window-free kernel (any cutoff, like the reference), every mode
+    for f in (1983, 2500, 6000):
+        _compare(dev, A, B, dA, dB, freq=f)
+    _compare(dev, B, A, dB, dA, flip=True, freq=2500)
+    _compare(dev, A, None, dA, None, freq=2500)
+    _compare(dev, A, B, dA, dB, freq=3000, soft_mask=True)
+    _compare(dev, B, A, dB, dA, flip=True, freq=3000, soft_mask=True)
+    _compare(dev, A, None, dA, None, freq=100000, soft_mask=True)
     _compare(dev, A, B, dA, dB, freq=600, soft_mask=True)
     # the tables carry mask bytes: -M inside the streamed windows, all modes
     plain = _compare(dev, A, B, dA, dB, freq=20)

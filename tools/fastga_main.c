@@ -327,8 +327,9 @@ int main(int argc, char *argv[])
     { fprintf(stderr,"FastGA: Only one of -paf[m] or -paf[x] can be set\n"); return 1; }
   if ((P.paf_flags & FGA_PAF_CS_SHORT) && (P.paf_flags & FGA_PAF_CS_LONG))
     { fprintf(stderr,"FastGA: Only one of -paf[s] or -paf[S] can be set\n"); return 1; }
-  if (P.freq < 1 || P.freq > 1982)                /* the merge kernel's largest window (fga_merge.hip); the reference has no bound */
-    { fprintf(stderr,"FastGA: The adaptive seed count cutoff must be in [1,1982]\n"); return 1; }
+  if (P.freq < 1)                                 /* any positive cutoff, like the reference (FastGA.c:4497-4499); beyond 1982 the
+                                                     merge runs on its slow, window-free kernel (fga_merge.hip)          */
+    { fprintf(stderr,"FastGA: The adaptive seed count cutoff must be positive\n"); return 1; }
   if (ident < .55 || ident >= 1.)
     { fprintf(stderr,"FastGA: '-i' minimum alignment similarity must be in [0.55,1.0)\n"); return 1; }
   if (P.nthreads < 1) P.nthreads = 1;
