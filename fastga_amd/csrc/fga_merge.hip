@@ -220,6 +220,8 @@ __device__ __forceinline__ uint32_t lds_c(const uint8_t *c, int cw, int i)
   return ((const uint32_t *) c)[i];
 }
 
+// (cache policy: nt -- aux 2 -- on these loads and on the seed stores was measured in round 5: 0.789-0.799 ms against 0.789-0.810
+// for the default policy on the bench pair, inside the run-to-run spread; the default stays)
 #define G2L(gp,lp,sz) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (gp), \
                                                        (__attribute__((address_space(3))) void *) (lp),sz,0,0)
 
@@ -916,8 +918,17 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
   }
   FGA_HIP(fga_dev_enter(dev));
   const int mode = self ? MODE_SELF : (prm->flip ? MODE_FLIP : MODE_PAIR);
-  if (mode == MODE_PAIR && fga_dgix_make_forward(dev,(fga_dgix *) t1))      // first use as table 1 of a pair comparison
-    return 1;
+  // The seed buffer is taken BEFORE the forward view is made (first use as table 1 of a pair comparison): at human scale it is
+  // the size of the index builder's key buffer, which lies free at this point -- taken first it fits that piece exactly,
+  // taken after the view's arrays have been carved out of the piece it is a fresh 38 GB region from the driver (~1 s on a
+  // device whose freed memory is still being cleared; the view's arrays are 17 GB)
+  void *pre_seeds = NULL;
+  if (append == NULL && capacity > 0 && mode == MODE_PAIR && t1->fview.K == NULL)
+    pre_seeds = fga_dev_acquire(dev,SLOT_SEEDS,sizeof(fga_seed)*(size_t) (capacity + 2*(int64_t) dev->ncu * 32 * FGA_SEED_BLOCK));
+  if (mode == MODE_PAIR && fga_dgix_make_forward(dev,(fga_dgix *) t1))
+    { fga_dev_release(dev,SLOT_SEEDS,pre_seeds);
+      return 1;
+    }
 
   merge_args A;
   memset(&A,0,sizeof(A));
@@ -952,6 +963,7 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
     { S = (fga_dseeds *) calloc(1,sizeof(fga_dseeds));
       if (S == NULL)
         { fga_set_error("out of memory");
+          fga_dev_release(dev,SLOT_SEEDS,pre_seeds);
           return 1;
         }
       S->dev = dev;
@@ -977,7 +989,8 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
   else
     { const int64_t nb = (S->phys_capacity + FGA_SEED_BLOCK-1) / FGA_SEED_BLOCK + 2;
       if ((err = fga_dmalloc(&counters,CTR_WORDS*sizeof(unsigned long long))) != hipSuccess ||
-          (S->seeds = (fga_seed *) fga_dev_acquire(dev,SLOT_SEEDS,sizeof(fga_seed)*(size_t) S->phys_capacity)) == NULL ||
+          (S->seeds = (fga_seed *) (pre_seeds != NULL ? pre_seeds
+                                                      : fga_dev_acquire(dev,SLOT_SEEDS,sizeof(fga_seed)*(size_t) S->phys_capacity))) == NULL ||
           (S->valid = (uint16_t *) fga_dev_acquire(dev,SLOT_VALID,sizeof(uint16_t)*(size_t) nb)) == NULL)
         { fga_set_error("fga_seed_merge: device allocation failed: %s",hipGetErrorString(err));
           fga_pool_free(counters); fga_dev_release(dev,SLOT_SEEDS,S->seeds); free(S);
