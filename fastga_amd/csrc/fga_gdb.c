@@ -476,12 +476,15 @@ static int read_image(FILE *f, uint8_t *dst, int64_t len)
     return fread(dst,1,(size_t) len,f) != (size_t) len;
   for (t = 0; t < nt; t++)
     { job[t].fd = fileno(f); job[t].dst = dst; job[t].beg = len*t/nt; job[t].end = len*(t+1)/nt; job[t].bad = 0; }
-  for (t = 1; t < nt; t++)
-    if (pthread_create(th+t,NULL,image_thread,job+t) != 0)
-      { image_thread(job+t); th[t] = 0; }
-  image_thread(job);
-  for (t = 1; t < nt; t++)
-    if (th[t]) pthread_join(th[t],NULL);
+  { int started[8];
+    for (t = 1; t < nt; t++)
+      { started[t] = pthread_create(th+t,NULL,image_thread,job+t) == 0;
+        if (!started[t]) image_thread(job+t);
+      }
+    image_thread(job);
+    for (t = 1; t < nt; t++)
+      if (started[t]) pthread_join(th[t],NULL);
+  }
   for (t = 0; t < nt; t++)
     bad |= job[t].bad;
   return bad;

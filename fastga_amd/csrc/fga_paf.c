@@ -16,6 +16,7 @@
 #include <string.h>
 #include <stdint.h>
 #include <pthread.h>
+#include <sys/stat.h>
 #if defined(__SSE2__)
 #include <emmintrin.h>
 #endif
@@ -818,6 +819,7 @@ static int write_lines(const char *path, const fga_gdb *g1, const fga_gdb *g2, c
   const char *who = psl ? "fga_write_psl" : "fga_write_paf";
   paf_run    R;
   pthread_t *th;
+  int *tstarted;
   FILE      *f;
   int        t, c, nchunk, rc = 0, started = 0;
   int64_t    total = 0, acc = 0, i, nxt;
@@ -847,8 +849,9 @@ static int write_lines(const char *path, const fga_gdb *g1, const fga_gdb *g2, c
   memset(&R,0,sizeof(R));
   R.chunk = calloc(nchunk,sizeof(paf_job));
   th = calloc(nthreads,sizeof(pthread_t));
-  if (R.chunk == NULL || th == NULL)
-    { free(R.chunk); free(th);
+  tstarted = calloc(nthreads > 0 ? nthreads : 1,sizeof(int));
+  if (R.chunk == NULL || th == NULL || tstarted == NULL)
+    { free(R.chunk); free(th); free(tstarted);
       fga_set_error("out of memory");
       return 1;
     }
@@ -868,17 +871,16 @@ static int write_lines(const char *path, const fga_gdb *g1, const fga_gdb *g2, c
   f = to_stdout ? stdout : fopen(path,"w");
   if (f == NULL)
     { fga_set_error("cannot create %s",path);
-      free(R.chunk); free(th);
+      free(R.chunk); free(th); free(tstarted);
       return 1;
     }
   pthread_mutex_init(&R.mu,NULL);
   pthread_cond_init(&R.cv,NULL);
   t0 = fga_wall();
   for (t = 0; t < nthreads; t++)
-    if (pthread_create(th+t,NULL,paf_worker,&R) == 0)
-      started = 1;
-    else
-      th[t] = 0;
+    { tstarted[t] = pthread_create(th+t,NULL,paf_worker,&R) == 0;
+      if (tstarted[t]) started = 1;
+    }
   if (!started)                                      /* no thread could be made: format here */
     paf_worker(&R);
   for (c = 0; c < nchunk && rc == 0; c++)
@@ -905,7 +907,7 @@ static int write_lines(const char *path, const fga_gdb *g1, const fga_gdb *g2, c
       J->out.s = NULL;
     }
   for (t = 0; t < nthreads; t++)
-    if (th[t]) pthread_join(th[t],NULL);
+    if (tstarted[t]) pthread_join(th[t],NULL);
   if (to_stdout)
     fflush(f);
   else
@@ -913,8 +915,11 @@ static int write_lines(const char *path, const fga_gdb *g1, const fga_gdb *g2, c
         { fga_set_error("write error on %s",path);
           rc = 1;
         }
-      if (rc != 0)
-        remove(path);
+      if (rc != 0)                                   /* a half-written regular file goes; a FIFO or device the caller named stays */
+        { struct stat sb;
+          if (stat(path,&sb) == 0 && S_ISREG(sb.st_mode))
+            remove(path);
+        }
     }
   if (getenv("FGA_PAF_TIMING") != NULL)
     fprintf(stderr,"  write_lines: %d threads, %d chunks: %.1f ms (writer waited %.1f ms for chunks, wrote for %.1f ms)\n",
@@ -923,7 +928,7 @@ static int write_lines(const char *path, const fga_gdb *g1, const fga_gdb *g2, c
     free(R.chunk[c].out.s);
   pthread_mutex_destroy(&R.mu);
   pthread_cond_destroy(&R.cv);
-  free(R.chunk); free(th);
+  free(R.chunk); free(th); free(tstarted);
   return rc;
 }
 

@@ -594,7 +594,7 @@ static int trace_pts_impl(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
       { const char *ev = getenv("FGA_REGROUP_CAPS");        // test hook / tuning: "<fcap>,<hcap>,<tmax>"
         long long f, h, m;
         if (ev != NULL && sscanf(ev,"%lld,%lld,%lld",&f,&h,&m) == 3 && f > 0 && h > 0 && m > 0)
-          { G.fcap = (int) f; G.hcap = h; G.tmax = (int) m; }
+          { G.fcap = (int) (f > 65535 ? 65535 : f); G.hcap = h > (1 << 20) ? (1 << 20) : h; G.tmax = (int) (m > 65535 ? 65535 : m); }
       }
       if (G.fcap > G.tmax+8)
         G.fcap = G.tmax+8;
