@@ -71,7 +71,7 @@ typedef struct
   } fga_seed;
 
 typedef struct
-  { int     freq;          /* -f : adaptamer frequency cutoff (FastGA.c:4451)                          */
+  { int     freq;          /* -f : adaptamer frequency cutoff (FastGA.c:4451); any positive value (beyond 1982: the slow, window-free kernel) */
     int     soft_mask;     /* -M or #mask arguments: mlen = plen (FastGA.c:824-825)                     */
     int     flip;          /* second pass of -S: table 1 is genome 2 (FastGA.c:2410-2470)               */
     int64_t prefix_begin;  /* 12-mer prefix range [begin,end) handled by this call (multi-GPU sharding; */
