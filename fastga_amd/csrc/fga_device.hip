@@ -200,7 +200,12 @@ hipError_t fga_pool_free(void *ptr)
         P->core.give(ptr);
       return hipSuccess;
     }
-  return hipFree(ptr);
+  // not an allocation of this library (or released before): the driver's to judge, and its verdict stays out of the
+  // sticky error state that the stages' hipGetLastError() checks read
+  const hipError_t e = hipFree(ptr);
+  if (e != hipSuccess)
+    (void) hipGetLastError();
+  return e;
 }
 
 // the small buffers nobody uses go back to the driver (the calling thread's device)
