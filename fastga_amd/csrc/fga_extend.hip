@@ -493,7 +493,7 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
       }
 #endif
 #ifdef EXT_MODE_PROF
-      { static const char *nm[6] = { "register <= 12", "register <= 30", "register <= 60", "ring <= 60", "ring <= 120", "ring wider" };
+      { static const char *nm[6] = { "register <= 12", "register <= 30", "register <= 60", "two blocks", "ring <= 120", "ring wider" };
         double tc = 0, tn = 0;
         for (int k = 0; k < 6; k++) { tc += (double) hc[20+k]; tn += (double) hc[26+k]; }
         for (int k = 0; k < 6; k++)

@@ -40,8 +40,14 @@ def replay_unit(H, spec, aseq_pad, bseq_pad, comp, hits, aln_min, aln_rate):
     return out
 
 
-def test_extension_matches_oracle(toy_pair):
+@pytest.mark.parametrize("build", ["latency", "throughput"])
+def test_extension_matches_oracle(toy_pair, build, monkeypatch):
+    """build = throughput: FGA_EXTEND_NARROW=1 sends the same units through ext_mid (one-copy ring updated in place, waves of
+    61 .. 124 diagonals in two register blocks, the handoff of wider ones to ext_full), which the pipeline only picks for
+    10^4 units and more"""
     from fastga_amd.gixio import Gix, Gdb
+    if build == "throughput":
+        monkeypatch.setenv("FGA_EXTEND_NARROW", "1")
     from fastga_amd import device as D, synth
     from oracle import harness as H
     d, ra, rb = toy_pair
