@@ -11,7 +11,7 @@ root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out
 mkdir -p $out/prof_$tag
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $root/bench.py --steps 5 --warmup 2 --no-cpu --no-cold --no-human-scale"
+BENCH="python $root/bench.py --steps 5 --warmup 2 --no-cpu --no-cold --no-human-scale --batch 0"
 timeout 200 rocprofv3 --kernel-trace --stats -d $out/prof_$tag/kt -o kt --output-format csv -- $BENCH > $out/prof_$tag/kt.log 2>&1
 cp $out/prof_$tag/kt/kt_kernel_stats.csv $out/${tag}_kernel_stats.csv
 grep -a '"metric"' $out/prof_$tag/kt.log | tail -1 > $out/${tag}_bench_under_rocprof.json
