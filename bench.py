@@ -758,16 +758,21 @@ def pmc_traffic():
         return None, None
     fetch = write = None
     commit = ""
+    rows = []
     for row in csv.reader(ln for ln in open(files[-1]) if not ln.startswith("#")):
         if len(row) < 5 or row[0] == "pass":
             continue
         # pass, kernel, counter, launches, avg_per_launch -- a template kernel's name holds commas of its own
-        k, counter, avg = ",".join(row[1:-3]), row[-3], row[-1]
+        rows.append((",".join(row[1:-3]), row[-3], float(row[-2]), float(row[-1])))
+    # per MERGE launch: the range cuts are made once per session since round 5 (fewer launches than the walk kernel)
+    walks = max([n for k, c, n, a in rows if "seed_merge" in k and c == "FETCH_SIZE"] or [1.0])
+    for k, counter, n, avg in rows:
         if "seed_merge" in k or "range_cut" in k:
+            share = avg * (min(n, walks) / walks if "range_cut" in k else 1.0)
             if counter == "FETCH_SIZE":
-                fetch = (fetch or 0.0) + float(avg)
+                fetch = (fetch or 0.0) + share
             elif counter == "WRITE_SIZE":
-                write = (write or 0.0) + float(avg)
+                write = (write or 0.0) + share
     for ln in open(files[-1]):
         if ln.startswith("# commit"):
             commit = ln.split(":", 1)[1].strip()
