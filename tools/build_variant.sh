@@ -9,8 +9,10 @@ obj=$root/build/obj
 mkdir -p $root/fastga_amd/variants $obj
 make -s -C $root/fastga_amd/csrc -j8 >/dev/null
 base=$(basename $src .hip)
+# the per-file flags of fastga_amd/csrc/Makefile
+extra=""; [ $base = fga_extend ] && extra="-mllvm -amdgpu-sched-strategy=max-ilp -fno-slp-vectorize"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -Wno-unused-value \
-  -I$root/include -I$root/fastga_amd/csrc "$@" -c $root/fastga_amd/csrc/$src -o $obj/variant_$name.o
+  -I$root/include -I$root/fastga_amd/csrc $extra "$@" -c $root/fastga_amd/csrc/$src -o $obj/variant_$name.o
 objs=$(ls $obj/*.o | grep -v "/variant_" | grep -v "/$base.hip.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/fastga_amd/variants/lib_$name.so $objs $obj/variant_$name.o -lz -lpthread
 echo built fastga_amd/variants/lib_$name.so
