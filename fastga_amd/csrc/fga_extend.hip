@@ -336,17 +336,31 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
     if (ev != NULL) narrow = atoi(ev) != 0;
     if (getenv("FGA_EXTEND_FORCE_LDS") != NULL) narrow = false;
   }
-  int nwg = dev->ncu * (narrow ? EXT_MID_WGS : (many ? 6 : 4));
+  // Scratch and output are sized by what the hits suggest, not by the worst case times the number of wavefronts; the
+  // kernel counts what it would have needed, so a launch that runs out is repeated once with exactly that
+  // (prm->cell_cap: pool cells; prm->aln_cap / prm->trace_cap: output records / trace bytes).
+  int64_t span = 0, span_max = 0;              // hit-box bases of all units / of the unit with the most
+  for (int64_t u = 0; u < H->nunits; u++)
+    { int64_t su = 0;
+      for (int64_t h = H->units[u].first_hit, e = h + H->units[u].nhits; h < e; h++)
+        su += (H->hits[h].ahgh - H->hits[h].alow) / 2 + 200;
+      span += su;
+      if (su > span_max) span_max = su;
+    }
+  // Latency regime: the run time is the longest unit's serial chain, and that chain is shortest when its wavefront has the CU
+  // to itself (bench pair, 20 launches each: four wavefronts per CU 58.1 .. 69.0 ms, mean 60.5; three 59.6; two 59.0; ONE 56.4 ..
+  // 58.5, mean 56.8 -- the neighbours share the CU's scalar unit, caches and LDS).  So: as few wavefronts per CU as leave
+  // every wavefront's share of the work below half of the longest unit's (both as hit-box bases), four at most.
+  int per_cu = 4;
+  if (!many)
+    for (per_cu = 1; per_cu < 4; per_cu++)
+      if (2*span <= span_max * (int64_t) dev->ncu * per_cu)
+        break;
+  int nwg = dev->ncu * (narrow ? EXT_MID_WGS : (many ? 6 : per_cu));
   { const char *ev = getenv("FGA_EXTEND_WGS");
     if (ev != NULL && atoi(ev) > 0) nwg = atoi(ev);
   }
   if (nwg > H->nunits) nwg = (int) H->nunits;
-  // Scratch and output are sized by what the hits suggest, not by the worst case times the number of wavefronts; the
-  // kernel counts what it would have needed, so a launch that runs out is repeated once with exactly that
-  // (prm->cell_cap: pool cells; prm->aln_cap / prm->trace_cap: output records / trace bytes).
-  int64_t span = 0;
-  for (int64_t h = 0; h < H->nhits; h++)
-    span += (H->hits[h].ahgh - H->hits[h].alow) / 2 + 200;
   // cells / trace bytes per hit-box base: 0.12 / 0.04 to begin with, afterwards what the device context's last launch needed
   // plus a quarter.  (Measured beyond every wavefront's first level: 0.02-0.03 cells per base -- 3 Gbp at 10 %: 4.0 GB used,
   // 150 Mbp repeat-heavy self: 1.1 GB, the 100 Mbp bench pair: 0.33 GB; the first estimate, 0.48, asked for 63.6 / 5.7 /
@@ -480,9 +494,9 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
       if (getenv("FGA_EXTEND_PROFILE") != NULL)
         fprintf(stderr,"extend profile: max per wavefront: steps %.2f Mcyc, unwind %.2f Mcyc, total %.2f Mcyc, waves %llu; "
                        "sum: steps %.1f Mcyc unwind %.1f Mcyc; kernel %.2f ms, %d workgroups, %lld units, %llu register->ring spills, "
-                       "pool %.1f of %.1f MB\n",
+                       "pool %.1f of %.1f MB; hit-box bases %.1f M, longest unit %.2f M\n",
                 hc[5]*1e-6,hc[6]*1e-6,hc[7]*1e-6,hc[10],hc[8]*1e-6,hc[9]*1e-6,dev->last_ms[FGA_STAGE_EXTEND],nwg,
-                (long long) H->nunits,hc[11],hc[16]*16e-6,pool_cells*16e-6);
+                (long long) H->nunits,hc[11],hc[16]*16e-6,pool_cells*16e-6,span*1e-6,span_max*1e-6);
 #ifdef EXT_STEP_PROF
       { unsigned long long sp[8], z[8] = {0,0,0,0,0,0,0,0};
         hipMemcpyFromSymbol(sp,HIP_SYMBOL(ext_full::ext_step_prof),sizeof(sp));
