@@ -494,9 +494,12 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
       if (getenv("FGA_EXTEND_PROFILE") != NULL)
         fprintf(stderr,"extend profile: max per wavefront: steps %.2f Mcyc, unwind %.2f Mcyc, total %.2f Mcyc, waves %llu; "
                        "sum: steps %.1f Mcyc unwind %.1f Mcyc; kernel %.2f ms, %d workgroups, %lld units, %llu register->ring spills, "
-                       "pool %.1f of %.1f MB; hit-box bases %.1f M, longest unit %.2f M\n",
+                       "pool %.1f of %.1f MB; hit-box bases %.1f M, longest unit %.2f M; the longest-running wavefront: %.2f Mcyc = steps %.2f + unwind %.2f "
+                       "(reverse walks %.2f) + rest, %llu calls\n",
                 hc[5]*1e-6,hc[6]*1e-6,hc[7]*1e-6,hc[10],hc[8]*1e-6,hc[9]*1e-6,dev->last_ms[FGA_STAGE_EXTEND],nwg,
-                (long long) H->nunits,hc[11],hc[16]*16e-6,pool_cells*16e-6,span*1e-6,span_max*1e-6);
+                (long long) H->nunits,hc[11],hc[16]*16e-6,pool_cells*16e-6,span*1e-6,span_max*1e-6,
+                (double) (hc[15] >> 42)*1024e-6,(double) ((hc[15] >> 21) & 0x1fffff)*1024e-6,(double) (hc[15] & 0x1fffff)*1024e-6,
+                (double) ((hc[17] >> 21) & 0x1fffff)*1024e-6,hc[17] & 0x1fffff);
 #ifdef EXT_STEP_PROF
       { unsigned long long sp[8], z[8] = {0,0,0,0,0,0,0,0};
         hipMemcpyFromSymbol(sp,HIP_SYMBOL(ext_full::ext_step_prof),sizeof(sp));
