@@ -571,10 +571,14 @@ def sharded_human_scale(D, workload, dist, workdir, threads, rank, world, local)
             shutil.rmtree(d, ignore_errors=True)
 
 
-# VALU wave-instructions per wave step of the extension (rocprofv3 PMC pass of the bench pair, profiles/r03_pmc_summary.csv)
-# and what the chip issues: 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction
-EXT_VALU_PER_STEP = 230.0
-VALU_ISSUE_PER_S = 1024 * 2.4e9 / 2
+# What a wave step of the throughput extension costs a SIMD's vector ALU: 224 VALU wave-instructions per step (rocprofv3 PMC,
+# profiles/r05_throughput_pmc_summary.csv), of which on the common path of ext_mid::ext_episode1 60 are of the kinds gfx950
+# issues in 2.2 cycles (v_add / v_sub / v_and / v_or / v_xor / v_mov on VGPRs or a literal) and 164 of the kinds that take 4.1
+# (selects, compares, shifts, min / max, DPP, SDWA, three-operand forms, anything with an SGPR operand) -- measured per kind by
+# tools/ubench/valu_rate.hip, profiles/r05_valu_issue_rates.txt; the chip has 1024 SIMDs at 2.4 GHz
+EXT_VALU_PER_STEP = 224.0
+EXT_VALU_CYCLES_PER_STEP = 60 * 2.2 + 164 * 4.1
+SIMD_CYCLES_PER_S = 1024 * 2.4e9
 XGMI_LINK_GBS = 153.0          # one xGMI link (point to point, 7 per GPU): MI355X_MICROARCH.md
 
 
@@ -595,9 +599,11 @@ def extend_block(st):
     return {"kernel": "ext_mid::extend_kernel (throughput regime: sixteen wavefronts per CU, issue-bound)", "bound": "valu issue",
             "kernel_ms": round(k, 1), "wave_steps": int(st["nwaves"]), "wave_steps_per_s": st["nwaves"] / (k * 1e-3),
             "avg_wave_width": st["ext_cells"] / max(1, st["nwaves"]),
-            "valu_issue_frac_est": st["nwaves"] * EXT_VALU_PER_STEP / (k * 1e-3) / VALU_ISSUE_PER_S,
-            "note": f"{EXT_VALU_PER_STEP:g} VALU wave-instructions per step (PMC, bench pair) x steps / kernel time / "
-                    f"{VALU_ISSUE_PER_S:.3g} per s; step-weighted wave widths: profiles/r04_extend_wave_widths.txt"}
+            "valu_issue_frac_est": st["nwaves"] * EXT_VALU_CYCLES_PER_STEP / (k * 1e-3) / SIMD_CYCLES_PER_S,
+            "note": f"{EXT_VALU_PER_STEP:g} VALU wave-instructions per step (PMC) = {EXT_VALU_CYCLES_PER_STEP:.0f} cycles of a SIMD's vector "
+                    f"ALU at the issue cost of each kind (profiles/r05_valu_issue_rates.txt) x steps / kernel time / "
+                    f"{SIMD_CYCLES_PER_S:.3g} SIMD cycles per s; PMC: SQ_ACTIVE_INST_VALU = 24 % of the wave cycles with four "
+                    f"wavefronts per SIMD (profiles/r05_throughput_pmc_summary.csv)"}
 
 
 def project_8gpu(st8, nparts):
