@@ -34,6 +34,14 @@
 #define I_SALU(i)  "s_add_u32 s20, s20, s21\n"
 #define I_CNDVCC(i) "v_cndmask_b32_e32 %" #i ", %" #i ", %8, vcc\n"
 #define I_MOV(i)   "v_mov_b32 %" #i ", %8\n"
+#define I_CNDVCC64(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %8, vcc\n"
+#define I_CNDVCCX(i) "v_cndmask_b32_e32 %" #i ", %8, %" #i ", vcc\n"
+#define I_CNDMIX(i) "v_cndmask_b32_e32 %" #i ", %" #i ", %8, vcc\n v_add_u32 %" #i ", %" #i ", %8\n"
+#define I_OR(i)    "v_or_b32 %" #i ", %" #i ", %8\n"
+#define I_SUBB(i)  "v_subrev_u32 %" #i ", %" #i ", %8\n"
+#define I_ASHR(i)  "v_ashrrev_i32 %" #i ", 1, %" #i "\n"
+#define I_NOT(i)   "v_not_b32 %" #i ", %" #i "\n"
+#define I_ADDCO(i) "v_add_co_u32 %" #i ", vcc, %" #i ", %8\n"
 #define I_LSHL(i)  "v_lshlrev_b32 %" #i ", 3, %" #i "\n"
 #define I_SUB(i)   "v_sub_u32 %" #i ", %" #i ", %8\n"
 #define I_MIN(i)   "v_min_i32 %" #i ", %" #i ", %8\n"
@@ -59,6 +67,7 @@ __global__ void k(int n, unsigned *out, unsigned long long *cyc)
   for (int i = 0; i < 8; i++) a[i] = threadIdx.x*(i+3);
   unsigned c = threadIdx.x | 1;
   unsigned long long m = 0x5555aaaa5555aaaaull;
+  asm volatile("s_mov_b64 vcc, %0" :: "s"(m) : "vcc");
   __syncthreads();
   unsigned long long t0 = clock64();
   for (int it = 0; it < n; it++)
@@ -93,6 +102,13 @@ __global__ void k(int n, unsigned *out, unsigned long long *cyc)
       if (KIND == 29) BODY(I_XORE64)
       if (KIND == 30) BODY(I_ADDC)
       if (KIND == 31) BODY(I_MAX)
+      if (KIND == 32) BODY(I_CNDVCC64)
+      if (KIND == 33) BODY(I_CNDVCCX)
+      if (KIND == 34) BODY(I_CNDMIX)
+      if (KIND == 35) BODY(I_OR)
+      if (KIND == 36) BODY(I_ASHR)
+      if (KIND == 37) BODY(I_NOT)
+      if (KIND == 38) BODY(I_ADDCO)
       if (KIND == 12) { asm volatile(I_SALU(0) I_SALU(0) I_SALU(0) I_SALU(0) I_SALU(0) I_SALU(0) I_SALU(0) I_SALU(0)
                                      I_SALU(0) I_SALU(0) I_SALU(0) I_SALU(0) I_SALU(0) I_SALU(0) I_SALU(0) I_SALU(0)
                                      I_SALU(0) I_SALU(0) I_SALU(0) I_SALU(0) I_SALU(0) I_SALU(0) I_SALU(0) I_SALU(0)
@@ -148,6 +164,13 @@ int main()
   run<11>("v_mul_lo_u32",out,cyc);
   run<12>("s_add_u32 (per CU: 4 SIMDs share)",out,cyc);
   run<13>("v_cndmask_b32_e32 (vcc)",out,cyc);
+  run<32>("v_cndmask_b32_e64 (vcc)",out,cyc);
+  run<33>("v_cndmask_b32_e32 (vcc), dst = src1",out,cyc);
+  run<34>("v_cndmask_e32 (vcc) + v_add_u32: per pair",out,cyc);
+  run<35>("v_or_b32",out,cyc);
+  run<36>("v_ashrrev_i32",out,cyc);
+  run<37>("v_not_b32",out,cyc);
+  run<38>("v_add_co_u32 -> vcc",out,cyc);
   run<14>("v_mov_b32",out,cyc);
   run<15>("v_lshlrev_b32",out,cyc);
   run<16>("v_sub_u32",out,cyc);
