@@ -246,15 +246,20 @@ struct res_fmt
   { static constexpr bool BIG = (T2CAP > 1024);
     typedef typename std::conditional<BIG,uint64_t,uint32_t>::type word;
     // i: the entry's index in the tile (< T1CAP = 256), or in a self comparison its distance from the run's start (<= -f)
+    // plen (12 .. 40): six bits in the wide word, plen - 11 in five bits of the narrow one (never 0: a descriptor is told from an
+    // empty slot by that); one bit above it: the run has members that do not count (a mask byte, the strand, the entry itself
+    // in a FLIP pass) -- only then does the emission have to walk the run to find a seed's partner
     static constexpr int I_BITS = BIG ? 16 : 8, LOW_SH = I_BITS, LOW_BITS = BIG ? 16 : 10, PLEN_SH = LOW_SH + LOW_BITS,
-                         CNT_SH = BIG ? 40 : 24;
-    static __device__ __forceinline__ word pack(int i, int low, int plen, int cnt)
-    { return (word) (uint32_t) i | ((word) (uint32_t) low << LOW_SH) | ((word) (uint32_t) plen << PLEN_SH) | ((word) (uint32_t) cnt << CNT_SH); }
+                         PLEN_BITS = BIG ? 6 : 5, PLEN_OFF = BIG ? 0 : 11, DIRTY_SH = PLEN_SH + PLEN_BITS, CNT_SH = BIG ? 40 : 24;
+    static __device__ __forceinline__ word pack(int i, int low, int plen, int cnt, bool dirty)
+    { return (word) (uint32_t) i | ((word) (uint32_t) low << LOW_SH) | ((word) (uint32_t) (plen - PLEN_OFF) << PLEN_SH)
+             | ((word) (dirty ? 1u : 0u) << DIRTY_SH) | ((word) (uint32_t) cnt << CNT_SH); }
+    static __device__ __forceinline__ bool dirty(word d) { return ((d >> DIRTY_SH) & 1) != 0; }
     static __device__ __forceinline__ int  cnt(word r)   { return (int) (r >> CNT_SH); }
     static __device__ __forceinline__ word body(word r)  { return r & (((word) 1 << CNT_SH) - 1); }          // all but the count
     static __device__ __forceinline__ int  i(word d)     { return (int) (d & (((word) 1 << I_BITS) - 1)); }
     static __device__ __forceinline__ int  low(word d)   { return (int) ((d >> LOW_SH) & (((word) 1 << LOW_BITS) - 1)); }
-    static __device__ __forceinline__ int  plen(word d)  { return (int) ((d >> PLEN_SH) & 0x3f); }
+    static __device__ __forceinline__ int  plen(word d)  { return (int) ((d >> PLEN_SH) & (((word) 1 << PLEN_BITS) - 1)) + PLEN_OFF; }
   };
 
 // The match of up to NR rounds of T1 entries (entry c = r*64 + lane of the tile) side by side.  qe: the entry's panel
@@ -370,7 +375,8 @@ __device__ __forceinline__ void match_rounds(const merge_args &A, const uint64_t
         }
       else
         cnt = pass ? (hgh-low) - (MODE == MODE_SELF ? 1 : 0) : 0;
-      res[r] = (pass && cnt > 0) ? res_fmt<T2CAP>::pack(MODE == MODE_SELF ? i - low : i,low,plen,cnt) : 0;
+      res[r] = (pass && cnt > 0) ? res_fmt<T2CAP>::pack(MODE == MODE_SELF ? i - low : i,low,plen,cnt,
+                                                        cnt != (hgh-low) - (MODE == MODE_SELF ? 1 : 0)) : 0;
       total += cnt;
       tsum += (unsigned long long) cnt * plen;
     }
@@ -535,7 +541,7 @@ __device__ __forceinline__ int walk_tile(const merge_args &A, tile_lds<T2CAP> &S
                   int k = (slot - start) + RF::cnt(d);
                   int j = RF::low(d);
                   const int i = RF::i(d) + (MODE == MODE_SELF ? j : 0);               // self: stored relative to the run's start
-                  if (plain)
+                  if (plain || !RF::dirty(d))      // every member of the run counts (but the entry itself): the k-th is the k-th
                     { j += k;
                       if (MODE == MODE_SELF && j >= i)
                         j += 1;
