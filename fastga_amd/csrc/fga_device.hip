@@ -114,6 +114,9 @@ hipError_t fga_dev_enter(const fga_dev *dev)
   return hipSetDevice(dev->device);
 }
 
+hipError_t fga_memset_here(void *ptr, int value, size_t bytes)
+{ return hipMemsetAsync(ptr,value,bytes,g_tls_have ? g_tls_stream : (hipStream_t) NULL); }
+
 #include <unordered_map>
 struct pool_owner { hipStream_t stream; bool have; int klass; };       // klass >= 0: a small buffer of 256 << klass bytes
 #define SMALL_CLASSES 13                                                // 256 B .. 1 MiB
@@ -466,7 +469,7 @@ static int dgix_upload_impl(fga_dev *dev, const fga_gix *X, int64_t pbeg, int64_
       return 1;
     }
   if ((e = hipMemcpy(D->table,X->table + (size_t) lo*X->ebytes,tbytes,hipMemcpyHostToDevice)) != hipSuccess ||
-      (e = hipMemset(D->table + tbytes,0,64)) != hipSuccess ||
+      (e = hipMemsetAsync(D->table + tbytes,0,64,dev->stream)) != hipSuccess ||
       (e = hipMemcpy(D->index,hidx,sizeof(int64_t)*FGA_NPREFIX,hipMemcpyHostToDevice)) != hipSuccess)
     { fga_set_error("fga_dgix_upload: copy failed: %s",hipGetErrorString(e));
       fga_pool_free(D->table); fga_pool_free(D->index); free(D); free(sub);

@@ -40,6 +40,10 @@ void fga_dev_note_memory(fga_dev *dev);
 // and the context's stream the thread's "current stream" -- the stream an allocation made by this thread belongs to, which is
 // what a release of the allocation waits for (fga_device.hip)
 hipError_t fga_dev_enter(const fga_dev *dev);
+// hipMemset on the calling thread's current stream.  (hipMemset itself returns before the fill has happened and runs on the
+// legacy default stream, which is NOT ordered with the contexts' non-blocking streams: with several contexts at work in one
+// process the fill could land after the kernel that was launched behind it had written the buffer.)
+hipError_t fga_memset_here(void *ptr, int value, size_t bytes);
 
 // Device memory of a MiB and more is a piece of a region the process keeps (fga_device.hip: the pool); smaller requests go
 // to hipMalloc.  fga_pool_free takes either kind.  Every allocation of the library goes through these two.

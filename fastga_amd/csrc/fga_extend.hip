@@ -254,9 +254,13 @@ static int dgenome_make(fga_dev *dev, const fga_gdb *G, const int *perm, int npe
       fga_pool_free(D->img); fga_pool_free(D->boff); fga_pool_free(D->clen); fga_pool_free(D->perm); fga_pool_free(D->img_rc); free(D);
       return 1;
     }
+  // every fill and the kernel below on the context's stream, in order: a hipMemset (legacy default stream, returns before it
+  // has happened) is not ordered with a non-blocking stream -- with several contexts opening at once in one process (fga_run_multi)
+  // the zeroing of the complement image could land AFTER revcomp_kernel had written it
   if (adopt == NULL)
-    { hipMemset(D->img,0,bytes);
-      hipMemcpy(D->img + IMG_PAD,G->bps,G->bpslen,hipMemcpyHostToDevice);
+    { hipMemsetAsync(D->img,0,IMG_PAD,dev->stream);
+      hipMemsetAsync(D->img + IMG_PAD + G->bpslen,0,bytes - IMG_PAD - (size_t) G->bpslen,dev->stream);
+      hipMemcpyAsync(D->img + IMG_PAD,G->bps,G->bpslen,hipMemcpyHostToDevice,dev->stream);
     }
   hipMemcpy(D->boff,boff.data(),sizeof(int64_t)*G->ncontig,hipMemcpyHostToDevice);
   hipMemcpy(D->clen,clen.data(),sizeof(int64_t)*G->ncontig,hipMemcpyHostToDevice);
@@ -266,7 +270,7 @@ static int dgenome_make(fga_dev *dev, const fga_gdb *G, const int *perm, int npe
   if (nperm > 0)
     hipMemcpy(D->perm,perm,sizeof(int)*nperm,hipMemcpyHostToDevice);
   if (want_revcomp)
-    { hipMemset(D->img_rc,0,bytes);
+    { hipMemsetAsync(D->img_rc,0,bytes,dev->stream);
       dim3 grid(256,G->ncontig);
       hipLaunchKernelGGL(revcomp_kernel,grid,dim3(256),0,dev->stream,D->img,D->img_rc,D->boff,D->clen,
                          G->ncontig,(int64_t) IMG_PAD);
@@ -648,7 +652,7 @@ extern "C" void *fga_shim_New_Work_Data(void)
   if (fga_dev_open(e != NULL ? atoi(e) : 0,&W->dev))
     { delete W; return NULL; }
   if (fga_dmalloc(&W->dout,sizeof(int)*8) != hipSuccess || fga_dmalloc(&W->dcnt,sizeof(unsigned long long)*32) != hipSuccess ||
-      fga_dmalloc(&W->dlists,sizeof(arena_lists)) != hipSuccess || hipMemset(W->dlists,0,sizeof(arena_lists)) != hipSuccess)
+      fga_dmalloc(&W->dlists,sizeof(arena_lists)) != hipSuccess || hipMemsetAsync(W->dlists,0,sizeof(arena_lists),W->dev->stream) != hipSuccess)
     { fga_set_error("fga_shim_New_Work_Data: device allocation failed");
       fga_pool_free(W->dout); fga_dev_close(W->dev); delete W;
       return NULL;

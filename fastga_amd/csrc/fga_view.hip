@@ -164,9 +164,10 @@ int fga_view_alloc(fga_view *V, int64_t n, int cont, int want_l)
       return 1;
     }
   // the slack behind the last entry is read (never used): keep it defined
-  hipMemset(V->K + n,0xff,8*256);
-  if (V->L) hipMemset(V->L + n,0,256);
-  hipMemset(V->M + n,0,256); hipMemset(V->P + n,0,4*256); hipMemset((uint8_t *) V->C + (size_t) V->cw*n,0,(size_t) V->cw*256);
+  // (on the calling context's stream: the kernels that fill the view follow on it)
+  fga_memset_here(V->K + n,0xff,8*256);
+  if (V->L) fga_memset_here(V->L + n,0,256);
+  fga_memset_here(V->M + n,0,256); fga_memset_here(V->P + n,0,4*256); fga_memset_here((uint8_t *) V->C + (size_t) V->cw*n,0,(size_t) V->cw*256);
   return 0;
 }
 

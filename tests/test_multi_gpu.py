@@ -151,3 +151,21 @@ def test_cli_with_gpu_list_is_the_reference(toy_pair, tmp_path):
         assert _keep(_view(out + ".1aln")) == ref, (args, env)
         if env:
             assert "Using %d GPUs" % len(env["FGA_DEVICES"].split(",")) in r.stderr
+
+
+@pytest.mark.gpu
+def test_run_multi_again_and_again(toy_pair, tmp_path):
+    """three virtual ranks = three host threads opening sessions, uploading genomes and launching kernels at once on their own
+    (non-blocking) streams, thirty times over: every run is the single-session run's file.  (Pins a race this flow found:
+    hipMemset runs on the legacy default stream, is not ordered with a non-blocking stream and returns before it has happened
+    -- with several contexts at work the zeroing of the complement genome image landed after revcomp_kernel had written it in
+    one run of thirty, and alignments of that strand went missing.  All fills are on the contexts' streams now.)"""
+    from fastga_amd import device as D
+    d, ra, rb = toy_pair
+    w = str(tmp_path)
+    D.run(ra, rb, os.path.join(w, "one.1aln"), nthreads=8, reference_threads=8)
+    ref = _keep(_view(os.path.join(w, "one.1aln")))
+    out = os.path.join(w, "m.1aln")
+    for k in range(30):
+        D.run_multi(ra, rb, out, devices=(0, 0, 0), nthreads=8, reference_threads=8)
+        assert _keep(_view(out)) == ref, k
