@@ -241,20 +241,22 @@ __device__ __forceinline__ void lds_fill(const void *g, void *l, int nbytes, int
 // How the match's result for one table-1 entry (and the emission's descriptor made from it) is packed: entry i of the tile
 // (self: i - low), first run member `low`, plen, number of seeds.  32 bits in the windows of up to 1024 entries (8 + 10 + 6 +
 // 8 bits: run counts below 256, i.e. -f <= 255); 64 bits in the 4096-entry windows of the build for larger cutoffs.
-template <int T2CAP>
+template <int T2CAP, bool FLAG = false>
 struct res_fmt
   { static constexpr bool BIG = (T2CAP > 1024);
     typedef typename std::conditional<BIG,uint64_t,uint32_t>::type word;
     // i: the entry's index in the tile (< T1CAP = 256), or in a self comparison its distance from the run's start (<= -f)
-    // plen (12 .. 40): six bits in the wide word, plen - 11 in five bits of the narrow one (never 0: a descriptor is told from an
-    // empty slot by that); one bit above it: the run has members that do not count (a mask byte, the strand, the entry itself
-    // in a FLIP pass) -- only then does the emission have to walk the run to find a seed's partner
+    // plen (12 .. 40) in six bits.  FLAG (the self and the FLIP kernels): one bit says that the run has members that do not
+    // count (a mask byte, the strand) -- only then does the emission have to walk the run to find a seed's partner; in the
+    // narrow word the bit is plen's sixth, and plen - 11 (never 0: a descriptor is told from an empty slot by that) takes five.
+    // The plain pair kernel keeps the word without the flag (its emission never walks; the two instructions per entry showed).
     static constexpr int I_BITS = BIG ? 16 : 8, LOW_SH = I_BITS, LOW_BITS = BIG ? 16 : 10, PLEN_SH = LOW_SH + LOW_BITS,
-                         PLEN_BITS = BIG ? 6 : 5, PLEN_OFF = BIG ? 0 : 11, DIRTY_SH = PLEN_SH + PLEN_BITS, CNT_SH = BIG ? 40 : 24;
+                         PLEN_BITS = (BIG || !FLAG) ? 6 : 5, PLEN_OFF = (BIG || !FLAG) ? 0 : 11, DIRTY_SH = PLEN_SH + PLEN_BITS,
+                         CNT_SH = BIG ? 40 : 24;
     static __device__ __forceinline__ word pack(int i, int low, int plen, int cnt, bool dirty)
     { return (word) (uint32_t) i | ((word) (uint32_t) low << LOW_SH) | ((word) (uint32_t) (plen - PLEN_OFF) << PLEN_SH)
-             | ((word) (dirty ? 1u : 0u) << DIRTY_SH) | ((word) (uint32_t) cnt << CNT_SH); }
-    static __device__ __forceinline__ bool dirty(word d) { return ((d >> DIRTY_SH) & 1) != 0; }
+             | (FLAG ? ((word) (dirty ? 1u : 0u) << DIRTY_SH) : (word) 0) | ((word) (uint32_t) cnt << CNT_SH); }
+    static __device__ __forceinline__ bool dirty(word d) { return FLAG ? ((d >> DIRTY_SH) & 1) != 0 : true; }
     static __device__ __forceinline__ int  cnt(word r)   { return (int) (r >> CNT_SH); }
     static __device__ __forceinline__ word body(word r)  { return r & (((word) 1 << CNT_SH) - 1); }          // all but the count
     static __device__ __forceinline__ int  i(word d)     { return (int) (d & (((word) 1 << I_BITS) - 1)); }
@@ -375,7 +377,7 @@ __device__ __forceinline__ void match_rounds(const merge_args &A, const uint64_t
         }
       else
         cnt = pass ? (hgh-low) - (MODE == MODE_SELF ? 1 : 0) : 0;
-      res[r] = (pass && cnt > 0) ? res_fmt<T2CAP>::pack(MODE == MODE_SELF ? i - low : i,low,plen,cnt,
+      res[r] = (pass && cnt > 0) ? res_fmt<T2CAP,MODE != MODE_PAIR>::pack(MODE == MODE_SELF ? i - low : i,low,plen,cnt,
                                                         cnt != (hgh-low) - (MODE == MODE_SELF ? 1 : 0)) : 0;
       total += cnt;
       tsum += (unsigned long long) cnt * plen;
@@ -469,7 +471,7 @@ __device__ __forceinline__ int walk_tile(const merge_args &A, tile_lds<T2CAP> &S
 
   XPROF(3)
   // 3. match: result per round packed i (8 bits; self: i - low) | low | plen | seeds (res_fmt)
-  typedef res_fmt<T2CAP> RF;
+  typedef res_fmt<T2CAP,MODE != MODE_PAIR> RF;
   typename RF::word res[4];
   int total = 0;
   { const int nr = (na + 63) >> 6;
