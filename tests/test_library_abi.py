@@ -56,3 +56,37 @@ def test_gdb_gix_roundtrip_through_c_abi(toy_pair):
         else:
             kmer = [3 - int(v) for v in seq[pos - 40:pos][::-1]]
             assert kmer[12:] == suf
+
+
+def test_product_sources_keep_the_stream_rules():
+    """Source rules the library's concurrency rests on, checked on the text of fastga_amd/csrc: every device
+    context launches on its own NON-BLOCKING stream, so nothing may go to the legacy default stream and expect to be
+    ordered with it -- no hipMemset (asynchronous, default stream: the fill of a buffer could land after the kernel
+    launched behind it had written it, which cost fga_run_multi alignments in 3 % of its runs), no kernel launch or
+    asynchronous copy / fill on stream 0; and the product never reaches for the oracle."""
+    import glob
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fastga_amd", "csrc")
+    files = sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.inc"))
+                   + glob.glob(os.path.join(root, "*.c")) + glob.glob(os.path.join(root, "*.h*")))
+    assert len(files) > 20
+    bad = []
+    for f in files:
+        text = open(f, errors="replace").read()
+        code = re.sub(r"//[^\n]*", "", re.sub(r"/\*.*?\*/", "", text, flags=re.S))      # comments may name what is banned
+        for m in re.finditer(r"\bhipMemset\s*\(", code):
+            bad.append((os.path.basename(f), "hipMemset("))
+        for m in re.finditer(r"\bhipMemsetAsync\s*\(([^;]*?)\)\s*[;)!=|&]", code, flags=re.S):
+            last = m.group(1).split(",")[-1].strip()
+            if last in ("0", "NULL", "nullptr", "(hipStream_t) 0"):
+                bad.append((os.path.basename(f), "hipMemsetAsync on stream 0"))
+        for m in re.finditer(r"hipLaunchKernelGGL\s*\(([^;]*?)\)\s*;", code, flags=re.S):
+            args = m.group(1).split(",")
+            if len(args) >= 5 and args[4].strip() in ("0", "NULL", "nullptr"):
+                bad.append((os.path.basename(f), "kernel launch on stream 0"))
+        if re.search(r"oracle/|liboracle|libalign_ref", code):
+            bad.append((os.path.basename(f), "mentions the oracle"))
+    assert not bad, bad
+    dev = open(os.path.join(root, "fga_device.hip")).read()
+    assert "hipStreamCreateWithFlags(&d->stream,hipStreamNonBlocking)" in dev
