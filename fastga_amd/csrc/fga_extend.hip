@@ -87,7 +87,7 @@ struct ext_args
     // alignment parameters
     int   tspace, path_ave, self, aln_min, mscore, force_lds;
     double aln_rate;
-    const int16_t *table, *score;
+    const int *trim32;                   // the reference's TABLE[32768] (align.c:207-218) as dwords: the scalar-side trim test
     // scratch (per workgroup)
     int4     *pool;   int64_t pool_cells;    // the launch's cell pool (pebble levels and trace scratch of all wavefronts)
     unsigned long long *pool_next;           // its head
@@ -396,7 +396,7 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
   int64_t ncalls_total = 0;
   fga_unit *d_units = NULL; fga_hit *d_hits = NULL; int *d_order = NULL, *d_next = NULL, *d_wide = NULL;
   std::vector<int> wide;
-  int16_t *d_tab = NULL;
+  int *d_tab = NULL;
   unsigned long long *d_cnt = NULL;
   arena_lists *d_lists = NULL;
   hipError_t e;
@@ -406,7 +406,7 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
       (e = fga_dmalloc(&d_order,sizeof(int)*H->nunits)) != hipSuccess ||
       (e = fga_dmalloc(&d_wide,sizeof(int)*H->nunits)) != hipSuccess ||
       (e = fga_dmalloc(&d_next,sizeof(int))) != hipSuccess ||
-      (e = fga_dmalloc(&d_tab,sizeof(int16_t)*2*32768)) != hipSuccess ||
+      (e = fga_dmalloc(&d_tab,sizeof(int)*32768)) != hipSuccess ||
       (e = fga_dmalloc(&d_cnt,sizeof(unsigned long long)*32)) != hipSuccess)
     { fga_set_error("fga_extend: device allocation failed: %s",hipGetErrorString(e));
       goto fail;
@@ -430,10 +430,12 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
         goto fail;
       }
   }
-  hipMemcpy(d_tab,prm->table,sizeof(int16_t)*32768,hipMemcpyHostToDevice);
-  hipMemcpy(d_tab+32768,prm->score,sizeof(int16_t)*32768,hipMemcpyHostToDevice);
+  { std::vector<int> t32(32768);
+    for (int i = 0; i < 32768; i++) t32[i] = prm->table[i];
+    hipMemcpy(d_tab,t32.data(),sizeof(int)*32768,hipMemcpyHostToDevice);
+  }
   A.units = d_units; A.hits = d_hits; A.order = d_order; A.next = d_next; A.wide_q = d_wide;
-  A.table = d_tab; A.score = d_tab+32768; A.counters = d_cnt;
+  A.trim32 = d_tab; A.counters = d_cnt;
 
   for (int attempt = 0; ; attempt++)
     { A.pool_cells = pool_cells; A.aln_cap = aln_cap; A.tbytes_cap = tb_cap;
