@@ -131,8 +131,8 @@ struct la_one_args
 #ifndef EXT_MID_RC
 #define EXT_MID_RC  256
 #define EXT_MID_WDW 192
-#define EXT_MID_OCC 4                  // wavefronts per SIMD the register budget is held to (128 VGPRs: ~40 spilled)
-#define EXT_MID_WGS 16                 // resident wavefronts per CU (8.2 KB of LDS each)
+#define EXT_MID_OCC 5                  // wavefronts per SIMD the register budget is held to (96 VGPRs)
+#define EXT_MID_WGS 20                 // resident wavefronts per CU (7.7 KB of LDS each)
 #endif
 #ifndef EXT_MID_INPLACE
 #define EXT_MID_INPLACE 1              // one copy of the ring, updated in place (fga_extend_kernel.inc)
