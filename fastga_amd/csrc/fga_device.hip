@@ -417,6 +417,22 @@ extern "C" int fga_dev_device_count(void)
   return n;
 }
 
+// the calling thread's current HIP device (-1: none can be told), and back: what an entry point that visits several devices
+// leaves as it found it
+extern "C" int fga_dev_current_device(void)
+{ int d = -1;
+  if (hipGetDevice(&d) != hipSuccess)
+    { (void) hipGetLastError();
+      return -1;
+    }
+  return d;
+}
+
+extern "C" void fga_dev_restore_device(int device)
+{ if (device >= 0 && hipSetDevice(device) != hipSuccess)
+    (void) hipGetLastError();
+}
+
 extern "C" int fga_dev_sync(fga_dev *d)
 { FGA_HIP(fga_dev_enter(d));
   FGA_HIP(hipStreamSynchronize(d->stream));

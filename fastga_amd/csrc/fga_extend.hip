@@ -96,6 +96,7 @@ struct ext_args
     fga_aln  *alns; int64_t aln_cap;
     uint8_t  *tbytes; int64_t tbytes_cap;
     unsigned long long *counters;            // [0] alignments, [1] trace bytes, [2] calls, [3] waves, [4] error flag
+    unsigned long long *ctg_waves;           // [A contigs, index order] wave steps of the contig's units (NULL: not counted)
   };
 
 struct la_one_args
@@ -397,7 +398,8 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
   fga_unit *d_units = NULL; fga_hit *d_hits = NULL; int *d_order = NULL, *d_next = NULL, *d_wide = NULL;
   std::vector<int> wide;
   int *d_tab = NULL;
-  unsigned long long *d_cnt = NULL;
+  unsigned long long *d_cnt = NULL, *d_cw = NULL;
+  const int ncw = GA->nperm > 0 ? GA->nperm : 1;
   arena_lists *d_lists = NULL;
   hipError_t e;
   if ((e = fga_dmalloc(&d_lists,sizeof(arena_lists))) != hipSuccess ||
@@ -407,6 +409,7 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
       (e = fga_dmalloc(&d_wide,sizeof(int)*H->nunits)) != hipSuccess ||
       (e = fga_dmalloc(&d_next,sizeof(int))) != hipSuccess ||
       (e = fga_dmalloc(&d_tab,sizeof(int)*32768)) != hipSuccess ||
+      (e = fga_dmalloc(&d_cw,sizeof(unsigned long long)*(size_t) ncw)) != hipSuccess ||
       (e = fga_dmalloc(&d_cnt,sizeof(unsigned long long)*32)) != hipSuccess)
     { fga_set_error("fga_extend: device allocation failed: %s",hipGetErrorString(e));
       goto fail;
@@ -435,7 +438,7 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
     hipMemcpy(d_tab,t32.data(),sizeof(int)*32768,hipMemcpyHostToDevice);
   }
   A.units = d_units; A.hits = d_hits; A.order = d_order; A.next = d_next; A.wide_q = d_wide;
-  A.trim32 = d_tab; A.counters = d_cnt;
+  A.trim32 = d_tab; A.counters = d_cnt; A.ctg_waves = d_cw;
 
   for (int attempt = 0; ; attempt++)
     { A.pool_cells = pool_cells; A.aln_cap = aln_cap; A.tbytes_cap = tb_cap;
@@ -453,6 +456,7 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
       fga_dev_note_memory(dev);                  // pool + output buffers + resident inputs: a footprint peak
       hipMemsetAsync(d_next,0,sizeof(int),dev->stream);
       hipMemsetAsync(d_cnt,0,sizeof(unsigned long long)*32,dev->stream);
+      hipMemsetAsync(d_cw,0,sizeof(unsigned long long)*(size_t) ncw,dev->stream);
 
       hipEventRecord(dev->ev0,dev->stream);
       unsigned long long hc[32];
@@ -566,7 +570,9 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
     }
   R->alns = (fga_aln *) malloc(sizeof(fga_aln)*(R->naln+1));
   R->tbytes = (uint8_t *) malloc(R->ntrace+16);
-  if (R->alns == NULL || R->tbytes == NULL)
+  R->ctg_waves = (int64_t *) malloc(sizeof(int64_t)*(size_t) ncw);
+  R->nctg_waves = GA->nperm;
+  if (R->alns == NULL || R->tbytes == NULL || R->ctg_waves == NULL)
     { fga_set_error("out of memory");
       goto fail;
     }
@@ -593,6 +599,7 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
     }
   if (R->ntrace > 0)
     hipMemcpy(R->tbytes,A.tbytes,R->ntrace,hipMemcpyDeviceToHost);
+  hipMemcpy(R->ctg_waves,d_cw,sizeof(int64_t)*(size_t) ncw,hipMemcpyDeviceToHost);      // (a handed-over unit counts in both launches)
   if (!wide.empty())
     { // alignments the narrow launch emitted for units it later handed over: the full kernel redid those units
       const int64_t nn = R->ncalls;           // = alignments of the narrow launch (they come first)
@@ -605,14 +612,14 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
       R->naln = o;
     }
   R->ncalls = ncalls_total;
-  fga_pool_free(d_units); fga_pool_free(d_hits); fga_pool_free(d_order); fga_pool_free(d_wide); fga_pool_free(d_next); fga_pool_free(d_tab); fga_pool_free(d_cnt); fga_pool_free(d_lists);
+  fga_pool_free(d_units); fga_pool_free(d_hits); fga_pool_free(d_order); fga_pool_free(d_wide); fga_pool_free(d_next); fga_pool_free(d_tab); fga_pool_free(d_cnt); fga_pool_free(d_cw); fga_pool_free(d_lists);
   fga_dev_release(dev,SLOT_CELLS,A.pool);
   fga_dev_release(dev,SLOT_ALNS,A.alns); fga_dev_release(dev,SLOT_TBYTES,A.tbytes);
   *out = R;
   return 0;
 
 fail:
-  fga_pool_free(d_units); fga_pool_free(d_hits); fga_pool_free(d_order); fga_pool_free(d_wide); fga_pool_free(d_next); fga_pool_free(d_tab); fga_pool_free(d_cnt); fga_pool_free(d_lists);
+  fga_pool_free(d_units); fga_pool_free(d_hits); fga_pool_free(d_order); fga_pool_free(d_wide); fga_pool_free(d_next); fga_pool_free(d_tab); fga_pool_free(d_cnt); fga_pool_free(d_cw); fga_pool_free(d_lists);
   fga_dev_release(dev,SLOT_CELLS,A.pool);
   fga_dev_release(dev,SLOT_ALNS,A.alns); fga_dev_release(dev,SLOT_TBYTES,A.tbytes);
   free(R->alns); free(R->tbytes); free(R);

@@ -111,6 +111,8 @@ void   fga_dev_trim(struct fga_dev *dev);          /* unused regions of the devi
 void  *fga_dev_stage_acquire(struct fga_dev *dev, size_t bytes);   /* the per-part staging buffer of a multi-pass run (a workspace slot) */
 void   fga_dev_stage_release(struct fga_dev *dev, void *ptr);
 size_t fga_dev_available(struct fga_dev *dev);     /* free device memory + the pool's free pieces    */
+int    fga_dev_current_device(void);               /* the calling thread's current HIP device (-1: cannot be told) */
+void   fga_dev_restore_device(int device);         /* ... and back to it (an entry point that visits several devices) */
 
 void   fga_aln_writer_threads(int n);              /* threads of the .1aln record formatters, for the calling thread (default 8) */
 void   fga_note(const char *what, double since);   /* FGA_TIMING=1: elapsed wall time since `since` on stderr */

@@ -1,25 +1,33 @@
-/* fga_multi.c -- one comparison over the GPUs of one node, from ONE process: fga_run_multi.
+/* fga_multi.c -- one comparison over the GPUs of one node, from ONE process: fga_multi_open / fga_multi_run / fga_multi_close
+ * (and fga_run_multi = the three in a row).
  *
- * The reference runs its whole parts machinery inside one process: the merge threads take k-mer prefix ranges
- * (FastGA.c:2291-2321) and append every seed to the file of (own slot, Select[A contig]) (FastGA.c:5057-5134), the search
- * phase re-reads the files of one A-contig part at a time (the transpose + NPARTS loop, FastGA.c:5160-5204), and la_merge
- * puts the threads' record files together (FastGA.c:3991-4133).  Here the same cut is laid over `ndev` devices, one host
- * thread (and one HIP stream) per device, all data-path work through the stage calls of fga_pipeline.c:
+ * The reference keeps its parts machinery alive inside one process for the whole run: the merge threads take k-mer prefix
+ * ranges (FastGA.c:2291-2321) and append every seed to the file of (own slot, Select[A contig]) (FastGA.c:5057-5134), the
+ * search phase re-reads the files of one A-contig part at a time (the transpose + NPARTS loop, FastGA.c:5160-5204), and
+ * la_merge puts the threads' record files together (FastGA.c:3991-4133).  Here the same cut is laid over `ndev` devices, one
+ * host thread (and one HIP stream) per device that lives as long as the session, all data-path work through the stage
+ * calls of fga_pipeline.c:
  *
  *   open      the GDBs (and index files, when there are any) are read ONCE and lent to every rank's session; rank r keeps
- *             only its 12-mer prefix range of both tables on device r (fga_session_open_impl, sliced), both genomes' bases whole
- *   phase 1   rank r merges its prefix range                                         fga_session_merge
- *   exchange  seeds per A contig counted (the reference's buck[]), summed over the ranks in host memory; every rank derives
- *             the same Select[] from the sums (fga_partition_contigs), regroups its seeds by part on its device
- *             (fga_seeds_split_to) and rank p pulls its part's piece from every rank's buffer: hipMemcpyPeerAsync over xGMI
- *             (fga_seeds_import_peer) -- no host staging, no collective library
- *   phase 2   rank p sorts / chain-scans / extends its part and runs the redundancy filter on its records (all records of a
- *             contig pair come from the part that owns the A contig)         fga_session_align, fga_filter_alignments_mt
- *   finish    the surviving records are host memory of this process already: rank 0 lays the ranks' runs out by A contig,
- *             puts ties into the reference's order from the summed per-strand seed counts and writes the .1aln / PAF once
- *                                                                                      fga_session_finish_filtered
- * The result does not depend on ndev (tests/test_multi_gpu.py: devices {0,0} and {0,0,0,0} -- virtual ranks on one GPU --
- * against the reference line for line).  fastga_amd/bin/FastGA reaches it with -G<n> or FGA_DEVICES.
+ *             only its 12-mer prefix range of both tables on device r (fga_session_open_impl, sliced), both genomes' bases
+ *             whole; peer access between the devices is enabled; the rank threads then wait for work
+ *   run       phase 1   rank r merges its prefix range                                         fga_session_merge
+ *             exchange  seeds per A contig counted (the reference's buck[]), summed over the ranks in host memory; every rank
+ *                       derives the same Select[] (fga_partition_contigs: weighted by the wave steps the contig's units took in
+ *                       the session's previous run -- what phase 2's time is made of -- or by the seed counts in the first),
+ *                       regroups its seeds by part on its device (fga_seeds_split_to) and rank p pulls its part's piece from
+ *                       every rank's buffer: hipMemcpyPeerAsync over xGMI (fga_seeds_import_peer) -- no host staging, no
+ *                       collective library
+ *             phase 2   rank p sorts / chain-scans / extends its part and runs the redundancy filter on its records (all
+ *                       records of a contig pair come from the part that owns the A contig)
+ *                                                                           fga_session_align, fga_filter_alignments_mt
+ *             finish    the surviving records are host memory of this process already: the calling thread lays the ranks'
+ *                       runs out by A contig, puts ties into the reference's order from the summed per-strand seed counts and
+ *                       writes the .1aln / PAF once                                          fga_session_finish_filtered
+ *   close     the rank threads close their sessions and end
+ * The result does not depend on ndev or on the weights (tests/test_multi_gpu.py: devices {0,0} and {0,0,0,0} -- virtual ranks
+ * on one GPU --, (0,1) / (0,1,2,3) where the node has them, three runs of one session, against the reference line for
+ * line).  fastga_amd/bin/FastGA reaches it with -G<n> or FGA_DEVICES; bench.py --gpus N times fga_multi_run.
  */
 #define _GNU_SOURCE
 #include <stdio.h>
@@ -31,43 +39,51 @@
 #include "fastga_amd.h"
 #include "fga_session.h"
 
-typedef struct multi_run multi_run;
+enum { CMD_IDLE = 0, CMD_RUN = 1, CMD_QUIT = 2 };
 
 typedef struct
-  { multi_run   *M;
+  { fga_multi   *M;
     int          rank;
     pthread_t    th;
     int          started;
     fga_session *Z;
     fga_run_stats st;
-    fga_alns    *fil;          /* this rank's records after the redundancy filter */
+    fga_alns    *fil;          /* this rank's records after the redundancy filter (of the last run) */
     void        *sendbuf;      /* its seeds regrouped by part (device memory of its own device) */
     int64_t     *off;          /* [ndev+1] part p = records [off[p], off[p+1]) of sendbuf */
     int64_t     *hist;         /* [nctg] seeds per A contig of its prefix range */
     int64_t     *scount;       /* [2*nctg] the same per strand (reference tie order) */
+    int64_t     *waves;        /* [nctg] wave steps per A contig of its part in the last run */
     double       open_s, phase1_s, exchange_s, phase2_s;
   } multi_rank;
 
-struct multi_run
-  { const char *root1, *root2;
-    const fga_run_params *P;
-    fga_run_params Pr;         /* the ranks' copy: their share of the host threads, no output */
+struct fga_multi
+  { char        *root1, *root2;
     int          ndev;
-    const int   *devices;
-    fga_shared_inputs shared;
-    fga_mask_args masks;
+    int         *devices;
+    int          open_threads, open_flags;
+    fga_mask_args masks;       /* (valid during fga_multi_open only: the caller's arrays) */
     int          have_masks;
+    fga_shared_inputs shared;
     int          nctg;
     multi_rank  *R;
+    fga_session *single;       /* ndev == 1: a plain session, nothing to cut */
     pthread_barrier_t bar;
     pthread_mutex_t   mu;
-    pthread_cond_t    cv;
-    int          go;           /* 0: the ranks' threads are being started, 1: all there, run, -1: one could not be started */
+    pthread_cond_t    cv_cmd, cv_done;
+    int          sync_made;
+    int          go;           /* 0: the ranks' threads are being started, 1: all there, -1: one could not be started */
+    int          cmd;
+    unsigned long gen, done_gen;       /* command number the ranks have been given / have finished */
     int          failed;
     char         err[1024];
+    fga_run_params Pr;         /* the ranks' parameters of the current run: their share of the host threads, no output */
+    int64_t     *cost;         /* [nctg] wave steps per A contig of the previous run of this session */
+    int          have_cost;
+    double       load_s;
   };
 
-static void multi_fail(multi_run *M, const char *where)
+static void multi_fail(fga_multi *M, const char *where)
 { pthread_mutex_lock(&M->mu);
   if (!M->failed)
     { M->failed = 1;
@@ -76,7 +92,7 @@ static void multi_fail(multi_run *M, const char *where)
   pthread_mutex_unlock(&M->mu);
 }
 
-static int multi_failed(multi_run *M)
+static int multi_failed(fga_multi *M)
 { int f;
   pthread_mutex_lock(&M->mu);
   f = M->failed;
@@ -87,30 +103,14 @@ static int multi_failed(multi_run *M)
 /* every rank passes every barrier, whatever happened: a rank that failed says so and the others skip their work */
 #define STEP_BARRIER(M)  pthread_barrier_wait(&(M)->bar)
 
-static void *multi_rank_main(void *arg)
-{ multi_rank *me = arg;
-  multi_run *M = me->M;
+/* ---- open: this rank's slice of the tables + both genomes on its device, direct access to the other ranks' devices ---- */
+static void rank_open(multi_rank *me)
+{ fga_multi *M = me->M;
   const int r = me->rank, n = M->ndev;
-  const fga_run_params *P = &M->Pr;
-  fga_dseeds *seeds = NULL, *part = NULL;
-  fga_alns *raw = NULL;
-  int *select = NULL;
-  double t0;
+  const double t0 = fga_wall();
   int q;
-
-  /* all ranks or none: a run short of a rank would wait at its first barrier for ever */
-  pthread_mutex_lock(&M->mu);
-  while (M->go == 0)
-    pthread_cond_wait(&M->cv,&M->mu);
-  q = M->go;
-  pthread_mutex_unlock(&M->mu);
-  if (q < 0)
-    return NULL;
-
-  /* ---- open: this rank's slice of the tables + both genomes on its device ---- */
-  t0 = fga_wall();
-  if (fga_session_open_impl(M->root1,M->root2,M->devices[r],M->P->nthreads > 0 ? M->P->nthreads : 8,r,n,
-                            M->P->build_index ? FGA_SESSION_BUILD_INDEX : 0,M->have_masks ? &M->masks : NULL,&M->shared,&me->Z))
+  if (fga_session_open_impl(M->root1,M->root2,M->devices[r],M->open_threads,r,n,M->open_flags,
+                            M->have_masks ? &M->masks : NULL,&M->shared,&me->Z))
     multi_fail(M,"open");
   else
     for (q = 0; q < n; q++)
@@ -121,41 +121,60 @@ static void *multi_rank_main(void *arg)
   if (!multi_failed(M) && r == 0)
     M->nctg = fga_session_nctg(me->Z);
   STEP_BARRIER(M);
-
-  /* ---- phase 1 on the rank's prefix range; its seeds counted per A contig ---- */
-  t0 = fga_wall();
   if (!multi_failed(M))
-    { const int nctg = M->nctg;
-      me->hist = calloc(nctg > 0 ? nctg : 1,sizeof(int64_t));
-      me->scount = calloc(2*(size_t) (nctg > 0 ? nctg : 1),sizeof(int64_t));
-      me->off = calloc(n+1,sizeof(int64_t));
-      if (me->hist == NULL || me->scount == NULL || me->off == NULL)
-        { fga_set_error("out of memory"); multi_fail(M,"phase 1"); }
-      else
-        { fga_session_clear_strand_counts(me->Z);
-          if (fga_session_merge(me->Z,P,0,0,&seeds,&me->st) ||
-              fga_seeds_contig_histogram(fga_session_device(me->Z),seeds,nctg,me->hist) ||
-              (P->reference_threads > 0 && fga_session_strand_counts(me->Z,me->scount)))
-            multi_fail(M,"phase 1");
-        }
+    { const size_t nc = M->nctg > 0 ? M->nctg : 1;
+      me->hist = calloc(nc,sizeof(int64_t)); me->scount = calloc(2*nc,sizeof(int64_t));
+      me->waves = calloc(nc,sizeof(int64_t)); me->off = calloc(n+1,sizeof(int64_t));
+      if (me->hist == NULL || me->scount == NULL || me->waves == NULL || me->off == NULL)
+        { fga_set_error("out of memory"); multi_fail(M,"open"); }
     }
+  STEP_BARRIER(M);
+}
+
+/* ---- one comparison: phase 1 / exchange / phase 2 + filter of this rank ---- */
+static void rank_run(multi_rank *me)
+{ fga_multi *M = me->M;
+  const int r = me->rank, n = M->ndev, nctg = M->nctg;
+  const fga_run_params *P = &M->Pr;
+  fga_dseeds *seeds = NULL, *part = NULL;
+  fga_alns *raw = NULL;
+  int *select = NULL;
+  double t0;
+  int q;
+
+  memset(&me->st,0,sizeof(me->st));
+  fga_alns_free(me->fil); me->fil = NULL;
+  memset(me->hist,0,sizeof(int64_t)*(nctg > 0 ? nctg : 1));
+  memset(me->scount,0,sizeof(int64_t)*2*(nctg > 0 ? nctg : 1));
+  memset(me->waves,0,sizeof(int64_t)*(nctg > 0 ? nctg : 1));
+
+  /* phase 1 on the rank's prefix range; its seeds counted per A contig */
+  t0 = fga_wall();
+  fga_session_clear_strand_counts(me->Z);
+  if (fga_session_merge(me->Z,P,0,0,&seeds,&me->st) ||
+      fga_seeds_contig_histogram(fga_session_device(me->Z),seeds,nctg,me->hist) ||
+      (P->reference_threads > 0 && fga_session_strand_counts(me->Z,me->scount)))
+    multi_fail(M,"phase 1");
   me->phase1_s = fga_wall() - t0;
   STEP_BARRIER(M);
 
-  /* ---- exchange: the same Select[] on every rank from the summed counts; seeds regrouped by part ---- */
+  /* exchange: the same Select[] on every rank; seeds regrouped by part */
   t0 = fga_wall();
   if (!multi_failed(M))
-    { const int nctg = M->nctg;
-      int64_t *tot = calloc(nctg > 0 ? nctg : 1,sizeof(int64_t));
+    { int64_t *tot = calloc(nctg > 0 ? nctg : 1,sizeof(int64_t));
       int c;
       select = malloc(sizeof(int)*(nctg > 0 ? nctg : 1));
       if (tot == NULL || select == NULL)
         { fga_set_error("out of memory"); multi_fail(M,"exchange"); }
       else
         { const int64_t cnt = fga_seeds_count(seeds);
-          for (q = 0; q < n; q++)
+          if (M->have_cost)                 /* what phase 2's time is made of: the wave steps of the contig's units last time */
             for (c = 0; c < nctg; c++)
-              tot[c] += M->R[q].hist[c];
+              tot[c] = M->cost[c];
+          else                              /* the first run of a session: the seeds, as the reference's IDBsplit weighs bases */
+            for (q = 0; q < n; q++)
+              for (c = 0; c < nctg; c++)
+                tot[c] += M->R[q].hist[c];
           if (fga_partition_contigs(tot,nctg,n,select) ||
               fga_dev_malloc(fga_session_device(me->Z),16*(size_t) (cnt > 0 ? cnt : 1),&me->sendbuf) ||
               fga_seeds_split_to(fga_session_device(me->Z),seeds,select,nctg,n,me->sendbuf,me->off))
@@ -184,17 +203,19 @@ static void *multi_rank_main(void *arg)
       free(src); free(cnt); free(ids);
     }
   STEP_BARRIER(M);                          /* every part has been pulled: the send buffers can go */
-  if (me->sendbuf != NULL && me->Z != NULL)
+  if (me->sendbuf != NULL)
     { fga_dev_free(fga_session_device(me->Z),me->sendbuf); me->sendbuf = NULL; }
   me->exchange_s = fga_wall() - t0;
 
-  /* ---- phase 2 on the rank's part + the redundancy filter on its records ---- */
+  /* phase 2 on the rank's part + the redundancy filter on its records */
   t0 = fga_wall();
   if (!multi_failed(M))
     { if (fga_session_align(me->Z,P,part,&raw,&me->st))
         multi_fail(M,"phase 2");
       else
         { const double tf = fga_wall();
+          if (raw->ctg_waves != NULL && raw->nctg_waves == nctg)
+            memcpy(me->waves,raw->ctg_waves,sizeof(int64_t)*nctg);
           if (fga_filter_alignments_mt(raw,P->nthreads,&me->fil))
             multi_fail(M,"filter");
           me->st.filter_s += fga_wall() - tf;
@@ -204,11 +225,62 @@ static void *multi_rank_main(void *arg)
   fga_seeds_free(part);
   fga_alns_free(raw);
   free(select);
-  if (me->Z != NULL)
-    me->st.hbm_peak_bytes = fga_dev_peak_bytes(fga_session_device(me->Z));
+  me->st.hbm_peak_bytes = fga_dev_peak_bytes(fga_session_device(me->Z));
   me->phase2_s = fga_wall() - t0;
   STEP_BARRIER(M);
+}
+
+static void *multi_rank_main(void *arg)
+{ multi_rank *me = arg;
+  fga_multi *M = me->M;
+  unsigned long seen = 0;
+  int go;
+
+  /* all ranks or none: a session short of a rank would wait at its first barrier for ever */
+  pthread_mutex_lock(&M->mu);
+  while (M->go == 0)
+    pthread_cond_wait(&M->cv_cmd,&M->mu);
+  go = M->go;
+  pthread_mutex_unlock(&M->mu);
+  if (go < 0)
+    return NULL;
+  rank_open(me);
+  for (;;)
+    { int cmd;
+      if (me->rank == 0)                    /* (all ranks are past the command's last barrier) */
+        { pthread_mutex_lock(&M->mu);
+          M->done_gen = seen;
+          pthread_cond_broadcast(&M->cv_done);
+          pthread_mutex_unlock(&M->mu);
+        }
+      pthread_mutex_lock(&M->mu);
+      while (M->gen == seen)
+        pthread_cond_wait(&M->cv_cmd,&M->mu);
+      seen = M->gen;
+      cmd = M->cmd;
+      pthread_mutex_unlock(&M->mu);
+      if (cmd == CMD_QUIT)
+        break;
+      if (multi_failed(M))                  /* (a session that did not open runs nothing; the barriers of a run are skipped by all) */
+        continue;
+      rank_run(me);
+    }
+  /* the thread that opened the session (and whose stream its buffers remember) closes it */
+  if (me->sendbuf != NULL && me->Z != NULL) fga_dev_free(fga_session_device(me->Z),me->sendbuf);
+  fga_session_close(me->Z); me->Z = NULL;
   return NULL;
+}
+
+/* hand the ranks a command and wait until rank 0 reports all of them past its last barrier */
+static void multi_command(fga_multi *M, int cmd, int wait)
+{ unsigned long g;
+  pthread_mutex_lock(&M->mu);
+  M->cmd = cmd;
+  g = ++M->gen;
+  pthread_cond_broadcast(&M->cv_cmd);
+  while (wait && M->done_gen != g)
+    pthread_cond_wait(&M->cv_done,&M->mu);
+  pthread_mutex_unlock(&M->mu);
 }
 
 static void sum_stats(fga_run_stats *S, const multi_rank *R, int n)
@@ -232,13 +304,267 @@ static void sum_stats(fga_run_stats *S, const multi_rank *R, int n)
     }
 }
 
+void fga_multi_close(fga_multi *M)
+{ const int dev0 = fga_dev_current_device();
+  int r;
+  if (M == NULL) return;
+  if (M->R != NULL)
+    { int any = 0;
+      for (r = 0; r < M->ndev; r++) any |= M->R[r].started;
+      if (any)
+        multi_command(M,CMD_QUIT,0);
+      for (r = 0; r < M->ndev; r++)
+        if (M->R[r].started)
+          pthread_join(M->R[r].th,NULL);
+      for (r = 0; r < M->ndev; r++)
+        { fga_alns_free(M->R[r].fil);
+          free(M->R[r].off); free(M->R[r].hist); free(M->R[r].scount); free(M->R[r].waves);
+        }
+    }
+  if (M->sync_made)
+    { pthread_barrier_destroy(&M->bar);
+      pthread_cond_destroy(&M->cv_cmd); pthread_cond_destroy(&M->cv_done);
+      pthread_mutex_destroy(&M->mu);
+    }
+  fga_session_close(M->single);
+  free(M->R);
+  fga_gix_close(M->shared.x2); fga_gix_close(M->shared.x1);
+  fga_gdb_close(M->shared.g2); fga_gdb_close(M->shared.g1);
+  free(M->cost); free(M->devices); free(M->root1); free(M->root2);
+  free(M);
+  fga_dev_restore_device(dev0);
+}
+
+int fga_multi_open(const char *root1, const char *root2, const fga_run_params *P, int ndev, const int *devices, fga_multi **out)
+{ const int dev0 = fga_dev_current_device();
+  fga_multi *M;
+  int r, have1, have2, self = (root2 == NULL), nhave;
+  double tl;
+
+  if (out != NULL) *out = NULL;
+  if (root1 == NULL || P == NULL || devices == NULL || out == NULL || ndev < 1 || ndev > 64)
+    { fga_set_error("fga_multi_open: bad argument (1 <= ndev <= 64 devices, a device list)");
+      return 1;
+    }
+  M = calloc(1,sizeof(fga_multi));
+  if (M == NULL)
+    { fga_set_error("out of memory");
+      return 1;
+    }
+  M->ndev = ndev;
+  M->root1 = strdup(root1); M->root2 = self ? NULL : strdup(root2);
+  M->devices = malloc(sizeof(int)*ndev);
+  if (M->root1 == NULL || (!self && M->root2 == NULL) || M->devices == NULL)
+    { fga_set_error("out of memory");
+      goto fail;
+    }
+  memcpy(M->devices,devices,sizeof(int)*ndev);
+  M->open_threads = P->nthreads > 0 ? P->nthreads : 8;
+  M->open_flags = P->build_index ? FGA_SESSION_BUILD_INDEX : 0;
+  M->masks.m1 = P->masks1; M->masks.n1 = P->nmasks1; M->masks.m2 = P->masks2; M->masks.n2 = P->nmasks2;
+  M->have_masks = P->nmasks1 > 0 || P->nmasks2 > 0;
+
+  if (ndev == 1)                          /* nothing to cut: a plain session on the one device */
+    { if (fga_session_open_masked(root1,root2,devices[0],M->open_threads,M->open_flags,P->masks1,P->nmasks1,P->masks2,P->nmasks2,
+                                  &M->single))
+        goto fail;
+      *out = M;
+      fga_dev_restore_device(dev0);
+      return 0;
+    }
+
+  /* the host-side inputs once for all ranks: the genomes (with their masks) and, when both exist, the index files */
+  tl = fga_wall();
+  have1 = !P->build_index && P->nmasks1 == 0 && fga_gix_files_exist(root1);
+  have2 = self ? have1 : (!P->build_index && P->nmasks2 == 0 && fga_gix_files_exist(root2));
+  if (fga_gdb_open(root1,&M->shared.g1) || (P->nmasks1 > 0 && fga_gdb_apply_masks(M->shared.g1,P->masks1,P->nmasks1)))
+    goto fail;
+  if (!self && (fga_gdb_open(root2,&M->shared.g2) || (P->nmasks2 > 0 && fga_gdb_apply_masks(M->shared.g2,P->masks2,P->nmasks2))))
+    goto fail;
+  if (have1 && have2)
+    { if (fga_gix_open(root1,&M->shared.x1) || (!self && fga_gix_open(root2,&M->shared.x2)))
+        goto fail;
+    }
+  else if (have1 != have2)                /* one genome has index files, the other (masked, or without files) has not: a
+                                             sliced session cuts its ranges from file counts OR device counts -- both built */
+    M->open_flags |= FGA_SESSION_BUILD_INDEX;
+  M->load_s = fga_wall() - tl;
+  nhave = fga_dev_device_count();         /* (after the inputs, like fga_run: a missing genome or mask is reported first) */
+  if (nhave <= 0)
+    { fga_set_error("no HIP device available: libfastga_amd has no CPU fallback");
+      goto fail;
+    }
+  for (r = 0; r < ndev; r++)
+    if (devices[r] < 0 || devices[r] >= nhave)
+      { fga_set_error("fga_multi_open: device %d out of range (have %d)",devices[r],nhave);
+        goto fail;
+      }
+  M->R = calloc(ndev,sizeof(multi_rank));
+  if (M->R == NULL)
+    { fga_set_error("out of memory");
+      goto fail;
+    }
+  pthread_mutex_init(&M->mu,NULL);
+  pthread_cond_init(&M->cv_cmd,NULL); pthread_cond_init(&M->cv_done,NULL);
+  pthread_barrier_init(&M->bar,NULL,ndev);
+  M->sync_made = 1;
+  M->done_gen = 1;                        /* (the open counts as command 0: done_gen is set to 0 when all ranks are through) */
+  for (r = 0; r < ndev; r++)
+    { M->R[r].M = M; M->R[r].rank = r; }
+  for (r = 0; r < ndev; r++)
+    { if (pthread_create(&M->R[r].th,NULL,multi_rank_main,&M->R[r]) != 0)
+        break;
+      M->R[r].started = 1;
+    }
+  pthread_mutex_lock(&M->mu);
+  M->go = (r == ndev) ? 1 : -1;
+  pthread_cond_broadcast(&M->cv_cmd);
+  pthread_mutex_unlock(&M->mu);
+  if (r < ndev)
+    { int q;
+      for (q = 0; q < r; q++) { pthread_join(M->R[q].th,NULL); M->R[q].started = 0; }
+      fga_set_error("fga_multi_open: cannot start a thread for rank %d",r);
+      goto fail;
+    }
+  pthread_mutex_lock(&M->mu);             /* wait for the open to be through on every rank */
+  while (M->done_gen != 0)
+    pthread_cond_wait(&M->cv_done,&M->mu);
+  pthread_mutex_unlock(&M->mu);
+  M->masks.m1 = M->masks.m2 = NULL; M->masks.n1 = M->masks.n2 = 0;       /* (the caller's arrays: not kept) */
+  if (M->failed)
+    { char e[1024];
+      snprintf(e,sizeof(e),"%s",M->err);
+      fga_multi_close(M);
+      fga_set_error("fga_multi_open (%d devices): %s",ndev,e);
+      fga_dev_restore_device(dev0);
+      return 1;
+    }
+  M->cost = calloc(M->nctg > 0 ? M->nctg : 1,sizeof(int64_t));
+  if (M->cost == NULL)
+    { fga_multi_close(M);
+      fga_set_error("out of memory");
+      fga_dev_restore_device(dev0);
+      return 1;
+    }
+  *out = M;
+  fga_dev_restore_device(dev0);
+  return 0;
+
+fail:
+  { char e[1024];
+    snprintf(e,sizeof(e),"%s",fga_last_error());
+    fga_multi_close(M);
+    fga_set_error("%s",e);
+  }
+  fga_dev_restore_device(dev0);
+  return 1;
+}
+
+int fga_multi_ndev(const fga_multi *M) { return M == NULL ? 0 : M->ndev; }
+
+int fga_multi_run(fga_multi *M, const fga_run_params *P, fga_run_stats *S)
+{ const int dev0 = fga_dev_current_device();
+  fga_run_stats st;
+  int r, c, rc = 1, ndev;
+  const double t0 = fga_wall();
+
+  memset(&st,0,sizeof(st));
+  if (S != NULL) *S = st;
+  if (M == NULL || P == NULL)
+    { fga_set_error("fga_multi_run: null argument");
+      return 1;
+    }
+  ndev = M->ndev;
+  if (M->single != NULL)
+    { fga_run_params Q = *P;
+      if (M->have_masks) Q.soft_mask = 1;   /* masks named: the comparison runs with soft masking on (FastGA.c:4580) */
+      rc = fga_session_run(M->single,&Q,S);
+      fga_dev_restore_device(dev0);
+      return rc;
+    }
+
+  M->Pr = *P;
+  M->Pr.out_path = NULL; M->Pr.paf_path = NULL;
+  /* a rank's host threads do its chain tails, its redundancy filter and its record formatting: at least four each */
+  M->Pr.nthreads = (P->nthreads > 0 ? P->nthreads : 8) / ndev;
+  if (M->Pr.nthreads < 4) M->Pr.nthreads = 4;
+  if (M->have_masks) M->Pr.soft_mask = 1;
+  multi_command(M,CMD_RUN,1);
+  if (M->failed)
+    { fga_set_error("fga_multi_run (%d devices): %s",ndev,M->err);
+      goto done;
+    }
+
+  /* the cost of every A contig's units in this run: the weights of the next run's partition */
+  for (c = 0; c < M->nctg; c++)
+    { int64_t w = 0;
+      for (r = 0; r < ndev; r++) w += M->R[r].waves[c];
+      M->cost[c] = w;
+    }
+  M->have_cost = 1;
+
+  /* ---- finish on rank 0's session: the ranks' filtered runs by A contig, the reference's tie order, one .1aln ---- */
+  { const fga_alns **sets = calloc(ndev,sizeof(fga_alns *));
+    fga_run_params Pf = *P;
+    int bad = (sets == NULL);
+    if (bad) fga_set_error("out of memory");
+    if (M->have_masks) Pf.soft_mask = 1;
+    if (!bad && P->reference_threads > 0)
+      { const int nc = M->nctg;
+        int64_t *sc = calloc(2*(size_t) (nc > 0 ? nc : 1),sizeof(int64_t));
+        if (sc == NULL) { fga_set_error("out of memory"); bad = 1; }
+        else
+          { for (r = 0; r < ndev; r++)
+              for (c = 0; c < 2*nc; c++)
+                sc[c] += M->R[r].scount[c];
+            bad = fga_session_set_strand_counts(M->R[0].Z,sc);
+          }
+        free(sc);
+      }
+    for (r = 0; r < ndev && !bad; r++)
+      sets[r] = M->R[r].fil;
+    st.load_s = M->load_s;
+    sum_stats(&st,M->R,ndev);
+    if (!bad && fga_session_finish_filtered(M->R[0].Z,&Pf,sets,ndev,&st)) bad = 1;
+    free(sets);
+    if (bad) goto done;
+  }
+  st.nparts = ndev;
+  st.bases1 = M->shared.g1->seqtot; st.bases2 = M->shared.g2 == NULL ? M->shared.g1->seqtot : M->shared.g2->seqtot;
+  st.phase23_s = fga_wall() - t0 - st.trace_s - st.paf_s;
+  if (getenv("FGA_TIMING") != NULL && atoi(getenv("FGA_TIMING")) != 0)
+    for (r = 0; r < ndev; r++)
+      fprintf(stderr,"[fga timing] rank %d on device %d: open %.3f  phase 1 %.3f  exchange %.3f  phase 2 %.3f s (%lld wave steps)\n",
+              r,M->devices[r],M->R[r].open_s,M->R[r].phase1_s,M->R[r].exchange_s,M->R[r].phase2_s,(long long) M->R[r].st.nwaves);
+  rc = 0;
+
+done:
+  for (r = 0; r < ndev; r++)              /* the records have been written: only the session stays */
+    { fga_alns_free(M->R[r].fil); M->R[r].fil = NULL; }
+  if (S != NULL) *S = st;
+  fga_dev_restore_device(dev0);
+  return rc;
+}
+
+/* per-rank figures of the last fga_multi_run (bench.py's per_rank block): seconds of phase 1 / exchange / phase 2 (incl. the
+   filter), the extension kernel's ms and wave steps, the seeds of the rank's part */
+int fga_multi_rank_stats(const fga_multi *M, int rank, double *seconds3, double *extend_kernel_ms, int64_t *wave_steps)
+{ if (M == NULL || M->R == NULL || rank < 0 || rank >= M->ndev)
+    { fga_set_error("fga_multi_rank_stats: no such rank");
+      return 1;
+    }
+  if (seconds3 != NULL)
+    { seconds3[0] = M->R[rank].phase1_s; seconds3[1] = M->R[rank].exchange_s; seconds3[2] = M->R[rank].phase2_s; }
+  if (extend_kernel_ms != NULL) *extend_kernel_ms = M->R[rank].st.extend_kernel_ms;
+  if (wave_steps != NULL) *wave_steps = M->R[rank].st.nwaves;
+  return 0;
+}
+
 int fga_run_multi(const char *root1, const char *root2, const fga_run_params *P, int ndev, const int *devices,
                   fga_run_stats *S)
-{ multi_run M;
+{ fga_multi *M = NULL;
   fga_run_stats st;
-  int r, rc = 1, have1, have2, self = (root2 == NULL), nhave;
-  double t0 = fga_wall(), tl;
-
+  int rc;
   memset(&st,0,sizeof(st));
   if (S != NULL) *S = st;
   if (root1 == NULL || P == NULL || devices == NULL || ndev < 1 || ndev > 64)
@@ -250,124 +576,16 @@ int fga_run_multi(const char *root1, const char *root2, const fga_run_params *P,
       Q.device = devices[0];
       return fga_run(root1,root2,&Q,S);
     }
-
-  memset(&M,0,sizeof(M));
-  M.root1 = root1; M.root2 = root2; M.P = P; M.ndev = ndev; M.devices = devices;
-  M.Pr = *P;
-  M.Pr.out_path = NULL; M.Pr.paf_path = NULL;
-  M.Pr.nthreads = (P->nthreads > 0 ? P->nthreads : 8) / ndev;
-  if (M.Pr.nthreads < 1) M.Pr.nthreads = 1;
-  M.masks.m1 = P->masks1; M.masks.n1 = P->nmasks1; M.masks.m2 = P->masks2; M.masks.n2 = P->nmasks2;
-  M.have_masks = P->nmasks1 > 0 || P->nmasks2 > 0;
-  if (M.have_masks)                       /* masks named: the comparison runs with soft masking on (FastGA.c:4580) */
-    M.Pr.soft_mask = 1;
-  M.R = calloc(ndev,sizeof(multi_rank));
-  if (M.R == NULL)
-    { fga_set_error("out of memory");
-      return 1;
+  if (fga_multi_open(root1,root2,P,ndev,devices,&M))
+    return 1;
+  rc = fga_multi_run(M,P,S);
+  if (rc != 0)
+    { char e[1024];
+      snprintf(e,sizeof(e),"%s",fga_last_error());
+      fga_multi_close(M);
+      fga_set_error("%s",e);
+      return rc;
     }
-
-  /* the host-side inputs once for all ranks: the genomes (with their masks) and, when both exist, the index files */
-  tl = fga_wall();
-  have1 = !P->build_index && P->nmasks1 == 0 && fga_gix_files_exist(root1);
-  have2 = self ? have1 : (!P->build_index && P->nmasks2 == 0 && fga_gix_files_exist(root2));
-  if (fga_gdb_open(root1,&M.shared.g1) || (P->nmasks1 > 0 && fga_gdb_apply_masks(M.shared.g1,P->masks1,P->nmasks1)))
-    goto done;
-  if (!self && (fga_gdb_open(root2,&M.shared.g2) || (P->nmasks2 > 0 && fga_gdb_apply_masks(M.shared.g2,P->masks2,P->nmasks2))))
-    goto done;
-  if (have1 && have2)
-    { if (fga_gix_open(root1,&M.shared.x1) || (!self && fga_gix_open(root2,&M.shared.x2)))
-        goto done;
-    }
-  st.load_s = fga_wall() - tl;
-  nhave = fga_dev_device_count();         /* (after the inputs, like fga_run: a missing genome or mask is reported first) */
-  if (nhave <= 0)
-    { fga_set_error("no HIP device available: libfastga_amd has no CPU fallback");
-      goto done;
-    }
-  for (r = 0; r < ndev; r++)
-    if (devices[r] < 0 || devices[r] >= nhave)
-      { fga_set_error("fga_run_multi: device %d out of range (have %d)",devices[r],nhave);
-        goto done;
-      }
-
-  pthread_mutex_init(&M.mu,NULL);
-  pthread_cond_init(&M.cv,NULL);
-  pthread_barrier_init(&M.bar,NULL,ndev);
-  for (r = 0; r < ndev; r++)
-    { M.R[r].M = &M; M.R[r].rank = r; }
-  for (r = 1; r < ndev; r++)
-    { if (pthread_create(&M.R[r].th,NULL,multi_rank_main,&M.R[r]) != 0)
-        break;
-      M.R[r].started = 1;
-    }
-  pthread_mutex_lock(&M.mu);
-  M.go = (r == ndev) ? 1 : -1;
-  pthread_cond_broadcast(&M.cv);
-  pthread_mutex_unlock(&M.mu);
-  if (r == ndev)
-    multi_rank_main(&M.R[0]);             /* rank 0 on the calling thread */
-  else
-    { M.failed = 1;
-      snprintf(M.err,sizeof(M.err),"cannot start a thread for rank %d",r);
-    }
-  for (r = 1; r < ndev; r++)
-    if (M.R[r].started)
-      pthread_join(M.R[r].th,NULL);
-  pthread_barrier_destroy(&M.bar);
-  pthread_cond_destroy(&M.cv);
-  pthread_mutex_destroy(&M.mu);
-  if (M.failed)
-    { fga_set_error("fga_run_multi (%d devices): %s",ndev,M.err);
-      goto done;
-    }
-
-  /* ---- finish on rank 0's session: the ranks' filtered runs by A contig, the reference's tie order, one .1aln ---- */
-  { const fga_alns **sets = calloc(ndev,sizeof(fga_alns *));
-    fga_run_params Pf = *P;
-    int bad = (sets == NULL);
-    if (bad) fga_set_error("out of memory");
-    if (M.have_masks) Pf.soft_mask = 1;
-    if (!bad && P->reference_threads > 0)
-      { const int nc = M.nctg;
-        int64_t *sc = calloc(2*(size_t) (nc > 0 ? nc : 1),sizeof(int64_t));
-        int c;
-        if (sc == NULL) { fga_set_error("out of memory"); bad = 1; }
-        else
-          { for (r = 0; r < ndev; r++)
-              for (c = 0; c < 2*nc; c++)
-                sc[c] += M.R[r].scount[c];
-            bad = fga_session_set_strand_counts(M.R[0].Z,sc);
-          }
-        free(sc);
-      }
-    for (r = 0; r < ndev && !bad; r++)
-      sets[r] = M.R[r].fil;
-    sum_stats(&st,M.R,ndev);
-    if (!bad && fga_session_finish_filtered(M.R[0].Z,&Pf,sets,ndev,&st)) bad = 1;
-    free(sets);
-    if (bad) goto done;
-  }
-  st.nparts = ndev;
-  st.bases1 = M.shared.g1->seqtot; st.bases2 = self ? M.shared.g1->seqtot : M.shared.g2->seqtot;
-  st.phase23_s = fga_wall() - t0 - st.trace_s - st.paf_s;
-  if (getenv("FGA_TIMING") != NULL && atoi(getenv("FGA_TIMING")) != 0)
-    for (r = 0; r < ndev; r++)
-      fprintf(stderr,"[fga timing] rank %d on device %d: open %.3f  phase 1 %.3f  exchange %.3f  phase 2 %.3f s\n",
-              r,devices[r],M.R[r].open_s,M.R[r].phase1_s,M.R[r].exchange_s,M.R[r].phase2_s);
-  rc = 0;
-
-done:
-  if (M.R != NULL)
-    for (r = 0; r < ndev; r++)
-      { if (M.R[r].sendbuf != NULL && M.R[r].Z != NULL) fga_dev_free(fga_session_device(M.R[r].Z),M.R[r].sendbuf);
-        fga_alns_free(M.R[r].fil);
-        fga_session_close(M.R[r].Z);
-        free(M.R[r].off); free(M.R[r].hist); free(M.R[r].scount);
-      }
-  free(M.R);
-  fga_gix_close(M.shared.x2); fga_gix_close(M.shared.x1);
-  fga_gdb_close(M.shared.g2); fga_gdb_close(M.shared.g1);
-  if (S != NULL) *S = st;
-  return rc;
+  fga_multi_close(M);
+  return 0;
 }

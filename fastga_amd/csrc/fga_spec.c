@@ -45,5 +45,5 @@ int fga_align_spec(double ave_corr, int tspace, const float *freq, int *path_ave
 
 void fga_alns_free(fga_alns *A)
 { if (A == NULL) return;
-  free(A->alns); free(A->tbytes); free(A);
+  free(A->alns); free(A->tbytes); free(A->ctg_waves); free(A);
 }

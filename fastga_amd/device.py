@@ -356,6 +356,61 @@ def run_multi(root1, root2=None, out_path=None, devices=(0,), freq=10, soft_mask
     return {n: getattr(st, n) for n, _ in RunStats._fields_}
 
 
+class Multi:
+    """fga_multi_open / fga_multi_run / fga_multi_close: ONE comparison at a time over `devices` from this one process, the
+    inputs resident between the runs (every rank's slice of both tables on its device, one host thread per device)."""
+
+    def __init__(self, root1, root2=None, devices=(0,), nthreads=8, build_index=False, masks1=None, masks2=None):
+        from .lib import RunParams
+        self.L = load_library()
+        self.devices = tuple(int(d) for d in devices)
+        def cstrs(paths):
+            if not paths:
+                return None, 0
+            return (C.c_char_p * len(paths))(*[p.encode() for p in paths]), len(paths)
+        m1, n1 = cstrs(masks1)
+        m2, n2 = cstrs(masks2)
+        prm = RunParams(0, 10, 0, 0, 2000, 170, 100, 0.3, nthreads, None, b"FastGA", None, 0, 0, int(build_index), m1, n1, m2, n2, 0)
+        devs = (C.c_int * max(len(self.devices), 1))(*self.devices)
+        h = C.c_void_p()
+        check(self.L.fga_multi_open(root1.encode(), root2.encode() if root2 else None, C.byref(prm), len(self.devices), devs,
+                                    C.byref(h)), "fga_multi_open")
+        self.h = h
+
+    def run(self, out_path=None, freq=10, soft_mask=False, symmetric=False, chain_break=1000, chain_min=85, align_min=100,
+            identity=0.7, nthreads=8, command_line="FastGA", paf_path=None, paf_flags=0, reference_threads=0):
+        from .lib import RunParams, RunStats
+        prm = RunParams(0, freq, int(soft_mask), int(symmetric), 2 * chain_break, 2 * chain_min, align_min,
+                        1.0 - identity, nthreads, out_path.encode() if out_path else None, command_line.encode(),
+                        paf_path.encode() if paf_path else None, paf_flags, 0, 0, None, 0, None, 0, reference_threads)
+        st = RunStats()
+        check(self.L.fga_multi_run(self.h, C.byref(prm), C.byref(st)), "fga_multi_run")
+        return {n: getattr(st, n) for n, _ in RunStats._fields_}
+
+    def rank_stats(self):
+        """per rank of the last run: seconds of phase 1 / exchange / phase 2 (+ filter), extension kernel ms, wave steps"""
+        out = []
+        if len(self.devices) < 2:
+            return out
+        for r in range(len(self.devices)):
+            s3, ms, ws = (C.c_double * 3)(), C.c_double(), C.c_int64()
+            check(self.L.fga_multi_rank_stats(self.h, r, s3, C.byref(ms), C.byref(ws)), "fga_multi_rank_stats")
+            out.append({"phase1_s": s3[0], "exchange_s": s3[1], "phase2_s": s3[2], "extend_kernel_ms": ms.value,
+                        "wave_steps": ws.value})
+        return out
+
+    def close(self):
+        if self.h:
+            self.L.fga_multi_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Session:
     """inputs resident in HBM; run() is one pass of the hot path (fga_session_*)."""
 

@@ -70,7 +70,8 @@ class ExtendParams(C.Structure):
 class Alns(C.Structure):
     _fields_ = [("naln", C.c_int64), ("ntrace", C.c_int64), ("ncalls", C.c_int64), ("nwaves", C.c_int64),
                 ("alns", C.c_void_p), ("tbytes", C.c_void_p),
-                ("ncells", C.c_int64), ("nbases", C.c_int64), ("busy_waves", C.c_double)]
+                ("ncells", C.c_int64), ("nbases", C.c_int64), ("busy_waves", C.c_double),
+                ("ctg_waves", C.c_void_p), ("nctg_waves", C.c_int)]
 
 
 class Traces(C.Structure):
@@ -195,6 +196,11 @@ def _declare(L):
         "fga_gap_improve": (i32, [vp, vp, P(Alns), P(Traces)]),
         "fga_run": (i32, [cp, cp, P(RunParams), P(RunStats)]),
         "fga_run_multi": (i32, [cp, cp, P(RunParams), i32, P(i32), P(RunStats)]),
+        "fga_multi_open": (i32, [cp, cp, P(RunParams), i32, P(i32), P(vp)]),
+        "fga_multi_run": (i32, [vp, P(RunParams), P(RunStats)]),
+        "fga_multi_close": (None, [vp]),
+        "fga_multi_ndev": (i32, [vp]),
+        "fga_multi_rank_stats": (i32, [vp, i32, P(C.c_double), P(C.c_double), P(i64)]),
         "fga_seeds_import_peer": (i32, [vp, P(vp), P(i32), P(i64), i32, P(vp)]),
         "fga_dev_enable_peer": (i32, [vp, i32]),
         "fga_dev_device_count": (i32, []),

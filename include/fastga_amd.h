@@ -240,6 +240,8 @@ typedef struct
     int64_t  ncells;           /* diagonal updates: sum over wave steps of the wave width                   */
     int64_t  nbases;           /* bases compared by the snakes (per sequence; + one probe per cell update)  */
     double   busy_waves;       /* wavefronts busy on average over the launch                                */
+    int64_t *ctg_waves;        /* [nctg_waves] wave steps per A contig (index order) of that launch, or NULL: the cost  */
+    int      nctg_waves;       /*   fga_multi_run weighs the next partition of the contigs over its ranks with          */
   } fga_alns;
 
 int  fga_align_spec(double ave_corr, int tspace, const float *freq4, int *path_ave, int16_t *table, int16_t *score);
@@ -457,6 +459,20 @@ int  fga_dev_device_count(void);                           /* HIP devices this p
  *      prm->device is ignored; prm->nthreads is shared out among the ranks.  fastga_amd/bin/FastGA: -G<n> / FGA_DEVICES. */
 int  fga_run_multi(const char *root1, const char *root2 /* NULL: self */, const fga_run_params *prm,
                    int ndev, const int *devices, fga_run_stats *stats);
+/*      The same as a session, the way the reference keeps its parts machinery for the length of its process: open reads the
+ *      inputs once, puts every rank's slice on its device, enables peer access and leaves one host thread per device waiting;
+ *      every run is one comparison from resident inputs (fga_run_multi = open + run + close); the contigs are dealt to the
+ *      ranks by the wave steps their units took in the session's previous run (the first run: by seed counts) -- the result
+ *      does not depend on it.  prm of open: nthreads, build_index, masks; prm of run: everything else.  One run at a time. */
+typedef struct fga_multi fga_multi;
+int  fga_multi_open(const char *root1, const char *root2 /* NULL: self */, const fga_run_params *prm,
+                    int ndev, const int *devices, fga_multi **out);
+int  fga_multi_run(fga_multi *m, const fga_run_params *prm, fga_run_stats *stats);
+void fga_multi_close(fga_multi *m);
+int  fga_multi_ndev(const fga_multi *m);
+/* figures of one rank in the last run: seconds of phase 1 / exchange / phase 2 (with its filter), its extension kernel's
+   ms and wave steps */
+int  fga_multi_rank_stats(const fga_multi *m, int rank, double *seconds3, double *extend_kernel_ms, int64_t *wave_steps);
 
 /* the same with the inputs kept resident in HBM between passes (what bench.py times) */
 typedef struct fga_session fga_session;

@@ -68,3 +68,25 @@ def test_comparison_with_a_named_mask_is_the_reference_s(masked_pair, built_libr
     a, b = keep(H.oneview(ours)), keep(H.oneview(os.path.join(d, "ref.1aln")))
     assert st["nlive"] > 0 and a == b
     assert b != keep(H.oneview(os.path.join(d, "refplain.1aln")))        # the mask really changed the reference's answer
+
+
+def test_masks_for_one_genome_only_over_several_ranks(masked_pair, built_library):
+    """one genome masked (its index is built anew on the device), the other with its index files on disk: a sliced session
+    cuts its prefix ranges from ONE kind of count, so fga_multi_open has both indices built on the devices -- and the result
+    is the one-GPU run's (pinned to the reference above) with any number of ranks (this combination failed with
+    'a sliced session wants both genome indices as files, or neither')"""
+    from fastga_amd import device as D
+    d = masked_pair
+    ra, rb = os.path.join(d, "A"), os.path.join(d, "B")
+    if not os.path.exists(rb + ".gix"):
+        H.run([H.ref_bin("GIXmake"), "-T1", f"-P{d}", rb], cwd=d)
+    keep = lambda lines: [ln for ln in lines if ln[0] not in "!<"]      # noqa: E731
+    mask = [os.path.join(d, "rep.1ano")]
+    one = os.path.join(d, "one_m.1aln")
+    st1 = D.run(ra, rb, one, nthreads=4, soft_mask=True, masks1=mask, reference_threads=4)
+    ref = keep(H.oneview(one))
+    assert st1["nlive"] > 0
+    for devices in ((0, 0), (0, 0, 0)):
+        out = os.path.join(d, "multi_m%d.1aln" % len(devices))
+        st = D.run_multi(ra, rb, out, devices=devices, nthreads=4, soft_mask=True, masks1=mask, reference_threads=4)
+        assert keep(H.oneview(out)) == ref and st["nlive"] == st1["nlive"], devices

@@ -52,6 +52,30 @@ def test_run_multi_argument_checks(built_library, toy_pair):
         assert rc == 1 and b"out of range" in L.fga_last_error()
 
 
+def test_multi_session_argument_checks(built_library, toy_pair):
+    from fastga_amd.lib import RunParams, RunStats
+    L = built_library
+    d, ra, rb = toy_pair
+    prm, st = RunParams(), RunStats()
+    prm.freq, prm.nthreads, prm.align_min, prm.align_rate = 10, 4, 100, 0.3
+    prm.chain_break, prm.chain_min = 2000, 170
+    dev2 = (C.c_int * 2)(0, 0)
+    h = C.c_void_p()
+    for ndev, devs in ((0, dev2), (65, dev2), (2, None)):
+        rc = L.fga_multi_open(ra.encode(), rb.encode(), C.byref(prm), ndev, devs, C.byref(h))
+        assert rc == 1 and b"fga_multi_open: bad argument" in L.fga_last_error() and not h.value
+    assert L.fga_multi_open(ra.encode(), rb.encode(), C.byref(prm), 2, dev2, None) == 1
+    assert L.fga_multi_run(None, C.byref(prm), C.byref(st)) == 1 and b"null argument" in L.fga_last_error()
+    L.fga_multi_close(None)                               # a no-op
+    assert L.fga_multi_ndev(None) == 0
+    import torch
+    if not torch.cuda.is_available():                     # no CPU fallback behind the session form either
+        rc = L.fga_multi_open(ra.encode(), rb.encode(), C.byref(prm), 2, dev2, C.byref(h))
+        assert rc == 1 and b"no CPU fallback" in L.fga_last_error() and not h.value
+        rc = L.fga_multi_open(os.path.join(d, "nothing_here").encode(), None, C.byref(prm), 2, dev2, C.byref(h))
+        assert rc == 1 and not h.value                    # a missing genome is reported before the device
+
+
 def test_cli_gpu_option_grammar(built_library, toy_pair, tmp_path):
     d, ra, rb = toy_pair
     def run(args, env=None):
@@ -82,6 +106,25 @@ def test_cli_gpu_option_grammar(built_library, toy_pair, tmp_path):
 
 # ------------------------------------------------------------------------------------------------ GPU: parity
 
+def _ngpu():
+    from fastga_amd.lib import load_library
+    return load_library().fga_dev_device_count()
+
+
+def _device_lists():
+    """virtual ranks on GPU 0 everywhere; distinct devices -- the hipMemcpyPeerAsync branch of fga_seeds_import_peer, peer
+    access, buffers released on another device's thread -- on a node that has them"""
+    lists = [(0,), (0, 0), (0, 0, 0, 0), (0, 0, 0)]
+    n = _ngpu()
+    if n >= 2:
+        lists += [(0, 1), (1, 0), (1, 1, 0)]
+    if n >= 4:
+        lists += [(0, 1, 2, 3)]
+    if n >= 8:
+        lists += [tuple(range(8))]
+    return lists
+
+
 def _reference(ra, rb, w, flags=(), threads=8):
     from oracle import harness as H
     if not H.have_reference():
@@ -101,8 +144,8 @@ def test_run_multi_with_virtual_ranks_is_the_reference_line_for_line(toy_pair, t
     ref = _reference(ra, b, w, flags=("-S", "-f6") if mode == "symmetric" else ())
     one = D.run(ra, b, os.path.join(w, "one.1aln"), nthreads=8, reference_threads=8, **kw)
     assert _keep(_view(os.path.join(w, "one.1aln"))) == ref
-    for devices in ((0,), (0, 0), (0, 0, 0, 0), (0, 0, 0)):
-        out = os.path.join(w, "multi%d.1aln" % len(devices))
+    for devices in _device_lists():
+        out = os.path.join(w, "multi%s.1aln" % "".join(map(str, devices)))
         st = D.run_multi(ra, b, out, devices=devices, nthreads=8, reference_threads=8, **kw)
         assert _keep(_view(out)) == ref, devices
         assert st["nalns"] == one["nalns"] and st["nlive"] == one["nlive"] and st["nhits"] == one["nhits"]
@@ -169,3 +212,48 @@ def test_run_multi_again_and_again(toy_pair, tmp_path):
     for k in range(30):
         D.run_multi(ra, rb, out, devices=(0, 0, 0), nthreads=8, reference_threads=8)
         assert _keep(_view(out)) == ref, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["pair", "self"])
+def test_multi_session_runs_warm_and_reweighs_its_parts(toy_pair, tmp_path, mode):
+    """fga_multi_open / run / run / run / close: the inputs stay on the devices, the rank threads stay alive, and from the
+    second run on the contigs are dealt to the ranks by the wave steps their units took the run before (the first: by seed
+    counts) -- every run is the reference's file line for line, with any parameters of the run"""
+    from fastga_amd import device as D
+    d, ra, rb = toy_pair
+    w = str(tmp_path)
+    b = None if mode == "self" else rb
+    ref = _reference(ra, b, w)
+    ref6 = None
+    for devices in [dl for dl in _device_lists() if len(dl) > 1][:4]:
+        M = D.Multi(ra, b, devices=devices, nthreads=8)
+        try:
+            for k in range(3):
+                out = os.path.join(w, "s%d.1aln" % k)
+                st = M.run(out_path=out, nthreads=8, reference_threads=8)
+                assert _keep(_view(out)) == ref, (devices, k)
+                assert st["nparts"] == len(devices)
+                rs = M.rank_stats()
+                assert len(rs) == len(devices) and sum(r["wave_steps"] for r in rs) == st["nwaves"]
+            if mode == "pair":                             # other parameters on the same session
+                if ref6 is None:
+                    ref6 = _reference(ra, b, os.path.join(w), flags=("-S", "-f6"))
+                out = os.path.join(w, "s6.1aln")
+                M.run(out_path=out, nthreads=8, reference_threads=8, symmetric=True, freq=6)
+                assert _keep(_view(out)) == ref6, devices
+        finally:
+            M.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif("_ngpu() < 2")
+def test_two_real_devices_leave_the_callers_device_alone(toy_pair, tmp_path):
+    """the ranks' threads visit their devices; the calling thread's current device is what it was"""
+    import torch
+    from fastga_amd import device as D
+    d, ra, rb = toy_pair
+    torch.cuda.set_device(1)
+    D.run_multi(ra, rb, os.path.join(str(tmp_path), "m.1aln"), devices=(0, 1), nthreads=8)
+    assert torch.cuda.current_device() == 1
+    torch.cuda.set_device(0)
