@@ -10,11 +10,15 @@ tables are already resident in HBM (uploaded / built on the device before the ti
 Workload = BASELINE.json configs[1]: synthetic pair, 2 % divergence, 2.5-Mbp contigs, 5 % repeats,
 2 % rearranged blocks, 100 Mbp per genome PER GPU:
   N = 1   100 Mbp x 100 Mbp, 40 contigs -- the configuration the metric is quoted on.
-  N > 1   ONE comparison of (N x 100 Mbp) x (N x 100 Mbp), 40 N contigs, cut over the N ranks the way the reference cuts
-          it over parts and threads (fastga_amd/parallel.py): every rank merges one 12-mer prefix range of the two
-          (replicated) tables, the seeds go to the rank that owns their A contig in one RCCL all-to-all-v, every rank
-          sorts / chains / extends its A-contig part, rank 0 gathers the records, filters, orders and writes the .1aln.
+  N > 1   ONE comparison of (N x 100 Mbp) x (N x 100 Mbp), 40 N contigs, cut over the N GPUs the way the reference cuts
+          it over parts and threads, by the C library itself (fga_multi_open / fga_multi_run, fastga_amd/csrc/fga_multi.c --
+          what `FastGA -G<N>` runs): the launcher's rank 0 holds the session -- one host thread + HIP stream per device, every
+          device its 12-mer prefix range of both tables, the seeds to the device that owns their A contig with
+          hipMemcpyPeerAsync, every device sorts / chains / extends / filters its A-contig part, the .1aln written once -- and
+          a step is ONE fga_multi_run; the launcher's other ranks only stand at the barriers (a gloo group: no kernel of theirs
+          on the GPUs that are being timed).  No torch and no collective library in the timed path.
           Per-GPU work is fixed as N grows ("scaling": "weak"); `value` = whole-comparison Gbp-pair per second.
+          `--devices 0,0` (one process, no launcher) takes the same path with ranks sharing a GPU: a code-path check.
 `--strong-mbp M` instead fixes the comparison at M Mbp per genome for every N (strong scaling; the extension's critical
 path -- the longest contig's serial wave chain -- bounds it).
 
@@ -61,8 +65,9 @@ def parse():
     ap.add_argument("--workdir", default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the reference leg (cpu_baseline + parity)")
     ap.add_argument("--no-cold", action="store_true")
-    ap.add_argument("--force-sharded", action="store_true",
-                    help="take the multi-GPU code path (process group, exchange, gather) even with one rank")
+    ap.add_argument("--devices", default=None,
+                    help="N = 1 only: run the step through fga_multi_run over these HIP devices (e.g. 0,0: two ranks sharing "
+                         "GPU 0) -- the N > 1 code path on a one-GPU box")
     ap.add_argument("--self", dest="self_", action="store_true",
                     help="BASELINE configs[2]'s shape instead of the pair: repeat-heavy genome of --mbp against itself, -M")
     ap.add_argument("--batch", type=int, default=8,
@@ -150,23 +155,29 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s): one rank per GPU "
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     dist = None
-    if world > 1 or args.force_sharded:
-        # torch FIRST: one HIP runtime per process (fastga_amd/lib.py::load_library)
+    multi_devs = None              # the step is fga_multi_run over these devices (rank 0 holds the session)
+    if world > 1:
+        # torch FIRST: one HIP runtime per process (fastga_amd/lib.py::load_library).  The process group is the launcher's
+        # control plane only -- barriers around the timed region -- on gloo: a RCCL barrier is a kernel spinning on every
+        # GPU, and the GPUs are rank 0's to time
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        if "MASTER_ADDR" not in os.environ:                  # --force-sharded without a launcher
-            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29517"
-            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group("gloo")
+        multi_devs = tuple(range(world))
+    elif args.devices:
+        multi_devs = tuple(int(x) for x in args.devices.split(","))
+    ndev = len(multi_devs) if multi_devs else 1
 
     from fastga_amd import workload, device as D
 
     shared = args.workdir or os.path.join(tempfile.gettempdir(), f"fga_bench_{os.environ.get('MASTER_PORT', os.getpid())}")
     os.makedirs(shared, exist_ok=True)
-    mbp = args.strong_mbp if args.strong_mbp > 0 else args.mbp * world
-    ncontig = max(world, int(round(args.contigs * mbp / 100.0)))
-    threads = max(1, min(32, (os.cpu_count() or 8) // max(1, world)))
+    mbp = args.strong_mbp if args.strong_mbp > 0 else args.mbp * ndev
+    ncontig = max(ndev, int(round(args.contigs * mbp / 100.0)))
+    threads = max(1, min(32 * ndev, (os.cpu_count() or 8)))      # one process: the session shares them out among its ranks
+    if multi_devs is None:
+        threads = min(32, threads)
     t0 = time.time()
     ra, rb = os.path.join(shared, "A"), os.path.join(shared, "B")
     if rank == 0:
@@ -182,64 +193,56 @@ def main():
     prep_s = time.time() - t0
 
     # inputs resident in HBM before the timed region: both GIX tables + both 2-bit genomes (every rank holds all of them)
-    # (with N ranks: every rank holds the genomes' bases and ITS 12-mer prefix range of the two tables only)
-    ses = D.Session(ra, rb, device=local, rank=rank if world > 1 else 0, nranks=world if world > 1 else 1, nthreads=threads)
+    # (with N devices: every device holds the genomes' bases and ITS 12-mer prefix range of the two tables only)
+    ses = None
+    if multi_devs is None:
+        ses = D.Session(ra, rb, device=local, nthreads=threads)
+    elif rank == 0:
+        ses = D.Multi(ra, rb, devices=multi_devs, nthreads=threads)
     out1aln = os.path.join(shared, "bench.1aln")
     # reference_threads: records that tie on (aread, abpos) in the order FastGA -T<threads> writes them (the reference leg
     # below runs with that -T): the parity gate is line equality
-    kw = dict(out_path=out1aln, nthreads=threads, command_line="bench.py FastGA hot path", reference_threads=threads)
+    kw = dict(out_path=out1aln, nthreads=threads, command_line="bench.py FastGA hot path", reference_threads=min(32, threads))
     if args.self_:
         kw["soft_mask"] = True
 
-    if dist is None:
-        def step():
-            return ses.run(**kw)
-    else:
-        from fastga_amd.parallel import run_sharded
-        dev = f"cuda:{local}"
-
-        def step():
-            return run_sharded(ses, dist, kw, dev)
+    def step():
+        return ses.run(**kw) if ses is not None else None      # (the launcher's other ranks: the barriers only)
 
     def barrier():
-        ses.sync()
+        if multi_devs is None:
+            ses.sync()                                # (fga_multi_run returns with the .1aln closed: nothing in flight)
         if dist is not None:
             import torch
             dist.barrier()
             torch.cuda.synchronize()
 
-    gix_ms = ses.dev_wrapper().stage_ms(5)            # kernel time of the session's own device build of genome B's index
-    do_cpu = (not args.no_cpu) and world == 1 and not args.self_     # the reference leg runs on rank 0 at N=1 only
+    gix_ms = ses.dev_wrapper().stage_ms(5) if multi_devs is None else None   # kernel time of the session's device build of genome B's index
+    do_cpu = (not args.no_cpu) and ndev == 1 and not args.self_     # the reference leg runs on rank 0 at N=1 only
 
     for _ in range(args.warmup):
         step()
     barrier()
     t = time.time()
     stats, cut_ms = [], []
+    rank_stats = []
     for _ in range(args.steps):
         stats.append(step())
-        cut_ms.append(ses.dev_wrapper().stage_ms(0))      # FGA_STAGE_MERGE_PARTITION: range_cut_kernel of the step's merge launch
+        if multi_devs is None:
+            cut_ms.append(ses.dev_wrapper().stage_ms(0))      # FGA_STAGE_MERGE_PARTITION: range_cut_kernel of the step's merge launch
+        elif ses is not None:
+            rank_stats.append(ses.rank_stats())
     barrier()
     elapsed = time.time() - t
 
-    if dist is not None:
+    if dist is not None:                              # the contract's MAX over the launcher's ranks
         import torch
-        tt = torch.tensor([elapsed], device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        # totals over the ranks (counts only; the records themselves were gathered inside the step)
-        keys = ("nseeds", "nhits", "nalns", "ncalls", "nwaves", "ext_cells", "ext_bases", "ext_trace", "part_seeds",
-                "exchange_seeds_out")
-        v = torch.tensor([int(stats[-1][k]) for k in keys], device="cuda", dtype=torch.int64)
-        allv = [torch.zeros_like(v) for _ in range(world)]
-        dist.all_gather(allv, v)
-        tot = {k: [int(a[i].item()) for a in allv] for i, k in enumerate(keys)}
-        km = torch.tensor([sum(s["merge_kernel_ms"] for s in stats) / len(stats),
-                           sum(s["extend_kernel_ms"] for s in stats) / len(stats)], device="cuda")
-        dist.all_reduce(km, op=dist.ReduceOp.MAX)
-        kavg, kext = float(km[0].item()), float(km[1].item())
-    else:
-        tot = None
+    tot = None
+    if rank == 0:
+        # (fga_multi_run's stats are totals over its ranks already; its kernel times the slowest rank's)
         kavg = sum(s["merge_kernel_ms"] for s in stats) / len(stats)
         kext = sum(s["extend_kernel_ms"] for s in stats) / len(stats)
 
@@ -253,15 +256,15 @@ def main():
         # algorithmic bytes of the merge launches of one step: every table entry once in its on-disk width, every seed
         # once in the reference's record width (with N ranks each launch covers 1/N of the prefix space)
         seed_bytes = nseeds * ses.seed_bytes * (2 if args.self_ else 1)    # self: the reported total is halved (FastGA.c:1906)
-        # a sliced session's table bytes are rank 0's share already (the ranges are cut for equal cost)
-        alg_bytes = ses.table_bytes * (world if ses.nranks > 1 else 1) + seed_bytes
+        world = ndev                                     # (below: the GPUs the comparison ran on)
+        alg_bytes = ses.table_bytes + seed_bytes         # (a multi-GPU session: its ranks' slices add up to the two tables)
         achieved = alg_bytes / max(1, world) / (kavg * 1e-3) / 1e9          # per GPU, slowest rank's launch time
         stage_ms = {k: round(1000 * sum(s[k] for s in stats) / len(stats), 2)
                     for k in ("merge_s", "sort_s", "chain_s", "extend_s", "filter_s", "write_s")}
         b_ext = 2 * (S("ext_bases") + S("ext_cells")) + 2 * S("ext_trace")
         out = {
             "metric": "Gbp-pair aligned/sec", "value": value, "unit": "Gbp-pair/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": len(set(multi_devs)) if multi_devs else 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong" if args.strong_mbp > 0 else "weak", "vs_baseline": None,
             "dtype": "u8/int32/u64", "data": "synthetic",
             "config": {"workload": (f"synthetic repeat-heavy {mbp:g} Mbp genome against itself, soft mask on (BASELINE configs[2]'s shape)"
@@ -272,8 +275,10 @@ def main():
                                        f"{args.mbp:g} Mbp per genome per GPU)")),
                        "step": "seed merge -> sort -> chain scan -> wave extension -> redundancy filter -> .1aln "
                                "written; GIX tables + genomes resident in HBM"
-                               + ("" if world == 1 else "; phase 1 by k-mer prefix range, seeds all-to-all-v by A-contig "
-                                  "part (RCCL), phase 2 by part, records gathered to rank 0"),
+                               + ("" if world == 1 else "; ONE fga_multi_run (C, one process, one host thread + stream per "
+                                  "device): phase 1 by k-mer prefix range, seeds to the device that owns their A contig "
+                                  "(hipMemcpyPeerAsync), phase 2 + filter by part, one .1aln"),
+                       "devices": list(multi_devs) if multi_devs else [local], "ranks": ndev,
                        "seeds": int(nseeds), "hits": S("nhits"), "alignments": S("nalns"),
                        "records": int(last["nlive"]), "la_calls": S("ncalls"), "waves": S("nwaves"),
                        "stage_ms": stage_ms,
@@ -284,12 +289,8 @@ def main():
             "roofline": {"kernel": "seed merge launch (HIP events around fga_seed_merge's kernels on the library's stream)",
                          "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes": int(alg_bytes // max(1, world)), "kernel_ms": kavg,
-                         # the walk kernel alone (the launch less its range_cut_kernel): what the rocprofv3 per-kernel average
-                         # of seed_merge_walk_kernel corresponds to
-                         "walk_kernel_ms": kavg - sum(cut_ms) / len(cut_ms),
-                         "walk_kernel_frac": (alg_bytes / max(1, world)) / ((kavg - sum(cut_ms) / len(cut_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            "sort": sort_block(last["sort_keys"] if tot is None else None, last["sort_passes"], last["sort_kernel_ms"]),
+                         "traffic": None, "algorithmic_bytes": int(alg_bytes // max(1, world)), "kernel_ms": kavg},
+            "sort": sort_block(last["sort_keys"] if world == 1 else None, last["sort_passes"], last["sort_kernel_ms"]),
             "extend": {"kernel": "extend_kernel", "bound": "latency (one wavefront per unit; longest unit's serial chain)",
                        "kernel_ms": kext, "algorithmic_bytes": int(b_ext),
                        "achieved_GBps": b_ext / (kext * 1e-3) / 1e9 if kext > 0 else None,
@@ -299,15 +300,27 @@ def main():
                        "avg_wave_width": S("ext_cells") / max(1, S("nwaves")),
                        "avg_busy_wavefronts": round(float(last["ext_busy_waves"]), 1)},
         }
-        if tot is not None:
-            out["config"]["per_rank"] = {"part_seeds": tot["part_seeds"], "seeds_sent": tot["exchange_seeds_out"],
-                                         "alignments": tot["nalns"], "waves": tot["nwaves"]}
-        if world == 1 and not args.self_ and abs(mbp - 100.0) < 1e-9 and abs(args.div - 0.02) < 1e-9:    # the profiled configuration
+        if cut_ms:
+            # the walk kernel alone (the launch less its range_cut_kernel): what the rocprofv3 per-kernel average of
+            # seed_merge_walk_kernel corresponds to
+            out["roofline"]["walk_kernel_ms"] = kavg - sum(cut_ms) / len(cut_ms)
+            out["roofline"]["walk_kernel_frac"] = alg_bytes / ((kavg - sum(cut_ms) / len(cut_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if rank_stats:
+            rs = rank_stats[-1]
+            ext = [r["extend_kernel_ms"] for r in rs]
+            out["config"]["per_rank"] = {k: [round(r[k], 4) for r in rs] for k in ("phase1_s", "exchange_s", "phase2_s")}
+            out["config"]["per_rank"]["extend_kernel_ms"] = [round(x, 2) for x in ext]
+            out["config"]["per_rank"]["wave_steps"] = [int(r["wave_steps"]) for r in rs]
+            out["config"]["per_rank"]["part_imbalance_extend"] = max(ext) / (sum(ext) / len(ext)) if sum(ext) > 0 else None
+            if len(rank_stats) > 1:               # the first step of the session deals the contigs by seed counts, the later ones by wave steps
+                e0 = [r["extend_kernel_ms"] for r in rank_stats[0]]
+                out["config"]["per_rank"]["part_imbalance_extend_first_timed_step"] = max(e0) / (sum(e0) / len(e0)) if sum(e0) > 0 else None
+        if multi_devs is None and not args.self_ and abs(mbp - 100.0) < 1e-9 and abs(args.div - 0.02) < 1e-9:    # the profiled configuration
             tr, src = pmc_traffic()
             if tr is not None:
                 out["roofline"]["traffic"] = tr
                 out["roofline"]["traffic_source"] = src
-        if world == 1 and not args.no_cold and not args.self_:
+        if multi_devs is None and not args.no_cold and not args.self_:
             out["cold"] = cold_run(D, ra, rb, shared, threads, pair_gbp)
         if do_cpu:
             try:
@@ -322,12 +335,12 @@ def main():
             except Exception as e:      # the baseline leg must never take the bench line down
                 out["cpu_baseline"] = {"value": None, "unit": "Gbp-pair/s", "cores": 0, "kind": "reference",
                                        "sample": f"failed: {e}"}
-        if world == 1 and not args.self_ and args.batch > 1:
+        if multi_devs is None and not args.self_ and args.batch > 1:
             try:
                 out["batch"] = batch_leg(D, ra, rb, shared, threads, pair_gbp, args.batch, max(2, min(args.steps, 5)), ms_per_step)
             except Exception as e:                # never takes the bench line down
                 out["batch"] = {"error": str(e)}
-        if world == 1 and not args.self_ and not args.no_human_scale:
+        if multi_devs is None and not args.self_ and not args.no_human_scale:
             ses.close()                           # the 3 Gbp leg wants the whole device
             ses = None
             for key, div in (("human_scale", 0.01), ("human_scale_10pct", 0.10)):
@@ -335,38 +348,29 @@ def main():
                     out[key] = human_scale_run(D, workload, shared, threads, div, project=(div == 0.01))
                 except Exception as e:            # never takes the bench line down
                     out[key] = {"error": str(e)}
-    # N > 1: parity of the step that was timed (the sharded .1aln against the same comparison on one GPU, record lines in
-    # sequence), and the same comparison through fga_run_multi -- the C-ABI's own multi-GPU entry, what FastGA -G<N> runs
-    if dist is not None and os.environ.get("FGA_BENCH_VERIFY", "1") != "0":
-        try:
-            if ses is not None:
+    # N > 1: parity of the step that was timed (its .1aln against the same comparison on one GPU, record lines in sequence),
+    # the cold form of the same entry (fga_run_multi = open + run + close), and the comparison north_star names -- ONE 3 Gbp x
+    # 3 Gbp pair over the N GPUs (strong scaling) beside the weak-scaled `value` above.  All on rank 0; the others wait.
+    if multi_devs is not None and rank == 0:
+        if os.environ.get("FGA_BENCH_VERIFY", "1") != "0":
+            try:
                 ses.close()
                 ses = None
-            got = file_digest(workload, out1aln) if rank == 0 else None
-            par = verify_sharded_step(D, workload, dist, kw, ra, rb, got, shared, threads, rank, world, local)
-            mul = c_abi_multi_leg(D, workload, dist, ra, rb, shared, threads, rank, world, mbp * 1e-3, threads, compare_with=got)
-            if rank == 0:
-                out["parity"] = par
-                out["c_abi_multi"] = mul
-        except Exception as e:                    # never takes the bench line down
-            if rank == 0:
+                got = file_digest(workload, out1aln)
+                out["parity"] = verify_multi_step(D, workload, kw, ra, rb, got, shared, min(32, threads))
+                out["c_abi_multi_cold"] = multi_cold_leg(D, workload, ra, rb, shared, threads, multi_devs, mbp * 1e-3, min(32, threads), compare_with=got)
+            except Exception as e:                    # never takes the bench line down
                 out["parity"] = {"error": str(e)}
-    # N > 1: the comparison north_star names -- ONE 3 Gbp x 3 Gbp pair cut over the N GPUs (strong scaling), beside the
-    # weak-scaled `value` above.  Every rank opens a sliced session (its 12-mer prefix range of both tables, built on the
-    # device) and runs run_sharded once warm; the cold span is the open + that run.  FGA_BENCH_SHARDED_3G=0 skips it.
-    sharded3g = None
-    want3g = os.environ.get("FGA_BENCH_SHARDED_3G", "1")          # "force": also with one rank under --force-sharded (a code-path check)
-    if dist is not None and (world > 1 or want3g == "force") and not args.no_human_scale and args.strong_mbp <= 0 and want3g != "0":
-        try:
-            if ses is not None:
-                ses.close()
-                ses = None
-            sharded3g = sharded_human_scale(D, workload, dist, shared, threads, rank, world, local)
-        except Exception as e:                    # never takes the bench line down
-            sharded3g = {"error": str(e)}
+        want3g = os.environ.get("FGA_BENCH_SHARDED_3G", "1")          # "force": also over a --devices list (a code-path check)
+        if (world > 1 or want3g == "force") and not args.no_human_scale and args.strong_mbp <= 0 and want3g != "0":
+            try:
+                if ses is not None:
+                    ses.close()
+                    ses = None
+                out["human_scale_sharded"] = multi_human_scale(D, workload, shared, threads, multi_devs)
+            except Exception as e:                    # never takes the bench line down
+                out["human_scale_sharded"] = {"error": str(e)}
     if rank == 0:
-        if sharded3g is not None:
-            out["human_scale_sharded"] = sharded3g
         print(json.dumps(out), flush=True)
 
     if ses is not None:
@@ -430,145 +434,105 @@ def file_digest(workload, path, golden_keys=False):
     return workload.digest_1aln_records(path)
 
 
-def verify_sharded_step(D, workload, dist, ses_kw, ra, rb, got, workdir, threads, rank, world, local):
-    """Parity of the N-rank step: the SAME comparison once more on rank 0's GPU alone (whole tables, fga_session_run) must
-    give the file the sharded step wrote, record line for record line.  (The one-GPU path is what the test suite pins to the
-    reference; at N x 100 Mbp no golden digest exists.)  The other ranks wait."""
-    import torch
-    res = None
-    if rank == 0:
-        try:
-            one = os.path.join(workdir, "one_gpu.1aln")
-            ses = D.Session(ra, rb, device=local, nthreads=threads)
-            kw = dict(ses_kw); kw["out_path"] = one
-            t = time.time()
-            st = ses.run(**kw)
-            dt = time.time() - t
-            ses.close()
-            exp = file_digest(workload, one)
-            res = {"sharded_equals_one_gpu_run": bool(got == exp), "records": int(st["nlive"]),
-                   "one_gpu_seconds_first_run": round(dt, 3),
-                   "digest": {k: got[k] for k in got if k in ("records", "lines_md5", "order_md5", "fields_md5", "trace_md5")},
-                   "how": "the step's .1aln vs fga_session_run of the same pair on one GPU: record lines in sequence"}
-        except Exception as e:
-            res = {"error": str(e)}
-    dist.barrier()
-    torch.cuda.synchronize()
+def verify_multi_step(D, workload, ses_kw, ra, rb, got, workdir, threads):
+    """Parity of the N-GPU step: the SAME comparison once more on GPU 0 alone (whole tables, fga_session_run) must give the
+    file the step wrote, record line for record line.  (The one-GPU path is what the test suite pins to the reference; at
+    N x 100 Mbp no golden digest exists.)"""
+    one = os.path.join(workdir, "one_gpu.1aln")
+    ses = D.Session(ra, rb, device=0, nthreads=threads)
+    kw = dict(ses_kw); kw["out_path"] = one; kw["nthreads"] = threads
+    t = time.time()
+    st = ses.run(**kw)
+    dt = time.time() - t
+    ses.close()
+    exp = file_digest(workload, one)
+    return {"multi_equals_one_gpu_run": bool(got == exp), "records": int(st["nlive"]),
+            "one_gpu_seconds_first_run": round(dt, 3),
+            "digest": {k: got[k] for k in got if k in ("records", "lines_md5", "order_md5", "fields_md5", "trace_md5")},
+            "how": "the step's .1aln vs fga_session_run of the same pair on one GPU: record lines in sequence"}
+
+
+def multi_cold_leg(D, workload, ra, rb, workdir, threads, devs, gbp, ref_threads, compare_with=None, golden=None):
+    """The same comparison through fga_run_multi -- what `FastGA -G<N>` runs from the command line: open + run + close in one
+    call, so the span includes reading the GDBs, the genomes to every device and every rank's slice of both index builds."""
+    out = os.path.join(workdir, "c_abi_multi.1aln")
+    t = time.time()
+    st = D.run_multi(ra, rb, out, devices=devs, nthreads=threads, reference_threads=ref_threads,
+                     command_line="bench.py FastGA -G%d" % len(devs))
+    dt = time.time() - t
+    res = {"entry": "fga_run_multi (one process, devices %s, hipMemcpyPeerAsync exchange)" % (list(devs),),
+           "seconds_cold": round(dt, 3), "value_cold": gbp / dt, "unit": "Gbp-pair/s", "records": int(st["nlive"]),
+           "stage_s_max_over_ranks": {k: round(st[k], 3) for k in ("merge_s", "sort_s", "chain_s", "extend_s", "filter_s", "write_s")},
+           "open_s": round(st["upload_s"], 3)}
+    got = file_digest(workload, out, golden_keys=golden is not None)
+    if golden is not None and got is not None:
+        res["digest_equals_reference"] = all(got[k] == golden[k] for k in ("records", "header_md5", "records_sum128", "order_md5", "lines_md5"))
+    elif compare_with is not None:
+        res["equals_timed_step"] = bool(got == compare_with)
+    os.unlink(out)
     return res
 
 
-def c_abi_multi_leg(D, workload, dist, ra, rb, workdir, threads, rank, world, gbp, ref_threads, compare_with=None, golden=None):
-    """The same comparison through the C-ABI's own multi-GPU entry, fga_run_multi -- what `FastGA -G<world>` runs: ONE
-    process (rank 0's; the other ranks have released their sessions and wait), one host thread + HIP stream per device,
-    seeds exchanged with hipMemcpyPeerAsync, no torch, no RCCL.  Cold by construction (it opens and closes its sessions)."""
-    import torch
-    res = None
-    torch.cuda.empty_cache()
-    dist.barrier()
-    if rank == 0:
-        try:
-            out = os.path.join(workdir, "c_abi_multi.1aln")
-            t = time.time()
-            devs = tuple(int(x) for x in os.environ["FGA_BENCH_MULTI_DEVICES"].split(",")) \
-                if os.environ.get("FGA_BENCH_MULTI_DEVICES") else tuple(range(world))      # "0,0": ranks sharing a GPU (a code-path check)
-            st = D.run_multi(ra, rb, out, devices=devs, nthreads=threads, reference_threads=ref_threads,
-                             command_line="bench.py FastGA -G%d" % world)
-            dt = time.time() - t
-            res = {"entry": "fga_run_multi (one process, devices %s, hipMemcpyPeerAsync exchange)" % (list(devs),),
-                   "seconds_cold": round(dt, 3), "value_cold": gbp / dt, "unit": "Gbp-pair/s", "records": int(st["nlive"]),
-                   "stage_s_max_over_ranks": {k: round(st[k], 3) for k in ("merge_s", "sort_s", "chain_s", "extend_s", "filter_s", "write_s")},
-                   "open_s": round(st["upload_s"], 3)}
-            got = file_digest(workload, out, golden_keys=golden is not None)
-            if golden is not None and got is not None:
-                res["digest_equals_reference"] = all(got[k] == golden[k] for k in ("records", "header_md5", "records_sum128", "order_md5", "lines_md5"))
-            elif compare_with is not None:
-                res["equals_sharded_step"] = bool(got == compare_with)
-            os.unlink(out)
-        except Exception as e:
-            res = {"error": str(e)}
-    dist.barrier()
-    return res
-
-
-def sharded_human_scale(D, workload, dist, workdir, threads, rank, world, local):
-    """BASELINE configs[3] over the N GPUs of the node: 3 Gbp x 3 Gbp, 1 %, one comparison (fastga_amd.parallel.run_sharded
-    with sliced sessions).  Rank 0 makes the genomes (C generator, ~12 s) in the shared work directory."""
+def multi_human_scale(D, workload, workdir, threads, devs):
+    """BASELINE configs[3] over the N GPUs of the node: 3 Gbp x 3 Gbp, 1 %, ONE comparison at a time on a fga_multi session
+    (every device its slice of both indices, built on it).  The cold span is the open + the first run; three runs follow
+    on the warm session -- from the second on the contigs are dealt to the devices by the wave steps of the run before."""
     import shutil
-    import torch
-    from fastga_amd.parallel import run_sharded
     d = os.path.join(workdir, "human_scale_sharded")
     gbp = float(os.environ.get("FGA_BENCH_SHARDED_MBP", "3000")) * 1e-3        # 3 Gbp unless a code-path check asks for less
-    ra, rb = os.path.join(d, "A"), os.path.join(d, "B")
-    t = time.time()
-    if rank == 0:
-        os.makedirs(d, exist_ok=True)
-        ra, rb = workload.build_config4(d, mbp=1000.0 * gbp, divergence=0.01, threads=threads)
-    names = [ra, rb]
-    dist.broadcast_object_list(names, src=0)
-    ra, rb = names
-    dist.barrier()
-    prep = time.time() - t
+    os.makedirs(d, exist_ok=True)
     try:
-        torch.cuda.synchronize()
-        dist.barrier()
         t = time.time()
-        ses = D.Session(ra, rb, device=local, rank=rank, nranks=world, nthreads=threads)
-        ses.sync()
-        dist.barrier()
+        ra, rb = workload.build_config4(d, mbp=1000.0 * gbp, divergence=0.01, threads=min(32, threads))
+        prep = time.time() - t
+        t = time.time()
+        M = D.Multi(ra, rb, devices=devs, nthreads=threads)
         opened = time.time() - t
         out = os.path.join(d, "sharded.1aln")
-        kw = dict(out_path=out, nthreads=threads, command_line="bench.py FastGA 3 Gbp sharded", reference_threads=32)
-        times = []
-        last = None
-        for _ in range(2):                         # the first run also pays RCCL's buffers for these message sizes
-            dist.barrier(); torch.cuda.synchronize()
+        kw = dict(out_path=out, nthreads=threads, command_line="bench.py FastGA 3 Gbp over %d GPUs" % len(devs), reference_threads=32)
+        times, ranks, last = [], [], None
+        for _ in range(4):
             t = time.time()
-            last = run_sharded(ses, dist, kw, f"cuda:{local}")
-            ses.sync(); dist.barrier(); torch.cuda.synchronize()
-            tt = torch.tensor([time.time() - t], device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            times.append(float(tt.item()))
-        ses.close()
-        res = None
-        golden = None
-        if rank == 0:
-            dt = min(times)
-            res = {"workload": f"synthetic {gbp:g} Gbp vs {gbp:g} Gbp, 1% divergence, 32 contigs, 45% repeats (BASELINE configs[3]): "
-                               f"ONE comparison over {world} GPUs (prefix ranges -> all-to-all-v by A-contig part -> gather)",
-                   "n_gpus": world, "scaling": "strong", "value": gbp / dt, "unit": "Gbp-pair/s", "seconds": round(dt, 3),
-                   "seconds_runs": [round(x, 3) for x in times], "records": int(last["nlive"]),
-                   "open_sliced_sessions_s": round(opened, 2), "genomes_s": round(prep, 1),
-                   "cold": {"seconds": round(opened + dt, 2), "span": "GDBs on disk -> every rank's slice of both indices built "
-                                                                       "on its GPU -> the comparison -> .1aln closed on rank 0"}}
-            gold = os.path.join(ROOT, "tests", "golden", "config4_3000m_digest.json")
-            if os.path.exists(gold) and abs(gbp - 3.0) < 1e-9:
-                g = json.load(open(gold))
-                golden = g
-                res["records_equal_reference"] = bool(last["nlive"] == g["records"])
-                # the parity gate of the leg: header, records as a multiset, (aread, abpos) order and the record LINES in
-                # sequence against the digest the real reference's file gave (tests/golden/make_golden_config4.py)
-                try:
-                    got = file_digest(workload, out, golden_keys=True)
-                    if got is not None:
-                        res["digest_equals_reference"] = all(got[k] == g[k] for k in
-                                                              ("records", "header_md5", "records_sum128", "order_md5", "lines_md5"))
-                        res["lines_md5"] = got["lines_md5"]
-                    else:
-                        res["digest_equals_reference"] = None      # oracle/_ref/ONEview did not travel
-                except Exception as e:
-                    res["digest_error"] = str(e)
-                if g.get("reference_seconds"):
-                    res["reference_seconds"] = g["reference_seconds"]
-                    res["vs_reference_warm"] = g["reference_seconds"] / dt
-                    res["cold"]["vs_reference"] = g["reference_seconds"] / (opened + dt)
-        multi = c_abi_multi_leg(D, workload, dist, ra, rb, d, threads, rank, world, gbp, 32, golden=golden)
-        if rank == 0 and res is not None:
-            res["c_abi_multi"] = multi
+            last = M.run(**kw)
+            times.append(time.time() - t)
+            ranks.append(M.rank_stats())
+        M.close()
+        dt = min(times[1:])
+        ext = [[r["extend_kernel_ms"] for r in rs] for rs in ranks]
+        res = {"workload": f"synthetic {gbp:g} Gbp vs {gbp:g} Gbp, 1% divergence, 32 contigs, 45% repeats (BASELINE configs[3]): "
+                           f"ONE comparison over {len(devs)} GPUs (fga_multi_run: prefix ranges -> seeds by A-contig part over "
+                           f"xGMI -> phase 2 + filter by part -> one .1aln)",
+               "n_gpus": len(devs), "devices": list(devs), "scaling": "strong", "value": gbp / dt, "unit": "Gbp-pair/s",
+               "seconds": round(dt, 3), "seconds_runs": [round(x, 3) for x in times], "records": int(last["nlive"]),
+               "open_s": round(opened, 2), "genomes_s": round(prep, 1),
+               "per_rank_last_run": {k: [round(r[k], 3) for r in ranks[-1]] for k in ("phase1_s", "exchange_s", "phase2_s", "extend_kernel_ms")},
+               "part_imbalance_extend_by_run": [round(max(e) / (sum(e) / len(e)), 3) if sum(e) > 0 else None for e in ext],
+               "cold": {"seconds": round(opened + times[0], 2),
+                        "span": "GDBs on disk -> every device's slice of both indices built on it -> the first comparison -> "
+                                ".1aln closed"}}
+        gold = os.path.join(ROOT, "tests", "golden", "config4_3000m_digest.json")
+        if os.path.exists(gold) and abs(gbp - 3.0) < 1e-9:
+            g = json.load(open(gold))
+            res["records_equal_reference"] = bool(last["nlive"] == g["records"])
+            # the parity gate of the leg: header, records as a multiset, (aread, abpos) order and the record LINES in
+            # sequence against the digest the real reference's file gave (tests/golden/make_golden_config4.py)
+            try:
+                got = file_digest(workload, out, golden_keys=True)
+                if got is not None:
+                    res["digest_equals_reference"] = all(got[k] == g[k] for k in
+                                                          ("records", "header_md5", "records_sum128", "order_md5", "lines_md5"))
+                    res["lines_md5"] = got["lines_md5"]
+                else:
+                    res["digest_equals_reference"] = None      # oracle/_ref/ONEview did not travel
+            except Exception as e:
+                res["digest_error"] = str(e)
+            if g.get("reference_seconds"):
+                res["reference_seconds"] = g["reference_seconds"]
+                res["vs_reference_warm"] = g["reference_seconds"] / dt
+                res["cold"]["vs_reference"] = g["reference_seconds"] / (opened + times[0])
         return res
     finally:
-        dist.barrier()
-        if rank == 0:
-            shutil.rmtree(d, ignore_errors=True)
+        shutil.rmtree(d, ignore_errors=True)
 
 
 # What a wave step of the throughput extension costs a SIMD's vector ALU: 224 VALU wave-instructions per step (rocprofv3 PMC,

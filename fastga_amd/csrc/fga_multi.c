@@ -462,6 +462,31 @@ fail:
 
 int fga_multi_ndev(const fga_multi *M) { return M == NULL ? 0 : M->ndev; }
 
+/* what bench.py prices the merge launches with: entry bytes of both tables over all ranks' slices (N1 E1 + N2 E2), the
+   reference's seed record width, the bases of the two genomes */
+int fga_multi_info(const fga_multi *M, int64_t *table_bytes, int *seed_bytes, int64_t *bases1, int64_t *bases2)
+{ int r;
+  int64_t tb = 0;
+  if (M == NULL)
+    { fga_set_error("fga_multi_info: null argument");
+      return 1;
+    }
+  if (M->single != NULL)
+    { if (table_bytes != NULL) *table_bytes = fga_session_table_bytes(M->single);
+      if (seed_bytes != NULL) *seed_bytes = fga_session_seed_bytes(M->single);
+      if (bases1 != NULL) *bases1 = fga_session_bases(M->single,0);
+      if (bases2 != NULL) *bases2 = fga_session_bases(M->single,1);
+      return 0;
+    }
+  for (r = 0; r < M->ndev; r++)
+    tb += fga_session_table_bytes(M->R[r].Z);
+  if (table_bytes != NULL) *table_bytes = tb;
+  if (seed_bytes != NULL) *seed_bytes = fga_session_seed_bytes(M->R[0].Z);
+  if (bases1 != NULL) *bases1 = fga_session_bases(M->R[0].Z,0);
+  if (bases2 != NULL) *bases2 = fga_session_bases(M->R[0].Z,1);
+  return 0;
+}
+
 int fga_multi_run(fga_multi *M, const fga_run_params *P, fga_run_stats *S)
 { const int dev0 = fga_dev_current_device();
   fga_run_stats st;

@@ -376,6 +376,9 @@ class Multi:
         check(self.L.fga_multi_open(root1.encode(), root2.encode() if root2 else None, C.byref(prm), len(self.devices), devs,
                                     C.byref(h)), "fga_multi_open")
         self.h = h
+        tb, sb, b1, b2 = C.c_int64(), C.c_int(), C.c_int64(), C.c_int64()
+        check(self.L.fga_multi_info(h, C.byref(tb), C.byref(sb), C.byref(b1), C.byref(b2)), "fga_multi_info")
+        self.table_bytes, self.seed_bytes, self.bases = tb.value, sb.value, (b1.value, b2.value)
 
     def run(self, out_path=None, freq=10, soft_mask=False, symmetric=False, chain_break=1000, chain_min=85, align_min=100,
             identity=0.7, nthreads=8, command_line="FastGA", paf_path=None, paf_flags=0, reference_threads=0):

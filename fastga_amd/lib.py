@@ -200,6 +200,7 @@ def _declare(L):
         "fga_multi_run": (i32, [vp, P(RunParams), P(RunStats)]),
         "fga_multi_close": (None, [vp]),
         "fga_multi_ndev": (i32, [vp]),
+        "fga_multi_info": (i32, [vp, P(i64), P(i32), P(i64), P(i64)]),
         "fga_multi_rank_stats": (i32, [vp, i32, P(C.c_double), P(C.c_double), P(i64)]),
         "fga_seeds_import_peer": (i32, [vp, P(vp), P(i32), P(i64), i32, P(vp)]),
         "fga_dev_enable_peer": (i32, [vp, i32]),

@@ -470,6 +470,8 @@ int  fga_multi_open(const char *root1, const char *root2 /* NULL: self */, const
 int  fga_multi_run(fga_multi *m, const fga_run_params *prm, fga_run_stats *stats);
 void fga_multi_close(fga_multi *m);
 int  fga_multi_ndev(const fga_multi *m);
+/* N1 E1 + N2 E2 over all ranks' slices, the reference's seed record width, the bases of the two genomes */
+int  fga_multi_info(const fga_multi *m, int64_t *table_bytes, int *seed_bytes, int64_t *bases1, int64_t *bases2);
 /* figures of one rank in the last run: seconds of phase 1 / exchange / phase 2 (with its filter), its extension kernel's
    ms and wave steps */
 int  fga_multi_rank_stats(const fga_multi *m, int rank, double *seconds3, double *extend_kernel_ms, int64_t *wave_steps);
