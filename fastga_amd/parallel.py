@@ -214,10 +214,13 @@ def prefix_cuts(ses, nshards):
     return cuts
 
 
-def run_parts_on_one_gpu(ses, nparts, **prm_kwargs):
+def run_parts_on_one_gpu(ses, nparts, weights=None, **prm_kwargs):
     """The sharded run's C-ABI calls on ONE GPU, rank by rank in sequence (merge of each prefix range, histogram,
     partition, split, import of each part's pieces, align, finish over all parts): the parity check of the multi-GPU
-    path for any number of parts.  The staging buffers come from fga_dev_malloc (no torch in this process)."""
+    path for any number of parts.  The staging buffers come from fga_dev_malloc (no torch in this process).
+    weights: what the contigs are dealt to the parts by (per A contig, index order) -- None: the seed counts, as the first run of
+    a fga_multi session does; the `contig_waves` a previous call returned: the wave steps of every contig's units, as the
+    session's later runs do."""
     import time
     prm = ses.params(**prm_kwargs)
     st = ses.new_stats()
@@ -237,7 +240,8 @@ def run_parts_on_one_gpu(ses, nparts, **prm_kwargs):
         # buffers alive side by side, so late ranks may have to ask the driver for a fresh region (a real rank never does)
         per_rank["merge_driver_alloc_s"].append(ses.L.fga_dev_driver_seconds() - w)
         merged.append((seeds, ses.dev_malloc(16 * seeds.count)))
-    select = partition_contigs(hist, nparts)
+    select = partition_contigs(hist if weights is None else np.asarray(weights, dtype=np.int64), nparts)
+    contig_waves = np.zeros(ses.nctg, dtype=np.int64)
     for seeds, buf in merged:
         t = time.time()
         offs.append(ses.split_to(seeds, select, nparts, buf))
@@ -252,6 +256,8 @@ def run_parts_on_one_gpu(ses, nparts, **prm_kwargs):
         part = ses.import_seeds(pieces)
         raw = ses.align(prm, st, part)
         per_rank["align_s"].append(time.time() - t)
+        if raw.contents.ctg_waves and raw.contents.nctg_waves == ses.nctg:     # wave steps per A contig of this part's units
+            contig_waves += np.frombuffer((C.c_int64 * ses.nctg).from_address(raw.contents.ctg_waves), dtype=np.int64)
         after = ses.stats_dict(st)
         for k in ("sort_s", "chain_s", "extend_s", "extend_kernel_ms"):
             per_rank[k].append(after[k] - before[k])
@@ -276,4 +282,5 @@ def run_parts_on_one_gpu(ses, nparts, **prm_kwargs):
     d["sent_bytes"] = [[16 * int(offs[r][p + 1] - offs[r][p]) for p in range(nparts)] for r in range(nparts)]   # [from][to]
     d["gather_bytes"] = gather_bytes
     d["finish_s"] = finish_s
+    d["contig_waves"] = contig_waves
     return d
