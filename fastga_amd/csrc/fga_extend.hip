@@ -568,8 +568,8 @@ extern "C" int fga_extend(fga_dev *dev, const fga_dgenome *GA, const fga_dgenome
       if (R->naln > aln_cap)  aln_cap = R->naln + R->naln/8 + 1024;
       if (R->ntrace > tb_cap) tb_cap = R->ntrace + R->ntrace/8 + (1 << 20);
     }
-  R->alns = (fga_aln *) malloc(sizeof(fga_aln)*(R->naln+1));
-  R->tbytes = (uint8_t *) malloc(R->ntrace+16);
+  R->alns = (fga_aln *) fga_big_malloc(sizeof(fga_aln)*(R->naln+1));       // (kept between comparisons: fga_hbuf.c)
+  R->tbytes = (uint8_t *) fga_big_malloc(R->ntrace+16);
   R->ctg_waves = (int64_t *) malloc(sizeof(int64_t)*(size_t) ncw);
   R->nctg_waves = GA->nperm;
   if (R->alns == NULL || R->tbytes == NULL || R->ctg_waves == NULL)
@@ -622,7 +622,7 @@ fail:
   fga_pool_free(d_units); fga_pool_free(d_hits); fga_pool_free(d_order); fga_pool_free(d_wide); fga_pool_free(d_next); fga_pool_free(d_tab); fga_pool_free(d_cnt); fga_pool_free(d_cw); fga_pool_free(d_lists);
   fga_dev_release(dev,SLOT_CELLS,A.pool);
   fga_dev_release(dev,SLOT_ALNS,A.alns); fga_dev_release(dev,SLOT_TBYTES,A.tbytes);
-  free(R->alns); free(R->tbytes); free(R);
+  fga_big_free(R->alns); fga_big_free(R->tbytes); free(R->ctg_waves); free(R);
   return 1;
 }
 

@@ -9,6 +9,7 @@
 
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -116,6 +117,20 @@ void   fga_dev_restore_device(int device);         /* ... and back to it (an ent
 
 void   fga_aln_writer_threads(int n);              /* threads of the .1aln record formatters, for the calling thread (default 8) */
 void   fga_note(const char *what, double since);   /* FGA_TIMING=1: elapsed wall time since `since` on stderr */
+
+/* the library's large host arrays are kept between comparisons (fga_hbuf.c): blocks of 4 MB and more come from a cache of
+   their own and go back to it; everything else is plain malloc / free.  The C sources reach it through these macros */
+void  *fga_big_malloc(size_t n);
+void  *fga_big_calloc(size_t n, size_t m);
+void  *fga_big_realloc(void *p, size_t n);
+void   fga_big_free(void *p);
+void   fga_host_cache_trim(void);                  /* the parked blocks back to the system */
+#if !defined(FGA_NO_MALLOC_MACROS) && !defined(__cplusplus)
+#define malloc(n)     fga_big_malloc(n)
+#define calloc(n,m)   fga_big_calloc(n,m)
+#define realloc(p,n)  fga_big_realloc(p,n)
+#define free(p)       fga_big_free(p)
+#endif
 
 /* small helpers */
 char *fga_path_dir(const char *path);                       /* malloc'd directory part ("." if none) */
