@@ -329,43 +329,99 @@ __device__ __forceinline__ void match_rounds(const merge_args &A, const uint64_t
   if (__builtin_amdgcn_ballot_w64(kb[0] + kc[0] + bd[0] + bu[0] == 0x1234567) != 0) tsum += 1;     // the reads have landed
 #endif
   XPROF(9)
+  // The run of every entry, grown on the table's own lcp bytes (lcpB[x] = what entry x shares with entry x-1) as the reference
+  // grows it one entry at a time -- down while low > panel start, the run spans at most freq + 1 entries below the lower bound
+  // and the next byte reaches plen; then up likewise.  The first step of either direction is decided on the bytes read above;
+  // the rest takes EIGHT lcp bytes per LDS read (one unaligned ds_read_b64, the bytes compared side by side), all rounds'
+  // reads in flight together: a tile pays two or three dependent LDS round trips for its longest run instead of one per
+  // member and round (the entries of repeat families -- every tile has some -- grow to the cutoff: 11 steps either way).
   total = 0;
+  int low[NR], hgh[NR], lbnd[NR], plen[NR], ei[NR];
+  bool ok[NR], cd[NR], cu[NR];
+  bool anyd = false;
   #pragma unroll
   for (int r = 0; r < NR; r++)
     { const int c = r*64 + lane;
       const bool act = c < na;
-      const int i = (MODE == MODE_SELF) ? base[r] : c;
-      int low, hgh, lbnd;
-      if (MODE == MODE_SELF) { low = i; hgh = i+1; lbnd = i; }
-      else                   { low = hgh = lbnd = base[r]; }
+      ei[r] = (MODE == MODE_SELF) ? base[r] : c;
+      if (MODE == MODE_SELF) { low[r] = ei[r]; hgh[r] = ei[r]+1; lbnd[r] = ei[r]; }
+      else                   { low[r] = hgh[r] = lbnd[r] = base[r]; }
       const bool hasb = nb[r] >= pb0[r], hasa = na_[r] < pb1[r];
       const int lkb = hasb ? lcp_key(ks[r],kb[r]) : 0, lka = hasa ? lcp_key(ks[r],kc[r]) : 0;
-      const int plen = lkb > lka ? lkb : lka;                      // 0: no T2 entry of this panel next to the key
-      const bool ok = act && plen >= 12;
-      // run growth on the table's own lcp bytes; the first step of either direction is decided on the bytes read above
-      const bool gd = ok && lkb >= plen;
-      low -= gd ? 1 : 0;
-      if (gd && low > pb0[r] && lbnd-low <= freq && bd[r] >= plen)
-        { low -= 1;
-          while (low > pb0[r] && lbnd-low <= freq && (int) lcpB[low] >= plen)
-            low -= 1;
+      plen[r] = lkb > lka ? lkb : lka;                      // 0: no T2 entry of this panel next to the key
+      ok[r] = act && plen[r] >= 12;
+      const bool gd = ok[r] && lkb >= plen[r];
+      low[r] -= gd ? 1 : 0;
+      cd[r] = gd && low[r] > pb0[r] && lbnd[r]-low[r] <= freq && bd[r] >= plen[r];
+      low[r] -= cd[r] ? 1 : 0;
+      cu[r] = ok[r] && lka >= plen[r];                      // (the upward growth's first test; completed below, with the final low)
+      anyd = anyd || cd[r];
+    }
+  while (__builtin_amdgcn_ballot_w64(anyd) != 0)
+    { uint64_t w[NR];
+      #pragma unroll
+      for (int r = 0; r < NR; r++)
+        __builtin_memcpy(&w[r],lcpB + (cd[r] ? low[r] : 7) - 7,8);          // bytes low-7 .. low: the top byte is lcpB[low]
+      anyd = false;
+      #pragma unroll
+      for (int r = 0; r < NR; r++)
+        { const uint32_t k = (uint32_t) plen[r] * 0x01010101u;
+          const uint32_t nl = ((((uint32_t) w[r] | 0x80808080u) - k) & 0x80808080u) ^ 0x80808080u;             // 0x80 where a byte is below plen
+          const uint32_t nh = ((((uint32_t) (w[r] >> 32) | 0x80808080u) - k) & 0x80808080u) ^ 0x80808080u;
+          const int t = nh ? (__builtin_clz(nh) >> 3) : 4 + (nl ? (__builtin_clz(nl) >> 3) : 4);
+          int lim = low[r] - pb0[r];
+          const int l2 = freq + 1 - (lbnd[r] - low[r]);
+          lim = lim < l2 ? lim : l2;
+          int st = t < lim ? t : lim;
+          st = (cd[r] && st > 0) ? st : 0;
+          low[r] -= st;
+          cd[r] = st == 8;
+          anyd = anyd || cd[r];
         }
-      const bool gu = ok && lka >= plen && hgh < pb1[r] && hgh-low <= freq;
-      hgh += gu ? 1 : 0;
-      if (gu && hgh < pb1[r] && hgh-low <= freq && bu[r] >= plen)
-        { hgh += 1;
-          while (hgh < pb1[r] && hgh-low <= freq && (int) lcpB[hgh] >= plen)
-            hgh += 1;
+    }
+  bool anyu = false;
+  #pragma unroll
+  for (int r = 0; r < NR; r++)
+    { const bool gu = cu[r] && hgh[r] < pb1[r] && hgh[r]-low[r] <= freq;
+      hgh[r] += gu ? 1 : 0;
+      cu[r] = gu && hgh[r] < pb1[r] && hgh[r]-low[r] <= freq && bu[r] >= plen[r];
+      hgh[r] += cu[r] ? 1 : 0;
+      anyu = anyu || cu[r];
+    }
+  while (__builtin_amdgcn_ballot_w64(anyu) != 0)
+    { uint64_t w[NR];
+      #pragma unroll
+      for (int r = 0; r < NR; r++)
+        __builtin_memcpy(&w[r],lcpB + (cu[r] ? hgh[r] : 0),8);              // bytes hgh .. hgh+7
+      anyu = false;
+      #pragma unroll
+      for (int r = 0; r < NR; r++)
+        { const uint32_t k = (uint32_t) plen[r] * 0x01010101u;
+          const uint32_t nl = ((((uint32_t) w[r] | 0x80808080u) - k) & 0x80808080u) ^ 0x80808080u;
+          const uint32_t nh = ((((uint32_t) (w[r] >> 32) | 0x80808080u) - k) & 0x80808080u) ^ 0x80808080u;
+          const int t = nl ? (__builtin_ctz(nl) >> 3) : 4 + (nh ? (__builtin_ctz(nh) >> 3) : 4);
+          int lim = pb1[r] - hgh[r];
+          const int l2 = freq + 1 - (hgh[r] - low[r]);
+          lim = lim < l2 ? lim : l2;
+          int st = t < lim ? t : lim;
+          st = (cu[r] && st > 0) ? st : 0;
+          hgh[r] += st;
+          cu[r] = st == 8;
+          anyu = anyu || cu[r];
         }
-      const int mlen = A.soft_mask ? plen : 41;
-      bool pass = ok && hgh-low < freq;
+    }
+  #pragma unroll
+  for (int r = 0; r < NR; r++)
+    { const int i = ei[r];
+      const int mlen = A.soft_mask ? plen[r] : 41;
+      bool pass = ok[r] && hgh[r]-low[r] < freq;
       if (A.soft_mask)
         pass = pass && (int) (MODE == MODE_SELF ? mB[i] : mA[i]) < mlen;
       int cnt;
       if (MODE == MODE_FLIP || A.soft_mask)
         { cnt = 0;
           if (pass)
-            for (int j = low; j < hgh; j++)
+            for (int j = low[r]; j < hgh[r]; j++)
               { if (A.soft_mask && (int) mB[j] >= mlen)
                   continue;
                 if (MODE == MODE_FLIP && (lds_c(cB,A.cw2,j) & A.sign2))
@@ -376,11 +432,11 @@ __device__ __forceinline__ void match_rounds(const merge_args &A, const uint64_t
               }
         }
       else
-        cnt = pass ? (hgh-low) - (MODE == MODE_SELF ? 1 : 0) : 0;
-      res[r] = (pass && cnt > 0) ? res_fmt<T2CAP,MODE != MODE_PAIR>::pack(MODE == MODE_SELF ? i - low : i,low,plen,cnt,
-                                                        cnt != (hgh-low) - (MODE == MODE_SELF ? 1 : 0)) : 0;
+        cnt = pass ? (hgh[r]-low[r]) - (MODE == MODE_SELF ? 1 : 0) : 0;
+      res[r] = (pass && cnt > 0) ? res_fmt<T2CAP,MODE != MODE_PAIR>::pack(MODE == MODE_SELF ? i - low[r] : i,low[r],plen[r],cnt,
+                                                        cnt != (hgh[r]-low[r]) - (MODE == MODE_SELF ? 1 : 0)) : 0;
       total += cnt;
-      tsum += (unsigned long long) cnt * plen;
+      tsum += (unsigned long long) cnt * plen[r];
     }
   XPROF(10)
   // lower bound of the last consumed entry (entry na-1: round (na-1) >> 6, lane (na-1) & 63)
@@ -485,11 +541,33 @@ __device__ __forceinline__ int walk_tile(const merge_args &A, tile_lds<T2CAP> &S
   }
 
   XPROF(4)
-  // 4. slots and emission
-  int T;
-  int off = wave_excl_scan_add_dpp(total,T);
+  // 4. slots and emission.  Most table-1 entries with seeds have exactly ONE (a k-mer met once in the other genome): such an
+  // entry writes its seed itself -- its own position and contig word, its run's first member: four LDS reads and the store --
+  // into the first `T1` slots of the tile's stretch (one per entry, in entry order); only the seeds of the other entries (runs of
+  // several members, or runs in which mask bytes / strands / the entry itself drop members) go through the slot windows below
+  const bool plain = (MODE != MODE_FLIP) && !A.soft_mask;
+  int T, T1, off1, off;
+  typename RF::word resm[4];
+  { int n1s = 0, nm = 0;
+    #pragma unroll
+    for (int r = 0; r < 4; r++)
+      { const int cnt = RF::cnt(res[r]);
+        const bool single = cnt == 1 && (plain || !RF::dirty(res[r]));
+        n1s += single ? 1 : 0;
+        nm  += single ? 0 : cnt;
+        resm[r] = single ? (typename RF::word) 0 : res[r];
+      }
+    if (RF::BIG)
+      { off1 = wave_excl_scan_add_dpp(n1s,T1); off = wave_excl_scan_add_dpp(nm,T); }
+    else                                 // (counts below 256: 64 lanes x 4 entries fit 16 bits) both sums in one scan
+      { int tt;
+        const int o = wave_excl_scan_add_dpp(nm | (n1s << 16),tt);
+        off = o & 0xffff; off1 = o >> 16; T = tt & 0xffff; T1 = tt >> 16;
+      }
+    T += T1;                             // slots of the tile: [0, T1) the single seeds, [T1, T) the others
+  }
 #ifdef MERGE_NO_EMIT                    // timing experiment: matched, not emitted
-  O.tsum += T; T = 0;
+  O.tsum += T; T = 0; T1 = 0;
 #endif
   if (T > 0)
     { const int64_t rem = O.chunk_end - O.chunk_pos;
@@ -503,26 +581,53 @@ __device__ __forceinline__ int walk_tile(const merge_args &A, tile_lds<T2CAP> &S
           const uint32_t bhi = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (bb >> 32));
           nbase = (int64_t) (((uint64_t) bhi << 32) | blo);
         }
-      // Seed-parallel, in windows of EWIN slots: every entry with seeds in the window leaves a descriptor at its first
-      // slot there -- i | low << 8 | plen << 18 | (seeds of its run before the window) << 24 -- and a wave max-scan over
+      XPROF(11)
+      if (T1 > 0)                        // the single seeds, entry-parallel
+        { int o1 = off1;
+          #pragma unroll
+          for (int r = 0; r < 4; r++)
+            { const typename RF::word d = res[r];
+              if (RF::cnt(d) == 1 && (plain || !RF::dirty(d)))
+                { const int plen = RF::plen(d);
+                  int j = RF::low(d);
+                  const int i = RF::i(d) + (MODE == MODE_SELF ? j : 0);               // self: stored relative to the run's start
+                  if (MODE == MODE_SELF && j >= i)
+                    j += 1;
+                  const uint32_t spos = (MODE == MODE_SELF) ? pB[i] : pA[i];
+                  const uint32_t sc = (MODE == MODE_SELF) ? lds_c(cB,cw2,i) : lds_c(cA,cw1,i);
+                  const uint32_t cpos = pB[j], cc = lds_c(cB,cw2,j);
+                  const uint32_t ssign = (sc & A.sign1) != 0, csign = (cc & A.sign2) != 0;
+                  const int64_t gs = (int64_t) o1;
+                  const int64_t at = (gs < rem) ? O.chunk_pos + gs : nbase + (gs - rem);
+#ifdef MERGE_NO_STORE
+                  if (at < A.cap && spos + cpos + sc + cc + ssign + csign + plen == 0xfffffff7u)
+#else
+                  if (at < A.cap)
+#endif
+                    A.out[at] = make_seed<MODE>(plen,spos,sc & (A.sign1-1),ssign,cpos,cc & (A.sign2-1),csign);
+                  o1 += 1;
+                }
+            }
+        }
+      // The other seeds, seed-parallel in windows of EWIN slots: every entry with seeds in the window leaves a descriptor at its
+      // first slot there -- i | low << 8 | plen << 18 | (seeds of its run before the window) << 24 -- and a wave max-scan over
       // "slot+1 where a descriptor sits" tells every slot where its entry's run begins.  The lane of a slot then finds its
       // partner: the k-th T2 entry of the run, or, where mask bytes / strands / the entry itself drop members of the run,
       // the k-th one that stays.
-      const bool plain = (MODE != MODE_FLIP) && !A.soft_mask;
-      XPROF(11)
+      const int Tm = T - T1;
       WSYNC();                                                   // the match's key reads are done: the array becomes the window
-      for (int wb = 0; wb < T; wb += EWIN)
-        { const int wn = T - wb < EWIN ? T - wb : EWIN;          // slots of this window
+      for (int wb = 0; wb < Tm; wb += EWIN)
+        { const int wn = Tm - wb < EWIN ? Tm - wb : EWIN;        // slots of this window
           for (int x = lane; (int) (16/sizeof(typename RF::word))*x < wn; x += 64)
             ((uint4 *) ownd)[x] = make_uint4(0,0,0,0);
           WSYNC();
           { int o = off;
             #pragma unroll
             for (int r = 0; r < 4; r++)
-              { const int cnt = RF::cnt(res[r]);
+              { const int cnt = RF::cnt(resm[r]);
                 if (cnt > 0 && o + cnt > wb && o < wb + EWIN)
                   { const int before = o < wb ? wb - o : 0;
-                    ownd[o + before - wb] = RF::body(res[r]) | ((typename RF::word) (uint32_t) before << RF::CNT_SH);
+                    ownd[o + before - wb] = RF::body(resm[r]) | ((typename RF::word) (uint32_t) before << RF::CNT_SH);
                   }
                 o += cnt;
               }
@@ -566,7 +671,7 @@ __device__ __forceinline__ int walk_tile(const merge_args &A, tile_lds<T2CAP> &S
                   const uint32_t sc = (MODE == MODE_SELF) ? lds_c(cB,cw2,i) : lds_c(cA,cw1,i);
                   const uint32_t cpos = pB[j], cc = lds_c(cB,cw2,j);
                   const uint32_t ssign = (sc & A.sign1) != 0, csign = (cc & A.sign2) != 0;
-                  const int64_t gs = (int64_t) wb + slot;
+                  const int64_t gs = (int64_t) T1 + wb + slot;
                   const int64_t at = (gs < rem) ? O.chunk_pos + gs : nbase + (gs - rem);
 #ifdef MERGE_NO_STORE                   // timing experiment: everything but the seed stores (the test keeps the operands alive)
                   if (at < A.cap && spos + cpos + sc + cc + ssign + csign + plen == 0xfffffff7u)
