@@ -418,7 +418,25 @@ __device__ __forceinline__ void match_rounds(const merge_args &A, const uint64_t
       if (A.soft_mask)
         pass = pass && (int) (MODE == MODE_SELF ? mB[i] : mA[i]) < mlen;
       int cnt;
-      if (MODE == MODE_FLIP || A.soft_mask)
+      if (MODE != MODE_FLIP && A.soft_mask)
+        { // members whose mask byte is below mlen, eight bytes per LDS read (the entry itself, whose byte `pass` has tested,
+          // is among them in a self comparison)
+          cnt = 0;
+          if (pass)
+            { const uint32_t k = (uint32_t) mlen * 0x01010101u;
+              for (int j = low[r]; j < hgh[r]; j += 8)
+                { uint64_t w;
+                  __builtin_memcpy(&w,mB + j,8);
+                  const int n = hgh[r] - j < 8 ? hgh[r] - j : 8;
+                  const uint64_t keep = n < 8 ? ((1ull << (8*n)) - 1ull) : ~0ull;
+                  const uint32_t bl = ((((uint32_t) w | 0x80808080u) - k) & 0x80808080u) ^ 0x80808080u;           // 0x80 where a byte is below mlen
+                  const uint32_t bh = ((((uint32_t) (w >> 32) | 0x80808080u) - k) & 0x80808080u) ^ 0x80808080u;
+                  cnt += __popc(bl & (uint32_t) keep) + __popc(bh & (uint32_t) (keep >> 32));
+                }
+              cnt -= (MODE == MODE_SELF) ? 1 : 0;
+            }
+        }
+      else if (MODE == MODE_FLIP)
         { cnt = 0;
           if (pass)
             for (int j = low[r]; j < hgh[r]; j++)
