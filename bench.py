@@ -535,13 +535,13 @@ def multi_human_scale(D, workload, workdir, threads, devs):
         shutil.rmtree(d, ignore_errors=True)
 
 
-# What a wave step of the throughput extension costs a SIMD's vector ALU: 224 VALU wave-instructions per step (rocprofv3 PMC,
-# profiles/r05_throughput_pmc_summary.csv), of which on the common path of ext_mid::ext_episode1 60 are of the kinds gfx950
-# issues in 2.2 cycles (v_add / v_sub / v_and / v_or / v_xor / v_mov on VGPRs or a literal) and 164 of the kinds that take 4.1
-# (selects, compares, shifts, min / max, DPP, SDWA, three-operand forms, anything with an SGPR operand) -- measured per kind by
-# tools/ubench/valu_rate.hip, profiles/r05_valu_issue_rates.txt; the chip has 1024 SIMDs at 2.4 GHz
-EXT_VALU_PER_STEP = 224.0
-EXT_VALU_CYCLES_PER_STEP = 60 * 2.2 + 164 * 4.1
+# What a wave step of the throughput extension costs a SIMD's vector ALU (rocprofv3 PMC of round 6 over the 150 Mbp self
+# comparison, profiles/r06_throughput_pmc_summary.csv, 5.65e8 wave steps per launch): 128 VALU wave-instructions per step (round 5:
+# 224) that keep the vector ALU busy for SQ_ACTIVE_INST_VALU = 134.6 quad-cycles = 538 cycles (4.2 per instruction: selects, compares,
+# shifts, lane moves and anything with an SGPR operand take four cycles, plain two-operand integer ops two --
+# profiles/r05_valu_issue_rates.txt); beside them 138 SALU, 12 LDS, 2 SMEM and 25 branch instructions.  The chip has 1024 SIMDs at 2.4 GHz
+EXT_VALU_PER_STEP = 128.0
+EXT_VALU_CYCLES_PER_STEP = 538.0
 SIMD_CYCLES_PER_S = 1024 * 2.4e9
 XGMI_LINK_GBS = 153.0          # one xGMI link (point to point, 7 per GPU): MI355X_MICROARCH.md
 
@@ -560,14 +560,14 @@ def extend_block(st):
     k = st["extend_kernel_ms"]
     if not k:
         return None
-    return {"kernel": "ext_mid::extend_kernel (throughput regime: sixteen wavefronts per CU, issue-bound)", "bound": "valu issue",
+    return {"kernel": "ext_mid::extend_kernel (throughput regime: twenty wavefronts per CU, issue-bound)", "bound": "valu + scalar issue",
             "kernel_ms": round(k, 1), "wave_steps": int(st["nwaves"]), "wave_steps_per_s": st["nwaves"] / (k * 1e-3),
             "avg_wave_width": st["ext_cells"] / max(1, st["nwaves"]),
             "valu_issue_frac_est": st["nwaves"] * EXT_VALU_CYCLES_PER_STEP / (k * 1e-3) / SIMD_CYCLES_PER_S,
             "note": f"{EXT_VALU_PER_STEP:g} VALU wave-instructions per step (PMC) = {EXT_VALU_CYCLES_PER_STEP:.0f} cycles of a SIMD's vector "
-                    f"ALU at the issue cost of each kind (profiles/r05_valu_issue_rates.txt) x steps / kernel time / "
-                    f"{SIMD_CYCLES_PER_S:.3g} SIMD cycles per s; PMC: SQ_ACTIVE_INST_VALU = 24 % of the wave cycles with four "
-                    f"wavefronts per SIMD (profiles/r05_throughput_pmc_summary.csv)"}
+                    f"ALU x steps / kernel time / {SIMD_CYCLES_PER_S:.3g} SIMD cycles per s at the nominal 2.4 GHz; PMC: SQ_ACTIVE_INST_VALU = "
+                    f"16 % of the wave cycles with five wavefronts per SIMD = 0.8 busy, the scalar unit ~ 0.7 "
+                    f"(profiles/r06_throughput_pmc_summary.csv)"}
 
 
 def project_8gpu(st8, nparts):
