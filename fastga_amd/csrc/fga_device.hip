@@ -120,10 +120,12 @@ hipError_t fga_memset_here(void *ptr, int value, size_t bytes)
 #include <unordered_map>
 struct pool_owner { hipStream_t stream; bool have; int klass; };       // klass >= 0: a small buffer of 256 << klass bytes
 #define SMALL_CLASSES 13                                                // 256 B .. 1 MiB
+#include <unordered_set>
 struct small_state
   { std::unordered_map<void *,pool_owner> owner;                        // every live allocation of the device
     std::vector<void *> idle[SMALL_CLASSES];
-  };
+    std::unordered_set<void *> parked;                                  // the small buffers in the idle lists: a SECOND release of one of
+  };                                                                    //   them is ignored (it must never reach hipFree: the list still holds it)
 static small_state g_small[POOL_MAXDEV];
 
 static void wait_for_owner(const pool_owner &o, int owner_dev)
@@ -157,6 +159,7 @@ hipError_t fga_pool_malloc(void **out, size_t bytes)
         if (!Q->idle[k].empty())
           { *out = Q->idle[k].back();
             Q->idle[k].pop_back();
+            Q->parked.erase(*out);
             Q->owner[*out] = o;
             return hipSuccess;
           }
@@ -198,13 +201,19 @@ hipError_t fga_pool_free(void *ptr)
       wait_for_owner(o,d == here ? -1 : d);
       lock.lock();
       if (o.klass >= 0)
-        Q->idle[o.klass].push_back(ptr);
+        { Q->idle[o.klass].push_back(ptr); Q->parked.insert(ptr); }
       else
         P->core.give(ptr);
       return hipSuccess;
     }
-  // not an allocation of this library (or released before): the driver's to judge, and its verdict stays out of the
-  // sticky error state that the stages' hipGetLastError() checks read
+  // released before?  A small buffer that sits in an idle list is not the driver's to free
+  for (int d = 0; d < POOL_MAXDEV; d++)
+    { std::lock_guard<std::mutex> lock(g_pool[d].mu);
+      if (g_small[d].parked.count(ptr) != 0)
+        return hipSuccess;
+    }
+  // not an allocation of this library: the driver's to judge, and its verdict stays out of the sticky error state that the
+  // stages' hipGetLastError() checks read
   const hipError_t e = hipFree(ptr);
   if (e != hipSuccess)
     (void) hipGetLastError();
@@ -220,6 +229,7 @@ static void small_trim(int d)
       { gone.insert(gone.end(),g_small[d].idle[k].begin(),g_small[d].idle[k].end());
         g_small[d].idle[k].clear();
       }
+    g_small[d].parked.clear();
   }
   for (void *p : gone)
     hipFree(p);

@@ -59,10 +59,32 @@ struct fga_view
     uint8_t  *M;          // soft-mask byte
     uint32_t *P;          // position inside the contig
     void     *C;          // contig | sign, cw bytes each
-    uint32_t *idx;        // [2^24] inclusive cumulative entry count per 12-mer prefix
+    uint32_t *idx;        // [2^24] inclusive cumulative entry count per 12-mer prefix: its LOW 32 bits
     int64_t   n;
     int       cw;         // 1, 2 or 4
-  };
+    uint32_t  car[4];     // car[k] = the first prefix whose cumulative count reaches (k+1) * 2^32 (2^24: none): the high part of
+                          //   an absolute count is the number of car[] <= p.  Differences inside a tile are plain u32 arithmetic
+    uint64_t  gen;        // a number no other view of this process has (fga_view_alloc): what caches key on -- the pool hands
+  };                      //   addresses out again
+
+// the carries of a view by value (kernel arguments), and the absolute count of the prefixes <= p (p = -1: 0)
+struct fga_car { uint32_t c[4]; };
+static inline fga_car fga_view_car(const fga_view &V) { fga_car r; for (int k = 0; k < 4; k++) r.c[k] = V.car[k]; return r; }
+#ifdef __HIPCC__
+__device__ __forceinline__ int64_t fga_idx_abs(const uint32_t *idx, const fga_car &car, int64_t p)
+{ if (p < 0) return 0;
+  const uint32_t q = (uint32_t) p;
+  const int64_t hi = (q >= car.c[0]) + (q >= car.c[1]) + (q >= car.c[2]) + (q >= car.c[3]);
+  return (hi << 32) | (int64_t) idx[p];
+}
+#endif
+static inline int64_t fga_idx_hi(const fga_view &V, int64_t p)      // the high part alone (host: the low word is on the device)
+{ if (p < 0) return 0;
+  int64_t hi = 0;
+  for (int k = 0; k < 4; k++) hi += ((uint32_t) p >= V.car[k]);
+  return hi << 32;
+}
+int fga_view_set_carries(fga_dev *dev, const int64_t *idx64_device, fga_view *V);   // V->car from the table's 64-bit index
 
 // device-resident genome index: the prefix index and the field arrays of the table (the on-disk bytes themselves only
 // while the view is being made)
@@ -77,7 +99,7 @@ struct fga_dgix
     fga_view  fview;      // forward-strand entries only (made on first use as table 1 of a pair comparison)
     // the range cuts of the last merge launch with this table as table 1 (fga_merge.hip): a session repeats the same
     // comparison, and the cuts depend on the two prefix indices, the prefix range and the launch geometry only
-    struct { const void *idx1, *idx2; int pbeg, pend, nranges, nbig; int64_t base, total; int64_t *cuts; } cutc;
+    struct { uint64_t gen1, gen2; int pbeg, pend, nranges, nbig; int64_t base, total; int64_t *cuts; } cutc;
   };
 int  fga_dgix_make_view(fga_dev *dev, fga_dgix *D, int keep_table);
 int  fga_view_alloc(fga_view *V, int64_t n, int cont, int want_l);       // the field arrays of n entries (+ read slack), defined

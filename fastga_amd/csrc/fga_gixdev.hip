@@ -440,11 +440,19 @@ struct gix_entries_args
   };
 
 template <bool TO_VIEW>
+__device__ __forceinline__ void gix_entry_one(const gix_entries_args &A, const int64_t i);
+
+// one entry per thread and turn (a dispatch holds at most 2^32 work-items: a table of more entries takes several turns)
+template <bool TO_VIEW>
 __global__ __launch_bounds__(256)
 void gix_entries_kernel(gix_entries_args A)
-{ const int64_t i = (int64_t) blockIdx.x*blockDim.x + threadIdx.x;
-  if (i >= A.n)
-    return;
+{ for (int64_t i = (int64_t) blockIdx.x*blockDim.x + threadIdx.x; i < A.n; i += (int64_t) gridDim.x*blockDim.x)
+    gix_entry_one<TO_VIEW>(A,i);
+}
+
+template <bool TO_VIEW>
+__device__ __forceinline__ void gix_entry_one(const gix_entries_args &A, const int64_t i)
+{
   const uint4 k = A.keys[i];
   const uint64_t hi = ((uint64_t) k.w << 32) | k.z, lo = ((uint64_t) k.y << 32) | k.x;
   const uint32_t lo16 = (uint32_t) (lo >> 48);
@@ -693,8 +701,8 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
   // with a host copy wanted the on-disk entry bytes are made (and turned into the view afterwards, as for an uploaded table);
   // otherwise the entries go straight into the view's field arrays: 14 bytes per entry that are never allocated or written
   direct_view = !want_host_copy;
-  if (direct_view && (nkeys >= ((int64_t) 1 << 32) - 1024 || postbytes > 4))
-    { fga_set_error("genome index of %lld entries, %d position bytes: beyond what a table view holds (2^32 entries, 4 Gbp contigs)",
+  if (direct_view && (nkeys >= ((int64_t) 5 << 32) - 1024 || postbytes > 4))
+    { fga_set_error("genome index of %lld entries, %d position bytes: beyond what a table view holds (5 x 2^32 entries, 4 Gbp contigs)",
                     (long long) nkeys,postbytes);
       goto done;
     }
@@ -808,10 +816,11 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
           hipStreamSynchronize(dev->stream);
           E.moff = dmoff; E.mbeg = dmbeg; E.mend = dmend; E.perm = dperm;
         }
+      const unsigned egrid = (unsigned) (((nkeys + 255)/256) < (int64_t) (1 << 23) ? ((nkeys + 255)/256) : (int64_t) (1 << 23));
       if (direct_view)
-        hipLaunchKernelGGL(gix_entries_kernel<true>,dim3((unsigned) ((nkeys + 255)/256)),dim3(256),0,dev->stream,E);
+        hipLaunchKernelGGL(gix_entries_kernel<true>,dim3(egrid),dim3(256),0,dev->stream,E);
       else
-        hipLaunchKernelGGL(gix_entries_kernel<false>,dim3((unsigned) ((nkeys + 255)/256)),dim3(256),0,dev->stream,E);
+        hipLaunchKernelGGL(gix_entries_kernel<false>,dim3(egrid),dim3(256),0,dev->stream,E);
     }
   if (direct_view)
     hipLaunchKernelGGL(gix_view_index_kernel,dim3(FGA_NPREFIX/256),dim3(256),0,dev->stream,D->index,D->view.idx);
@@ -825,6 +834,8 @@ static int dgix_build_impl(fga_dev *dev, const fga_gdb *G, int nthreads, int fla
     hipEventElapsedTime(&ms,dev->ev0,dev->ev1);
     dev->last_ms[FGA_STAGE_GIX] = ms;
     fga_note("index build: sort + index + entries",tn); tn = fga_wall();
+    if (direct_view && fga_view_set_carries(dev,D->index,&D->view))
+      goto done;
 
     X = (fga_gix *) calloc(1,sizeof(fga_gix));
     if (X == NULL) { fga_set_error("out of memory"); goto done; }

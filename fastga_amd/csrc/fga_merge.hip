@@ -74,6 +74,7 @@ struct merge_cold                     // what a wavefront needs once, at its end
 struct merge_args
   { const uint64_t *K1; const uint32_t *P1; const uint8_t *C1; const uint8_t *M1; const uint32_t *idx1;
     const uint64_t *K2; const uint32_t *P2; const uint8_t *C2; const uint8_t *M2; const uint32_t *idx2;
+    fga_car car1, car2;                 // the prefix indices hold low words: where their counts pass multiples of 2^32 (fga_device.hpp)
     const uint8_t  *L2;
     int   cw1, cw2;                   // bytes per contig|sign word
     uint32_t sign1, sign2;            // sign bit of the contig words
@@ -91,7 +92,7 @@ struct merge_args
 // pieces: its tail is one small range, not a quarter of a wavefront's share)
 // (One wavefront per cut probing 64 split points a round -- four rounds instead of a lane's 24 dependent loads -- was tried:
 // ten times the memory transactions, 50 us instead of 19.)
-__global__ void range_cut_kernel(const uint32_t *idx1, const uint32_t *idx2, int pbeg, int pend, int64_t base,
+__global__ void range_cut_kernel(const uint32_t *idx1, const uint32_t *idx2, fga_car car1, fga_car car2, int pbeg, int pend, int64_t base,
                                  int64_t total, int nranges, int nbig, int64_t *cuts)
 { const int w = blockIdx.x*blockDim.x + threadIdx.x;
   if (w > nranges)
@@ -105,7 +106,7 @@ __global__ void range_cut_kernel(const uint32_t *idx1, const uint32_t *idx2, int
       int lo = pbeg, hi = pend;
       while (lo < hi)
         { const int mid = lo + ((hi-lo) >> 1);
-          const int64_t c = (int64_t) idx1[mid] + (int64_t) idx2[mid] + 2*((int64_t) mid+1);
+          const int64_t c = fga_idx_abs(idx1,car1,mid) + fga_idx_abs(idx2,car2,mid) + 2*((int64_t) mid+1);
           if (c > target) hi = mid; else lo = mid+1;
         }
       p = lo;
@@ -765,7 +766,10 @@ void seed_merge_walk_kernel(merge_args A)
           }                                                                                                            \
       }
       IDX_ISSUE(p,0)
-      uint32_t a = p > 0 ? idx1[p-1] : 0u, b = p > 0 ? idx2[p-1] : 0u;
+      // entries before the range: absolute (the tables may hold more than 2^32: the index arrays carry the low words, the
+      // differences below are u32 arithmetic that wraps with them) -- a64 / b64 follow the low words a / b tile by tile
+      int64_t a64 = fga_idx_abs(idx1,A.car1,(int64_t) p - 1), b64 = fga_idx_abs(idx2,(MODE == MODE_SELF) ? A.car1 : A.car2,(int64_t) p - 1);
+      uint32_t a = (uint32_t) a64, b = (uint32_t) b64;
       VM_WAIT();
       XPROF(15)
       while (p < pe)
@@ -797,7 +801,7 @@ void seed_merge_walk_kernel(merge_args A)
             { a1 = (uint32_t) __builtin_amdgcn_readlane((int) ca0,adv-1); b1 = (uint32_t) __builtin_amdgcn_readlane((int) cb0,adv-1); }
           else
             { a1 = (uint32_t) __builtin_amdgcn_readlane((int) ca1,adv-65); b1 = (uint32_t) __builtin_amdgcn_readlane((int) cb1,adv-65); }
-          const int64_t n1 = (int64_t) a1 - a, n2 = (int64_t) b1 - b;
+          const int64_t n1 = (int64_t) (uint32_t) (a1 - a), n2 = (int64_t) (uint32_t) (b1 - b);
           // the entries before the tile, for the panel bounds of its keys
           if (lane == 0)
             { S.ixs[u][0][3] = a; S.ixs[u][1][3] = b; }
@@ -812,7 +816,7 @@ void seed_merge_walk_kernel(merge_args A)
           if (n1 > 0 && n2 > 0)
             { int lbl;
               if (q > 0)
-                { walk_tile<MODE,T2CAP>(A,S,cdyn,ix1,ix2,p,true,a,(int) n1,b,(int) n2,0,(int) n1,false,margin,O,lbl);
+                { walk_tile<MODE,T2CAP>(A,S,cdyn,ix1,ix2,p,true,a64,(int) n1,b64,(int) n2,0,(int) n1,false,margin,O,lbl);
                   tiled = true;
                 }
               else if (MODE == MODE_SELF)
@@ -821,15 +825,15 @@ void seed_merge_walk_kernel(merge_args A)
                   for (int64_t i0 = 0; i0 < n1; i0 += C)
                     { const int64_t i1 = i0 + C < n1 ? i0 + C : n1;
                       const int64_t s0 = i0 - margin > 0 ? i0 - margin : 0, s1 = i1 + margin < n1 ? i1 + margin : n1;
-                      walk_tile<MODE,T2CAP>(A,S,cdyn,ix1,ix2,p,false,a+s0,(int) (s1-s0),a+s0,(int) (s1-s0),(int) (i0-s0),
+                      walk_tile<MODE,T2CAP>(A,S,cdyn,ix1,ix2,p,false,a64+s0,(int) (s1-s0),a64+s0,(int) (s1-s0),(int) (i0-s0),
                                             (int) (i1-s0),false,margin,O,lbl);
                     }
                   tiled = true;
                 }
               else
                 { // one oversize panel, streamed: a window of the T2 panel, the T1 entries it can finish, move on
-                  int64_t aw = a, bw = b;
-                  const int64_t ae = a1, be = b1;
+                  int64_t aw = a64, bw = b64;
+                  const int64_t ae = a64 + n1, be = b64 + n2;
                   while (aw < ae)
                     { const int n1w = (int) (ae - aw < T1CAP ? ae - aw : T1CAP);
                       const int n2w = (int) (be - bw < T2CAP ? be - bw : T2CAP);
@@ -852,7 +856,7 @@ void seed_merge_walk_kernel(merge_args A)
             }
           if (!tiled)                                          // no tile, no wait of a tile: the index entries may be on their way
             VM_WAIT();
-          a = a1; b = b1; p = pn; u ^= 1;
+          a = a1; b = b1; a64 += n1; b64 += n2; p = pn; u ^= 1;
         }
 #undef IDX_ISSUE
     }
@@ -903,8 +907,9 @@ void seed_merge_any_kernel(merge_args A, int pbeg, int pend)
   const int freq = A.freq, cw1 = A.cw1, cw2 = A.cw2;
   unsigned long long tsum = 0;
   for (int64_t p = (int64_t) pbeg + blockIdx.x; p < pend; p += gridDim.x)
-    { const int64_t a0 = p > 0 ? idx1[p-1] : 0, a1 = idx1[p];
-      const int64_t b0 = p > 0 ? idx2[p-1] : 0, b1 = idx2[p];
+    { const fga_car &cq = (MODE == MODE_SELF) ? A.car1 : A.car2;
+      const int64_t a0 = fga_idx_abs(idx1,A.car1,p-1), a1 = fga_idx_abs(idx1,A.car1,p);
+      const int64_t b0 = fga_idx_abs(idx2,cq,p-1), b1 = fga_idx_abs(idx2,cq,p);
       if (a1 <= a0 || b1 <= b0)
         continue;
       for (int64_t ab = a0; ab < a1; ab += 64)
@@ -1066,6 +1071,7 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
   const fga_view &v1 = (mode == MODE_PAIR) ? t1->fview : t1->view, &v2 = t2->view;
   A.K1 = v1.K; A.P1 = v1.P; A.C1 = (const uint8_t *) v1.C; A.M1 = v1.M; A.idx1 = v1.idx; A.cw1 = v1.cw;
   A.K2 = v2.K; A.P2 = v2.P; A.C2 = (const uint8_t *) v2.C; A.M2 = v2.M; A.idx2 = v2.idx; A.cw2 = v2.cw; A.L2 = v2.L;
+  A.car1 = fga_view_car(v1); A.car2 = fga_view_car(v2);
   A.sign1 = 0x80u << (8*(t1->contbytes-1)); A.sign2 = 0x80u << (8*(t2->contbytes-1));
   A.freq = prm->freq; A.soft_mask = prm->soft_mask;
   // prefix range: (0,0) = everything; an empty range elsewhere is an empty shard (prefix cuts of a low-complexity input)
@@ -1079,15 +1085,21 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
   // cost at both ends of the prefix range (4 tiny D2H copies)
   uint32_t c1e = 0, c2e = 0, c1b = 0, c2b = 0;
   if (!empty)
-    { FGA_HIP(hipMemcpy(&c1e,v1.idx + (pend-1),4,hipMemcpyDeviceToHost));
-      FGA_HIP(hipMemcpy(&c2e,v2.idx + (pend-1),4,hipMemcpyDeviceToHost));
-      if (pbeg > 0)
-        { FGA_HIP(hipMemcpy(&c1b,v1.idx + (pbeg-1),4,hipMemcpyDeviceToHost));
-          FGA_HIP(hipMemcpy(&c2b,v2.idx + (pbeg-1),4,hipMemcpyDeviceToHost));
+    { hipError_t ce = hipMemcpy(&c1e,v1.idx + (pend-1),4,hipMemcpyDeviceToHost);
+      if (ce == hipSuccess) ce = hipMemcpy(&c2e,v2.idx + (pend-1),4,hipMemcpyDeviceToHost);
+      if (ce == hipSuccess && pbeg > 0) ce = hipMemcpy(&c1b,v1.idx + (pbeg-1),4,hipMemcpyDeviceToHost);
+      if (ce == hipSuccess && pbeg > 0) ce = hipMemcpy(&c2b,v2.idx + (pbeg-1),4,hipMemcpyDeviceToHost);
+      if (ce != hipSuccess)
+        { fga_set_error("fga_seed_merge: reading the prefix index failed: %s",hipGetErrorString(ce));
+          fga_dev_release(dev,SLOT_SEEDS,pre_seeds);          // (taken before the forward view was made: not to be left behind)
+          return 1;
         }
     }
-  const int64_t base = (int64_t) c1b + c2b + 2*(int64_t) pbeg;
-  const int64_t total = ((int64_t) c1e + c2e + 2*(int64_t) pend) - base;
+  // (the index arrays hold low words: the absolute counts add the carries' high parts)
+  const int64_t a1b = (int64_t) c1b + fga_idx_hi(v1,(int64_t) pbeg-1), a1e = (int64_t) c1e + fga_idx_hi(v1,(int64_t) pend-1);
+  const int64_t a2b = (int64_t) c2b + fga_idx_hi(v2,(int64_t) pbeg-1), a2e = (int64_t) c2e + fga_idx_hi(v2,(int64_t) pend-1);
+  const int64_t base = a1b + a2b + 2*(int64_t) pbeg;
+  const int64_t total = empty ? 0 : (a1e + a2e + 2*(int64_t) pend) - base;
 
   fga_dseeds *S = append;
   if (S == NULL)
@@ -1099,7 +1111,7 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
         }
       S->dev = dev;
       if (capacity <= 0)
-        capacity = (mode == MODE_PAIR ? 4 : 2)*((int64_t) c1e - c1b) + (1<<20);      // two seeds per table-1 entry (the forward view holds half)
+        capacity = (mode == MODE_PAIR ? 4 : 2)*(empty ? 0 : a1e - a1b) + (1<<20);      // two seeds per table-1 entry (the forward view holds half)
       S->capacity = capacity;
       // every wavefront of the kernel may leave up to a block unused, in this call and in a later append (-S)
       S->phys_capacity = capacity + 2*(int64_t) dev->ncu * 32 * FGA_SEED_BLOCK;
@@ -1119,9 +1131,10 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
     }
   else
     { const int64_t nb = (S->phys_capacity + FGA_SEED_BLOCK-1) / FGA_SEED_BLOCK + 2;
+      S->seeds = (fga_seed *) pre_seeds;            // (assigned first: every failure below releases it through S->seeds)
       if ((err = fga_dmalloc(&counters,CTR_WORDS*sizeof(unsigned long long))) != hipSuccess ||
-          (S->seeds = (fga_seed *) (pre_seeds != NULL ? pre_seeds
-                                                      : fga_dev_acquire(dev,SLOT_SEEDS,sizeof(fga_seed)*(size_t) S->phys_capacity))) == NULL ||
+          (S->seeds == NULL &&
+           (S->seeds = (fga_seed *) fga_dev_acquire(dev,SLOT_SEEDS,sizeof(fga_seed)*(size_t) S->phys_capacity)) == NULL) ||
           (S->valid = (uint16_t *) fga_dev_acquire(dev,SLOT_VALID,sizeof(uint16_t)*(size_t) nb)) == NULL)
         { fga_set_error("fga_seed_merge: device allocation failed: %s",hipGetErrorString(err));
           fga_pool_free(counters); fga_dev_release(dev,SLOT_SEEDS,S->seeds); free(S);
@@ -1200,8 +1213,8 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
       // repeats its comparison): they stay with table 1 until its views go (FGA_MERGE_CUT_CACHE=0: cut anew every time)
       fga_dgix *own = (fga_dgix *) t1;
       static const int cache_on = getenv("FGA_MERGE_CUT_CACHE") == NULL || atoi(getenv("FGA_MERGE_CUT_CACHE")) != 0;
-      const bool hit = cache_on && own->cutc.cuts != NULL && own->cutc.idx1 == (const void *) A.idx1 &&
-                       own->cutc.idx2 == (const void *) A.idx2 && own->cutc.pbeg == pbeg && own->cutc.pend == pend &&
+      const bool hit = cache_on && own->cutc.cuts != NULL && own->cutc.gen1 == v1.gen &&
+                       own->cutc.gen2 == v2.gen && own->cutc.pbeg == pbeg && own->cutc.pend == pend &&
                        own->cutc.nranges == nranges && own->cutc.nbig == nbig && own->cutc.base == base && own->cutc.total == total;
       if (!hit)
         { fga_pool_free(own->cutc.cuts);
@@ -1219,8 +1232,8 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
       hipEventRecord(dev->ev0,dev->stream);
       if (!hit)
         { hipLaunchKernelGGL(range_cut_kernel,dim3((nranges+1+255)/256),dim3(256),0,dev->stream,
-                             A.idx1,A.idx2,pbeg,pend,base,total,nranges,nbig,cuts);
-          own->cutc.idx1 = A.idx1; own->cutc.idx2 = A.idx2; own->cutc.pbeg = pbeg; own->cutc.pend = pend;
+                             A.idx1,A.idx2,A.car1,(mode == MODE_SELF) ? A.car1 : A.car2,pbeg,pend,base,total,nranges,nbig,cuts);
+          own->cutc.gen1 = v1.gen; own->cutc.gen2 = v2.gen; own->cutc.pbeg = pbeg; own->cutc.pend = pend;
           own->cutc.nranges = nranges; own->cutc.nbig = nbig; own->cutc.base = base; own->cutc.total = total;
         }
       hipEventRecord(dev->ev1,dev->stream);
@@ -1311,7 +1324,7 @@ done:
 
 // cuts[0..nshards]: 12-mer prefix ranges [cuts[r], cuts[r+1]) of equal merge cost (entries of both tables + prefixes), the
 // phase-1 shards of a multi-GPU run -- the reference splits its merge threads the same way (FastGA.c:2291-2321)
-__global__ void prefix_cut_kernel(const uint32_t *idx1, const uint32_t *idx2, int64_t total, int nshards, int64_t *cuts)
+__global__ void prefix_cut_kernel(const uint32_t *idx1, const uint32_t *idx2, fga_car car1, fga_car car2, int64_t total, int nshards, int64_t *cuts)
 { const int w = blockIdx.x*blockDim.x + threadIdx.x;
   if (w > nshards)
     return;
@@ -1323,7 +1336,7 @@ __global__ void prefix_cut_kernel(const uint32_t *idx1, const uint32_t *idx2, in
       int lo = 0, hi = FGA_NPREFIX;
       while (lo < hi)                                  // smallest p whose inclusive cost exceeds the target
         { const int mid = lo + ((hi-lo) >> 1);
-          const int64_t c = (int64_t) idx1[mid] + (int64_t) idx2[mid] + 2*((int64_t) mid+1);
+          const int64_t c = fga_idx_abs(idx1,car1,mid) + fga_idx_abs(idx2,car2,mid) + 2*((int64_t) mid+1);
           if (c > target) hi = mid; else lo = mid+1;
         }
       p = lo;
@@ -1348,7 +1361,8 @@ extern "C" int fga_merge_prefix_cuts(fga_dev *dev, const fga_dgix *t1, const fga
     { fga_set_error("fga_merge_prefix_cuts: device allocation failed");
       return 1;
     }
-  hipLaunchKernelGGL(prefix_cut_kernel,dim3((nshards+1+63)/64),dim3(64),0,dev->stream,t1->view.idx,t2->view.idx,total,nshards,d);
+  hipLaunchKernelGGL(prefix_cut_kernel,dim3((nshards+1+63)/64),dim3(64),0,dev->stream,t1->view.idx,t2->view.idx,
+                     fga_view_car(t1->view),fga_view_car(t2->view),total,nshards,d);
   hipError_t e = hipMemcpyAsync(cuts,d,sizeof(int64_t)*(size_t) (nshards+1),hipMemcpyDeviceToHost,dev->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
   if (e == hipSuccess) e = hipGetLastError();

@@ -13,13 +13,15 @@
 //   M[i]  u8    soft-mask byte (read by -M runs only)
 //   P[i]  u32   position inside the contig
 //   C[i]  u8 / u16 / u32   contig | sign, as stored (sign = top bit of the last byte)
-//   idx[p] u32  inclusive cumulative entry count per 12-mer prefix (tables of >= 2^32 entries are refused)
+//   idx[p] u32  inclusive cumulative entry count per 12-mer prefix, low 32 bits; car[k] = the first prefix at which the count
+//               reaches (k+1) * 2^32 (tables of up to 5 * 2^32 entries: the reference indexes with int64, libfastk.c:785-907)
 //
 // = 14 + ContBytes bytes per entry of which a pair comparison reads K, P, C of table 1 and K, L, P, C of table 2: the
 // on-disk width or one byte more.  The FORWARD view (fga_view_forward) holds the forward-strand entries of a table only,
 // with their own prefix index: in a pair comparison the entries of table 1 on the complement strand produce nothing
 // (FastGA.c:921-928: they are skipped after having been read), so the kernel does not read them at all.
 #include "fga_device.hpp"
+#include <atomic>
 
 #define VW_T 256
 
@@ -125,23 +127,68 @@ void view_fwd_scatter_kernel(fga_view V, fga_view F, uint32_t signbit, const int
     }
 }
 
-// pass 3: the forward view's prefix index: forward entries before the end of every panel
+// forward entries among the entries of the prefixes <= p
+__device__ __forceinline__ int64_t view_fwd_upto(const fga_view &V, const fga_car &car, int64_t fn, uint32_t signbit,
+                                                 const int64_t *blkoff, const uint16_t *sub, int64_t p)
+{ const int64_t e = fga_idx_abs(V.idx,car,p);         // entries [0,e) belong to prefixes <= p
+  if (e >= V.n)
+    return fn;
+  const int64_t piece = e >> 6;
+  int64_t r = blkoff[piece >> 4] + sub[piece];
+  for (int64_t i = piece << 6; i < e; i++)
+    r += !(view_c(V,i) & signbit);
+  return r;
+}
+
+// pass 3: the forward view's prefix index: forward entries before the end of every panel (low words; the carries below)
 __global__ __launch_bounds__(VW_T)
-void view_fwd_index_kernel(fga_view V, fga_view F, uint32_t signbit, const int64_t *blkoff, const uint16_t *sub)
+void view_fwd_index_kernel(fga_view V, fga_car car, fga_view F, uint32_t signbit, const int64_t *blkoff, const uint16_t *sub)
 { const int64_t p = (int64_t) blockIdx.x*VW_T + threadIdx.x;
   if (p >= FGA_NPREFIX)
     return;
-  const int64_t e = V.idx[p];                        // entries [0,e) belong to prefixes <= p
-  int64_t r;
-  if (e >= V.n)
-    r = F.n;
-  else
-    { const int64_t piece = e >> 6;
-      r = blkoff[piece >> 4] + sub[piece];
-      for (int64_t i = piece << 6; i < e; i++)
-        r += !(view_c(V,i) & signbit);
+  F.idx[p] = (uint32_t) view_fwd_upto(V,car,F.n,signbit,blkoff,sub,p);
+}
+
+// car[k] of a cumulative count given as a function of the prefix: the first prefix at which it reaches (k+1) * 2^32
+__global__ void view_fwd_carry_kernel(fga_view V, fga_car car, int64_t fn, uint32_t signbit, const int64_t *blkoff, const uint16_t *sub,
+                                      uint32_t *out)
+{ const int k = threadIdx.x;
+  if (k >= 4) return;
+  const int64_t want = (int64_t) (k+1) << 32;
+  int64_t lo = 0, hi = FGA_NPREFIX;                  // smallest p with count(p) >= want, or 2^24
+  while (lo < hi)
+    { const int64_t mid = (lo + hi) >> 1;
+      if (view_fwd_upto(V,car,fn,signbit,blkoff,sub,mid) >= want) hi = mid; else lo = mid + 1;
     }
-  F.idx[p] = (uint32_t) r;
+  out[k] = (uint32_t) lo;
+}
+
+__global__ void view_carry_kernel(const int64_t *idx64, uint32_t *out)
+{ const int k = threadIdx.x;
+  if (k >= 4) return;
+  const int64_t want = (int64_t) (k+1) << 32;
+  int64_t lo = 0, hi = FGA_NPREFIX;
+  while (lo < hi)
+    { const int64_t mid = (lo + hi) >> 1;
+      if (idx64[mid] >= want) hi = mid; else lo = mid + 1;
+    }
+  out[k] = (uint32_t) lo;
+}
+
+int fga_view_set_carries(fga_dev *dev, const int64_t *idx64, fga_view *V)
+{ uint32_t *d = NULL;
+  for (int k = 0; k < 4; k++) V->car[k] = (uint32_t) FGA_NPREFIX;
+  if (V->n < ((int64_t) 1 << 32))
+    return 0;
+  if (fga_dmalloc(&d,sizeof(uint32_t)*4) != hipSuccess)
+    { fga_set_error("device allocation failed"); return 1; }
+  hipLaunchKernelGGL(view_carry_kernel,dim3(1),dim3(64),0,dev->stream,idx64,d);
+  hipError_t e = hipMemcpyAsync(V->car,d,sizeof(uint32_t)*4,hipMemcpyDeviceToHost,dev->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
+  fga_pool_free(d);
+  if (e != hipSuccess)
+    { fga_set_error("table view: carries: %s",hipGetErrorString(e)); return 1; }
+  return 0;
 }
 
 static void view_free(fga_view *V)
@@ -150,8 +197,11 @@ static void view_free(fga_view *V)
 }
 
 int fga_view_alloc(fga_view *V, int64_t n, int cont, int want_l)
-{ memset(V,0,sizeof(*V));
+{ static std::atomic<uint64_t> next_gen{1};
+  memset(V,0,sizeof(*V));
   V->n = n;
+  V->gen = next_gen.fetch_add(1);
+  for (int k = 0; k < 4; k++) V->car[k] = (uint32_t) FGA_NPREFIX;
   V->cw = cont <= 1 ? 1 : (cont == 2 ? 2 : 4);
   const size_t m = (size_t) n + 256;                 // windows are loaded in 16-byte pieces from 4-entry aligned starts
   hipError_t e;
@@ -173,8 +223,8 @@ int fga_view_alloc(fga_view *V, int64_t n, int cont, int want_l)
 
 // D->table (the on-disk bytes) + D->index -> D->view; the on-disk bytes leave the device afterwards unless keep_table
 int fga_dgix_make_view(fga_dev *dev, fga_dgix *D, int keep_table)
-{ if (D->nents >= ((int64_t) 1 << 32) - 1024)
-    { fga_set_error("genome index of %lld entries: tables of 2^32 entries and more are not supported",(long long) D->nents);
+{ if (D->nents >= ((int64_t) 5 << 32) - 1024)
+    { fga_set_error("genome index of %lld entries: tables of 5 x 2^32 entries and more are not supported",(long long) D->nents);
       return 1;
     }
   if (D->postbytes > 4)
@@ -200,6 +250,10 @@ int fga_dgix_make_view(fga_dev *dev, fga_dgix *D, int keep_table)
       return 1;
     }
   fga_note("view: repack kernel",t0); t0 = fga_wall();
+  if (fga_view_set_carries(dev,D->index,&D->view))
+    { view_free(&D->view);
+      return 1;
+    }
   if (!keep_table)
     { fga_pool_free(D->table);
       D->table = NULL;
@@ -250,7 +304,22 @@ int fga_dgix_make_forward(fga_dev *dev, fga_dgix *D)
     }
   if (nblk > 0)
     hipLaunchKernelGGL(view_fwd_scatter_kernel,dim3((unsigned) nblk),dim3(VW_T),0,dev->stream,V,F,signbit,doff,dsub);
-  hipLaunchKernelGGL(view_fwd_index_kernel,dim3(FGA_NPREFIX/VW_T),dim3(VW_T),0,dev->stream,V,F,signbit,doff,dsub);
+  hipLaunchKernelGGL(view_fwd_index_kernel,dim3(FGA_NPREFIX/VW_T),dim3(VW_T),0,dev->stream,V,fga_view_car(V),F,signbit,doff,dsub);
+  if (nf >= ((int64_t) 1 << 32))            // the forward view's own carries
+    { uint32_t *dc = NULL;
+      if ((e = fga_dmalloc(&dc,sizeof(uint32_t)*4)) != hipSuccess)
+        { fga_set_error("forward view: device allocation failed: %s",hipGetErrorString(e));
+          goto done;
+        }
+      hipLaunchKernelGGL(view_fwd_carry_kernel,dim3(1),dim3(64),0,dev->stream,V,fga_view_car(V),nf,signbit,doff,dsub,dc);
+      e = hipMemcpyAsync(F.car,dc,sizeof(uint32_t)*4,hipMemcpyDeviceToHost,dev->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
+      fga_pool_free(dc);
+      if (e != hipSuccess)
+        { fga_set_error("forward view: carries: %s",hipGetErrorString(e));
+          goto done;
+        }
+    }
   e = hipStreamSynchronize(dev->stream);
   if (e == hipSuccess) e = hipGetLastError();
   if (e != hipSuccess)

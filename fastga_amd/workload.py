@@ -94,6 +94,34 @@ def build_config4(workdir, mbp=3000.0, divergence=0.01, seed=3, ncontig=32, repe
     return tuple(roots)
 
 
+
+def build_config6g(workdir, mbp=6000.0, ncontig=64, nsmall=4, repeats=0.01, threads=8):
+    """A genome whose index holds more than 2^32 entries (6 Gbp in 64 contigs of ~94 Mbp, 1 % repeats: 4.76 G entries) and a
+    small one that is homologous to its beginning: the first `nsmall` contigs of its 1 %-diverged copy (C generator, seed 6).
+    Returns (root of the big genome G, root of the small genome S)."""
+    lens = synth.contig_lengths(6, ncontig, int(mbp * 1e6))
+    fa, fb = os.path.join(workdir, "G.fa"), os.path.join(workdir, "B.fa")
+    synth.write_pair_fast(6, lens, 0.01, fa, fb, repeat_frac=repeats, nfam=max(4, int(round(mbp * 256 / 60))), inv_frac=0.02,
+                          swap_frac=0.02, bseed=10, prefix_a="g", prefix_b="s", threads=threads)
+    fs = os.path.join(workdir, "S.fa")
+    with open(fb) as src, open(fs, "w") as dst:            # the first nsmall records of the copy
+        n = 0
+        for ln in src:
+            if ln.startswith(">"):
+                n += 1
+                if n > nsmall:
+                    break
+            dst.write(ln)
+    os.unlink(fb)
+    roots = []
+    for nm, f in (("G", fa), ("S", fs)):
+        root = os.path.join(workdir, nm)
+        fasta_to_gdb(f, root)
+        os.unlink(f)
+        roots.append(root)
+    return tuple(roots)
+
+
 def digest_1aln(lines):
     """A digest of a .1aln as ONEview prints it that does not depend on how ties on (aread, abpos) are ordered (the
     reference orders them by the thread slot that held the record, FastGA.c:3906-3918): record count, md5 of the

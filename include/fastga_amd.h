@@ -82,7 +82,7 @@ enum { FGA_STAGE_MERGE_PARTITION = 0, FGA_STAGE_MERGE = 1, FGA_STAGE_SORT = 2, F
        FGA_STAGE_EXTEND = 4, FGA_STAGE_GIX = 5, FGA_STAGE_TRACE = 6, FGA_STAGE_REGROUP = 7, FGA_NSTAGES = 8 };
 
 int   fga_dev_open(int device, fga_dev **out);
-void  fga_dev_close(fga_dev *dev);
+void  fga_dev_close(fga_dev *dev);        /* not while another thread can still allocate, copy or launch under the context */
 int   fga_dev_sync(fga_dev *dev);
 float fga_dev_stage_ms(const fga_dev *dev, int stage);   /* HIP-event time of the stage's last launch */
 
