@@ -587,63 +587,146 @@ static void *bin_thread(void *arg)
   return NULL;
 }
 
-int fga_write_1aln_binary(const char *path, const fga_gdb *g1, const fga_gdb *g2, const fga_alns *A, int tspace,
-                          const char *db1_name, const char *db2_name, const char *command_line)
-{ FILE *f;
-  skel_stats st;
-  int64_t i, nR = 0, maxT = 0, totT = 0;
-  int64_t *goff = NULL, *soff = NULL, *aoff = NULL, ng = 0, ns = 0;
-  int64_t base, nscaf;
-  char date[64], *cwd;
-  time_t t = time(NULL);
-  bbuf H, B, F;
-  int nth = writer_threads, q, rc = 1;
+/* The file as a stream: header + skeletons when it is opened, records appended set by set in final order (each set formatted
+ * on the writer threads and written through the one stream), footer -- counts in schema order, the object indices -- when it is
+ * closed.  A comparison that runs phase 2 in several parts writes a part's records while the next part's kernels run
+ * (fga_pipeline.c); fga_write_1aln_binary is open + one append + close. */
+struct fga_aln_stream
+  { FILE    *f;
+    char    *path;
+    const fga_gdb *g1, *g2;
+    skel_stats st;
+    int64_t  base, pos;          /* start of the data / absolute position of the next record */
+    int64_t *goff, *soff, *aoff; /* object indices; aoff grows */
+    int64_t  ng, ns, na, acap;
+    int64_t  nR, maxT, totT;
+    int64_t  datalen;            /* bytes of data written behind the header */
+    wcodec   ct, cx;
+    int      trained;
+    int      fail;
+  };
+
+static int stream_format_and_write(fga_aln_stream *S, const fga_alns *A)
+{ int nth = writer_threads, q, rc = 1;
   bin_job job[WRITER_MAXT];
   pthread_t th[WRITER_MAXT];
-  wcodec ct, cx;
-
-  memset(&H,0,sizeof(H)); memset(&B,0,sizeof(B)); memset(&F,0,sizeof(F));
+  int64_t i, maxT = 0, totT = 0;
   memset(job,0,sizeof(job));
-  memset(&st,0,sizeof(st));
-  skeleton_stats(g1,&st);
-  if (g2 != NULL)
-    skeleton_stats(g2,&st);
   for (i = 0; i < A->naln; i++)
     { int64_t tl = A->alns[i].tlen/2;
-      if (A->alns[i].flags & 1) nR += 1;
+      if (A->alns[i].flags & 1) S->nR += 1;
       if (tl > maxT) maxT = tl;
       totT += tl;
     }
+  if (maxT > S->maxT) S->maxT = maxT;
+  S->totT += totT;
   /* list codes for the T and X lines, like the reference's files carry them once a type has > ~100 KB of list data.
    * Opt-in (FGA_ALN_CODEC=1): training + encoding doubles the writer's time (it is inside the timed hot path) for a
-   * file 2.4x smaller; from 16 K trace points on, trained on all of the data */
-  memset(&ct,0,sizeof(ct)); memset(&cx,0,sizeof(cx));
-  if (totT >= 16384 && getenv("FGA_ALN_CODEC") != NULL && atoi(getenv("FGA_ALN_CODEC")) != 0)
-    { uint64_t ht[256], hx[256];
-      int64_t k;
-      memset(ht,0,sizeof(ht)); memset(hx,0,sizeof(hx));
-      for (i = 0; i < A->naln; i++)
-        { const uint8_t *tr = A->tbytes + A->alns[i].toff;
-          const int64_t n = A->alns[i].tlen/2;
-          int okt = 1, okx = 1;
-          for (k = 1; k < n && (okt || okx); k++)
-            { const int dt = (int) tr[2*k+1] - (int) tr[2*k-1], dx = (int) tr[2*k] - (int) tr[2*k-2];
-              if (dt >= 128 || dt < -128) okt = 0;
-              if (dx >= 128 || dx < -128) okx = 0;
+   * file 2.4x smaller; from 16 K trace points on, trained on the first set that is appended */
+  if (!S->trained)
+    { S->trained = 1;
+      if (totT >= 16384 && getenv("FGA_ALN_CODEC") != NULL && atoi(getenv("FGA_ALN_CODEC")) != 0)
+        { uint64_t ht[256], hx[256];
+          int64_t k;
+          memset(ht,0,sizeof(ht)); memset(hx,0,sizeof(hx));
+          for (i = 0; i < A->naln; i++)
+            { const uint8_t *tr = A->tbytes + A->alns[i].toff;
+              const int64_t n = A->alns[i].tlen/2;
+              int okt = 1, okx = 1;
+              for (k = 1; k < n && (okt || okx); k++)
+                { const int dt = (int) tr[2*k+1] - (int) tr[2*k-1], dx = (int) tr[2*k] - (int) tr[2*k-2];
+                  if (dt >= 128 || dt < -128) okt = 0;
+                  if (dx >= 128 || dx < -128) okx = 0;
+                }
+              for (k = 1; k < n; k++)
+                { if (okt) ht[(uint8_t) ((int) tr[2*k+1] - (int) tr[2*k-1])] += 1;
+                  if (okx) hx[(uint8_t) ((int) tr[2*k] - (int) tr[2*k-2])] += 1;
+                }
             }
-          for (k = 1; k < n; k++)
-            { if (okt) ht[(uint8_t) ((int) tr[2*k+1] - (int) tr[2*k-1])] += 1;
-              if (okx) hx[(uint8_t) ((int) tr[2*k] - (int) tr[2*k-2])] += 1;
-            }
+          wcodec_build(ht,&S->ct);
+          wcodec_build(hx,&S->cx);
         }
-      wcodec_build(ht,&ct);
-      wcodec_build(hx,&cx);
     }
+  if (S->na + A->naln + 2 > S->acap)
+    { const int64_t nc = 2*(S->na + A->naln) + 1024;
+      int64_t *x = realloc(S->aoff,sizeof(int64_t)*nc);
+      if (x == NULL) goto oom;
+      S->aoff = x; S->acap = nc;
+    }
+  { long nc = sysconf(_SC_NPROCESSORS_ONLN);
+    if (nc > 0 && nc < nth) nth = (int) nc;
+    if (totT < 200000) nth = 1;
+  }
+  for (q = 0; q < nth; q++)
+    { job[q].A = A;
+      job[q].i0 = (A->naln*q)/nth; job[q].i1 = (A->naln*(q+1))/nth;
+      job[q].rel = malloc(sizeof(int64_t)*(job[q].i1-job[q].i0+1));
+      job[q].tmp = malloc((size_t) (3*maxT + 64));
+      job[q].ct = S->ct.have ? &S->ct : NULL; job[q].cx = S->cx.have ? &S->cx : NULL;
+      if (job[q].rel == NULL || job[q].tmp == NULL) goto oom;
+    }
+  { int started[WRITER_MAXT];
+    for (q = 1; q < nth; q++)
+      { started[q] = pthread_create(th+q,NULL,bin_thread,job+q) == 0;
+        if (!started[q]) bin_thread(job+q);
+      }
+    bin_thread(job);
+    for (q = 1; q < nth; q++)
+      if (started[q])
+        pthread_join(th[q],NULL);
+  }
+  for (q = 0; q < nth; q++)
+    { if (job[q].B.fail) goto oom;
+      for (i = job[q].i0; i < job[q].i1; i++)
+        S->aoff[S->na + i + 1] = S->pos + job[q].rel[i-job[q].i0];
+      S->pos += (int64_t) job[q].B.len;
+    }
+  S->na += A->naln;
+  /* One stream writes the file.  Measured in round 5 on the 289 MB of a 3 Gbp comparison's 4.2 M records (32 formatter
+     threads): this 108-166 ms; every job writing its own stretch with pwrite 137-211 ms (buffered writes to one file take
+     turns on the inode's lock); the jobs copying into a shared mapping of the file 420-530 ms (a page fault per 4 KB). */
+  { int ok = 1;
+    for (q = 0; q < nth; q++)
+      if (job[q].B.len > 0)
+        { ok &= fwrite(job[q].B.p,1,job[q].B.len,S->f) == job[q].B.len;
+          S->datalen += (int64_t) job[q].B.len;
+        }
+    if (!ok)
+      { fga_set_error("IO error writing %s",S->path);
+        goto done;
+      }
+  }
+  rc = 0;
+  goto done;
+oom:
+  fga_set_error("out of memory");
+done:
+  for (q = 0; q < WRITER_MAXT; q++) { free(job[q].B.p); free(job[q].rel); free(job[q].tmp); }
+  if (rc) S->fail = 1;
+  return rc;
+}
+
+int fga_aln_stream_open(const char *path, const fga_gdb *g1, const fga_gdb *g2, int tspace,
+                        const char *db1_name, const char *db2_name, const char *command_line, fga_aln_stream **out)
+{ fga_aln_stream *S = calloc(1,sizeof(fga_aln_stream));
+  char date[64], *cwd;
+  time_t t = time(NULL);
+  bbuf H, B;
+  int64_t nscaf;
+  *out = NULL;
+  memset(&H,0,sizeof(H)); memset(&B,0,sizeof(B));
+  if (S == NULL) goto oom;
+  S->g1 = g1; S->g2 = g2;
+  S->path = strdup(path);
+  skeleton_stats(g1,&S->st);
+  if (g2 != NULL)
+    skeleton_stats(g2,&S->st);
   nscaf = g1->nscaff + (g2 != NULL ? g2->nscaff : 0);
-  goff = malloc(sizeof(int64_t)*4);
-  soff = malloc(sizeof(int64_t)*(nscaf+2));
-  aoff = malloc(sizeof(int64_t)*(A->naln+2));
-  if (goff == NULL || soff == NULL || aoff == NULL) goto oom;
+  S->goff = malloc(sizeof(int64_t)*4);
+  S->soff = malloc(sizeof(int64_t)*(nscaf+2));
+  S->acap = 1024;
+  S->aoff = malloc(sizeof(int64_t)*S->acap);
+  if (S->path == NULL || S->goff == NULL || S->soff == NULL || S->aoff == NULL) goto oom;
 
   /* ---- ASCII header ---- */
   strftime(date,sizeof(date),"%Y-%m-%d_%H:%M:%S",localtime(&t));
@@ -670,82 +753,95 @@ int fga_write_1aln_binary(const char *path, const fga_gdb *g1, const fga_gdb *g2
     bb_bytes(&H,"$ 0\n",4);
   }
   if (H.fail) goto oom;
-  base = (int64_t) H.len;                       /* the data starts here: index[0] of every object type */
-  goff[0] = soff[0] = aoff[0] = base;
+  S->base = (int64_t) H.len;                    /* the data starts here: index[0] of every object type */
+  S->goff[0] = S->soff[0] = S->aoff[0] = S->base;
 
-  /* ---- data: t, skeletons, then the records (formatted in parallel) ---- */
+  /* ---- data: t, skeletons ---- */
   bb_type(&B,'t'); bb_int(&B,tspace);
-  bin_skeleton(&B,g1,base,goff,&ng,soff,&ns);
+  bin_skeleton(&B,g1,S->base,S->goff,&S->ng,S->soff,&S->ns);
   if (g2 != NULL)
-    bin_skeleton(&B,g2,base,goff,&ng,soff,&ns);
+    bin_skeleton(&B,g2,S->base,S->goff,&S->ng,S->soff,&S->ns);
   if (B.fail) goto oom;
+  S->pos = S->base + (int64_t) B.len;
+  S->datalen = (int64_t) B.len;
 
-  { long nc = sysconf(_SC_NPROCESSORS_ONLN);
-    if (nc > 0 && nc < nth) nth = (int) nc;
-    if (totT < 200000) nth = 1;
-  }
-  for (q = 0; q < nth; q++)
-    { job[q].A = A;
-      job[q].i0 = (A->naln*q)/nth; job[q].i1 = (A->naln*(q+1))/nth;
-      job[q].rel = malloc(sizeof(int64_t)*(job[q].i1-job[q].i0+1));
-      job[q].tmp = malloc((size_t) (3*maxT + 64));
-      job[q].ct = ct.have ? &ct : NULL; job[q].cx = cx.have ? &cx : NULL;
-      if (job[q].rel == NULL || job[q].tmp == NULL) goto oom;
+  S->f = fopen(path,"w");
+  if (S->f == NULL)
+    { fga_set_error("cannot open %s for writing",path);
+      goto fail;
     }
-  { int started[WRITER_MAXT];
-    for (q = 1; q < nth; q++)
-      { started[q] = pthread_create(th+q,NULL,bin_thread,job+q) == 0;
-        if (!started[q]) bin_thread(job+q);
-      }
-    bin_thread(job);
-    for (q = 1; q < nth; q++)
-      if (started[q])
-        pthread_join(th[q],NULL);
-  }
-  { int64_t pos = base + (int64_t) B.len;
-    for (q = 0; q < nth; q++)
-      { if (job[q].B.fail) goto oom;
-        for (i = job[q].i0; i < job[q].i1; i++)
-          aoff[i+1] = pos + job[q].rel[i-job[q].i0];
-        pos += (int64_t) job[q].B.len;
-      }
-  }
+  if (fwrite(H.p,1,H.len,S->f) != H.len || fwrite(B.p,1,B.len,S->f) != B.len)
+    { fga_set_error("IO error writing %s",path);
+      goto fail;
+    }
+  free(H.p); free(B.p);
+  *out = S;
+  return 0;
+oom:
+  fga_set_error("out of memory");
+fail:
+  free(H.p); free(B.p);
+  if (S != NULL)
+    { if (S->f != NULL) fclose(S->f);
+      free(S->path); free(S->goff); free(S->soff); free(S->aoff); free(S);
+    }
+  return 1;
+}
 
+int fga_aln_stream_append(fga_aln_stream *S, const fga_alns *A)
+{ if (S == NULL || A == NULL || S->fail)
+    { fga_set_error("fga_aln_stream_append: no open stream");
+      return 1;
+    }
+  if (A->naln == 0)
+    return 0;
+  return stream_format_and_write(S,A);
+}
+
+int64_t fga_aln_stream_records(const fga_aln_stream *S) { return S == NULL ? 0 : S->na; }
+
+int fga_aln_stream_close(fga_aln_stream *S, int keep)
+{ bbuf F;
+  int rc = 1;
+  if (S == NULL) return 0;
+  memset(&F,0,sizeof(F));
+  if (!keep || S->fail)
+    goto done;
   /* ---- footer: counts in schema order (t g S G C a A p L R D T X ...), '&' index lines of g, S, A ---- */
 #define FPRINT(...) { char *_s = NULL; int _n = asprintf(&_s,__VA_ARGS__); if (_n < 0) goto oom; bb_bytes(&F,_s,(size_t) _n); free(_s); }
   FPRINT("# t 1\n")
-  FPRINT("# g %lld\n",(long long) ng)
-  FPRINT("%% g # C %lld\n",(long long) st.gC)
-  if (st.gG > 0) FPRINT("%% g # G %lld\n",(long long) st.gG)
-  FPRINT("%% g # S %lld\n",(long long) st.gS)
-  FPRINT("%% g + S %lld\n",(long long) st.gSt)
-  bb_index(&F,'g',goff,ng);
-  FPRINT("# S %lld\n",(long long) st.nS)
-  FPRINT("@ S %lld\n",(long long) st.maxS)
-  FPRINT("+ S %lld\n",(long long) st.totS)
-  FPRINT("%% S # C %lld\n",(long long) st.sC)
-  if (st.sG > 0) FPRINT("%% S # G %lld\n",(long long) st.sG)
-  bb_index(&F,'S',soff,ns);
-  if (st.nG > 0) FPRINT("# G %lld\n",(long long) st.nG)
-  FPRINT("# C %lld\n",(long long) st.nC)
-  if (A->naln > 0)
-    { FPRINT("# A %lld\n",(long long) A->naln)
+  FPRINT("# g %lld\n",(long long) S->ng)
+  FPRINT("%% g # C %lld\n",(long long) S->st.gC)
+  if (S->st.gG > 0) FPRINT("%% g # G %lld\n",(long long) S->st.gG)
+  FPRINT("%% g # S %lld\n",(long long) S->st.gS)
+  FPRINT("%% g + S %lld\n",(long long) S->st.gSt)
+  bb_index(&F,'g',S->goff,S->ng);
+  FPRINT("# S %lld\n",(long long) S->st.nS)
+  FPRINT("@ S %lld\n",(long long) S->st.maxS)
+  FPRINT("+ S %lld\n",(long long) S->st.totS)
+  FPRINT("%% S # C %lld\n",(long long) S->st.sC)
+  if (S->st.sG > 0) FPRINT("%% S # G %lld\n",(long long) S->st.sG)
+  bb_index(&F,'S',S->soff,S->ns);
+  if (S->st.nG > 0) FPRINT("# G %lld\n",(long long) S->st.nG)
+  FPRINT("# C %lld\n",(long long) S->st.nC)
+  if (S->na > 0)
+    { FPRINT("# A %lld\n",(long long) S->na)
       FPRINT("%% A # D 1\n")
-      if (nR > 0) FPRINT("%% A # R 1\n")
+      if (S->nR > 0) FPRINT("%% A # R 1\n")
       FPRINT("%% A # T 1\n")
-      if (maxT > 0) FPRINT("%% A + T %lld\n",(long long) maxT)
+      if (S->maxT > 0) FPRINT("%% A + T %lld\n",(long long) S->maxT)
       FPRINT("%% A # X 1\n")
-      if (maxT > 0) FPRINT("%% A + X %lld\n",(long long) maxT)
-      bb_index(&F,'A',aoff,A->naln);
-      if (nR > 0) FPRINT("# R %lld\n",(long long) nR)
-      FPRINT("# D %lld\n",(long long) A->naln)
-      FPRINT("# T %lld\n",(long long) A->naln)
-      if (maxT > 0) FPRINT("@ T %lld\n",(long long) maxT)
-      if (totT > 0) FPRINT("+ T %lld\n",(long long) totT)
-      FPRINT("# X %lld\n",(long long) A->naln)
-      if (maxT > 0) FPRINT("@ X %lld\n",(long long) maxT)
-      if (totT > 0) FPRINT("+ X %lld\n",(long long) totT)
-      { const wcodec *cc[2] = { &ct, &cx };           /* ';' lines: CHAR line type, STRING serialised code */
+      if (S->maxT > 0) FPRINT("%% A + X %lld\n",(long long) S->maxT)
+      bb_index(&F,'A',S->aoff,S->na);
+      if (S->nR > 0) FPRINT("# R %lld\n",(long long) S->nR)
+      FPRINT("# D %lld\n",(long long) S->na)
+      FPRINT("# T %lld\n",(long long) S->na)
+      if (S->maxT > 0) FPRINT("@ T %lld\n",(long long) S->maxT)
+      if (S->totT > 0) FPRINT("+ T %lld\n",(long long) S->totT)
+      FPRINT("# X %lld\n",(long long) S->na)
+      if (S->maxT > 0) FPRINT("@ X %lld\n",(long long) S->maxT)
+      if (S->totT > 0) FPRINT("+ X %lld\n",(long long) S->totT)
+      { const wcodec *cc[2] = { &S->ct, &S->cx };           /* ';' lines: CHAR line type, STRING serialised code */
         int z;
         for (z = 0; z < 2; z++)
           if (cc[z]->have)
@@ -762,40 +858,45 @@ int fga_write_1aln_binary(const char *path, const fga_gdb *g1, const fga_gdb *g2
   FPRINT("^\n")
 #undef FPRINT
   if (F.fail) goto oom;
-
-  /* One stream writes the file.  Measured in round 5 on the 289 MB of a 3 Gbp comparison's 4.2 M records (32 formatter
-     threads): this 108-166 ms; every job writing its own stretch with pwrite 137-211 ms (buffered writes to one file take
-     turns on the inode's lock); the jobs copying into a shared mapping of the file 420-530 ms (a page fault per 4 KB). */
-  f = fopen(path,"w");
-  if (f == NULL)
-    { fga_set_error("cannot open %s for writing",path);
-      goto done;
-    }
-  { int64_t foot = base + (int64_t) B.len + 1;       /* + the end-of-data '\n' */
+  { const int64_t foot = S->base + S->datalen + 1;       /* + the end-of-data '\n' */
     int ok = 1;
-    ok &= fwrite(H.p,1,H.len,f) == H.len;
-    ok &= fwrite(B.p,1,B.len,f) == B.len;
-    for (q = 0; q < nth; q++)
-      { if (job[q].B.len > 0)
-          ok &= fwrite(job[q].B.p,1,job[q].B.len,f) == job[q].B.len;
-        foot += (int64_t) job[q].B.len;
-      }
-    ok &= fputc('\n',f) != EOF;
-    ok &= fwrite(F.p,1,F.len,f) == F.len;
-    ok &= fwrite(&foot,sizeof(int64_t),1,f) == 1;
-    if (fclose(f) != 0 || !ok)
-      { fga_set_error("IO error writing %s",path);
+    ok &= fputc('\n',S->f) != EOF;
+    ok &= fwrite(F.p,1,F.len,S->f) == F.len;
+    ok &= fwrite(&foot,sizeof(int64_t),1,S->f) == 1;
+    if (!ok)
+      { fga_set_error("IO error writing %s",S->path);
         goto done;
       }
   }
   rc = 0;
   goto done;
-
 oom:
   fga_set_error("out of memory");
 done:
-  for (q = 0; q < WRITER_MAXT; q++) { free(job[q].B.p); free(job[q].rel); free(job[q].tmp); }
-  free(H.p); free(B.p); free(F.p);
-  free(goff); free(soff); free(aoff);
+  if (S->f != NULL && fclose(S->f) != 0 && rc == 0)
+    { fga_set_error("IO error writing %s",S->path);
+      rc = 1;
+    }
+  if (rc != 0 || !keep)
+    { unlink(S->path);
+      if (!keep && !S->fail) rc = 0;
+    }
+  free(F.p);
+  free(S->path); free(S->goff); free(S->soff); free(S->aoff); free(S);
   return rc;
+}
+
+int fga_write_1aln_binary(const char *path, const fga_gdb *g1, const fga_gdb *g2, const fga_alns *A, int tspace,
+                          const char *db1_name, const char *db2_name, const char *command_line)
+{ fga_aln_stream *S;
+  if (fga_aln_stream_open(path,g1,g2,tspace,db1_name,db2_name,command_line,&S))
+    return 1;
+  if (fga_aln_stream_append(S,A))
+    { char e[512];
+      snprintf(e,sizeof(e),"%s",fga_last_error());
+      fga_aln_stream_close(S,0);
+      fga_set_error("%s",e);
+      return 1;
+    }
+  return fga_aln_stream_close(S,1);
 }

@@ -20,23 +20,70 @@
 #include "fastga_amd.h"
 #include "fga_session.h"
 
-/* the redundancy filter of one part's records on a thread of its own, while the next part's kernels run */
+/* the redundancy filter of one part's records on a thread of its own, while the next part's kernels run -- and, when the parts
+   are contiguous in the output's order (A contigs in original order), the part's stretch of the .1aln behind it: the
+   reference's tie order, the records formatted and appended to the stream as soon as the parts before have been */
+typedef struct
+  { pthread_mutex_t mu;
+    pthread_cond_t  cv;
+    int             turn;        /* the part whose records go to the stream next */
+    int             failed;
+  } part_chain;
+
+static int reference_order(fga_session *Z, const fga_run_params *P, fga_alns *fin);
+
 typedef struct
   { const fga_alns *in;
     fga_alns *out;
-    int nthreads, rc, started;
-    double seconds;
+    int nthreads, rc, started, part;
+    double seconds, write_s;
     char *err;
     pthread_t th;
+    /* streaming (stream != NULL) */
+    fga_aln_stream *stream;
+    part_chain *chain;
+    fga_session *Z;
+    const fga_run_params *P;
+    int64_t nlive, cover;
   } part_filter;
 
 static void *part_filter_main(void *arg)
 { part_filter *F = arg;
   const double t0 = fga_wall();
   F->rc = fga_filter_alignments_mt(F->in,F->nthreads,&F->out);
+  if (F->rc == 0 && F->stream != NULL && F->P->reference_threads > 0)
+    F->rc = reference_order(F->Z,F->P,F->out);
   if (F->rc != 0)
     F->err = strdup(fga_last_error());
   F->seconds = fga_wall() - t0;
+  if (F->stream != NULL)
+    { part_chain *C = F->chain;
+      int go;
+      pthread_mutex_lock(&C->mu);
+      while (C->turn != F->part)
+        pthread_cond_wait(&C->cv,&C->mu);
+      if (F->rc != 0) C->failed = 1;
+      go = !C->failed;
+      pthread_mutex_unlock(&C->mu);
+      if (go)
+        { const double t1 = fga_wall();
+          int64_t i;
+          fga_aln_writer_threads(F->nthreads > 8 ? F->nthreads : 8);
+          F->nlive = F->out->naln;
+          for (i = 0; i < F->out->naln; i++)
+            F->cover += F->out->alns[i].aepos - F->out->alns[i].abpos;
+          if (fga_aln_stream_append(F->stream,F->out))
+            { F->rc = 1;
+              F->err = strdup(fga_last_error());
+            }
+          F->write_s = fga_wall() - t1;
+        }
+      pthread_mutex_lock(&C->mu);
+      if (F->rc != 0) C->failed = 1;
+      C->turn = F->part + 1;
+      pthread_cond_broadcast(&C->cv);
+      pthread_mutex_unlock(&C->mu);
+    }
   return NULL;
 }
 
@@ -690,6 +737,9 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
   fga_alns **raw = NULL;
   int nparts = 1, p, status = 1, finished = 0;
   part_filter *pf = NULL;
+  part_chain chain;
+  fga_aln_stream *stream = NULL;
+  int streaming = 0, chain_made = 0;
   int64_t limit = P->pass_seeds > 0 ? P->pass_seeds : (int64_t) 1500000000;
   int64_t *cnt = NULL, *poff = NULL;
   int *select = NULL;
@@ -730,7 +780,32 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
         { fga_set_error("out of memory");
           goto done;
         }
-      if (fga_seeds_contig_histogram(dev,seeds,nctg,cnt) || fga_partition_contigs(cnt,nctg,nparts,select))
+      /* The .1aln as a stream: with the A contigs dealt to the parts in ORIGINAL order (the output's primary order) part p's
+         records all come before part p+1's, so they are filtered, ordered, formatted and written while the next part's
+         kernels run; the finish is the footer.  Not with PAF / PSL output (which wants the whole set) or the text form */
+      streaming = P->out_path != NULL && P->paf_path == NULL &&
+                  !(getenv("FGA_ALN_ASCII") != NULL && atoi(getenv("FGA_ALN_ASCII")) != 0) &&
+                  !(getenv("FGA_STREAM_PARTS") != NULL && atoi(getenv("FGA_STREAM_PARTS")) == 0);
+      if (fga_seeds_contig_histogram(dev,seeds,nctg,cnt))
+        goto done;
+      if (streaming)
+        { int64_t big = 0, *sum = calloc(nparts,sizeof(int64_t));
+          int j;
+          if (sum == NULL)
+            { fga_set_error("out of memory");
+              goto done;
+            }
+          if (fga_partition_contigs_in_order(cnt,Z->x1->perm,nctg,nparts,select))
+            { free(sum);
+              goto done;
+            }
+          for (j = 0; j < nctg; j++)
+            if ((sum[select[j]] += cnt[j]) > big) big = sum[select[j]];
+          free(sum);
+          if (big > limit + limit/2 && big > n/nparts + n/(2*nparts))     /* a stretch half again over a pass's seeds (one */
+            streaming = 0;                                                /* contig dominates): the balanced deal instead  */
+        }
+      if (!streaming && fga_partition_contigs(cnt,nctg,nparts,select))
         goto done;
       if ((stage = fga_dev_stage_acquire(dev,(size_t) n*sizeof(fga_seed) + 64)) == NULL) goto done;
       if (fga_seeds_split_to(dev,seeds,select,nctg,nparts,stage,poff)) goto done;
@@ -740,6 +815,19 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
       if (pf == NULL)
         { fga_set_error("out of memory");
           goto done;
+        }
+      if (streaming)
+        { char *n1 = NULL, *n2 = NULL;
+          int rc;
+          if (asprintf(&n1,"%s",Z->g1->path) < 0) n1 = NULL;
+          if (!Z->self && asprintf(&n2,"%s",Z->g2->path) < 0) n2 = NULL;
+          rc = fga_aln_stream_open(P->out_path,Z->g1,Z->self ? NULL : Z->g2,100,n1 ? n1 : "genome1",n2,
+                                   P->command_line ? P->command_line : "FastGA",&stream);
+          free(n1); free(n2);
+          if (rc) goto done;
+          pthread_mutex_init(&chain.mu,NULL); pthread_cond_init(&chain.cv,NULL);
+          chain.turn = 0; chain.failed = 0;
+          chain_made = 1;
         }
       for (p = 0; p < nparts; p++)
         { const void *src = (const char *) stage + (size_t) poff[p]*sizeof(fga_seed);
@@ -754,6 +842,7 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
           /* half of the run's threads beside the next part's kernels (whose host tails want the rest); all of them for the
              last part, which nothing runs beside */
           pf[p].in = raw[p]; pf[p].nthreads = p == nparts-1 ? P->nthreads : (P->nthreads > 2 ? P->nthreads/2 : 1);
+          pf[p].part = p; pf[p].stream = stream; pf[p].chain = &chain; pf[p].Z = Z; pf[p].P = P;
           if (pthread_create(&pf[p].th,NULL,part_filter_main,&pf[p]) == 0)
             pf[p].started = 1;
           else
@@ -771,9 +860,19 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
               }
             if (fsets != NULL) fsets[p] = pf[p].out;
           }
-        st.filter_s += fga_wall() - tj;                 /* what the filter added to the critical path */
-        fga_note("run: filters joined",tstart);
-        if (!bad && fga_session_finish_filtered(Z,P,fsets,nparts,&st)) bad = 1;
+        st.filter_s += fga_wall() - tj;                 /* what the filter (and a stream's last stretch) added to the critical path */
+        fga_note(streaming ? "run: filters joined, parts written" : "run: filters joined",tstart);
+        if (streaming)
+          { const double tw = fga_wall();
+            for (p = 0; p < nparts; p++)
+              { st.nlive += pf[p].nlive; st.cover += pf[p].cover; st.write_s += pf[p].write_s; }
+            if (fga_aln_stream_close(stream,!bad)) bad = 1;
+            stream = NULL;
+            st.streamed_parts = nparts;
+            st.write_s += fga_wall() - tw;
+            fga_note("finish: .1aln closed (footer)",tw);
+          }
+        else if (!bad && fga_session_finish_filtered(Z,P,fsets,nparts,&st)) bad = 1;
         free(fsets);
         if (bad) goto done;
       }
@@ -794,6 +893,8 @@ done:
         fga_alns_free(pf[p].out); free(pf[p].err);
       }
   free(pf);
+  if (stream != NULL) fga_aln_stream_close(stream,0);      /* (a failed run leaves no file) */
+  if (chain_made) { pthread_mutex_destroy(&chain.mu); pthread_cond_destroy(&chain.cv); }
   if (raw != NULL)
     for (p = 0; p < nparts; p++) fga_alns_free(raw[p]);
   free(raw); free(cnt); free(poff); free(select);

@@ -98,7 +98,7 @@ class RunStats(C.Structure):
                                          "trace_kernel_ms")] + [("nparts", C.c_int), ("bases1", C.c_int64), ("bases2", C.c_int64), ("ext_cells", C.c_int64),
                                                      ("ext_bases", C.c_int64), ("ext_trace", C.c_int64),
                                                      ("ext_busy_waves", C.c_double), ("hbm_peak_bytes", C.c_int64),
-                                                     ("sort_keys", C.c_int64), ("sort_passes", C.c_int)]
+                                                     ("sort_keys", C.c_int64), ("sort_passes", C.c_int), ("streamed_parts", C.c_int)]
 
 
 class SortParams(C.Structure):
@@ -185,6 +185,10 @@ def _declare(L):
         "fga_filter_alignments_mt": (i32, [P(Alns), i32, P(P(Alns))]),
         "fga_write_1aln": (i32, [cp, vp, vp, P(Alns), i32, cp, cp, cp]),
         "fga_write_1aln_binary": (i32, [cp, vp, vp, P(Alns), i32, cp, cp, cp]),
+        "fga_aln_stream_open": (i32, [cp, vp, vp, i32, cp, cp, cp, P(vp)]),
+        "fga_aln_stream_append": (i32, [vp, P(Alns)]),
+        "fga_aln_stream_records": (i64, [vp]),
+        "fga_aln_stream_close": (i32, [vp, i32]),
         "fga_trace_pts": (i32, [vp, vp, vp, P(Alns), i32, i32, P(P(Traces))]),
         "fga_trace_pts_regrouped": (i32, [vp, vp, vp, P(Alns), i32, i32, P(P(Traces))]),
         "fga_gap_core_check": (i32, [vp, vp, P(Alns), P(Traces), i32, C.c_int64]),
@@ -221,6 +225,7 @@ def _declare(L):
         "fga_session_finish": (i32, [vp, P(RunParams), P(P(Alns)), i32, P(RunStats)]),
         "fga_seeds_contig_histogram": (i32, [vp, vp, i32, P(i64)]),
         "fga_partition_contigs": (i32, [P(i64), i32, i32, P(i32)]),
+        "fga_partition_contigs_in_order": (i32, [P(i64), P(i32), i32, i32, P(i32)]),
         "fga_seeds_split_to": (i32, [vp, vp, P(i32), i32, i32, vp, P(i64)]),
         "fga_seeds_import": (i32, [vp, P(vp), P(i64), i32, P(vp)]),
         "fga_seeds_device_ptr": (vp, [vp]),

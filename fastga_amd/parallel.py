@@ -63,6 +63,20 @@ def partition_contigs(weights, nparts):
     return sel
 
 
+def partition_contigs_in_order(weights, perm, nparts):
+    """fga_partition_contigs_in_order: the A contigs dealt out contiguously in their ORIGINAL order (perm[j] = original
+    index of contig j of the index order), stretches of about equal weight -- what fga_session_run deals when it streams the
+    parts' records to the .1aln"""
+    from .lib import load_library, check
+    L = load_library()
+    w = np.ascontiguousarray(weights, dtype=np.int64)
+    pm = np.ascontiguousarray(perm, dtype=np.int32)
+    sel = np.zeros(len(w), dtype=np.int32)
+    check(L.fga_partition_contigs_in_order(w.ctypes.data_as(C.POINTER(C.c_int64)), pm.ctypes.data_as(C.POINTER(C.c_int)),
+                                           len(w), nparts, sel.ctypes.data_as(C.POINTER(C.c_int))), "partition in order")
+    return sel
+
+
 def alns_to_arrays(ptr):
     """POINTER(Alns) -> (records as ALN_DTYPE array, trace bytes, (ncalls, nwaves)); copies"""
     from .device import ALN_DTYPE

@@ -269,6 +269,15 @@ int  fga_write_1aln(const char *path, const fga_gdb *g1, const fga_gdb *g2 /* NU
  * reference's seeking readers -- ALNtoPAF, ALNshow -- accept it); fga_write_1aln is the ASCII form */
 int  fga_write_1aln_binary(const char *path, const fga_gdb *g1, const fga_gdb *g2 /* NULL: self */, const fga_alns *alns,
                            int tspace, const char *db1_name, const char *db2_name, const char *command_line);
+/* the same file as a stream: header and skeletons at open, record sets appended in final order (a comparison that runs phase 2
+ * in several parts writes a part's records while the next part's kernels run), footer -- counts and object indices -- at close
+ * (keep = 0: the file is removed).  What the reference's per-thread Write_Aln_* calls into one file are (alncode.c:239-305) */
+typedef struct fga_aln_stream fga_aln_stream;
+int  fga_aln_stream_open(const char *path, const fga_gdb *g1, const fga_gdb *g2 /* NULL: self */, int tspace,
+                         const char *db1_name, const char *db2_name, const char *command_line, fga_aln_stream **out);
+int  fga_aln_stream_append(fga_aln_stream *s, const fga_alns *alns);
+int64_t fga_aln_stream_records(const fga_aln_stream *s);
+int  fga_aln_stream_close(fga_aln_stream *s, int keep);
 
 /* ---- edit scripts from trace points: replaces Compute_Trace_PTS (align.h:341-342, align.c:6171-6308) in the mode every
  *      reader of a .1aln uses it (ALNtoPAF.c:278, ALNshow.c:524, ALNtoPSL.c:193, ONEaln.c:1011: GREEDIEST, dlow > dhgh)
@@ -396,7 +405,8 @@ typedef struct
     int64_t hbm_peak_bytes;                    /* peak device memory in use by this process, sampled at the stage boundaries */
     int64_t sort_keys;                         /* records sorted, summed over the parts; sort_passes radix passes each:      */
     int     sort_passes;                       /*   algorithmic traffic of the sort = 2 x 16 B x sort_keys x sort_passes     */
-  } fga_run_stats;
+    int     streamed_parts;                    /* parts whose records went to the .1aln while later parts' kernels ran (0:   */
+  } fga_run_stats;                             /*   the file was written after the last part)                                */
 
 int  fga_run(const char *root1, const char *root2 /* NULL: self */, const fga_run_params *prm, fga_run_stats *stats);
 
@@ -424,6 +434,10 @@ int  fga_alns_reference_order(fga_alns *alns, const int *slot, const int *invp /
 /* select[c] = part of A contig c: heaviest contig first, each to the lightest part so far.  A pure function of its
    arguments (every rank computes the same map from the all-reduced counts) */
 int  fga_partition_contigs(const int64_t *weight, int nctg, int nparts, int *select);
+/* the same contigs dealt out contiguously in their ORIGINAL order (perm[j] = original index of contig j), stretches of about
+   equal weight: the records of part p then all come before those of part p+1 in the .1aln (fga_session_run writes a part's
+   stretch while the next part's kernels run) */
+int  fga_partition_contigs_in_order(const int64_t *weight, const int *perm, int nctg, int nparts, int *select);
 /* the seeds regrouped by part into a caller-provided DEVICE buffer of fga_seeds_count x 16 bytes (e.g. the send buffer
    of an all-to-all-v); part p occupies records [part_off[p], part_off[p+1]) */
 int  fga_seeds_split_to(fga_dev *dev, const fga_dseeds *seeds, const int *select, int nctg, int nparts /* <= 64 */,

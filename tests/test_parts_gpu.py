@@ -100,6 +100,30 @@ def test_session_run_in_several_passes(toy_pair, tmp_path):
     assert many["nseeds"] == one["nseeds"] and many["nhits"] == one["nhits"] and many["nlive"] == one["nlive"]
 
 
+@pytest.mark.parametrize("self_mode", [False, True])
+def test_parts_streamed_to_the_1aln_while_later_parts_run(toy_pair, tmp_path, self_mode, monkeypatch):
+    """with the A contigs dealt to the parts in original order, each part's records are filtered, put in the reference's
+    tie order and appended to the .1aln while the next part's kernels run (fga_aln_stream_*): the same bytes as the file
+    written after the last part, and as the one-pass run's"""
+    from fastga_amd import device as D
+    d, ra, rb = toy_pair
+    w = str(tmp_path)
+    b = None if self_mode else rb
+    kw = dict(nthreads=8, reference_threads=8)
+    one = D.run(ra, b, os.path.join(w, "one.1aln"), **kw)
+    lim = max(1, one["nseeds"] // 3)
+    streamed = D.run(ra, b, os.path.join(w, "streamed.1aln"), pass_seeds=lim, **kw)
+    monkeypatch.setenv("FGA_STREAM_PARTS", "0")
+    after = D.run(ra, b, os.path.join(w, "after.1aln"), pass_seeds=lim, **kw)
+    assert streamed["nparts"] == after["nparts"] >= 3 and after["streamed_parts"] == 0
+    assert streamed["streamed_parts"] == streamed["nparts"], "the contiguous deal was judged too uneven: nothing streamed"
+    ref = open(os.path.join(w, "one.1aln"), "rb").read()
+    assert open(os.path.join(w, "streamed.1aln"), "rb").read() == ref
+    assert open(os.path.join(w, "after.1aln"), "rb").read() == ref
+    for k in ("nseeds", "nhits", "nalns", "nlive", "cover"):
+        assert streamed[k] == after[k] == one[k], k
+
+
 # ---- run_sharded itself with N = 2: two processes on cuda:0, backend gloo (the exchange staged through the host) ----------
 
 def _sharded_worker(rank, world, port, ra, rb, out, q, self_mode):

@@ -118,6 +118,26 @@ def test_partition_is_balanced_and_a_pure_function(built_library):
     assert len(set(partition_contigs(np.zeros(16, np.int64), 4).tolist())) == 4
 
 
+def test_partition_in_original_order_is_contiguous(built_library):
+    """the deal fga_session_run uses when the parts' records stream to the .1aln: part numbers do not decrease along the
+    contigs' original order, so part p's records all come before part p+1's"""
+    from fastga_amd.parallel import partition_contigs_in_order
+    rng = np.random.default_rng(5)
+    for nctg, nparts in ((1, 1), (5, 8), (40, 2), (40, 8), (1000, 8), (24, 3)):
+        w = (rng.pareto(1.5, nctg) * 1e6).astype(np.int64)
+        perm = rng.permutation(nctg).astype(np.int32)
+        sel = partition_contigs_in_order(w, perm, nparts)
+        assert sel.min() >= 0 and sel.max() < nparts
+        inv = np.empty(nctg, np.int64); inv[perm] = np.arange(nctg)
+        along = sel[inv]                                               # part of original contig 0, 1, ..
+        assert np.all(np.diff(along) >= 0)
+        load = np.bincount(sel, weights=w, minlength=nparts)
+        assert load.max() <= w.sum() / nparts + w.max() + nparts       # a stretch ends with the contig that fills its share
+    # contigs an index pads a short genome with (perm beyond the genome's own, no seeds) go along at the end
+    sel = partition_contigs_in_order(np.array([5, 5, 0, 0], np.int64), np.array([1, 0, 2, 3], np.int32), 2)
+    assert sel.tolist() == [1, 0, 1, 1]
+
+
 # ------------------------------------------------------------------------------------------------ record gather
 
 def _raw_records(seed=11, ngroups=60):
