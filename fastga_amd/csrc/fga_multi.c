@@ -55,6 +55,9 @@ typedef struct
     int64_t     *scount;       /* [2*nctg] the same per strand (reference tie order) */
     int64_t     *waves;        /* [nctg] wave steps per A contig of its part in the last run */
     double       open_s, phase1_s, exchange_s, phase2_s;
+    int          streams;      /* this run's parts are contiguous stretches of A contigs: the rank appends its records itself */
+    int64_t      nlive, cover;
+    double       write_s;
   } multi_rank;
 
 struct fga_multi
@@ -81,6 +84,13 @@ struct fga_multi
     int64_t     *cost;         /* [nctg] wave steps per A contig of the previous run of this session */
     int          have_cost;
     double       load_s;
+    /* the .1aln as a stream (fga_aln_stream_*): with the A contigs dealt to the ranks in original order, rank r's records all
+       come before rank r+1's, and every rank formats and appends its own as soon as the ranks before it have */
+    fga_run_params Pout;       /* the caller's parameters (output path, command line) */
+    int          want_stream;  /* this run's output can be a stream (fga_run_can_stream) */
+    fga_aln_stream *stream;    /* opened by rank 0 when the contiguous deal is balanced enough */
+    int          turn;         /* the rank whose records go to the stream next */
+    pthread_cond_t cv_turn;
   };
 
 static void multi_fail(fga_multi *M, const char *where)
@@ -175,8 +185,40 @@ static void rank_run(multi_rank *me)
             for (q = 0; q < n; q++)
               for (c = 0; c < nctg; c++)
                 tot[c] += M->R[q].hist[c];
-          if (fga_partition_contigs(tot,nctg,n,select) ||
-              fga_dev_malloc(fga_session_device(me->Z),16*(size_t) (cnt > 0 ? cnt : 1),&me->sendbuf) ||
+          me->streams = 0;
+          if (fga_partition_contigs(tot,nctg,n,select))
+            multi_fail(M,"exchange (split)");
+          else if (M->want_stream)          /* the same contigs in original order, when that deal is not much worse */
+            { int *inord = malloc(sizeof(int)*(nctg > 0 ? nctg : 1));
+              int64_t *load = calloc(2*(size_t) n,sizeof(int64_t)), lmax = 0, omax = 0;
+              if (inord != NULL && load != NULL && fga_partition_contigs_in_order(tot,me->Z->x1->perm,nctg,n,inord) == 0)
+                { for (c = 0; c < nctg; c++)
+                    { if ((load[select[c]] += tot[c]) > lmax) lmax = load[select[c]];
+                      if ((load[n + inord[c]] += tot[c]) > omax) omax = load[n + inord[c]];
+                    }
+                  if (omax <= lmax + lmax/4 + 1 || fga_run_stream_forced())
+                    { memcpy(select,inord,sizeof(int)*nctg);
+                      me->streams = 1;
+                    }
+                }
+              free(inord); free(load);
+            }
+          if (me->streams && P->reference_threads > 0)     /* the tie order wants the strand counts of ALL prefix ranges */
+            { int64_t *sc = calloc(2*(size_t) (nctg > 0 ? nctg : 1),sizeof(int64_t));
+              if (sc == NULL) { fga_set_error("out of memory"); multi_fail(M,"exchange"); }
+              else
+                { for (q = 0; q < n; q++)
+                    for (c = 0; c < 2*nctg; c++)
+                      sc[c] += M->R[q].scount[c];
+                  if (fga_session_set_strand_counts(me->Z,sc)) multi_fail(M,"exchange");
+                }
+              free(sc);
+            }
+          if (me->streams && r == 0 && fga_session_stream_open(me->Z,&M->Pout,&M->stream))
+            multi_fail(M,"output");
+          if (multi_failed(M))
+            ;
+          else if (fga_dev_malloc(fga_session_device(me->Z),16*(size_t) (cnt > 0 ? cnt : 1),&me->sendbuf) ||
               fga_seeds_split_to(fga_session_device(me->Z),seeds,select,nctg,n,me->sendbuf,me->off))
             multi_fail(M,"exchange (split)");
         }
@@ -216,17 +258,42 @@ static void rank_run(multi_rank *me)
         { const double tf = fga_wall();
           if (raw->ctg_waves != NULL && raw->nctg_waves == nctg)
             memcpy(me->waves,raw->ctg_waves,sizeof(int64_t)*nctg);
-          if (fga_filter_alignments_mt(raw,P->nthreads,&me->fil))
+          if (fga_filter_alignments_mt(raw,P->nthreads,&me->fil) ||
+              (me->streams && fga_session_reference_order(me->Z,P,me->fil)))
             multi_fail(M,"filter");
           me->st.filter_s += fga_wall() - tf;
         }
       part = NULL;                          /* consumed by fga_session_align */
     }
   fga_seeds_free(part);
-  fga_alns_free(raw);
+  fga_alns_free(raw); raw = NULL;
   free(select);
   me->st.hbm_peak_bytes = fga_dev_peak_bytes(fga_session_device(me->Z));
   me->phase2_s = fga_wall() - t0;
+  /* a streamed run: this rank's stretch of the .1aln, as soon as the ranks before it have written theirs (every rank takes
+     its turn, whatever happened to it) */
+  me->nlive = me->cover = 0; me->write_s = 0.;
+  if (M->want_stream)
+    { pthread_mutex_lock(&M->mu);
+      while (M->turn != r)
+        pthread_cond_wait(&M->cv_turn,&M->mu);
+      pthread_mutex_unlock(&M->mu);
+      if (me->streams && M->stream != NULL && me->fil != NULL && !multi_failed(M))
+        { const double tw = fga_wall();
+          int64_t i;
+          me->nlive = me->fil->naln;
+          for (i = 0; i < me->fil->naln; i++)
+            me->cover += me->fil->alns[i].aepos - me->fil->alns[i].abpos;
+          fga_aln_writer_threads(P->nthreads > 8 ? P->nthreads : 8);
+          if (fga_aln_stream_append(M->stream,me->fil))
+            multi_fail(M,"output");
+          me->write_s = fga_wall() - tw;
+        }
+      pthread_mutex_lock(&M->mu);
+      M->turn = r + 1;
+      pthread_cond_broadcast(&M->cv_turn);
+      pthread_mutex_unlock(&M->mu);
+    }
   STEP_BARRIER(M);
 }
 
@@ -323,7 +390,7 @@ void fga_multi_close(fga_multi *M)
     }
   if (M->sync_made)
     { pthread_barrier_destroy(&M->bar);
-      pthread_cond_destroy(&M->cv_cmd); pthread_cond_destroy(&M->cv_done);
+      pthread_cond_destroy(&M->cv_cmd); pthread_cond_destroy(&M->cv_done); pthread_cond_destroy(&M->cv_turn);
       pthread_mutex_destroy(&M->mu);
     }
   fga_session_close(M->single);
@@ -405,7 +472,7 @@ int fga_multi_open(const char *root1, const char *root2, const fga_run_params *P
       goto fail;
     }
   pthread_mutex_init(&M->mu,NULL);
-  pthread_cond_init(&M->cv_cmd,NULL); pthread_cond_init(&M->cv_done,NULL);
+  pthread_cond_init(&M->cv_cmd,NULL); pthread_cond_init(&M->cv_done,NULL); pthread_cond_init(&M->cv_turn,NULL);
   pthread_barrier_init(&M->bar,NULL,ndev);
   M->sync_made = 1;
   M->done_gen = 1;                        /* (the open counts as command 0: done_gen is set to 0 when all ranks are through) */
@@ -514,6 +581,9 @@ int fga_multi_run(fga_multi *M, const fga_run_params *P, fga_run_stats *S)
   M->Pr.nthreads = (P->nthreads > 0 ? P->nthreads : 8) / ndev;
   if (M->Pr.nthreads < 4) M->Pr.nthreads = 4;
   if (M->have_masks) M->Pr.soft_mask = 1;
+  M->Pout = *P;
+  M->want_stream = fga_run_can_stream(P);
+  M->stream = NULL; M->turn = 0;
   multi_command(M,CMD_RUN,1);
   if (M->failed)
     { fga_set_error("fga_multi_run (%d devices): %s",ndev,M->err);
@@ -528,6 +598,24 @@ int fga_multi_run(fga_multi *M, const fga_run_params *P, fga_run_stats *S)
     }
   M->have_cost = 1;
 
+  /* ---- a streamed run: every rank has appended its stretch; the footer ---- */
+  if (M->stream != NULL)
+    { const double tw = fga_wall();
+      st.load_s = M->load_s;
+      sum_stats(&st,M->R,ndev);
+      for (r = 0; r < ndev; r++)
+        { st.nlive += M->R[r].nlive; st.cover += M->R[r].cover;
+          if (M->R[r].write_s > st.write_s) st.write_s = M->R[r].write_s;
+        }
+      if (fga_aln_stream_close(M->stream,1))
+        { M->stream = NULL;
+          goto done;
+        }
+      M->stream = NULL;
+      st.write_s += fga_wall() - tw;
+      st.streamed_parts = ndev;
+    }
+  else
   /* ---- finish on rank 0's session: the ranks' filtered runs by A contig, the reference's tie order, one .1aln ---- */
   { const fga_alns **sets = calloc(ndev,sizeof(fga_alns *));
     fga_run_params Pf = *P;
@@ -564,6 +652,8 @@ int fga_multi_run(fga_multi *M, const fga_run_params *P, fga_run_stats *S)
   rc = 0;
 
 done:
+  if (M->stream != NULL)                  /* (a failed run leaves no file) */
+    { fga_aln_stream_close(M->stream,0); M->stream = NULL; }
   for (r = 0; r < ndev; r++)              /* the records have been written: only the session stays */
     { fga_alns_free(M->R[r].fil); M->R[r].fil = NULL; }
   if (S != NULL) *S = st;

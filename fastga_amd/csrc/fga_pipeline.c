@@ -32,6 +32,32 @@ typedef struct
 
 static int reference_order(fga_session *Z, const fga_run_params *P, fga_alns *fin);
 
+/* can the .1aln of this run be written as a stream of A-contig stretches (fga_aln_stream_*)?  Not with PAF / PSL output
+   (which wants the whole set), not the text form; FGA_STREAM_PARTS=0 switches it off */
+int fga_run_can_stream(const fga_run_params *P)
+{ return P->out_path != NULL && P->paf_path == NULL &&
+         !(getenv("FGA_ALN_ASCII") != NULL && atoi(getenv("FGA_ALN_ASCII")) != 0) &&
+         !(getenv("FGA_STREAM_PARTS") != NULL && atoi(getenv("FGA_STREAM_PARTS")) == 0);
+}
+
+/* FGA_STREAM_PARTS=2: stream whatever the balance of the contiguous deal (tests) */
+int fga_run_stream_forced(void)
+{ return getenv("FGA_STREAM_PARTS") != NULL && atoi(getenv("FGA_STREAM_PARTS")) >= 2; }
+
+int fga_session_stream_open(fga_session *Z, const fga_run_params *P, fga_aln_stream **out)
+{ char *n1 = NULL, *n2 = NULL;
+  int rc;
+  if (asprintf(&n1,"%s",Z->g1->path) < 0) n1 = NULL;
+  if (!Z->self && asprintf(&n2,"%s",Z->g2->path) < 0) n2 = NULL;
+  rc = fga_aln_stream_open(P->out_path,Z->g1,Z->self ? NULL : Z->g2,100,n1 ? n1 : "genome1",n2,
+                           P->command_line ? P->command_line : "FastGA",out);
+  free(n1); free(n2);
+  return rc;
+}
+
+int fga_session_reference_order(fga_session *Z, const fga_run_params *P, fga_alns *set)
+{ return P->reference_threads > 0 ? reference_order(Z,P,set) : 0; }
+
 typedef struct
   { const fga_alns *in;
     fga_alns *out;
@@ -685,6 +711,7 @@ done:
 /* A-contig parts of the seeds of this session (weights: seeds per A contig, summed over ranks by the caller when there
    are several): see fga_partition_contigs */
 int fga_session_nctg(const fga_session *Z) { return Z->x1->nctg; }
+const int *fga_session_contig_perm(const fga_session *Z) { return Z->x1->perm; }
 
 int fga_session_strand_counts(const fga_session *Z, int64_t *counts)
 { if (Z == NULL || counts == NULL)
@@ -783,9 +810,7 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
       /* The .1aln as a stream: with the A contigs dealt to the parts in ORIGINAL order (the output's primary order) part p's
          records all come before part p+1's, so they are filtered, ordered, formatted and written while the next part's
          kernels run; the finish is the footer.  Not with PAF / PSL output (which wants the whole set) or the text form */
-      streaming = P->out_path != NULL && P->paf_path == NULL &&
-                  !(getenv("FGA_ALN_ASCII") != NULL && atoi(getenv("FGA_ALN_ASCII")) != 0) &&
-                  !(getenv("FGA_STREAM_PARTS") != NULL && atoi(getenv("FGA_STREAM_PARTS")) == 0);
+      streaming = fga_run_can_stream(P);
       if (fga_seeds_contig_histogram(dev,seeds,nctg,cnt))
         goto done;
       if (streaming)
@@ -802,7 +827,7 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
           for (j = 0; j < nctg; j++)
             if ((sum[select[j]] += cnt[j]) > big) big = sum[select[j]];
           free(sum);
-          if (big > limit + limit/2 && big > n/nparts + n/(2*nparts))     /* a stretch half again over a pass's seeds (one */
+          if (big > limit + limit/2 && big > n/nparts + n/(2*nparts) && !fga_run_stream_forced())     /* a stretch half again over a pass's seeds (one */
             streaming = 0;                                                /* contig dominates): the balanced deal instead  */
         }
       if (!streaming && fga_partition_contigs(cnt,nctg,nparts,select))
@@ -817,14 +842,7 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
           goto done;
         }
       if (streaming)
-        { char *n1 = NULL, *n2 = NULL;
-          int rc;
-          if (asprintf(&n1,"%s",Z->g1->path) < 0) n1 = NULL;
-          if (!Z->self && asprintf(&n2,"%s",Z->g2->path) < 0) n2 = NULL;
-          rc = fga_aln_stream_open(P->out_path,Z->g1,Z->self ? NULL : Z->g2,100,n1 ? n1 : "genome1",n2,
-                                   P->command_line ? P->command_line : "FastGA",&stream);
-          free(n1); free(n2);
-          if (rc) goto done;
+        { if (fga_session_stream_open(Z,P,&stream)) goto done;
           pthread_mutex_init(&chain.mu,NULL); pthread_cond_init(&chain.cv,NULL);
           chain.turn = 0; chain.failed = 0;
           chain_made = 1;

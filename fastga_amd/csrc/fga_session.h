@@ -31,4 +31,9 @@ int fga_session_open_impl(const char *root1, const char *root2, int device, int 
                           const fga_mask_args *masks, const fga_shared_inputs *shared, fga_session **out);
 int fga_gix_files_exist(const char *root);
 
+/* the .1aln as a stream of A-contig stretches (fga_session_run's parts, fga_multi_run's ranks): whether this run's output
+   can be one, the stream on the session's genomes, and a filtered set put into the reference's tie order */
+int fga_run_can_stream(const fga_run_params *P);
+int fga_run_stream_forced(void);
+
 #endif

@@ -468,6 +468,11 @@ class Session:
     def nctg(self):
         return self.L.fga_session_nctg(self.h)
 
+    def contig_perm(self):
+        """original index of every A contig of the (length-sorted) index order"""
+        p = self.L.fga_session_contig_perm(self.h)
+        return np.array([p[j] for j in range(self.nctg)], dtype=np.int32)
+
     def merge(self, prm, stats, prefix_begin=0, prefix_end=0):
         """phase 1 over a 12-mer prefix range -> Seeds (device resident)"""
         h = C.c_void_p()
@@ -545,6 +550,16 @@ class Session:
         arr = (C.POINTER(Alns) * max(len(filtered), 1))(*filtered)
         check(self.L.fga_session_finish_filtered(self.h, C.byref(prm), arr, len(filtered), C.byref(stats)),
               "session finish (filtered sets)")
+
+    def stream_open(self, prm):
+        """fga_session_stream_open: the .1aln of this session's genomes as a stream (prm: out_path, command_line)"""
+        h = C.c_void_p()
+        check(self.L.fga_session_stream_open(self.h, C.byref(prm), C.byref(h)), "stream open")
+        return h
+
+    def reference_order(self, prm, filtered):
+        """one part's filtered set into the reference's tie order (in place)"""
+        check(self.L.fga_session_reference_order(self.h, C.byref(prm), filtered), "reference order")
 
     def sync(self):
         check(self.L.fga_dev_sync(self.L.fga_session_device(self.h)), "sync")

@@ -220,6 +220,7 @@ def _declare(L):
         "fga_session_seed_bytes": (i32, [vp]),
         "fga_session_bases": (i64, [vp, i32]),
         "fga_session_nctg": (i32, [vp]),
+        "fga_session_contig_perm": (P(i32), [vp]),
         "fga_session_merge": (i32, [vp, P(RunParams), i64, i64, P(vp), P(RunStats)]),
         "fga_session_align": (i32, [vp, P(RunParams), vp, P(P(Alns)), P(RunStats)]),
         "fga_session_finish": (i32, [vp, P(RunParams), P(P(Alns)), i32, P(RunStats)]),
@@ -246,6 +247,8 @@ def _declare(L):
         "fga_alns_merge_filtered": (i32, [P(P(Alns)), i32, P(P(Alns))]),
         "fga_alns_merge_filtered_mt": (i32, [P(P(Alns)), i32, i32, P(P(Alns))]),
         "fga_session_finish_filtered": (i32, [vp, P(RunParams), P(P(Alns)), i32, P(RunStats)]),
+        "fga_session_stream_open": (i32, [vp, P(RunParams), P(vp)]),
+        "fga_session_reference_order": (i32, [vp, P(RunParams), P(Alns)]),
         "fga_shim_New_Work_Data": (vp, []),
         "fga_shim_Free_Work_Data": (None, [vp]),
         "fga_shim_New_Align_Spec": (vp, [C.c_double, i32, P(C.c_float), i32]),

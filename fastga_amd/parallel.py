@@ -228,14 +228,18 @@ def prefix_cuts(ses, nshards):
     return cuts
 
 
-def run_parts_on_one_gpu(ses, nparts, weights=None, **prm_kwargs):
+def run_parts_on_one_gpu(ses, nparts, weights=None, stream=True, **prm_kwargs):
     """The sharded run's C-ABI calls on ONE GPU, rank by rank in sequence (merge of each prefix range, histogram,
     partition, split, import of each part's pieces, align, finish over all parts): the parity check of the multi-GPU
     path for any number of parts.  The staging buffers come from fga_dev_malloc (no torch in this process).
     weights: what the contigs are dealt to the parts by (per A contig, index order) -- None: the seed counts, as the first run of
     a fga_multi session does; the `contig_waves` a previous call returned: the wave steps of every contig's units, as the
-    session's later runs do."""
+    session's later runs do.
+    stream: like fga_multi_run, deal the contigs in ORIGINAL order when that deal's heaviest part is within 1.25 x of the balanced
+    one's, and have every "rank" put its own records into the reference's tie order and append them to the .1aln
+    (fga_aln_stream_*); what is left for the finish is the footer."""
     import time
+    from .lib import check
     prm = ses.params(**prm_kwargs)
     st = ses.new_stats()
     cuts = prefix_cuts(ses, nparts)
@@ -254,7 +258,17 @@ def run_parts_on_one_gpu(ses, nparts, weights=None, **prm_kwargs):
         # buffers alive side by side, so late ranks may have to ask the driver for a fresh region (a real rank never does)
         per_rank["merge_driver_alloc_s"].append(ses.L.fga_dev_driver_seconds() - w)
         merged.append((seeds, ses.dev_malloc(16 * seeds.count)))
-    select = partition_contigs(hist if weights is None else np.asarray(weights, dtype=np.int64), nparts)
+    wts = hist if weights is None else np.asarray(weights, dtype=np.int64)
+    select = partition_contigs(wts, nparts)
+    streamed = False
+    if stream and prm.out_path and not prm.paf_path:
+        inord = partition_contigs_in_order(wts, ses.contig_perm(), nparts)
+        lmax = np.bincount(select, weights=wts, minlength=nparts).max()
+        omax = np.bincount(inord, weights=wts, minlength=nparts).max()
+        if omax <= lmax + lmax // 4 + 1:
+            select, streamed = inord, True
+    per_rank["order_s"], per_rank["append_s"] = [], []
+    out_stream = ses.stream_open(prm) if streamed else None
     contig_waves = np.zeros(ses.nctg, dtype=np.int64)
     for seeds, buf in merged:
         t = time.time()
@@ -281,10 +295,21 @@ def run_parts_on_one_gpu(ses, nparts, weights=None, **prm_kwargs):
         per_rank["filter_s"].append(time.time() - t)
         per_rank["records"].append(int(raws[-1].contents.naln))
         ses.free_alns(raw)
+        if streamed:                                          # "rank p": the tie order of its records, its stretch of the file
+            t = time.time()
+            ses.reference_order(prm, raws[-1])
+            per_rank["order_s"].append(time.time() - t)
+            t = time.time()
+            check(ses.L.fga_aln_stream_append(out_stream, raws[-1]), "stream append")
+            per_rank["append_s"].append(time.time() - t)
     for buf in sends:
         ses.dev_free(buf)
     t = time.time()
-    ses.finish_filtered(prm, st, raws)
+    if streamed:
+        check(ses.L.fga_aln_stream_close(out_stream, 1), "stream close")
+        st.nlive = sum(int(r.contents.naln) for r in raws)
+    else:
+        ses.finish_filtered(prm, st, raws)
     finish_s = time.time() - t
     gather_bytes = [int(r.contents.naln) * 56 + int(r.contents.ntrace) for r in raws]
     for r in raws:
@@ -296,5 +321,6 @@ def run_parts_on_one_gpu(ses, nparts, weights=None, **prm_kwargs):
     d["sent_bytes"] = [[16 * int(offs[r][p + 1] - offs[r][p]) for p in range(nparts)] for r in range(nparts)]   # [from][to]
     d["gather_bytes"] = gather_bytes
     d["finish_s"] = finish_s
+    d["streamed"] = streamed
     d["contig_waves"] = contig_waves
     return d

@@ -516,6 +516,7 @@ int64_t  fga_session_table_bytes(const fga_session *s);   /* N1*E1 + N2*E2      
 int      fga_session_seed_bytes(const fga_session *s);    /* 1 + IBYTE + JBYTE of the reference seed */
 int64_t  fga_session_bases(const fga_session *s, int which);
 int      fga_session_nctg(const fga_session *s);          /* A contigs of the index (the partition's domain) */
+const int *fga_session_contig_perm(const fga_session *s);  /* [nctg] original index of A contig j of the index order  */
 int      fga_session_prefix_cuts(fga_session *s, int nshards, int64_t *cuts /* nshards+1 */);
 /* per-strand seed counts of the A contigs (2 * fga_session_nctg values) that fga_session_merge has accumulated when
    prm->reference_threads > 0; ranks of a sharded run add theirs up (all-reduce) and hand the sums to the rank that finishes */
@@ -536,6 +537,13 @@ int      fga_session_finish(fga_session *s, const fga_run_params *prm, const fga
    the rank that produced it): merge by A contig + phase 3 */
 int      fga_session_finish_filtered(fga_session *s, const fga_run_params *prm, const fga_alns *const *filtered, int nsets,
                                      fga_run_stats *stats);
+/* finish as a stream, for parts that are contiguous stretches of A contigs in their original order
+   (fga_partition_contigs_in_order): the stream on the session's genomes (prm: out_path, command_line), and one part's filtered
+   set put into the reference's tie order (reference_threads > 0; the session's strand counts must be those of ALL prefix
+   ranges: fga_session_set_strand_counts) -- then fga_aln_stream_append part by part, fga_aln_stream_close.  What
+   fga_session_run does with its passes and fga_multi_run with its ranks; replaces la_merge (FastGA.c:3991-4133) */
+int      fga_session_stream_open(fga_session *s, const fga_run_params *prm, fga_aln_stream **out);
+int      fga_session_reference_order(fga_session *s, const fga_run_params *prm, fga_alns *set);
 
 #ifdef __cplusplus
 }

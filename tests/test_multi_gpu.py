@@ -20,6 +20,12 @@ def _view(path):
     return H.oneview(path)
 
 
+def _sans_date(path):
+    """the file's bytes with the provenance line's time stamp blanked (two runs may straddle a second)"""
+    import re
+    return re.sub(rb"\d{4}-\d\d-\d\d_\d\d:\d\d:\d\d", b"D", open(path, "rb").read())
+
+
 def _keep(lines):
     return [ln for ln in lines if ln[0] not in "!<"]
 
@@ -242,6 +248,32 @@ def test_multi_session_runs_warm_and_reweighs_its_parts(toy_pair, tmp_path, mode
                 out = os.path.join(w, "s6.1aln")
                 M.run(out_path=out, nthreads=8, reference_threads=8, symmetric=True, freq=6)
                 assert _keep(_view(out)) == ref6, devices
+        finally:
+            M.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["pair", "self"])
+def test_multi_ranks_stream_their_stretches_of_the_1aln(toy_pair, tmp_path, mode, monkeypatch):
+    """with the A contigs dealt to the ranks in original order every rank puts its own records into the reference's tie order
+    and appends them to the .1aln when the ranks before it have (fga_aln_stream_*): the file is the one rank 0 writes from
+    the gathered records, byte for byte, and the reference's line for line"""
+    from fastga_amd import device as D
+    d, ra, rb = toy_pair
+    w = str(tmp_path)
+    b = None if mode == "self" else rb
+    ref = _reference(ra, b, w)
+    for devices in [dl for dl in _device_lists() if len(dl) > 1][:4]:
+        M = D.Multi(ra, b, devices=devices, nthreads=8)
+        try:
+            for k, (env, want) in enumerate((("2", len(devices)), ("0", 0), ("2", len(devices)))):
+                monkeypatch.setenv("FGA_STREAM_PARTS", env)       # 2: whatever the balance of the contiguous deal
+                out = os.path.join(w, "t%d.1aln" % k)
+                st = M.run(out_path=out, nthreads=8, reference_threads=8, command_line="FastGA test")
+                assert st["streamed_parts"] == want, (devices, env)
+                assert _keep(_view(out)) == ref, (devices, env)
+            one = [_sans_date(os.path.join(w, "t%d.1aln" % k)) for k in range(3)]
+            assert one[0] == one[1] == one[2], devices
         finally:
             M.close()
 

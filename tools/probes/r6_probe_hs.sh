@@ -18,6 +18,6 @@ for k in ("human_scale", "human_scale_10pct"):
     print("   sort", {a: h["sort"][a] for a in ("passes", "kernel_ms", "frac")}, "cold", h["cold"]["seconds"], h["cold"].get("of_which_driver_alloc_s"), "open", h["upload_and_2_index_builds_s"], "eq", h.get("counts_equal_reference"), "ref", h.get("reference"))
     if "projected_8gpu" in h:
         p = h["projected_8gpu"]
-        print("   proj", {a: p[a] for a in ("seconds", "phase1_s_max", "phase2_s_max", "finish_s", "part_imbalance_extend", "part_imbalance_seeds", "records_equal_one_gpu_run", "first_run_of_a_session")})
+        print("   proj", {a: p[a] for a in ("seconds", "phase1_s_max", "phase2_s_max", "finish_s", "streamed_finish", "appends_after_slowest_rank_s", "part_imbalance_extend", "part_imbalance_seeds", "records_equal_one_gpu_run", "first_run_of_a_session")})
 PY
 grep -i "timing\|error\|fga" $o/hs.err | tail -${TLINES:-5}
