@@ -569,7 +569,8 @@ extern "C" int fga_seeds_download(const fga_dseeds *S, fga_seed *host, int64_t m
 extern "C" void fga_seeds_free(fga_dseeds *S)
 { if (S == NULL) return;
   fga_dev_enter(S->dev);
-  fga_dev_release(S->dev,S->slot,S->seeds);
+  if (S->slot != SLOT_BORROWED)
+    fga_dev_release(S->dev,S->slot,S->seeds);
   fga_dev_release(S->dev,SLOT_VALID,S->valid);
   fga_pool_free(S->dcount);
   free(S);

@@ -112,6 +112,7 @@ void fga_dgix_free_views(fga_dgix *D);
 //   bctg       : B contig | (B entry's own sign bit) << 30 | (C-stream flag) << 31
 enum { SLOT_SEEDS = 0, SLOT_SORT0, SLOT_SORT1, SLOT_HIST, SLOT_TILES, SLOT_CELLS, SLOT_TRACE, SLOT_ALNS,
        SLOT_TBYTES, SLOT_MISC, SLOT_VALID, SLOT_STAGE, SLOT_COUNT };
+#define SLOT_BORROWED (-2)      // fga_dseeds.slot: the seeds are a stretch of somebody else's buffer (fga_seeds_view): not released
 void *fga_dev_acquire(fga_dev *dev, int slot, size_t bytes);   // a work buffer (the slot names its purpose); NULL on failure
 void  fga_dev_release(fga_dev *dev, int slot, void *ptr);
 void *fga_dev_pinned(fga_dev *dev, size_t bytes);              // host pinned staging, grow-only

@@ -820,6 +820,9 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
             { fga_set_error("out of memory");
               goto done;
             }
+          /* (equal stretches: a smaller last pass would shorten the host work behind its kernels -- 1.27 -> 1.24 s on the
+             3 Gbp pair at 1 % -- but a pass's kernel time has a floor, the serial chain of its longest alignment, and at 10 %
+             the small pass sits on it: 2.84 -> 3.01 s) */
           if (fga_partition_contigs_in_order(cnt,Z->x1->perm,nctg,nparts,select))
             { free(sum);
               goto done;
@@ -851,8 +854,7 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
         { const void *src = (const char *) stage + (size_t) poff[p]*sizeof(fga_seed);
           const int64_t c = poff[p+1] - poff[p];
           fga_dseeds *part = NULL;
-          if (fga_seeds_import(dev,&src,&c,1,&part)) goto done;
-          fga_note("run: part imported",tstart);
+          if (fga_seeds_view(dev,src,c,&part)) goto done;        /* (the piece itself: the sort's first pass reads it once) */
           if (fga_session_align(Z,P,part,&raw[p],&st)) goto done;
           fga_note("run: part aligned",tstart);
           /* this part's records through the redundancy filter in the background (every contig pair's records are in the

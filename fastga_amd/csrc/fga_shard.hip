@@ -196,6 +196,39 @@ extern "C" int fga_seeds_import(fga_dev *dev, const void *const *src_device, con
                                 fga_dseeds **out)
 { return seeds_import(dev,src_device,NULL,counts,npieces,out); }
 
+// a seed buffer that IS a dense stretch of device memory the caller keeps (one part's piece of a fga_seeds_split_to buffer on
+// the same device): nothing is copied, fga_seeds_free leaves the stretch alone -- the caller releases it when the consumers
+// (fga_session_align reads its seeds once, in the sort's first pass) are through
+extern "C" int fga_seeds_view(fga_dev *dev, const void *src_device, int64_t count, fga_dseeds **out)
+{ *out = NULL;
+  if (dev == NULL || count < 0 || (count > 0 && src_device == NULL))
+    { fga_set_error("fga_seeds_view: bad argument");
+      return 1;
+    }
+  FGA_HIP(fga_dev_enter(dev));
+  fga_dseeds *S = (fga_dseeds *) calloc(1,sizeof(fga_dseeds));
+  if (S == NULL)
+    { fga_set_error("out of memory");
+      return 1;
+    }
+  S->dev = dev; S->capacity = S->phys_capacity = count; S->count = S->phys_count = count; S->tseed = 0;
+  S->seeds = (fga_seed *) src_device;
+  S->slot = SLOT_BORROWED;
+  hipError_t e = fga_dmalloc(&S->dcount,4*sizeof(unsigned long long));
+  if (e == hipSuccess)
+    { unsigned long long hc[4] = { (unsigned long long) count, 0ull, 0ull, 0ull };
+      e = hipMemcpyAsync(S->dcount,hc,sizeof(hc),hipMemcpyHostToDevice,dev->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
+    }
+  if (e != hipSuccess)
+    { fga_set_error("fga_seeds_view: %s",hipGetErrorString(e));
+      fga_seeds_free(S);
+      return 1;
+    }
+  *out = S;
+  return 0;
+}
+
 // the same for pieces that lie in the memory of OTHER devices of the node (src_device_id[k] = HIP device of piece k): the
 // receiving side of the seed exchange of fga_run_multi, hipMemcpyPeerAsync over xGMI
 extern "C" int fga_seeds_import_peer(fga_dev *dev, const void *const *src_device, const int *src_device_id,

@@ -229,6 +229,7 @@ def _declare(L):
         "fga_partition_contigs_in_order": (i32, [P(i64), P(i32), i32, i32, P(i32)]),
         "fga_seeds_split_to": (i32, [vp, vp, P(i32), i32, i32, vp, P(i64)]),
         "fga_seeds_import": (i32, [vp, P(vp), P(i64), i32, P(vp)]),
+        "fga_seeds_view": (i32, [vp, vp, i64, P(vp)]),
         "fga_seeds_device_ptr": (vp, [vp]),
         "fga_merge_prefix_cuts": (i32, [vp, vp, vp, i32, P(i64)]),
         "fga_session_prefix_cuts": (i32, [vp, i32, P(i64)]),

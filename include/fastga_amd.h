@@ -444,6 +444,9 @@ int  fga_seeds_split_to(fga_dev *dev, const fga_dseeds *seeds, const int *select
                         void *dst_device, int64_t *part_off /* host, nparts+1 */);
 /* a seed buffer made of `npieces` runs of 16-byte records that already are in DEVICE memory (the receive buffer) */
 int  fga_seeds_import(fga_dev *dev, const void *const *src_device, const int64_t *counts, int npieces, fga_dseeds **out);
+/* one dense stretch of device memory the caller keeps (a part's piece of its own fga_seeds_split_to buffer) as a seed buffer:
+   nothing copied, fga_seeds_free leaves the stretch alone */
+int  fga_seeds_view(fga_dev *dev, const void *src_device, int64_t count, fga_dseeds **out);
 const void *fga_seeds_device_ptr(const fga_dseeds *seeds);
 /* 12-mer prefix ranges [cuts[r], cuts[r+1]) of equal merge cost: the phase-1 shards (FastGA.c:2291-2321) */
 int  fga_merge_prefix_cuts(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2 /* NULL: self */, int nshards,
