@@ -348,6 +348,11 @@ def main():
                     out[key] = human_scale_run(D, workload, shared, threads, div, project=(div == 0.01))
                 except Exception as e:            # never takes the bench line down
                     out[key] = {"error": str(e)}
+            if os.environ.get("FGA_BENCH_SELF_1G", "1") != "0":
+                try:
+                    out["self_scale"] = self_scale_run(D, workload, shared, threads)
+                except Exception as e:
+                    out["self_scale"] = {"error": str(e)}
     # N > 1: parity of the step that was timed (its .1aln against the same comparison on one GPU, record lines in sequence),
     # the cold form of the same entry (fga_run_multi = open + run + close), and the comparison north_star names -- ONE 3 Gbp x
     # 3 Gbp pair over the N GPUs (strong scaling) beside the weak-scaled `value` above.  All on rank 0; the others wait.
@@ -609,6 +614,53 @@ def project_8gpu(st8, nparts):
             "extend_kernel_ms": [round(x, 1) for x in ext], "wave_steps": pr["wave_steps"],
             "part_imbalance_extend": max(ext) / (sum(ext) / len(ext)) if sum(ext) > 0 else None,
             "part_imbalance_seeds": max(st8["part_seed_counts"]) / (sum(st8["part_seed_counts"]) / nparts)}
+
+
+def self_scale_run(D, workload, workdir, threads, mbp=1000.0):
+    """BASELINE configs[2]'s shape at its stated size: a repeat-heavy 1 Gbp genome (30 % repeats, 2 % tandem arrays, 85 % of the
+    repeats soft-masked) against ITSELF with -M, index built on the device; the warm comparison of a session, the seed merge's
+    roofline block in self mode (every table entry once in its on-disk width; every seed once in the reference's record width --
+    a self run reports half of the seeds it writes, FastGA.c:1906)."""
+    d = os.path.join(workdir, "self_scale")
+    os.makedirs(d, exist_ok=True)
+    t = time.time()
+    ra = workload.build_config3(d, mbp=mbp, threads=threads, gix=False, name="A")
+    prep = time.time() - t
+    t = time.time()
+    ses = D.Session(ra, None, nthreads=threads)
+    opened = time.time() - t
+    try:
+        kw = dict(out_path=os.path.join(d, "self.1aln"), nthreads=threads, command_line="bench.py FastGA self", soft_mask=True,
+                  reference_threads=min(32, threads))
+        t = time.time()
+        st1 = ses.run(**kw)
+        first = time.time() - t
+        t = time.time()
+        st = ses.run(**kw)
+        dt = time.time() - t
+        alg = ses.table_bytes + 2 * st["nseeds"] * ses.seed_bytes
+        ach = alg / (st["merge_kernel_ms"] * 1e-3) / 1e9
+        res = {"workload": f"synthetic repeat-heavy {mbp:g} Mbp genome against itself, soft mask on (BASELINE configs[2]), 1 GPU",
+               "value": mbp * 1e-3 / dt, "unit": "Gbp-pair/s", "seconds": round(dt, 2), "first_run_seconds": round(first, 2),
+               "parts": int(st["nparts"]), "seeds": int(st["nseeds"]), "hits": int(st["nhits"]), "alignments": int(st["nalns"]),
+               "records": int(st["nlive"]),
+               "stage_s": {k: round(st[k], 2) for k in ("merge_s", "sort_s", "chain_s", "extend_s", "filter_s", "write_s")},
+               "kernel_ms": {"merge": round(st["merge_kernel_ms"], 2), "sort": round(st["sort_kernel_ms"], 1),
+                             "extend": round(st["extend_kernel_ms"], 1)},
+               "roofline": {"kernel": "seed merge launch, self mode", "bound": "hbm", "algorithmic_bytes": int(alg),
+                            "stored_bytes": int(ses.table_bytes + 2 * st["nseeds"] * 16),
+                            "kernel_ms": st["merge_kernel_ms"], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": ach / HBM_PEAK_GBS,
+                            "note": "the kernel stores 16-byte seeds (stored_bytes); the reference's record is seed_bytes wide"},
+               "sort": sort_block(st["sort_keys"], st["sort_passes"], st["sort_kernel_ms"]),
+               "extend": extend_block(st),
+               "hbm_peak_gib": round(st["hbm_peak_bytes"] / 2**30, 1),
+               "genome_s": round(prep, 1), "upload_and_index_build_s": round(opened, 2)}
+        if st1["nlive"] != st["nlive"]:
+            res["error"] = "the two comparisons of the session differ"
+        return res
+    finally:
+        ses.close()
 
 
 def human_scale_run(D, workload, workdir, threads, div=0.01, project=False):

@@ -672,14 +672,40 @@ __device__ __forceinline__ int walk_tile(const merge_args &A, tile_lds<T2CAP> &S
                       if (MODE == MODE_SELF && j >= i)
                         j += 1;
                     }
+                  else if (MODE != MODE_FLIP)
+                    { // the k-th member whose mask byte is below plen (the entry itself left out in a self comparison), eight mask
+                      // bytes per LDS read like the count that made k < (members that stay): the k-th one lies inside the run,
+                      // whatever the bytes behind its end say
+                      const uint32_t kk = (uint32_t) plen * 0x01010101u;
+                      for (;;)
+                        { uint64_t w;
+                          __builtin_memcpy(&w,mB + j,8);
+                          uint32_t bl = ((((uint32_t) w | 0x80808080u) - kk) & 0x80808080u) ^ 0x80808080u;      // 0x80 where a byte stays
+                          uint32_t bh = ((((uint32_t) (w >> 32) | 0x80808080u) - kk) & 0x80808080u) ^ 0x80808080u;
+                          if (MODE == MODE_SELF)
+                            { const uint32_t d = (uint32_t) (i - j);
+                              if (d < 4u)      bl &= ~(0x80u << (8*d));
+                              else if (d < 8u) bh &= ~(0x80u << (8*(d-4)));
+                            }
+                          const int cl = __popc(bl), ch = __popc(bh);
+                          if (k >= cl + ch)
+                            { k -= cl + ch; j += 8;
+                              continue;
+                            }
+                          uint32_t m = bl;
+                          if (k >= cl) { k -= cl; m = bh; j += 4; }
+                          const uint32_t m1 = m & (m-1), m2 = m1 & (m1-1), m3 = m2 & (m2-1);       // flags with the lowest 1 / 2 / 3 cleared
+                          m = k == 0 ? m : (k == 1 ? m1 : (k == 2 ? m2 : m3));
+                          j += (__ffs((int) m) - 1) >> 3;
+                          break;
+                        }
+                    }
                   else
                     { const int mlen = A.soft_mask ? plen : 41;
                       for (;; j++)
                         { if (A.soft_mask && (int) mB[j] >= mlen)
                             continue;
-                          if (MODE == MODE_FLIP && (lds_c(cB,cw2,j) & A.sign2))
-                            continue;
-                          if (MODE == MODE_SELF && j == i)
+                          if (lds_c(cB,cw2,j) & A.sign2)
                             continue;
                           if (k == 0)
                             break;
