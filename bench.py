@@ -596,14 +596,14 @@ def project_8gpu(st8, nparts):
         # ranks before it have (all ranks are threads of one process: no gather); what follows the last append is the footer
         done = 0.0
         for p in range(nparts):
-            ready = max(phase1) + link / (XGMI_LINK_GBS * 1e9) + phase2[p] + pr["order_s"][p]
+            ready = max(phase1) + link / (XGMI_LINK_GBS * 1e9) + phase2[p] + pr["order_s"][p] + pr["format_s"][p]
             done = max(ready, done) + pr["append_s"][p]
         tail = done - (max(phase1) + link / (XGMI_LINK_GBS * 1e9) + max(phase2))
         seconds = done + st8["finish_s"]
         gather = 0.0
     return {"seconds": seconds,
             "streamed_finish": bool(st8.get("streamed")), "appends_after_slowest_rank_s": None if tail is None else round(tail, 3),
-            "order_s": [round(x, 3) for x in pr.get("order_s", [])], "append_s": [round(x, 3) for x in pr.get("append_s", [])],
+            "order_s": [round(x, 3) for x in pr.get("order_s", [])], "format_s": [round(x, 3) for x in pr.get("format_s", [])], "append_s": [round(x, 3) for x in pr.get("append_s", [])],
             "is": "a PROJECTION from 8 prefix ranges x 8 parts run one after the other on this GPU (index builds excluded: "
                   "each rank builds 1/8 of both tables); not a measurement on 8 GPUs",
             "phase1_s_max": round(max(phase1), 3), "phase1_s": [round(x, 3) for x in phase1],

@@ -618,90 +618,152 @@ struct fga_aln_stream
     int      fail;
   };
 
-static int stream_format_and_write(fga_aln_stream *S, const fga_alns *A)
-{ int nth = writer_threads, q, rc = 1;
-  bin_job job[WRITER_MAXT];
+/* a record set formatted for a stream, not yet in it: the formatter threads' buffers, every record's start relative to its
+   buffer, and what the footer counts.  Made by any thread (fga_aln_stream_format reads the stream, it does not change it),
+   committed in the file's order */
+struct fga_aln_block
+  { int      nth;
+    bin_job  job[WRITER_MAXT];
+    int64_t  naln, nR, maxT, totT;
+  };
+
+void fga_aln_block_free(fga_aln_block *K)
+{ int q;
+  if (K == NULL) return;
+  for (q = 0; q < WRITER_MAXT; q++) { free(K->job[q].B.p); free(K->job[q].rel); free(K->job[q].tmp); }
+  free(K);
+}
+
+/* list codes for the T and X lines, like the reference's files carry them once a type has > ~100 KB of list data.
+ * Opt-in (FGA_ALN_CODEC=1): training + encoding doubles the writer's time (it is inside the timed hot path) for a
+ * file 2.4x smaller; from 16 K trace points on, trained on the first set that is appended */
+static int stream_wants_codecs(void)
+{ return getenv("FGA_ALN_CODEC") != NULL && atoi(getenv("FGA_ALN_CODEC")) != 0; }
+
+static void stream_train(fga_aln_stream *S, const fga_alns *A)
+{ int64_t i, totT = 0;
+  if (S->trained) return;
+  S->trained = 1;
+  for (i = 0; i < A->naln; i++) totT += A->alns[i].tlen/2;
+  if (totT >= 16384 && stream_wants_codecs())
+    { uint64_t ht[256], hx[256];
+      int64_t k;
+      memset(ht,0,sizeof(ht)); memset(hx,0,sizeof(hx));
+      for (i = 0; i < A->naln; i++)
+        { const uint8_t *tr = A->tbytes + A->alns[i].toff;
+          const int64_t n = A->alns[i].tlen/2;
+          int okt = 1, okx = 1;
+          for (k = 1; k < n && (okt || okx); k++)
+            { const int dt = (int) tr[2*k+1] - (int) tr[2*k-1], dx = (int) tr[2*k] - (int) tr[2*k-2];
+              if (dt >= 128 || dt < -128) okt = 0;
+              if (dx >= 128 || dx < -128) okx = 0;
+            }
+          for (k = 1; k < n; k++)
+            { if (okt) ht[(uint8_t) ((int) tr[2*k+1] - (int) tr[2*k-1])] += 1;
+              if (okx) hx[(uint8_t) ((int) tr[2*k] - (int) tr[2*k-2])] += 1;
+            }
+        }
+      wcodec_build(ht,&S->ct);
+      wcodec_build(hx,&S->cx);
+    }
+}
+
+/* can a set be formatted before its turn in the file has come (fga_aln_stream_format on the thread that made it, the commit
+   when the sets before it are in)?  Not when list codes are wanted: they are trained on the first set of the FILE */
+int fga_aln_stream_preformats(const fga_aln_stream *S)
+{ return S != NULL && !S->fail && !stream_wants_codecs(); }
+
+int fga_aln_stream_format(const fga_aln_stream *S, const fga_alns *A, fga_aln_block **out)
+{ fga_aln_block *K;
   pthread_t th[WRITER_MAXT];
-  int64_t i, maxT = 0, totT = 0;
-  memset(job,0,sizeof(job));
+  int nth = writer_threads, q;
+  int64_t i, maxT = 0, totT = 0, nR = 0;
+  if (out != NULL) *out = NULL;
+  if (S == NULL || A == NULL || out == NULL)
+    { fga_set_error("fga_aln_stream_format: null argument");
+      return 1;
+    }
+  K = calloc(1,sizeof(fga_aln_block));
+  if (K == NULL) goto oom;
   for (i = 0; i < A->naln; i++)
     { int64_t tl = A->alns[i].tlen/2;
-      if (A->alns[i].flags & 1) S->nR += 1;
+      if (A->alns[i].flags & 1) nR += 1;
       if (tl > maxT) maxT = tl;
       totT += tl;
     }
-  if (maxT > S->maxT) S->maxT = maxT;
-  S->totT += totT;
-  /* list codes for the T and X lines, like the reference's files carry them once a type has > ~100 KB of list data.
-   * Opt-in (FGA_ALN_CODEC=1): training + encoding doubles the writer's time (it is inside the timed hot path) for a
-   * file 2.4x smaller; from 16 K trace points on, trained on the first set that is appended */
-  if (!S->trained)
-    { S->trained = 1;
-      if (totT >= 16384 && getenv("FGA_ALN_CODEC") != NULL && atoi(getenv("FGA_ALN_CODEC")) != 0)
-        { uint64_t ht[256], hx[256];
-          int64_t k;
-          memset(ht,0,sizeof(ht)); memset(hx,0,sizeof(hx));
-          for (i = 0; i < A->naln; i++)
-            { const uint8_t *tr = A->tbytes + A->alns[i].toff;
-              const int64_t n = A->alns[i].tlen/2;
-              int okt = 1, okx = 1;
-              for (k = 1; k < n && (okt || okx); k++)
-                { const int dt = (int) tr[2*k+1] - (int) tr[2*k-1], dx = (int) tr[2*k] - (int) tr[2*k-2];
-                  if (dt >= 128 || dt < -128) okt = 0;
-                  if (dx >= 128 || dx < -128) okx = 0;
-                }
-              for (k = 1; k < n; k++)
-                { if (okt) ht[(uint8_t) ((int) tr[2*k+1] - (int) tr[2*k-1])] += 1;
-                  if (okx) hx[(uint8_t) ((int) tr[2*k] - (int) tr[2*k-2])] += 1;
-                }
-            }
-          wcodec_build(ht,&S->ct);
-          wcodec_build(hx,&S->cx);
-        }
-    }
-  if (S->na + A->naln + 2 > S->acap)
-    { const int64_t nc = 2*(S->na + A->naln) + 1024;
-      int64_t *x = realloc(S->aoff,sizeof(int64_t)*nc);
-      if (x == NULL) goto oom;
-      S->aoff = x; S->acap = nc;
-    }
+  K->naln = A->naln; K->nR = nR; K->maxT = maxT; K->totT = totT;
   { long nc = sysconf(_SC_NPROCESSORS_ONLN);
     if (nc > 0 && nc < nth) nth = (int) nc;
     if (totT < 200000) nth = 1;
   }
+  K->nth = nth;
   for (q = 0; q < nth; q++)
-    { job[q].A = A;
-      job[q].i0 = (A->naln*q)/nth; job[q].i1 = (A->naln*(q+1))/nth;
-      job[q].rel = malloc(sizeof(int64_t)*(job[q].i1-job[q].i0+1));
-      job[q].tmp = malloc((size_t) (3*maxT + 64));
-      job[q].ct = S->ct.have ? &S->ct : NULL; job[q].cx = S->cx.have ? &S->cx : NULL;
-      if (job[q].rel == NULL || job[q].tmp == NULL) goto oom;
+    { bin_job *J = K->job + q;
+      J->A = A;
+      J->i0 = (A->naln*q)/nth; J->i1 = (A->naln*(q+1))/nth;
+      J->rel = malloc(sizeof(int64_t)*(J->i1-J->i0+1));
+      J->tmp = malloc((size_t) (3*maxT + 64));
+      J->ct = S->ct.have ? &S->ct : NULL; J->cx = S->cx.have ? &S->cx : NULL;
+      if (J->rel == NULL || J->tmp == NULL) goto oom;
     }
   { int started[WRITER_MAXT];
     for (q = 1; q < nth; q++)
-      { started[q] = pthread_create(th+q,NULL,bin_thread,job+q) == 0;
-        if (!started[q]) bin_thread(job+q);
+      { started[q] = pthread_create(th+q,NULL,bin_thread,K->job+q) == 0;
+        if (!started[q]) bin_thread(K->job+q);
       }
-    bin_thread(job);
+    bin_thread(K->job);
     for (q = 1; q < nth; q++)
       if (started[q])
         pthread_join(th[q],NULL);
   }
   for (q = 0; q < nth; q++)
-    { if (job[q].B.fail) goto oom;
-      for (i = job[q].i0; i < job[q].i1; i++)
-        S->aoff[S->na + i + 1] = S->pos + job[q].rel[i-job[q].i0];
-      S->pos += (int64_t) job[q].B.len;
+    { if (K->job[q].B.fail) goto oom;
+      K->job[q].A = NULL;                       /* (the set may go once its records are formatted) */
+      free(K->job[q].tmp); K->job[q].tmp = NULL;
     }
-  S->na += A->naln;
+  *out = K;
+  return 0;
+oom:
+  fga_set_error("out of memory");
+  fga_aln_block_free(K);
+  return 1;
+}
+
+/* the block's records behind those already in the stream; the block is consumed */
+int fga_aln_stream_commit(fga_aln_stream *S, fga_aln_block *K)
+{ int q, rc = 1;
+  int64_t i;
+  if (S == NULL || K == NULL || S->fail)
+    { fga_set_error("fga_aln_stream_commit: no open stream");
+      fga_aln_block_free(K);
+      return 1;
+    }
+  if (S->na + K->naln + 2 > S->acap)
+    { const int64_t nc = 2*(S->na + K->naln) + 1024;
+      int64_t *x = realloc(S->aoff,sizeof(int64_t)*nc);
+      if (x == NULL)
+        { fga_set_error("out of memory");
+          goto done;
+        }
+      S->aoff = x; S->acap = nc;
+    }
+  S->nR += K->nR; S->totT += K->totT;
+  if (K->maxT > S->maxT) S->maxT = K->maxT;
+  for (q = 0; q < K->nth; q++)
+    { const bin_job *J = K->job + q;
+      for (i = J->i0; i < J->i1; i++)
+        S->aoff[S->na + i + 1] = S->pos + J->rel[i-J->i0];
+      S->pos += (int64_t) J->B.len;
+    }
+  S->na += K->naln;
   /* One stream writes the file.  Measured in round 5 on the 289 MB of a 3 Gbp comparison's 4.2 M records (32 formatter
      threads): this 108-166 ms; every job writing its own stretch with pwrite 137-211 ms (buffered writes to one file take
      turns on the inode's lock); the jobs copying into a shared mapping of the file 420-530 ms (a page fault per 4 KB). */
   { int ok = 1;
-    for (q = 0; q < nth; q++)
-      if (job[q].B.len > 0)
-        { ok &= fwrite(job[q].B.p,1,job[q].B.len,S->f) == job[q].B.len;
-          S->datalen += (int64_t) job[q].B.len;
+    for (q = 0; q < K->nth; q++)
+      if (K->job[q].B.len > 0)
+        { ok &= fwrite(K->job[q].B.p,1,K->job[q].B.len,S->f) == K->job[q].B.len;
+          S->datalen += (int64_t) K->job[q].B.len;
         }
     if (!ok)
       { fga_set_error("IO error writing %s",S->path);
@@ -709,11 +771,8 @@ static int stream_format_and_write(fga_aln_stream *S, const fga_alns *A)
       }
   }
   rc = 0;
-  goto done;
-oom:
-  fga_set_error("out of memory");
 done:
-  for (q = 0; q < WRITER_MAXT; q++) { free(job[q].B.p); free(job[q].rel); free(job[q].tmp); }
+  fga_aln_block_free(K);
   if (rc) S->fail = 1;
   return rc;
 }
@@ -807,7 +866,14 @@ int fga_aln_stream_append(fga_aln_stream *S, const fga_alns *A)
     }
   if (A->naln == 0)
     return 0;
-  return stream_format_and_write(S,A);
+  { fga_aln_block *K;
+    stream_train(S,A);
+    if (fga_aln_stream_format(S,A,&K))
+      { S->fail = 1;
+        return 1;
+      }
+    return fga_aln_stream_commit(S,K);
+  }
 }
 
 int64_t fga_aln_stream_records(const fga_aln_stream *S) { return S == NULL ? 0 : S->na; }

@@ -274,21 +274,31 @@ static void rank_run(multi_rank *me)
      its turn, whatever happened to it) */
   me->nlive = me->cover = 0; me->write_s = 0.;
   if (M->want_stream)
-    { pthread_mutex_lock(&M->mu);
-      while (M->turn != r)
-        pthread_cond_wait(&M->cv_turn,&M->mu);
-      pthread_mutex_unlock(&M->mu);
-      if (me->streams && M->stream != NULL && me->fil != NULL && !multi_failed(M))
-        { const double tw = fga_wall();
-          int64_t i;
+    { fga_aln_block *blk = NULL;
+      const int mine = me->streams && M->stream != NULL && me->fil != NULL && !multi_failed(M);
+      double tw = fga_wall();
+      if (mine)                             /* formatted now, on this rank's threads; written when its turn has come */
+        { int64_t i;
           me->nlive = me->fil->naln;
           for (i = 0; i < me->fil->naln; i++)
             me->cover += me->fil->alns[i].aepos - me->fil->alns[i].abpos;
           fga_aln_writer_threads(P->nthreads > 8 ? P->nthreads : 8);
-          if (fga_aln_stream_append(M->stream,me->fil))
+          if (me->fil->naln > 0 && fga_aln_stream_preformats(M->stream) && fga_aln_stream_format(M->stream,me->fil,&blk))
             multi_fail(M,"output");
           me->write_s = fga_wall() - tw;
         }
+      pthread_mutex_lock(&M->mu);
+      while (M->turn != r)
+        pthread_cond_wait(&M->cv_turn,&M->mu);
+      pthread_mutex_unlock(&M->mu);
+      tw = fga_wall();
+      if (mine && !multi_failed(M))
+        { if (blk != NULL ? fga_aln_stream_commit(M->stream,blk) : fga_aln_stream_append(M->stream,me->fil))
+            multi_fail(M,"output");
+          blk = NULL;
+          me->write_s += fga_wall() - tw;
+        }
+      fga_aln_block_free(blk);
       pthread_mutex_lock(&M->mu);
       M->turn = r + 1;
       pthread_cond_broadcast(&M->cv_turn);

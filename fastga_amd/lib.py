@@ -187,6 +187,10 @@ def _declare(L):
         "fga_write_1aln_binary": (i32, [cp, vp, vp, P(Alns), i32, cp, cp, cp]),
         "fga_aln_stream_open": (i32, [cp, vp, vp, i32, cp, cp, cp, P(vp)]),
         "fga_aln_stream_append": (i32, [vp, P(Alns)]),
+        "fga_aln_stream_preformats": (i32, [vp]),
+        "fga_aln_stream_format": (i32, [vp, P(Alns), P(vp)]),
+        "fga_aln_stream_commit": (i32, [vp, vp]),
+        "fga_aln_block_free": (None, [vp]),
         "fga_aln_stream_records": (i64, [vp]),
         "fga_aln_stream_close": (i32, [vp, i32]),
         "fga_trace_pts": (i32, [vp, vp, vp, P(Alns), i32, i32, P(P(Traces))]),

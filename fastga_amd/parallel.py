@@ -267,7 +267,7 @@ def run_parts_on_one_gpu(ses, nparts, weights=None, stream=True, **prm_kwargs):
         omax = np.bincount(inord, weights=wts, minlength=nparts).max()
         if omax <= lmax + lmax // 4 + 1:
             select, streamed = inord, True
-    per_rank["order_s"], per_rank["append_s"] = [], []
+    per_rank["order_s"], per_rank["format_s"], per_rank["append_s"] = [], [], []
     out_stream = ses.stream_open(prm) if streamed else None
     contig_waves = np.zeros(ses.nctg, dtype=np.int64)
     for seeds, buf in merged:
@@ -299,8 +299,17 @@ def run_parts_on_one_gpu(ses, nparts, weights=None, stream=True, **prm_kwargs):
             t = time.time()
             ses.reference_order(prm, raws[-1])
             per_rank["order_s"].append(time.time() - t)
-            t = time.time()
-            check(ses.L.fga_aln_stream_append(out_stream, raws[-1]), "stream append")
+            t = time.time()                                   # formatted on the rank's own threads before its turn ..
+            blk = C.c_void_p()
+            pre = bool(ses.L.fga_aln_stream_preformats(out_stream)) and raws[-1].contents.naln > 0
+            if pre:
+                check(ses.L.fga_aln_stream_format(out_stream, raws[-1], C.byref(blk)), "stream format")
+            per_rank["format_s"].append(time.time() - t)
+            t = time.time()                                   # .. written when the ranks before it have
+            if pre:
+                check(ses.L.fga_aln_stream_commit(out_stream, blk), "stream commit")
+            else:
+                check(ses.L.fga_aln_stream_append(out_stream, raws[-1]), "stream append")
             per_rank["append_s"].append(time.time() - t)
     for buf in sends:
         ses.dev_free(buf)

@@ -276,6 +276,14 @@ typedef struct fga_aln_stream fga_aln_stream;
 int  fga_aln_stream_open(const char *path, const fga_gdb *g1, const fga_gdb *g2 /* NULL: self */, int tspace,
                          const char *db1_name, const char *db2_name, const char *command_line, fga_aln_stream **out);
 int  fga_aln_stream_append(fga_aln_stream *s, const fga_alns *alns);
+/* append in two steps, for writers that hold their set before its turn in the file has come: the records formatted by any
+   thread (the stream is read, not changed; fga_aln_stream_preformats: not when list codes are wanted, FGA_ALN_CODEC=1 -- those
+   are trained on the file's first set), the block committed in the file's order (consumed, also on failure) */
+typedef struct fga_aln_block fga_aln_block;
+int  fga_aln_stream_preformats(const fga_aln_stream *s);
+int  fga_aln_stream_format(const fga_aln_stream *s, const fga_alns *alns, fga_aln_block **out);
+int  fga_aln_stream_commit(fga_aln_stream *s, fga_aln_block *block);
+void fga_aln_block_free(fga_aln_block *block);
 int64_t fga_aln_stream_records(const fga_aln_stream *s);
 int  fga_aln_stream_close(fga_aln_stream *s, int keep);
 
