@@ -743,8 +743,8 @@ def human_scale_run(D, workload, workdir, threads, div=0.01, project=False):
                                                 reference_threads=32)
             res["projected_8gpu"] = project_8gpu(st8, 8)
             res["projected_8gpu"]["records_equal_one_gpu_run"] = bool(st8["nlive"] == st["nlive"] and st8a["nlive"] == st["nlive"])
-            first = project_8gpu(st8a, 8)
-            res["projected_8gpu"]["first_run_of_a_session"] = {k: first[k] for k in ("seconds", "phase2_s_max", "part_imbalance_extend",
+            proj1 = project_8gpu(st8a, 8)
+            res["projected_8gpu"]["first_run_of_a_session"] = {k: proj1[k] for k in ("seconds", "phase2_s_max", "part_imbalance_extend",
                                                                                       "part_imbalance_seeds")}
         ses.close()
         # The denominator of the 3 Gbp ratios measured in THIS run, on this box's host cores: the real reference's GIXmake -T32 on
@@ -755,26 +755,44 @@ def human_scale_run(D, workload, workdir, threads, div=0.01, project=False):
         if want != "0" and (want == "1" or (div < 0.05 and (os.cpu_count() or 1) >= 64)):
             from oracle import harness as H
             if H.have_reference():
+                rd = None
                 try:
+                    # the reference's index files (2 x 34 GB) and seed files (15 GB) want ~100 GB of scratch: /dev/shm where it has
+                    # the room (the GPU boxes: 1.5 TB of it, 74 GB of /tmp), else beside the genomes
+                    import tempfile
+                    rd = d
+                    if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) and shutil.disk_usage("/dev/shm").free > 200e9:
+                        rd = tempfile.mkdtemp(prefix="fga_ref3g_", dir="/dev/shm")
+                        for r in (ra, rb):
+                            b = os.path.basename(r)
+                            for f in os.listdir(d):
+                                if f in (b + ".gdb", b + ".1gdb", "." + b + ".bps"):
+                                    shutil.copy(os.path.join(d, f), os.path.join(rd, f))
+                    elif shutil.disk_usage(d).free < 130e9:
+                        raise RuntimeError(f"skipped: {shutil.disk_usage(d).free/1e9:.0f} GB of scratch, the reference needs ~130")
+                    rra, rrb = os.path.join(rd, os.path.basename(ra)), os.path.join(rd, os.path.basename(rb))
                     t = time.time()
-                    for r in (ra, rb):
-                        H.run([H.ref_bin("GIXmake"), "-T32", f"-P{d}", r], cwd=d)
+                    for r in (rra, rrb):
+                        H.run([H.ref_bin("GIXmake"), "-T32", f"-P{rd}", r], cwd=rd)
                     gt = time.time() - t
                     t = time.time()
-                    H.ref_fastga(ra, rb, d, os.path.join(d, "ref"), threads=32)
+                    H.ref_fastga(rra, rrb, rd, os.path.join(rd, "ref"), threads=32)
                     ft = time.time() - t
                     res["reference"] = {"seconds": round(ft, 1), "threads": 32, "measured_in_this_run": True, "gixmake_s": round(gt, 1),
                                         "where": f"oracle/_ref/FastGA -T32 on this box ({os.cpu_count()} host cores), index files by "
                                                  f"oracle/_ref/GIXmake -T32 (not in the span)"}
                     res["vs_reference_warm"] = ft / dt
                     res["cold"]["vs_reference"] = ft / (opened + first)
-                    refd = os.path.join(d, "ref.1aln")
+                    refd = os.path.join(rd, "ref.1aln")
                     if os.path.exists(refd) and os.path.exists(H.ref_bin("ONEview")):
                         a = workload.digest_1aln_stream(out, H.ref_bin("ONEview"))
                         b = workload.digest_1aln_stream(refd, H.ref_bin("ONEview"))
                         res["identical_to_reference_here"] = bool(a["lines_md5"] == b["lines_md5"] and a["records"] == b["records"])
                 except Exception as e:
-                    res["reference_error"] = str(e)
+                    res["reference_error"] = str(e)[-400:]
+                finally:
+                    if rd is not None and rd != d:
+                        shutil.rmtree(rd, ignore_errors=True)
         if "reference" in res and not res["reference"].get("measured_in_this_run"):
             res["reference"]["measured_in_this_run"] = False
         return res
