@@ -371,7 +371,7 @@ static void sum_stats(fga_run_stats *S, const multi_rank *R, int n)
       /* the ranks run side by side: a stage takes as long as its slowest rank */
 #define MAXOF(f) if (s->f > S->f) S->f = s->f
       MAXOF(merge_s); MAXOF(sort_s); MAXOF(chain_s); MAXOF(extend_s); MAXOF(filter_s);
-      MAXOF(merge_kernel_ms); MAXOF(sort_kernel_ms); MAXOF(extend_kernel_ms);
+      MAXOF(merge_kernel_ms); MAXOF(sort_kernel_ms); MAXOF(extend_kernel_ms); MAXOF(chain_kernel_ms);
       MAXOF(sort_passes); MAXOF(ext_busy_waves); MAXOF(hbm_peak_bytes);
 #undef MAXOF
       if (R[r].Z != NULL)

@@ -474,6 +474,7 @@ int fga_session_align(fga_session *Z, const fga_run_params *P, fga_dseeds *seeds
     fga_keys_free(keys); keys = NULL;
     st.nhits = hits->nhits;
     st.nunits = hits->nunits;
+    st.chain_kernel_ms = fga_dev_stage_ms(dev,FGA_STAGE_CHAIN);
     st.chain_s = fga_wall() - t1;
   }
 
@@ -501,7 +502,7 @@ int fga_session_align(fga_session *Z, const fga_run_params *P, fga_dseeds *seeds
 done:
   if (S != NULL)
     { S->sort_s += st.sort_s; S->chain_s += st.chain_s; S->extend_s += st.extend_s;
-      S->sort_kernel_ms += st.sort_kernel_ms; S->extend_kernel_ms += st.extend_kernel_ms;
+      S->sort_kernel_ms += st.sort_kernel_ms; S->extend_kernel_ms += st.extend_kernel_ms; S->chain_kernel_ms += st.chain_kernel_ms;
       S->nhits += st.nhits; S->nunits += st.nunits; S->nalns += st.nalns; S->ncalls += st.ncalls; S->nwaves += st.nwaves;
       S->ext_cells += st.ext_cells; S->ext_bases += st.ext_bases; S->ext_trace += st.ext_trace;
       S->sort_keys += st.sort_keys;

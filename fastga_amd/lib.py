@@ -98,7 +98,8 @@ class RunStats(C.Structure):
                                          "trace_kernel_ms")] + [("nparts", C.c_int), ("bases1", C.c_int64), ("bases2", C.c_int64), ("ext_cells", C.c_int64),
                                                      ("ext_bases", C.c_int64), ("ext_trace", C.c_int64),
                                                      ("ext_busy_waves", C.c_double), ("hbm_peak_bytes", C.c_int64),
-                                                     ("sort_keys", C.c_int64), ("sort_passes", C.c_int), ("streamed_parts", C.c_int)]
+                                                     ("sort_keys", C.c_int64), ("sort_passes", C.c_int), ("streamed_parts", C.c_int),
+                                                     ("chain_kernel_ms", C.c_float)]
 
 
 class SortParams(C.Structure):

@@ -414,7 +414,9 @@ typedef struct
     int64_t sort_keys;                         /* records sorted, summed over the parts; sort_passes radix passes each:      */
     int     sort_passes;                       /*   algorithmic traffic of the sort = 2 x 16 B x sort_keys x sort_passes     */
     int     streamed_parts;                    /* parts whose records went to the .1aln while later parts' kernels ran (0:   */
-  } fga_run_stats;                             /*   the file was written after the last part)                                */
+                                               /*   the file was written after the last part)                                */
+    float   chain_kernel_ms;                   /* the chain scan's kernels (HIP events), summed over the parts               */
+  } fga_run_stats;
 
 int  fga_run(const char *root1, const char *root2 /* NULL: self */, const fga_run_params *prm, fga_run_stats *stats);
 
