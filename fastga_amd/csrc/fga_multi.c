@@ -161,9 +161,17 @@ static void rank_run(multi_rank *me)
   /* phase 1 on the rank's prefix range; its seeds counted per A contig */
   t0 = fga_wall();
   fga_session_clear_strand_counts(me->Z);
-  if (fga_session_merge(me->Z,P,0,0,&seeds,&me->st) ||
-      fga_seeds_contig_histogram(fga_session_device(me->Z),seeds,nctg,me->hist) ||
-      (P->reference_threads > 0 && fga_session_strand_counts(me->Z,me->scount)))
+  if (fga_session_merge(me->Z,P,0,0,&seeds,&me->st))
+    multi_fail(M,"phase 1");
+  else if (P->reference_threads > 0)        /* (the merge has counted them per strand for the tie order: their sums) */
+    { int c;
+      if (fga_session_strand_counts(me->Z,me->scount))
+        multi_fail(M,"phase 1");
+      else
+        for (c = 0; c < nctg; c++)
+          me->hist[c] = me->scount[c] + me->scount[nctg + c];
+    }
+  else if (fga_seeds_contig_histogram(fga_session_device(me->Z),seeds,nctg,me->hist))
     multi_fail(M,"phase 1");
   me->phase1_s = fga_wall() - t0;
   STEP_BARRIER(M);

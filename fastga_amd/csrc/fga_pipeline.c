@@ -812,7 +812,13 @@ int fga_session_run(fga_session *Z, const fga_run_params *P, fga_run_stats *S)
          records all come before part p+1's, so they are filtered, ordered, formatted and written while the next part's
          kernels run; the finish is the footer.  Not with PAF / PSL output (which wants the whole set) or the text form */
       streaming = fga_run_can_stream(P);
-      if (fga_seeds_contig_histogram(dev,seeds,nctg,cnt))
+      /* seeds per A contig: the two strands' counts the merge has just taken for the reference's tie order, or a pass of its own */
+      if (P->reference_threads > 0 && Z->scount != NULL)
+        { int j;
+          for (j = 0; j < nctg; j++)
+            cnt[j] = Z->scount[j] + Z->scount[nctg + j];
+        }
+      else if (fga_seeds_contig_histogram(dev,seeds,nctg,cnt))
         goto done;
       if (streaming)
         { int64_t big = 0, *sum = calloc(nparts,sizeof(int64_t));
