@@ -186,7 +186,9 @@ __device__ __forceinline__ int64_t wave_lower_bound(const uint64_t *K, int64_t l
 }
 
 #ifdef MERGE_PROF      // per-phase cycle accounting of every wavefront (tools/merge_bench.py prints it): timing builds only
-__device__ unsigned long long merge_prof[16];
+__device__ unsigned long long merge_prof[16*32];    // counter k at [32 k]: a cache line each -- 3,072 wavefronts flushing 16 counters of ONE line
+                                                     // at their ends (~88 atomics per microsecond and line) stalled that memory channel
+                                                     // for everybody and made the launch's last ranges take five times as long
 __device__ unsigned long long merge_tl[8192*4];     // per workgroup: start, end (100 MHz clock), tiles, ranges
 static int merge_prof_grid = 0;
 #define XPROF(k)   { unsigned long long _n = clock64(); O.pa[k] += _n - O.pt; O.pt = _n; }
@@ -899,7 +901,7 @@ void seed_merge_walk_kernel(merge_args A)
 #ifdef MERGE_PROF
   XPROF(6)
   if (lane == 0)
-    { for (int k = 0; k < 16; k++) atomicAdd(merge_prof+k,O.pa[k]);
+    { for (int k = 0; k < 16; k++) atomicAdd(merge_prof+32*k,O.pa[k]);
       if (blockIdx.x < 8192)
         { merge_tl[4*blockIdx.x] = O.t0; merge_tl[4*blockIdx.x+1] = wall_clock64();
           merge_tl[4*blockIdx.x+2] = O.ntile; merge_tl[4*blockIdx.x+3] = O.nrange;
@@ -1290,9 +1292,11 @@ static int merge_impl(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
       hipEventElapsedTime(&dev->last_ms[FGA_STAGE_MERGE],dev->ev0,ev2);
     }
 #ifdef MERGE_PROF
-  { unsigned long long hp[16], z[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};
-    hipMemcpyFromSymbol(hp,HIP_SYMBOL(merge_prof),sizeof(hp));
+  { unsigned long long hp[16];
+    static unsigned long long hpw[16*32], z[16*32];
+    hipMemcpyFromSymbol(hpw,HIP_SYMBOL(merge_prof),sizeof(hpw));
     hipMemcpyToSymbol(HIP_SYMBOL(merge_prof),z,sizeof(z));
+    for (int k = 0; k < 16; k++) hp[k] = hpw[32*k];
     double tot = 0; for (int k = 0; k < 16; k++) tot += (double) hp[k];
     if (tot > 0)
       fprintf(stderr,"merge phases (%% of wave cycles): tile select %.1f  load issue %.1f  load wait %.1f  window %.1f  match %.1f  emit %.1f  rest %.1f   (%.0f Mcycles)\n",
