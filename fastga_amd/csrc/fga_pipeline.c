@@ -77,8 +77,12 @@ static void *part_filter_main(void *arg)
 { part_filter *F = arg;
   const double t0 = fga_wall();
   F->rc = fga_filter_alignments_mt(F->in,F->nthreads,&F->out);
+  fga_note("part: redundancy filter",t0);
   if (F->rc == 0 && F->stream != NULL && F->P->reference_threads > 0)
-    F->rc = reference_order(F->Z,F->P,F->out);
+    { const double t1 = fga_wall();
+      F->rc = reference_order(F->Z,F->P,F->out);
+      fga_note("part: the reference's tie order",t1);
+    }
   if (F->rc != 0)
     F->err = strdup(fga_last_error());
   F->seconds = fga_wall() - t0;
@@ -103,6 +107,7 @@ static void *part_filter_main(void *arg)
               F->err = strdup(fga_last_error());
             }
           F->write_s = fga_wall() - t1;
+          fga_note("part: records formatted and written",t1);
         }
       pthread_mutex_lock(&C->mu);
       if (F->rc != 0) C->failed = 1;
