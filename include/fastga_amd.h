@@ -135,7 +135,10 @@ int   fga_dgix_prefix_counts(fga_dev *dev, const fga_gdb *gdb, int nthreads, uin
 /* Adaptive seed merge: replaces adaptamer_merge -> new_merge_thread (FastGA.c:2281, 610) and, with
  * t2 == NULL, self_adaptamer_merge -> new_self_merge_thread (FastGA.c:2496, 1616).  Returns 0, or 2 when
  * more than `capacity` seeds were found (count is still exact; re-run with a larger buffer).
- * capacity <= 0 picks 2 x (entries of t1 in range) + 1M.                                              */
+ * capacity <= 0 picks 2 x (entries of t1 in range) + 1M.
+ * t1 keeps the range cuts of its last launch (reused when the next one names the same tables -- by their view generations --,
+ * prefix range and geometry): a table must not be table 1 of two merges running at the same time (two sessions never share
+ * one; a caller of the stage API that does serialises those launches)                                 */
 int     fga_seed_merge(fga_dev *dev, const fga_dgix *t1, const fga_dgix *t2,
                        const fga_merge_params *prm, int64_t capacity, fga_dseeds **out);
 int64_t fga_seeds_count(const fga_dseeds *seeds);
