@@ -2,7 +2,7 @@
 """tools/multi_stress.py [iterations] -- fga_run_multi with virtual ranks on the toy pair, again and again: every run must give
 the single-session run's records.  Prints the runs that do not and what they lack."""
 import os, sys, tempfile
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from fastga_amd import workload, device as D
 from oracle import harness as H
 it = int(sys.argv[1]) if len(sys.argv) > 1 else 30
