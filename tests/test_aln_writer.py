@@ -143,3 +143,96 @@ def test_binary_writer_on_many_threads_writes_the_same_file(toy_pair, tmp_path, 
     txt = H.oneview(str(tmp_path / "w64.1aln"))
     assert sum(1 for ln in txt if ln[0] == "A") == n
     g1.close(); g2.close()
+
+
+def _synthetic_set(g1, g2, n, seed):
+    """n records with traces of 1-20 panels inside the two genomes' contigs, in final order (aread ascending)"""
+    from fastga_amd.device import ALN_DTYPE
+    rng = np.random.default_rng(seed)
+    recs = np.zeros(n, dtype=ALN_DTYPE)
+    recs["aread"] = np.sort(rng.integers(0, g1.ncontig, n))
+    recs["bread"] = rng.integers(0, g2.ncontig, n)
+    recs["flags"] = rng.integers(0, 2, n)
+    pieces, off = [], 0
+    for i in range(n):
+        la, lb = int(g1.clen[recs["aread"][i]]), int(g2.clen[recs["bread"][i]])
+        k = max(1, int(min(rng.integers(1, 21), la // 100 - 2, lb // 110 - 2)))
+        ab = 100 * int(rng.integers(0, la // 100 - k))
+        bb = int(rng.integers(0, lb - 110 * k))
+        t = np.empty(2 * k, dtype=np.uint8)
+        t[0::2] = rng.integers(0, 12, k)
+        t[1::2] = rng.integers(95, 106, k)
+        recs["tlen"][i] = 2 * k
+        recs["abpos"][i], recs["aepos"][i] = ab, ab + 100 * k
+        recs["bbpos"][i], recs["bepos"][i] = bb, bb + int(t[1::2].sum())
+        recs["diffs"][i] = int(t[0::2].sum())
+        recs["toff"][i] = off
+        pieces.append(t)
+        off += 2 * k
+    recs["unit"], recs["seq"] = -1, np.arange(n)
+    return recs, np.concatenate(pieces)
+
+
+def test_stream_appended_in_stretches_is_the_file_written_at_once(toy_pair, tmp_path, built_library):
+    """fga_aln_stream_*: the records of a file appended in stretches of A contigs (what fga_session_run does with its passes
+    and fga_multi_run with its ranks), each stretch either appended in one call or formatted first -- by a thread that does
+    not hold the stream's turn -- and committed later, give the bytes of fga_write_1aln_binary on the whole set; a stream
+    closed without `keep` leaves no file"""
+    import re
+    from fastga_amd.lib import Alns
+    from fastga_amd.gixio import Gdb
+    L = built_library
+    d, ra, rb = toy_pair
+    g1, g2 = Gdb(ra + ".gdb"), Gdb(rb + ".gdb")
+    recs, tb = _synthetic_set(g1, g2, 30_000, 21)
+    whole = Alns(len(recs), len(tb), 0, 0, recs.ctypes.data, tb.ctypes.data)
+    p0 = str(tmp_path / "whole.1aln")
+    assert L.fga_write_1aln_binary(p0.encode(), g1.h, g2.h, C.byref(whole), 100, ra.encode(), rb.encode(), b"test") == 0
+    strip = lambda b: re.sub(rb"\n! [^\n]*\n", b"\n!\n", b, count=1)        # noqa: E731  (the time stamp)
+    ref = strip(open(p0, "rb").read())
+    # stretches: cut where the A contig changes, near 1/4, 1/2, 3/4 (and an empty one)
+    cuts = [0]
+    for f in (0.25, 0.5, 0.5, 0.75):
+        i = int(f * len(recs))
+        while 0 < i < len(recs) and recs["aread"][i] == recs["aread"][i - 1]:
+            i += 1
+        cuts.append(max(i, cuts[-1]))
+    cuts.append(len(recs))
+    sets = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        r = recs[a:b].copy()
+        t0 = int(recs["toff"][a]) if b > a else 0
+        t1 = int(recs["toff"][b - 1] + recs["tlen"][b - 1]) if b > a else 0
+        r["toff"] -= t0
+        tt = np.ascontiguousarray(tb[t0:t1]) if t1 > t0 else np.zeros(1, np.uint8)
+        sets.append((r, tt, Alns(len(r), t1 - t0, 0, 0, r.ctypes.data, tt.ctypes.data)))
+    for how in ("append", "format-then-commit"):
+        p = str(tmp_path / (how + ".1aln"))
+        h = C.c_void_p()
+        assert L.fga_aln_stream_open(p.encode(), g1.h, g2.h, 100, ra.encode(), rb.encode(), b"test", C.byref(h)) == 0
+        if how == "append":
+            for _, _, A in sets:
+                assert L.fga_aln_stream_append(h, C.byref(A)) == 0
+        else:
+            assert L.fga_aln_stream_preformats(h) == 1
+            blocks = []
+            for _, _, A in reversed(sets):                      # formatted in any order ..
+                b = C.c_void_p()
+                if A.naln > 0:
+                    assert L.fga_aln_stream_format(h, C.byref(A), C.byref(b)) == 0 and b.value
+                blocks.append(b)
+            for b in reversed(blocks):                          # .. committed in the file's
+                if b.value:
+                    assert L.fga_aln_stream_commit(h, b) == 0
+        assert L.fga_aln_stream_records(h) == len(recs)
+        assert L.fga_aln_stream_close(h, 1) == 0
+        assert strip(open(p, "rb").read()) == ref, how
+    p = str(tmp_path / "dropped.1aln")
+    h = C.c_void_p()
+    assert L.fga_aln_stream_open(p.encode(), g1.h, g2.h, 100, ra.encode(), rb.encode(), b"test", C.byref(h)) == 0
+    assert L.fga_aln_stream_append(h, C.byref(sets[0][2])) == 0
+    b = C.c_void_p()
+    assert L.fga_aln_stream_format(h, C.byref(sets[-1][2]), C.byref(b)) == 0
+    L.fga_aln_block_free(b)                                     # a block that is never committed
+    assert L.fga_aln_stream_close(h, 0) == 0 and not os.path.exists(p)
+    g1.close(); g2.close()
